@@ -1,0 +1,245 @@
+"""Generate tests/golden/*.npz by running the REFERENCE on CPU (build container only).
+
+TEST INFRASTRUCTURE.  Usage:  python oracle/make_golden.py [--out tests/golden]
+
+Each fixture holds only data: the seeds/shapes needed to re-synthesise inputs and parameters
+(``oracle.xmc_ref.synth_params`` / ``synth_batch`` are deterministic and order-independent) plus
+the reference's outputs.  No reference source text is stored.
+
+Fixtures
+  fwd_<name>.npz     reference NetG / NetD / COND_DNET forward outputs + state_dict key/shape table
+  labels.npz         reference make_labels / sent_loss / img_loss on fixed embeddings (all b_global modes)
+  step_<name>.npz    the reference's real train() loop for a few iterations: every loss scalar,
+                     per-parameter gradient statistics at each optimizer step (incl. which grads are
+                     None), per-parameter statistics after the last step, first fake image.
+"""
+import argparse
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_harness as RH  # noqa: E402
+import xmc_ref as X      # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def stats(t):
+    """(sum, abs-sum, first, middle, last) of a tensor as float64."""
+    f = t.detach().double().flatten()
+    n = f.numel()
+    return np.array([f.sum().item(), f.abs().sum().item(), f[0].item(), f[n // 2].item(), f[-1].item()])
+
+
+def build_ref(cfg, M, seed):
+    """Reference models with deterministic synthetic parameters (strict load pins keys+shapes)."""
+    h = X.Hyper.from_cfg(cfg)
+    gen_cls = {"DF_GEN": M.df_gan.NetG, "CONCEPT_IN_DF_GEN": M.df_concept_gan.InNetG,
+               "CONCEPT_OUT_DF_GEN": M.df_concept_gan.OutNetG}[cfg.GEN.ENCODER_NAME]
+    netG = gen_cls(cfg)
+    netD = M.df_gan.NetD(cfg, is_disc=True)
+    PG = X.synth_params(X.gen_shapes(h), seed)
+    PD = X.synth_params(X.netd_shapes(h), seed + 1)
+    netG.load_state_dict(PG, strict=True)
+    netD.load_state_dict(PD, strict=True)
+    return h, netG, netD
+
+
+def shape_table(sd):
+    return np.array([f"{k}:{','.join(map(str, v.shape))}" for k, v in sd.items()])
+
+
+def golden_forward(name, yml, batch, seed, out_dir, **over):
+    cfg = RH.load_cfg(yml, **over)
+    M = RH.modules()
+    h, netG, netD = build_ref(cfg, M, seed)
+    b = X.synth_batch(h, batch, seed=seed + 50, words_len=cfg.TEXT.MAX_LENGTH)
+    with torch.no_grad():
+        fake = netG(noise=b["noise"], sent_embs=b["sent_embs"], words_embs=b["words_embs"], mask=b["mask"])
+        psent = b["sent_embs"] if cfg.DISC.SEPERATE else netG.proj_sent(b["sent_embs"])
+        feat = netD(b["imgs"])
+        logit, img_emb, txt_emb = netD.COND_DNET(feat, sent_embs=psent)
+        feat_f = netD(fake)
+    np.savez_compressed(
+        os.path.join(out_dir, f"fwd_{name}.npz"),
+        yml=yml, over=np.array([f"{k}={v}" for k, v in over.items()]), batch=batch, seed=seed,
+        g_keys=shape_table(netG.state_dict()), d_keys=shape_table(netD.state_dict()),
+        fake=fake.numpy(), feat=feat.numpy(), feat_fake_stats=stats(feat_f), logit=logit.numpy(),
+        img_emb=img_emb.numpy(), txt_emb=txt_emb.numpy(), psent=psent.numpy())
+    print(f"fwd_{name}: fake {tuple(fake.shape)} feat {tuple(feat.shape)}")
+
+
+def golden_labels(out_dir):
+    cfg = RH.load_cfg("df_gan_damsm.yml")
+    tg = RH.modules().train_gan
+    g = torch.Generator().manual_seed(7)
+    B, Dm = 12, 48
+    base = torch.randn(4, Dm, generator=g)
+    sent = base.repeat(3, 1) + 0.35 * torch.randn(B, Dm, generator=g)   # clusters -> some global positives
+    a = torch.randn(B, Dm, generator=g)
+    b = a * 0.5 + torch.randn(B, Dm, generator=g)
+    rec = dict(sent=sent.numpy(), a=a.numpy(), b=b.numpy())
+    for tag, bg, sg in (("local", False, 0.0), ("adaptive", True, 0.0), ("smooth", True, 0.5)):
+        cfg.TRAIN.SMOOTH.GLOBAL = sg
+        labels = tg.make_labels(B, sent, bg)
+        rec[f"labels_{tag}"] = labels.numpy()
+        rec[f"sent_loss_{tag}"] = tg.sent_loss(a, b, labels, bg).item()
+        rec[f"img_loss_{tag}"] = tg.img_loss(a, b, labels, bg).item()
+    rec["scores"] = tg.cosine_scores(a, b).numpy()
+    np.savez_compressed(os.path.join(out_dir, "labels.npz"), **rec)
+    print("labels: ok", {k: v for k, v in rec.items() if "loss" in k})
+
+
+class _RecAdam(torch.optim.Adam):
+    """torch.optim.Adam that records gradient statistics just before each step."""
+
+    def __init__(self, named, log, tag, **kw):
+        self._names = [n for n, _ in named]
+        self._log, self._tag = log, tag
+        super().__init__([p for _, p in named], **kw)
+
+    def step(self, closure=None):
+        rec = {}
+        for n, p in zip(self._names, self.param_groups[0]["params"]):
+            rec[n] = None if p.grad is None else stats(p.grad)
+        self._log.append((self._tag, rec))
+        return super().step(closure)
+
+
+def golden_step(name, yml, batch, steps, seed, out_dir, **over):
+    cfg = RH.load_cfg(yml, **over)
+    cfg.TRAIN.MAX_EPOCH = 1
+    cfg.TRAIN.LOG_INTERVAL = 10 ** 9
+    cfg.TEXT.TYPE = "SENT"            # skips index_to_sent(train_set.i2w, ...) at train_gan.py:149
+    M = RH.modules()
+    tg = M.train_gan
+    h, netG, netD = build_ref(cfg, M, seed)
+    T = cfg.TEXT.MAX_LENGTH
+    batches = [X.synth_batch(h, batch, seed=seed + 100 + i, words_len=T) for i in range(steps)]
+
+    # loader yields (imgs, [(caps, cap_lens)], keys); first next(it) is consumed for the fixed batch
+    def loader_items():
+        return [(b["imgs"], [((i,), torch.full((batch,), T))], None) for i, b in enumerate(batches)]
+
+    class Loader:
+        def __iter__(self):
+            return iter(loader_items())
+
+        def __len__(self):
+            return steps
+
+    def text_encoder(caps, cap_lens):
+        b = batches[caps[0]]
+        return b["words_embs"], b["sent_embs"], b["mask"]
+
+    log = []
+    scal = []
+    optG = _RecAdam(list(netG.named_parameters()), log, "G", lr=cfg.TRAIN.OPT.G_LR,
+                    betas=(cfg.TRAIN.OPT.G_BETA1, cfg.TRAIN.OPT.G_BETA2))
+    optD = _RecAdam(list(netD.named_parameters()), log, "D", lr=cfg.TRAIN.OPT.D_LR,
+                    betas=(cfg.TRAIN.OPT.D_BETA1, cfg.TRAIN.OPT.D_BETA2))
+
+    # record every loss the loop computes: the contrastive helpers by wrapping, the scalars
+    # that get .backward() by hooking Tensor.backward, the hinge terms by wrapping F.relu
+    orig_sent, orig_img = tg.sent_loss, tg.img_loss
+    tg.sent_loss = lambda **k: (lambda v: (scal.append(("sent_loss", v.item())), v)[1])(orig_sent(**k))
+    tg.img_loss = lambda **k: (lambda v: (scal.append(("img_loss", v.item())), v)[1])(orig_img(**k))
+    orig_bwd = torch.Tensor.backward
+
+    def rec_bwd(self, *a, **k):
+        scal.append(("backward", self.item()))
+        return orig_bwd(self, *a, **k)
+
+    torch.Tensor.backward = rec_bwd
+    orig_relu = tg.F.relu
+    relu_ns = types.SimpleNamespace(**{k: getattr(tg.F, k) for k in dir(tg.F) if not k.startswith("__")})
+
+    def rec_relu(x, inplace=False):
+        y = orig_relu(x, inplace=inplace)
+        scal.append(("hinge", y.mean().item()))
+        return y
+
+    relu_ns.relu = rec_relu
+    tg.F = relu_ns
+    fakes = []
+    orig_G_fwd = netG.forward
+    netG.forward = lambda *a, **k: (lambda y: (fakes.append(y.detach().clone()), y)[1])(orig_G_fwd(*a, **k))
+
+    tmp = tempfile.mkdtemp()
+    tg.img_dir = tmp
+    tg.args = types.SimpleNamespace(log_type="tb")
+    tg.writer = types.SimpleNamespace(add_scalar=lambda *a, **k: None)
+    tg.netD = netD
+    logger = types.SimpleNamespace(info=lambda *a, **k: None)
+
+    torch.manual_seed(seed)
+    noise_rng_check = torch.get_rng_state()
+    try:
+        tg.train(train_loader=Loader(), test_loader=None, state_epoch=0, text_encoder=text_encoder,
+                 netG=netG, netD=netD, optimizerG=optG, optimizerD=optD, logger=logger, model_dir=tmp)
+    finally:
+        torch.Tensor.backward = orig_bwd
+        tg.sent_loss, tg.img_loss = orig_sent, orig_img
+        import torch.nn.functional as realF
+        tg.F = realF
+
+    # the noise sequence the loop drew from the global CPU generator (train_gan.py:156,197)
+    torch.set_rng_state(noise_rng_check)
+    fixed_noise = torch.randn(batch, cfg.TRAIN.NOISE_DIM)
+    noises = [torch.randn(batch, cfg.TRAIN.NOISE_DIM) for _ in range(steps)]
+
+    rec = dict(yml=yml, over=np.array([f"{k}={v}" for k, v in over.items()]), batch=batch, steps=steps,
+               seed=seed, noises=torch.stack(noises).numpy(), fake0=fakes[0].numpy(),
+               fake_last_stats=stats(fakes[steps - 1]),
+               scal_names=np.array([s[0] for s in scal]), scal_vals=np.array([s[1] for s in scal]))
+    for i, (tag, r) in enumerate(log):
+        names = list(r.keys())
+        rec[f"opt{i}_tag"] = tag
+        rec[f"opt{i}_none"] = np.array([r[n] is None for n in names])
+        rec[f"opt{i}_stats"] = np.stack([np.zeros(5) if r[n] is None else r[n] for n in names])
+    rec["n_opt"] = len(log)
+    rec["g_names"] = np.array([n for n, _ in netG.named_parameters()])
+    rec["d_names"] = np.array([n for n, _ in netD.named_parameters()])
+    rec["g_final"] = np.stack([stats(p) for _, p in netG.named_parameters()])
+    rec["d_final"] = np.stack([stats(p) for _, p in netD.named_parameters()])
+    np.savez_compressed(os.path.join(out_dir, f"step_{name}.npz"), **rec)
+    print(f"step_{name}: {len(log)} optimizer steps, scalars:",
+          [(n, round(v, 4)) for n, v in scal[: 12]])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(os.path.dirname(HERE), "tests", "golden"))
+    a = ap.parse_args()
+    os.makedirs(a.out, exist_ok=True)
+    N8 = {"TRAIN.NCH": 8}
+    golden_labels(a.out)
+    golden_forward("df64_nch32", "df_gan_damsm.yml", 2, 11, a.out)
+    golden_forward("df128_nch8", "df_gan_damsm.yml", 2, 12, a.out, **{"IMG.SIZE": 128, **N8})
+    golden_forward("df256_nch8", "df_gan_sbert_damsm_nomagp.yml", 2, 13, a.out, **{"IMG.SIZE": 256, **N8})
+    golden_forward("sep64_nch8", "df_gan_sbert_seperate.yml", 2, 14, a.out, **N8)
+    # df_gan_sbert.yml / concept_in_df_gan_sbert.yml cannot run in the reference itself: with E=768 != NEF and
+    # neither IMG_MATCH/SENT_MATCH/SEPERATE, D_GET_LOGITS sizes joint_conv for text_dim (df_gan.py:152-157)
+    # while train() feeds it netG.proj_sent(sent) of width NEF (train_gan.py:191) -> channel mismatch.
+    golden_forward("nomatch64_nch8", "concept_in_df_gan.yml", 2, 15, a.out, **N8)
+    golden_forward("cin64_nch8", "concept_in_df_gan_damsm_nomagp.yml", 2, 16, a.out, **N8)
+    golden_forward("cin128_nch8", "concept_in_df_gan_sbert_n2_damsm.yml", 1, 17, a.out, **{"IMG.SIZE": 128, **N8})
+    golden_forward("cout64_nch8", "concept_out_df_gan_sbert_damsm_nomagp.yml", 2, 18, a.out, **N8)
+    golden_forward("cout64_nonorm", "concept_out_df_gan_sbert_damsm_nomagp.yml", 2, 19, a.out,
+                   **{"GEN.NORMALIZE": False, **N8})
+    golden_step("df64_magp", "df_gan_damsm.yml", 4, 2, 21, a.out, **N8)
+    golden_step("df64_nomagp", "df_gan_damsm_nomagp.yml", 4, 2, 22, a.out, **N8)
+    golden_step("df64_sep", "df_gan_sbert_seperate.yml", 3, 2, 23, a.out, **N8)
+    golden_step("df64_ncrit2", "concept_in_df_gan_sbert_n2_damsm.yml", 3, 2, 24, a.out, **N8)
+    golden_step("cout64", "concept_out_df_gan_sbert_damsm_nomagp.yml", 3, 1, 25, a.out, **N8)
+    golden_step("df128_nomagp", "df_gan_damsm_nomagp.yml", 2, 1, 26, a.out, **{"IMG.SIZE": 128, **N8})
+
+
+if __name__ == "__main__":
+    main()

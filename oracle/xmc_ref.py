@@ -1,0 +1,612 @@
+"""CPU oracle for the XMC-GAN G+D training step  --  TEST INFRASTRUCTURE, NOT PRODUCT.
+
+A functional, single-file restatement (plain PyTorch, fp32, CPU) of the arithmetic the
+reference performs on its hot path.  Only ``tests/``, ``__graft_entry__.smoke()`` and
+``bench.py``'s ``cpu_baseline`` leg may import this file; the product (``xmc_gan/`` and
+``xmc-gan_amd/``) never does and fails loudly when the HIP library is missing.
+
+Parity status: PINNED.  ``oracle/make_golden.py`` runs the reference's own modules and its
+real ``train()`` loop in the build container (recipe: SURVEY.md section 8c) and writes
+``tests/golden/*.npz``; ``tests/test_oracle_golden.py`` checks every function here against
+those vectors.
+
+Parameters are passed as plain ``dict[str, Tensor]`` keyed exactly like the reference's
+``state_dict()``, so the same dict can be loaded into the reference, this
+oracle and the product.  Every function cites the reference lines it restates
+(paths relative to /root/reference/xmc_gan/).
+"""
+from __future__ import annotations
+
+import math
+import zlib
+from dataclasses import dataclass, field
+
+import torch
+import torch.nn.functional as F
+
+LRELU = 0.2
+CARD, PW, SD = 16, 8, 4  # cardinality, bottleneck width p, state dim p' (df_concept_gan.py:110,118)
+
+
+# ----------------------------------------------------------------------------------------
+# hyper-parameters
+# ----------------------------------------------------------------------------------------
+@dataclass
+class Hyper:
+    """The subset of the reference cfg (config/gan.py:7-90) the hot path reads."""
+    img_size: int = 64
+    nch: int = 32
+    nef: int = 256
+    noise_dim: int = 100
+    text_dim: int = 256
+    gen: str = "DF_GEN"           # cfg.GEN.ENCODER_NAME
+    normalize: bool = True        # cfg.GEN.NORMALIZE
+    img_match: bool = True        # cfg.DISC.IMG_MATCH
+    sent_match: bool = False      # cfg.DISC.SENT_MATCH
+    seperate: bool = False        # cfg.DISC.SEPERATE (sic)
+    rmis: bool = True             # cfg.TRAIN.RMIS_LOSS
+    magp: bool = False            # cfg.TRAIN.MAGP
+    enc_sent: bool = True         # cfg.TRAIN.ENCODER_LOSS.SENT
+    enc_disc: bool = True         # cfg.TRAIN.ENCODER_LOSS.DISC
+    b_global: bool = False        # cfg.TRAIN.ENCODER_LOSS.B_GLOBAL
+    smooth_mismatch: float = 1.0
+    smooth_global: float = 0.0
+    smooth_sent: float = 1.0
+    smooth_disc: float = 1.0
+    n_critic: int = 1
+    g_lr: float = 1e-4
+    g_betas: tuple = (0.0, 0.9)
+    d_lr: float = 4e-4
+    d_betas: tuple = (0.0, 0.9)
+
+    @staticmethod
+    def from_cfg(cfg) -> "Hyper":
+        """cfg: nested mapping with the reference schema (attribute or item access)."""
+        g = lambda node, k: node[k] if isinstance(node, dict) else getattr(node, k)
+        T, D, E = g(cfg, "TRAIN"), g(cfg, "DISC"), g(g(cfg, "TRAIN"), "ENCODER_LOSS")
+        S, O = g(T, "SMOOTH"), g(T, "OPT")
+        return Hyper(
+            img_size=g(g(cfg, "IMG"), "SIZE"), nch=g(T, "NCH"), nef=g(T, "NEF"),
+            noise_dim=g(T, "NOISE_DIM"), text_dim=g(g(cfg, "TEXT"), "EMBEDDING_DIM"),
+            gen=g(g(cfg, "GEN"), "ENCODER_NAME"), normalize=g(g(cfg, "GEN"), "NORMALIZE"),
+            img_match=g(D, "IMG_MATCH"), sent_match=g(D, "SENT_MATCH"), seperate=g(D, "SEPERATE"),
+            rmis=g(T, "RMIS_LOSS"), magp=g(T, "MAGP"), enc_sent=g(E, "SENT"), enc_disc=g(E, "DISC"),
+            b_global=g(E, "B_GLOBAL"), smooth_mismatch=g(S, "MISMATCH"), smooth_global=g(S, "GLOBAL"),
+            smooth_sent=g(S, "SENT"), smooth_disc=g(S, "DISC"), n_critic=g(T, "N_CRITIC"),
+            g_lr=g(O, "G_LR"), g_betas=(g(O, "G_BETA1"), g(O, "G_BETA2")),
+            d_lr=g(O, "D_LR"), d_betas=(g(O, "D_BETA1"), g(O, "D_BETA2")))
+
+
+# ----------------------------------------------------------------------------------------
+# architecture tables  (model/df_gan.py:9-61, duplicated at model/df_concept_gan.py:10-62)
+# ----------------------------------------------------------------------------------------
+def gen_arch(img_size: int, nch: int):
+    assert img_size in (64, 128, 256)
+    depth = {64: 5, 128: 6, 256: 7}[img_size]           # the last block keeps its resolution
+    mult_in = [8] * (depth - 2) + [4, 2]                # 64: [8,8,8,4,2] ... 256: [8,8,8,8,8,4,2]
+    mult_out = mult_in[1:] + [1]
+    return dict(cin=[m * nch for m in mult_in], cout=[m * nch for m in mult_out],
+                upsample=[True] * (depth - 1) + [False], depth=depth)
+
+
+def disc_arch(img_size: int, nch: int):
+    assert img_size in (64, 128, 256)
+    depth = {64: 5, 128: 6, 256: 7}[img_size]
+    mult_out = [1, 2, 4, 8, 16, 16, 16][:depth]
+    cout = [m * nch for m in mult_out]
+    cin = [3] + cout[:-1]
+    return dict(cin=cin, cout=cout, depth=depth)
+
+
+# ----------------------------------------------------------------------------------------
+# state_dict key/shape tables (pinned against the reference's state_dict() in the golden test)
+# ----------------------------------------------------------------------------------------
+def _affine_shapes(prefix, nfeat, cond):
+    s = {}
+    for br in ("fc_gamma", "fc_beta"):
+        s[f"{prefix}.{br}.linear1.weight"] = (256, cond)
+        s[f"{prefix}.{br}.linear1.bias"] = (256,)
+        s[f"{prefix}.{br}.linear2.weight"] = (nfeat, 256)
+        s[f"{prefix}.{br}.linear2.bias"] = (nfeat,)
+    return s
+
+
+def _stem_tail_shapes(h: Hyper, arch):
+    s = {"proj_noise.weight": (8 * h.nch * 16, h.noise_dim), "proj_noise.bias": (8 * h.nch * 16,)}
+    if h.text_dim != h.nef:
+        s["proj_sent.weight"] = (h.nef, h.text_dim)
+        s["proj_sent.bias"] = (h.nef,)
+    return s
+
+
+def netg_shapes(h: Hyper):
+    """DF_GEN state_dict (model/df_gan.py:64-103,179-263), in registration order."""
+    a = gen_arch(h.img_size, h.nch)
+    s = _stem_tail_shapes(h, a)
+    for i in range(a["depth"]):
+        ci, co, p = a["cin"][i], a["cout"][i], f"upblocks.{i}"
+        s[f"{p}.gamma"] = (1,)
+        s[f"{p}.c1.weight"] = (co, ci, 3, 3); s[f"{p}.c1.bias"] = (co,)
+        s[f"{p}.c2.weight"] = (co, co, 3, 3); s[f"{p}.c2.bias"] = (co,)
+        s.update(_affine_shapes(f"{p}.affine0", ci, h.nef))
+        s.update(_affine_shapes(f"{p}.affine1", ci, h.nef))
+        s.update(_affine_shapes(f"{p}.affine2", co, h.nef))
+        s.update(_affine_shapes(f"{p}.affine3", co, h.nef))
+        if ci != co:
+            s[f"{p}.c_sc.weight"] = (co, ci, 1, 1); s[f"{p}.c_sc.bias"] = (co,)
+    s["conv_out.1.weight"] = (3, a["cout"][-1], 3, 3); s["conv_out.1.bias"] = (3,)
+    return s
+
+
+def netd_shapes(h: Hyper):
+    """DF_DISC state_dict (model/df_gan.py:106-176,266-294). conv_s always exists (280)."""
+    a = disc_arch(h.img_size, h.nch)
+    s = {"conv_img.weight": (a["cout"][0], 3, 3, 3), "conv_img.bias": (a["cout"][0],)}
+    for i in range(1, a["depth"]):
+        ci, co, p = a["cin"][i], a["cout"][i], f"downblocks.{i - 1}"
+        s[f"{p}.gamma"] = (1,)
+        s[f"{p}.conv_r.0.weight"] = (co, ci, 4, 4)
+        s[f"{p}.conv_r.2.weight"] = (co, co, 3, 3)
+        s[f"{p}.conv_s.weight"] = (co, ci, 1, 1); s[f"{p}.conv_s.bias"] = (co,)
+    ndf16 = 16 * h.nch
+    if h.img_match:                                        # df_gan.py:143-145
+        s["COND_DNET.proj_match.weight"] = (h.nef, ndf16); s["COND_DNET.proj_match.bias"] = (h.nef,)
+        cond = h.nef
+    elif h.sent_match:                                     # 146-148
+        s["COND_DNET.proj_match.weight"] = (ndf16, h.nef); s["COND_DNET.proj_match.bias"] = (ndf16,)
+        cond = ndf16
+    elif h.seperate and h.text_dim != h.nef:               # 149-151
+        s["COND_DNET.proj_match.weight"] = (h.nef, h.text_dim); s["COND_DNET.proj_match.bias"] = (h.nef,)
+        cond = h.nef
+    else:                                                  # 152-154
+        cond = h.text_dim
+    s["COND_DNET.joint_conv.0.weight"] = (2 * h.nch, ndf16 + cond, 3, 3)
+    s["COND_DNET.joint_conv.2.weight"] = (1, 2 * h.nch, 4, 4)
+    return s
+
+
+def _concept_block_shapes(p, in_dim, h: Hyper, kind):
+    """InConceptBlock (df_concept_gan.py:159-200) / OutConceptBlock (421-465)."""
+    gw, sw = CARD * PW, CARD * SD
+    cgw = CARD * (SD + h.nef)
+    s = {f"{p}.split_conv.weight": (gw, in_dim, 1, 1), f"{p}.trans_gconv.weight": (gw, PW, 3, 3)}
+    if h.normalize:
+        s[f"{p}.gn.weight"] = (gw,); s[f"{p}.gn.bias"] = (gw,)
+    for j in (1, 2):
+        q = f"{p}.concept_sampler{j}"
+        if kind == "in":   # CondConceptSampler 256-271
+            s[f"{q}.query_gconv.weight"] = (sw, h.nef, 1, 1)
+        else:              # ConceptSampler 535-552 (registers buffer 'norm' last)
+            s[f"{q}.query_gconv.weight"] = (sw, PW, 1, 1)
+        s[f"{q}.key_gconv.weight"] = (sw, PW, 1, 1)
+        s[f"{q}.value_gconv.weight"] = (sw, PW, 1, 1)
+        if h.normalize:
+            for gn in ("gn1", "gn2"):
+                s[f"{q}.{gn}.weight"] = (sw,); s[f"{q}.{gn}.bias"] = (sw,)
+        if kind == "out":
+            s[f"{q}.norm"] = ()
+        s[f"{p}.concept_reasoner{j}.proj_edge.weight"] = (CARD, SD)
+        # registration order in the reference: sampler1, reasoner1, sampler2, reasoner2
+    if kind == "out":
+        s[f"{p}.sent_linear1.weight"] = (SD, h.nef)
+        s[f"{p}.sent_linear2.weight"] = (SD, h.nef)
+    for name in ("gamma1_gconv", "beta1_gconv", "gamma2_gconv", "beta2_gconv"):
+        s[f"{p}.{name}.0.weight"] = (2 * sw, SD + h.nef, 1, 1); s[f"{p}.{name}.0.bias"] = (2 * sw,)
+        s[f"{p}.{name}.2.weight"] = (gw, 2 * SD, 1, 1); s[f"{p}.{name}.2.bias"] = (gw,)
+    return s
+
+
+def concept_netg_shapes(h: Hyper):
+    """CONCEPT_IN_DF_GEN / CONCEPT_OUT_DF_GEN state_dict (df_concept_gan.py:65-156, 328-418)."""
+    kind = {"CONCEPT_IN_DF_GEN": "in", "CONCEPT_OUT_DF_GEN": "out"}[h.gen]
+    a = gen_arch(h.img_size, h.nch)
+    s = _stem_tail_shapes(h, a)
+    gw = CARD * PW
+    k = 3 if kind == "in" else 1      # conv_out1/2 are 3x3 in ICAttnG_Block (125-126), 1x1 in OCAG_Block (387-388)
+    for i in range(a["depth"]):
+        ci, co, p = a["cin"][i], a["cout"][i], f"upblocks.{i}"
+        s[f"{p}.gamma"] = (1,)
+        s.update(_concept_block_shapes(f"{p}.concept1", ci, h, kind))
+        s.update(_concept_block_shapes(f"{p}.concept2", co, h, kind))
+        s[f"{p}.conv_out1.weight"] = (co, gw, k, k); s[f"{p}.conv_out1.bias"] = (co,)
+        s[f"{p}.conv_out2.weight"] = (co, gw, k, k); s[f"{p}.conv_out2.bias"] = (co,)
+        if ci != co:
+            s[f"{p}.c_sc.weight"] = (co, ci, 1, 1); s[f"{p}.c_sc.bias"] = (co,)
+    s["conv_out.1.weight"] = (3, a["cout"][-1], 3, 3); s["conv_out.1.bias"] = (3,)
+    return s
+
+
+def gen_shapes(h: Hyper):
+    return netg_shapes(h) if h.gen == "DF_GEN" else concept_netg_shapes(h)
+
+
+# ----------------------------------------------------------------------------------------
+# deterministic, order-independent parameter synthesis (shared by goldens and GPU tests)
+# ----------------------------------------------------------------------------------------
+def synth_params(shapes: dict, seed: int = 0) -> dict:
+    """Kaiming-scaled weights (cf. weight_init, train_gan.py:65-69) but with non-zero biases
+    and block gammas so every branch contributes; each tensor is drawn from its own
+    generator seeded by crc32(key), so the values do not depend on construction order."""
+    out = {}
+    for key, shape in shapes.items():
+        g = torch.Generator().manual_seed((zlib.crc32(key.encode()) + 7919 * seed) & 0x7FFFFFFF)
+        leaf = key.rsplit(".", 1)[-1]
+        if key.endswith(".norm"):
+            t = torch.rsqrt(torch.tensor(float(SD)))
+        elif leaf == "gamma":
+            t = 0.25 + 0.5 * torch.rand(shape, generator=g)
+        elif ".gn" in key and leaf == "weight":
+            t = 1.0 + 0.1 * torch.randn(shape, generator=g)
+        elif leaf == "bias":
+            t = 0.05 * torch.randn(shape, generator=g)
+        else:
+            fan_in = 1
+            for d in shape[1:]:
+                fan_in *= d
+            t = torch.randn(shape, generator=g) * math.sqrt(2.0 / fan_in)
+        out[key] = t.to(torch.float32)
+    return out
+
+
+def synth_batch(h: Hyper, batch: int, seed: int = 100, words_len: int = 20):
+    """COCO-shaped synthetic batch (shapes per dataset.py:34-37, encoder.py:149)."""
+    g = torch.Generator().manual_seed(seed)
+    imgs = torch.rand(batch, 3, h.img_size, h.img_size, generator=g) * 2 - 1
+    sent = torch.randn(batch, h.text_dim, generator=g)
+    words = torch.randn(batch, h.text_dim, words_len, generator=g)
+    lens = torch.randint(5, words_len + 1, (batch,), generator=g)
+    mask = torch.arange(words_len)[None, :] >= lens[:, None]
+    noise = torch.randn(batch, h.noise_dim, generator=g)
+    return dict(imgs=imgs, sent_embs=sent, words_embs=words, mask=mask, noise=noise)
+
+
+# ----------------------------------------------------------------------------------------
+# DF_GEN forward (model/df_gan.py:91-103, 199-224, 250-263)
+# ----------------------------------------------------------------------------------------
+def _affine(P, p, x, c):
+    """affine.forward (df_gan.py:250-263): two 2-layer MLPs give per-sample channel scale/shift."""
+    def mlp(br):
+        hdn = F.relu(F.linear(c, P[f"{p}.{br}.linear1.weight"], P[f"{p}.{br}.linear1.bias"]))
+        return F.linear(hdn, P[f"{p}.{br}.linear2.weight"], P[f"{p}.{br}.linear2.bias"])
+    w, b = mlp("fc_gamma"), mlp("fc_beta")
+    return w[:, :, None, None] * x + b[:, :, None, None]
+
+
+def _g_block(P, p, x, c, upsample):
+    """G_Block.forward (df_gan.py:199-224)."""
+    hdn = F.leaky_relu(_affine(P, f"{p}.affine0", x, c), LRELU)
+    hdn = F.leaky_relu(_affine(P, f"{p}.affine1", hdn, c), LRELU)
+    hdn = F.conv2d(hdn, P[f"{p}.c1.weight"], P[f"{p}.c1.bias"], 1, 1)
+    hdn = F.leaky_relu(_affine(P, f"{p}.affine2", hdn, c), LRELU)
+    hdn = F.leaky_relu(_affine(P, f"{p}.affine3", hdn, c), LRELU)
+    res = F.conv2d(hdn, P[f"{p}.c2.weight"], P[f"{p}.c2.bias"], 1, 1)
+    sc = F.conv2d(x, P[f"{p}.c_sc.weight"], P[f"{p}.c_sc.bias"]) if f"{p}.c_sc.weight" in P else x
+    out = sc + P[f"{p}.gamma"] * res
+    if upsample:
+        out = F.interpolate(out, scale_factor=2)   # nearest (df_gan.py:202)
+    return out
+
+
+def proj_sent(P, sent):
+    """netG.proj_sent: Linear(E->NEF) or Identity (df_gan.py:74-75)."""
+    if "proj_sent.weight" in P:
+        return F.linear(sent, P["proj_sent.weight"], P["proj_sent.bias"])
+    return sent
+
+
+def _stem(P, h: Hyper, noise):
+    out = F.linear(noise, P["proj_noise.weight"], P["proj_noise.bias"])
+    return out.view(out.size(0), 8 * h.nch, 4, 4)
+
+
+def _tail(P, x):
+    """conv_out = LeakyReLU -> Conv3x3(->3) -> Tanh (df_gan.py:84-88)."""
+    return torch.tanh(F.conv2d(F.leaky_relu(x, LRELU), P["conv_out.1.weight"], P["conv_out.1.bias"], 1, 1))
+
+
+def netg_forward(P, h: Hyper, noise, sent_embs, **_):
+    a = gen_arch(h.img_size, h.nch)
+    out = _stem(P, h, noise)
+    c = proj_sent(P, sent_embs)
+    for i in range(a["depth"]):
+        out = _g_block(P, f"upblocks.{i}", out, c, a["upsample"][i])
+    return _tail(P, out)
+
+
+# ----------------------------------------------------------------------------------------
+# attention-modulation generators (model/df_concept_gan.py)
+# ----------------------------------------------------------------------------------------
+def _gn(P, p, x, groups):
+    return F.group_norm(x, groups, P[f"{p}.weight"], P[f"{p}.bias"])
+
+
+def _cond_sampler(P, p, x, sent, normalize):
+    """CondConceptSampler.forward (df_concept_gan.py:273-302): sentence query, region keys,
+    softmax over H*W per (sample, concept), attention-weighted sum of x, grouped value proj."""
+    B, _, H, W = x.shape
+    q = sent.view(B, 1, -1).repeat(1, CARD, 1).view(B, -1, 1, 1)
+    q = F.conv2d(q, P[f"{p}.query_gconv.weight"], groups=CARD)
+    if normalize:
+        q = _gn(P, f"{p}.gn1", q, CARD)
+    q = q.view(B, CARD, -1, 1)
+    k = F.conv2d(x, P[f"{p}.key_gconv.weight"], groups=CARD)
+    if normalize:
+        k = _gn(P, f"{p}.gn2", k, CARD)
+    k = k.view(B, CARD, -1, H * W)
+    attn = torch.softmax(torch.matmul(q.transpose(2, 3), k), dim=3)          # [B,C,1,HW]
+    ctx = torch.matmul(attn, x.view(B, CARD, -1, H * W).transpose(2, 3))      # [B,C,1,p]
+    return F.conv2d(ctx.reshape(B, -1, 1, 1), P[f"{p}.value_gconv.weight"], groups=CARD)
+
+
+def _self_sampler(P, p, x, normalize):
+    """ConceptSampler.forward (df_concept_gan.py:554-581): query from global average pool,
+    scores scaled by rsqrt(state_dim) buffer."""
+    B, _, H, W = x.shape
+    q = F.conv2d(F.adaptive_avg_pool2d(x, 1), P[f"{p}.query_gconv.weight"], groups=CARD)
+    if normalize:
+        q = _gn(P, f"{p}.gn1", q, CARD)
+    q = q.view(B, CARD, 1, -1)
+    k = F.conv2d(x, P[f"{p}.key_gconv.weight"], groups=CARD)
+    if normalize:
+        k = _gn(P, f"{p}.gn2", k, CARD)
+    k = k.view(B, CARD, -1, H * W)
+    attn = torch.matmul(q, k).view(B, CARD, -1) * P[f"{p}.norm"]
+    attn = torch.softmax(attn, dim=2).view(B, CARD, 1, H * W)
+    ctx = torch.matmul(attn, x.view(B, CARD, -1, H * W).transpose(2, 3))
+    return F.conv2d(ctx.reshape(B, -1, 1, 1), P[f"{p}.value_gconv.weight"], groups=CARD)
+
+
+def _reasoner(P, p, x):
+    """ConceptReasoner.forward (df_concept_gan.py:313-326); its normalize flag is forced False (308)."""
+    B = x.size(0)
+    x = x.view(B, CARD, -1)
+    adj = torch.tanh(F.linear(x, P[f"{p}.proj_edge.weight"]))
+    return F.relu(x + torch.matmul(adj, x)).view(B, -1, 1, 1)
+
+
+def _mod_mlp(P, p, cond):
+    hdn = F.leaky_relu(F.conv2d(cond, P[f"{p}.0.weight"], P[f"{p}.0.bias"], groups=CARD), LRELU)
+    return F.conv2d(hdn, P[f"{p}.2.weight"], P[f"{p}.2.bias"], groups=CARD)
+
+
+def _concept_block(P, p, x, sent, h: Hyper, kind):
+    """InConceptBlock.residual (df_concept_gan.py:213-253) / OutConceptBlock.residual (481-531)."""
+    B = x.size(0)
+    e = F.leaky_relu(F.conv2d(x, P[f"{p}.split_conv.weight"]), LRELU)
+    e = F.conv2d(e, P[f"{p}.trans_gconv.weight"], None, 1, 1, 1, CARD)
+    if h.normalize:
+        e = _gn(P, f"{p}.gn", e, CARD)
+    e = F.leaky_relu(e, LRELU)
+    gc = sent.view(B, 1, -1).repeat(1, CARD, 1)
+    out = e
+    for j in (1, 2):
+        if kind == "in":
+            ctx = _cond_sampler(P, f"{p}.concept_sampler{j}", out, sent, h.normalize)
+            ctx = _reasoner(P, f"{p}.concept_reasoner{j}", ctx).view(B, CARD, -1)
+        else:
+            st = _self_sampler(P, f"{p}.concept_sampler{j}", out, h.normalize)
+            st = _reasoner(P, f"{p}.concept_reasoner{j}", st).view(B, CARD, -1).transpose(1, 2)  # [B,p',C]
+            s = F.linear(sent, P[f"{p}.sent_linear{j}.weight"]).view(B, -1, 1)                  # [B,p',1]
+            attn = torch.softmax(torch.matmul(s.transpose(1, 2), st), dim=2)                     # [B,1,C] (475-476)
+            ctx = (st * attn).transpose(1, 2)                                                    # [B,C,p']
+        cond = torch.cat([gc, ctx], dim=2).reshape(B, -1, 1, 1)
+        gamma = _mod_mlp(P, f"{p}.gamma{j}_gconv", cond)
+        beta = _mod_mlp(P, f"{p}.beta{j}_gconv", cond)
+        out = F.leaky_relu(gamma * out + beta, LRELU)
+    return out
+
+
+def _concept_g_block(P, p, x, sent, h: Hyper, kind, upsample):
+    """ICAttnG_Block (df_concept_gan.py:133-156) / OCAG_Block (395-418)."""
+    pad = 1 if kind == "in" else 0
+    r = _concept_block(P, f"{p}.concept1", x, sent, h, kind)
+    r = F.leaky_relu(F.conv2d(r, P[f"{p}.conv_out1.weight"], P[f"{p}.conv_out1.bias"], 1, pad), LRELU)
+    r = _concept_block(P, f"{p}.concept2", r, sent, h, kind)
+    r = F.conv2d(r, P[f"{p}.conv_out2.weight"], P[f"{p}.conv_out2.bias"], 1, pad)
+    sc = F.conv2d(x, P[f"{p}.c_sc.weight"], P[f"{p}.c_sc.bias"]) if f"{p}.c_sc.weight" in P else x
+    out = P[f"{p}.gamma"] * r + sc
+    if upsample:
+        out = F.interpolate(out, scale_factor=2)
+    return out
+
+
+def concept_netg_forward(P, h: Hyper, noise, sent_embs, **_):
+    kind = {"CONCEPT_IN_DF_GEN": "in", "CONCEPT_OUT_DF_GEN": "out"}[h.gen]
+    a = gen_arch(h.img_size, h.nch)
+    c = proj_sent(P, sent_embs)
+    out = _stem(P, h, noise)
+    for i in range(a["depth"]):
+        out = _concept_g_block(P, f"upblocks.{i}", out, c, h, kind, a["upsample"][i])
+    return _tail(P, out)
+
+
+def gen_forward(P, h: Hyper, noise, sent_embs, **kw):
+    f = netg_forward if h.gen == "DF_GEN" else concept_netg_forward
+    return f(P, h, noise, sent_embs, **kw)
+
+
+# ----------------------------------------------------------------------------------------
+# DF_DISC forward (model/df_gan.py:125-132, 283-294) and COND_DNET (162-176)
+# ----------------------------------------------------------------------------------------
+def netd_forward(P, h: Hyper, x):
+    a = disc_arch(h.img_size, h.nch)
+    out = F.conv2d(x, P["conv_img.weight"], P["conv_img.bias"], 1, 1)
+    for i in range(1, a["depth"]):
+        p = f"downblocks.{i - 1}"
+        r = F.leaky_relu(F.conv2d(out, P[f"{p}.conv_r.0.weight"], None, 2, 1), LRELU)
+        r = F.leaky_relu(F.conv2d(r, P[f"{p}.conv_r.2.weight"], None, 1, 1), LRELU)
+        s = out
+        if a["cin"][i] != a["cout"][i]:                     # learned_shortcut (df_gan.py:270,287)
+            s = F.conv2d(s, P[f"{p}.conv_s.weight"], P[f"{p}.conv_s.bias"])
+        s = F.avg_pool2d(s, 2)
+        out = s + P[f"{p}.gamma"] * r
+    return out
+
+
+def cond_dnet(P, h: Hyper, feat, sent_embs):
+    """D_GET_LOGITS.forward (df_gan.py:162-176) -> [logit[B,1,1,1], img_emb, txt_emb]."""
+    B = feat.size(0)
+    out = F.avg_pool2d(feat, 4).view(B, -1)
+    has_proj = "COND_DNET.proj_match.weight" in P
+    if h.img_match:
+        out = F.linear(out, P["COND_DNET.proj_match.weight"], P["COND_DNET.proj_match.bias"])
+    elif has_proj:
+        sent_embs = F.linear(sent_embs, P["COND_DNET.proj_match.weight"], P["COND_DNET.proj_match.bias"])
+    c = sent_embs.view(B, -1, 1, 1).repeat(1, 1, 4, 4)
+    hc = torch.cat((feat, c), 1)
+    m = F.leaky_relu(F.conv2d(hc, P["COND_DNET.joint_conv.0.weight"], None, 1, 1), LRELU)
+    m = F.conv2d(m, P["COND_DNET.joint_conv.2.weight"])
+    return [m, out, sent_embs]
+
+
+# ----------------------------------------------------------------------------------------
+# contrastive head (train_gan.py:72-139)
+# ----------------------------------------------------------------------------------------
+def cosine_scores(a, b):
+    """train_gan.py:85-91."""
+    return F.normalize(a, p=2, dim=1) @ F.normalize(b, p=2, dim=1).t()
+
+
+def make_labels(batch_size, sent_embs, b_global, smooth_global=0.0, p=0.6):
+    """train_gan.py:72-83 (note the [B]-against-[B,B] broadcast of 1/num_pos runs along columns)."""
+    labels = torch.eye(batch_size)
+    if b_global:
+        sim = cosine_scores(sent_embs, sent_embs)
+        sim.fill_diagonal_(3)
+        pos = (sim > p) & (sim < 3)
+        num_pos = pos.sum(1).clamp(min=1) + 1
+        w = smooth_global if smooth_global != 0.0 else torch.reciprocal(num_pos.float())
+        labels = (labels + w * pos).clamp(max=1)
+    return labels.detach()
+
+
+def contrastive_loss(a, b, labels, b_global, smooth_global=0.0):
+    """sent_loss / img_loss (train_gan.py:93-115 / 117-139; identical bodies): symmetric InfoNCE,
+    no temperature, column-direction then row-direction."""
+    if not b_global:
+        num_pos = 1
+    elif smooth_global == 0.0:
+        num_pos = 2
+    else:
+        num_pos = (labels > 0).sum(1)
+    s = cosine_scores(a, b)
+    l0 = (-(F.log_softmax(s, dim=0) * labels).sum(0) / num_pos).mean()
+    l1 = (-(F.log_softmax(s, dim=1) * labels).sum(1) / num_pos).mean()
+    return l0 + l1
+
+
+# ----------------------------------------------------------------------------------------
+# Adam (torch.optim.Adam defaults: eps 1e-8, no weight decay, no amsgrad; train_gan.py:483-484)
+# ----------------------------------------------------------------------------------------
+@dataclass
+class AdamState:
+    lr: float
+    betas: tuple
+    eps: float = 1e-8
+    step: dict = field(default_factory=dict)
+    m: dict = field(default_factory=dict)
+    v: dict = field(default_factory=dict)
+
+    def apply(self, P: dict, grads: dict):
+        """Update P in place for every key with a (non-None) grad, like optimizer.step()."""
+        b1, b2 = self.betas
+        for k, g in grads.items():
+            if g is None:
+                continue
+            if k not in self.m:
+                self.m[k] = torch.zeros_like(P[k]); self.v[k] = torch.zeros_like(P[k]); self.step[k] = 0
+            self.step[k] += 1
+            t = self.step[k]
+            self.m[k].mul_(b1).add_(g, alpha=1 - b1)
+            self.v[k].mul_(b2).addcmul_(g, g, value=1 - b2)
+            bc1, bc2 = 1 - b1 ** t, 1 - b2 ** t
+            denom = (self.v[k].sqrt() / math.sqrt(bc2)).add_(self.eps)
+            with torch.no_grad():
+                P[k].addcdiv_(self.m[k], denom, value=-(self.lr / bc1))
+
+
+# ----------------------------------------------------------------------------------------
+# one training iteration (train_gan.py:174-293)
+# ----------------------------------------------------------------------------------------
+def _leaves(P):
+    return {k: v.detach().clone().requires_grad_(not k.endswith(".norm")) for k, v in P.items()}
+
+
+def _grads(loss, P, retain=False):
+    keys = [k for k, v in P.items() if v.requires_grad]
+    gs = torch.autograd.grad(loss, [P[k] for k in keys], allow_unused=True, retain_graph=retain)
+    return dict(zip(keys, gs))
+
+
+def train_step(PG, PD, optG: AdamState, optD: AdamState, h: Hyper, batch, it_count=1):
+    """One iteration of the loop body.  PG / PD are updated in place (plain tensors).
+    Returns a dict with every scalar the reference computes and the grads of each backward."""
+    imgs, sent, words, mask, noise = (batch[k] for k in ("imgs", "sent_embs", "words_embs", "mask", "noise"))
+    B = imgs.size(0)
+    G, D = _leaves(PG), _leaves(PD)
+    out = {}
+
+    # ---- D step (187-229)
+    psent = sent if h.seperate else proj_sent(G, sent)
+    real_feat = netd_forward(D, h, imgs)
+    o_real = cond_dnet(D, h, real_feat, psent.detach())
+    errD_real = F.relu(1.0 - o_real[0]).mean()
+    fake = gen_forward(G, h, noise, sent, words_embs=words, mask=mask)
+    o_fake = cond_dnet(D, h, netd_forward(D, h, fake.detach()), psent.detach())
+    errD_fake = F.relu(1.0 + o_fake[0]).mean()
+    mis = errD_fake
+    if h.rmis:
+        o_mis = cond_dnet(D, h, real_feat[: B - 1], psent[1:B].detach())
+        errD_mis = F.relu(1.0 + o_mis[0]).mean()
+        mis = mis + errD_mis
+        out["errD_mismatch"] = errD_mis.item()
+    any_enc = h.enc_sent or h.enc_disc
+    labels = make_labels(B, sent, h.b_global, h.smooth_global) if any_enc else None
+    enc = 0.0
+    if h.enc_sent:
+        assert h.sent_match or h.img_match
+        ds = contrastive_loss(o_real[1], o_real[2], labels, h.b_global, h.smooth_global)
+        enc = enc + h.smooth_sent * ds
+        out["ds_loss"] = ds.item()
+    errD = errD_real + mis * h.smooth_mismatch + enc
+    gD = _grads(errD, D)
+    optD.apply(PD, gD)
+    out.update(errD_real=errD_real.item(), errD_fake=errD_fake.item(), errD=errD.item(), grads_D=gD,
+               fake=fake.detach(), logit_real=o_real[0].detach(), logit_fake=o_fake[0].detach())
+
+    # ---- MA-GP (231-252): uses the post-step D weights, own optimizer step
+    if h.magp:
+        D = _leaves(PD)
+        xi = imgs.detach().clone().requires_grad_()
+        si = psent.detach().clone().requires_grad_()
+        o = cond_dnet(D, h, netd_forward(D, h, xi), si)
+        g0, g1 = torch.autograd.grad(o[0], (xi, si), torch.ones_like(o[0]), create_graph=True)
+        gcat = torch.cat((g0.reshape(B, -1), g1.reshape(B, -1)), dim=1)
+        gp = (gcat.pow(2).sum(1).sqrt() ** 6).mean()
+        d_loss = 2.0 * gp
+        gGP = _grads(d_loss, D)
+        optD.apply(PD, gGP)
+        out.update(d_loss_gp=gp.item(), grads_GP=gGP)
+
+    # ---- G step (256-291)
+    if it_count % h.n_critic == 0:
+        D = _leaves(PD)
+        feat = netd_forward(D, h, fake)
+        o = cond_dnet(D, h, feat, psent)
+        errG_fake = -o[0].mean()
+        enc = 0.0
+        if h.enc_sent:
+            gs = contrastive_loss(o[1], o[2], labels, h.b_global, h.smooth_global)
+            enc = enc + h.smooth_sent * gs
+            out["gs_loss"] = gs.item()
+        if h.enc_disc:
+            rf = F.avg_pool2d(netd_forward(D, h, imgs).detach(), 4).view(B, -1)
+            ff = F.avg_pool2d(feat, 4).view(B, -1)
+            dl = contrastive_loss(rf, ff, labels, h.b_global, h.smooth_global)
+            enc = enc + h.smooth_disc * dl
+            out["disc_loss"] = dl.item()
+        errG = errG_fake + enc
+        gG = _grads(errG, G)
+        optG.apply(PG, gG)
+        out.update(errG_fake=errG_fake.item(), errG=errG.item(), grads_G=gG)
+    return out
