@@ -1,0 +1,182 @@
+/*
+ * xmc_gan_hip.h -- C ABI of libxmc_gan_hip.so (MI355X / gfx950 kernels for the XMC-GAN G+D step).
+ *
+ * The reference (Eun0/XMC-GAN) has no native layer: its hot path bottoms out in stock ATen calls
+ * made from the files under xmc_gan/model/ and from xmc_gan/train_gan.py.  Each entry point below therefore cites the
+ * reference call site(s) whose arithmetic it takes over.  The Python host code in xmc-gan_amd/ binds
+ * these with ctypes; nothing here knows about torch.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless stated; no allocation or ownership crosses the ABI;
+ *   - `stream` is a hipStream_t (void* here so the header needs no HIP include); kernels are only
+ *     enqueued, never synchronised, so every call is hipGraph-capturable;
+ *   - activations are NHWC, channel count a multiple of 8, element type bf16 (XMC_BF16) or
+ *     f32 (XMC_F32); parameters/gradients of parameters are f32;
+ *   - return value: 0 on success, a positive hipError_t from the launch, or a negative XMC_E* code
+ *     for a rejected argument (nothing is launched in that case).
+ */
+#ifndef XMC_GAN_HIP_H
+#define XMC_GAN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XMC_ABI_VERSION 1
+
+enum { XMC_BF16 = 0, XMC_F32 = 1 };
+enum { XMC_ACT_NONE = 0, XMC_ACT_LRELU = 1, XMC_ACT_TANH = 2, XMC_ACT_RELU = 3 };
+enum { XMC_EINVAL = -1, XMC_EALIGN = -2, XMC_ESHAPE = -3 };
+
+#define XMC_MAX_TAPS 16
+#define XMC_MAX_CLASSES 4
+
+/*
+ * Tap-table description of one implicit-GEMM convolution pass.  One descriptor covers
+ *   forward   F.conv2d / nn.Linear      (df_gan.py:187-188,197,273,276,280,86,157,159; nn.Linear at 73-74,233-240,144)
+ *   dgrad     d(loss)/d(input) of those  (the autograd the reference gets from errD.backward()/errG.backward(),
+ *                                         train_gan.py:228,251,288)
+ * Index space: m -> (n, a, b), a < MH, b < MW.  For tap t of class z the source pixel is
+ * (a*SA + dh[z][t], b*SA + dw[z][t]) (zero outside [0,SH<<src_shift) x [0,SW<<src_shift), then >> src_shift:
+ * a fused nearest x2 upsample, F.interpolate at df_gan.py:202), the destination pixel is
+ * (a*DA + dph[z], b*DA + dpw[z]); the tap's weight slice is wpk[wi[z][t]] : [CDw][CS] (K contiguous).
+ * Stride-2 dgrad uses 4 classes (output-pixel parities) of 4 taps each so no MFMA work is wasted on
+ * structurally-zero taps.
+ * Epilogue:  v = acc + bias[c];  v = act(v);  v = alpha*v (alpha = *alpha_dev or 1);  v += res;  store.
+ */
+typedef struct XmcConvDesc {
+    const void* src;        /* [N,SH,SW,CS] */
+    const void* wpk;        /* packed weights [nslices][CDw][CS], same dtype as src */
+    void* dst;              /* [N,DH,DW,CD] */
+    const float* bias;      /* [CD] or NULL */
+    const void* res;        /* residual, dst layout+dtype, or NULL */
+    const float* alpha_dev; /* device scalar or NULL */
+    int32_t N, SH, SW, CS;
+    int32_t DH, DW, CD;
+    int32_t MH, MW;
+    int32_t SA, DA;
+    int32_t src_shift;
+    int32_t ntaps, nclass;
+    int32_t CDw;            /* rows per weight slice (>= CD, multiple of 32, zero padded) */
+    int32_t act;            /* XMC_ACT_* */
+    int32_t dtype;          /* XMC_BF16 / XMC_F32: src, wpk */
+    int32_t out_dtype;      /* dst, res */
+    int8_t dh[XMC_MAX_CLASSES][XMC_MAX_TAPS];
+    int8_t dw[XMC_MAX_CLASSES][XMC_MAX_TAPS];
+    int8_t wi[XMC_MAX_CLASSES][XMC_MAX_TAPS];
+    int8_t dph[XMC_MAX_CLASSES];
+    int8_t dpw[XMC_MAX_CLASSES];
+} XmcConvDesc;
+
+int xmc_abi_version(void);
+
+/* forward / dgrad implicit GEMM on MFMA (bf16: v_mfma_f32_16x16x32_bf16; f32: v_mfma_f32_16x16x4_f32) */
+int xmc_conv_igemm(const XmcConvDesc* d, void* stream);
+
+/*
+ * Weight gradient of the same convolution (train_gan.py:228,251,288 -> conv2d weight grads):
+ *   dwp[t][co][ci] += sum_{n,a,b} dy[n,a,b,co] * x[n, a*SA+dh[t], b*SA+dw[t], ci]      (f32, atomically accumulated;
+ * the caller zeroes dwp).  x: [N,SH,SW,CS], dy: [N,MH,MW,CD].  Uses class 0 of the tap table.
+ */
+int xmc_conv_wgrad(const XmcConvDesc* d /* src=x, dst=dy (read only) */, float* dwp, void* stream);
+
+/* ---- weight (un)packing between nn.Parameter layout [Co][Ci][KH][KW] f32 and kernel layouts --------------- */
+/* fwd pack:  wpk[kh*KW+kw][co][ci]      (rows padded to CDw, cols to CSp, zeros)                               */
+/* dgrad pack: wpk[kh*KW+kw][ci][co]     (rows padded to CSw, cols to CDp)                                       */
+int xmc_pack_weight(const float* w, void* wpk, int Co, int Ci, int KH, int KW, int rows_pad, int cols_pad,
+                    int transpose /*0 fwd, 1 dgrad*/, int dtype, const int32_t* row_perm /*NULL or [Co]*/, void* stream);
+/* grad unpack: gw[co][ci][kh][kw] (+)= scale * dwp[kh*KW+kw][co][ci] (dwp rows padded to rows_pad, cols to cols_pad) */
+int xmc_unpack_wgrad(const float* dwp, float* gw, int Co, int Ci, int KH, int KW, int rows_pad, int cols_pad,
+                     const float* scale_dev, const int32_t* row_perm, int accumulate, void* stream);
+
+/* ---- layout conversion at the module boundary (NetD.forward input df_gan.py:127, NetG output df_gan.py:101) -- */
+int xmc_nchw_to_nhwc8(const float* src /*[N,C,H,W] f32*/, void* dst /*[N,H,W,8]*/, int N, int C, int H, int W,
+                      int dtype, void* stream);
+int xmc_nhwc8_to_nchw(const void* src /*[N,H,W,8]*/, float* dst /*[N,C,H,W] f32*/, int N, int C, int H, int W,
+                      int dtype, void* stream);
+
+/* ---- pointwise / small reductions (NHWC, C % 8 == 0) ------------------------------------------------------- */
+/* y = x > 0 ? x : slope*x                   (nn.LeakyReLU(0.2) df_gan.py:85,158,214-222,274,277; slope 0 = nn.ReLU 234,239) */
+int xmc_lrelu(const void* x, void* y, int64_t n, float slope, int dtype, void* stream);
+/* dx = ref > 0 ? dy : slope*dy             (ref may be the pre- or post-activation tensor) */
+int xmc_lrelu_mask(const void* dy, const void* ref, void* dx, int64_t n, float slope, int dtype, void* stream);
+/* y = tanh(x) ; dx = dy * (1 - y^2)         (nn.Tanh df_gan.py:87) */
+int xmc_tanh(const void* x, void* y, int64_t n, int dtype, void* stream);
+int xmc_tanh_bwd(const void* dy, const void* y, void* dx, int64_t n, int dtype, void* stream);
+/* y = a + (*alpha_dev) * b                  (shortcut + gamma*residual, df_gan.py:200,284) */
+int xmc_axpby(const void* a, const void* b, const float* alpha_dev, void* y, int64_t n, int dtype, void* stream);
+/* y = (*alpha_dev) * x */
+int xmc_scale(const void* x, const float* alpha_dev, void* y, int64_t n, int dtype, void* stream);
+/* *out (+)= sum(a*b)  (f32 scalar; out zeroed by caller when accumulate==0 is not desired) */
+int xmc_dot(const void* a, const void* b, float* out, int64_t n, int dtype, void* stream);
+/* out[c] = sum over rows of x[r][c]         (bias gradients) ; out is f32 [C], zeroed by the caller */
+int xmc_colsum(const void* x, float* out, int64_t rows, int C, int dtype, void* stream);
+/* 2x2 average pool (F.avg_pool2d(x,2) df_gan.py:290) and its adjoint (nearest x2 upsample * scale) */
+int xmc_avgpool2(const void* x, void* y, int N, int H, int W, int C, int dtype, void* stream);
+int xmc_upsample2(const void* x, void* y, int N, int H, int W, int C, float scale, int dtype, void* stream);
+/* 2x2 sum pool * scale  (adjoint of nearest upsample, F.interpolate df_gan.py:202) == avgpool2 with scale 4*scale */
+int xmc_sumpool2(const void* x, void* y, int N, int H, int W, int C, float scale, int dtype, void* stream);
+/* global average over HW -> [N,C] (F.avg_pool2d(x,4) on 4x4 maps df_gan.py:165, train_gan.py:272,275) + adjoint */
+int xmc_global_avgpool(const void* x, void* y, int N, int HW, int C, int dtype, int out_dtype, void* stream);
+int xmc_global_avgpool_bwd(const void* dy, void* dx, int N, int HW, int C, int dtype, int in_dtype, void* stream);
+
+/*
+ * DF-GAN conditional affine pair + LeakyReLU, fused (affine.forward df_gan.py:250-263 twice with
+ * LeakyReLU(0.2) after each, as used at df_gan.py:213-216 and 219-222):
+ *   y = lrelu( lrelu(x*g0 + b0) * g1 + b1 ),   g*,b* : f32 [N,C] (per sample, per channel)
+ * backward returns dx and the four [N,C] f32 reductions (zeroed by the caller; atomically accumulated).
+ */
+int xmc_affine2_lrelu_fwd(const void* x, const float* g0, const float* b0, const float* g1, const float* b1,
+                          void* y, int N, int HW, int C, int dtype, void* stream);
+int xmc_affine2_lrelu_bwd(const void* x, const void* dy, const float* g0, const float* b0, const float* g1,
+                          const float* b1, void* dx, float* dg0, float* db0, float* dg1, float* db1,
+                          int N, int HW, int C, int dtype, void* stream);
+
+/*
+ * Contrastive head (cosine_scores + sent_loss/img_loss, train_gan.py:85-139), fused:
+ *   S = normalize(A) normalize(B)^T ; loss = mean_j(-sum_i L_ij logsoftmax_col(S)_ij / np_j)
+ *                                         + mean_i(-sum_j L_ij logsoftmax_row(S)_ij / np_i)
+ * A,B: f32 [n,D] row-major; labels f32 [n,n] or NULL (identity); inv_num_pos f32 [n] or NULL (1).
+ * ws: workspace of xmc_contrastive_ws_bytes(n,D) bytes (kept by the caller until backward has run).
+ * fwd writes *loss; bwd writes dA,dB = dloss * dLoss/d{A,B}  (dloss is a device scalar).
+ */
+int64_t xmc_contrastive_ws_bytes(int n, int D);
+int xmc_contrastive_fwd(const float* A, const float* B, const float* labels, const float* inv_num_pos,
+                        int n, int D, float* loss, void* ws, void* stream);
+int xmc_contrastive_bwd(const float* A, const float* B, const float* labels, const float* inv_num_pos,
+                        int n, int D, const float* dloss_dev, void* ws, float* dA, float* dB, void* stream);
+
+/* hinge terms: *out = mean_i relu(1 + sign*x[i*stride])  (train_gan.py:195,204,209);
+ * bwd: dx[i*stride] = (*dloss_dev)*sign/n where the hinge is active, else 0 (other elements of dx untouched) */
+int xmc_hinge_fwd(const void* x, int stride, float sign, float* out, int64_t n, int dtype, void* stream);
+int xmc_hinge_bwd(const void* x, int stride, float sign, const float* dloss_dev, void* dx, int64_t n, int dtype,
+                  void* stream);
+
+/* element type conversion between the activation dtypes (n % 8 == 0) */
+int xmc_cast(const void* x, void* y, int64_t n, int src_dtype, int dst_dtype, void* stream);
+
+/*
+ * Multi-tensor Adam (torch.optim.Adam.step as used at train_gan.py:229,252,289; eps 1e-8, no weight decay):
+ * one launch updates every tensor of `table_dev` (DEVICE array).  `chunks_dev` is a DEVICE array of
+ * nchunks (tensor index, chunk index) int32 pairs, one per block, chunk = xmc_adam_chunk_elems() elements.
+ * `step` is a device counter per tensor holding the number of updates already applied; the launch uses
+ * step+1 for the bias corrections and then increments it, so the whole call is hipGraph-replayable.
+ */
+typedef struct XmcAdamEntry {
+    float* param;
+    const float* grad;
+    float* m;        /* exp_avg */
+    float* v;        /* exp_avg_sq */
+    int32_t* step;
+    int64_t n;
+} XmcAdamEntry;
+int xmc_adam_chunk_elems(void);
+int xmc_adam_step(const XmcAdamEntry* table_dev, int ntensors, const int32_t* chunks_dev, int nchunks,
+                  float lr, float beta1, float beta2, float eps, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XMC_GAN_HIP_H */

@@ -1,0 +1,69 @@
+// Shared device helpers for the gfx950 kernels (wave = 64 lanes, 16-byte vector memory ops).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "xmc_gan_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+#define XMC_LRELU 0.2f
+
+static inline int xmc_esz(int dtype) { return dtype == XMC_BF16 ? 2 : 4; }
+
+#define XMC_LAUNCH_CHECK()                         \
+    do {                                           \
+        hipError_t e__ = hipGetLastError();        \
+        if (e__ != hipSuccess) return (int)e__;    \
+    } while (0)
+
+__device__ __forceinline__ float lrelu_f(float v) { return v > 0.f ? v : XMC_LRELU * v; }
+__device__ __forceinline__ float lrelu_slope(float ref) { return ref > 0.f ? 1.f : XMC_LRELU; }
+
+// 8 consecutive channels <-> 8 floats, for either storage type
+template <int DT> struct Vec8;
+template <> struct Vec8<XMC_BF16> {
+    static constexpr int BYTES = 16;
+    __device__ static __forceinline__ void load(const void* p, size_t idx8, float (&v)[8]) {
+        bf16x8 t = reinterpret_cast<const bf16x8*>(p)[idx8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (float)t[i];
+    }
+    __device__ static __forceinline__ void store(void* p, size_t idx8, const float (&v)[8]) {
+        bf16x8 t;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t[i] = (__bf16)v[i];
+        reinterpret_cast<bf16x8*>(p)[idx8] = t;
+    }
+};
+template <> struct Vec8<XMC_F32> {
+    static constexpr int BYTES = 32;
+    __device__ static __forceinline__ void load(const void* p, size_t idx8, float (&v)[8]) {
+        const f32x4* q = reinterpret_cast<const f32x4*>(p) + idx8 * 2;
+        f32x4 a = q[0], b = q[1];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[i] = a[i]; v[4 + i] = b[i]; }
+    }
+    __device__ static __forceinline__ void store(void* p, size_t idx8, const float (&v)[8]) {
+        f32x4* q = reinterpret_cast<f32x4*>(p) + idx8 * 2;
+        f32x4 a, b;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { a[i] = v[i]; b[i] = v[4 + i]; }
+        q[0] = a; q[1] = b;
+    }
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}

@@ -1,0 +1,279 @@
+// Implicit-GEMM convolution (forward and data-gradient) for gfx950.
+//
+//   D[m][n] = sum_{tap,ci} A[m][tap,ci] * W[tap][n][ci]        m = (image, a, b), n = destination channel
+//
+// A is never materialised: each 16-byte unit (8 bf16 / 4 f32 channels of one source pixel of one tap)
+// is gathered straight from the NHWC source tensor, zero filled outside the image, into an LDS tile;
+// W comes from a pre-packed [tap][n][ci] matrix so both MFMA operands are K-contiguous 16-byte
+// fragments.  Work decomposition: one 256-thread workgroup (4 waves) per BM x BN output tile,
+// waves arranged WM x WN, each wave a (BM/WM) x (BN/WN) patch of 16x16 MFMA tiles.
+// K loop: double-buffered LDS, global loads for step k+1 issued before the MFMAs of step k and
+// written to LDS after them (one barrier per step).  LDS rows are 64 B (one K sub-step) with the
+// 16-byte chunk XOR-swizzled by g[(row>>2)&3] = {0,2,3,1}, which makes both the ds_write_b128
+// staging pattern and the ds_read_b128 fragment pattern (lane -> row l&15, chunk l>>4) conflict
+// free for the 4x16 lane groups of ds_read_b128 (MI355X_MICROARCH.md, LDS table).
+// Epilogue: accumulators -> LDS (f32) -> each thread owns 8 consecutive channels of one pixel ->
+// bias / activation / alpha / residual -> one 16-byte (bf16) or 32-byte (f32) coalesced store.
+//
+// Takes over: F.conv2d / nn.Linear forward at df_gan.py:73-74,86,144,157-159,187-188,197,233-240,
+// 273,276,280 and the input-gradient halves of errD.backward()/d_loss.backward()/errG.backward()
+// (train_gan.py:228,251,288).
+#include "common.h"
+
+namespace {
+
+template <int DT> struct Mma;
+template <> struct Mma<XMC_BF16> {
+    __device__ static __forceinline__ f32x4 run(u32x4 a, u32x4 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+};
+template <> struct Mma<XMC_F32> {
+    // 16 bytes = 4 f32 per lane; instruction j contracts k = 4*(lane>>4)+j of A and B alike, so the
+    // four instructions together cover the 16 k of the 64-byte row exactly once.
+    __device__ static __forceinline__ f32x4 run(u32x4 a, u32x4 b, f32x4 c) {
+        f32x4 af = __builtin_bit_cast(f32x4, a), bf = __builtin_bit_cast(f32x4, b);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bf[j], c, 0, 0, 0);
+        return c;
+    }
+};
+
+__device__ __forceinline__ int swz(int row) {  // {0,2,3,1}[(row>>2)&3]
+    int q = (row >> 2) & 3;
+    return (((q ^ (q >> 1)) & 1) << 1) | (q >> 1);
+}
+
+template <int DT, int BM, int BN, int WM, int WN, int KSUB>
+__global__ __launch_bounds__(256) void igemm_kernel(const XmcConvDesc d) {
+    constexpr int NT = 256;
+    static_assert(WM * WN == 4, "4 waves");
+    constexpr int WTM = BM / WM, WTN = BN / WN;      // wave tile
+    constexpr int TM = WTM / 16, TN = WTN / 16;      // 16x16 MFMA tiles per wave
+    constexpr int AL = BM * 4 / NT;                  // A chunks per thread per sub-step
+    constexpr int BL = (BN * 4 + NT - 1) / NT;       // B chunks per thread per sub-step
+    constexpr int STAGE_U = 2 * KSUB * (BM + BN) * 4;            // 16-byte units
+    constexpr int EP_LD = BN + 4;
+    constexpr int EP_U = (BM * EP_LD * 4 + 15) / 16;
+    constexpr int SMEM_U = STAGE_U > EP_U ? STAGE_U : EP_U;
+    __shared__ u32x4 smem[SMEM_U];
+    __shared__ int s_tap[XMC_MAX_TAPS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int cls = blockIdx.z;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int MHW = d.MH * d.MW;
+    const int M = d.N * MHW;
+    constexpr int ESZ = DT == XMC_BF16 ? 2 : 4;
+    const int upt = d.CS * ESZ / 16;                 // 16-byte units per tap
+    const int ktot = d.ntaps * upt;                  // total units along K
+    const int nsub = (ktot + 3) / 4;                 // 64-byte sub-steps
+    const int nstep = (nsub + KSUB - 1) / KSUB;
+
+    if (tid < XMC_MAX_TAPS)
+        s_tap[tid] = tid < d.ntaps ? ((d.dh[cls][tid] & 0xff) | ((d.dw[cls][tid] & 0xff) << 8) | ((d.wi[cls][tid] & 0xff) << 16)) : 0;
+    __syncthreads();
+
+    // ---- per-thread staging coordinates (fixed over the K loop)
+    const int c = tid & 3, r0 = tid >> 2;
+    int ph[AL], pw[AL], pn[AL];
+#pragma unroll
+    for (int i = 0; i < AL; ++i) {
+        int m = m0 + r0 + 64 * i;
+        if (m < M) {
+            int n = m / MHW, rem = m - n * MHW;
+            int a = rem / d.MW, b = rem - a * d.MW;
+            ph[i] = a * d.SA; pw[i] = b * d.SA; pn[i] = n * d.SH;
+        } else {
+            ph[i] = -(1 << 20); pw[i] = 0; pn[i] = 0;
+        }
+    }
+    const int SHv = d.SH << d.src_shift, SWv = d.SW << d.src_shift;
+    const u32x4* __restrict__ src16 = reinterpret_cast<const u32x4*>(d.src);
+    const u32x4* __restrict__ w16 = reinterpret_cast<const u32x4*>(d.wpk);
+
+    int tap = c / upt, cu = c % upt;                 // unit index u = sub*4 + c  ->  (tap, cu)
+    u32x4 ra[KSUB][AL], rb[KSUB][BL];
+
+    auto load_step = [&](int step) {
+#pragma unroll
+        for (int s = 0; s < KSUB; ++s) {
+            const bool tapok = tap < d.ntaps;
+            const int tv = s_tap[tapok ? tap : 0];
+            const int tdh = (int8_t)(tv & 0xff), tdw = (int8_t)((tv >> 8) & 0xff), twi = (tv >> 16) & 0xff;
+#pragma unroll
+            for (int i = 0; i < AL; ++i) {
+                int sh = ph[i] + tdh, sw = pw[i] + tdw;
+                bool ok = tapok && (unsigned)sh < (unsigned)SHv && (unsigned)sw < (unsigned)SWv;
+                size_t off = ((size_t)(pn[i] + (sh >> d.src_shift)) * d.SW + (sw >> d.src_shift)) * upt + cu;
+                u32x4 z = {0, 0, 0, 0};
+                ra[s][i] = ok ? src16[off] : z;
+            }
+#pragma unroll
+            for (int j = 0; j < BL; ++j) {
+                int rn = r0 + 64 * j;
+                u32x4 z = {0, 0, 0, 0};
+                bool ok = tapok && rn < BN;
+                size_t off = ((size_t)twi * d.CDw + n0 + rn) * upt + cu;
+                rb[s][j] = ok ? w16[off] : z;
+            }
+            cu += 4;
+            while (cu >= upt) { cu -= upt; ++tap; }
+        }
+        (void)step;
+    };
+    auto store_step = [&](int buf) {
+        u32x4* la = smem + buf * (KSUB * (BM + BN) * 4);
+        u32x4* lb = la + KSUB * BM * 4;
+#pragma unroll
+        for (int s = 0; s < KSUB; ++s) {
+#pragma unroll
+            for (int i = 0; i < AL; ++i) {
+                int r = r0 + 64 * i;
+                la[(s * BM + r) * 4 + (c ^ swz(r))] = ra[s][i];
+            }
+#pragma unroll
+            for (int j = 0; j < BL; ++j) {
+                int r = r0 + 64 * j;
+                if (r < BN) lb[(s * BN + r) * 4 + (c ^ swz(r))] = rb[s][j];
+            }
+        }
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, fc = lane >> 4;        // fragment row / 16-byte chunk
+    load_step(0);
+    store_step(0);
+    __syncthreads();
+    for (int step = 0; step < nstep; ++step) {
+        const int buf = step & 1;
+        const bool more = step + 1 < nstep;
+        if (more) load_step(step + 1);
+        const u32x4* la = smem + buf * (KSUB * (BM + BN) * 4);
+        const u32x4* lb = la + KSUB * BM * 4;
+#pragma unroll
+        for (int s = 0; s < KSUB; ++s) {
+            u32x4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                int r = wm * WTM + i * 16 + fr;
+                af[i] = la[(s * BM + r) * 4 + (fc ^ swz(r))];
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                int r = wn * WTN + j * 16 + fr;
+                bf[j] = lb[(s * BN + r) * 4 + (fc ^ swz(r))];
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = Mma<DT>::run(af[i], bf[j], acc[i][j]);
+        }
+        if (more) store_step(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: acc -> LDS (f32 [BM][BN+4]) -> coalesced channel-vector stores
+    float* ep = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                ep[(wm * WTM + i * 16 + fc * 4 + r) * EP_LD + wn * WTN + j * 16 + fr] = acc[i][j][r];
+    __syncthreads();
+
+    const float alpha = d.alpha_dev ? *d.alpha_dev : 1.f;
+    constexpr int CPR = BN / 8;                      // 8-channel chunks per tile row
+    const int dph = d.dph[cls], dpw = d.dpw[cls];
+    for (int id = tid; id < BM * CPR; id += NT) {
+        int row = id / CPR, cc = id - row * CPR;
+        int m = m0 + row, ch = n0 + cc * 8;
+        if (m >= M || ch >= d.CD) continue;
+        int n = m / MHW, rem = m - n * MHW;
+        int a = rem / d.MW, b = rem - a * d.MW;
+        size_t pix = ((size_t)n * d.DH + a * d.DA + dph) * d.DW + b * d.DA + dpw;
+        size_t idx8 = (pix * d.CD + ch) >> 3;
+        float v[8];
+        const f32x4 e0 = *reinterpret_cast<const f32x4*>(&ep[row * EP_LD + cc * 8]);
+        const f32x4 e1 = *reinterpret_cast<const f32x4*>(&ep[row * EP_LD + cc * 8 + 4]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[k] = e0[k]; v[4 + k] = e1[k]; }
+        if (d.bias) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] += d.bias[ch + k];
+        }
+        if (d.act == XMC_ACT_LRELU) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = lrelu_f(v[k]);
+        } else if (d.act == XMC_ACT_RELU) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+        } else if (d.act == XMC_ACT_TANH) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = tanhf(v[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] *= alpha;
+        if (d.out_dtype == XMC_BF16) {
+            if (d.res) {
+                float rr[8];
+                Vec8<XMC_BF16>::load(d.res, idx8, rr);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] += rr[k];
+            }
+            Vec8<XMC_BF16>::store(d.dst, idx8, v);
+        } else {
+            if (d.res) {
+                float rr[8];
+                Vec8<XMC_F32>::load(d.res, idx8, rr);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] += rr[k];
+            }
+            Vec8<XMC_F32>::store(d.dst, idx8, v);
+        }
+    }
+}
+
+template <int DT, int BM, int BN, int WM, int WN, int KSUB>
+int launch(const XmcConvDesc& d, hipStream_t st) {
+    const int64_t M = (int64_t)d.N * d.MH * d.MW;
+    dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)(d.CDw / BN), (unsigned)d.nclass);
+    hipLaunchKernelGGL((igemm_kernel<DT, BM, BN, WM, WN, KSUB>), grid, dim3(256), 0, st, d);
+    XMC_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int DT>
+int dispatch(const XmcConvDesc& d, hipStream_t st) {
+    if (d.CDw % 128 == 0) return launch<DT, 128, 128, 2, 2, 2>(d, st);
+    if (d.CDw % 64 == 0) return launch<DT, 128, 64, 4, 1, 2>(d, st);
+    return launch<DT, 128, 32, 4, 1, 2>(d, st);
+}
+
+}  // namespace
+
+extern "C" int xmc_conv_igemm(const XmcConvDesc* d, void* stream) {
+    if (!d || !d->src || !d->wpk || !d->dst) return XMC_EINVAL;
+    if (d->dtype != XMC_BF16 && d->dtype != XMC_F32) return XMC_EINVAL;
+    if (d->out_dtype != XMC_BF16 && d->out_dtype != XMC_F32) return XMC_EINVAL;
+    const int esz = xmc_esz(d->dtype);
+    if (d->ntaps < 1 || d->ntaps > XMC_MAX_TAPS || d->nclass < 1 || d->nclass > XMC_MAX_CLASSES) return XMC_ESHAPE;
+    if ((d->CS * esz) % 16 != 0 || d->CD % 8 != 0 || d->CDw % 32 != 0 || d->CDw < d->CD) return XMC_EALIGN;
+    if (d->N < 1 || d->MH < 1 || d->MW < 1 || d->SH < 1 || d->SW < 1 || d->DH < 1 || d->DW < 1) return XMC_ESHAPE;
+    if (d->src_shift < 0 || d->src_shift > 1 || d->SA < 1 || d->DA < 1) return XMC_ESHAPE;
+    // destination pixels must stay inside the destination tensor
+    for (int z = 0; z < d->nclass; ++z)
+        if ((d->MH - 1) * d->DA + d->dph[z] >= d->DH || (d->MW - 1) * d->DA + d->dpw[z] >= d->DW || d->dph[z] < 0 || d->dpw[z] < 0)
+            return XMC_ESHAPE;
+    if ((int64_t)d->N * d->MH * d->MW >= (1ll << 31)) return XMC_ESHAPE;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    return d->dtype == XMC_BF16 ? dispatch<XMC_BF16>(*d, st) : dispatch<XMC_F32>(*d, st);
+}

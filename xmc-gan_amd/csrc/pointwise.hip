@@ -1,0 +1,558 @@
+// HBM-bound pointwise / small-reduction kernels (NHWC, 8-channel vectors, 16-byte accesses).
+// Each cites the reference op it replaces in include/xmc_gan_hip.h.
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 256;
+inline int nblocks(int64_t items, int per_block = NT, int cap = 256 * 16) {
+    int64_t b = (items + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    return (int)(b > cap ? cap : b);
+}
+
+// ------------------------------------------------------------------ generic 8-wide maps
+template <int DT, class F>
+__global__ void map1_kernel(const void* x, void* y, int64_t n8, F f) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        float v[8];
+        Vec8<DT>::load(x, i, v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = f(v[k]);
+        Vec8<DT>::store(y, i, v);
+    }
+}
+template <int DT, class F>
+__global__ void map2_kernel(const void* a, const void* b, void* y, int64_t n8, F f) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        float u[8], v[8];
+        Vec8<DT>::load(a, i, u);
+        Vec8<DT>::load(b, i, v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) u[k] = f(u[k], v[k]);
+        Vec8<DT>::store(y, i, u);
+    }
+}
+
+struct FLrelu { float slope; __device__ float operator()(float v) const { return v > 0.f ? v : slope * v; } };
+struct FTanh { __device__ float operator()(float v) const { return tanhf(v); } };
+struct FLreluMask { float slope; __device__ float operator()(float dy, float ref) const { return ref > 0.f ? dy : slope * dy; } };
+struct FTanhBwd { __device__ float operator()(float dy, float y) const { return dy * (1.f - y * y); } };
+struct FAxpby { const float* alpha; __device__ float operator()(float a, float b) const { return a + (*alpha) * b; } };
+struct FScale { const float* alpha; __device__ float operator()(float v) const { return (*alpha) * v; } };
+
+template <class F>
+int run_map1(const void* x, void* y, int64_t n, int dtype, hipStream_t st, F f) {
+    if (n % 8) return XMC_EALIGN;
+    if (n == 0) return 0;
+    int64_t n8 = n / 8;
+    if (dtype == XMC_BF16) hipLaunchKernelGGL((map1_kernel<XMC_BF16, F>), dim3(nblocks(n8)), dim3(NT), 0, st, x, y, n8, f);
+    else if (dtype == XMC_F32) hipLaunchKernelGGL((map1_kernel<XMC_F32, F>), dim3(nblocks(n8)), dim3(NT), 0, st, x, y, n8, f);
+    else return XMC_EINVAL;
+    XMC_LAUNCH_CHECK();
+    return 0;
+}
+template <class F>
+int run_map2(const void* a, const void* b, void* y, int64_t n, int dtype, hipStream_t st, F f) {
+    if (n % 8) return XMC_EALIGN;
+    if (n == 0) return 0;
+    int64_t n8 = n / 8;
+    if (dtype == XMC_BF16) hipLaunchKernelGGL((map2_kernel<XMC_BF16, F>), dim3(nblocks(n8)), dim3(NT), 0, st, a, b, y, n8, f);
+    else if (dtype == XMC_F32) hipLaunchKernelGGL((map2_kernel<XMC_F32, F>), dim3(nblocks(n8)), dim3(NT), 0, st, a, b, y, n8, f);
+    else return XMC_EINVAL;
+    XMC_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------ cast
+template <int SD, int DD>
+__global__ void cast_kernel(const void* x, void* y, int64_t n8) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        float v[8];
+        Vec8<SD>::load(x, i, v);
+        Vec8<DD>::store(y, i, v);
+    }
+}
+
+// ------------------------------------------------------------------ dot / colsum
+template <int DT>
+__global__ void dot_kernel(const void* a, const void* b, float* out, int64_t n8) {
+    float s = 0.f;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        float u[8], v[8];
+        Vec8<DT>::load(a, i, u);
+        Vec8<DT>::load(b, i, v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += u[k] * v[k];
+    }
+    s = wave_sum(s);
+    __shared__ float part[NT / 64];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < NT / 64; ++w) t += part[w];
+        atomicAdd(out, t);
+    }
+}
+
+// out[c] += sum_r x[r][c];  thread owns channel chunk (tid % C8) and strides over rows
+template <int DT>
+__global__ void colsum_kernel(const void* x, float* out, int64_t rows, int C8) {
+    const int groups = NT / C8;                       // row-lanes per block
+    const int cc = threadIdx.x % C8, g = threadIdx.x / C8;
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (g < groups)
+        for (int64_t r = (int64_t)blockIdx.x * groups + g; r < rows; r += (int64_t)gridDim.x * groups) {
+            float v[8];
+            Vec8<DT>::load(x, r * C8 + cc, v);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s[k] += v[k];
+        }
+    __shared__ float red[NT * 8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[threadIdx.x * 8 + k] = s[k];
+    __syncthreads();
+    if (threadIdx.x < C8) {
+        float t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int gg = 0; gg < groups; ++gg)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t[k] += red[(gg * C8 + threadIdx.x) * 8 + k];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) atomicAdd(&out[threadIdx.x * 8 + k], t[k]);
+    }
+}
+
+// ------------------------------------------------------------------ pooling / resampling
+template <int DT>
+__global__ void pool2_kernel(const void* x, void* y, int N, int H, int W, int C8, float scale) {
+    const int OH = H / 2, OW = W / 2;
+    const int64_t total = (int64_t)N * OH * OW * C8;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int cc = (int)(i % C8);
+        int64_t p = i / C8;
+        int ow = (int)(p % OW); p /= OW;
+        int oh = (int)(p % OH);
+        int n = (int)(p / OH);
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, v[8];
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                Vec8<DT>::load(x, (((int64_t)n * H + 2 * oh + dy) * W + 2 * ow + dx) * C8 + cc, v);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[k] += v[k];
+            }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] *= scale;
+        Vec8<DT>::store(y, i, acc);
+    }
+}
+template <int DT>
+__global__ void up2_kernel(const void* x, void* y, int N, int H, int W, int C8, float scale) {
+    const int OH = H * 2, OW = W * 2;
+    const int64_t total = (int64_t)N * OH * OW * C8;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int cc = (int)(i % C8);
+        int64_t p = i / C8;
+        int ow = (int)(p % OW); p /= OW;
+        int oh = (int)(p % OH);
+        int n = (int)(p / OH);
+        float v[8];
+        Vec8<DT>::load(x, (((int64_t)n * H + (oh >> 1)) * W + (ow >> 1)) * C8 + cc, v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] *= scale;
+        Vec8<DT>::store(y, i, v);
+    }
+}
+template <int DT, int OD>
+__global__ void gap_kernel(const void* x, void* y, int N, int HW, int C8) {
+    const int64_t total = (int64_t)N * C8;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int cc = (int)(i % C8);
+        int n = (int)(i / C8);
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, v[8];
+        for (int p = 0; p < HW; ++p) {
+            Vec8<DT>::load(x, ((int64_t)n * HW + p) * C8 + cc, v);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] += v[k];
+        }
+        const float inv = 1.f / HW;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] *= inv;
+        Vec8<OD>::store(y, i, acc);
+    }
+}
+template <int DT, int ID>
+__global__ void gap_bwd_kernel(const void* dy, void* dx, int N, int HW, int C8) {
+    const int64_t total = (int64_t)N * HW * C8;
+    const float inv = 1.f / HW;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int cc = (int)(i % C8);
+        int n = (int)(i / ((int64_t)HW * C8));
+        float v[8];
+        Vec8<ID>::load(dy, (int64_t)n * C8 + cc, v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] *= inv;
+        Vec8<DT>::store(dx, i, v);
+    }
+}
+
+// ------------------------------------------------------------------ NCHW f32 <-> NHWC8
+template <int DT>
+__global__ void nchw_to_nhwc8_kernel(const float* src, void* dst, int N, int C, int HW) {
+    const int64_t total = (int64_t)N * HW;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t n = i / HW, p = i - n * HW;
+        float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int c = 0; c < C; ++c) v[c] = src[(n * C + c) * HW + p];
+        Vec8<DT>::store(dst, i, v);
+    }
+}
+template <int DT>
+__global__ void nhwc8_to_nchw_kernel(const void* src, float* dst, int N, int C, int HW) {
+    const int64_t total = (int64_t)N * HW;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t n = i / HW, p = i - n * HW;
+        float v[8];
+        Vec8<DT>::load(src, i, v);
+        for (int c = 0; c < C; ++c) dst[(n * C + c) * HW + p] = v[c];
+    }
+}
+
+// ------------------------------------------------------------------ fused DF-GAN affine pair
+// block = (pixel range, image n); thread owns channel chunk cc = tid % C8 and strides over pixels
+template <int DT>
+__global__ void affine2_fwd_kernel(const void* x, const float* g0, const float* b0, const float* g1, const float* b1,
+                                   void* y, int HW, int C8, int pix_per_block) {
+    const int n = blockIdx.y, groups = NT / C8;
+    const int cc = threadIdx.x % C8, g = threadIdx.x / C8;
+    if (g >= groups) return;
+    float G0[8], B0[8], G1[8], B1[8];
+    const size_t pb = ((size_t)n * C8 + cc) * 8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { G0[k] = g0[pb + k]; B0[k] = b0[pb + k]; G1[k] = g1[pb + k]; B1[k] = b1[pb + k]; }
+    const int p_end = min(HW, (int)(blockIdx.x + 1) * pix_per_block);
+    for (int p = blockIdx.x * pix_per_block + g; p < p_end; p += groups) {
+        float v[8];
+        const size_t idx = ((size_t)n * HW + p) * C8 + cc;
+        Vec8<DT>::load(x, idx, v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = lrelu_f(lrelu_f(v[k] * G0[k] + B0[k]) * G1[k] + B1[k]);
+        Vec8<DT>::store(y, idx, v);
+    }
+}
+template <int DT>
+__global__ void affine2_bwd_kernel(const void* x, const void* dy, const float* g0, const float* b0, const float* g1,
+                                   const float* b1, void* dx, float* dg0, float* db0, float* dg1, float* db1,
+                                   int HW, int C8, int pix_per_block) {
+    const int n = blockIdx.y, groups = NT / C8;
+    const int cc = threadIdx.x % C8, g = threadIdx.x / C8;
+    float G0[8], B0[8], G1[8], B1[8];
+    float sg0[8], sb0[8], sg1[8], sb1[8];
+    const size_t pb = ((size_t)n * C8 + cc) * 8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        G0[k] = g0[pb + k]; B0[k] = b0[pb + k]; G1[k] = g1[pb + k]; B1[k] = b1[pb + k];
+        sg0[k] = sb0[k] = sg1[k] = sb1[k] = 0.f;
+    }
+    const int p_end = min(HW, (int)(blockIdx.x + 1) * pix_per_block);
+    if (g < groups)
+        for (int p = blockIdx.x * pix_per_block + g; p < p_end; p += groups) {
+            float xv[8], dv[8];
+            const size_t idx = ((size_t)n * HW + p) * C8 + cc;
+            Vec8<DT>::load(x, idx, xv);
+            Vec8<DT>::load(dy, idx, dv);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float u = xv[k] * G0[k] + B0[k];
+                float a1 = lrelu_f(u);
+                float v = a1 * G1[k] + B1[k];
+                float dvv = dv[k] * lrelu_slope(v);
+                sg1[k] += dvv * a1; sb1[k] += dvv;
+                float du = dvv * G1[k] * lrelu_slope(u);
+                sg0[k] += du * xv[k]; sb0[k] += du;
+                xv[k] = du * G0[k];
+            }
+            Vec8<DT>::store(dx, idx, xv);
+        }
+    // block reduction over the `groups` pixel lanes that share a channel chunk
+    __shared__ float red[NT * 8];
+    float* outs[4] = {dg0, db0, dg1, db1};
+    float* sums[4] = {sg0, sb0, sg1, sb1};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 8; ++k) red[threadIdx.x * 8 + k] = sums[q][k];
+        __syncthreads();
+        if (threadIdx.x < C8) {
+            float t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int gg = 0; gg < groups; ++gg)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) t[k] += red[(gg * C8 + threadIdx.x) * 8 + k];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) atomicAdd(&outs[q][((size_t)n * C8 + threadIdx.x) * 8 + k], t[k]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ hinge
+template <int DT>
+__global__ void hinge_fwd_kernel(const void* x, int stride, float sign, float* out, int64_t n) {
+    float s = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+        float v = DT == XMC_BF16 ? (float)reinterpret_cast<const __bf16*>(x)[i * stride] : reinterpret_cast<const float*>(x)[i * stride];
+        s += fmaxf(1.f + sign * v, 0.f);
+    }
+    s = wave_sum(s);
+    __shared__ float part[NT / 64];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < NT / 64; ++w) t += part[w];
+        *out = t / (float)n;
+    }
+}
+template <int DT>
+__global__ void hinge_bwd_kernel(const void* x, int stride, float sign, const float* dloss, void* dx, int64_t n) {
+    const float gscale = (*dloss) * sign / (float)n;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float v = DT == XMC_BF16 ? (float)reinterpret_cast<const __bf16*>(x)[i * stride] : reinterpret_cast<const float*>(x)[i * stride];
+        float gval = (1.f + sign * v) > 0.f ? gscale : 0.f;
+        if (DT == XMC_BF16) reinterpret_cast<__bf16*>(dx)[i * stride] = (__bf16)gval;
+        else reinterpret_cast<float*>(dx)[i * stride] = gval;
+    }
+}
+
+// ------------------------------------------------------------------ weight pack / unpack
+template <int DT>
+__global__ void pack_weight_kernel(const float* w, void* wpk, int Co, int Ci, int KHW, int rows_pad, int cols_pad,
+                                   int transpose, const int32_t* row_perm) {
+    const int64_t total = (int64_t)KHW * rows_pad * cols_pad;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int c = (int)(i % cols_pad);
+        int64_t q = i / cols_pad;
+        int r = (int)(q % rows_pad);
+        int t = (int)(q / rows_pad);
+        int co = transpose ? c : r, ci = transpose ? r : c;
+        float v = 0.f;
+        if (co < Co && ci < Ci) {
+            int sco = row_perm ? row_perm[co] : co;
+            v = w[((int64_t)sco * Ci + ci) * KHW + t];
+        }
+        if (DT == XMC_BF16) reinterpret_cast<__bf16*>(wpk)[i] = (__bf16)v;
+        else reinterpret_cast<float*>(wpk)[i] = v;
+    }
+}
+__global__ void unpack_wgrad_kernel(const float* dwp, float* gw, int Co, int Ci, int KHW, int rows_pad, int cols_pad,
+                                    const float* scale_dev, const int32_t* row_perm, int accumulate) {
+    const float scale = scale_dev ? *scale_dev : 1.f;
+    const int64_t total = (int64_t)Co * Ci * KHW;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int t = (int)(i % KHW);
+        int64_t q = i / KHW;
+        int ci = (int)(q % Ci);
+        int r = (int)(q / Ci);              // packed row r holds parameter row row_perm[r]
+        float v = scale * dwp[((int64_t)t * rows_pad + r) * cols_pad + ci];
+        int dco = row_perm ? row_perm[r] : r;
+        int64_t o = ((int64_t)dco * Ci + ci) * KHW + t;
+        gw[o] = accumulate ? gw[o] + v : v;
+    }
+}
+
+}  // namespace
+
+#define ST(s) reinterpret_cast<hipStream_t>(s)
+
+extern "C" int xmc_abi_version(void) { return XMC_ABI_VERSION; }
+
+extern "C" int xmc_lrelu(const void* x, void* y, int64_t n, float slope, int dtype, void* s) { return run_map1(x, y, n, dtype, ST(s), FLrelu{slope}); }
+extern "C" int xmc_tanh(const void* x, void* y, int64_t n, int dtype, void* s) { return run_map1(x, y, n, dtype, ST(s), FTanh{}); }
+extern "C" int xmc_lrelu_mask(const void* dy, const void* ref, void* dx, int64_t n, float slope, int dtype, void* s) {
+    return run_map2(dy, ref, dx, n, dtype, ST(s), FLreluMask{slope});
+}
+extern "C" int xmc_tanh_bwd(const void* dy, const void* y, void* dx, int64_t n, int dtype, void* s) {
+    return run_map2(dy, y, dx, n, dtype, ST(s), FTanhBwd{});
+}
+extern "C" int xmc_axpby(const void* a, const void* b, const float* alpha, void* y, int64_t n, int dtype, void* s) {
+    if (!alpha) return XMC_EINVAL;
+    return run_map2(a, b, y, n, dtype, ST(s), FAxpby{alpha});
+}
+extern "C" int xmc_scale(const void* x, const float* alpha, void* y, int64_t n, int dtype, void* s) {
+    if (!alpha) return XMC_EINVAL;
+    return run_map1(x, y, n, dtype, ST(s), FScale{alpha});
+}
+extern "C" int xmc_cast(const void* x, void* y, int64_t n, int src_dtype, int dst_dtype, void* s) {
+    if (n % 8) return XMC_EALIGN;
+    if (n == 0) return 0;
+    int64_t n8 = n / 8;
+    dim3 g(nblocks(n8)), b(NT);
+    if (src_dtype == XMC_F32 && dst_dtype == XMC_BF16) hipLaunchKernelGGL((cast_kernel<XMC_F32, XMC_BF16>), g, b, 0, ST(s), x, y, n8);
+    else if (src_dtype == XMC_BF16 && dst_dtype == XMC_F32) hipLaunchKernelGGL((cast_kernel<XMC_BF16, XMC_F32>), g, b, 0, ST(s), x, y, n8);
+    else if (src_dtype == XMC_F32 && dst_dtype == XMC_F32) hipLaunchKernelGGL((cast_kernel<XMC_F32, XMC_F32>), g, b, 0, ST(s), x, y, n8);
+    else if (src_dtype == XMC_BF16 && dst_dtype == XMC_BF16) hipLaunchKernelGGL((cast_kernel<XMC_BF16, XMC_BF16>), g, b, 0, ST(s), x, y, n8);
+    else return XMC_EINVAL;
+    XMC_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int xmc_dot(const void* a, const void* b, float* out, int64_t n, int dtype, void* s) {
+    if (n % 8) return XMC_EALIGN;
+    int64_t n8 = n / 8;
+    dim3 g(nblocks(n8, NT, 512)), blk(NT);
+    if (dtype == XMC_BF16) hipLaunchKernelGGL((dot_kernel<XMC_BF16>), g, blk, 0, ST(s), a, b, out, n8);
+    else if (dtype == XMC_F32) hipLaunchKernelGGL((dot_kernel<XMC_F32>), g, blk, 0, ST(s), a, b, out, n8);
+    else return XMC_EINVAL;
+    XMC_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int xmc_colsum(const void* x, float* out, int64_t rows, int C, int dtype, void* s) {
+    if (C % 8 || C / 8 > NT) return XMC_EALIGN;
+    const int C8 = C / 8, groups = NT / C8;
+    dim3 g(nblocks(rows, groups * 8, 1024)), blk(NT);
+    if (dtype == XMC_BF16) hipLaunchKernelGGL((colsum_kernel<XMC_BF16>), g, blk, 0, ST(s), x, out, rows, C8);
+    else if (dtype == XMC_F32) hipLaunchKernelGGL((colsum_kernel<XMC_F32>), g, blk, 0, ST(s), x, out, rows, C8);
+    else return XMC_EINVAL;
+    XMC_LAUNCH_CHECK();
+    return 0;
+}
+static int pool2(const void* x, void* y, int N, int H, int W, int C, float scale, int dtype, void* s) {
+    if (C % 8 || H % 2 || W % 2) return XMC_EALIGN;
+    int64_t total = (int64_t)N * (H / 2) * (W / 2) * (C / 8);
+    dim3 g(nblocks(total)), blk(NT);
+    if (dtype == XMC_BF16) hipLaunchKernelGGL((pool2_kernel<XMC_BF16>), g, blk, 0, ST(s), x, y, N, H, W, C / 8, scale);
+    else if (dtype == XMC_F32) hipLaunchKernelGGL((pool2_kernel<XMC_F32>), g, blk, 0, ST(s), x, y, N, H, W, C / 8, scale);
+    else return XMC_EINVAL;
+    XMC_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int xmc_avgpool2(const void* x, void* y, int N, int H, int W, int C, int dtype, void* s) {
+    return pool2(x, y, N, H, W, C, 0.25f, dtype, s);
+}
+extern "C" int xmc_sumpool2(const void* x, void* y, int N, int H, int W, int C, float scale, int dtype, void* s) {
+    return pool2(x, y, N, H, W, C, scale, dtype, s);
+}
+extern "C" int xmc_upsample2(const void* x, void* y, int N, int H, int W, int C, float scale, int dtype, void* s) {
+    if (C % 8) return XMC_EALIGN;
+    int64_t total = (int64_t)N * H * 2 * W * 2 * (C / 8);
+    dim3 g(nblocks(total)), blk(NT);
+    if (dtype == XMC_BF16) hipLaunchKernelGGL((up2_kernel<XMC_BF16>), g, blk, 0, ST(s), x, y, N, H, W, C / 8, scale);
+    else if (dtype == XMC_F32) hipLaunchKernelGGL((up2_kernel<XMC_F32>), g, blk, 0, ST(s), x, y, N, H, W, C / 8, scale);
+    else return XMC_EINVAL;
+    XMC_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int xmc_global_avgpool(const void* x, void* y, int N, int HW, int C, int dtype, int out_dtype, void* s) {
+    if (C % 8) return XMC_EALIGN;
+    dim3 g(nblocks((int64_t)N * (C / 8))), blk(NT);
+    if (dtype == XMC_BF16 && out_dtype == XMC_F32) hipLaunchKernelGGL((gap_kernel<XMC_BF16, XMC_F32>), g, blk, 0, ST(s), x, y, N, HW, C / 8);
+    else if (dtype == XMC_BF16 && out_dtype == XMC_BF16) hipLaunchKernelGGL((gap_kernel<XMC_BF16, XMC_BF16>), g, blk, 0, ST(s), x, y, N, HW, C / 8);
+    else if (dtype == XMC_F32 && out_dtype == XMC_F32) hipLaunchKernelGGL((gap_kernel<XMC_F32, XMC_F32>), g, blk, 0, ST(s), x, y, N, HW, C / 8);
+    else return XMC_EINVAL;
+    XMC_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int xmc_global_avgpool_bwd(const void* dy, void* dx, int N, int HW, int C, int dtype, int in_dtype, void* s) {
+    if (C % 8) return XMC_EALIGN;
+    dim3 g(nblocks((int64_t)N * HW * (C / 8))), blk(NT);
+    if (dtype == XMC_BF16 && in_dtype == XMC_F32) hipLaunchKernelGGL((gap_bwd_kernel<XMC_BF16, XMC_F32>), g, blk, 0, ST(s), dy, dx, N, HW, C / 8);
+    else if (dtype == XMC_BF16 && in_dtype == XMC_BF16) hipLaunchKernelGGL((gap_bwd_kernel<XMC_BF16, XMC_BF16>), g, blk, 0, ST(s), dy, dx, N, HW, C / 8);
+    else if (dtype == XMC_F32 && in_dtype == XMC_F32) hipLaunchKernelGGL((gap_bwd_kernel<XMC_F32, XMC_F32>), g, blk, 0, ST(s), dy, dx, N, HW, C / 8);
+    else return XMC_EINVAL;
+    XMC_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int xmc_nchw_to_nhwc8(const float* src, void* dst, int N, int C, int H, int W, int dtype, void* s) {
+    if (C < 1 || C > 8) return XMC_ESHAPE;
+    dim3 g(nblocks((int64_t)N * H * W)), blk(NT);
+    if (dtype == XMC_BF16) hipLaunchKernelGGL((nchw_to_nhwc8_kernel<XMC_BF16>), g, blk, 0, ST(s), src, dst, N, C, H * W);
+    else if (dtype == XMC_F32) hipLaunchKernelGGL((nchw_to_nhwc8_kernel<XMC_F32>), g, blk, 0, ST(s), src, dst, N, C, H * W);
+    else return XMC_EINVAL;
+    XMC_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int xmc_nhwc8_to_nchw(const void* src, float* dst, int N, int C, int H, int W, int dtype, void* s) {
+    if (C < 1 || C > 8) return XMC_ESHAPE;
+    dim3 g(nblocks((int64_t)N * H * W)), blk(NT);
+    if (dtype == XMC_BF16) hipLaunchKernelGGL((nhwc8_to_nchw_kernel<XMC_BF16>), g, blk, 0, ST(s), src, dst, N, C, H * W);
+    else if (dtype == XMC_F32) hipLaunchKernelGGL((nhwc8_to_nchw_kernel<XMC_F32>), g, blk, 0, ST(s), src, dst, N, C, H * W);
+    else return XMC_EINVAL;
+    XMC_LAUNCH_CHECK();
+    return 0;
+}
+
+static inline int affine_grid(int HW, int C8, int N, dim3& g, int& ppb) {
+    const int groups = NT / C8;
+    int per = groups * 16;                       // >= 16 pixels per thread-lane
+    int bx = (HW + per - 1) / per;
+    if (bx < 1) bx = 1;
+    ppb = (HW + bx - 1) / bx;
+    g = dim3(bx, N);
+    return 0;
+}
+extern "C" int xmc_affine2_lrelu_fwd(const void* x, const float* g0, const float* b0, const float* g1, const float* b1,
+                                     void* y, int N, int HW, int C, int dtype, void* s) {
+    if (C % 8 || C / 8 > NT) return XMC_EALIGN;
+    dim3 g; int ppb;
+    affine_grid(HW, C / 8, N, g, ppb);
+    if (dtype == XMC_BF16) hipLaunchKernelGGL((affine2_fwd_kernel<XMC_BF16>), g, dim3(NT), 0, ST(s), x, g0, b0, g1, b1, y, HW, C / 8, ppb);
+    else if (dtype == XMC_F32) hipLaunchKernelGGL((affine2_fwd_kernel<XMC_F32>), g, dim3(NT), 0, ST(s), x, g0, b0, g1, b1, y, HW, C / 8, ppb);
+    else return XMC_EINVAL;
+    XMC_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int xmc_affine2_lrelu_bwd(const void* x, const void* dy, const float* g0, const float* b0, const float* g1,
+                                     const float* b1, void* dx, float* dg0, float* db0, float* dg1, float* db1,
+                                     int N, int HW, int C, int dtype, void* s) {
+    if (C % 8 || C / 8 > NT) return XMC_EALIGN;
+    dim3 g; int ppb;
+    affine_grid(HW, C / 8, N, g, ppb);
+    if (dtype == XMC_BF16)
+        hipLaunchKernelGGL((affine2_bwd_kernel<XMC_BF16>), g, dim3(NT), 0, ST(s), x, dy, g0, b0, g1, b1, dx, dg0, db0, dg1, db1, HW, C / 8, ppb);
+    else if (dtype == XMC_F32)
+        hipLaunchKernelGGL((affine2_bwd_kernel<XMC_F32>), g, dim3(NT), 0, ST(s), x, dy, g0, b0, g1, b1, dx, dg0, db0, dg1, db1, HW, C / 8, ppb);
+    else return XMC_EINVAL;
+    XMC_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int xmc_hinge_fwd(const void* x, int stride, float sign, float* out, int64_t n, int dtype, void* s) {
+    if (n < 1 || stride < 1) return XMC_ESHAPE;
+    if (dtype == XMC_BF16) hipLaunchKernelGGL((hinge_fwd_kernel<XMC_BF16>), dim3(1), dim3(NT), 0, ST(s), x, stride, sign, out, n);
+    else if (dtype == XMC_F32) hipLaunchKernelGGL((hinge_fwd_kernel<XMC_F32>), dim3(1), dim3(NT), 0, ST(s), x, stride, sign, out, n);
+    else return XMC_EINVAL;
+    XMC_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int xmc_hinge_bwd(const void* x, int stride, float sign, const float* dloss, void* dx, int64_t n, int dtype, void* s) {
+    if (n < 1 || stride < 1) return XMC_ESHAPE;
+    dim3 g(nblocks(n)), blk(NT);
+    if (dtype == XMC_BF16) hipLaunchKernelGGL((hinge_bwd_kernel<XMC_BF16>), g, blk, 0, ST(s), x, stride, sign, dloss, dx, n);
+    else if (dtype == XMC_F32) hipLaunchKernelGGL((hinge_bwd_kernel<XMC_F32>), g, blk, 0, ST(s), x, stride, sign, dloss, dx, n);
+    else return XMC_EINVAL;
+    XMC_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int xmc_pack_weight(const float* w, void* wpk, int Co, int Ci, int KH, int KW, int rows_pad, int cols_pad,
+                               int transpose, int dtype, const int32_t* row_perm, void* s) {
+    if (!w || !wpk) return XMC_EINVAL;
+    if (transpose ? (rows_pad < Ci || cols_pad < Co) : (rows_pad < Co || cols_pad < Ci)) return XMC_ESHAPE;
+    int64_t total = (int64_t)KH * KW * rows_pad * cols_pad;
+    dim3 g(nblocks(total)), blk(NT);
+    if (dtype == XMC_BF16)
+        hipLaunchKernelGGL((pack_weight_kernel<XMC_BF16>), g, blk, 0, ST(s), w, wpk, Co, Ci, KH * KW, rows_pad, cols_pad, transpose, row_perm);
+    else if (dtype == XMC_F32)
+        hipLaunchKernelGGL((pack_weight_kernel<XMC_F32>), g, blk, 0, ST(s), w, wpk, Co, Ci, KH * KW, rows_pad, cols_pad, transpose, row_perm);
+    else return XMC_EINVAL;
+    XMC_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int xmc_unpack_wgrad(const float* dwp, float* gw, int Co, int Ci, int KH, int KW, int rows_pad, int cols_pad,
+                                const float* scale_dev, const int32_t* row_perm, int accumulate, void* s) {
+    if (!dwp || !gw || rows_pad < Co || cols_pad < Ci) return XMC_EINVAL;
+    int64_t total = (int64_t)Co * Ci * KH * KW;
+    hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(nblocks(total)), dim3(NT), 0, ST(s), dwp, gw, Co, Ci, KH * KW, rows_pad, cols_pad,
+                       scale_dev, row_perm, accumulate);
+    XMC_LAUNCH_CHECK();
+    return 0;
+}
