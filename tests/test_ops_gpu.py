@@ -1,0 +1,302 @@
+"""GPU parity tests of the individual HIP operators (through the C ABI) against plain PyTorch CPU math.
+
+fp32 mode: f32 MFMA path, tolerance ~1e-4 (exact f32 products, different summation order).
+bf16 mode: operands are pre-rounded to bf16 so the only differences are the f32-accumulate order and
+the bf16 rounding of stored outputs (tolerance 2^-8 relative to the output scale).
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from xmc_gan_amd import ops
+    from xmc_gan_amd import lib as L
+    import xmc_ref as X
+
+DEV = "cuda"
+MODES = ["fp32", "bf16"]
+
+
+def rt(t, mode):
+    """round-trip through the activation dtype (so CPU reference and kernel see identical operands)."""
+    return t.to(torch.bfloat16).float() if mode == "bf16" else t
+
+
+def tol(mode, scale=1.0):
+    return dict(rtol=2e-2, atol=2e-2 * scale) if mode == "bf16" else dict(rtol=2e-4, atol=2e-4 * scale)
+
+
+def to_nhwc(x, cpad, dtype):
+    """CPU NCHW f32 -> device NHWC padded to cpad channels."""
+    N, C, H, W = x.shape
+    y = torch.zeros(N, H, W, cpad)
+    y[..., :C] = x.permute(0, 2, 3, 1)
+    return y.to(DEV, dtype).contiguous()
+
+
+def from_nhwc(y, C):
+    return y.float().cpu()[..., :C].permute(0, 3, 1, 2).contiguous()
+
+
+CONV_CASES = [
+    # cin, cout, k, s, p, H, N
+    (3, 32, 3, 1, 1, 16, 2),       # conv_img (Cin padded 3->8: four taps per K sub-step)
+    (32, 64, 4, 2, 1, 16, 3),      # resD conv_r.0
+    (64, 64, 3, 1, 1, 8, 2),       # resD conv_r.2 / G c2
+    (32, 3, 3, 1, 1, 8, 2),        # conv_out (Cout padded 3->8)
+    (96, 16, 3, 1, 1, 4, 5),       # joint_conv.0 style (odd tile tails: M=80)
+    (16, 1, 4, 1, 0, 4, 6),        # joint_conv.2 (4x4 valid -> 1x1)
+    (64, 128, 1, 1, 0, 8, 2),      # 1x1 shortcut, BN=128 tile
+    (256, 256, 3, 1, 1, 4, 9),     # deep K, 128x128 tiles, M=144 (tail)
+    (8, 8, 3, 1, 1, 32, 1),        # NCH=8 sized layer
+]
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(case, mode):
+    cin, cout, k, s, p, H, N = case
+    ops.set_precision(mode)
+    dt = ops.act_dtype()
+    g = torch.Generator().manual_seed(hash(case) & 0xFFFF)
+    x = rt(torch.randn(N, cin, H, H, generator=g), mode)
+    w = rt(torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k), mode)
+    b = torch.randn(cout, generator=g) * 0.1
+    xr, wr, br = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    yr = F.leaky_relu(F.conv2d(xr, wr, br, s, p), 0.2)
+    r = rt(torch.randn(yr.shape, generator=g), mode)
+    (yr * r).sum().backward()
+
+    geom = ops.ConvGeom(cin, cout, k, s, p)
+    xd = to_nhwc(x, ops.chan_pad(cin, dt), dt).requires_grad_()
+    wd = torch.nn.Parameter(w.to(DEV))
+    bd = torch.nn.Parameter(b.to(DEV))
+    y = ops.conv2d(xd, wd, bd, geom, act=L.ACT_LRELU)
+    assert y.shape == (N, yr.shape[2], yr.shape[3], ops.pad_to(cout, 8))
+    sc = yr.abs().max().item()
+    torch.testing.assert_close(from_nhwc(y, cout), yr.detach(), **tol(mode, sc))
+    if ops.pad_to(cout, 8) != cout:
+        assert y[..., cout:].abs().max().item() == 0.0
+    rd = to_nhwc(r, ops.pad_to(cout, 8), dt)
+    (y.float() * rd.float()).sum().backward()
+    torch.testing.assert_close(from_nhwc(xd.grad, cin), xr.grad, **tol(mode, xr.grad.abs().max().item()))
+    torch.testing.assert_close(wd.grad.cpu(), wr.grad, **tol(mode, wr.grad.abs().max().item()))
+    torch.testing.assert_close(bd.grad.cpu(), br.grad, **tol(mode, br.grad.abs().max().item()))
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_linear_row_perm_and_mixed_dtype(mode):
+    """proj_noise: f32 [B,100] -> NHWC [B,4,4,C] in the activation dtype via a row permutation."""
+    ops.set_precision(mode)
+    from xmc_gan.model.df_gan import nhwc_feature_perm
+    g = torch.Generator().manual_seed(3)
+    B, K, Cc = 5, 100, 16
+    x = torch.randn(B, K, generator=g)
+    w = torch.randn(Cc * 16, K, generator=g) / 10
+    b = torch.randn(Cc * 16, generator=g)
+    xr, wr, br = x.clone(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    yr = F.linear(xr, wr, br).view(B, Cc, 4, 4)
+    r = torch.randn(yr.shape, generator=g)
+    (yr * r).sum().backward()
+    geom = ops.ConvGeom(K, Cc * 16, 1, 1, 0, row_perm=nhwc_feature_perm(Cc))
+    wd, bd = torch.nn.Parameter(w.to(DEV)), torch.nn.Parameter(b.to(DEV))
+    y = ops.linear(x.to(DEV), wd, bd, geom, out_dtype=ops.act_dtype()).view(B, 4, 4, Cc)
+    torch.testing.assert_close(from_nhwc(y, Cc), yr.detach(), **tol(mode, yr.abs().max().item()))
+    (y.float() * to_nhwc(r, Cc, torch.float32)).sum().backward()
+    t = tol("fp32" if mode == "fp32" else "bf16", wr.grad.abs().max().item())
+    torch.testing.assert_close(wd.grad.cpu(), wr.grad, **t)
+    torch.testing.assert_close(bd.grad.cpu(), br.grad, **tol(mode, br.grad.abs().max().item()))
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_double_backward_gradient_penalty(mode):
+    """grad-of-grad through conv(4x4,s2)+lrelu -> conv(3x3)+lrelu -> avgpool -> 1x1: the MA-GP pattern
+    (train_gan.py:231-252) on a miniature discriminator."""
+    ops.set_precision(mode)
+    dt = ops.act_dtype()
+    g = torch.Generator().manual_seed(11)
+    N, H = 3, 8
+    x = rt(torch.randn(N, 8, H, H, generator=g), mode)
+    w1 = rt(torch.randn(16, 8, 4, 4, generator=g) / 10, mode)
+    w2 = rt(torch.randn(16, 16, 3, 3, generator=g) / 10, mode)
+    w3 = rt(torch.randn(8, 16, 1, 1, generator=g) / 4, mode)
+    gam = torch.tensor([0.7])
+
+    def ref():
+        xr = x.clone().requires_grad_()
+        ws = [w.clone().requires_grad_() for w in (w1, w2, w3)]
+        gm = gam.clone().requires_grad_()
+        hdn = F.leaky_relu(F.conv2d(xr, ws[0], None, 2, 1), 0.2)
+        h2 = F.leaky_relu(F.conv2d(hdn, ws[1], None, 1, 1), 0.2)
+        out = F.conv2d(F.avg_pool2d(hdn + gm * h2, 2), ws[2])
+        (gx,) = torch.autograd.grad(out.sum(), xr, create_graph=True)
+        pen = (gx.reshape(N, -1).pow(2).sum(1).sqrt() ** 6).mean()
+        grads = torch.autograd.grad(pen, ws + [gm])
+        return pen.item(), gx.detach(), grads
+
+    pen_r, gx_r, grads_r = ref()
+    xd = to_nhwc(x, 8, dt).requires_grad_()
+    ps = [torch.nn.Parameter(w.to(DEV)) for w in (w1, w2, w3)]
+    gm = torch.nn.Parameter(gam.to(DEV))
+    geoms = [ops.ConvGeom(8, 16, 4, 2, 1), ops.ConvGeom(16, 16, 3, 1, 1), ops.ConvGeom(16, 8, 1, 1, 0)]
+    hdn = ops.conv2d(xd, ps[0], None, geoms[0], act=L.ACT_LRELU)
+    h2 = ops.conv2d(hdn, ps[1], None, geoms[1], act=L.ACT_LRELU)
+    out = ops.conv2d(ops.avgpool2(ops.axpby(hdn, h2, gm)), ps[2], None, geoms[2])
+    with ops.no_wgrad():
+        (gx,) = torch.autograd.grad(out, xd, torch.ones_like(out), create_graph=True)
+    pen = (gx.float().reshape(N, -1).pow(2).sum(1).sqrt() ** 6).mean()
+    grads = torch.autograd.grad(pen, ps + [gm])
+    torch.testing.assert_close(from_nhwc(gx.detach(), 8), gx_r, **tol(mode, gx_r.abs().max().item()))
+    assert abs(pen.item() - pen_r) <= (5e-2 if mode == "bf16" else 1e-3) * abs(pen_r)
+    for a, b in zip(grads, grads_r):
+        t = tol(mode, b.abs().max().item())
+        if mode == "bf16":
+            t = dict(rtol=6e-2, atol=6e-2 * b.abs().max().item())
+        torch.testing.assert_close(a.cpu().reshape(b.shape), b, **t)
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_affine2_lrelu(mode):
+    ops.set_precision(mode)
+    dt = ops.act_dtype()
+    g = torch.Generator().manual_seed(5)
+    N, Cc, H = 3, 24, 6
+    x = rt(torch.randn(N, Cc, H, H, generator=g), mode)
+    ps = [torch.randn(N, Cc, generator=g) for _ in range(4)]
+    xr = x.clone().requires_grad_()
+    pr = [p.clone().requires_grad_() for p in ps]
+    e = lambda t: t[:, :, None, None]
+    yr = F.leaky_relu(F.leaky_relu(xr * e(pr[0]) + e(pr[1]), 0.2) * e(pr[2]) + e(pr[3]), 0.2)
+    r = rt(torch.randn(yr.shape, generator=g), mode)
+    (yr * r).sum().backward()
+    xd = to_nhwc(x, Cc, dt).requires_grad_()
+    pd = [p.to(DEV).requires_grad_() for p in ps]
+    y = ops.affine2_lrelu(xd, *pd)
+    torch.testing.assert_close(from_nhwc(y, Cc), yr.detach(), **tol(mode, yr.abs().max().item()))
+    (y.float() * to_nhwc(r, Cc, torch.float32)).sum().backward()
+    torch.testing.assert_close(from_nhwc(xd.grad, Cc), xr.grad, **tol(mode, xr.grad.abs().max().item()))
+    for a, b in zip(pd, pr):
+        torch.testing.assert_close(a.grad.cpu(), b.grad, **tol(mode, b.grad.abs().max().item()))
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_pool_resample_convert(mode):
+    ops.set_precision(mode)
+    dt = ops.act_dtype()
+    g = torch.Generator().manual_seed(6)
+    x = rt(torch.randn(2, 16, 8, 8, generator=g), mode)
+    xd = to_nhwc(x, 16, dt).requires_grad_()
+    xr = x.clone().requires_grad_()
+    # avgpool2 / upsample2 / global pool, forward and backward
+    for fn_d, fn_r in ((ops.avgpool2, lambda t: F.avg_pool2d(t, 2)),
+                       (ops.upsample2, lambda t: F.interpolate(t, scale_factor=2)),
+                       (lambda t: ops.lrelu(t), lambda t: F.leaky_relu(t, 0.2))):
+        xd.grad = None; xr.grad = None
+        yd, yr = fn_d(xd), fn_r(xr)
+        torch.testing.assert_close(from_nhwc(yd, 16), yr.detach(), **tol(mode, 3.0))
+        r = rt(torch.randn(yr.shape, generator=g), mode)
+        (yd.float() * to_nhwc(r, 16, torch.float32)).sum().backward()
+        (yr * r).sum().backward()
+        torch.testing.assert_close(from_nhwc(xd.grad, 16), xr.grad, **tol(mode, 3.0))
+    xd.grad = None; xr.grad = None
+    x4 = xd[:, :4, :4, :].contiguous()
+    yd = ops.global_avgpool(x4)
+    yr = F.avg_pool2d(xr[:, :, :4, :4], 4).view(2, 16)
+    torch.testing.assert_close(yd.cpu(), yr.detach(), **tol(mode))
+    r = torch.randn(2, 16, generator=g)
+    (yd * r.to(DEV)).sum().backward(); (yr * r).sum().backward()
+    torch.testing.assert_close(from_nhwc(xd.grad, 16), xr.grad, **tol(mode))
+    # image boundary converters
+    img = torch.rand(3, 3, 8, 8, generator=g) * 2 - 1
+    imd = img.to(DEV).requires_grad_()
+    z = ops.to_nhwc8(imd)
+    assert z.shape == (3, 8, 8, 8) and z[..., 3:].abs().max().item() == 0
+    back = ops.to_nchw(z, 3)
+    torch.testing.assert_close(back.cpu(), rt(img, mode), rtol=0, atol=0)
+    back.backward(torch.ones_like(back))
+    torch.testing.assert_close(imd.grad.cpu(), torch.ones_like(img), rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_axpby_scale_dot_hinge(mode):
+    ops.set_precision(mode)
+    dt = ops.act_dtype()
+    g = torch.Generator().manual_seed(8)
+    a = rt(torch.randn(2, 4, 4, 16, generator=g), mode)
+    b = rt(torch.randn(2, 4, 4, 16, generator=g), mode)
+    al = torch.tensor([0.37])
+    ar, br_, alr = a.clone().requires_grad_(), b.clone().requires_grad_(), al.clone().requires_grad_()
+    yr = ar + alr * br_
+    r = rt(torch.randn(yr.shape, generator=g), mode)
+    (yr * r).sum().backward()
+    ad, bd = a.to(DEV, dt).requires_grad_(), b.to(DEV, dt).requires_grad_()
+    ald = torch.nn.Parameter(al.to(DEV))
+    y = ops.axpby(ad, bd, ald)
+    torch.testing.assert_close(y.float().cpu(), yr.detach(), **tol(mode, 3.0))
+    (y.float() * r.to(DEV)).sum().backward()
+    torch.testing.assert_close(ad.grad.float().cpu(), ar.grad, **tol(mode, 3.0))
+    torch.testing.assert_close(bd.grad.float().cpu(), br_.grad, **tol(mode, 3.0))
+    torch.testing.assert_close(ald.grad.cpu(), alr.grad, **tol(mode, 30.0))
+    # hinge on channel 0 of a padded logit tensor, read through a strided view
+    lg = rt(torch.randn(7, 1, 1, 8, generator=g), mode)
+    lgd = lg.to(DEV, dt).requires_grad_()
+    view = lgd[..., :1].permute(0, 3, 1, 2)
+    for sign in (-1.0, 1.0):
+        lgd.grad = None
+        lr_ = lg[..., 0].clone().requires_grad_()
+        ref = F.relu(1.0 + sign * lr_).mean()
+        ref.backward()
+        out = ops.hinge(view, sign)
+        assert abs(out.item() - ref.item()) < 1e-5
+        out.backward()
+        torch.testing.assert_close(lgd.grad.float().cpu()[..., 0], lr_.grad, **tol(mode))
+        assert lgd.grad[..., 1:].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("n,D", [(8, 256), (5, 48), (64, 512), (200, 256)])
+@pytest.mark.parametrize("labels_kind", ["identity", "global_adaptive", "global_smooth"])
+def test_contrastive_head(n, D, labels_kind):
+    """fused cosine-similarity + symmetric InfoNCE vs the oracle (train_gan.py:85-139); f32, logits/loss 1e-3 rel."""
+    g = torch.Generator().manual_seed(n * 7 + D)
+    a = torch.randn(n, D, generator=g)
+    b = a * 0.7 + torch.randn(n, D, generator=g)
+    sent = torch.randn(max(n // 4, 1), D, generator=g).repeat(4, 1)[:n]
+    sent = torch.cat([sent, torch.randn(n - sent.size(0), D, generator=g)]) + 0.3 * torch.randn(n, D, generator=g)
+    if labels_kind == "identity":
+        labels, bg, sg = X.make_labels(n, sent, False), False, 0.0
+    elif labels_kind == "global_adaptive":
+        labels, bg, sg = X.make_labels(n, sent, True, 0.0), True, 0.0
+    else:
+        labels, bg, sg = X.make_labels(n, sent, True, 0.5), True, 0.5
+    ar, br_ = a.clone().requires_grad_(), b.clone().requires_grad_()
+    ref = X.contrastive_loss(ar, br_, labels, bg, sg)
+    ref.backward()
+    if not bg:
+        inv_np = None
+    elif sg == 0.0:
+        inv_np = torch.full((n,), 0.5)
+    else:
+        inv_np = 1.0 / (labels > 0).sum(1).float()
+    ad, bd = a.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
+    lab_d = None if labels_kind == "identity" else labels.to(DEV).contiguous()
+    out = ops.contrastive(ad, bd, lab_d, None if inv_np is None else inv_np.to(DEV))
+    assert abs(out.item() - ref.item()) <= 1e-4 * abs(ref.item()) + 1e-5
+    (out * 1.7).backward()
+    torch.testing.assert_close(ad.grad.cpu(), 1.7 * ar.grad, rtol=2e-3, atol=2e-6)
+    torch.testing.assert_close(bd.grad.cpu(), 1.7 * br_.grad, rtol=2e-3, atol=2e-6)
+    # explicit identity labels must give the same result as the labels=None fast path
+    if labels_kind == "identity":
+        out2 = ops.contrastive(ad.detach(), bd.detach(), labels.to(DEV).contiguous(), None)
+        assert abs(out2.item() - out.item()) < 1e-5 * abs(out.item())
+
+
+def test_rejects_cpu_tensors_and_bad_shapes():
+    with pytest.raises(RuntimeError):
+        ops.conv2d(torch.zeros(1, 4, 4, 8), torch.nn.Parameter(torch.zeros(8, 8, 3, 3)), None, ops.ConvGeom(8, 8, 3, 1, 1))
+    d = L.ConvDesc()
+    import ctypes as C
+    assert L.load().xmc_conv_igemm(C.byref(d), None) < 0          # null pointers -> XMC_EINVAL, nothing launched

@@ -1,0 +1,107 @@
+"""ctypes binding of libxmc_gan_hip.so (C ABI: include/xmc_gan_hip.h).
+
+The library is the product's only compute path.  Loading fails loudly (RuntimeError) when the
+shared object has not been built -- there is no PyTorch/CPU fallback.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libxmc_gan_hip.so")
+
+BF16, F32 = 0, 1
+ACT_NONE, ACT_LRELU, ACT_TANH, ACT_RELU = 0, 1, 2, 3
+MAX_TAPS, MAX_CLASSES = 16, 4
+
+vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("src", vp), ("wpk", vp), ("dst", vp), ("bias", vp), ("res", vp), ("alpha_dev", vp),
+                ("N", i32), ("SH", i32), ("SW", i32), ("CS", i32),
+                ("DH", i32), ("DW", i32), ("CD", i32),
+                ("MH", i32), ("MW", i32), ("SA", i32), ("DA", i32), ("src_shift", i32),
+                ("ntaps", i32), ("nclass", i32), ("CDw", i32), ("act", i32), ("dtype", i32), ("out_dtype", i32),
+                ("dh", (C.c_int8 * MAX_TAPS) * MAX_CLASSES), ("dw", (C.c_int8 * MAX_TAPS) * MAX_CLASSES),
+                ("wi", (C.c_int8 * MAX_TAPS) * MAX_CLASSES),
+                ("dph", C.c_int8 * MAX_CLASSES), ("dpw", C.c_int8 * MAX_CLASSES)]
+
+
+class AdamEntry(C.Structure):
+    _fields_ = [("param", vp), ("grad", vp), ("m", vp), ("v", vp), ("step", vp), ("n", i64)]
+
+
+# name -> argtypes  (restype is int unless listed in _RESTYPE)
+_SIGS = {
+    "xmc_abi_version": [],
+    "xmc_conv_igemm": [C.POINTER(ConvDesc), vp],
+    "xmc_conv_wgrad": [C.POINTER(ConvDesc), vp, vp],
+    "xmc_pack_weight": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp],
+    "xmc_unpack_wgrad": [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp],
+    "xmc_nchw_to_nhwc8": [vp, vp, i32, i32, i32, i32, i32, vp],
+    "xmc_nhwc8_to_nchw": [vp, vp, i32, i32, i32, i32, i32, vp],
+    "xmc_lrelu": [vp, vp, i64, f32, i32, vp],
+    "xmc_lrelu_mask": [vp, vp, vp, i64, f32, i32, vp],
+    "xmc_tanh": [vp, vp, i64, i32, vp],
+    "xmc_tanh_bwd": [vp, vp, vp, i64, i32, vp],
+    "xmc_axpby": [vp, vp, vp, vp, i64, i32, vp],
+    "xmc_scale": [vp, vp, vp, i64, i32, vp],
+    "xmc_dot": [vp, vp, vp, i64, i32, vp],
+    "xmc_colsum": [vp, vp, i64, i32, i32, vp],
+    "xmc_avgpool2": [vp, vp, i32, i32, i32, i32, i32, vp],
+    "xmc_upsample2": [vp, vp, i32, i32, i32, i32, f32, i32, vp],
+    "xmc_sumpool2": [vp, vp, i32, i32, i32, i32, f32, i32, vp],
+    "xmc_global_avgpool": [vp, vp, i32, i32, i32, i32, i32, vp],
+    "xmc_global_avgpool_bwd": [vp, vp, i32, i32, i32, i32, i32, vp],
+    "xmc_affine2_lrelu_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    "xmc_affine2_lrelu_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    "xmc_contrastive_ws_bytes": [i32, i32],
+    "xmc_contrastive_fwd": [vp, vp, vp, vp, i32, i32, vp, vp, vp],
+    "xmc_contrastive_bwd": [vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp],
+    "xmc_hinge_fwd": [vp, i32, f32, vp, i64, i32, vp],
+    "xmc_hinge_bwd": [vp, i32, f32, vp, vp, i64, i32, vp],
+    "xmc_cast": [vp, vp, i64, i32, i32, vp],
+    "xmc_adam_chunk_elems": [],
+    "xmc_adam_step": [vp, i32, vp, i32, f32, f32, f32, f32, vp],
+}
+_RESTYPE = {"xmc_contrastive_ws_bytes": i64}
+EXPORTS = tuple(_SIGS)
+
+_lib = None
+
+
+class XmcHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (once) and set prototypes."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `make -C xmc-gan_amd/csrc` (or __graft_entry__.build()). "
+            "The XMC-GAN step has no CPU/PyTorch fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, args in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = _RESTYPE.get(name, C.c_int)
+    if lib.xmc_abi_version() != 1:
+        raise RuntimeError("libxmc_gan_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+_ECODES = {-1: "XMC_EINVAL (bad argument)", -2: "XMC_EALIGN (alignment / channel multiple)", -3: "XMC_ESHAPE (shape out of range)"}
+
+
+def check(rc, what):
+    if rc != 0:
+        raise XmcHipError(f"{what} failed: {_ECODES.get(rc, f'hipError_t {rc}')}")
+
+
+def call(name, *args):
+    lib = load()
+    check(getattr(lib, name)(*args), name)

@@ -1,0 +1,734 @@
+"""Autograd-visible operators backed by libxmc_gan_hip.so.
+
+Every operator is a ``torch.autograd.Function`` whose backward is itself written with operators
+from this file, so the set is closed under differentiation: that is what lets the MA-GP term
+(train_gan.py:231-252, ``autograd.grad(create_graph=True)`` followed by ``backward()``) run through
+hand-written kernels.  Activations are contiguous NHWC tensors ``[N,H,W,C]`` (C % 8 == 0) in the
+engine's activation dtype (bf16 by default, f32 in parity mode); parameters stay f32 in the
+reference's ``[Co,Ci,KH,KW]`` / ``[out,in]`` layout and are packed on demand (cached).
+PyTorch is used for storage, streams and the autograd graph only.
+"""
+import ctypes as C
+import os
+import threading
+import weakref
+
+import torch
+
+from . import lib as L
+
+# ------------------------------------------------------------------------------------------ config
+_state = threading.local()
+_PRECISION = os.environ.get("XMC_PRECISION", "bf16")
+
+
+def set_precision(p):
+    """'bf16' (default: bf16 activations/MFMA operands, f32 accumulate, f32 parameters) or 'fp32'."""
+    global _PRECISION
+    assert p in ("bf16", "fp32")
+    _PRECISION = p
+
+
+def precision():
+    return _PRECISION
+
+
+def act_dtype():
+    return torch.bfloat16 if _PRECISION == "bf16" else torch.float32
+
+
+class no_wgrad:
+    """Context: convolutions skip weight/bias gradients (used where the reference computes and
+    then discards them, e.g. D's weight grads during the G step, train_gan.py:288 then 226-227)."""
+
+    def __enter__(self):
+        self.prev = getattr(_state, "skip_wgrad", False)
+        _state.skip_wgrad = True
+
+    def __exit__(self, *a):
+        _state.skip_wgrad = self.prev
+
+
+def _skip_wgrad():
+    return getattr(_state, "skip_wgrad", False)
+
+
+# ------------------------------------------------------------------------------------------ helpers
+def _code(dtype):
+    if dtype == torch.bfloat16:
+        return L.BF16
+    if dtype == torch.float32:
+        return L.F32
+    raise TypeError(f"unsupported dtype {dtype}")
+
+
+def _esz(dtype):
+    return 2 if dtype == torch.bfloat16 else 4
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _st():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("xmc_gan_amd operators run on the GPU only (no CPU fallback)")
+
+
+def pad_to(n, m):
+    return (n + m - 1) // m * m
+
+
+def chan_pad(c, dtype):
+    """stored channel count for c logical channels: a multiple of 8, except that f32 feature vectors
+    whose width is already a multiple of 4 (16-byte units, e.g. the 100-d noise) are kept as they are."""
+    if dtype == torch.float32 and c % 4 == 0:
+        return c
+    return pad_to(c, 8)
+
+
+_weights_epoch = [0]
+
+
+def bump_weights_epoch():
+    """Called by the optimizer kernels' wrapper: parameters changed behind autograd's back."""
+    _weights_epoch[0] += 1
+
+
+# ------------------------------------------------------------------------------------------ geometry
+class ConvGeom:
+    """Geometry of one convolution / linear layer (square kernel k, stride s, padding p)."""
+
+    __slots__ = ("cin", "cout", "k", "s", "p", "row_perm", "_perm_dev")
+
+    def __init__(self, cin, cout, k=1, s=1, p=0, row_perm=None):
+        assert k * k <= L.MAX_TAPS and k % s == 0
+        self.cin, self.cout, self.k, self.s, self.p = cin, cout, k, s, p
+        self.row_perm = row_perm          # optional LongTensor/list: packed output row r <- parameter row perm[r]
+        self._perm_dev = None
+
+    def out_hw(self, h, w):
+        return (h + 2 * self.p - self.k) // self.s + 1, (w + 2 * self.p - self.k) // self.s + 1
+
+    def perm_dev(self, device):
+        if self.row_perm is None:
+            return None
+        if self._perm_dev is None or self._perm_dev.device != device:
+            self._perm_dev = torch.as_tensor(self.row_perm, dtype=torch.int32, device=device).contiguous()
+        return self._perm_dev
+
+
+def _fill_taps(d, cls, taps):
+    for t, (dh, dw, wi) in enumerate(taps):
+        d.dh[cls][t] = dh
+        d.dw[cls][t] = dw
+        d.wi[cls][t] = wi
+
+
+_pack_cache = {}
+
+
+def _pack(w, geom, transpose, dtype):
+    cs_p = chan_pad(geom.cin, dtype)          # stored channels of x
+    cd_p = pad_to(geom.cout, 8)               # stored channels of y
+    if transpose:
+        rows, cols = pad_to(cs_p, 32), cd_p
+    else:
+        rows, cols = pad_to(cd_p, 32), cs_p
+    out = torch.empty((geom.k * geom.k, rows, cols), dtype=dtype, device=w.device)
+    wf = w.detach()
+    if wf.dtype != torch.float32 or not wf.is_contiguous():
+        wf = wf.float().contiguous()
+    L.call("xmc_pack_weight", _p(wf), _p(out), geom.cout, geom.cin, geom.k, geom.k, rows, cols, int(transpose),
+           _code(dtype), _p(geom.perm_dev(w.device)), _st())
+    return out
+
+
+def _packed_cached(w, geom, transpose, dtype):
+    """Packed copy of ``w`` ([Co,Ci,k,k] / [Co,Ci]) for the forward (transpose=0: [tap][co][ci]) or the
+    data-gradient (transpose=1: [tap][ci][co]) kernel; cached per nn.Parameter until it changes."""
+    if not isinstance(w, torch.nn.Parameter):
+        return _pack(w, geom, transpose, dtype)
+    k = (id(w), transpose, dtype)
+    hit = _pack_cache.get(k)
+    if hit is not None and hit[0]() is w and hit[1] == w._version and hit[2] == _weights_epoch[0] and hit[3] is geom:
+        return hit[4]
+    out = _pack(w, geom, transpose, dtype)
+    _pack_cache[k] = (weakref.ref(w), w._version, _weights_epoch[0], geom, out)
+    return out
+
+
+def _conv_fwd_raw(x, w, bias, geom, act, out_dtype, res=None, alpha=None, up=False):
+    """y = act(conv(x, w) + bias) [*alpha] [+ res]; x [N,H,W,Cs]. ``up``: x is read through a fused nearest x2."""
+    _need_cuda(x, w)
+    N, H, W, CS = x.shape
+    sh = 1 if up else 0
+    Hv, Wv = H << sh, W << sh
+    OH, OW = geom.out_hw(Hv, Wv)
+    cd_p = pad_to(geom.cout, 8)
+    assert CS == chan_pad(geom.cin, x.dtype), (CS, geom.cin)
+    wpk = _packed_cached(w, geom, 0, x.dtype)
+    y = torch.empty((N, OH, OW, cd_p), dtype=out_dtype, device=x.device)
+    d = L.ConvDesc()
+    d.src, d.wpk, d.dst = x.data_ptr(), wpk.data_ptr(), y.data_ptr()
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.res = res.data_ptr() if res is not None else None
+    d.alpha_dev = alpha.data_ptr() if alpha is not None else None
+    d.N, d.SH, d.SW, d.CS = N, H, W, CS
+    d.DH, d.DW, d.CD = OH, OW, cd_p
+    d.MH, d.MW, d.SA, d.DA, d.src_shift = OH, OW, geom.s, 1, sh
+    d.ntaps, d.nclass, d.CDw = geom.k * geom.k, 1, wpk.shape[1]
+    d.act, d.dtype, d.out_dtype = act, _code(x.dtype), _code(out_dtype)
+    _fill_taps(d, 0, [(kh - geom.p, kw - geom.p, kh * geom.k + kw) for kh in range(geom.k) for kw in range(geom.k)])
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.numel() >= cd_p, "bias must be f32 and padded to the stored channels"
+    if res is not None:
+        assert res.shape == y.shape and res.dtype == out_dtype and res.is_contiguous()
+    L.check(L.load().xmc_conv_igemm(C.byref(d), _st()), "xmc_conv_igemm(fwd)")
+    return y
+
+
+def _conv_dgrad_raw(dy, w, geom, in_hw, in_dtype):
+    """dx [N,H,W,cin_p] from dy [N,OH,OW,cout_p]."""
+    _need_cuda(dy, w)
+    N, OH, OW, CDy = dy.shape
+    H, W = in_hw
+    assert CDy == pad_to(geom.cout, 8)
+    cs_p = chan_pad(geom.cin, in_dtype)
+    wpk = _packed_cached(w, geom, 1, dy.dtype)
+    if cs_p % 8:
+        raise RuntimeError("dgrad destination needs a channel count that is a multiple of 8")
+    dx = torch.empty((N, H, W, cs_p), dtype=in_dtype, device=dy.device)
+    d = L.ConvDesc()
+    d.src, d.wpk, d.dst = dy.data_ptr(), wpk.data_ptr(), dx.data_ptr()
+    d.N, d.SH, d.SW, d.CS = N, OH, OW, CDy
+    d.DH, d.DW, d.CD = H, W, cs_p
+    s, k, p = geom.s, geom.k, geom.p
+    d.MH, d.MW, d.SA, d.DA, d.src_shift = H // s, W // s, 1, s, 0
+    d.nclass, d.CDw = s * s, wpk.shape[1]
+    d.act, d.dtype, d.out_dtype = L.ACT_NONE, _code(dy.dtype), _code(in_dtype)
+    assert H % s == 0 and W % s == 0
+    ntaps = None
+    for ph in range(s):
+        for pw in range(s):
+            cls = ph * s + pw
+            taps = [((ph + p - kh) // s, (pw + p - kw) // s, kh * k + kw)
+                    for kh in range(k) if (ph + p - kh) % s == 0
+                    for kw in range(k) if (pw + p - kw) % s == 0]
+            assert ntaps in (None, len(taps))
+            ntaps = len(taps)
+            _fill_taps(d, cls, taps)
+            d.dph[cls], d.dpw[cls] = ph, pw
+    d.ntaps = ntaps
+    L.check(L.load().xmc_conv_igemm(C.byref(d), _st()), "xmc_conv_igemm(dgrad)")
+    return dx
+
+
+def _conv_wgrad_raw(x, dy, geom, scale=None, up=False):
+    """gw [Co,Ci,k,k] f32 from x [N,H,W,cs_p], dy [N,OH,OW,cd_p]."""
+    _need_cuda(x, dy)
+    N, H, W, CS = x.shape
+    _, OH, OW, CDy = dy.shape
+    assert x.dtype == dy.dtype, (x.dtype, dy.dtype)
+    rows = pad_to(CDy, 32)
+    dwp = torch.zeros((geom.k * geom.k, rows, CS), dtype=torch.float32, device=x.device)
+    d = L.ConvDesc()
+    d.src, d.dst = x.data_ptr(), dy.data_ptr()
+    d.N, d.SH, d.SW, d.CS = N, H, W, CS
+    d.DH, d.DW, d.CD = OH, OW, CDy
+    d.MH, d.MW, d.SA, d.DA, d.src_shift = OH, OW, geom.s, 1, 1 if up else 0
+    d.ntaps, d.nclass, d.CDw = geom.k * geom.k, 1, rows
+    d.dtype, d.out_dtype = _code(x.dtype), L.F32
+    _fill_taps(d, 0, [(kh - geom.p, kw - geom.p, kh * geom.k + kw) for kh in range(geom.k) for kw in range(geom.k)])
+    L.check(L.load().xmc_conv_wgrad(C.byref(d), _p(dwp), _st()), "xmc_conv_wgrad")
+    gw = torch.empty((geom.cout, geom.cin, geom.k, geom.k), dtype=torch.float32, device=x.device)
+    L.call("xmc_unpack_wgrad", _p(dwp), _p(gw), geom.cout, geom.cin, geom.k, geom.k, rows, CS, _p(scale),
+           _p(geom.perm_dev(x.device)), 0, _st())
+    return gw
+
+
+# ------------------------------------------------------------------------------------------ conv / linear
+class ConvFn(torch.autograd.Function):
+    """y = act(conv2d(x, w) + b).  F.conv2d / nn.Linear call sites: df_gan.py:73-74,86,144,157-159,187-188,
+    197,233-240,273,276,280."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, geom, act, out_dtype):
+        x = x.contiguous()
+        bp = None
+        if b is not None:
+            cd_p = pad_to(geom.cout, 8)
+            bp = b.detach().float()
+            if geom.row_perm is not None:
+                bp = bp.index_select(0, geom.perm_dev(b.device).long())
+            if bp.numel() < cd_p:
+                bp = torch.nn.functional.pad(bp, (0, cd_p - bp.numel()))
+            bp = bp.contiguous()
+        y = _conv_fwd_raw(x, w, bp, geom, act, out_dtype)
+        ctx.geom, ctx.act, ctx.has_b = geom, act, b is not None
+        ctx.save_for_backward(x, w, y if act != L.ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        geom = ctx.geom
+        dy = dy.contiguous()
+        if ctx.act in (L.ACT_LRELU, L.ACT_RELU):
+            dy = MaskFn.apply(dy, y, 0.2 if ctx.act == L.ACT_LRELU else 0.0)
+        elif ctx.act == L.ACT_TANH:
+            dy = TanhBwdFn.apply(dy, y)
+        if dy.dtype != x.dtype:
+            dy = CastFn.apply(dy, x.dtype)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = ConvDgradFn.apply(dy, w, geom, (x.shape[1], x.shape[2]), x.dtype)
+        if not _skip_wgrad():
+            if ctx.needs_input_grad[1]:
+                dw = ConvWgradFn.apply(x, dy, geom).view(w.shape)
+            if ctx.has_b and ctx.needs_input_grad[2]:
+                db = ColSumFn.apply(dy)
+                if geom.row_perm is not None:
+                    db = torch.zeros_like(db).index_copy(0, geom.perm_dev(db.device).long(), db)
+                db = db[: geom.cout]
+        return dx, dw, db, None, None, None
+
+
+class ConvDgradFn(torch.autograd.Function):
+    """dx of ConvFn (a transposed convolution); linear in dy and in w."""
+
+    @staticmethod
+    def forward(ctx, dy, w, geom, in_hw, in_dtype):
+        dy = dy.contiguous()
+        dx = _conv_dgrad_raw(dy, w, geom, in_hw, in_dtype)
+        ctx.geom = geom
+        ctx.save_for_backward(dy, w)
+        return dx
+
+    @staticmethod
+    def backward(ctx, g):
+        dy, w = ctx.saved_tensors
+        geom = ctx.geom
+        g = g.contiguous()
+        if g.dtype != dy.dtype:
+            g = CastFn.apply(g, dy.dtype)
+        ddy = dw = None
+        if ctx.needs_input_grad[0]:
+            ddy = ConvFn.apply(g, w, None, geom, L.ACT_NONE, dy.dtype)
+        if ctx.needs_input_grad[1] and not _skip_wgrad():
+            dw = ConvWgradFn.apply(g, dy, geom).view(w.shape)
+        return ddy, dw, None, None, None
+
+
+class ConvWgradFn(torch.autograd.Function):
+    """dw of ConvFn; bilinear in (x, dy)."""
+
+    @staticmethod
+    def forward(ctx, x, dy, geom):
+        x, dy = x.contiguous(), dy.contiguous()
+        gw = _conv_wgrad_raw(x, dy, geom)
+        ctx.geom = geom
+        ctx.save_for_backward(x, dy)
+        return gw
+
+    @staticmethod
+    def backward(ctx, ggw):
+        x, dy = ctx.saved_tensors
+        geom = ctx.geom
+        ggw = ggw.contiguous().view(geom.cout, geom.cin, geom.k, geom.k)
+        dx = ddy = None
+        if ctx.needs_input_grad[0]:
+            dx = ConvDgradFn.apply(dy, ggw, geom, (x.shape[1], x.shape[2]), x.dtype)
+        if ctx.needs_input_grad[1]:
+            ddy = ConvFn.apply(x, ggw, None, geom, L.ACT_NONE, dy.dtype)
+        return dx, ddy, None
+
+
+def conv2d(x, w, b, geom, act=L.ACT_NONE, out_dtype=None):
+    return ConvFn.apply(x, w, b, geom, act, out_dtype or x.dtype)
+
+
+def linear(x, w, b, geom, act=L.ACT_NONE, out_dtype=None):
+    """x [B,K] -> [B,cout_p] through the 1x1 path (nn.Linear: df_gan.py:73-74,144,233-240)."""
+    y = ConvFn.apply(x.contiguous().view(x.shape[0], 1, 1, x.shape[1]), w, b, geom, act, out_dtype or x.dtype)
+    return y.view(x.shape[0], -1)
+
+
+# ------------------------------------------------------------------------------------------ pointwise
+class CastFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ctx.src = x.dtype
+        if x.dtype == dtype:
+            return x
+        x = x.contiguous()
+        y = torch.empty_like(x, dtype=dtype)
+        L.call("xmc_cast", _p(x), _p(y), x.numel(), _code(x.dtype), _code(dtype), _st())
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return CastFn.apply(dy, ctx.src), None
+
+
+class MaskFn(torch.autograd.Function):
+    """ref > 0 ? dy : slope*dy  (derivative of LeakyReLU/ReLU applied to dy; linear in dy)."""
+
+    @staticmethod
+    def forward(ctx, dy, ref, slope):
+        dy = dy.contiguous()
+        if dy.dtype != ref.dtype:
+            dy = dy.to(ref.dtype)
+        out = torch.empty_like(dy)
+        L.call("xmc_lrelu_mask", _p(dy), _p(ref), _p(out), dy.numel(), float(slope), _code(dy.dtype), _st())
+        ctx.slope = slope
+        ctx.save_for_backward(ref)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (ref,) = ctx.saved_tensors
+        return MaskFn.apply(g, ref, ctx.slope), None, None
+
+
+class LreluFn(torch.autograd.Function):
+    """nn.LeakyReLU(0.2) (df_gan.py:85,158,214-222,274,277); slope 0 gives nn.ReLU."""
+
+    @staticmethod
+    def forward(ctx, x, slope):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        L.call("xmc_lrelu", _p(x), _p(y), x.numel(), float(slope), _code(x.dtype), _st())
+        ctx.slope = slope
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        return MaskFn.apply(dy, y, ctx.slope), None
+
+
+class TanhBwdFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, dy, y):
+        dy = dy.contiguous()
+        if dy.dtype != y.dtype:
+            dy = dy.to(y.dtype)
+        out = torch.empty_like(dy)
+        L.call("xmc_tanh_bwd", _p(dy), _p(y), _p(out), dy.numel(), _code(dy.dtype), _st())
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        raise NotImplementedError("second derivative through tanh is not on the XMC-GAN path")
+
+
+class ScaleFn(torch.autograd.Function):
+    """alpha * x with alpha a device scalar (f32 tensor with one element)."""
+
+    @staticmethod
+    def forward(ctx, x, alpha):
+        x = x.contiguous()
+        a = alpha.detach().reshape(-1).float()
+        y = torch.empty_like(x)
+        L.call("xmc_scale", _p(x), _p(a), _p(y), x.numel(), _code(x.dtype), _st())
+        ctx.save_for_backward(x, alpha)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, alpha = ctx.saved_tensors
+        dx = ScaleFn.apply(dy, alpha) if ctx.needs_input_grad[0] else None
+        da = DotFn.apply(dy, x).reshape(alpha.shape) if ctx.needs_input_grad[1] else None
+        return dx, da
+
+
+class DotFn(torch.autograd.Function):
+    """sum(a*b) -> f32 [1]."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = a.contiguous(), b.contiguous()
+        if a.dtype != b.dtype:
+            b = b.to(a.dtype)
+        out = torch.zeros(1, dtype=torch.float32, device=a.device)
+        L.call("xmc_dot", _p(a), _p(b), _p(out), a.numel(), _code(a.dtype), _st())
+        ctx.save_for_backward(a, b)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        da = ScaleFn.apply(b, g) if ctx.needs_input_grad[0] else None
+        db = ScaleFn.apply(a, g) if ctx.needs_input_grad[1] else None
+        return da, db
+
+
+class AxpbyFn(torch.autograd.Function):
+    """a + alpha*b  (shortcut + gamma*residual, df_gan.py:200,284)."""
+
+    @staticmethod
+    def forward(ctx, a, b, alpha):
+        a, b = a.contiguous(), b.contiguous()
+        al = alpha.detach().reshape(-1).float()
+        y = torch.empty_like(a)
+        L.call("xmc_axpby", _p(a), _p(b), _p(al), _p(y), a.numel(), _code(a.dtype), _st())
+        ctx.save_for_backward(b, alpha)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        b, alpha = ctx.saved_tensors
+        da = dy if ctx.needs_input_grad[0] else None
+        db = ScaleFn.apply(dy, alpha) if ctx.needs_input_grad[1] else None
+        dal = DotFn.apply(dy, b).reshape(alpha.shape) if ctx.needs_input_grad[2] else None
+        return da, db, dal
+
+
+class ColSumFn(torch.autograd.Function):
+    """sum over all pixels -> f32 [C]  (bias gradients)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        Cc = x.shape[-1]
+        out = torch.zeros(Cc, dtype=torch.float32, device=x.device)
+        L.call("xmc_colsum", _p(x), _p(out), x.numel() // Cc, Cc, _code(x.dtype), _st())
+        ctx.shape, ctx.dtype = x.shape, x.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(ctx.dtype).expand(ctx.shape).contiguous()
+
+
+class SumPool2Fn(torch.autograd.Function):
+    """scale * (2x2 sum pool).  scale=0.25: F.avg_pool2d(x, 2) (df_gan.py:290); adjoint of Up2Fn."""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        x = x.contiguous()
+        N, H, W, Cc = x.shape
+        y = torch.empty((N, H // 2, W // 2, Cc), dtype=x.dtype, device=x.device)
+        L.call("xmc_sumpool2", _p(x), _p(y), N, H, W, Cc, float(scale), _code(x.dtype), _st())
+        ctx.scale = scale
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return Up2Fn.apply(dy, ctx.scale), None
+
+
+class Up2Fn(torch.autograd.Function):
+    """scale * nearest x2 upsample.  scale=1: F.interpolate(scale_factor=2) (df_gan.py:202)."""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        x = x.contiguous()
+        N, H, W, Cc = x.shape
+        y = torch.empty((N, 2 * H, 2 * W, Cc), dtype=x.dtype, device=x.device)
+        L.call("xmc_upsample2", _p(x), _p(y), N, H, W, Cc, float(scale), _code(x.dtype), _st())
+        ctx.scale = scale
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return SumPool2Fn.apply(dy, ctx.scale), None
+
+
+class GapFn(torch.autograd.Function):
+    """mean over all pixels of an [N,H,W,C] map -> [N,C] (F.avg_pool2d(x,4) on 4x4: df_gan.py:165, train_gan.py:272,275)."""
+
+    @staticmethod
+    def forward(ctx, x, out_dtype):
+        x = x.contiguous()
+        N, H, W, Cc = x.shape
+        y = torch.empty((N, Cc), dtype=out_dtype, device=x.device)
+        L.call("xmc_global_avgpool", _p(x), _p(y), N, H * W, Cc, _code(x.dtype), _code(out_dtype), _st())
+        ctx.hw, ctx.dtype = (H, W), x.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return GapBwdFn.apply(dy, ctx.hw, ctx.dtype), None
+
+
+class GapBwdFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, dy, hw, dtype):
+        dy = dy.contiguous()
+        N, Cc = dy.shape
+        dx = torch.empty((N, hw[0], hw[1], Cc), dtype=dtype, device=dy.device)
+        L.call("xmc_global_avgpool_bwd", _p(dy), _p(dx), N, hw[0] * hw[1], Cc, _code(dtype), _code(dy.dtype), _st())
+        ctx.in_dtype = dy.dtype
+        return dx
+
+    @staticmethod
+    def backward(ctx, g):
+        return GapFn.apply(g, ctx.in_dtype), None, None
+
+
+class NchwToNhwc8Fn(torch.autograd.Function):
+    """[N,C<=8,H,W] f32 (module boundary, df_gan.py:127) -> [N,H,W,8] activation dtype, zero padded."""
+
+    @staticmethod
+    def forward(ctx, x, dtype):
+        _need_cuda(x)
+        x = x.contiguous().float()
+        N, Cc, H, W = x.shape
+        y = torch.empty((N, H, W, 8), dtype=dtype, device=x.device)
+        L.call("xmc_nchw_to_nhwc8", _p(x), _p(y), N, Cc, H, W, _code(dtype), _st())
+        ctx.c = Cc
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return Nhwc8ToNchwFn.apply(dy, ctx.c), None
+
+
+class Nhwc8ToNchwFn(torch.autograd.Function):
+    """[N,H,W,8] -> [N,C,H,W] f32 (the image NetG returns, df_gan.py:101-103)."""
+
+    @staticmethod
+    def forward(ctx, x, c):
+        x = x.contiguous()
+        N, H, W, _ = x.shape
+        y = torch.empty((N, c, H, W), dtype=torch.float32, device=x.device)
+        L.call("xmc_nhwc8_to_nchw", _p(x), _p(y), N, c, H, W, _code(x.dtype), _st())
+        ctx.dtype = x.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return NchwToNhwc8Fn.apply(dy, ctx.dtype), None
+
+
+class Affine2LreluFn(torch.autograd.Function):
+    """lrelu(lrelu(x*g0+b0)*g1+b1) with per-sample, per-channel f32 g/b [N,C] -- two DF-GAN `affine`
+    modules each followed by LeakyReLU(0.2) (df_gan.py:213-216 / 219-222, affine.forward 250-263)."""
+
+    @staticmethod
+    def forward(ctx, x, g0, b0, g1, b1):
+        x = x.contiguous()
+        N, H, W, Cc = x.shape
+        ps = [t.contiguous().float() for t in (g0, b0, g1, b1)]
+        for t in ps:
+            assert t.shape == (N, Cc), (t.shape, (N, Cc))
+        y = torch.empty_like(x)
+        L.call("xmc_affine2_lrelu_fwd", _p(x), *[_p(t) for t in ps], _p(y), N, H * W, Cc, _code(x.dtype), _st())
+        ctx.save_for_backward(x, *ps)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        x, g0, b0, g1, b1 = ctx.saved_tensors
+        dy = dy.contiguous()
+        N, H, W, Cc = x.shape
+        dx = torch.empty_like(x)
+        red = torch.zeros((4, N, Cc), dtype=torch.float32, device=x.device)
+        L.call("xmc_affine2_lrelu_bwd", _p(x), _p(dy), _p(g0), _p(b0), _p(g1), _p(b1), _p(dx),
+               _p(red[0]), _p(red[1]), _p(red[2]), _p(red[3]), N, H * W, Cc, _code(x.dtype), _st())
+        return dx, red[0], red[1], red[2], red[3]
+
+
+# ------------------------------------------------------------------------------------------ losses
+class HingeFn(torch.autograd.Function):
+    """mean(relu(1 + sign*logit)) over the first channel of a padded [B,...,8] logit tensor
+    (train_gan.py:195 sign=-1, 204/209 sign=+1)."""
+
+    @staticmethod
+    def forward(ctx, logits, sign):
+        logits = logits.contiguous()
+        n = logits.numel() // logits.shape[-1]
+        out = torch.empty(1, dtype=torch.float32, device=logits.device)
+        L.call("xmc_hinge_fwd", _p(logits), logits.shape[-1], float(sign), _p(out), n, _code(logits.dtype), _st())
+        ctx.sign = sign
+        ctx.save_for_backward(logits)
+        return out.reshape(())
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        (logits,) = ctx.saved_tensors
+        n = logits.numel() // logits.shape[-1]
+        dx = torch.zeros_like(logits)
+        gg = g.reshape(1).float().contiguous()
+        L.call("xmc_hinge_bwd", _p(logits), logits.shape[-1], float(ctx.sign), _p(gg), _p(dx), n, _code(logits.dtype), _st())
+        return dx, None
+
+
+class ContrastiveFn(torch.autograd.Function):
+    """Symmetric InfoNCE on cosine similarities, no temperature (cosine_scores + sent_loss/img_loss,
+    train_gan.py:85-139).  a,b: [n,D] f32;  labels: None (identity) or f32 [n,n];  inv_num_pos: None or f32 [n]."""
+
+    @staticmethod
+    def forward(ctx, a, b, labels, inv_num_pos):
+        a, b = a.contiguous().float(), b.contiguous().float()
+        n, D = a.shape
+        ws = torch.empty(L.load().xmc_contrastive_ws_bytes(n, D), dtype=torch.uint8, device=a.device)
+        loss = torch.empty(1, dtype=torch.float32, device=a.device)
+        L.call("xmc_contrastive_fwd", _p(a), _p(b), _p(labels), _p(inv_num_pos), n, D, _p(loss), _p(ws), _st())
+        ctx.save_for_backward(a, b, labels, inv_num_pos, ws)
+        return loss.reshape(())
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        a, b, labels, inv_num_pos, ws = ctx.saved_tensors
+        n, D = a.shape
+        da, db = torch.empty_like(a), torch.empty_like(b)
+        gg = g.reshape(1).float().contiguous()
+        L.call("xmc_contrastive_bwd", _p(a), _p(b), _p(labels), _p(inv_num_pos), n, D, _p(gg), _p(ws), _p(da), _p(db), _st())
+        return da, db, None, None
+
+
+# ------------------------------------------------------------------------------------------ functional sugar
+def lrelu(x, slope=0.2):
+    return LreluFn.apply(x, slope)
+
+
+def avgpool2(x):
+    return SumPool2Fn.apply(x, 0.25)
+
+
+def upsample2(x):
+    return Up2Fn.apply(x, 1.0)
+
+
+def axpby(a, b, alpha):
+    return AxpbyFn.apply(a, b, alpha)
+
+
+def global_avgpool(x, out_dtype=torch.float32):
+    return GapFn.apply(x, out_dtype)
+
+
+def to_nhwc8(x_nchw):
+    return NchwToNhwc8Fn.apply(x_nchw, act_dtype())
+
+
+def to_nchw(x_nhwc8, c):
+    return Nhwc8ToNchwFn.apply(x_nhwc8, c)
+
+
+def affine2_lrelu(x, g0, b0, g1, b1):
+    return Affine2LreluFn.apply(x, g0, b0, g1, b1)
+
+
+def hinge(logits_padded, sign):
+    return HingeFn.apply(logits_padded, sign)
+
+
+def contrastive(a, b, labels=None, inv_num_pos=None):
+    return ContrastiveFn.apply(a, b, labels, inv_num_pos)
+
+
+def cast(x, dtype):
+    return CastFn.apply(x, dtype)

@@ -1,0 +1,260 @@
+"""DF-GAN generator / discriminator with the reference's module API (model/df_gan.py), running on the
+MI355X kernels in ``xmc-gan_amd``.
+
+Same class names, constructor signatures ``(cfg, **kwargs)``, forward signatures, return conventions
+and ``state_dict()`` keys as the reference, so it is a drop-in for ``train_gan.py``'s registries.
+Internally activations are NHWC in the engine's activation dtype; the public tensors keep the
+reference's logical NCHW shapes (``netD(x)`` returns a channels-last view, ``netG`` an f32 NCHW image).
+"""
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from xmc_gan_amd import ops
+from xmc_gan_amd.lib import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH
+
+from .modules import HipConv2d, HipLinear, as_nchw_view, as_nhwc, conv2d_nxn, linear
+
+
+def gen_arch(img_size, nch):
+    """channel/upsample schedule of the generator (reference table: df_gan.py:9-34)."""
+    assert img_size in [64, 128, 256]
+    depth = {64: 5, 128: 6, 256: 7}[img_size]
+    mult = [8] * (depth - 2) + [4, 2, 1]
+    return {
+        'in_channels': [m * nch for m in mult[:-1]],
+        'out_channels': [m * nch for m in mult[1:]],
+        'upsample': [True] * (depth - 1) + [False],
+        'resolution': [8 << i for i in range(depth - 1)] + [img_size],
+        'depth': depth,
+    }
+
+
+def disc_arch(img_size, nch):
+    """channel schedule of the discriminator (reference table: df_gan.py:36-61)."""
+    assert img_size in [64, 128, 256]
+    depth = {64: 5, 128: 6, 256: 7}[img_size]
+    mult = [1, 2, 4, 8, 16, 16, 16][:depth]
+    out_channels = [m * nch for m in mult]
+    return {
+        'in_channels': [3] + out_channels[:-1],
+        'out_channels': out_channels,
+        'downsample': [True] * depth,
+        'resolution': [img_size >> (i + 1) for i in range(depth - 1)] + [4],
+        'depth': depth,
+    }
+
+
+def nhwc_feature_perm(channels, hw=16):
+    """row permutation that makes Linear(...)->view(B,C,4,4) come out as NHWC [B,4,4,C] directly:
+    packed row r = p*C + c  <-  parameter row c*hw + p."""
+    return [(r % channels) * hw + r // channels for r in range(channels * hw)]
+
+
+class NetG(nn.Module):
+    def __init__(self, cfg, **kwargs):
+        super(NetG, self).__init__()
+        self.ngf = cfg.TRAIN.NCH
+        noise_dim = cfg.TRAIN.NOISE_DIM
+        arch = gen_arch(img_size=cfg.IMG.SIZE, nch=self.ngf)
+
+        init_size = (8 * self.ngf) * 4 * 4
+        self.proj_noise = HipLinear(noise_dim, init_size, row_perm=nhwc_feature_perm(8 * self.ngf))
+        self.proj_sent = HipLinear(cfg.TEXT.EMBEDDING_DIM, cfg.TRAIN.NEF) \
+            if (cfg.TEXT.EMBEDDING_DIM != cfg.TRAIN.NEF) else nn.Identity()
+        self.upblocks = nn.ModuleList(
+            [G_Block(in_dim=arch['in_channels'][i], out_dim=arch['out_channels'][i],
+                     cond_dim=cfg.TRAIN.NEF, upsample=arch['upsample'][i]) for i in range(arch['depth'])])
+        self.conv_out = nn.Sequential(
+            nn.LeakyReLU(0.2, inplace=True),
+            HipConv2d(arch['out_channels'][-1], 3, 3, 1, 1),
+            nn.Tanh(),
+        )
+
+    def stem(self, noise):
+        """proj_noise + view(B, 8*ngf, 4, 4) (reference df_gan.py:93-94), emitted as NHWC."""
+        out = self.proj_noise(noise.float(), out_dtype=ops.act_dtype())
+        return out.view(noise.size(0), 4, 4, 8 * self.ngf)
+
+    def tail(self, out):
+        """LeakyReLU -> Conv3x3(->3) -> Tanh (reference df_gan.py:84-88,101); tanh fused in the conv epilogue."""
+        out = ops.lrelu(out)
+        out = self.conv_out[1](out, act=ACT_TANH)
+        return ops.to_nchw(out, 3)
+
+    def forward(self, noise, sent_embs, **kwargs):
+        out = self.stem(noise)
+        sent_embs = self.proj_sent(sent_embs.float())
+        for gblock in self.upblocks:
+            out = gblock(out, sent_embs)
+        return self.tail(out)
+
+
+class NetD(nn.Module):
+    def __init__(self, cfg, **kwargs):
+        super(NetD, self).__init__()
+        ndf = cfg.TRAIN.NCH
+        spec_norm = cfg.DISC.SPEC_NORM
+        arch = disc_arch(img_size=cfg.IMG.SIZE, nch=ndf)
+        self.conv_img = conv2d_nxn(in_dim=arch['in_channels'][0], out_dim=arch['out_channels'][0], kernel_size=3,
+                                   stride=1, padding=1, spec_norm=spec_norm)
+        self.downblocks = nn.ModuleList(
+            [resD(in_dim=arch['in_channels'][i], out_dim=arch['out_channels'][i],
+                  downsample=arch['downsample'][i], spec_norm=spec_norm) for i in range(1, arch['depth'])])
+        self.COND_DNET = D_GET_LOGITS(cfg, ndf=ndf, spec_norm=spec_norm)
+
+    def forward(self, x, **kwargs):
+        """x: [B,3,S,S] f32 image -> [B,16*ndf,4,4] feature map (channels-last view)."""
+        out = self.conv_img(ops.to_nhwc8(x))
+        for block in self.downblocks:
+            out = block(out)
+        return as_nchw_view(out)
+
+
+class D_GET_LOGITS(nn.Module):
+    """Conditional logit and contrastive projection head (reference df_gan.py:134-176)."""
+
+    def __init__(self, cfg, ndf, spec_norm=False):
+        super(D_GET_LOGITS, self).__init__()
+        nef = cfg.TRAIN.NEF
+        text_dim = cfg.TEXT.EMBEDDING_DIM
+        self.img_match = cfg.DISC.IMG_MATCH
+        if self.img_match:
+            self.proj_match = linear(ndf * 16, nef, spec_norm=spec_norm)       # image side
+            cond_dim = nef
+        elif cfg.DISC.SENT_MATCH:
+            self.proj_match = linear(nef, ndf * 16, spec_norm=spec_norm)       # sentence side
+            cond_dim = ndf * 16
+        elif cfg.DISC.SEPERATE and (text_dim != nef):
+            self.proj_match = linear(text_dim, nef, spec_norm=spec_norm)
+            cond_dim = nef
+        else:
+            self.proj_match = nn.Identity()
+            cond_dim = text_dim
+        self.joint_conv = nn.Sequential(
+            conv2d_nxn(in_dim=ndf * 16 + cond_dim, out_dim=ndf * 2, kernel_size=3, stride=1, padding=1, bias=False,
+                       spec_norm=spec_norm),
+            nn.LeakyReLU(0.2, inplace=True),
+            conv2d_nxn(in_dim=ndf * 2, out_dim=1, kernel_size=4, stride=1, padding=0, bias=False, spec_norm=spec_norm),
+        )
+
+    def forward(self, x, sent_embs, **kwargs):
+        """x [B,16*ndf,4,4], sent_embs [B,cond] -> [logit [B,1,1,1], image embedding, text embedding]."""
+        xh = as_nhwc(x)
+        B = xh.size(0)
+        out = ops.global_avgpool(xh)                               # F.avg_pool2d(x, 4).view(B, -1)
+        sent_embs = sent_embs.float()
+        if self.img_match:
+            out = self.proj_match(out)
+        else:
+            sent_embs = self.proj_match(sent_embs)
+        c = ops.cast(_pad8(sent_embs), xh.dtype)
+        c = c.view(B, 1, 1, -1).expand(B, xh.size(1), xh.size(2), c.size(-1))
+        h_c_code = torch.cat((xh, c), 3)
+        m = self.joint_conv[0](h_c_code, act=ACT_LRELU)
+        m = self.joint_conv[2](m)                                  # [B,1,1,8], channel 0 is the logit
+        match = as_nchw_view(m[..., :1])
+        return [match, out, sent_embs]
+
+
+def _pad8(t):
+    r = (-t.size(-1)) % 8
+    return t if r == 0 else torch.nn.functional.pad(t, (0, r))
+
+
+class G_Block(nn.Module):
+    def __init__(self, in_dim, out_dim, cond_dim, upsample):
+        super(G_Block, self).__init__()
+        self.learnable_sc = (in_dim != out_dim)
+        self.upsample = upsample
+        self.c1 = HipConv2d(in_dim, out_dim, 3, 1, 1)
+        self.c2 = HipConv2d(out_dim, out_dim, 3, 1, 1)
+        self.affine0 = affine(num_features=in_dim, cond_dim=cond_dim)
+        self.affine1 = affine(num_features=in_dim, cond_dim=cond_dim)
+        self.affine2 = affine(num_features=out_dim, cond_dim=cond_dim)
+        self.affine3 = affine(num_features=out_dim, cond_dim=cond_dim)
+        self.gamma = nn.Parameter(torch.zeros(1))
+        if self.learnable_sc:
+            self.c_sc = HipConv2d(in_dim, out_dim, 1, stride=1, padding=0)
+
+    def forward(self, x, c):
+        out = ops.axpby(self.shortcut(x), self.residual(x, c), self.gamma)
+        if self.upsample:
+            out = ops.upsample2(out)
+        return out
+
+    def shortcut(self, x):
+        return self.c_sc(x) if self.learnable_sc else x
+
+    def residual(self, x, c):
+        # affine0 -> LeakyReLU -> affine1 -> LeakyReLU fused into one pass (df_gan.py:213-216), same for 2/3
+        h = ops.affine2_lrelu(x, *self.affine0.scale_shift(c), *self.affine1.scale_shift(c))
+        h = self.c1(h)
+        h = ops.affine2_lrelu(h, *self.affine2.scale_shift(c), *self.affine3.scale_shift(c))
+        return self.c2(h)
+
+
+class _CondMLP(nn.Module):
+    """Linear(cond,256) -> ReLU -> Linear(256,C) with the reference's child names (df_gan.py:232-241)."""
+
+    def __init__(self, cond_dim, num_features):
+        super().__init__()
+        self.linear1 = HipLinear(cond_dim, 256)
+        self.relu1 = nn.ReLU(inplace=True)
+        self.linear2 = HipLinear(256, num_features)
+
+    def forward(self, y):
+        return self.linear2(self.linear1(y, act=ACT_RELU))
+
+
+class affine(nn.Module):
+    def __init__(self, num_features, cond_dim):
+        super(affine, self).__init__()
+        self.fc_gamma = _CondMLP(cond_dim, num_features)
+        self.fc_beta = _CondMLP(cond_dim, num_features)
+        self._initialize()
+
+    def _initialize(self):
+        nn.init.zeros_(self.fc_gamma.linear2.weight.data)
+        nn.init.ones_(self.fc_gamma.linear2.bias.data)
+        nn.init.zeros_(self.fc_beta.linear2.weight.data)
+        nn.init.zeros_(self.fc_beta.linear2.bias.data)
+
+    def scale_shift(self, y):
+        """per-sample, per-channel (weight, bias), each f32 [B,C]."""
+        return self.fc_gamma(y), self.fc_beta(y)
+
+    def forward(self, x, y=None):
+        """weight(y) * x + bias(y) on an NHWC tensor (reference df_gan.py:250-263)."""
+        w, b = self.scale_shift(y)
+        return x * w[:, None, None, :].to(x.dtype) + b[:, None, None, :].to(x.dtype)
+
+
+class resD(nn.Module):
+    def __init__(self, in_dim, out_dim, downsample, spec_norm=False):
+        super().__init__()
+        self.downsample = downsample
+        self.learned_shortcut = (in_dim != out_dim)
+        self.conv_r = nn.Sequential(
+            conv2d_nxn(in_dim=in_dim, out_dim=out_dim, kernel_size=4, stride=2, padding=1, bias=False, spec_norm=spec_norm),
+            nn.LeakyReLU(0.2, inplace=True),
+            conv2d_nxn(in_dim=out_dim, out_dim=out_dim, kernel_size=3, stride=1, padding=1, bias=False, spec_norm=spec_norm),
+            nn.LeakyReLU(0.2, inplace=True),
+        )
+        self.conv_s = conv2d_nxn(in_dim=in_dim, out_dim=out_dim, kernel_size=1, stride=1, padding=0, spec_norm=spec_norm)
+        self.gamma = nn.Parameter(torch.zeros(1))
+
+    def forward(self, x, c=None):
+        return ops.axpby(self.shortcut(x), self.residual(x), self.gamma)
+
+    def shortcut(self, x):
+        if self.learned_shortcut:
+            x = self.conv_s(x)
+        if self.downsample:
+            return ops.avgpool2(x)
+        return x
+
+    def residual(self, x):
+        r = self.conv_r[0](x, act=ACT_LRELU)        # conv + LeakyReLU fused in the epilogue
+        return self.conv_r[2](r, act=ACT_LRELU)
