@@ -148,6 +148,9 @@ int xmc_contrastive_fwd(const float* A, const float* B, const float* labels, con
 int xmc_contrastive_bwd(const float* A, const float* B, const float* labels, const float* inv_num_pos,
                         int n, int D, const float* dloss_dev, void* ws, float* dA, float* dB, void* stream);
 
+/* cosine_scores alone (train_gan.py:85-91), S f32 [n][n]; same workspace size as the fused head */
+int xmc_cosine_scores(const float* A, const float* B, int n, int D, float* S, void* ws, void* stream);
+
 /* hinge terms: *out = mean_i relu(1 + sign*x[i*stride])  (train_gan.py:195,204,209);
  * bwd: dx[i*stride] = (*dloss_dev)*sign/n where the hinge is active, else 0 (other elements of dx untouched) */
 int xmc_hinge_fwd(const void* x, int stride, float sign, float* out, int64_t n, int dtype, void* stream);

@@ -237,6 +237,8 @@ def synth_params(shapes: dict, seed: int = 0) -> dict:
             t = 0.25 + 0.5 * torch.rand(shape, generator=g)
         elif ".gn" in key and leaf == "weight":
             t = 1.0 + 0.1 * torch.randn(shape, generator=g)
+        elif ".fc_gamma.linear2.bias" in key:
+            t = 1.0 + 0.05 * torch.randn(shape, generator=g)      # modulation scale ~ 1 (+ a data-dependent part)
         elif leaf == "bias":
             t = 0.05 * torch.randn(shape, generator=g)
         else:
@@ -244,6 +246,10 @@ def synth_params(shapes: dict, seed: int = 0) -> dict:
             for d in shape[1:]:
                 fan_in *= d
             t = torch.randn(shape, generator=g) * math.sqrt(2.0 / fan_in)
+            if ".linear2.weight" in key and ".affine" in key:
+                t = t * 0.15                                       # keep activations O(1) through 5-7 blocks
+            if key == "conv_out.1.weight":
+                t = t * 0.35                                       # tanh mostly unsaturated
         out[key] = t.to(torch.float32)
     return out
 

@@ -216,3 +216,34 @@ extern "C" int xmc_contrastive_bwd(const float* A, const float* B, const float* 
     XMC_LAUNCH_CHECK();
     return 0;
 }
+
+namespace {
+__global__ void copy_ld_kernel(const float* S, int ld, float* out, int n) {
+    const int64_t total = (int64_t)n * n;
+    for (int64_t id = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; id < total; id += (int64_t)gridDim.x * blockDim.x) {
+        int i = (int)(id / n), j = (int)(id - (int64_t)i * n);
+        out[id] = S[(size_t)i * ld + j];
+    }
+}
+}  // namespace
+
+// cosine_scores (train_gan.py:85-91) alone: S[n][n] = normalize(A) normalize(B)^T  (used by make_labels, 72-83)
+extern "C" int xmc_cosine_scores(const float* A, const float* B, int n, int D, float* S, void* ws, void* stream) {
+    if (!A || !B || !S || !ws) return XMC_EINVAL;
+    if (n < 1 || D < 4 || D % 4) return XMC_EALIGN;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    Ws w = carve(ws, n, D);
+    const int rb = (w.n32 + NT / 64 - 1) / (NT / 64);
+    hipLaunchKernelGGL(normalize_rows_kernel, dim3(rb), dim3(NT), 0, st, A, w.Ah, w.ina, n, w.n32, D);
+    hipLaunchKernelGGL(normalize_rows_kernel, dim3(rb), dim3(NT), 0, st, B, w.Bh, w.inb, n, w.n32, D);
+    XMC_LAUNCH_CHECK();
+    XmcConvDesc d;
+    fill_linear_desc(d, w.Ah, w.Bh, w.S, n, D, w.n8, w.n32);
+    int rc = xmc_conv_igemm(&d, stream);
+    if (rc) return rc;
+    int64_t total = (int64_t)n * n;
+    int blocks = (int)((total + NT - 1) / NT); if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(copy_ld_kernel, dim3(blocks), dim3(NT), 0, st, w.S, w.n8, S, n);
+    XMC_LAUNCH_CHECK();
+    return 0;
+}

@@ -58,6 +58,7 @@ _SIGS = {
     "xmc_contrastive_ws_bytes": [i32, i32],
     "xmc_contrastive_fwd": [vp, vp, vp, vp, i32, i32, vp, vp, vp],
     "xmc_contrastive_bwd": [vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp],
+    "xmc_cosine_scores": [vp, vp, i32, i32, vp, vp, vp],
     "xmc_hinge_fwd": [vp, i32, f32, vp, i64, i32, vp],
     "xmc_hinge_bwd": [vp, i32, f32, vp, vp, i64, i32, vp],
     "xmc_cast": [vp, vp, i64, i32, i32, vp],

@@ -689,6 +689,17 @@ class ContrastiveFn(torch.autograd.Function):
         return da, db, None, None
 
 
+def cosine_scores(a, b):
+    """normalize(a) @ normalize(b).T -> f32 [n,n] (train_gan.py:85-91); not differentiable (label construction only)."""
+    a, b = a.detach().contiguous().float(), b.detach().contiguous().float()
+    _need_cuda(a, b)
+    n, D = a.shape
+    ws = torch.empty(L.load().xmc_contrastive_ws_bytes(n, D), dtype=torch.uint8, device=a.device)
+    s = torch.empty((n, n), dtype=torch.float32, device=a.device)
+    L.call("xmc_cosine_scores", _p(a), _p(b), n, D, _p(s), _p(ws), _st())
+    return s
+
+
 # ------------------------------------------------------------------------------------------ functional sugar
 def lrelu(x, slope=0.2):
     return LreluFn.apply(x, slope)

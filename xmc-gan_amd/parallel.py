@@ -1,0 +1,72 @@
+"""Data-parallel plumbing for the G+D step: one process per GPU, RCCL (torch.distributed 'nccl') over xGMI.
+
+The reference is single-GPU (train_gan.py:427); data parallelism is defined here by equivalence with the
+single-process step on the concatenated batch:
+  * batch-mean losses (hinge terms, MA-GP)  ->  gradient MEAN all-reduce over ranks;
+  * batch-coupled contrastive terms          ->  every rank evaluates the loss on the all-gathered embeddings
+    (identical value on all ranks); ``gather_rows`` scales its backward by world_size so that the mean
+    all-reduce reproduces the sum over ranks of the per-rank partial derivatives.
+Works on CPU tensors with the gloo backend too (used by the world_size-2 tests).
+"""
+import torch
+import torch.distributed as dist
+
+
+def world():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def rank():
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def allreduce_mean_grads(params, bucket_elems=16 * 1024 * 1024):
+    """Average ``.grad`` over ranks in flat f32 buckets (<= 64 MB each: a handful of large ring/tree
+    collectives per step instead of one per tensor).  Parameters whose grad is None are skipped; every rank
+    runs the same graph so the skip pattern is identical."""
+    W = world()
+    if W == 1:
+        return
+    grads = [p.grad for p in params if p.grad is not None]
+    bucket, n = [], 0
+
+    def flush():
+        nonlocal bucket, n
+        if not bucket:
+            return
+        flat = torch.cat([g.reshape(-1) for g in bucket])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.mul_(1.0 / W)
+        off = 0
+        for g in bucket:
+            g.copy_(flat[off:off + g.numel()].view_as(g))
+            off += g.numel()
+        bucket, n = [], 0
+
+    for g in grads:
+        if n + g.numel() > bucket_elems:
+            flush()
+        bucket.append(g)
+        n += g.numel()
+    flush()
+
+
+class _GatherRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        W = world()
+        x = x.contiguous()
+        out = torch.empty((W * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        dist.all_gather_into_tensor(out, x)
+        ctx.n = x.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        r, W = rank(), world()
+        return g[r * ctx.n:(r + 1) * ctx.n] * float(W)
+
+
+def gather_rows(x):
+    """[n, ...] -> [world*n, ...] (rank-major), differentiable; identity when not distributed."""
+    return x if world() == 1 else _GatherRows.apply(x)

@@ -1,0 +1,413 @@
+"""cfg-driven XMC-GAN / DF-GAN trainer on MI355X -- drop-in for the reference entrypoint
+(``python xmc_gan/train_gan.py --cfg xmc_gan/cfg/<preset>.yml [--gpu --seed --resume_epoch --log_type --bs --imsize]``).
+
+Same flags, registries (``_GEN_ARCH`` / ``_DISC_ARCH``), helper names (``weight_init``, ``make_labels``,
+``cosine_scores``, ``sent_loss``, ``img_loss``, ``train``, ``eval``) and the same arithmetic per iteration
+as the reference loop (train_gan.py:174-293); every tensor op on the path runs in hand-written HIP
+kernels through ``xmc_gan_amd``.  Extras that the reference lacks: ``--synthetic`` COCO-shaped random data
+(the COCO pickles / DAMSM weights are not redistributable), ``--precision``, and one-process-per-GPU data
+parallelism when launched under ``torch.distributed.run`` (gradient all-reduce + optional all-gathered
+contrastive negatives, ``--gather_negatives``).
+"""
+import os
+import sys
+
+PROJ_DIR = os.path.abspath(os.path.join(os.path.dirname(os.path.realpath(__file__)), os.pardir))
+if PROJ_DIR not in sys.path:
+    sys.path.append(PROJ_DIR)
+
+import argparse
+import random
+
+import numpy as np
+import torch
+
+from xmc_gan.config.gan import cfg, cfg_from_file
+from xmc_gan.model.df_gan import NetG as DF_GEN, NetD as DF_DISC
+from xmc_gan.model.df_concept_gan import InNetG as CONCEPT_IN_DF_GEN, OutNetG as CONCEPT_OUT_DF_GEN, NetD as CONCEPT_NETD
+from xmc_gan.utils.logger import setup_logger
+from xmc_gan.utils.miscc import count_params
+from xmc_gan_amd import ops, parallel
+from xmc_gan_amd.optim import HipAdam
+
+_GEN_ARCH = {"DF_GEN": DF_GEN, "CONCEPT_IN_DF_GEN": CONCEPT_IN_DF_GEN, "CONCEPT_OUT_DF_GEN": CONCEPT_OUT_DF_GEN}
+_DISC_ARCH = {"DF_DISC": DF_DISC, "CONCEPT_NETD": CONCEPT_NETD}
+
+
+def parse_args(argv=None):
+    parser = argparse.ArgumentParser(description='Train XMC-GAN')
+    parser.add_argument('--cfg', type=str, default='xmc_gan/cfg/df_gan_sbert_seperate.yml')
+    parser.add_argument('--gpu', dest='gpu_id', type=int, default=0)
+    parser.add_argument('--seed', type=int, default=100)
+    parser.add_argument('--resume_epoch', type=int, default=0)
+    parser.add_argument('--log_type', type=str, default='tb')
+    parser.add_argument('--bs', type=int, default=-1)
+    parser.add_argument('--imsize', type=int, default=-1)
+    # additions
+    parser.add_argument('--synthetic', type=int, default=0, metavar='N',
+                        help='train on N COCO-shaped random batches per epoch instead of data/<DATASET_NAME>')
+    parser.add_argument('--max_epoch', type=int, default=-1)
+    parser.add_argument('--precision', type=str, default=None, choices=['bf16', 'fp32'])
+    parser.add_argument('--gather_negatives', action='store_true',
+                        help='data parallel: all-gather embeddings so the contrastive losses see world*batch negatives')
+    return parser.parse_args(argv)
+
+
+def weight_init(m):
+    """Kaiming-normal (fan_in, relu gain) for every conv / linear weight, zero bias (train_gan.py:65-69)."""
+    if isinstance(m, (torch.nn.Conv2d, torch.nn.Linear)):
+        torch.nn.init.kaiming_normal_(m.weight, mode='fan_in', nonlinearity='relu')
+        if m.bias is not None:
+            torch.nn.init.constant_(m.bias, 0)
+
+
+# --------------------------------------------------------------------------------------- contrastive head
+def cosine_scores(emb0, emb1):
+    """[bs,D] x [bs,D] -> [bs,bs] cosine similarities (train_gan.py:85-91)."""
+    return ops.cosine_scores(emb0, emb1)
+
+
+def make_labels(batch_size, sent_embs, b_global, p=0.6):
+    """Positive-pair weights for the contrastive losses (train_gan.py:72-83)."""
+    labels = torch.eye(batch_size, device=sent_embs.device)
+    if b_global:
+        sim_mat = cosine_scores(sent_embs, sent_embs)
+        sim_mat.fill_diagonal_(3)
+        global_pos = (sim_mat > p) & (sim_mat < 3)
+        num_pos = global_pos.sum(1).clamp_(min=1) + 1
+        global_weight = cfg.TRAIN.SMOOTH.GLOBAL if (cfg.TRAIN.SMOOTH.GLOBAL != 0.) else torch.reciprocal(num_pos.float())
+        labels = (labels + global_weight * global_pos).clamp_(max=1)   # [bs] weight broadcasts along columns
+    return labels.detach()
+
+
+def _info_nce(a, b, labels, b_global):
+    if not b_global:
+        inv_num_pos, lab = None, None                   # labels are the identity: kernel fast path
+    elif cfg.TRAIN.SMOOTH.GLOBAL == 0.:
+        inv_num_pos, lab = torch.full((labels.size(0),), 0.5, device=labels.device), labels.contiguous()
+    else:
+        inv_num_pos, lab = torch.reciprocal((labels > 0).sum(1).float()), labels.contiguous()
+    return ops.contrastive(a, b, lab, inv_num_pos)
+
+
+def sent_loss(imgs, txts, labels, b_global):
+    """image-embedding <-> sentence-embedding symmetric InfoNCE without temperature (train_gan.py:93-115)."""
+    return _info_nce(imgs, txts, labels, b_global)
+
+
+def img_loss(real_imgs, fake_imgs, labels, b_global):
+    """real-feature <-> fake-feature symmetric InfoNCE (train_gan.py:117-139)."""
+    return _info_nce(real_imgs, fake_imgs, labels, b_global)
+
+
+# --------------------------------------------------------------------------------------- one iteration
+class StepOptions:
+    """Engine-side switches of an iteration (not part of the reference cfg)."""
+
+    def __init__(self, gather_negatives=False):
+        self.gather_negatives = gather_negatives
+
+
+def _set_requires_grad(module, flag):
+    for p_ in module.parameters():
+        p_.requires_grad_(flag)
+
+
+def gan_iteration(netG, netD, optimizerG, optimizerD, imgs, sent_embs, words_embs, mask, noise, it_state,
+                  opts=None):
+    """One pass of the reference loop body (train_gan.py:185-291) on device tensors.
+
+    Returns a dict of 0-d loss tensors (no host sync).  ``it_state['i']`` carries the N_CRITIC counter.
+    """
+    opts = opts or StepOptions()
+    T, E = cfg.TRAIN, cfg.TRAIN.ENCODER_LOSS
+    batch_size = mask.size(0)
+    gather = parallel.gather_rows if opts.gather_negatives else (lambda t: t)
+    out = {}
+
+    # ---- discriminator step (train_gan.py:187-229)
+    psent_embs = sent_embs if cfg.DISC.SEPERATE else netG.proj_sent(sent_embs.float())
+    real_features = netD(imgs)
+    outputs_real = netD.COND_DNET(real_features, sent_embs=psent_embs.detach())
+    errD_real = ops.hinge(outputs_real[0], -1.0)
+    fake = netG(noise=noise, sent_embs=sent_embs, words_embs=words_embs, mask=mask)
+    fake_features = netD(fake.detach())
+    outputs_fake = netD.COND_DNET(fake_features, sent_embs=psent_embs.detach())
+    errD_fake = ops.hinge(outputs_fake[0], 1.0)
+    mis_loss = errD_fake
+    if T.RMIS_LOSS:
+        outputs_mis = netD.COND_DNET(real_features[:(batch_size - 1)], sent_embs=psent_embs[1:batch_size].detach())
+        errD_mismatch = ops.hinge(outputs_mis[0], 1.0)
+        mis_loss = mis_loss + errD_mismatch
+        out['errD_mismatch'] = errD_mismatch.detach()
+    labels = None
+    if E.SENT or E.WORD or E.DISC or E.VGG:
+        labels = make_labels(batch_size * (parallel.world() if opts.gather_negatives else 1),
+                             sent_embs=gather(sent_embs.float()), b_global=E.B_GLOBAL)
+    enc_loss = 0.
+    if E.SENT:
+        assert cfg.DISC.SENT_MATCH or cfg.DISC.IMG_MATCH
+        ds_loss = sent_loss(imgs=gather(outputs_real[1]), txts=gather(outputs_real[2]), labels=labels, b_global=E.B_GLOBAL)
+        enc_loss = enc_loss + T.SMOOTH.SENT * ds_loss
+        out['ds_loss'] = ds_loss.detach()
+    if E.WORD:
+        raise NotImplementedError
+    errD = errD_real + (mis_loss * T.SMOOTH.MISMATCH) + enc_loss
+    netG.zero_grad()
+    netD.zero_grad()
+    errD.backward()
+    parallel.allreduce_mean_grads(netD.parameters())
+    optimizerD.step()
+    out.update(errD=errD.detach(), errD_real=errD_real.detach(), errD_fake=errD_fake.detach())
+
+    # ---- matching-aware gradient penalty on real pairs (train_gan.py:231-252)
+    if T.MAGP:
+        interpolated = imgs.detach().requires_grad_()
+        sent_inter = psent_embs.detach().requires_grad_()
+        features = netD(interpolated)
+        o = netD.COND_DNET(features, sent_inter)
+        with ops.no_wgrad():           # first-order pass only needs d(logit)/d(inputs)
+            grads = torch.autograd.grad(outputs=o[0], inputs=(interpolated, sent_inter),
+                                        grad_outputs=torch.ones_like(o[0]), retain_graph=True, create_graph=True,
+                                        only_inputs=True)
+        grad0 = grads[0].reshape(grads[0].size(0), -1)
+        grad1 = grads[1].reshape(grads[1].size(0), -1).float()
+        grad_l2norm = torch.sqrt(torch.sum(torch.cat((grad0, grad1), dim=1) ** 2, dim=1))
+        d_loss_gp = torch.mean(grad_l2norm ** 6)
+        d_loss = 2.0 * d_loss_gp
+        optimizerD.zero_grad()
+        optimizerG.zero_grad()
+        d_loss.backward()
+        # the reference's autograd hands zero (not None) grads to every bias that feeds the logit
+        # (their only path is through LeakyReLU'' == 0), which still advances Adam's moments/step.
+        for name, p_ in netD.named_parameters():
+            if p_.grad is None and name.endswith('.bias') and 'proj_match' not in name and _bias_on_logit_path(netD, name):
+                p_.grad = torch.zeros_like(p_)
+        parallel.allreduce_mean_grads(netD.parameters())
+        optimizerD.step()
+        out['d_loss_gp'] = d_loss_gp.detach()
+
+    # ---- generator step (train_gan.py:254-291)
+    it_state['i'] = it_state.get('i', 0) + 1
+    if it_state['i'] % T.N_CRITIC == 0:
+        _set_requires_grad(netD, False)          # D's weight grads would be discarded (zero_grad at 226-227)
+        try:
+            features = netD(fake)
+            outputs = netD.COND_DNET(features, sent_embs=psent_embs)
+            errG_fake = -outputs[0].float().mean()
+            enc_loss = 0.0
+            if E.SENT:
+                gs_loss = sent_loss(imgs=gather(outputs[1]), txts=gather(outputs[2]), labels=labels, b_global=E.B_GLOBAL)
+                enc_loss = enc_loss + T.SMOOTH.SENT * gs_loss
+                out['gs_loss'] = gs_loss.detach()
+            if E.WORD:
+                raise NotImplementedError
+            if E.DISC:
+                with torch.no_grad():
+                    real_pooled = ops.global_avgpool(netD(imgs).permute(0, 2, 3, 1).contiguous())
+                fake_pooled = ops.global_avgpool(features.permute(0, 2, 3, 1).contiguous())
+                disc_loss = img_loss(real_imgs=gather(real_pooled), fake_imgs=gather(fake_pooled), labels=labels,
+                                     b_global=E.B_GLOBAL)
+                enc_loss = enc_loss + T.SMOOTH.DISC * disc_loss
+                out['disc_loss'] = disc_loss.detach()
+            if E.VGG:
+                raise NotImplementedError
+            errG = errG_fake + enc_loss
+            netG.zero_grad()
+            netD.zero_grad()
+            errG.backward()
+        finally:
+            _set_requires_grad(netD, True)
+        parallel.allreduce_mean_grads(netG.parameters())
+        optimizerG.step()
+        it_state['i'] = 0
+        out.update(errG=errG.detach(), errG_fake=errG_fake.detach())
+    out['fake'] = fake.detach()
+    return out
+
+
+def _bias_on_logit_path(netD, name):
+    """conv_img.bias and the conv_s.bias of blocks whose learned shortcut is active (df_gan.py:286-288)."""
+    if name == 'conv_img.bias':
+        return True
+    if name.startswith('downblocks.') and name.endswith('.conv_s.bias'):
+        return netD.downblocks[int(name.split('.')[1])].learned_shortcut
+    return False
+
+
+# --------------------------------------------------------------------------------------- synthetic front end
+class SyntheticCOCO:
+    """COCO-shaped random batches with the tuple layout of the reference loader
+    ``(imgs, [(caps, cap_lens)], keys)`` (dataset.py:64); `caps` is the batch index used by
+    :class:`SyntheticTextEncoder`.  Images are uniform in [-1,1] like Normalize(0.5,0.5) output (dataset.py:34-37)."""
+
+    def __init__(self, n_batches, batch_size, img_size, max_len, seed):
+        self.n, self.bs, self.size, self.max_len, self.seed = n_batches, batch_size, img_size, max_len, seed
+
+    def __len__(self):
+        return self.n
+
+    def __iter__(self):
+        for i in range(self.n):
+            g = torch.Generator().manual_seed(self.seed * 100003 + i)
+            imgs = torch.rand(self.bs, 3, self.size, self.size, generator=g) * 2 - 1
+            lens = torch.randint(5, self.max_len + 1, (self.bs,), generator=g)
+            yield imgs, [((i,), lens)], [f'syn{i}_{j}' for j in range(self.bs)]
+
+
+class SyntheticTextEncoder(torch.nn.Module):
+    """Stands in for the frozen RNN/SBERT encoder (encoder.py:70,154): returns
+    words_embs [B,E,T], sent_embs [B,E], mask [B,T] (True = padding) as deterministic random tensors."""
+
+    def __init__(self, emb_dim, max_len, seed, device):
+        super().__init__()
+        self.e, self.t, self.seed, self.device = emb_dim, max_len, seed, device
+
+    def forward(self, caps, cap_lens):
+        g = torch.Generator().manual_seed(self.seed * 7919 + int(caps[0]))
+        B = cap_lens.size(0)
+        words = torch.randn(B, self.e, self.t, generator=g)
+        sent = torch.randn(B, self.e, generator=g)
+        mask = torch.arange(self.t)[None, :] >= cap_lens.cpu()[:, None]
+        return words.to(self.device), sent.to(self.device), mask.to(self.device)
+
+
+# --------------------------------------------------------------------------------------- epoch loop
+def train(train_loader, test_loader, state_epoch, text_encoder, netG, netD, optimizerG, optimizerD, logger, model_dir,
+          opts=None, img_dir=None, max_steps=None):
+    """Epoch loop with the reference's signature (train_gan.py:142); returns the last iteration's losses."""
+    device = next(netG.parameters()).device
+    it_state, last, nsteps = {}, {}, 0
+    for epoch in range(state_epoch + 1, cfg.TRAIN.MAX_EPOCH + 1):
+        netG.train()
+        netD.train()
+        for step, data in enumerate(train_loader):
+            imgs, texts_lst, keys = data
+            caps, cap_lens = texts_lst[0]
+            with torch.no_grad():
+                words_embs, sent_embs, mask = text_encoder(caps, cap_lens)
+            words_embs, sent_embs = words_embs.detach(), sent_embs.detach()
+            imgs = imgs.to(device, non_blocking=True)
+            noise = torch.randn(mask.size(0), cfg.TRAIN.NOISE_DIM).to(device)        # CPU generator, as upstream (197-198)
+            last = gan_iteration(netG, netD, optimizerG, optimizerD, imgs, sent_embs, words_embs, mask, noise,
+                                 it_state, opts)
+            if 'errG' in last:
+                logger.info(f'[{epoch}/{cfg.TRAIN.MAX_EPOCH}][{step + 1}/{len(train_loader)}] '
+                            f'Loss_D: {last["errD"].item():.3f} Loss_G: {last["errG"].item():.3f} '
+                            f'errD_real: {last["errD_real"].item():.3f} errD_fake: {last["errD_fake"].item():.3f} ')
+            nsteps += 1
+            if max_steps is not None and nsteps >= max_steps:
+                return last
+        if epoch > 50 and parallel.rank() == 0:
+            torch.save(netG.state_dict(), f'{model_dir}/netG_{epoch:03d}.pth')
+            torch.save(netD.state_dict(), f'{model_dir}/netD_{epoch:03d}.pth')
+            torch.save(optimizerG.state_dict(), f'{model_dir}/optimizerG.pth')
+            torch.save(optimizerD.state_dict(), f'{model_dir}/optimizerD.pth')
+            logger.info('Save models')
+    return last
+
+
+@torch.no_grad()
+def eval(loader, state_epoch, text_encoder, netG, logger, num_samples=6000, save_dir=None):
+    """Generate images for a loader (G forward only, train_gan.py:338-387).  FID (389-390) needs the optional
+    ``pytorch_fid`` package and image files on disk; without it only the tensors are produced."""
+    netG.eval()
+    device = next(netG.parameters()).device
+    cnt, outs = 0, []
+    for imgs, texts_lst, keys in loader:
+        caps, cap_lens = texts_lst[0]
+        words_embs, sent_embs, mask = text_encoder(caps, cap_lens)
+        noise = torch.randn(sent_embs.size(0), cfg.TRAIN.NOISE_DIM).to(device)
+        fake = netG(noise=noise, sent_embs=sent_embs, words_embs=words_embs, mask=mask)
+        outs.append(((fake + 1.0) * 127.5).clamp(0, 255).to(torch.uint8).cpu())
+        cnt += fake.size(0)
+        if cnt >= num_samples:
+            break
+    logger.info(f' epoch {state_epoch}, generated {cnt} images')
+    return torch.cat(outs) if outs else None
+
+
+def build_models(device):
+    """netG / netD from the registries + the two Adam optimizers (train_gan.py:470-484)."""
+    netG = _GEN_ARCH[cfg.GEN.ENCODER_NAME](cfg).to(device)
+    netD = _DISC_ARCH[cfg.DISC.ENCODER_NAME](cfg, is_disc=True).to(device)
+    if cfg.TRAIN.HE_INIT:
+        netG.apply(weight_init)
+        netD.apply(weight_init)
+    O = cfg.TRAIN.OPT
+    optimizerG = HipAdam(netG.parameters(), lr=O.G_LR, betas=(O.G_BETA1, O.G_BETA2))
+    optimizerD = HipAdam(netD.parameters(), lr=O.D_LR, betas=(O.D_BETA1, O.D_BETA2))
+    return netG, netD, optimizerG, optimizerD
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    cfg_from_file(args.cfg)
+    if args.imsize != -1:
+        cfg.IMG.SIZE = args.imsize
+    if args.bs != -1:
+        cfg.TRAIN.BATCH_SIZE = args.bs
+    if args.max_epoch != -1:
+        cfg.TRAIN.MAX_EPOCH = args.max_epoch
+    if args.precision:
+        ops.set_precision(args.precision)
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', str(args.gpu_id)))
+    if not torch.cuda.is_available():
+        raise RuntimeError('xmc_gan/train_gan.py needs an MI355X (HIP kernels only; the CPU restatement lives in oracle/)')
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        torch.distributed.init_process_group('nccl')
+    rank = parallel.rank()
+
+    seed = args.seed + rank
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    torch.cuda.manual_seed_all(seed)
+
+    output_dir = f'{PROJ_DIR}/output/{cfg.DATASET_NAME}{cfg.IMG.SIZE}_{cfg.CONFIG_NAME}_{args.seed}'
+    img_dir, log_dir, model_dir = output_dir + '/img', output_dir + '/log', output_dir + '/model'
+    if rank == 0:
+        for d_ in (output_dir, img_dir, log_dir, model_dir):
+            os.makedirs(d_, exist_ok=True)
+    logger = setup_logger(name=cfg.CONFIG_NAME, save_dir=log_dir if rank == 0 else None, distributed_rank=rank)
+    logger.info('Using config:')
+    logger.info(cfg)
+    logger.info(f'seed now is : {args.seed}')
+
+    if args.synthetic <= 0:
+        raise RuntimeError(
+            'real-data front end (dataset.py COCO pickles + frozen DAMSM/SBERT encoder weights) is not part of this '
+            'build; run with --synthetic N for COCO-shaped random batches')
+    train_loader = SyntheticCOCO(args.synthetic, cfg.TRAIN.BATCH_SIZE, cfg.IMG.SIZE, cfg.TEXT.MAX_LENGTH, seed)
+    text_encoder = SyntheticTextEncoder(cfg.TEXT.EMBEDDING_DIM, cfg.TEXT.MAX_LENGTH, seed, device)
+
+    netG, netD, optimizerG, optimizerD = build_models(device)
+    if world > 1:   # same initial weights on every rank
+        for p_ in list(netG.parameters()) + list(netD.parameters()):
+            torch.distributed.broadcast(p_.data, 0)
+    logger.info(f'netG # of parameters: {count_params(netG)}')
+    logger.info(f'netD # of parameters: {count_params(netD)}')
+
+    state_epoch = args.resume_epoch
+    if state_epoch != 0:
+        netG.load_state_dict(torch.load(f'{model_dir}/netG_{state_epoch:03d}.pth', map_location=device))
+        netD.load_state_dict(torch.load(f'{model_dir}/netD_{state_epoch:03d}.pth', map_location=device))
+        logger.info(f'Load models, epoch : {state_epoch}')
+    elif cfg.DISC.ENCODER_DIR:
+        netD.load_state_dict(torch.load(f'{PROJ_DIR}/{cfg.DISC.ENCODER_DIR}', map_location=device), strict=False)
+
+    last = train(train_loader=train_loader, test_loader=None, state_epoch=state_epoch, text_encoder=text_encoder,
+                 netG=netG, netD=netD, optimizerG=optimizerG, optimizerD=optimizerD, logger=logger, model_dir=model_dir,
+                 opts=StepOptions(gather_negatives=args.gather_negatives), img_dir=img_dir)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+    return last
+
+
+if __name__ == '__main__':
+    main()
