@@ -1,0 +1,186 @@
+"""Benchmark of the XMC-GAN G+D training iteration on MI355X (metric and configs: BASELINE.json).
+
+    python bench.py [--gpus N --steps K --warmup W] [--imsize 256 --batch B --cfg df_gan_damsm_nomagp.yml]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one full iteration of the reference loop body (train_gan.py:185-291: D step, optional MA-GP, G step,
+both Adam updates) on one synthetic COCO-shaped batch that is already resident in HBM.  One process per GPU;
+weak scaling (per-GPU batch fixed); value = images of all ranks / max-over-ranks time.  Rank 0 prints ONE JSON line
+carrying, besides the throughput, `roofline` (the dominant kernel family -- the MFMA implicit-GEMM convolution --
+timed per launch with HIP events on the launch stream) and `cpu_baseline` (the CPU oracle timed on this host).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p_ in (ROOT, os.path.join(ROOT, "oracle")):
+    if p_ not in sys.path:
+        sys.path.insert(0, p_)
+
+import torch
+
+# algorithmic FLOPs per image of one minimal G+D iteration = 9*D + 3*G forward-equivalents
+STEP_GFLOP = {(64, False): 8.74, (128, False): 36.48, (256, False): 147.4,
+              (64, True): 12.69, (128, True): 53.30, (256, True): 215.7}
+PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_F32_TFLOPS = 157.3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--imsize", type=int, default=256)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
+    ap.add_argument("--cfg", type=str, default="df_gan_damsm_nomagp.yml")
+    ap.add_argument("--precision", type=str, default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--gather_negatives", action="store_true", help="BASELINE config 5: all-gather contrastive negatives")
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--no_roofline", action="store_true")
+    return ap.parse_args()
+
+
+def host_cores():
+    """CPU threads this process may really use: affinity mask, capped by the cgroup CPU quota when there is one
+    (os.cpu_count() reports the whole host and badly oversubscribes a container with a CPU share)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 64))
+
+
+def cpu_baseline(cfg, cfg_name, imsize, seconds_budget=25.0):
+    """Time the CPU oracle (oracle/xmc_ref.py, the parity checker) on this host: same cfg and image size, batch 2."""
+    import xmc_ref as X
+    h = X.Hyper.from_cfg(cfg)
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    B = 2
+    PG, PD = X.synth_params(X.gen_shapes(h), 1), X.synth_params(X.netd_shapes(h), 2)
+    optG, optD = X.AdamState(h.g_lr, h.g_betas), X.AdamState(h.d_lr, h.d_betas)
+    batch = X.synth_batch(h, B, seed=1)
+    X.train_step(PG, PD, optG, optD, h, batch)          # warm-up (allocator, thread pool)
+    t0, n = time.perf_counter(), 0
+    while True:
+        X.train_step(PG, PD, optG, optD, h, batch)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt > seconds_budget or n >= 5:
+            break
+    return dict(value=round(B * n / dt, 4), unit="images/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{n} full G+D iterations of oracle/xmc_ref.py (PyTorch CPU fp32), {imsize}x{imsize}, batch {B}, {cfg_name}")
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product has no CPU path (the CPU oracle is only the baseline leg)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        torch.distributed.init_process_group("nccl", device_id=dev)
+
+    from xmc_gan.config import gan
+    import xmc_gan.train_gan as tg
+    from xmc_gan_amd import ops, prof
+    ops.set_precision(a.precision)
+    gan.reset_cfg()
+    gan.cfg_from_file(os.path.join(ROOT, "xmc_gan", "cfg", a.cfg))
+    cfg = gan.cfg
+    cfg.IMG.SIZE, cfg.TRAIN.BATCH_SIZE = a.imsize, a.batch
+    torch.manual_seed(100 + rank)
+    netG, netD, optG, optD = tg.build_models(dev)
+    if world > 1:
+        for p_ in list(netG.parameters()) + list(netD.parameters()):
+            torch.distributed.broadcast(p_.data, 0)
+    # block gammas start at 0 in the reference (df_gan.py:195,281); give them a value so no branch is dead weight
+    with torch.no_grad():
+        for n_, p_ in list(netG.named_parameters()) + list(netD.named_parameters()):
+            if n_.endswith("gamma"):
+                p_.fill_(0.1)
+
+    B, S, E, T = a.batch, a.imsize, cfg.TEXT.EMBEDDING_DIM, cfg.TEXT.MAX_LENGTH
+    g = torch.Generator().manual_seed(100 + rank)
+    nb = 4                                                    # a few distinct resident batches, cycled
+    data = []
+    for _ in range(nb):
+        lens = torch.randint(5, T + 1, (B,), generator=g)
+        data.append(dict(imgs=(torch.rand(B, 3, S, S, generator=g) * 2 - 1).to(dev),
+                         sent=torch.randn(B, E, generator=g).to(dev), words=torch.randn(B, E, T, generator=g).to(dev),
+                         mask=(torch.arange(T)[None, :] >= lens[:, None]).to(dev),
+                         noise=torch.randn(B, cfg.TRAIN.NOISE_DIM, generator=g).to(dev)))
+    opts = tg.StepOptions(gather_negatives=a.gather_negatives)
+    state = {}
+
+    def step(i):
+        d = data[i % nb]
+        return tg.gan_iteration(netG, netD, optG, optD, d["imgs"], d["sent"], d["words"], d["mask"], d["noise"], state, opts)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        last = step(a.warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = t.item()
+    finite = all(torch.isfinite(v).all().item() for k, v in last.items() if k != "fake")
+
+    roof = None
+    if not a.no_roofline and rank == 0:
+        # one more iteration with every conv launch bracketed by HIP events on the launch stream
+        prof.enable()
+        step(a.warmup + a.steps)
+        torch.cuda.synchronize()
+        roof = prof.summary(PEAK_BF16_TFLOPS if a.precision == "bf16" else PEAK_F32_TFLOPS)
+        prof.disable()
+
+    if rank == 0:
+        magp = bool(cfg.TRAIN.MAGP)
+        imgs_s = world * B * a.steps / dt
+        gf = STEP_GFLOP.get((S, magp))
+        out = dict(metric="images/sec per G+D step", value=round(imgs_s, 2), unit="images/s", n_gpus=world, steps=a.steps,
+                   warmup=a.warmup, ms_per_step=round(1e3 * dt / a.steps, 3), higher_is_better=True, scaling="weak",
+                   vs_baseline=None, dtype=a.precision if a.precision == "bf16" else "f32", data="synthetic",
+                   config=dict(workload=f"{S}x{S} COCO-shaped synthetic batch, {B} images per GPU, one full G+D iteration "
+                                        f"(D step{' + MA-GP' if magp else ''} + G step + Adam x{3 if magp else 2}), {a.cfg}",
+                               per_gpu_batch=B, global_batch=B * world, image_size=S, cfg=a.cfg,
+                               parallelism=f"dp{world}" + ("+gather" if a.gather_negatives else ""),
+                               losses_finite=finite),
+                   step_algorithmic_tflops=None if gf is None else round(imgs_s * gf / 1e3, 2),
+                   step_frac_of_bf16_peak=None if gf is None else round(imgs_s * gf / 1e3 / (PEAK_BF16_TFLOPS * world), 4))
+        if roof is not None:
+            out["roofline"] = roof
+        if not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, a.cfg, S)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

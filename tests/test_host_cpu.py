@@ -1,0 +1,93 @@
+"""CPU-only checks of the host side: C-ABI library exports, cfg schema/merge rules, module state_dict parity with the
+oracle's key tables (pinned to the reference by the golden test), preset loading."""
+import ctypes
+import glob
+import os
+import re
+
+import pytest
+import torch
+
+import xmc_ref as X
+from golden_util import CFG_DIR, ROOT
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    import xmc_gan_amd.lib as L
+    lib = L.load()
+    hdr = open(os.path.join(ROOT, "include", "xmc_gan_hip.h")).read()
+    declared = set(re.findall(r"\b(xmc_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/xmc_gan_hip.h but not exported"
+    assert set(L.EXPORTS) == declared
+    assert lib.xmc_abi_version() == 1
+    # argument validation happens before any launch, so it is safe without a GPU
+    d = L.ConvDesc()
+    assert lib.xmc_conv_igemm(ctypes.byref(d), None) == -1
+    assert lib.xmc_conv_wgrad(ctypes.byref(d), None, None) == -1
+    assert ctypes.sizeof(L.ConvDesc) == 320 and ctypes.sizeof(L.AdamEntry) == 48
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    import xmc_gan_amd.lib as L
+    monkeypatch.setattr(L, "_lib", None)
+    monkeypatch.setattr(L, "LIB_PATH", "/nonexistent/libxmc_gan_hip.so")
+    with pytest.raises(RuntimeError, match="no CPU/PyTorch fallback"):
+        L.load()
+
+
+def test_ops_refuse_cpu_tensors():
+    from xmc_gan_amd import ops
+    with pytest.raises(RuntimeError, match="GPU only"):
+        ops.conv2d(torch.zeros(1, 4, 4, 8), torch.nn.Parameter(torch.zeros(8, 8, 3, 3)), None, ops.ConvGeom(8, 8, 3, 1, 1))
+
+
+def test_cfg_merge_rules():
+    from xmc_gan.config import gan
+    gan.reset_cfg()
+    with pytest.raises(KeyError):
+        gan._merge_a_into_b(gan.AttrDict({"NOPE": 1}), gan.cfg)
+    with pytest.raises(ValueError):
+        gan._merge_a_into_b(gan.AttrDict({"TRAIN": {"NCH": "32"}}), gan.cfg)
+    gan._merge_a_into_b(gan.AttrDict({"TRAIN": {"NCH": 16, "SMOOTH": {"SENT": 0.25}}}), gan.cfg)
+    assert gan.cfg.TRAIN.NCH == 16 and gan.cfg.TRAIN.SMOOTH.SENT == 0.25 and gan.cfg.TRAIN.SMOOTH.DISC == 1.0
+    gan.reset_cfg()
+    assert gan.cfg.TRAIN.NCH == 32 and gan.cfg.DISC.SPEC_NORM is True
+
+
+@pytest.mark.parametrize("yml", sorted(os.path.basename(f) for f in glob.glob(os.path.join(CFG_DIR, "*.yml"))))
+def test_presets_load_and_modules_match_reference_state_dict(yml):
+    from xmc_gan.config import gan
+    import xmc_gan.train_gan as tg
+    gan.reset_cfg()
+    gan.cfg_from_file(os.path.join(CFG_DIR, yml))
+    cfg = gan.cfg
+    h = X.Hyper.from_cfg(cfg)
+    if cfg.DISC.ENCODER_NAME == "CONCEPT_NETD":
+        with pytest.raises(NotImplementedError):
+            tg._DISC_ARCH[cfg.DISC.ENCODER_NAME](cfg, is_disc=True)        # as upstream (df_concept_gan.py:587)
+        return
+    for size in (64, 128, 256):
+        cfg.IMG.SIZE = size
+        h.img_size = size
+        netD = tg._DISC_ARCH[cfg.DISC.ENCODER_NAME](cfg, is_disc=True)
+        assert {k: tuple(v.shape) for k, v in netD.state_dict().items()} == X.netd_shapes(h)
+        try:
+            netG = tg._GEN_ARCH[cfg.GEN.ENCODER_NAME](cfg)
+        except NotImplementedError:
+            continue
+        assert {k: tuple(v.shape) for k, v in netG.state_dict().items()} == X.gen_shapes(h)
+        # weight_init reaches every conv/linear exactly like upstream's isinstance checks
+        n_init = sum(isinstance(m, (torch.nn.Conv2d, torch.nn.Linear)) for m in netG.modules())
+        assert n_init == sum(1 for k in X.gen_shapes(h) if k.endswith(".weight") and ".gn" not in k and "proj_edge" not in k) \
+            or cfg.GEN.ENCODER_NAME != "DF_GEN"
+
+
+def test_cli_flags_match_reference():
+    import xmc_gan.train_gan as tg
+    a = tg.parse_args([])
+    assert (a.cfg, a.gpu_id, a.seed, a.resume_epoch, a.log_type, a.bs, a.imsize) == \
+        ('xmc_gan/cfg/df_gan_sbert_seperate.yml', 0, 100, 0, 'tb', -1, -1)
+    assert set(tg._GEN_ARCH) == {"DF_GEN", "CONCEPT_IN_DF_GEN", "CONCEPT_OUT_DF_GEN"}
+    assert set(tg._DISC_ARCH) == {"DF_DISC", "CONCEPT_NETD"}

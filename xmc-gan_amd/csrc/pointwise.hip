@@ -96,11 +96,15 @@ __global__ void dot_kernel(const void* a, const void* b, float* out, int64_t n8)
     }
 }
 
-// out[c] += sum_r x[r][c];  thread owns channel chunk (tid % C8) and strides over rows
+// out[c] += sum_r x[r][c];  thread owns one 8-channel chunk and strides over rows; blockIdx.y walks
+// over groups of NT chunks when C/8 > NT (e.g. the 4096-wide proj_noise bias)
 template <int DT>
 __global__ void colsum_kernel(const void* x, float* out, int64_t rows, int C8) {
-    const int groups = NT / C8;                       // row-lanes per block
-    const int cc = threadIdx.x % C8, g = threadIdx.x / C8;
+    const int c8_base = blockIdx.y * NT;
+    const int c8_here = min(C8 - c8_base, NT);
+    const int groups = NT / c8_here;                  // row-lanes per block
+    const int cl = threadIdx.x % c8_here, g = threadIdx.x / c8_here;
+    const int cc = c8_base + cl;
     float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (g < groups)
         for (int64_t r = (int64_t)blockIdx.x * groups + g; r < rows; r += (int64_t)gridDim.x * groups) {
@@ -113,13 +117,13 @@ __global__ void colsum_kernel(const void* x, float* out, int64_t rows, int C8) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) red[threadIdx.x * 8 + k] = s[k];
     __syncthreads();
-    if (threadIdx.x < C8) {
+    if (threadIdx.x < c8_here) {
         float t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (int gg = 0; gg < groups; ++gg)
 #pragma unroll
-            for (int k = 0; k < 8; ++k) t[k] += red[(gg * C8 + threadIdx.x) * 8 + k];
+            for (int k = 0; k < 8; ++k) t[k] += red[(gg * c8_here + threadIdx.x) * 8 + k];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) atomicAdd(&out[threadIdx.x * 8 + k], t[k]);
+        for (int k = 0; k < 8; ++k) atomicAdd(&out[(c8_base + threadIdx.x) * 8 + k], t[k]);
     }
 }
 
@@ -408,9 +412,9 @@ extern "C" int xmc_dot(const void* a, const void* b, float* out, int64_t n, int 
     return 0;
 }
 extern "C" int xmc_colsum(const void* x, float* out, int64_t rows, int C, int dtype, void* s) {
-    if (C % 8 || C / 8 > NT) return XMC_EALIGN;
-    const int C8 = C / 8, groups = NT / C8;
-    dim3 g(nblocks(rows, groups * 8, 1024)), blk(NT);
+    if (C % 8) return XMC_EALIGN;
+    const int C8 = C / 8, groups = C8 >= NT ? 1 : NT / C8;
+    dim3 g(nblocks(rows, groups * 8, 1024), (C8 + NT - 1) / NT), blk(NT);
     if (dtype == XMC_BF16) hipLaunchKernelGGL((colsum_kernel<XMC_BF16>), g, blk, 0, ST(s), x, out, rows, C8);
     else if (dtype == XMC_F32) hipLaunchKernelGGL((colsum_kernel<XMC_F32>), g, blk, 0, ST(s), x, out, rows, C8);
     else return XMC_EINVAL;

@@ -16,6 +16,7 @@ import weakref
 import torch
 
 from . import lib as L
+from . import prof
 
 # ------------------------------------------------------------------------------------------ config
 _state = threading.local()
@@ -189,7 +190,8 @@ def _conv_fwd_raw(x, w, bias, geom, act, out_dtype, res=None, alpha=None, up=Fal
         assert bias.dtype == torch.float32 and bias.numel() >= cd_p, "bias must be f32 and padded to the stored channels"
     if res is not None:
         assert res.shape == y.shape and res.dtype == out_dtype and res.is_contiguous()
-    L.check(L.load().xmc_conv_igemm(C.byref(d), _st()), "xmc_conv_igemm(fwd)")
+    with prof.launch("igemm_kernel (conv fwd+dgrad, MFMA implicit GEMM)", 2.0 * N * OH * OW * geom.cout * geom.cin * geom.k * geom.k):
+        L.check(L.load().xmc_conv_igemm(C.byref(d), _st()), "xmc_conv_igemm(fwd)")
     return y
 
 
@@ -225,7 +227,8 @@ def _conv_dgrad_raw(dy, w, geom, in_hw, in_dtype):
             _fill_taps(d, cls, taps)
             d.dph[cls], d.dpw[cls] = ph, pw
     d.ntaps = ntaps
-    L.check(L.load().xmc_conv_igemm(C.byref(d), _st()), "xmc_conv_igemm(dgrad)")
+    with prof.launch("igemm_kernel (conv fwd+dgrad, MFMA implicit GEMM)", 2.0 * N * OH * OW * geom.cout * geom.cin * geom.k * geom.k):
+        L.check(L.load().xmc_conv_igemm(C.byref(d), _st()), "xmc_conv_igemm(dgrad)")
     return dx
 
 
@@ -245,7 +248,8 @@ def _conv_wgrad_raw(x, dy, geom, scale=None, up=False):
     d.ntaps, d.nclass, d.CDw = geom.k * geom.k, 1, rows
     d.dtype, d.out_dtype = _code(x.dtype), L.F32
     _fill_taps(d, 0, [(kh - geom.p, kw - geom.p, kh * geom.k + kw) for kh in range(geom.k) for kw in range(geom.k)])
-    L.check(L.load().xmc_conv_wgrad(C.byref(d), _p(dwp), _st()), "xmc_conv_wgrad")
+    with prof.launch("wgrad_kernel (conv weight gradient, MFMA + split-K atomics)", 2.0 * N * OH * OW * geom.cout * geom.cin * geom.k * geom.k):
+        L.check(L.load().xmc_conv_wgrad(C.byref(d), _p(dwp), _st()), "xmc_conv_wgrad")
     gw = torch.empty((geom.cout, geom.cin, geom.k, geom.k), dtype=torch.float32, device=x.device)
     L.call("xmc_unpack_wgrad", _p(dwp), _p(gw), geom.cout, geom.cin, geom.k, geom.k, rows, CS, _p(scale),
            _p(geom.perm_dev(x.device)), 0, _st())
