@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--cfg", type=str, default="df_gan_damsm_nomagp.yml")
     ap.add_argument("--precision", type=str, default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--gather_negatives", action="store_true", help="BASELINE config 5: all-gather contrastive negatives")
+    ap.add_argument("--graph", type=int, default=-1, help="replay the iteration as a hipGraph (default: on for 1 GPU)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_roofline", action="store_true")
     return ap.parse_args()
@@ -127,9 +128,24 @@ def main():
     opts = tg.StepOptions(gather_negatives=a.gather_negatives)
     state = {}
 
-    def step(i):
+    def eager(imgs, sent, words, mask, noise, st):
+        return tg.gan_iteration(netG, netD, optG, optD, imgs, sent, words, mask, noise, st, opts)
+
+    use_graph = (world == 1) if a.graph < 0 else bool(a.graph)
+    graphed = None
+    if use_graph:
+        from xmc_gan_amd.graph import GraphedIteration
+        d0 = data[0]
+        graphed = GraphedIteration(eager, (d0["imgs"], d0["sent"], d0["words"], d0["mask"], d0["noise"]),
+                                   n_critic=cfg.TRAIN.N_CRITIC, warmup=2)
+        for i in range(3):                       # 2 eager warm-ups + the capture itself, outside the timed region
+            graphed(d0["imgs"], d0["sent"], d0["words"], d0["mask"], d0["noise"])
+
+    def step(i, force_eager=False):
         d = data[i % nb]
-        return tg.gan_iteration(netG, netD, optG, optD, d["imgs"], d["sent"], d["words"], d["mask"], d["noise"], state, opts)
+        if graphed is not None and not force_eager:
+            return graphed(d["imgs"], d["sent"], d["words"], d["mask"], d["noise"])
+        return eager(d["imgs"], d["sent"], d["words"], d["mask"], d["noise"], state)
 
     def barrier():
         if world > 1:
@@ -154,9 +170,13 @@ def main():
     if not a.no_roofline and rank == 0:
         # one more iteration with every conv launch bracketed by HIP events on the launch stream
         prof.enable()
-        step(a.warmup + a.steps)
+        step(a.warmup + a.steps, force_eager=True)
         torch.cuda.synchronize()
         roof = prof.summary(PEAK_BF16_TFLOPS if a.precision == "bf16" else PEAK_F32_TFLOPS)
+        if os.environ.get("XMC_PROF_SHAPES"):
+            for fam, tag, n, ms, tf in prof.by_shape()[:60]:
+                print(f"{fam:14s} {tag:60s} n={n:3d} {ms:8.3f} ms {tf:8.1f} TF/s", file=sys.stderr)
+            print(f"max memory allocated: {torch.cuda.max_memory_allocated() / 2**30:.2f} GiB", file=sys.stderr)
         prof.disable()
 
     if rank == 0:
@@ -169,7 +189,7 @@ def main():
                    config=dict(workload=f"{S}x{S} COCO-shaped synthetic batch, {B} images per GPU, one full G+D iteration "
                                         f"(D step{' + MA-GP' if magp else ''} + G step + Adam x{3 if magp else 2}), {a.cfg}",
                                per_gpu_batch=B, global_batch=B * world, image_size=S, cfg=a.cfg,
-                               parallelism=f"dp{world}" + ("+gather" if a.gather_negatives else ""),
+                               parallelism=f"dp{world}" + ("+gather" if a.gather_negatives else ""), hipgraph=bool(use_graph),
                                losses_finite=finite),
                    step_algorithmic_tflops=None if gf is None else round(imgs_s * gf / 1e3, 2),
                    step_frac_of_bf16_peak=None if gf is None else round(imgs_s * gf / 1e3 / (PEAK_BF16_TFLOPS * world), 4))

@@ -13,6 +13,21 @@ class HipAdam(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
         self._tables = {}
         self._chunk = None
+        self._arena, self._arena_off = None, 0
+
+    def _pinned(self, nbytes):
+        """slice of a pinned host arena that was allocated before any stream capture started"""
+        if self._arena is None or self._arena_off + nbytes > self._arena.numel():
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("HipAdam: pinned staging arena exhausted during graph capture; run a warm-up step first")
+            total = sum(p.numel() for g in self.param_groups for p in g["params"])
+            nparams = sum(len(g["params"]) for g in self.param_groups)
+            per_table = 64 * nparams + 8 * (total // 4096 + nparams) + 256
+            self._arena = torch.empty(max(16 * per_table, nbytes), dtype=torch.uint8).pin_memory()
+            self._arena_off = 0
+        out = self._arena[self._arena_off: self._arena_off + nbytes]
+        self._arena_off += nbytes
+        return out
 
     def _state_for(self, p):
         st = self.state[p]
@@ -40,10 +55,15 @@ class HipAdam(torch.optim.Optimizer):
             ents[i].m, ents[i].v = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
             ents[i].step, ents[i].n = st["step"].data_ptr(), p.numel()
             chunks += [(i, c) for c in range((p.numel() + self._chunk - 1) // self._chunk)]
-        tab = torch.frombuffer(bytearray(bytes(ents)), dtype=torch.uint8).to(device)
-        ch = torch.tensor(chunks, dtype=torch.int32).to(device)
-        if len(self._tables) > 16:
-            self._tables.clear()
+        # pinned staging (allocated outside capture) + async copies: legal inside hipGraph capture
+        raw = bytes(ents)
+        chb = torch.tensor(chunks, dtype=torch.int32).numpy().tobytes()
+        n0, n1 = (len(raw) + 63) // 64 * 64, (len(chb) + 63) // 64 * 64
+        tab_h, ch_h = self._pinned(n0), self._pinned(n1)
+        tab_h[: len(raw)].copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
+        ch_h[: len(chb)].copy_(torch.frombuffer(bytearray(chb), dtype=torch.uint8))
+        tab = tab_h.to(device, non_blocking=True)
+        ch = ch_h.to(device, non_blocking=True).view(torch.int32)
         self._tables[key] = (tab, ch, len(ps), len(chunks))
         return self._tables[key]
 
