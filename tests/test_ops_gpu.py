@@ -53,6 +53,13 @@ CONV_CASES = [
     (64, 128, 1, 1, 0, 8, 2),      # 1x1 shortcut, BN=128 tile
     (256, 256, 3, 1, 1, 4, 9),     # deep K, 128x128 tiles, M=144 (tail)
     (8, 8, 3, 1, 1, 32, 1),        # NCH=8 sized layer
+    # halo-tile kernel (conv_tile.hip): unit-stride bf16 layers on >= 16x16 maps
+    (64, 32, 3, 1, 1, 32, 2),      # 64-channel slab, BN=32, 8x32 tiles
+    (32, 64, 3, 1, 1, 16, 3),      # 32-channel slab, BN=64, 16x16 tiles
+    (128, 128, 3, 1, 1, 16, 2),    # two slabs, BN=128
+    (64, 64, 4, 2, 1, 32, 2),      # forward on the gather kernel, dgrad = 4 parity classes of 2x2 taps on the tile kernel
+    (32, 64, 1, 1, 0, 32, 2),      # 1x1 shortcut
+    (192, 32, 3, 1, 1, 64, 1),     # three slabs, 64x64 map
 ]
 
 

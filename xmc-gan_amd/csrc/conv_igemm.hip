@@ -19,6 +19,7 @@
 // 273,276,280 and the input-gradient halves of errD.backward()/d_loss.backward()/errG.backward()
 // (train_gan.py:228,251,288).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -260,6 +261,8 @@ int dispatch(const XmcConvDesc& d, hipStream_t st) {
 
 }  // namespace
 
+int xmc_conv_tile_try(const XmcConvDesc* d, const float* const* pro, void* stream);   // conv_tile.hip
+
 extern "C" int xmc_conv_igemm(const XmcConvDesc* d, void* stream) {
     if (!d || !d->src || !d->wpk || !d->dst) return XMC_EINVAL;
     if (d->dtype != XMC_BF16 && d->dtype != XMC_F32) return XMC_EINVAL;
@@ -274,6 +277,11 @@ extern "C" int xmc_conv_igemm(const XmcConvDesc* d, void* stream) {
         if ((d->MH - 1) * d->DA + d->dph[z] >= d->DH || (d->MW - 1) * d->DA + d->dpw[z] >= d->DW || d->dph[z] < 0 || d->dpw[z] < 0)
             return XMC_ESHAPE;
     if ((int64_t)d->N * d->MH * d->MW >= (1ll << 31)) return XMC_ESHAPE;
+    static const bool no_tile = getenv("XMC_NO_TILE") != nullptr;
+    if (!no_tile) {                       // halo-tile kernel for unit-stride bf16 layers on >= 16x16 maps
+        int rc = xmc_conv_tile_try(d, nullptr, stream);
+        if (rc <= 0) return rc;
+    }
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     return d->dtype == XMC_BF16 ? dispatch<XMC_BF16>(*d, st) : dispatch<XMC_F32>(*d, st);
 }

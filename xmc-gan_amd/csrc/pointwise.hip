@@ -106,13 +106,25 @@ __global__ void colsum_kernel(const void* x, float* out, int64_t rows, int C8) {
     const int cl = threadIdx.x % c8_here, g = threadIdx.x / c8_here;
     const int cc = c8_base + cl;
     float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (g < groups)
-        for (int64_t r = (int64_t)blockIdx.x * groups + g; r < rows; r += (int64_t)gridDim.x * groups) {
+    if (g < groups) {
+        const int64_t step = (int64_t)gridDim.x * groups;
+        int64_t r = (int64_t)blockIdx.x * groups + g;
+        for (; r + 3 * step < rows; r += 4 * step) {       // 4 independent 16-byte loads in flight per thread
+            float v0[8], v1[8], v2[8], v3[8];
+            Vec8<DT>::load(x, r * C8 + cc, v0);
+            Vec8<DT>::load(x, (r + step) * C8 + cc, v1);
+            Vec8<DT>::load(x, (r + 2 * step) * C8 + cc, v2);
+            Vec8<DT>::load(x, (r + 3 * step) * C8 + cc, v3);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s[k] += (v0[k] + v1[k]) + (v2[k] + v3[k]);
+        }
+        for (; r < rows; r += step) {
             float v[8];
             Vec8<DT>::load(x, r * C8 + cc, v);
 #pragma unroll
             for (int k = 0; k < 8; ++k) s[k] += v[k];
         }
+    }
     __shared__ float red[NT * 8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) red[threadIdx.x * 8 + k] = s[k];
