@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--imsize", type=int, default=256)
-    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (BASELINE configs 4/5: 256 per GPU)")
     ap.add_argument("--cfg", type=str, default="df_gan_damsm_nomagp.yml")
     ap.add_argument("--precision", type=str, default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--gather_negatives", action="store_true", help="BASELINE config 5: all-gather contrastive negatives")
@@ -91,10 +91,15 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU path (the CPU oracle is only the baseline leg)")
+    local_rank %= max(torch.cuda.device_count(), 1)      # (rehearsals with more ranks than GPUs share a device over gloo)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        torch.distributed.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("XMC_DIST_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=dev)
+        else:
+            torch.distributed.init_process_group(backend)
 
     from xmc_gan.config import gan
     import xmc_gan.train_gan as tg
@@ -167,17 +172,19 @@ def main():
     finite = all(torch.isfinite(v).all().item() for k, v in last.items() if k != "fake")
 
     roof = None
-    if not a.no_roofline and rank == 0:
-        # one more iteration with every conv launch bracketed by HIP events on the launch stream
+    if not a.no_roofline:
+        # one more iteration (on EVERY rank: it contains the collectives) with each conv launch bracketed by HIP
+        # events on the launch stream; rank 0 reports
         prof.enable()
         step(a.warmup + a.steps, force_eager=True)
         torch.cuda.synchronize()
         roof = prof.summary(PEAK_BF16_TFLOPS if a.precision == "bf16" else PEAK_F32_TFLOPS)
-        if os.environ.get("XMC_PROF_SHAPES"):
+        if os.environ.get("XMC_PROF_SHAPES") and rank == 0:
             for fam, tag, n, ms, tf in prof.by_shape()[:60]:
                 print(f"{fam:14s} {tag:60s} n={n:3d} {ms:8.3f} ms {tf:8.1f} TF/s", file=sys.stderr)
             print(f"max memory allocated: {torch.cuda.max_memory_allocated() / 2**30:.2f} GiB", file=sys.stderr)
         prof.disable()
+        barrier()
 
     if rank == 0:
         magp = bool(cfg.TRAIN.MAGP)
