@@ -107,18 +107,18 @@ def compare_losses(prod, orac, rtol, atol):
 
 
 def compare_grads(tap_rec, oracle_grads, rtol, name=""):
-    """Per-tensor relative L2 error of every gradient; None-ness must match.  One-element parameters (the block
-    gammas: d/dgamma = <dout, residual>, a heavily cancelling sum) are compared on the scale of the largest
-    scalar gradient in the same backward instead of their own magnitude."""
+    """Per-tensor relative L2 error of every gradient; None-ness must match.  Parameters with <= 4 elements (the block
+    gammas: d/dgamma = <dout, residual>, and conv_out's 3-channel bias: heavily cancelling sums over every pixel) are
+    compared on the scale of the largest such gradient in the same backward instead of their own magnitude."""
     worst = 0.0
-    sc_scale = max([go.abs().item() for go in oracle_grads.values() if go is not None and go.numel() == 1] + [0.0])
+    sc_scale = max([go.abs().max().item() for go in oracle_grads.values() if go is not None and go.numel() <= 4] + [0.0])
     for n, go in oracle_grads.items():
         gp = tap_rec.get(n)
         assert (gp is None) == (go is None), f"{name}{n}: None-ness differs (product {gp is None}, oracle {go is None})"
         if go is None:
             continue
-        if go.numel() == 1:
-            err = abs(gp.item() - go.item()) / max(sc_scale, 1e-12)
+        if go.numel() <= 4:      # gammas and the 3-channel conv_out bias: sums over every pixel with heavy cancellation
+            err = (gp - go).abs().max().item() / max(sc_scale, 1e-12)
         else:
             den = go.norm().item()
             err = (gp - go).norm().item() / den if den > 0 else gp.norm().item()

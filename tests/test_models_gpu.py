@@ -17,7 +17,7 @@ if torch.cuda.is_available():
     from parity_util import (DEV, build_product, compare_grads, compare_losses, mean_abs_err, rel_err, run_oracle_steps,
                              run_product_steps, setup_cfg)
 
-TOL = {"fp32": dict(fwd=1e-3, loss=1e-3, grad=5e-3), "bf16": dict(fwd=3e-2, loss=5e-2, grad=5e-1)}
+TOL = {"fp32": dict(fwd=1e-3, loss=1e-3, grad=5e-3, latol=1e-4), "bf16": dict(fwd=3e-2, loss=5e-2, grad=5e-1, latol=1e-2)}
 # Adam eps used in the multi-phase parity runs: with the presets' beta1=0 the very first update is
 # lr*g/(|g|+eps), i.e. +-lr for ANY non-zero g, so a rounding-level sign difference in a near-zero gradient moves
 # that weight by 2*lr and the later phases (MA-GP, G step, next iteration) then differ at the 1e-2 level for reasons
@@ -94,7 +94,7 @@ def test_train_iteration_parity(yml, over, batch, steps, mode):
     for s in range(steps):
         # later steps inherit the (sign-sensitive, beta1=0) Adam updates of earlier ones: loosen
         k = 1.0 if s == 0 else 4.0
-        worst["loss"] = max(worst["loss"], compare_losses(p_outs[s], o_outs[s], t["loss"] * k, 1e-4 * k))
+        worst["loss"] = max(worst["loss"], compare_losses(p_outs[s], o_outs[s], t["loss"] * k, t["latol"] * k))
         assert mean_abs_err(p_outs[s]["fake"], o_outs[s]["fake"]) < t["fwd"] * k
         worst["D"] = max(worst["D"], compare_grads(tapD.records[di], o_outs[s]["grads_D"], t["grad"] * k, f"step{s} D ")); di += 1
         if h.magp:

@@ -187,6 +187,8 @@ int dispatch(const XmcConvDesc& d, float* dwp, hipStream_t st) {
 
 }  // namespace
 
+int xmc_conv_wgrad_tile_try(const XmcConvDesc* d, float* dwp, void* stream);   // conv_wgrad_tile.hip
+
 extern "C" int xmc_conv_wgrad(const XmcConvDesc* d, float* dwp, void* stream) {
     if (!d || !d->src || !d->dst || !dwp) return XMC_EINVAL;
     if (d->dtype != XMC_BF16 && d->dtype != XMC_F32) return XMC_EINVAL;
@@ -195,6 +197,10 @@ extern "C" int xmc_conv_wgrad(const XmcConvDesc* d, float* dwp, void* stream) {
     if ((d->CS * esz) % 16 != 0 || (d->CD * esz) % 16 != 0 || d->CDw % 32 != 0 || d->CDw < d->CD) return XMC_EALIGN;
     if (d->N < 1 || d->MH < 1 || d->MW < 1 || d->SH < 1 || d->SW < 1) return XMC_ESHAPE;
     if (d->src_shift < 0 || d->src_shift > 1 || d->SA < 1) return XMC_ESHAPE;
+    {
+        int rc = xmc_conv_wgrad_tile_try(d, dwp, stream);     // all-taps-per-tile kernel for the few-channel layers
+        if (rc != 1) return rc;
+    }
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     return d->dtype == XMC_BF16 ? dispatch<XMC_BF16>(*d, dwp, st) : dispatch<XMC_F32>(*d, dwp, st);
 }

@@ -1,0 +1,181 @@
+// Weight gradient for the high-resolution, few-channel layers (Cin <= 64, Cout <= 64, unit stride, bf16).
+//
+// The generic wgrad kernel gives every (tap, co-tile, ci-tile) its own workgroups, so a 3x3 layer streams both
+// activations nine times; at 256x256 that is 2.4 GB per launch for tensors of 0.27 GB (rocprof FETCH_SIZE).
+// Here a persistent workgroup walks over 8x32-pixel tiles: dy tile and the x patch (tile + halo) are staged in
+// LDS once per tile (next tile prefetched into registers during the MFMAs) and ALL taps are accumulated from
+// them into register-resident f32 accumulators (up to 9 x 64 x 64); one atomic add per weight per workgroup at
+// the very end.  HBM traffic = each activation read ~1.3x, once.
+// MFMA operands are pixel-major in LDS, fragments come from ds_read_b64_tr_b16 (see conv_wgrad.hip).
+#include "common.h"
+#include <stdlib.h>
+
+namespace {
+
+constexpr int TH = 8, TW = 32, NT = 256;
+
+struct WTCfg {
+    int tiles_y, tiles_x, ntiles;
+    int PH, PW, dh0, dw0;
+};
+
+template <int NCO, int NCI>     // 16-wide blocks of (padded) Cout and Cin
+__global__ __launch_bounds__(256) void wgrad_tile_kernel(const XmcConvDesc d, float* __restrict__ dwp, const WTCfg t) {
+    constexpr int CDP = NCO * 16, CSP = NCI * 16;
+    constexpr int YS = CDP * 2 + 32, XS = CSP * 2 + 32;      // LDS row strides (bytes)
+    constexpr int NS = 4 / NCO;                               // waves sharing one co block
+    constexpr int MAXI = (NCI * 9 + NS - 1) / NS;             // (ci block, tap) items per wave
+    constexpr int YCH = CDP / 8, XCH = CSP / 8;               // 16-byte chunks per pixel
+    constexpr int YIT = TH * TW * YCH / NT;                   // dy chunks per thread per tile (>= 2)
+    constexpr int XIT = (10 * 34 * XCH + NT - 1) / NT;        // patch chunks per thread per tile
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* ydy = smem;                                // [256][YS]
+    unsigned char* xp = smem + TH * TW * YS;                  // [PH*PW][XS]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cb = wave % NCO, slice = wave / NCO;
+    const int tpi = t.tiles_y * t.tiles_x;
+    const int PH = t.PH, PW = t.PW;
+    const int cd_units = d.CD / 8, cs_units = d.CS / 8;
+    const u32x4* __restrict__ x16 = reinterpret_cast<const u32x4*>(d.src);
+    const u32x4* __restrict__ y16 = reinterpret_cast<const u32x4*>(d.dst);
+
+    f32x4 acc[MAXI];
+#pragma unroll
+    for (int j = 0; j < MAXI; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    u32x4 yv[YIT], xv[XIT];
+    auto prefetch = [&](int tile) {
+        const int img = tile / tpi, trem = tile - img * tpi;
+        const int a0 = (trem / t.tiles_x) * TH, b0 = (trem % t.tiles_x) * TW;
+#pragma unroll
+        for (int it = 0; it < YIT; ++it) {
+            int id = tid + it * NT;
+            int pix = id / YCH, ch = id - pix * YCH;
+            int py = pix / TW, px = pix - py * TW;
+            u32x4 z = {0, 0, 0, 0};
+            yv[it] = ch < cd_units ? y16[(((size_t)img * d.MH + a0 + py) * d.MW + b0 + px) * cd_units + ch] : z;
+        }
+#pragma unroll
+        for (int it = 0; it < XIT; ++it) {
+            int id = tid + it * NT;
+            int pp = id / XCH, ch = id - pp * XCH;
+            int py = pp / PW, px = pp - py * PW;
+            int sy = a0 + t.dh0 + py, sx = b0 + t.dw0 + px;
+            bool ok = pp < PH * PW && ch < cs_units && (unsigned)sy < (unsigned)d.SH && (unsigned)sx < (unsigned)d.SW;
+            u32x4 z = {0, 0, 0, 0};
+            xv[it] = ok ? x16[(((size_t)img * d.SH + sy) * d.SW + sx) * cs_units + ch] : z;
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile < t.ntiles) prefetch(tile);
+    const int fr = lane & 15, fg = lane >> 4;
+    const int q = fr >> 2, pp4 = fr & 3;
+    const int nitems = NCI * d.ntaps;
+
+    for (; tile < t.ntiles; tile += gridDim.x) {
+        __syncthreads();                                      // previous tile's reads are done
+#pragma unroll
+        for (int it = 0; it < YIT; ++it) {
+            int id = tid + it * NT;
+            int pix = id / YCH, ch = id - pix * YCH;
+            *reinterpret_cast<u32x4*>(ydy + pix * YS + ch * 16) = yv[it];
+        }
+#pragma unroll
+        for (int it = 0; it < XIT; ++it) {
+            int id = tid + it * NT;
+            int pp = id / XCH, ch = id - pp * XCH;
+            if (pp < PH * PW) *reinterpret_cast<u32x4*>(xp + pp * XS + ch * 16) = xv[it];
+        }
+        __syncthreads();
+        if (tile + (int)gridDim.x < t.ntiles) prefetch(tile + gridDim.x);
+
+        // K loop: one tile row (32 pixels) per step
+        for (int r = 0; r < TH; ++r) {
+            // A' fragment: dy^T [co = cb*16 + lane&15][pix = r*32 + 8*fg + j]
+            const unsigned char* ab = ydy + (size_t)(r * TW + 8 * fg + q) * YS + (cb * 16 + 4 * pp4) * 2;
+            bf16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(ab));
+            bf16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(ab + 4 * YS));
+            const bf16x8 af = bf16x8{alo[0], alo[1], alo[2], alo[3], ahi[0], ahi[1], ahi[2], ahi[3]};
+#pragma unroll
+            for (int j = 0; j < MAXI; ++j) {
+                const int item = slice + j * NS;
+                if (item < nitems) {                          // wave-uniform
+                    const int ib = item / d.ntaps, tap = item - ib * d.ntaps;
+                    const int prow = r + d.dh[0][tap] - t.dh0, pcol = d.dw[0][tap] - t.dw0;
+                    const unsigned char* bb = xp + (size_t)(prow * PW + pcol + 8 * fg + q) * XS + (ib * 16 + 4 * pp4) * 2;
+                    bf16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(bb));
+                    bf16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(bb + 4 * XS));
+                    const bf16x8 bf = bf16x8{blo[0], blo[1], blo[2], blo[3], bhi[0], bhi[1], bhi[2], bhi[3]};
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, acc[j], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // D[row = co][col = ci] -> one atomic per element per workgroup
+#pragma unroll
+    for (int j = 0; j < MAXI; ++j) {
+        const int item = slice + j * NS;
+        if (item < nitems) {
+            const int ib = item / d.ntaps, tap = item - ib * d.ntaps;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                int co = cb * 16 + fg * 4 + rr, ci = ib * 16 + fr;
+                if (co < d.CDw && co < CDP && ci < d.CS)
+                    atomicAdd(&dwp[((size_t)d.wi[0][tap] * d.CDw + co) * d.CS + ci], acc[j][rr]);
+            }
+        }
+    }
+}
+
+template <int NCO, int NCI>
+int launch_wt(const XmcConvDesc& d, float* dwp, const WTCfg& t, hipStream_t st) {
+    constexpr int YS = NCO * 32 + 32, XS = NCI * 32 + 32;
+    size_t lds = (size_t)TH * TW * YS + (size_t)t.PH * t.PW * XS;
+    if (lds > 160 * 1024) return 1;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_tile_kernel<NCO, NCI>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    int per_cu = (int)(160 * 1024 / lds);
+    if (per_cu > 2) per_cu = 2;
+    int gx = 256 * per_cu;
+    if (gx > t.ntiles) gx = t.ntiles;
+    hipLaunchKernelGGL((wgrad_tile_kernel<NCO, NCI>), dim3(gx), dim3(256), lds, st, d, dwp, t);
+    XMC_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+// 0 = launched, 1 = not eligible (caller falls back to the generic kernel), other = error
+int xmc_conv_wgrad_tile_try(const XmcConvDesc* d, float* dwp, void* stream) {
+    static const bool off = getenv("XMC_NO_WTILE") != nullptr;
+    if (off) return 1;
+    if (d->dtype != XMC_BF16 || d->SA != 1 || d->src_shift != 0) return 1;
+    if (d->CD > 64 || d->CS > 64 || d->ntaps > 9 || d->ntaps < 1) return 1;
+    if (d->MW % TW != 0 || d->MH % TH != 0) return 1;
+    if (d->CD % 8 != 0 || d->CS % 8 != 0) return 1;
+    WTCfg t;
+    t.tiles_y = d->MH / TH; t.tiles_x = d->MW / TW; t.ntiles = d->N * t.tiles_y * t.tiles_x;
+    int hmin = 127, hmax = -128, wmin = 127, wmax = -128;
+    for (int k = 0; k < d->ntaps; ++k) {
+        int h = d->dh[0][k], w = d->dw[0][k];
+        hmin = h < hmin ? h : hmin; hmax = h > hmax ? h : hmax;
+        wmin = w < wmin ? w : wmin; wmax = w > wmax ? w : wmax;
+    }
+    t.dh0 = hmin; t.dw0 = wmin; t.PH = TH + hmax - hmin; t.PW = TW + wmax - wmin;
+    if (t.PH > 10 || t.PW > 34) return 1;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int nco = d->CD <= 16 ? 1 : (d->CD <= 32 ? 2 : 4);
+    const int nci = d->CS <= 16 ? 1 : (d->CS <= 32 ? 2 : 4);
+#define WT_CASE(a, b) if (nco == a && nci == b) return launch_wt<a, b>(*d, dwp, t, st);
+    // (4,4) = 64x64 channels needs 144 accumulator + 76 staging registers per lane: measured slower than the
+    // split-K kernel (166 vs 230 TF/s), so it stays there
+    WT_CASE(1, 2) WT_CASE(1, 4) WT_CASE(2, 1) WT_CASE(2, 2) WT_CASE(2, 4) WT_CASE(4, 1) WT_CASE(4, 2)
+#undef WT_CASE
+    return 1;
+}

@@ -249,10 +249,12 @@ class resD(nn.Module):
         return ops.axpby(self.shortcut(x), self.residual(x), self.gamma)
 
     def shortcut(self, x):
+        # upstream: avg_pool2d(conv_s(x), 2) (df_gan.py:286-291).  A 1x1 convolution (and its bias) commutes with
+        # average pooling, so pooling first gives the same function with 4x less conv work and HBM traffic.
+        if self.downsample:
+            x = ops.avgpool2(x)
         if self.learned_shortcut:
             x = self.conv_s(x)
-        if self.downsample:
-            return ops.avgpool2(x)
         return x
 
     def residual(self, x):
