@@ -134,6 +134,27 @@ int xmc_affine2_lrelu_bwd(const void* x, const void* dy, const float* g0, const 
                           const float* b1, void* dx, float* dg0, float* db0, float* dg1, float* db1,
                           int N, int HW, int C, int dtype, void* stream);
 
+/* single-stage form of the same kernels: pass g1 = b1 = NULL (and dg1 = db1 = NULL) -> y = lrelu(x*g0 + b0), the
+ * concept blocks' modulation `gamma * img_embs + beta` + LeakyReLU (df_concept_gan.py:238-239,250-251) */
+
+/*
+ * Attention-modulation blocks (model/df_concept_gan.py).
+ * GroupNorm over NHWC with optional fused LeakyReLU (slope < 0: none): nn.GroupNorm at 171,270-271,549-550.
+ *   stats: f32 [N][G][2] (mean, rstd), written by fwd, read by bwd;  ws: f32 [N][C][2] scratch.
+ * Region attention pooling (CondConceptSampler.forward 293-299 / ConceptSampler.forward 570-578):
+ *   scores[n,c,p] = scale * <q[n,c,:], key[n,p,c*pk:(c+1)*pk]>, attn = softmax over p, ctx[n,c,:] = sum_p attn * x[n,p,c*px:(c+1)*px]
+ *   key [N][HW][ncon*pk], x [N][HW][ncon*px] (activation dtype); q, attn [N][ncon][HW], ctx [N][ncon][px] f32.
+ *   bwd writes dq, dkey, dx (every element exactly once).
+ */
+int xmc_groupnorm_fwd(const void* x, const float* w, const float* b, void* y, float* stats, float* ws,
+                      int N, int HW, int C, int G, float eps, float slope, int dtype, void* stream);
+int xmc_groupnorm_bwd(const void* x, const void* dy, const float* w, const float* b, const float* stats, void* dx,
+                      float* dw, float* db, float* ws, int N, int HW, int C, int G, float slope, int dtype, void* stream);
+int xmc_attn_pool_fwd(const void* key, const float* q, const void* x, float* attn, float* ctx, int N, int HW,
+                      int ncon, int pk, int px, float scale, int dtype, void* stream);
+int xmc_attn_pool_bwd(const void* key, const float* q, const void* x, const float* attn, const float* dctx, float* dq,
+                      void* dkey, void* dx, int N, int HW, int ncon, int pk, int px, float scale, int dtype, void* stream);
+
 /*
  * Contrastive head (cosine_scores + sent_loss/img_loss, train_gan.py:85-139), fused:
  *   S = normalize(A) normalize(B)^T ; loss = mean_j(-sum_i L_ij logsoftmax_col(S)_ij / np_j)

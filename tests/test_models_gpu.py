@@ -33,6 +33,10 @@ FWD_CASES = [
     ("df_gan_sbert_damsm_nomagp.yml", {"IMG.SIZE": 256, "TRAIN.NCH": 8}, 1),
     ("df_gan_sbert_seperate.yml", {"TRAIN.NCH": 8}, 2),
     ("concept_in_df_gan.yml", {"TRAIN.NCH": 8, "GEN.ENCODER_NAME": "DF_GEN"}, 2),   # IMG_MATCH False, Identity proj
+    # attention-modulation generators (BASELINE config 3 exercises them at 128 px)
+    ("concept_in_df_gan_damsm_nomagp.yml", {"TRAIN.NCH": 8}, 2),
+    ("concept_in_df_gan_damsm_nomagp.yml", {"TRAIN.NCH": 8, "IMG.SIZE": 128}, 1),
+    ("concept_out_df_gan_sbert_damsm_nomagp.yml", {"TRAIN.NCH": 8}, 2),
 ]
 
 
@@ -72,6 +76,9 @@ STEP_CASES = [
     ("df_gan_sbert_seperate.yml", {"TRAIN.NCH": 8}, 3, 1),                # SEPERATE, E=768, no contrastive
     ("df_gan_damsm_nomagp.yml", {"IMG.SIZE": 128, "TRAIN.NCH": 8}, 2, 1),
     ("df_gan_damsm.yml", {"TRAIN.NCH": 8, "TRAIN.ENCODER_LOSS.B_GLOBAL": True}, 6, 1),   # global positives
+    ("concept_in_df_gan_damsm_nomagp.yml", {"TRAIN.NCH": 8}, 3, 1),                      # sentence->region attention G
+    ("concept_out_df_gan_sbert_damsm_nomagp.yml", {"TRAIN.NCH": 8}, 3, 1),               # self-attention G, E=768
+    ("concept_in_df_gan_sbert_n2_damsm.yml", {"TRAIN.NCH": 8}, 3, 2),                    # N_CRITIC=2 + MA-GP
 ]
 
 
@@ -91,16 +98,17 @@ def test_train_iteration_parity(yml, over, batch, steps, mode):
     t = TOL[mode]
     gi = di = 0
     worst = dict(loss=0.0, D=0.0, GP=0.0, G=0.0)
+    fl = 1e-5 if mode == "fp32" else 2e-2      # gradient tensors below this fraction of the largest norm are compared on that scale
     for s in range(steps):
         # later steps inherit the (sign-sensitive, beta1=0) Adam updates of earlier ones: loosen
-        k = 1.0 if s == 0 else 4.0
+        k = 1.0 if s == 0 else (4.0 if mode == "fp32" else 20.0)
         worst["loss"] = max(worst["loss"], compare_losses(p_outs[s], o_outs[s], t["loss"] * k, t["latol"] * k))
         assert mean_abs_err(p_outs[s]["fake"], o_outs[s]["fake"]) < t["fwd"] * k
-        worst["D"] = max(worst["D"], compare_grads(tapD.records[di], o_outs[s]["grads_D"], t["grad"] * k, f"step{s} D ")); di += 1
+        worst["D"] = max(worst["D"], compare_grads(tapD.records[di], o_outs[s]["grads_D"], t["grad"] * k, f"step{s} D ", fl)); di += 1
         if h.magp:
-            worst["GP"] = max(worst["GP"], compare_grads(tapD.records[di], o_outs[s]["grads_GP"], t["grad"] * 2 * k, f"step{s} GP ")); di += 1
+            worst["GP"] = max(worst["GP"], compare_grads(tapD.records[di], o_outs[s]["grads_GP"], t["grad"] * 2 * k, f"step{s} GP ", fl)); di += 1
         if "grads_G" in o_outs[s]:
-            worst["G"] = max(worst["G"], compare_grads(tapG.records[gi], o_outs[s]["grads_G"], t["grad"] * k, f"step{s} G ")); gi += 1
+            worst["G"] = max(worst["G"], compare_grads(tapG.records[gi], o_outs[s]["grads_G"], t["grad"] * k, f"step{s} G ", fl)); gi += 1
     assert di == len(tapD.records) and gi == len(tapG.records)
     print(f"\n[parity {mode} {yml} {over}] worst rel err: " + ", ".join(f"{k}={v:.2e}" for k, v in worst.items()))
 

@@ -246,15 +246,19 @@ __global__ void affine2_fwd_kernel(const void* x, const float* g0, const float* 
     if (g >= groups) return;
     float G0[8], B0[8], G1[8], B1[8];
     const size_t pb = ((size_t)n * C8 + cc) * 8;
+    const bool two = g1 != nullptr;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { G0[k] = g0[pb + k]; B0[k] = b0[pb + k]; G1[k] = g1[pb + k]; B1[k] = b1[pb + k]; }
+    for (int k = 0; k < 8; ++k) { G0[k] = g0[pb + k]; B0[k] = b0[pb + k]; G1[k] = two ? g1[pb + k] : 1.f; B1[k] = two ? b1[pb + k] : 0.f; }
     const int p_end = min(HW, (int)(blockIdx.x + 1) * pix_per_block);
     for (int p = blockIdx.x * pix_per_block + g; p < p_end; p += groups) {
         float v[8];
         const size_t idx = ((size_t)n * HW + p) * C8 + cc;
         Vec8<DT>::load(x, idx, v);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = lrelu_f(lrelu_f(v[k] * G0[k] + B0[k]) * G1[k] + B1[k]);
+        for (int k = 0; k < 8; ++k) {
+            float u = lrelu_f(v[k] * G0[k] + B0[k]);
+            v[k] = two ? lrelu_f(u * G1[k] + B1[k]) : u;
+        }
         Vec8<DT>::store(y, idx, v);
     }
 }
@@ -267,9 +271,10 @@ __global__ void affine2_bwd_kernel(const void* x, const void* dy, const float* g
     float G0[8], B0[8], G1[8], B1[8];
     float sg0[8], sb0[8], sg1[8], sb1[8];
     const size_t pb = ((size_t)n * C8 + cc) * 8;
+    const bool two = g1 != nullptr;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        G0[k] = g0[pb + k]; B0[k] = b0[pb + k]; G1[k] = g1[pb + k]; B1[k] = b1[pb + k];
+        G0[k] = g0[pb + k]; B0[k] = b0[pb + k]; G1[k] = two ? g1[pb + k] : 1.f; B1[k] = two ? b1[pb + k] : 0.f;
         sg0[k] = sb0[k] = sg1[k] = sb1[k] = 0.f;
     }
     const int p_end = min(HW, (int)(blockIdx.x + 1) * pix_per_block);
@@ -284,7 +289,7 @@ __global__ void affine2_bwd_kernel(const void* x, const void* dy, const float* g
                 float u = xv[k] * G0[k] + B0[k];
                 float a1 = lrelu_f(u);
                 float v = a1 * G1[k] + B1[k];
-                float dvv = dv[k] * lrelu_slope(v);
+                float dvv = two ? dv[k] * lrelu_slope(v) : dv[k];
                 sg1[k] += dvv * a1; sb1[k] += dvv;
                 float du = dvv * G1[k] * lrelu_slope(u);
                 sg0[k] += du * xv[k]; sb0[k] += du;
@@ -298,6 +303,7 @@ __global__ void affine2_bwd_kernel(const void* x, const void* dy, const float* g
     float* sums[4] = {sg0, sb0, sg1, sb1};
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
+        if (!two && q >= 2) break;
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < 8; ++k) red[threadIdx.x * 8 + k] = sums[q][k];

@@ -55,6 +55,10 @@ _SIGS = {
     "xmc_global_avgpool_bwd": [vp, vp, i32, i32, i32, i32, i32, vp],
     "xmc_affine2_lrelu_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "xmc_affine2_lrelu_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    "xmc_groupnorm_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, i32, vp],
+    "xmc_groupnorm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp],
+    "xmc_attn_pool_fwd": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp],
+    "xmc_attn_pool_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp],
     "xmc_contrastive_ws_bytes": [i32, i32],
     "xmc_contrastive_fwd": [vp, vp, vp, vp, i32, i32, vp, vp, vp],
     "xmc_contrastive_bwd": [vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp],

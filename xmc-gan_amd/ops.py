@@ -617,32 +617,103 @@ class Nhwc8ToNchwFn(torch.autograd.Function):
 
 
 class Affine2LreluFn(torch.autograd.Function):
-    """lrelu(lrelu(x*g0+b0)*g1+b1) with per-sample, per-channel f32 g/b [N,C] -- two DF-GAN `affine`
-    modules each followed by LeakyReLU(0.2) (df_gan.py:213-216 / 219-222, affine.forward 250-263)."""
+    """lrelu(lrelu(x*g0+b0)*g1+b1) with per-sample, per-channel f32 g/b [N,C] -- two DF-GAN `affine` modules each
+    followed by LeakyReLU(0.2) (df_gan.py:213-216 / 219-222, affine.forward 250-263).  With g1 = b1 = None it is the
+    single modulation lrelu(x*g0+b0) of the concept blocks (df_concept_gan.py:238-239)."""
 
     @staticmethod
     def forward(ctx, x, g0, b0, g1, b1):
         x = x.contiguous()
         N, H, W, Cc = x.shape
-        ps = [t.contiguous().float() for t in (g0, b0, g1, b1)]
+        two = g1 is not None
+        ps = [t.contiguous().float() for t in ((g0, b0, g1, b1) if two else (g0, b0))]
         for t in ps:
             assert t.shape == (N, Cc), (t.shape, (N, Cc))
         y = torch.empty_like(x)
-        L.call("xmc_affine2_lrelu_fwd", _p(x), *[_p(t) for t in ps], _p(y), N, H * W, Cc, _code(x.dtype), _st())
+        ptrs = [_p(t) for t in ps] + ([] if two else [None, None])
+        L.call("xmc_affine2_lrelu_fwd", _p(x), *ptrs, _p(y), N, H * W, Cc, _code(x.dtype), _st())
+        ctx.two = two
         ctx.save_for_backward(x, *ps)
         return y
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, dy):
-        x, g0, b0, g1, b1 = ctx.saved_tensors
+        x, *ps = ctx.saved_tensors
         dy = dy.contiguous()
         N, H, W, Cc = x.shape
         dx = torch.empty_like(x)
-        red = torch.zeros((4, N, Cc), dtype=torch.float32, device=x.device)
-        L.call("xmc_affine2_lrelu_bwd", _p(x), _p(dy), _p(g0), _p(b0), _p(g1), _p(b1), _p(dx),
-               _p(red[0]), _p(red[1]), _p(red[2]), _p(red[3]), N, H * W, Cc, _code(x.dtype), _st())
-        return dx, red[0], red[1], red[2], red[3]
+        nred = 4 if ctx.two else 2
+        red = torch.zeros((nred, N, Cc), dtype=torch.float32, device=x.device)
+        ptrs = [_p(t) for t in ps] + ([] if ctx.two else [None, None])
+        rptrs = [_p(red[i]) for i in range(nred)] + ([] if ctx.two else [None, None])
+        L.call("xmc_affine2_lrelu_bwd", _p(x), _p(dy), *ptrs, _p(dx), *rptrs, N, H * W, Cc, _code(x.dtype), _st())
+        if ctx.two:
+            return dx, red[0], red[1], red[2], red[3]
+        return dx, red[0], red[1], None, None
+
+
+class GroupNormFn(torch.autograd.Function):
+    """nn.GroupNorm over NHWC (df_concept_gan.py:171,270-271,549-550) with optional fused LeakyReLU (slope >= 0)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, groups, slope, eps):
+        x = x.contiguous()
+        N, H, W, Cc = x.shape
+        wf, bf = w.detach().float().contiguous(), b.detach().float().contiguous()
+        y = torch.empty_like(x)
+        stats = torch.empty((N, groups, 2), dtype=torch.float32, device=x.device)
+        ws = torch.empty((N, Cc, 2), dtype=torch.float32, device=x.device)
+        L.call("xmc_groupnorm_fwd", _p(x), _p(wf), _p(bf), _p(y), _p(stats), _p(ws), N, H * W, Cc, groups, float(eps),
+               float(slope), _code(x.dtype), _st())
+        ctx.groups, ctx.slope = groups, slope
+        ctx.save_for_backward(x, wf, bf, stats)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        x, wf, bf, stats = ctx.saved_tensors
+        dy = dy.contiguous()
+        N, H, W, Cc = x.shape
+        dx = torch.empty_like(x)
+        dw, db = torch.empty_like(wf), torch.empty_like(bf)
+        ws = torch.empty((N, Cc, 2), dtype=torch.float32, device=x.device)
+        L.call("xmc_groupnorm_bwd", _p(x), _p(dy), _p(wf), _p(bf), _p(stats), _p(dx), _p(dw), _p(db), _p(ws), N, H * W, Cc,
+               ctx.groups, float(ctx.slope), _code(x.dtype), _st())
+        return dx, dw, db, None, None, None
+
+
+class AttnPoolFn(torch.autograd.Function):
+    """Region attention of the concept samplers (df_concept_gan.py:293-299, 570-578): per (sample, concept) softmax over
+    H*W of scale*<q, key>, then the attention-weighted sum of x.  key [N,H,W,ncon*pk], x [N,H,W,ncon*px], q f32 [N,ncon,pk]
+    -> f32 [N,ncon,px]."""
+
+    @staticmethod
+    def forward(ctx, key, q, x, ncon, scale):
+        key, x = key.contiguous(), x.contiguous()
+        q = q.contiguous().float()
+        N, H, W, CK = key.shape
+        pk, px = CK // ncon, x.shape[3] // ncon
+        attn = torch.empty((N, ncon, H * W), dtype=torch.float32, device=x.device)
+        out = torch.empty((N, ncon, px), dtype=torch.float32, device=x.device)
+        L.call("xmc_attn_pool_fwd", _p(key), _p(q), _p(x), _p(attn), _p(out), N, H * W, ncon, pk, px, float(scale),
+               _code(x.dtype), _st())
+        ctx.ncon, ctx.scale = ncon, scale
+        ctx.save_for_backward(key, q, x, attn)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dctx):
+        key, q, x, attn = ctx.saved_tensors
+        N, H, W, CK = key.shape
+        pk, px = CK // ctx.ncon, x.shape[3] // ctx.ncon
+        dq = torch.empty_like(q)
+        dkey, dx = torch.empty_like(key), torch.empty_like(x)
+        L.call("xmc_attn_pool_bwd", _p(key), _p(q), _p(x), _p(attn), _p(dctx.contiguous().float()), _p(dq), _p(dkey), _p(dx),
+               N, H * W, ctx.ncon, pk, px, float(ctx.scale), _code(x.dtype), _st())
+        return dkey, dq, dx, None, None
 
 
 # ------------------------------------------------------------------------------------------ losses
@@ -738,6 +809,18 @@ def to_nchw(x_nhwc8, c):
 
 def affine2_lrelu(x, g0, b0, g1, b1):
     return Affine2LreluFn.apply(x, g0, b0, g1, b1)
+
+
+def affine_lrelu(x, g, b):
+    return Affine2LreluFn.apply(x, g, b, None, None)
+
+
+def groupnorm(x, w, b, groups, slope=-1.0, eps=1e-5):
+    return GroupNormFn.apply(x, w, b, groups, slope, eps)
+
+
+def attn_pool(key, q, x, ncon, scale=1.0):
+    return AttnPoolFn.apply(key, q, x, ncon, scale)
 
 
 def hinge(logits_padded, sign):

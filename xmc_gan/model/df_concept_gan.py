@@ -1,20 +1,280 @@
-"""Attention-modulation generators (reference model/df_concept_gan.py) -- placeholder until the grouped-conv /
-region-attention kernels land; class names and the NetD contract are already in place."""
+"""Attention-modulation ("concept") generators with the reference's module API (model/df_concept_gan.py):
+``InNetG`` (CONCEPT_IN_DF_GEN: sentence-conditioned region attention) and ``OutNetG`` (CONCEPT_OUT_DF_GEN:
+self region attention + sentence->concept attention), plus the ``NetD`` stub that raises like upstream.
+
+Same class names, constructor/forward signatures and ``state_dict()`` keys.  Heavy per-pixel work runs in HIP kernels:
+1x1 / 3x3 / block-diagonal grouped convolutions on the MFMA implicit-GEMM kernels, GroupNorm(+LeakyReLU), the region
+attention (scores, softmax over H*W, weighted sum) and the per-sample channel modulation.  What remains in ATen is the
+per-sample concept algebra on ``[B,16,<=260]`` tensors (query/value projections, ConceptReasoner, the gamma/beta MLPs).
+"""
+import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
-from .df_gan import gen_arch, disc_arch  # noqa: F401  (same tables upstream: df_concept_gan.py:10-62)
+from xmc_gan_amd import ops
+from xmc_gan_amd.lib import ACT_LRELU, ACT_NONE
+
+from .df_gan import NetG as _DFNetG, gen_arch, disc_arch, nhwc_feature_perm  # noqa: F401 (tables are shared upstream too)
+from .modules import HipConv2d, HipLinear
+
+CARD, PW, SD = 16, 8, 4          # cardinality, bottleneck width, state dim (hard-coded upstream: 110,118)
 
 
-class InNetG(nn.Module):
+def _blockdiag(w, groups):
+    """grouped conv weight [Co, Ci/g, k, k] -> dense block-diagonal [Co, Ci, k, k] (differentiable)."""
+    co, cig, k, _ = w.shape
+    cog = co // groups
+    eye = torch.eye(groups, device=w.device, dtype=w.dtype)
+    w6 = w.view(groups, cog, 1, cig, k, k) * eye.view(groups, 1, groups, 1, 1, 1)
+    return w6.reshape(co, groups * cig, k, k)
+
+
+class _GroupedConv(nn.Conv2d):
+    """nn.Conv2d(groups=16) parameter holder whose forward runs the dense MFMA kernel on the block-diagonal expansion
+    (16 groups of 8 channels are far too thin for their own GEMMs)."""
+
+    def __init__(self, in_dim, out_dim, k, pad, groups=CARD, bias=False):
+        super().__init__(in_dim, out_dim, k, 1, pad, groups=groups, bias=bias)
+        self.geom = ops.ConvGeom(in_dim, out_dim, k, 1, pad)
+
+    def forward(self, x):
+        return ops.conv2d(x, _blockdiag(self.weight, self.groups), self.bias, self.geom)
+
+
+def _grouped_vec(x, conv):
+    """grouped 1x1 conv applied to a per-sample vector laid out [B, groups, in_per_group] -> [B, groups, out_per_group]."""
+    g = conv.groups
+    w = conv.weight.view(g, conv.out_channels // g, conv.in_channels // g)
+    y = torch.einsum('bgi,goi->bgo', x, w)
+    if conv.bias is not None:
+        y = y + conv.bias.view(1, g, -1)
+    return y
+
+
+class _ModMLP(nn.Sequential):
+    """gamma/beta generator: grouped 1x1 -> LeakyReLU -> grouped 1x1 on the per-concept condition (178-200, 443-465)."""
+
+    def __init__(self, cond_group_width):
+        super().__init__(
+            nn.Conv2d(cond_group_width, 2 * CARD * SD, 1, 1, 0, groups=CARD),
+            nn.LeakyReLU(0.2, inplace=True),
+            nn.Conv2d(2 * CARD * SD, CARD * PW, 1, 1, 0, groups=CARD))
+
+    def forward(self, cond):                      # cond [B,16,nef+4] -> [B,128]
+        h = F.leaky_relu(_grouped_vec(cond, self[0]), 0.2)
+        return _grouped_vec(h, self[2]).reshape(cond.size(0), -1)
+
+
+class ConceptReasoner(nn.Module):
+    def __init__(self, cardinality, state_dim, spec_norm=False, normalize=True):
+        super(ConceptReasoner, self).__init__()
+        self.cardinality = cardinality
+        self.normalize = False                    # forced off upstream (308)
+        self.proj_edge = nn.Linear(state_dim, cardinality, bias=False)
+
+    def forward(self, x, **kwargs):               # x [B,16,4]
+        adj = torch.tanh(F.linear(x, self.proj_edge.weight))
+        return F.relu(x + torch.matmul(adj, x))
+
+
+class _SamplerBase(nn.Module):
+    def _init_common(self, cardinality, bottleneck_width, state_dim, normalize):
+        self.cardinality, self.normalize = cardinality, normalize
+        gw, sw = cardinality * bottleneck_width, cardinality * state_dim
+        self.key_gconv = _GroupedConv(gw, sw, 1, 0)
+        self.value_gconv = nn.Conv2d(gw, sw, 1, 1, 0, groups=cardinality, bias=False)
+        if normalize:
+            self.gn1 = nn.GroupNorm(cardinality, sw)
+            self.gn2 = nn.GroupNorm(cardinality, sw)
+
+    def _attend(self, x, q, scale):
+        """x [B,H,W,128], q [B,16,4] f32 -> value-projected context [B,16,4]."""
+        B = x.size(0)
+        if self.normalize:
+            q = F.group_norm(q.reshape(B, -1), self.cardinality, self.gn1.weight, self.gn1.bias).view(B, self.cardinality, -1)
+        key = self.key_gconv(x)
+        if self.normalize:
+            key = ops.groupnorm(key, self.gn2.weight, self.gn2.bias, self.cardinality)
+        ctx = ops.attn_pool(key, q, x, self.cardinality, scale)            # [B,16,8]
+        return _grouped_vec(ctx, self.value_gconv)
+
+
+class CondConceptSampler(_SamplerBase):
+    """sentence query -> region keys (reference 256-302)."""
+
+    def __init__(self, cardinality, bottleneck_width, state_dim, cond_dim, normalize=True, spec_norm=False):
+        super(CondConceptSampler, self).__init__()
+        self.query_gconv = nn.Conv2d(cardinality * cond_dim, cardinality * state_dim, 1, 1, 0, groups=cardinality, bias=False)
+        self._init_common(cardinality, bottleneck_width, state_dim, normalize)
+
+    def forward(self, x, sent_embs):
+        B = x.size(0)
+        q = _grouped_vec(sent_embs.view(B, 1, -1).expand(B, self.cardinality, -1), self.query_gconv)
+        return self._attend(x, q, 1.0)
+
+
+class ConceptSampler(_SamplerBase):
+    """global-average query -> region keys, scores scaled by rsqrt(state_dim) (reference 535-581)."""
+
+    def __init__(self, cardinality, bottleneck_width, state_dim, spec_norm=False, normalize=True):
+        super(ConceptSampler, self).__init__()
+        self.query_gconv = nn.Conv2d(cardinality * bottleneck_width, cardinality * state_dim, 1, 1, 0, groups=cardinality, bias=False)
+        self._init_common(cardinality, bottleneck_width, state_dim, normalize)
+        self.register_buffer('norm', torch.rsqrt(torch.as_tensor(state_dim, dtype=torch.float)))
+        self._scale = float(state_dim) ** -0.5
+
+    def forward(self, x, **kwargs):
+        B = x.size(0)
+        q0 = ops.global_avgpool(x).view(B, self.cardinality, -1)
+        return self._attend(x, _grouped_vec(q0, self.query_gconv), self._scale)
+
+
+class _ConceptBlockBase(nn.Module):
+    def _init_trunk(self, in_dim, cardinality, bottleneck_width, normalize):
+        self.cardinality, self.normalize = cardinality, normalize
+        gw = cardinality * bottleneck_width
+        self.split_conv = HipConv2d(in_dim, gw, 1, 1, 0, bias=False)
+        self.trans_gconv = _GroupedConv(gw, gw, 3, 1)
+        if normalize:
+            self.gn = nn.GroupNorm(cardinality, gw)
+
+    def _trunk(self, x):
+        e = self.split_conv(x, act=ACT_LRELU)
+        e = self.trans_gconv(e)
+        if self.normalize:
+            return ops.groupnorm(e, self.gn.weight, self.gn.bias, self.cardinality, slope=0.2)
+        return ops.lrelu(e)
+
+    def _modulate(self, out, gc, ctx, gmlp, bmlp):
+        cond = torch.cat([gc, ctx], dim=2)
+        return ops.affine_lrelu(out, gmlp(cond), bmlp(cond))
+
+
+class InConceptBlock(_ConceptBlockBase):
+    def __init__(self, in_dim, cardinality, bottleneck_width, state_dim, cond_dim, normalize=False):
+        super(InConceptBlock, self).__init__()
+        self._init_trunk(in_dim, cardinality, bottleneck_width, normalize)
+        cgw = cardinality * (state_dim + cond_dim)
+        self.concept_sampler1 = CondConceptSampler(cardinality, bottleneck_width, state_dim, cond_dim, normalize)
+        self.concept_reasoner1 = ConceptReasoner(cardinality, state_dim, normalize=normalize)
+        self.concept_sampler2 = CondConceptSampler(cardinality, bottleneck_width, state_dim, cond_dim, normalize)
+        self.concept_reasoner2 = ConceptReasoner(cardinality, state_dim, normalize=normalize)
+        self.gamma1_gconv, self.beta1_gconv = _ModMLP(cgw), _ModMLP(cgw)
+        self.gamma2_gconv, self.beta2_gconv = _ModMLP(cgw), _ModMLP(cgw)
+
+    def forward(self, x, sent_embs):
+        B = x.size(0)
+        out = self._trunk(x)
+        gc = sent_embs.view(B, 1, -1).expand(B, self.cardinality, -1)
+        for samp, reas, gm, bm in ((self.concept_sampler1, self.concept_reasoner1, self.gamma1_gconv, self.beta1_gconv),
+                                   (self.concept_sampler2, self.concept_reasoner2, self.gamma2_gconv, self.beta2_gconv)):
+            ctx = reas(samp(out, sent_embs))
+            out = self._modulate(out, gc, ctx, gm, bm)
+        return out
+
+
+class OutConceptBlock(_ConceptBlockBase):
+    def __init__(self, in_dim, cardinality, bottleneck_width, state_dim, cond_dim, normalize=False):
+        super(OutConceptBlock, self).__init__()
+        self._init_trunk(in_dim, cardinality, bottleneck_width, normalize)
+        cgw = cardinality * (state_dim + cond_dim)
+        self.concept_sampler1 = ConceptSampler(cardinality, bottleneck_width, state_dim, normalize=normalize)
+        self.concept_reasoner1 = ConceptReasoner(cardinality, state_dim, normalize=normalize)
+        self.concept_sampler2 = ConceptSampler(cardinality, bottleneck_width, state_dim, normalize=normalize)
+        self.concept_reasoner2 = ConceptReasoner(cardinality, state_dim, normalize=normalize)
+        self.sent_linear1 = nn.Linear(cond_dim, state_dim, bias=False)
+        self.sent_linear2 = nn.Linear(cond_dim, state_dim, bias=False)
+        self.gamma1_gconv, self.beta1_gconv = _ModMLP(cgw), _ModMLP(cgw)
+        self.gamma2_gconv, self.beta2_gconv = _ModMLP(cgw), _ModMLP(cgw)
+
+    @staticmethod
+    def get_context_embs(state_embs, sent_embs):
+        """state [B,p',C], sentence [B,p',1] -> softmax over concepts of <sent, state>, re-weighted states (471-478)."""
+        attn = F.softmax(torch.matmul(sent_embs.transpose(1, 2), state_embs), dim=2)
+        return state_embs * attn
+
+    def forward(self, x, sent_embs):
+        B = x.size(0)
+        out = self._trunk(x)
+        gc = sent_embs.view(B, 1, -1).expand(B, self.cardinality, -1)
+        for samp, reas, sl, gm, bm in (
+                (self.concept_sampler1, self.concept_reasoner1, self.sent_linear1, self.gamma1_gconv, self.beta1_gconv),
+                (self.concept_sampler2, self.concept_reasoner2, self.sent_linear2, self.gamma2_gconv, self.beta2_gconv)):
+            st = reas(samp(out)).transpose(1, 2)                                  # [B,p',C]
+            s = F.linear(sent_embs, sl.weight).view(B, -1, 1)
+            ctx = self.get_context_embs(st, s).transpose(1, 2)                    # [B,C,p']
+            out = self._modulate(out, gc, ctx, gm, bm)
+        return out
+
+
+class _AttnGBlock(nn.Module):
+    def _init(self, block_cls, in_dim, out_dim, cond_dim, upsample, cardinality, bottleneck_width, normalize, k):
+        self.learnable_sc = (in_dim != out_dim)
+        self.upsample, self.cardinality = upsample, cardinality
+        gw = cardinality * bottleneck_width
+        self.concept1 = block_cls(in_dim, cardinality, bottleneck_width, 4, cond_dim, normalize)
+        self.concept2 = block_cls(out_dim, cardinality, bottleneck_width, 4, cond_dim, normalize)
+        self.conv_out1 = HipConv2d(gw, out_dim, k, 1, k // 2)
+        self.conv_out2 = HipConv2d(gw, out_dim, k, 1, k // 2)
+        self.gamma = nn.Parameter(torch.zeros(1))
+        if self.learnable_sc:
+            self.c_sc = HipConv2d(in_dim, out_dim, 1, stride=1, padding=0)
+
+    def shortcut(self, x):
+        return self.c_sc(x) if self.learnable_sc else x
+
+    def residual(self, x, sent_embs):
+        out = self.conv_out1(self.concept1(x, sent_embs), act=ACT_LRELU)
+        return self.conv_out2(self.concept2(out, sent_embs))
+
+    def forward(self, x, sent_embs):
+        out = ops.axpby(self.shortcut(x), self.residual(x, sent_embs), self.gamma)
+        return ops.upsample2(out) if self.upsample else out
+
+
+class ICAttnG_Block(_AttnGBlock):
+    def __init__(self, in_dim, out_dim, cond_dim, upsample, cardinality=16, bottleneck_width=8, normalize=True):
+        super(ICAttnG_Block, self).__init__()
+        self._init(InConceptBlock, in_dim, out_dim, cond_dim, upsample, cardinality, bottleneck_width, normalize, 3)
+
+
+class OCAG_Block(_AttnGBlock):
+    def __init__(self, in_dim, out_dim, cond_dim, upsample, cardinality=16, bottleneck_width=8, normalize=True):
+        super(OCAG_Block, self).__init__()
+        self.normalize = normalize
+        self._init(OutConceptBlock, in_dim, out_dim, cond_dim, upsample, cardinality, bottleneck_width, normalize, 1)
+
+
+class _ConceptNetG(_DFNetG):
+    """stem (proj_noise -> [B,8*ngf,4,4]) and tail (LeakyReLU, Conv3x3, Tanh) are DF_GEN's (65-105 / 328-367)."""
+    _block = None
+
     def __init__(self, cfg, **kwargs):
-        super().__init__()
-        raise NotImplementedError("CONCEPT_IN_DF_GEN: HIP attention-modulation blocks not built yet")
+        nn.Module.__init__(self)
+        self.ngf = cfg.TRAIN.NCH
+        arch = gen_arch(img_size=cfg.IMG.SIZE, nch=self.ngf)
+        self.proj_noise = HipLinear(cfg.TRAIN.NOISE_DIM, (8 * self.ngf) * 16, row_perm=nhwc_feature_perm(8 * self.ngf))
+        self.proj_sent = HipLinear(cfg.TEXT.EMBEDDING_DIM, cfg.TRAIN.NEF) \
+            if (cfg.TEXT.EMBEDDING_DIM != cfg.TRAIN.NEF) else nn.Identity()
+        self.upblocks = nn.ModuleList(
+            [self._block(in_dim=arch['in_channels'][i], out_dim=arch['out_channels'][i], cond_dim=cfg.TRAIN.NEF,
+                         upsample=arch['upsample'][i], normalize=cfg.GEN.NORMALIZE) for i in range(arch['depth'])])
+        self.conv_out = nn.Sequential(nn.LeakyReLU(0.2, inplace=True), HipConv2d(arch['out_channels'][-1], 3, 3, 1, 1), nn.Tanh())
+
+    def forward(self, noise, sent_embs, **kwargs):
+        sent_embs = self.proj_sent(sent_embs.float())
+        out = self.stem(noise)
+        for gblock in self.upblocks:
+            out = gblock(out, sent_embs)
+        return self.tail(out)
 
 
-class OutNetG(nn.Module):
-    def __init__(self, cfg, **kwargs):
-        super().__init__()
-        raise NotImplementedError("CONCEPT_OUT_DF_GEN: HIP attention-modulation blocks not built yet")
+class InNetG(_ConceptNetG):
+    _block = ICAttnG_Block
+
+
+class OutNetG(_ConceptNetG):
+    _block = OCAG_Block
 
 
 class NetD(nn.Module):
