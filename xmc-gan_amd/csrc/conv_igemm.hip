@@ -63,9 +63,21 @@ __global__ __launch_bounds__(256) void igemm_kernel(const XmcConvDesc d) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int cls = blockIdx.z;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const int MHW = d.MH * d.MW;
     const int M = d.N * MHW;
+    // XCD-aware tile order (workgroups are dealt round-robin over the 8 XCDs, each with a private L2): XCD k walks a
+    // contiguous range of M tiles and, inside it, all N tiles of one M tile back to back, so the gathered activation
+    // rows (shared by the N tiles and, through the halo, by neighbouring M tiles) are re-read from that XCD's L2.
+    int mt, nt;
+    {
+        const int MT = (M + BM - 1) / BM, NTn = d.CDw / BN;
+        const int bid = blockIdx.x, nwg = MT * NTn;
+        const int xcd = bid & 7, j = bid >> 3;
+        const int q = nwg >> 3, r = nwg & 7;                       // bijective for any nwg
+        const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+        mt = lin / NTn; nt = lin - mt * NTn;
+    }
+    const int m0 = mt * BM, n0 = nt * BN;
     constexpr int ESZ = DT == XMC_BF16 ? 2 : 4;
     const int upt = d.CS * ESZ / 16;                 // 16-byte units per tap
     const int ktot = d.ntaps * upt;                  // total units along K
@@ -246,7 +258,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const XmcConvDesc d) {
 template <int DT, int BM, int BN, int WM, int WN, int KSUB>
 int launch(const XmcConvDesc& d, hipStream_t st) {
     const int64_t M = (int64_t)d.N * d.MH * d.MW;
-    dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)(d.CDw / BN), (unsigned)d.nclass);
+    dim3 grid((unsigned)(((M + BM - 1) / BM) * (d.CDw / BN)), 1, (unsigned)d.nclass);
     hipLaunchKernelGGL((igemm_kernel<DT, BM, BN, WM, WN, KSUB>), grid, dim3(256), 0, st, d);
     XMC_LAUNCH_CHECK();
     return 0;
