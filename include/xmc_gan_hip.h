@@ -81,6 +81,9 @@ int xmc_conv_igemm(const XmcConvDesc* d, void* stream);
  * the caller zeroes dwp).  x: [N,SH,SW,CS], dy: [N,MH,MW,CD].  Uses class 0 of the tap table.
  */
 int xmc_conv_wgrad(const XmcConvDesc* d /* src=x, dst=dy (read only) */, float* dwp, void* stream);
+/* same launch, additionally dbias[co] += sum over all pixels of dy[.,co] (f32 [CD], zeroed by the caller): the bias gradient
+ * costs no extra pass over dy */
+int xmc_conv_wgrad_bias(const XmcConvDesc* d, float* dwp, float* dbias, void* stream);
 
 /* ---- weight (un)packing between nn.Parameter layout [Co][Ci][KH][KW] f32 and kernel layouts --------------- */
 /* fwd pack:  wpk[kh*KW+kw][co][ci]      (rows padded to CDw, cols to CSp, zeros)                               */

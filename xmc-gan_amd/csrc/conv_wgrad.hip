@@ -10,12 +10,14 @@
 // (train_gan.py:228,251,288) for every conv2d / Linear on the path.
 #include "common.h"
 
+extern "C" int xmc_conv_wgrad_bias(const XmcConvDesc* d, float* dwp, float* dbias, void* stream);
+
 namespace {
 
 constexpr int KP = 32;  // pixels per K step
 
 template <int DT, int BCO, int BCI, int WM, int WN>
-__global__ __launch_bounds__(256) void wgrad_kernel(const XmcConvDesc d, float* __restrict__ dwp, int pix_per_block) {
+__global__ __launch_bounds__(256) void wgrad_kernel(const XmcConvDesc d, float* __restrict__ dwp, float* __restrict__ dbias, int pix_per_block) {
     constexpr int NT = 256;
     static_assert(WM * WN == 4, "4 waves");
     constexpr int ESZ = DT == XMC_BF16 ? 2 : 4;
@@ -100,12 +102,20 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const XmcConvDesc d, float* 
     };
 
     const int fr = lane & 15, fg = lane >> 4;
+    const bool do_bias = dbias != nullptr && tap == 0 && ci0 == 0;
+    float bsum = 0.f;
     load_tiles(p_begin);
     for (int64_t p0 = p_begin; p0 < p_end; p0 += KP) {
         __syncthreads();                 // previous step's LDS reads are done
         store_tiles();
         __syncthreads();
         if (p0 + KP < p_end) load_tiles(p0 + KP);
+        if (do_bias && tid < BCO) {                  // column sums of the staged dy tile (bias gradient)
+            float sacc = 0.f;
+#pragma unroll 8
+            for (int r = 0; r < KP; ++r) sacc += (float)s_dy[r * LDO + tid];
+            bsum += sacc;
+        }
         if constexpr (DT == XMC_BF16) {
             // lane 4q+pp of each 16-lane group addresses row (8*fg + q [+4]), columns base + 4*pp .. +3
             const int q = fr >> 2, pp = fr & 3;
@@ -146,6 +156,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const XmcConvDesc d, float* 
         }
     }
 
+    if (do_bias && tid < BCO && co0 + tid < d.CD) atomicAdd(&dbias[co0 + tid], bsum);
     // accumulate: D[row = co][col = ci]
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -160,7 +171,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const XmcConvDesc d, float* 
 }
 
 template <int DT, int BCO, int BCI, int WM, int WN>
-int launch(const XmcConvDesc& d, float* dwp, hipStream_t st) {
+int launch(const XmcConvDesc& d, float* dwp, float* dbias, hipStream_t st) {
     const int64_t P = (int64_t)d.N * d.MH * d.MW;
     const int nci = (d.CS + BCI - 1) / BCI;
     const int tiles = (d.CDw / BCO) * nci * d.ntaps;
@@ -172,24 +183,27 @@ int launch(const XmcConvDesc& d, float* dwp, hipStream_t st) {
     ppb = (ppb + KP - 1) / KP * KP;
     nsplit = (P + ppb - 1) / ppb;
     dim3 grid((unsigned)nsplit, (unsigned)((d.CDw / BCO) * nci), (unsigned)d.ntaps);
-    hipLaunchKernelGGL((wgrad_kernel<DT, BCO, BCI, WM, WN>), grid, dim3(256), 0, st, d, dwp, (int)ppb);
+    hipLaunchKernelGGL((wgrad_kernel<DT, BCO, BCI, WM, WN>), grid, dim3(256), 0, st, d, dwp, dbias, (int)ppb);
     XMC_LAUNCH_CHECK();
     return 0;
 }
 
 template <int DT>
-int dispatch(const XmcConvDesc& d, float* dwp, hipStream_t st) {
+int dispatch(const XmcConvDesc& d, float* dwp, float* dbias, hipStream_t st) {
     const bool wide_ci = d.CS > 32;
-    if (d.CDw % 128 == 0) return wide_ci ? launch<DT, 128, 64, 4, 1>(d, dwp, st) : launch<DT, 128, 32, 4, 1>(d, dwp, st);
-    if (d.CDw % 64 == 0) return wide_ci ? launch<DT, 64, 64, 2, 2>(d, dwp, st) : launch<DT, 64, 32, 2, 2>(d, dwp, st);
-    return wide_ci ? launch<DT, 32, 64, 1, 4>(d, dwp, st) : launch<DT, 32, 32, 2, 2>(d, dwp, st);
+    if (d.CDw % 128 == 0) return wide_ci ? launch<DT, 128, 64, 4, 1>(d, dwp, dbias, st) : launch<DT, 128, 32, 4, 1>(d, dwp, dbias, st);
+    if (d.CDw % 64 == 0) return wide_ci ? launch<DT, 64, 64, 2, 2>(d, dwp, dbias, st) : launch<DT, 64, 32, 2, 2>(d, dwp, dbias, st);
+    return wide_ci ? launch<DT, 32, 64, 1, 4>(d, dwp, dbias, st) : launch<DT, 32, 32, 2, 2>(d, dwp, dbias, st);
 }
 
 }  // namespace
 
-int xmc_conv_wgrad_tile_try(const XmcConvDesc* d, float* dwp, void* stream);   // conv_wgrad_tile.hip
+int xmc_conv_wgrad_tile_try(const XmcConvDesc* d, float* dwp, float* dbias, void* stream);   // conv_wgrad_tile.hip
 
-extern "C" int xmc_conv_wgrad(const XmcConvDesc* d, float* dwp, void* stream) {
+extern "C" int xmc_conv_wgrad(const XmcConvDesc* d, float* dwp, void* stream) { return xmc_conv_wgrad_bias(d, dwp, nullptr, stream); }
+
+// same, and additionally dbias[co] += sum over all pixels of dy[.,co] (f32 [CD], zeroed by the caller) when dbias != NULL
+extern "C" int xmc_conv_wgrad_bias(const XmcConvDesc* d, float* dwp, float* dbias, void* stream) {
     if (!d || !d->src || !d->dst || !dwp) return XMC_EINVAL;
     if (d->dtype != XMC_BF16 && d->dtype != XMC_F32) return XMC_EINVAL;
     const int esz = xmc_esz(d->dtype);
@@ -198,9 +212,9 @@ extern "C" int xmc_conv_wgrad(const XmcConvDesc* d, float* dwp, void* stream) {
     if (d->N < 1 || d->MH < 1 || d->MW < 1 || d->SH < 1 || d->SW < 1) return XMC_ESHAPE;
     if (d->src_shift < 0 || d->src_shift > 1 || d->SA < 1) return XMC_ESHAPE;
     {
-        int rc = xmc_conv_wgrad_tile_try(d, dwp, stream);     // all-taps-per-tile kernel for the few-channel layers
+        int rc = xmc_conv_wgrad_tile_try(d, dwp, dbias, stream);     // all-taps-per-tile kernel for the few-channel layers
         if (rc != 1) return rc;
     }
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    return d->dtype == XMC_BF16 ? dispatch<XMC_BF16>(*d, dwp, st) : dispatch<XMC_F32>(*d, dwp, st);
+    return d->dtype == XMC_BF16 ? dispatch<XMC_BF16>(*d, dwp, dbias, st) : dispatch<XMC_F32>(*d, dwp, dbias, st);
 }

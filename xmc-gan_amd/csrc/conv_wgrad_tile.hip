@@ -20,7 +20,7 @@ struct WTCfg {
 };
 
 template <int NCO, int NCI>     // 16-wide blocks of (padded) Cout and Cin
-__global__ __launch_bounds__(256) void wgrad_tile_kernel(const XmcConvDesc d, float* __restrict__ dwp, const WTCfg t) {
+__global__ __launch_bounds__(256) void wgrad_tile_kernel(const XmcConvDesc d, float* __restrict__ dwp, float* __restrict__ dbias, const WTCfg t) {
     constexpr int CDP = NCO * 16, CSP = NCI * 16;
     constexpr int YS = CDP * 2 + 32, XS = CSP * 2 + 32;      // LDS row strides (bytes)
     constexpr int NS = 4 / NCO;                               // waves sharing one co block
@@ -68,6 +68,7 @@ __global__ __launch_bounds__(256) void wgrad_tile_kernel(const XmcConvDesc d, fl
         }
     };
 
+    float bsum = 0.f;
     int tile = blockIdx.x;
     if (tile < t.ntiles) prefetch(tile);
     const int fr = lane & 15, fg = lane >> 4;
@@ -90,6 +91,13 @@ __global__ __launch_bounds__(256) void wgrad_tile_kernel(const XmcConvDesc d, fl
         }
         __syncthreads();
         if (tile + (int)gridDim.x < t.ntiles) prefetch(tile + gridDim.x);
+        if (dbias != nullptr) {                               // bias gradient: column sums of the staged dy tile
+            // thread -> (channel = tid % CDP, pixel lane = tid / CDP), strided over the 256 pixels
+            const int ch = tid % CDP, pl = tid / CDP;
+            float sacc = 0.f;
+            for (int p = pl; p < TH * TW; p += NT / CDP) sacc += (float)reinterpret_cast<const __bf16*>(ydy + p * YS)[ch];
+            bsum += sacc;
+        }
 
         // K loop: one tile row (32 pixels) per step
         for (int r = 0; r < TH; ++r) {
@@ -114,6 +122,7 @@ __global__ __launch_bounds__(256) void wgrad_tile_kernel(const XmcConvDesc d, fl
         }
     }
 
+    if (dbias != nullptr && (tid % CDP) < d.CD) atomicAdd(&dbias[tid % CDP], bsum);
     // D[row = co][col = ci] -> one atomic per element per workgroup
 #pragma unroll
     for (int j = 0; j < MAXI; ++j) {
@@ -131,7 +140,7 @@ __global__ __launch_bounds__(256) void wgrad_tile_kernel(const XmcConvDesc d, fl
 }
 
 template <int NCO, int NCI>
-int launch_wt(const XmcConvDesc& d, float* dwp, const WTCfg& t, hipStream_t st) {
+int launch_wt(const XmcConvDesc& d, float* dwp, float* dbias, const WTCfg& t, hipStream_t st) {
     constexpr int YS = NCO * 32 + 32, XS = NCI * 32 + 32;
     size_t lds = (size_t)TH * TW * YS + (size_t)t.PH * t.PW * XS;
     if (lds > 160 * 1024) return 1;
@@ -144,7 +153,7 @@ int launch_wt(const XmcConvDesc& d, float* dwp, const WTCfg& t, hipStream_t st) 
     if (per_cu > 2) per_cu = 2;
     int gx = 256 * per_cu;
     if (gx > t.ntiles) gx = t.ntiles;
-    hipLaunchKernelGGL((wgrad_tile_kernel<NCO, NCI>), dim3(gx), dim3(256), lds, st, d, dwp, t);
+    hipLaunchKernelGGL((wgrad_tile_kernel<NCO, NCI>), dim3(gx), dim3(256), lds, st, d, dwp, dbias, t);
     XMC_LAUNCH_CHECK();
     return 0;
 }
@@ -152,7 +161,7 @@ int launch_wt(const XmcConvDesc& d, float* dwp, const WTCfg& t, hipStream_t st) 
 }  // namespace
 
 // 0 = launched, 1 = not eligible (caller falls back to the generic kernel), other = error
-int xmc_conv_wgrad_tile_try(const XmcConvDesc* d, float* dwp, void* stream) {
+int xmc_conv_wgrad_tile_try(const XmcConvDesc* d, float* dwp, float* dbias, void* stream) {
     static const bool off = getenv("XMC_NO_WTILE") != nullptr;
     if (off) return 1;
     if (d->dtype != XMC_BF16 || d->SA != 1 || d->src_shift != 0) return 1;
@@ -172,7 +181,7 @@ int xmc_conv_wgrad_tile_try(const XmcConvDesc* d, float* dwp, void* stream) {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int nco = d->CD <= 16 ? 1 : (d->CD <= 32 ? 2 : 4);
     const int nci = d->CS <= 16 ? 1 : (d->CS <= 32 ? 2 : 4);
-#define WT_CASE(a, b) if (nco == a && nci == b) return launch_wt<a, b>(*d, dwp, t, st);
+#define WT_CASE(a, b) if (nco == a && nci == b) return launch_wt<a, b>(*d, dwp, dbias, t, st);
     // (4,4) = 64x64 channels needs 144 accumulator + 76 staging registers per lane: measured slower than the
     // split-K kernel (166 vs 230 TF/s), so it stays there
     WT_CASE(1, 2) WT_CASE(1, 4) WT_CASE(2, 1) WT_CASE(2, 2) WT_CASE(2, 4) WT_CASE(4, 1) WT_CASE(4, 2)

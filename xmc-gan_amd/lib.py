@@ -36,6 +36,7 @@ _SIGS = {
     "xmc_abi_version": [],
     "xmc_conv_igemm": [C.POINTER(ConvDesc), vp],
     "xmc_conv_wgrad": [C.POINTER(ConvDesc), vp, vp],
+    "xmc_conv_wgrad_bias": [C.POINTER(ConvDesc), vp, vp, vp],
     "xmc_pack_weight": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp],
     "xmc_unpack_wgrad": [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp],
     "xmc_nchw_to_nhwc8": [vp, vp, i32, i32, i32, i32, i32, vp],

@@ -234,8 +234,8 @@ def _conv_dgrad_raw(dy, w, geom, in_hw, in_dtype):
     return dx
 
 
-def _conv_wgrad_raw(x, dy, geom, scale=None, up=False):
-    """gw [Co,Ci,k,k] f32 from x [N,H,W,cs_p], dy [N,OH,OW,cd_p]."""
+def _conv_wgrad_raw(x, dy, geom, scale=None, up=False, want_bias=False):
+    """gw [Co,Ci,k,k] f32 from x [N,H,W,cs_p], dy [N,OH,OW,cd_p] (and the bias gradient [cd_p] f32 from the same launch)."""
     _need_cuda(x, dy)
     N, H, W, CS = x.shape
     _, OH, OW, CDy = dy.shape
@@ -252,11 +252,12 @@ def _conv_wgrad_raw(x, dy, geom, scale=None, up=False):
     _fill_taps(d, 0, [(kh - geom.p, kw - geom.p, kh * geom.k + kw) for kh in range(geom.k) for kw in range(geom.k)])
     with prof.launch("wgrad_kernel (conv weight gradient, MFMA + split-K atomics)", 2.0 * N * OH * OW * geom.cout * geom.cin * geom.k * geom.k,
                      f"wgrad {x.dtype} N{N} {H}x{W} {geom.cin}->{geom.cout} k{geom.k}s{geom.s}"):
-        L.check(L.load().xmc_conv_wgrad(C.byref(d), _p(dwp), _st()), "xmc_conv_wgrad")
+        gb = torch.zeros(CDy, dtype=torch.float32, device=x.device) if want_bias else None
+        L.check(L.load().xmc_conv_wgrad_bias(C.byref(d), _p(dwp), _p(gb), _st()), "xmc_conv_wgrad")
     gw = torch.empty((geom.cout, geom.cin, geom.k, geom.k), dtype=torch.float32, device=x.device)
     L.call("xmc_unpack_wgrad", _p(dwp), _p(gw), geom.cout, geom.cin, geom.k, geom.k, rows, CS, _p(scale),
            _p(geom.perm_dev(x.device)), 0, _st())
-    return gw
+    return (gw, gb) if want_bias else gw
 
 
 # ------------------------------------------------------------------------------------------ conv / linear
@@ -296,10 +297,16 @@ class ConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = ConvDgradFn.apply(dy, w, geom, (x.shape[1], x.shape[2]), x.dtype)
         if not _skip_wgrad():
+            want_b = ctx.has_b and ctx.needs_input_grad[2]
             if ctx.needs_input_grad[1]:
-                dw = ConvWgradFn.apply(x, dy, geom).view(w.shape)
-            if ctx.has_b and ctx.needs_input_grad[2]:
+                if want_b:                      # bias gradient rides on the weight-gradient launch
+                    dw, db = ConvWgradBiasFn.apply(x, dy, geom)
+                    dw = dw.view(w.shape)
+                else:
+                    dw = ConvWgradFn.apply(x, dy, geom).view(w.shape)
+            elif want_b:
                 db = ColSumFn.apply(dy)
+            if db is not None:
                 if geom.row_perm is not None:
                     db = torch.zeros_like(db).index_copy(0, geom.perm_dev(db.device).long(), db)
                 db = db[: geom.cout]
@@ -345,6 +352,31 @@ class ConvWgradFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, ggw):
+        x, dy = ctx.saved_tensors
+        geom = ctx.geom
+        ggw = ggw.contiguous().view(geom.cout, geom.cin, geom.k, geom.k)
+        dx = ddy = None
+        if ctx.needs_input_grad[0]:
+            dx = ConvDgradFn.apply(dy, ggw, geom, (x.shape[1], x.shape[2]), x.dtype)
+        if ctx.needs_input_grad[1]:
+            ddy = ConvFn.apply(x, ggw, None, geom, L.ACT_NONE, dy.dtype)
+        return dx, ddy, None
+
+
+class ConvWgradBiasFn(torch.autograd.Function):
+    """ConvWgradFn that also returns the bias gradient (column sums of dy) from the same kernel launch."""
+
+    @staticmethod
+    def forward(ctx, x, dy, geom):
+        x, dy = x.contiguous(), dy.contiguous()
+        gw, gb = _conv_wgrad_raw(x, dy, geom, want_bias=True)
+        ctx.geom = geom
+        ctx.save_for_backward(x, dy)
+        ctx.mark_non_differentiable(gb)
+        return gw, gb
+
+    @staticmethod
+    def backward(ctx, ggw, _ggb):
         x, dy = ctx.saved_tensors
         geom = ctx.geom
         ggw = ggw.contiguous().view(geom.cout, geom.cin, geom.k, geom.k)
