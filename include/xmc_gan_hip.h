@@ -81,8 +81,10 @@ int xmc_conv_igemm(const XmcConvDesc* d, void* stream);
  * the caller zeroes dwp).  x: [N,SH,SW,CS], dy: [N,MH,MW,CD].  Uses class 0 of the tap table.
  */
 int xmc_conv_wgrad(const XmcConvDesc* d /* src=x, dst=dy (read only) */, float* dwp, void* stream);
-/* same launch, additionally dbias[co] += sum over all pixels of dy[.,co] (f32 [CD], zeroed by the caller): the bias gradient
- * costs no extra pass over dy */
+/* same launch, additionally the bias gradient (sum over all pixels of dy[.,co]) without an extra pass over dy.  To keep the
+ * atomics off a single cache line, workgroups add into XMC_BIAS_REPLICAS replicas: dbias is f32 [XMC_BIAS_REPLICAS][CD],
+ * zeroed by the caller, and the caller sums the replicas. */
+#define XMC_BIAS_REPLICAS 16
 int xmc_conv_wgrad_bias(const XmcConvDesc* d, float* dwp, float* dbias, void* stream);
 
 /* ---- weight (un)packing between nn.Parameter layout [Co][Ci][KH][KW] f32 and kernel layouts --------------- */

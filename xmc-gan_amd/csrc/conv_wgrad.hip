@@ -14,9 +14,8 @@ extern "C" int xmc_conv_wgrad_bias(const XmcConvDesc* d, float* dwp, float* dbia
 
 namespace {
 
-constexpr int KP = 32;  // pixels per K step
 
-template <int DT, int BCO, int BCI, int WM, int WN>
+template <int DT, int BCO, int BCI, int WM, int WN, int KP>
 __global__ __launch_bounds__(256) void wgrad_kernel(const XmcConvDesc d, float* __restrict__ dwp, float* __restrict__ dbias, int pix_per_block) {
     constexpr int NT = 256;
     static_assert(WM * WN == 4, "4 waves");
@@ -54,6 +53,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const XmcConvDesc d, float* 
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     constexpr int LO = (KP * CHO + NT - 1) / NT, LI = (KP * CHI + NT - 1) / NT;
+    static_assert(NT % CHO == 0 && (CHO & (CHO - 1)) == 0 && CHO <= 64, "bias reduction layout");
+    const bool do_bias = dbias != nullptr && tap == 0 && ci0 == 0;
+    float bsum[EPC];
+#pragma unroll
+    for (int k = 0; k < EPC; ++k) bsum[k] = 0.f;
     u32x4 ro[LO], ri[LI];
     auto load_tiles = [&](int64_t p0) {
 #pragma unroll
@@ -92,6 +96,17 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const XmcConvDesc d, float* 
             int id = tid + i * NT;
             int row = id / CHO, ch = id - row * CHO;
             if (id < KP * CHO) *reinterpret_cast<u32x4*>(&s_dy[row * LDO + ch * EPC]) = ro[i];
+            if (do_bias) {                           // bias gradient: this thread always holds chunk tid % CHO (NT % CHO == 0)
+                if constexpr (DT == XMC_BF16) {
+                    bf16x8 h = __builtin_bit_cast(bf16x8, ro[i]);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) bsum[k] += (float)h[k];
+                } else {
+                    f32x4 h = __builtin_bit_cast(f32x4, ro[i]);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) bsum[k] += h[k];
+                }
+            }
         }
 #pragma unroll
         for (int i = 0; i < LI; ++i) {
@@ -102,34 +117,28 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const XmcConvDesc d, float* 
     };
 
     const int fr = lane & 15, fg = lane >> 4;
-    const bool do_bias = dbias != nullptr && tap == 0 && ci0 == 0;
-    float bsum = 0.f;
     load_tiles(p_begin);
     for (int64_t p0 = p_begin; p0 < p_end; p0 += KP) {
         __syncthreads();                 // previous step's LDS reads are done
         store_tiles();
         __syncthreads();
         if (p0 + KP < p_end) load_tiles(p0 + KP);
-        if (do_bias && tid < BCO) {                  // column sums of the staged dy tile (bias gradient)
-            float sacc = 0.f;
-#pragma unroll 8
-            for (int r = 0; r < KP; ++r) sacc += (float)s_dy[r * LDO + tid];
-            bsum += sacc;
-        }
         if constexpr (DT == XMC_BF16) {
-            // lane 4q+pp of each 16-lane group addresses row (8*fg + q [+4]), columns base + 4*pp .. +3
-            const int q = fr >> 2, pp = fr & 3;
+          // lane 4q+pp of each 16-lane group addresses row (8*fg + q [+4]), columns base + 4*pp .. +3
+          const int q = fr >> 2, pp = fr & 3;
+#pragma unroll
+          for (int ks = 0; ks < KP / 32; ++ks) {
             bf16x8 af[TM], bfr[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                const __bf16* base = &s_dy[(8 * fg + q) * LDO + wm * WTM + i * 16 + 4 * pp];
+                const __bf16* base = &s_dy[(ks * 32 + 8 * fg + q) * LDO + wm * WTM + i * 16 + 4 * pp];
                 bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(base));
                 bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(base + 4 * LDO));
                 af[i] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const __bf16* base = &s_x[(8 * fg + q) * LDI + wn * WTN + j * 16 + 4 * pp];
+                const __bf16* base = &s_x[(ks * 32 + 8 * fg + q) * LDI + wn * WTN + j * 16 + 4 * pp];
                 bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(base));
                 bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(base + 4 * LDI));
                 bfr[j] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -139,6 +148,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const XmcConvDesc d, float* 
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+          }
         } else {
 #pragma unroll
             for (int kk = 0; kk < KP / 4; ++kk) {
@@ -156,7 +166,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const XmcConvDesc d, float* 
         }
     }
 
-    if (do_bias && tid < BCO && co0 + tid < d.CD) atomicAdd(&dbias[co0 + tid], bsum);
+    if (do_bias) {                                   // lanes with equal (lane % CHO) hold the same channels
+#pragma unroll
+        for (int k = 0; k < EPC; ++k) {
+            float v = bsum[k];
+            for (int o = 32; o >= CHO; o >>= 1) v += __shfl_xor(v, o, 64);
+            int ch = co0 + (lane % CHO) * EPC + k;
+            if (lane < CHO && ch < d.CD) atomicAdd(&dbias[(blockIdx.x & (XMC_BIAS_REPLICAS - 1)) * d.CD + ch], v);
+        }
+    }
     // accumulate: D[row = co][col = ci]
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -170,7 +188,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const XmcConvDesc d, float* 
             }
 }
 
-template <int DT, int BCO, int BCI, int WM, int WN>
+template <int DT, int BCO, int BCI, int WM, int WN, int KP>
 int launch(const XmcConvDesc& d, float* dwp, float* dbias, hipStream_t st) {
     const int64_t P = (int64_t)d.N * d.MH * d.MW;
     const int nci = (d.CS + BCI - 1) / BCI;
@@ -183,7 +201,7 @@ int launch(const XmcConvDesc& d, float* dwp, float* dbias, hipStream_t st) {
     ppb = (ppb + KP - 1) / KP * KP;
     nsplit = (P + ppb - 1) / ppb;
     dim3 grid((unsigned)nsplit, (unsigned)((d.CDw / BCO) * nci), (unsigned)d.ntaps);
-    hipLaunchKernelGGL((wgrad_kernel<DT, BCO, BCI, WM, WN>), grid, dim3(256), 0, st, d, dwp, dbias, (int)ppb);
+    hipLaunchKernelGGL((wgrad_kernel<DT, BCO, BCI, WM, WN, KP>), grid, dim3(256), 0, st, d, dwp, dbias, (int)ppb);
     XMC_LAUNCH_CHECK();
     return 0;
 }
@@ -191,9 +209,13 @@ int launch(const XmcConvDesc& d, float* dwp, float* dbias, hipStream_t st) {
 template <int DT>
 int dispatch(const XmcConvDesc& d, float* dwp, float* dbias, hipStream_t st) {
     const bool wide_ci = d.CS > 32;
-    if (d.CDw % 128 == 0) return wide_ci ? launch<DT, 128, 64, 4, 1>(d, dwp, dbias, st) : launch<DT, 128, 32, 4, 1>(d, dwp, dbias, st);
-    if (d.CDw % 64 == 0) return wide_ci ? launch<DT, 64, 64, 2, 2>(d, dwp, dbias, st) : launch<DT, 64, 32, 2, 2>(d, dwp, dbias, st);
-    return wide_ci ? launch<DT, 32, 64, 1, 4>(d, dwp, dbias, st) : launch<DT, 32, 32, 2, 2>(d, dwp, dbias, st);
+    constexpr int KPB = DT == XMC_BF16 ? 64 : 32;     // pixels per K step for the big tiles
+    if (d.CDw % 128 == 0) {
+        if (d.CS % 128 == 0 && DT == XMC_BF16) return launch<DT, 128, 128, 2, 2, KPB>(d, dwp, dbias, st);
+        return wide_ci ? launch<DT, 128, 64, 4, 1, KPB>(d, dwp, dbias, st) : launch<DT, 128, 32, 4, 1, KPB>(d, dwp, dbias, st);
+    }
+    if (d.CDw % 64 == 0) return wide_ci ? launch<DT, 64, 64, 2, 2, KPB>(d, dwp, dbias, st) : launch<DT, 64, 32, 2, 2, 32>(d, dwp, dbias, st);
+    return wide_ci ? launch<DT, 32, 64, 1, 4, 32>(d, dwp, dbias, st) : launch<DT, 32, 32, 2, 2, 32>(d, dwp, dbias, st);
 }
 
 }  // namespace

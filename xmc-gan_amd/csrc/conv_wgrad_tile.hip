@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void wgrad_tile_kernel(const XmcConvDesc d, fl
         }
     };
 
-    float bsum = 0.f;
+    float bsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int tile = blockIdx.x;
     if (tile < t.ntiles) prefetch(tile);
     const int fr = lane & 15, fg = lane >> 4;
@@ -82,6 +82,11 @@ __global__ __launch_bounds__(256) void wgrad_tile_kernel(const XmcConvDesc d, fl
             int id = tid + it * NT;
             int pix = id / YCH, ch = id - pix * YCH;
             *reinterpret_cast<u32x4*>(ydy + pix * YS + ch * 16) = yv[it];
+            if (dbias != nullptr) {                           // bias gradient: this thread always holds chunk tid % YCH
+                bf16x8 h = __builtin_bit_cast(bf16x8, yv[it]);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) bsum[k] += (float)h[k];
+            }
         }
 #pragma unroll
         for (int it = 0; it < XIT; ++it) {
@@ -91,13 +96,6 @@ __global__ __launch_bounds__(256) void wgrad_tile_kernel(const XmcConvDesc d, fl
         }
         __syncthreads();
         if (tile + (int)gridDim.x < t.ntiles) prefetch(tile + gridDim.x);
-        if (dbias != nullptr) {                               // bias gradient: column sums of the staged dy tile
-            // thread -> (channel = tid % CDP, pixel lane = tid / CDP), strided over the 256 pixels
-            const int ch = tid % CDP, pl = tid / CDP;
-            float sacc = 0.f;
-            for (int p = pl; p < TH * TW; p += NT / CDP) sacc += (float)reinterpret_cast<const __bf16*>(ydy + p * YS)[ch];
-            bsum += sacc;
-        }
 
         // K loop: one tile row (32 pixels) per step
         for (int r = 0; r < TH; ++r) {
@@ -122,7 +120,15 @@ __global__ __launch_bounds__(256) void wgrad_tile_kernel(const XmcConvDesc d, fl
         }
     }
 
-    if (dbias != nullptr && (tid % CDP) < d.CD) atomicAdd(&dbias[tid % CDP], bsum);
+    if (dbias != nullptr) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float v = bsum[k];
+            for (int o = 32; o >= YCH; o >>= 1) v += __shfl_xor(v, o, 64);
+            int ch = (lane % YCH) * 8 + k;
+            if (lane < YCH && ch < d.CD) atomicAdd(&dbias[(blockIdx.x & (XMC_BIAS_REPLICAS - 1)) * d.CD + ch], v);
+        }
+    }
     // D[row = co][col = ci] -> one atomic per element per workgroup
 #pragma unroll
     for (int j = 0; j < MAXI; ++j) {

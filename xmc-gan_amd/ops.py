@@ -252,12 +252,12 @@ def _conv_wgrad_raw(x, dy, geom, scale=None, up=False, want_bias=False):
     _fill_taps(d, 0, [(kh - geom.p, kw - geom.p, kh * geom.k + kw) for kh in range(geom.k) for kw in range(geom.k)])
     with prof.launch("wgrad_kernel (conv weight gradient, MFMA + split-K atomics)", 2.0 * N * OH * OW * geom.cout * geom.cin * geom.k * geom.k,
                      f"wgrad {x.dtype} N{N} {H}x{W} {geom.cin}->{geom.cout} k{geom.k}s{geom.s}"):
-        gb = torch.zeros(CDy, dtype=torch.float32, device=x.device) if want_bias else None
+        gb = torch.zeros((16, CDy), dtype=torch.float32, device=x.device) if want_bias else None     # XMC_BIAS_REPLICAS
         L.check(L.load().xmc_conv_wgrad_bias(C.byref(d), _p(dwp), _p(gb), _st()), "xmc_conv_wgrad")
     gw = torch.empty((geom.cout, geom.cin, geom.k, geom.k), dtype=torch.float32, device=x.device)
     L.call("xmc_unpack_wgrad", _p(dwp), _p(gw), geom.cout, geom.cin, geom.k, geom.k, rows, CS, _p(scale),
            _p(geom.perm_dev(x.device)), 0, _st())
-    return (gw, gb) if want_bias else gw
+    return (gw, gb.sum(0)) if want_bias else gw
 
 
 # ------------------------------------------------------------------------------------------ conv / linear
