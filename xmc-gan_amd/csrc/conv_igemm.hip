@@ -266,7 +266,12 @@ int launch(const XmcConvDesc& d, hipStream_t st) {
 
 template <int DT>
 int dispatch(const XmcConvDesc& d, hipStream_t st) {
-    if (d.CDw % 128 == 0) return launch<DT, 128, 128, 2, 2, 2>(d, st);
+    static const int variant = getenv("XMC_IGEMM_VARIANT") ? atoi(getenv("XMC_IGEMM_VARIANT")) : 0;
+    if (d.CDw % 128 == 0) {
+        if (variant == 1) return launch<DT, 128, 128, 2, 2, 4>(d, st);
+        if (variant == 2) return launch<DT, 128, 128, 2, 2, 1>(d, st);
+        return launch<DT, 128, 128, 2, 2, 2>(d, st);
+    }
     if (d.CDw % 64 == 0) return launch<DT, 128, 64, 4, 1, 2>(d, st);
     return launch<DT, 128, 32, 4, 1, 2>(d, st);
 }

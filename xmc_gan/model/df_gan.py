@@ -46,6 +46,16 @@ def disc_arch(img_size, nch):
     }
 
 
+_SIDE = {}
+
+
+def _side_stream(device):
+    key = (device.type, device.index)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=device)
+    return _SIDE[key]
+
+
 def nhwc_feature_perm(channels, hw=16):
     """row permutation that makes Linear(...)->view(B,C,4,4) come out as NHWC [B,4,4,C] directly:
     packed row r = p*C + c  <-  parameter row c*hw + p."""
@@ -86,8 +96,23 @@ class NetG(nn.Module):
     def forward(self, noise, sent_embs, **kwargs):
         out = self.stem(noise)
         sent_embs = self.proj_sent(sent_embs.float())
-        for gblock in self.upblocks:
-            out = gblock(out, sent_embs)
+        # The 8 conditioning MLPs of every block depend only on the sentence embedding: enqueue them on a side stream
+        # so their ~100 tiny launches (and, through autograd, their backward) overlap the convolution stream.
+        main = torch.cuda.current_stream()
+        side = _side_stream(sent_embs.device)
+        side.wait_stream(main)
+        mods, events = [], []
+        with torch.cuda.stream(side):
+            for gblock in self.upblocks:
+                mods.append(gblock.modulation(sent_embs))
+                ev = torch.cuda.Event()
+                ev.record(side)
+                events.append(ev)
+        for gblock, m, ev in zip(self.upblocks, mods, events):
+            main.wait_event(ev)
+            for t in m:
+                t.record_stream(main)
+            out = gblock(out, sent_embs, m)
         return self.tail(out)
 
 
@@ -178,8 +203,13 @@ class G_Block(nn.Module):
         if self.learnable_sc:
             self.c_sc = HipConv2d(in_dim, out_dim, 1, stride=1, padding=0)
 
-    def forward(self, x, c):
-        out = ops.axpby(self.shortcut(x), self.residual(x, c), self.gamma)
+    def modulation(self, c):
+        """the eight per-sample (scale, shift) vectors of this block, f32 [B,C] each"""
+        return (*self.affine0.scale_shift(c), *self.affine1.scale_shift(c),
+                *self.affine2.scale_shift(c), *self.affine3.scale_shift(c))
+
+    def forward(self, x, c, mod=None):
+        out = ops.axpby(self.shortcut(x), self.residual(x, c, mod), self.gamma)
         if self.upsample:
             out = ops.upsample2(out)
         return out
@@ -187,11 +217,12 @@ class G_Block(nn.Module):
     def shortcut(self, x):
         return self.c_sc(x) if self.learnable_sc else x
 
-    def residual(self, x, c):
+    def residual(self, x, c, mod=None):
+        m = self.modulation(c) if mod is None else mod
         # affine0 -> LeakyReLU -> affine1 -> LeakyReLU fused into one pass (df_gan.py:213-216), same for 2/3
-        h = ops.affine2_lrelu(x, *self.affine0.scale_shift(c), *self.affine1.scale_shift(c))
+        h = ops.affine2_lrelu(x, *m[0:4])
         h = self.c1(h)
-        h = ops.affine2_lrelu(h, *self.affine2.scale_shift(c), *self.affine3.scale_shift(c))
+        h = ops.affine2_lrelu(h, *m[4:8])
         return self.c2(h)
 
 
