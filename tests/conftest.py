@@ -9,3 +9,20 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+
+
+def _usable_cores():
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 16))
+
+
+def pytest_sessionstart(session):
+    import torch
+    torch.set_num_threads(_usable_cores())      # the CPU oracle must not oversubscribe a container with a CPU quota

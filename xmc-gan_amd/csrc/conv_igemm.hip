@@ -55,7 +55,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const XmcConvDesc d) {
     constexpr int BL = (BN * 4 + NT - 1) / NT;       // B chunks per thread per sub-step
     constexpr int STAGE_U = 2 * KSUB * (BM + BN) * 4;            // 16-byte units
     constexpr int EP_LD = BN + 4;
-    constexpr int EP_U = (BM * EP_LD * 4 + 15) / 16;
+    constexpr int EP_ROWS = BM > 128 ? 128 : BM;     // the f32 staging of the epilogue is done 128 rows at a time
+    constexpr int EP_U = (EP_ROWS * EP_LD * 4 + 15) / 16;
     constexpr int SMEM_U = STAGE_U > EP_U ? STAGE_U : EP_U;
     __shared__ u32x4 smem[SMEM_U];
     __shared__ int s_tap[XMC_MAX_TAPS];
@@ -192,65 +193,71 @@ __global__ __launch_bounds__(256) void igemm_kernel(const XmcConvDesc d) {
         __syncthreads();
     }
 
-    // ---- epilogue: acc -> LDS (f32 [BM][BN+4]) -> coalesced channel-vector stores
+    // ---- epilogue: acc -> LDS (f32 [EP_ROWS][BN+4]) -> coalesced channel-vector stores, EP_ROWS rows at a time
     float* ep = reinterpret_cast<float*>(smem);
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                ep[(wm * WTM + i * 16 + fc * 4 + r) * EP_LD + wn * WTN + j * 16 + fr] = acc[i][j][r];
-    __syncthreads();
-
     const float alpha = d.alpha_dev ? *d.alpha_dev : 1.f;
     constexpr int CPR = BN / 8;                      // 8-channel chunks per tile row
     const int dph = d.dph[cls], dpw = d.dpw[cls];
-    for (int id = tid; id < BM * CPR; id += NT) {
-        int row = id / CPR, cc = id - row * CPR;
-        int m = m0 + row, ch = n0 + cc * 8;
-        if (m >= M || ch >= d.CD) continue;
-        int n = m / MHW, rem = m - n * MHW;
-        int a = rem / d.MW, b = rem - a * d.MW;
-        size_t pix = ((size_t)n * d.DH + a * d.DA + dph) * d.DW + b * d.DA + dpw;
-        size_t idx8 = (pix * d.CD + ch) >> 3;
-        float v[8];
-        const f32x4 e0 = *reinterpret_cast<const f32x4*>(&ep[row * EP_LD + cc * 8]);
-        const f32x4 e1 = *reinterpret_cast<const f32x4*>(&ep[row * EP_LD + cc * 8 + 4]);
+    for (int half = 0; half < BM / EP_ROWS; ++half) {
+        if (half) __syncthreads();
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { v[k] = e0[k]; v[4 + k] = e1[k]; }
-        if (d.bias) {
+        for (int i = 0; i < TM; ++i) {
+            const int rbase = wm * WTM + i * 16;
+            if (rbase / EP_ROWS == half) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] += d.bias[ch + k];
-        }
-        if (d.act == XMC_ACT_LRELU) {
+                for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = lrelu_f(v[k]);
-        } else if (d.act == XMC_ACT_RELU) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
-        } else if (d.act == XMC_ACT_TANH) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = tanhf(v[k]);
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] *= alpha;
-        if (d.out_dtype == XMC_BF16) {
-            if (d.res) {
-                float rr[8];
-                Vec8<XMC_BF16>::load(d.res, idx8, rr);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] += rr[k];
+                    for (int r = 0; r < 4; ++r)
+                        ep[(rbase - half * EP_ROWS + fc * 4 + r) * EP_LD + wn * WTN + j * 16 + fr] = acc[i][j][r];
             }
-            Vec8<XMC_BF16>::store(d.dst, idx8, v);
-        } else {
-            if (d.res) {
-                float rr[8];
-                Vec8<XMC_F32>::load(d.res, idx8, rr);
+        }
+        __syncthreads();
+        for (int id = tid; id < EP_ROWS * CPR; id += NT) {
+            int row = id / CPR, cc = id - row * CPR;
+            int m = m0 + half * EP_ROWS + row, ch = n0 + cc * 8;
+            if (m >= M || ch >= d.CD) continue;
+            int n = m / MHW, rem = m - n * MHW;
+            int a = rem / d.MW, b = rem - a * d.MW;
+            size_t pix = ((size_t)n * d.DH + a * d.DA + dph) * d.DW + b * d.DA + dpw;
+            size_t idx8 = (pix * d.CD + ch) >> 3;
+            float v[8];
+            const f32x4 e0 = *reinterpret_cast<const f32x4*>(&ep[row * EP_LD + cc * 8]);
+            const f32x4 e1 = *reinterpret_cast<const f32x4*>(&ep[row * EP_LD + cc * 8 + 4]);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] += rr[k];
+            for (int k = 0; k < 4; ++k) { v[k] = e0[k]; v[4 + k] = e1[k]; }
+            if (d.bias) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] += d.bias[ch + k];
             }
-            Vec8<XMC_F32>::store(d.dst, idx8, v);
+            if (d.act == XMC_ACT_LRELU) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = lrelu_f(v[k]);
+            } else if (d.act == XMC_ACT_RELU) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+            } else if (d.act == XMC_ACT_TANH) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = tanhf(v[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] *= alpha;
+            if (d.out_dtype == XMC_BF16) {
+                if (d.res) {
+                    float rr[8];
+                    Vec8<XMC_BF16>::load(d.res, idx8, rr);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] += rr[k];
+                }
+                Vec8<XMC_BF16>::store(d.dst, idx8, v);
+            } else {
+                if (d.res) {
+                    float rr[8];
+                    Vec8<XMC_F32>::load(d.res, idx8, rr);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] += rr[k];
+                }
+                Vec8<XMC_F32>::store(d.dst, idx8, v);
+            }
         }
     }
 }
@@ -268,8 +275,11 @@ template <int DT>
 int dispatch(const XmcConvDesc& d, hipStream_t st) {
     static const int variant = getenv("XMC_IGEMM_VARIANT") ? atoi(getenv("XMC_IGEMM_VARIANT")) : 0;
     if (d.CDw % 128 == 0) {
-        if (variant == 1) return launch<DT, 128, 128, 2, 2, 4>(d, st);
-        if (variant == 2) return launch<DT, 128, 128, 2, 2, 1>(d, st);
+        const int64_t M = (int64_t)d.N * d.MH * d.MW;
+        if (variant == 1) return launch<DT, 128, 128, 2, 2, 2>(d, st);
+        // 256x128 tile, each wave a 128x64 patch: 1.33x fewer LDS fragment bytes per MFMA than 64x64 patches (the
+        // 128x128 structure measures 600-650 TF/s against a no-global-load ceiling of ~800 TF/s: LDS-read bound)
+        if (DT == XMC_BF16 && M >= 256 * 256) return launch<DT, 256, 128, 2, 2, 1>(d, st);
         return launch<DT, 128, 128, 2, 2, 2>(d, st);
     }
     if (d.CDw % 64 == 0) return launch<DT, 128, 64, 4, 1, 2>(d, st);

@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libxmc_gan_hip.so")
+LIB_PATH = os.environ.get("XMC_LIB_PATH", os.path.join(HERE, "libxmc_gan_hip.so"))   # override: kernel experiments
 
 BF16, F32 = 0, 1
 ACT_NONE, ACT_LRELU, ACT_TANH, ACT_RELU = 0, 1, 2, 3
