@@ -92,6 +92,11 @@ int xmc_conv_wgrad_bias(const XmcConvDesc* d, float* dwp, float* dbias, void* st
 /* dgrad pack: wpk[kh*KW+kw][ci][co]     (rows padded to CSw, cols to CDp)                                       */
 int xmc_pack_weight(const float* w, void* wpk, int Co, int Ci, int KH, int KW, int rows_pad, int cols_pad,
                     int transpose /*0 fwd, 1 dgrad*/, int dtype, const int32_t* row_perm /*NULL or [Co]*/, void* stream);
+/* Fused nearest-x2 upsample + 3x3 conv (F.interpolate(scale_factor=2) at df_gan.py:202 followed by the next block's c1, 187):
+ * 16 slices wpk[(i*2+j)*4 + th*2+tw][...] of pre-summed weights, one 2x2-tap convolution per output parity (i,j) on the
+ * LOW-resolution tensor -> 4/9 of the MACs and no materialised upsampled tensor.  Used with a 4-class tap table. */
+int xmc_pack_weight_upconv(const float* w, void* wpk, int Co, int Ci, int rows_pad, int cols_pad, int transpose, int dtype,
+                           void* stream);
 /* grad unpack: gw[co][ci][kh][kw] (+)= scale * dwp[kh*KW+kw][co][ci] (dwp rows padded to rows_pad, cols to cols_pad) */
 int xmc_unpack_wgrad(const float* dwp, float* gw, int Co, int Ci, int KH, int KW, int rows_pad, int cols_pad,
                      const float* scale_dev, const int32_t* row_perm, int accumulate, void* stream);
@@ -112,6 +117,8 @@ int xmc_tanh(const void* x, void* y, int64_t n, int dtype, void* stream);
 int xmc_tanh_bwd(const void* dy, const void* y, void* dx, int64_t n, int dtype, void* stream);
 /* y = a + (*alpha_dev) * b                  (shortcut + gamma*residual, df_gan.py:200,284) */
 int xmc_axpby(const void* a, const void* b, const float* alpha_dev, void* y, int64_t n, int dtype, void* stream);
+/* y[n,2h+i,2w+j] = a[n,h,w] + (*alpha_dev) * b[n,2h+i,2w+j]   (a is [N,H,W,C], b and y [N,2H,2W,C]) */
+int xmc_axpby_up(const void* a, const void* b, const float* alpha_dev, void* y, int N, int H, int W, int C, int dtype, void* stream);
 /* y = (*alpha_dev) * x */
 int xmc_scale(const void* x, const float* alpha_dev, void* y, int64_t n, int dtype, void* stream);
 /* *out (+)= sum(a*b)  (f32 scalar; out zeroed by caller when accumulate==0 is not desired) */

@@ -102,6 +102,53 @@ def test_conv_fwd_dgrad_wgrad(case, mode):
 
 
 @pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("cin,cout,H,N", [(64, 32, 16, 2), (32, 32, 32, 1), (128, 64, 8, 3), (256, 128, 4, 2), (8, 8, 16, 2)])
+def test_upsample_conv_fusion(cin, cout, H, N, mode):
+    """conv3x3(interpolate(x, 2), w) + b computed on the low-resolution tensor with pre-summed 2x2 weights
+    (df_gan.py:202 + 187): forward, dgrad (4x4-tap stride-2 gather), wgrad (through the fused upsample), bias grad;
+    and up2(a) + gamma*b."""
+    ops.set_precision(mode)
+    dt = ops.act_dtype()
+    g = torch.Generator().manual_seed(cin * 7 + H)
+    x = rt(torch.randn(N, cin, H, H, generator=g), mode)
+    w = rt(torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9), mode)
+    b = torch.randn(cout, generator=g) * 0.1
+    xr, wr, br = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    yr = F.conv2d(F.interpolate(xr, scale_factor=2), wr, br, 1, 1)
+    r = rt(torch.randn(yr.shape, generator=g), mode)
+    (yr * r).sum().backward()
+    geom = ops.ConvGeom(cin, cout, 3, 1, 1)
+    xd = to_nhwc(x, cin, dt).requires_grad_()
+    wd, bd = torch.nn.Parameter(w.to(DEV)), torch.nn.Parameter(b.to(DEV))
+    y = ops.upconv3x3(xd, wd, bd, geom)
+    # pre-summed weights are rounded once after the f32 sum: allow one extra bf16 ulp of the weight scale in bf16 mode
+    t = tol(mode, yr.abs().max().item())
+    if mode == "bf16":
+        t = dict(rtol=3e-2, atol=3e-2 * yr.abs().max().item())
+    torch.testing.assert_close(from_nhwc(y, cout), yr.detach(), **t)
+    (y.float() * to_nhwc(r, cout, torch.float32)).sum().backward()
+    tg = (lambda ref: dict(rtol=3e-2, atol=3e-2 * ref.abs().max().item())) if mode == "bf16" else (lambda ref: tol(mode, ref.abs().max().item()))
+    torch.testing.assert_close(from_nhwc(xd.grad, cin), xr.grad, **tg(xr.grad))
+    torch.testing.assert_close(wd.grad.cpu(), wr.grad, **tg(wr.grad))
+    torch.testing.assert_close(bd.grad.cpu(), br.grad, **tg(br.grad))
+    # up2(a) + gamma * b
+    a = rt(torch.randn(N, cout, H, H, generator=g), mode)
+    bb = rt(torch.randn(N, cout, 2 * H, 2 * H, generator=g), mode)
+    gm = torch.tensor([0.6])
+    ar, bbr, gmr = a.clone().requires_grad_(), bb.clone().requires_grad_(), gm.clone().requires_grad_()
+    zr = F.interpolate(ar, scale_factor=2) + gmr * bbr
+    (zr * r).sum().backward()
+    ad, bbd = to_nhwc(a, cout, dt).requires_grad_(), to_nhwc(bb, cout, dt).requires_grad_()
+    gmd = torch.nn.Parameter(gm.to(DEV))
+    z = ops.axpby_up(ad, bbd, gmd)
+    torch.testing.assert_close(from_nhwc(z, cout), zr.detach(), **tol(mode, 4.0))
+    (z.float() * to_nhwc(r, cout, torch.float32)).sum().backward()
+    torch.testing.assert_close(from_nhwc(ad.grad, cout), ar.grad, **tol(mode, 8.0))
+    torch.testing.assert_close(from_nhwc(bbd.grad, cout), bbr.grad, **tol(mode, 4.0))
+    torch.testing.assert_close(gmd.grad.cpu(), gmr.grad, **tol(mode, gmr.grad.abs().item() + 10.0))
+
+
+@pytest.mark.parametrize("mode", MODES)
 def test_linear_row_perm_and_mixed_dtype(mode):
     """proj_noise: f32 [B,100] -> NHWC [B,4,4,C] in the activation dtype via a row permutation."""
     ops.set_precision(mode)

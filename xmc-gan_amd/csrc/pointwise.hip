@@ -368,6 +368,54 @@ __global__ void pack_weight_kernel(const float* w, void* wpk, int Co, int Ci, in
         else reinterpret_cast<float*>(wpk)[i] = v;
     }
 }
+// Fused nearest-x2 upsample + 3x3 convolution: output parity class (i,j) sees only a 2x2 neighbourhood of the
+// low-resolution input, with weights that are sums of the 3x3 taps landing on the same low-res pixel:
+//   rows: i=0: {kh=0} | {kh=1,2}     i=1: {kh=0,1} | {kh=2}        (same for columns)
+// slice index = (i*2+j)*4 + th*2+tw.  Summation in f32, one rounding to the kernel dtype.
+template <int DT>
+__global__ void pack_upconv_kernel(const float* w, void* wpk, int Co, int Ci, int rows_pad, int cols_pad, int transpose) {
+    const int64_t total = (int64_t)16 * rows_pad * cols_pad;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        int c = (int)(idx % cols_pad);
+        int64_t q = idx / cols_pad;
+        int r = (int)(q % rows_pad);
+        int sl = (int)(q / rows_pad);
+        int cls = sl >> 2, t = sl & 3;
+        int i = cls >> 1, j = cls & 1, th = t >> 1, tw = t & 1;
+        int co = transpose ? c : r, ci = transpose ? r : c;
+        float v = 0.f;
+        if (co < Co && ci < Ci) {
+            int kh0 = (i == 0) ? (th == 0 ? 0 : 1) : (th == 0 ? 0 : 2), kh1 = (i == 0) ? (th == 0 ? 0 : 2) : (th == 0 ? 1 : 2);
+            int kw0 = (j == 0) ? (tw == 0 ? 0 : 1) : (tw == 0 ? 0 : 2), kw1 = (j == 0) ? (tw == 0 ? 0 : 2) : (tw == 0 ? 1 : 2);
+            const float* wp = w + ((int64_t)co * Ci + ci) * 9;
+            for (int kh = kh0; kh <= kh1; ++kh)
+                for (int kw = kw0; kw <= kw1; ++kw) v += wp[kh * 3 + kw];
+        }
+        if (DT == XMC_BF16) reinterpret_cast<__bf16*>(wpk)[idx] = (__bf16)v;
+        else reinterpret_cast<float*>(wpk)[idx] = v;
+    }
+}
+// y[n,2h+i,2w+j,:] = a[n,h,w,:] + alpha * b[n,2h+i,2w+j,:]      (up(shortcut) + gamma*residual without materialising up())
+template <int DT>
+__global__ void axpby_up_kernel(const void* a, const void* b, const float* alpha, void* y, int N, int H, int W, int C8) {
+    const float al = *alpha;
+    const int OH = 2 * H, OW = 2 * W;
+    const int64_t total = (int64_t)N * OH * OW * C8;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        int cc = (int)(idx % C8);
+        int64_t p = idx / C8;
+        int ow = (int)(p % OW); p /= OW;
+        int oh = (int)(p % OH);
+        int n = (int)(p / OH);
+        float u[8], v[8];
+        Vec8<DT>::load(a, (((int64_t)n * H + (oh >> 1)) * W + (ow >> 1)) * C8 + cc, u);
+        Vec8<DT>::load(b, idx, v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) u[k] += al * v[k];
+        Vec8<DT>::store(y, idx, u);
+    }
+}
+
 __global__ void unpack_wgrad_kernel(const float* dwp, float* gw, int Co, int Ci, int KHW, int rows_pad, int cols_pad,
                                     const float* scale_dev, const int32_t* row_perm, int accumulate) {
     const float scale = scale_dev ? *scale_dev : 1.f;
@@ -575,6 +623,29 @@ extern "C" int xmc_unpack_wgrad(const float* dwp, float* gw, int Co, int Ci, int
     int64_t total = (int64_t)Co * Ci * KH * KW;
     hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(nblocks(total)), dim3(NT), 0, ST(s), dwp, gw, Co, Ci, KH * KW, rows_pad, cols_pad,
                        scale_dev, row_perm, accumulate);
+    XMC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int xmc_pack_weight_upconv(const float* w, void* wpk, int Co, int Ci, int rows_pad, int cols_pad, int transpose,
+                                      int dtype, void* s) {
+    if (!w || !wpk) return XMC_EINVAL;
+    if (transpose ? (rows_pad < Ci || cols_pad < Co) : (rows_pad < Co || cols_pad < Ci)) return XMC_ESHAPE;
+    int64_t total = (int64_t)16 * rows_pad * cols_pad;
+    dim3 g(nblocks(total)), blk(NT);
+    if (dtype == XMC_BF16) hipLaunchKernelGGL((pack_upconv_kernel<XMC_BF16>), g, blk, 0, ST(s), w, wpk, Co, Ci, rows_pad, cols_pad, transpose);
+    else if (dtype == XMC_F32) hipLaunchKernelGGL((pack_upconv_kernel<XMC_F32>), g, blk, 0, ST(s), w, wpk, Co, Ci, rows_pad, cols_pad, transpose);
+    else return XMC_EINVAL;
+    XMC_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int xmc_axpby_up(const void* a, const void* b, const float* alpha, void* y, int N, int H, int W, int C, int dtype, void* s) {
+    if (!alpha || C % 8) return XMC_EINVAL;
+    int64_t total = (int64_t)N * 4 * H * W * (C / 8);
+    dim3 g(nblocks(total)), blk(NT);
+    if (dtype == XMC_BF16) hipLaunchKernelGGL((axpby_up_kernel<XMC_BF16>), g, blk, 0, ST(s), a, b, alpha, y, N, H, W, C / 8);
+    else if (dtype == XMC_F32) hipLaunchKernelGGL((axpby_up_kernel<XMC_F32>), g, blk, 0, ST(s), a, b, alpha, y, N, H, W, C / 8);
+    else return XMC_EINVAL;
     XMC_LAUNCH_CHECK();
     return 0;
 }

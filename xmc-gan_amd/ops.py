@@ -164,6 +164,88 @@ def _packed_cached(w, geom, transpose, dtype):
     return out
 
 
+def _pack_upconv(w, geom, transpose, dtype):
+    cs_p, cd_p = chan_pad(geom.cin, dtype), pad_to(geom.cout, 8)
+    rows, cols = (pad_to(cs_p, 32), cd_p) if transpose else (pad_to(cd_p, 32), cs_p)
+    out = torch.empty((16, rows, cols), dtype=dtype, device=w.device)
+    wf = w.detach()
+    if wf.dtype != torch.float32 or not wf.is_contiguous():
+        wf = wf.float().contiguous()
+    L.call("xmc_pack_weight_upconv", _p(wf), _p(out), geom.cout, geom.cin, rows, cols, int(transpose), _code(dtype), _st())
+    return out
+
+
+def _packed_upconv_cached(w, geom, transpose, dtype):
+    if not isinstance(w, torch.nn.Parameter):
+        return _pack_upconv(w, geom, transpose, dtype)
+    k = (id(w), "up", transpose, dtype)
+    hit = _pack_cache.get(k)
+    if hit is not None and hit[0]() is w and hit[1] == w._version and hit[2] == _weights_epoch[0] and hit[3] is geom:
+        return hit[4]
+    out = _pack_upconv(w, geom, transpose, dtype)
+    _pack_cache[k] = (weakref.ref(w), w._version, _weights_epoch[0], geom, out)
+    return out
+
+
+def _upconv_fwd_raw(x, w, bias, geom, act, out_dtype):
+    """conv3x3(nearest_up2(x), w) + bias on the LOW-resolution x [N,H,W,Cs] -> [N,2H,2W,Cd]: four output-parity classes,
+    each a 2x2-tap convolution with pre-summed weights (4/9 of the MACs, the upsampled tensor never exists)."""
+    _need_cuda(x, w)
+    assert geom.k == 3 and geom.s == 1 and geom.p == 1
+    N, H, W, CS = x.shape
+    cd_p = pad_to(geom.cout, 8)
+    wpk = _packed_upconv_cached(w, geom, 0, x.dtype)
+    y = torch.empty((N, 2 * H, 2 * W, cd_p), dtype=out_dtype, device=x.device)
+    d = L.ConvDesc()
+    d.src, d.wpk, d.dst = x.data_ptr(), wpk.data_ptr(), y.data_ptr()
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.N, d.SH, d.SW, d.CS = N, H, W, CS
+    d.DH, d.DW, d.CD = 2 * H, 2 * W, cd_p
+    d.MH, d.MW, d.SA, d.DA, d.src_shift = H, W, 1, 2, 0
+    d.ntaps, d.nclass, d.CDw = 4, 4, wpk.shape[1]
+    d.act, d.dtype, d.out_dtype = act, _code(x.dtype), _code(out_dtype)
+    for i in range(2):
+        for j in range(2):
+            cls = i * 2 + j
+            _fill_taps(d, cls, [(i - 1 + th, j - 1 + tw, cls * 4 + th * 2 + tw) for th in range(2) for tw in range(2)])
+            d.dph[cls], d.dpw[cls] = i, j
+    with prof.launch("igemm_kernel (conv fwd+dgrad, MFMA implicit GEMM)", 2.0 * N * 4 * H * W * geom.cout * geom.cin * 9,
+                     f"upconv-fwd {x.dtype} N{N} {2 * H}x{2 * W} {geom.cin}->{geom.cout} k3s1"):
+        L.check(L.load().xmc_conv_igemm(C.byref(d), _st()), "xmc_conv_igemm(upconv fwd)")
+    return y
+
+
+def _upconv_dgrad_raw(dy, w, geom, in_dtype):
+    """gradient of _upconv_fwd_raw w.r.t. its low-resolution input: a 4x4-tap stride-2 gather over dy with the same
+    pre-summed weight slices (transposed)."""
+    _need_cuda(dy, w)
+    N, OH, OW, CDy = dy.shape
+    H, W = OH // 2, OW // 2
+    cs_p = chan_pad(geom.cin, in_dtype)
+    wpk = _packed_upconv_cached(w, geom, 1, dy.dtype)
+    dx = torch.empty((N, H, W, cs_p), dtype=in_dtype, device=dy.device)
+    d = L.ConvDesc()
+    d.src, d.wpk, d.dst = dy.data_ptr(), wpk.data_ptr(), dx.data_ptr()
+    d.N, d.SH, d.SW, d.CS = N, OH, OW, CDy
+    d.DH, d.DW, d.CD = H, W, cs_p
+    d.MH, d.MW, d.SA, d.DA, d.src_shift = H, W, 2, 1, 0
+    d.ntaps, d.nclass, d.CDw = 16, 1, wpk.shape[1]
+    d.act, d.dtype, d.out_dtype = L.ACT_NONE, _code(dy.dtype), _code(in_dtype)
+    taps = []
+    for i in range(2):
+        for th in range(2):
+            ro = i - 2 * (i - 1 + th)
+            for j in range(2):
+                for tw in range(2):
+                    co = j - 2 * (j - 1 + tw)
+                    taps.append((ro, co, (i * 2 + j) * 4 + th * 2 + tw))
+    _fill_taps(d, 0, taps)
+    with prof.launch("igemm_kernel (conv fwd+dgrad, MFMA implicit GEMM)", 2.0 * N * OH * OW * geom.cout * geom.cin * 9,
+                     f"upconv-dgrad {dy.dtype} N{N} {OH}x{OW} {geom.cin}->{geom.cout} k3s1"):
+        L.check(L.load().xmc_conv_igemm(C.byref(d), _st()), "xmc_conv_igemm(upconv dgrad)")
+    return dx
+
+
 def _conv_fwd_raw(x, w, bias, geom, act, out_dtype, res=None, alpha=None, up=False):
     """y = act(conv(x, w) + bias) [*alpha] [+ res]; x [N,H,W,Cs]. ``up``: x is read through a fused nearest x2."""
     _need_cuda(x, w)
@@ -386,6 +468,71 @@ class ConvWgradBiasFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             ddy = ConvFn.apply(x, ggw, None, geom, L.ACT_NONE, dy.dtype)
         return dx, ddy, None
+
+
+class UpConvFn(torch.autograd.Function):
+    """conv3x3(F.interpolate(x, scale_factor=2), w) + b as ONE operator on the low-resolution tensor
+    (df_gan.py:202 of block i followed by c1 of block i+1, 187/217).  First-order only (generator path)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, geom):
+        x = x.contiguous()
+        bp = None
+        if b is not None:
+            cd_p = pad_to(geom.cout, 8)
+            bp = b.detach().float()
+            if bp.numel() < cd_p:
+                bp = torch.nn.functional.pad(bp, (0, cd_p - bp.numel()))
+            bp = bp.contiguous()
+        y = _upconv_fwd_raw(x, w, bp, geom, L.ACT_NONE, x.dtype)
+        ctx.geom, ctx.has_b = geom, b is not None
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        geom = ctx.geom
+        dy = dy.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = _upconv_dgrad_raw(dy, w, geom, x.dtype)
+        if not _skip_wgrad():
+            want_b = ctx.has_b and ctx.needs_input_grad[2]
+            if ctx.needs_input_grad[1]:
+                # the weight gradient is taken w.r.t. the original 3x3 taps: wgrad kernel reading x through the x2 upsample
+                r = _conv_wgrad_raw(x, dy, geom, up=True, want_bias=want_b)
+                dw, db = (r if want_b else (r, None))
+                dw = dw.view(w.shape)
+            elif want_b:
+                db = ColSumFn.apply(dy)
+            if db is not None:
+                db = db[: geom.cout]
+        return dx, dw, db, None
+
+
+class AxpbyUpFn(torch.autograd.Function):
+    """up2(a) + alpha*b without materialising up2(a): the block output `upsample(shortcut) + gamma*residual`."""
+
+    @staticmethod
+    def forward(ctx, a, b, alpha):
+        a, b = a.contiguous(), b.contiguous()
+        N, H, W, Cc = a.shape
+        assert b.shape == (N, 2 * H, 2 * W, Cc)
+        al = alpha.detach().reshape(-1).float()
+        y = torch.empty_like(b)
+        L.call("xmc_axpby_up", _p(a), _p(b), _p(al), _p(y), N, H, W, Cc, _code(a.dtype), _st())
+        ctx.save_for_backward(b, alpha)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        b, alpha = ctx.saved_tensors
+        da = SumPool2Fn.apply(dy, 1.0) if ctx.needs_input_grad[0] else None
+        db = ScaleFn.apply(dy, alpha) if ctx.needs_input_grad[1] else None
+        dal = DotFn.apply(dy, b).reshape(alpha.shape) if ctx.needs_input_grad[2] else None
+        return da, db, dal
 
 
 def conv2d(x, w, b, geom, act=L.ACT_NONE, out_dtype=None):
@@ -841,6 +988,14 @@ def to_nchw(x_nhwc8, c):
 
 def affine2_lrelu(x, g0, b0, g1, b1):
     return Affine2LreluFn.apply(x, g0, b0, g1, b1)
+
+
+def upconv3x3(x_lo, w, b, geom):
+    return UpConvFn.apply(x_lo, w, b, geom)
+
+
+def axpby_up(a_lo, b_hi, alpha):
+    return AxpbyUpFn.apply(a_lo, b_hi, alpha)
 
 
 def affine_lrelu(x, g, b):

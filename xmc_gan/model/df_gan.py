@@ -6,6 +6,7 @@ and ``state_dict()`` keys as the reference, so it is a drop-in for ``train_gan.p
 Internally activations are NHWC in the engine's activation dtype; the public tensors keep the
 reference's logical NCHW shapes (``netD(x)`` returns a channels-last view, ``netG`` an f32 NCHW image).
 """
+import os
 from collections import OrderedDict
 
 import torch
@@ -108,11 +109,20 @@ class NetG(nn.Module):
                 ev = torch.cuda.Event()
                 ev.record(side)
                 events.append(ev)
+        # Blocks hand over their output BEFORE the nearest x2 upsample (df_gan.py:201-202); the next block consumes it
+        # through operators that commute with / absorb the upsample, so the 4x larger tensor is never written.
+        pending_up = False
+        fuse_up = os.environ.get("XMC_NO_UPCONV") is None
         for gblock, m, ev in zip(self.upblocks, mods, events):
             main.wait_event(ev)
             for t in m:
                 t.record_stream(main)
-            out = gblock(out, sent_embs, m)
+            out = gblock.forward_fused(out, m, pending_up)
+            pending_up = gblock.upsample
+            if pending_up and not fuse_up:
+                out, pending_up = ops.upsample2(out), False
+        if pending_up:
+            out = ops.upsample2(out)
         return self.tail(out)
 
 
@@ -213,6 +223,18 @@ class G_Block(nn.Module):
         if self.upsample:
             out = ops.upsample2(out)
         return out
+
+    def forward_fused(self, x, mod, x_pending_up):
+        """Same function as ``forward`` on the logical input ``up2(x)`` when ``x_pending_up`` (else ``x``), returning the
+        block output WITHOUT its trailing upsample.  With a pending upsample: the conditional affines and the 1x1 shortcut
+        commute with nearest upsampling and run at low resolution, ``c1`` runs as the fused upsample+3x3 operator
+        (4 parity classes of 2x2 taps: 4/9 of the MACs) and the shortcut is upsampled inside the final add."""
+        if not x_pending_up:
+            return ops.axpby(self.shortcut(x), self.residual(x, None, mod), self.gamma)
+        h = ops.affine2_lrelu(x, *mod[0:4])
+        h = ops.upconv3x3(h, self.c1.weight, self.c1.bias, self.c1.geom)
+        h = ops.affine2_lrelu(h, *mod[4:8])
+        return ops.axpby_up(self.shortcut(x), self.c2(h), self.gamma)
 
     def shortcut(self, x):
         return self.c_sc(x) if self.learnable_sc else x
