@@ -43,6 +43,14 @@ __global__ __launch_bounds__(256) void tile_kernel(const XmcConvDesc d, const Ti
     const int cls = blockIdx.z;
     const int n0 = blockIdx.y * BN;
     const int tpi = t.tiles_y * t.tiles_x;
+    // tap tables live in LDS: indexing the kernel-argument arrays with a run-time tap would go through vector memory
+    __shared__ int s_toff[XMC_MAX_TAPS], s_twi[XMC_MAX_TAPS];
+    if (tid < XMC_MAX_TAPS) {
+        const int tt = tid < d.ntaps ? tid : 0;
+        s_toff[tid] = (d.dh[cls][tt] - t.dh0[cls]) * t.PW[cls] + (d.dw[cls][tt] - t.dw0[cls]);
+        s_twi[tid] = d.wi[cls][tt];
+    }
+    __syncthreads();
     const int img = blockIdx.x / tpi, trem = blockIdx.x - img * tpi;
     const int a0 = (trem / t.tiles_x) * t.TH, b0 = (trem % t.tiles_x) * t.TW;
     const int PH = t.PH[cls], PW = t.PW[cls], dh0 = t.dh0[cls], dw0 = t.dw0[cls];
@@ -62,7 +70,7 @@ __global__ __launch_bounds__(256) void tile_kernel(const XmcConvDesc d, const Ti
     constexpr int WL_MAX = (BN * 8 + NT - 1) / NT;        // cps <= 8
     u32x4 wr[WL_MAX];
     auto load_w = [&](int tap, int sl) {
-        const int twi = d.wi[cls][tap];
+        const int twi = s_twi[tap];
 #pragma unroll
         for (int j = 0; j < WL_MAX; ++j) {
             int id = tid + j * NT;
@@ -142,7 +150,7 @@ __global__ __launch_bounds__(256) void tile_kernel(const XmcConvDesc d, const Ti
         for (int tap = 0; tap < d.ntaps; ++tap) {
             const bool more = tap + 1 < d.ntaps;
             if (more) load_w(tap + 1, sl);
-            const int toff = (d.dh[cls][tap] - dh0) * PW + (d.dw[cls][tap] - dw0);
+            const int toff = s_toff[tap];
             const unsigned char* wb = wbuf + wcur * wbytes;
             for (int s = 0; s < slab / 32; ++s) {
                 u32x4 af[TM], bf[TN];
@@ -256,6 +264,11 @@ __global__ __launch_bounds__(256) void ptile_kernel(const XmcConvDesc d, const T
     const int n0 = blockIdx.y * BN;
     const int tpi = t.tiles_y * t.tiles_x;
     const int PH = t.PH[cls], PW = t.PW[cls], dh0 = t.dh0[cls], dw0 = t.dw0[cls];
+    __shared__ int s_toff[XMC_MAX_TAPS];          // tap -> patch offset (see tile_kernel)
+    if (tid < XMC_MAX_TAPS) {
+        const int tt = tid < d.ntaps ? tid : 0;
+        s_toff[tid] = (d.dh[cls][tt] - dh0) * PW + (d.dw[cls][tt] - dw0);
+    }
     const int slab = t.slab;                     // == CS (single slab)
     const int cps = slab / 8;
     const int pstride = slab * 2 + 32;
@@ -342,7 +355,7 @@ __global__ __launch_bounds__(256) void ptile_kernel(const XmcConvDesc d, const T
 #pragma unroll
             for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int tap = 0; tap < d.ntaps; ++tap) {
-            const int toff = (d.dh[cls][tap] - dh0) * PW + (d.dw[cls][tap] - dw0);
+            const int toff = s_toff[tap];
             const unsigned char* wb = wall + tap * BN * pstride;
             for (int s = 0; s < slab / 32; ++s) {
                 u32x4 af[TM], bf[TN];

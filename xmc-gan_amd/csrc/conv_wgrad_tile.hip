@@ -12,18 +12,18 @@
 
 namespace {
 
-constexpr int TH = 8, TW = 32, NT = 256;
+constexpr int TH = 8, TW = 32;
 
 struct WTCfg {
     int tiles_y, tiles_x, ntiles;
     int PH, PW, dh0, dw0;
 };
 
-template <int NCO, int NCI>     // 16-wide blocks of (padded) Cout and Cin
-__global__ __launch_bounds__(256) void wgrad_tile_kernel(const XmcConvDesc d, float* __restrict__ dwp, float* __restrict__ dbias, const WTCfg t) {
+template <int NCO, int NCI, int NT>     // 16-wide blocks of (padded) Cout and Cin; NT threads (4 or 8 waves)
+__global__ __launch_bounds__(NT) void wgrad_tile_kernel(const XmcConvDesc d, float* __restrict__ dwp, float* __restrict__ dbias, const WTCfg t) {
     constexpr int CDP = NCO * 16, CSP = NCI * 16;
     constexpr int YS = CDP * 2 + 32, XS = CSP * 2 + 32;      // LDS row strides (bytes)
-    constexpr int NS = 4 / NCO;                               // waves sharing one co block
+    constexpr int NS = (NT / 64) / NCO;                       // waves sharing one co block
     constexpr int MAXI = (NCI * 9 + NS - 1) / NS;             // (ci block, tap) items per wave
     constexpr int YCH = CDP / 8, XCH = CSP / 8;               // 16-byte chunks per pixel
     constexpr int YIT = TH * TW * YCH / NT;                   // dy chunks per thread per tile (>= 2)
@@ -74,6 +74,17 @@ __global__ __launch_bounds__(256) void wgrad_tile_kernel(const XmcConvDesc d, fl
     const int fr = lane & 15, fg = lane >> 4;
     const int q = fr >> 2, pp4 = fr & 3;
     const int nitems = NCI * d.ntaps;
+    // per-item LDS byte offset of the shifted x fragment, computed ONCE: indexing the tap tables of the kernel-argument
+    // struct with a run-time tap inside the MFMA loop makes the compiler fetch them with vector memory loads
+    // (rocprof: 223 VMEM reads per wave per tile instead of 10, SQ_WAIT_ANY 69 %)
+    int itoff[MAXI];
+#pragma unroll
+    for (int j = 0; j < MAXI; ++j) {
+        const int item = slice + j * NS;
+        int ib = 0, tap = 0;
+        if (item < nitems) { ib = item / d.ntaps; tap = item - ib * d.ntaps; }
+        itoff[j] = ((d.dh[0][tap] - t.dh0) * PW + (d.dw[0][tap] - t.dw0)) * XS + (ib * 16) * 2;
+    }
 
     for (; tile < t.ntiles; tile += gridDim.x) {
         __syncthreads();                                      // previous tile's reads are done
@@ -108,9 +119,7 @@ __global__ __launch_bounds__(256) void wgrad_tile_kernel(const XmcConvDesc d, fl
             for (int j = 0; j < MAXI; ++j) {
                 const int item = slice + j * NS;
                 if (item < nitems) {                          // wave-uniform
-                    const int ib = item / d.ntaps, tap = item - ib * d.ntaps;
-                    const int prow = r + d.dh[0][tap] - t.dh0, pcol = d.dw[0][tap] - t.dw0;
-                    const unsigned char* bb = xp + (size_t)(prow * PW + pcol + 8 * fg + q) * XS + (ib * 16 + 4 * pp4) * 2;
+                    const unsigned char* bb = xp + (r * PW + 8 * fg + q) * XS + itoff[j] + (4 * pp4) * 2;
                     bf16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(bb));
                     bf16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(bb + 4 * XS));
                     const bf16x8 bf = bf16x8{blo[0], blo[1], blo[2], blo[3], bhi[0], bhi[1], bhi[2], bhi[3]};
@@ -145,21 +154,21 @@ __global__ __launch_bounds__(256) void wgrad_tile_kernel(const XmcConvDesc d, fl
     }
 }
 
-template <int NCO, int NCI>
+template <int NCO, int NCI, int NT = 256>
 int launch_wt(const XmcConvDesc& d, float* dwp, float* dbias, const WTCfg& t, hipStream_t st) {
     constexpr int YS = NCO * 32 + 32, XS = NCI * 32 + 32;
     size_t lds = (size_t)TH * TW * YS + (size_t)t.PH * t.PW * XS;
     if (lds > 160 * 1024) return 1;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_tile_kernel<NCO, NCI>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_tile_kernel<NCO, NCI, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     int per_cu = (int)(160 * 1024 / lds);
     if (per_cu > 2) per_cu = 2;
     int gx = 256 * per_cu;
     if (gx > t.ntiles) gx = t.ntiles;
-    hipLaunchKernelGGL((wgrad_tile_kernel<NCO, NCI>), dim3(gx), dim3(256), lds, st, d, dwp, dbias, t);
+    hipLaunchKernelGGL((wgrad_tile_kernel<NCO, NCI, NT>), dim3(gx), dim3(NT), lds, st, d, dwp, dbias, t);
     XMC_LAUNCH_CHECK();
     return 0;
 }
@@ -188,9 +197,11 @@ int xmc_conv_wgrad_tile_try(const XmcConvDesc* d, float* dwp, float* dbias, void
     const int nco = d->CD <= 16 ? 1 : (d->CD <= 32 ? 2 : 4);
     const int nci = d->CS <= 16 ? 1 : (d->CS <= 32 ? 2 : 4);
 #define WT_CASE(a, b) if (nco == a && nci == b) return launch_wt<a, b>(*d, dwp, dbias, t, st);
-    // (4,4) = 64x64 channels needs 144 accumulator + 76 staging registers per lane: measured slower than the
-    // split-K kernel (166 vs 230 TF/s), so it stays there
+    // (4,4) = 64x64 channels with 4 waves needs 144 accumulator + 76 staging registers per lane and measured slower than
+    // the split-K kernel (166 vs 230 TF/s); it runs with 8 waves instead (below)
     WT_CASE(1, 2) WT_CASE(1, 4) WT_CASE(2, 1) WT_CASE(2, 2) WT_CASE(2, 4) WT_CASE(4, 1) WT_CASE(4, 2)
+    static const bool no44 = getenv("XMC_NO_WT44") != nullptr;
+    if (nco == 4 && nci == 4 && !no44) return launch_wt<4, 4, 512>(*d, dwp, dbias, t, st);   // 8 waves: 72 accumulator registers per lane
 #undef WT_CASE
     return 1;
 }
