@@ -257,6 +257,8 @@ __global__ __launch_bounds__(256) void ptile_kernel(const XmcConvDesc d, const T
     constexpr int TM = WTM / 16, TN = BN / 16;
     constexpr int EP_ROWS = 128, EP_LD = BN + 4;
     constexpr int PIT = 12;
+    constexpr int CPR = BN / 8;                  // 8-channel chunks per output row
+    constexpr int EIT = EP_ROWS * CPR / NT;      // epilogue chunks per thread per half
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wm = tid >> 6;
@@ -264,14 +266,14 @@ __global__ __launch_bounds__(256) void ptile_kernel(const XmcConvDesc d, const T
     const int n0 = blockIdx.y * BN;
     const int tpi = t.tiles_y * t.tiles_x;
     const int PH = t.PH[cls], PW = t.PW[cls], dh0 = t.dh0[cls], dw0 = t.dw0[cls];
-    __shared__ int s_toff[XMC_MAX_TAPS];          // tap -> patch offset (see tile_kernel)
-    if (tid < XMC_MAX_TAPS) {
-        const int tt = tid < d.ntaps ? tid : 0;
-        s_toff[tid] = (d.dh[cls][tt] - dh0) * PW + (d.dw[cls][tt] - dw0);
-    }
-    const int slab = t.slab;                     // == CS (single slab)
+    __shared__ int s_toff[XMC_MAX_TAPS];          // tap -> patch byte offset (kernel-argument arrays indexed with a
+    const int slab = t.slab;                      // run-time tap would be fetched through vector memory)
     const int cps = slab / 8;
     const int pstride = slab * 2 + 32;
+    if (tid < XMC_MAX_TAPS) {
+        const int tt = tid < d.ntaps ? tid : 0;
+        s_toff[tid] = ((d.dh[cls][tt] - dh0) * PW + (d.dw[cls][tt] - dw0)) * pstride;
+    }
     const int cs_units = d.CS / 8;
     unsigned char* patch = smem;
     const int patch_bytes = (PH * PW * pstride + 15) & ~15;
@@ -287,37 +289,62 @@ __global__ __launch_bounds__(256) void ptile_kernel(const XmcConvDesc d, const T
     }
 
     const int fr = lane & 15, fc = lane >> 4;
-    int apix[TM];
+    // All per-thread index arithmetic that does not depend on the tile is done ONCE here: with one or two waves per
+    // SIMD every VALU instruction costs ~4 issue cycles, and the first version of this kernel spent 890 VALU
+    // instructions per tile against 72 MFMAs (rocprof SQ_INSTS_VALU / SQ_INSTS_MFMA).
+    int abyte[TM];                                // patch byte offset of this lane's A-fragment rows (tap (0,0), k-chunk fc)
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         int ml = wm * WTM + i * 16;
-        apix[i] = (ml >> t.log2TW) * PW + (ml & (t.TW - 1)) + fr;
+        abyte[i] = ((ml >> t.log2TW) * PW + (ml & (t.TW - 1)) + fr) * pstride + fc * 16;
     }
+    const int bbyte = fr * pstride + fc * 16;     // weight-row byte offset of this lane's B fragment
     const int pchunk = tid % cps, ppix0 = tid / cps, ppix_step = NT / cps;
+    int pyx[PIT];                                 // (py << 16) | px of this thread's patch pixels, -1 if beyond the patch
+    int psrc[PIT];                                // source offset (16-byte units) relative to the tile origin pixel
+#pragma unroll
+    for (int it = 0; it < PIT; ++it) {
+        int pp = ppix0 + it * ppix_step;
+        int py = pp / PW, px = pp - py * PW;
+        pyx[it] = pp < PH * PW ? ((py << 16) | px) : -1;
+        psrc[it] = ((dh0 + py) * d.SW + (dw0 + px)) * cs_units + pchunk;
+    }
+    int eoff[EIT], erow[EIT], ecc[EIT];           // epilogue: destination offset (8-channel units) relative to tile origin
+#pragma unroll
+    for (int k = 0; k < EIT; ++k) {
+        int id = tid + k * NT;
+        erow[k] = id / CPR; ecc[k] = id - erow[k] * CPR;
+    }
+    const int dph = d.dph[cls], dpw = d.dpw[cls];
+    const int cd8 = d.CD / 8;
     const bool has_pro = t.pro[0] != nullptr;
 
     u32x4 pv[PIT];
     auto prefetch = [&](int tile) {
         const int img = tile / tpi, trem = tile - img * tpi;
         const int a0 = (trem / t.tiles_x) * t.TH, b0 = (trem % t.tiles_x) * t.TW;
+        const int base = ((img * d.SH + a0) * d.SW + b0) * cs_units;
+        const int ymin = -(a0 + dh0), ymax = d.SH - (a0 + dh0), xmin = -(b0 + dw0), xmax = d.SW - (b0 + dw0);
 #pragma unroll
         for (int it = 0; it < PIT; ++it) {
-            int pp = ppix0 + it * ppix_step;
-            int py = pp / PW, px = pp - py * PW;
-            int sy = a0 + dh0 + py, sx = b0 + dw0 + px;
-            bool ok = pp < PH * PW && (unsigned)sy < (unsigned)d.SH && (unsigned)sx < (unsigned)d.SW;
+            const int py = pyx[it] >> 16, px = pyx[it] & 0xffff;
+            const bool ok = pyx[it] >= 0 && py >= ymin && py < ymax && px >= xmin && px < xmax;
             u32x4 z = {0, 0, 0, 0};
-            pv[it] = ok ? src16[(((size_t)img * d.SH + sy) * d.SW + sx) * cs_units + pchunk] : z;
-            if (has_pro && !ok) pv[it] = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};   // marks padding (bf16 NaN pattern)
+            pv[it] = ok ? src16[(unsigned)(base + psrc[it])] : z;
+            if (has_pro && !ok) pv[it] = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};   // marks padding
         }
     };
 
     int tile = blockIdx.x;
     if (tile < ntiles) prefetch(tile);
     const float alpha = d.alpha_dev ? *d.alpha_dev : 1.f;
-    constexpr int CPR = BN / 8;
-    const int dph = d.dph[cls], dpw = d.dpw[cls];
     float* ep = reinterpret_cast<float*>(smem);
+    float bias8[EIT][8];
+#pragma unroll
+    for (int k = 0; k < EIT; ++k)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) bias8[k][c] = (d.bias && n0 + ecc[k] * 8 < d.CD) ? d.bias[n0 + ecc[k] * 8 + c] : 0.f;
+    __syncthreads();
 
     for (; tile < ntiles; tile += gridDim.x) {
         const int img = tile / tpi, trem = tile - img * tpi;
@@ -344,7 +371,7 @@ __global__ __launch_bounds__(256) void ptile_kernel(const XmcConvDesc d, const T
 #pragma unroll
         for (int it = 0; it < PIT; ++it) {
             int pp = ppix0 + it * ppix_step;
-            if (pp < PH * PW) *reinterpret_cast<u32x4*>(patch + pp * pstride + pchunk * 16) = pv[it];
+            if (pyx[it] >= 0) *reinterpret_cast<u32x4*>(patch + pp * pstride + pchunk * 16) = pv[it];
         }
         __syncthreads();
         if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);     // in flight during the MFMAs below
@@ -355,16 +382,14 @@ __global__ __launch_bounds__(256) void ptile_kernel(const XmcConvDesc d, const T
 #pragma unroll
             for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int tap = 0; tap < d.ntaps; ++tap) {
-            const int toff = s_toff[tap];
-            const unsigned char* wb = wall + tap * BN * pstride;
+            const unsigned char* pa = patch + s_toff[tap];
+            const unsigned char* wb = wall + tap * BN * pstride + bbyte;
             for (int s = 0; s < slab / 32; ++s) {
                 u32x4 af[TM], bf[TN];
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
-                    af[i] = *reinterpret_cast<const u32x4*>(patch + (apix[i] + toff) * pstride + (s * 4 + fc) * 16);
+                for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const u32x4*>(pa + abyte[i] + s * 64);
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    bf[j] = *reinterpret_cast<const u32x4*>(wb + (j * 16 + fr) * pstride + (s * 4 + fc) * 16);
+                for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const u32x4*>(wb + j * 16 * pstride + s * 64);
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -373,6 +398,7 @@ __global__ __launch_bounds__(256) void ptile_kernel(const XmcConvDesc d, const T
                                                                              __builtin_bit_cast(bf16x8, bf[j]), acc[i][j], 0, 0, 0);
             }
         }
+        const int dbase = (((img * d.DH + a0 * d.DA + dph) * d.DW) + b0 * d.DA + dpw) * cd8 + (n0 >> 3);
         for (int half = 0; half < BM / EP_ROWS; ++half) {
             __syncthreads();
             if (wm / 2 == half) {
@@ -385,40 +411,38 @@ __global__ __launch_bounds__(256) void ptile_kernel(const XmcConvDesc d, const T
                             ep[((wm & 1) * WTM + i * 16 + fc * 4 + r) * EP_LD + j * 16 + fr] = acc[i][j][r];
             }
             __syncthreads();
-            for (int id = tid; id < EP_ROWS * CPR; id += NT) {
-                int row = id / CPR, cc = id - row * CPR;
-                int ml = half * EP_ROWS + row, ch = n0 + cc * 8;
-                if (ch >= d.CD) continue;
-                int ty = ml >> t.log2TW, tx = ml & (t.TW - 1);
-                size_t pix = ((size_t)img * d.DH + (a0 + ty) * d.DA + dph) * d.DW + (b0 + tx) * d.DA + dpw;
-                size_t idx8 = (pix * d.CD + ch) >> 3;
+#pragma unroll
+            for (int k = 0; k < EIT; ++k) {
+                const int row = erow[k], cc = ecc[k];
+                if (n0 + cc * 8 >= d.CD) continue;
+                const int ml = half * EP_ROWS + row;
+                const int ty = ml >> t.log2TW, tx = ml & (t.TW - 1);
+                const size_t idx8 = (size_t)(dbase + ((ty * d.DA) * d.DW + tx * d.DA) * cd8 + cc);
                 float v[8];
                 const f32x4 e0 = *reinterpret_cast<const f32x4*>(&ep[row * EP_LD + cc * 8]);
                 const f32x4 e1 = *reinterpret_cast<const f32x4*>(&ep[row * EP_LD + cc * 8 + 4]);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { v[k] = e0[k]; v[4 + k] = e1[k]; }
-                if (d.bias) {
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] += d.bias[ch + k];
-                }
+                for (int q = 0; q < 4; ++q) { v[q] = e0[q] + bias8[k][q]; v[4 + q] = e1[q] + bias8[k][4 + q]; }
                 if (d.act == XMC_ACT_LRELU) {
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] = lrelu_f(v[k]);
+                    for (int q = 0; q < 8; ++q) v[q] = lrelu_f(v[q]);
                 } else if (d.act == XMC_ACT_RELU) {
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+                    for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
                 } else if (d.act == XMC_ACT_TANH) {
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] = tanhf(v[k]);
+                    for (int q = 0; q < 8; ++q) v[q] = tanhf(v[q]);
                 }
+                if (d.alpha_dev) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] *= alpha;
+                    for (int q = 0; q < 8; ++q) v[q] *= alpha;
+                }
                 if (d.out_dtype == XMC_BF16) {
                     if (d.res) {
                         float rr[8];
                         Vec8<XMC_BF16>::load(d.res, idx8, rr);
 #pragma unroll
-                        for (int k = 0; k < 8; ++k) v[k] += rr[k];
+                        for (int q = 0; q < 8; ++q) v[q] += rr[q];
                     }
                     Vec8<XMC_BF16>::store(d.dst, idx8, v);
                 } else {
@@ -426,7 +450,7 @@ __global__ __launch_bounds__(256) void ptile_kernel(const XmcConvDesc d, const T
                         float rr[8];
                         Vec8<XMC_F32>::load(d.res, idx8, rr);
 #pragma unroll
-                        for (int k = 0; k < 8; ++k) v[k] += rr[k];
+                        for (int q = 0; q < 8; ++q) v[q] += rr[q];
                     }
                     Vec8<XMC_F32>::store(d.dst, idx8, v);
                 }
