@@ -61,10 +61,11 @@ __global__ __launch_bounds__(NT) void wgrad_tile_kernel(const XmcConvDesc d, flo
             int id = tid + it * NT;
             int pp = id / XCH, ch = id - pp * XCH;
             int py = pp / PW, px = pp - py * PW;
-            int sy = a0 + t.dh0 + py, sx = b0 + t.dw0 + px;
-            bool ok = pp < PH * PW && ch < cs_units && (unsigned)sy < (unsigned)d.SH && (unsigned)sx < (unsigned)d.SW;
+            int sy = a0 + t.dh0 + py, sx = b0 + t.dw0 + px;          // coordinates at the (possibly x2-upsampled) resolution
+            bool ok = pp < PH * PW && ch < cs_units && (unsigned)sy < (unsigned)(d.SH << d.src_shift) &&
+                      (unsigned)sx < (unsigned)(d.SW << d.src_shift);
             u32x4 z = {0, 0, 0, 0};
-            xv[it] = ok ? x16[(((size_t)img * d.SH + sy) * d.SW + sx) * cs_units + ch] : z;
+            xv[it] = ok ? x16[(((size_t)img * d.SH + (sy >> d.src_shift)) * d.SW + (sx >> d.src_shift)) * cs_units + ch] : z;
         }
     };
 
@@ -179,7 +180,7 @@ int launch_wt(const XmcConvDesc& d, float* dwp, float* dbias, const WTCfg& t, hi
 int xmc_conv_wgrad_tile_try(const XmcConvDesc* d, float* dwp, float* dbias, void* stream) {
     static const bool off = getenv("XMC_NO_WTILE") != nullptr;
     if (off) return 1;
-    if (d->dtype != XMC_BF16 || d->SA != 1 || d->src_shift != 0) return 1;
+    if (d->dtype != XMC_BF16 || d->SA != 1 || d->src_shift < 0 || d->src_shift > 1) return 1;
     if (d->CD > 64 || d->CS > 64 || d->ntaps > 9 || d->ntaps < 1) return 1;
     if (d->MW % TW != 0 || d->MH % TH != 0) return 1;
     if (d->CD % 8 != 0 || d->CS % 8 != 0) return 1;
