@@ -152,7 +152,8 @@ int xmc_affine2_lrelu_bwd(const void* x, const void* dy, const float* g0, const 
 /*
  * Attention-modulation blocks (model/df_concept_gan.py).
  * GroupNorm over NHWC with optional fused LeakyReLU (slope < 0: none): nn.GroupNorm at 171,270-271,549-550.
- *   stats: f32 [N][G][2] (mean, rstd), written by fwd, read by bwd;  ws: f32 [N][C][2] scratch.
+ *   stats: f32 [N][G][2] (mean, rstd), written by fwd, read by bwd;  ws: f32 scratch, [N][C][2] for fwd and
+ *   [N][C][2] + [N][G][2] for bwd.
  * Region attention pooling (CondConceptSampler.forward 293-299 / ConceptSampler.forward 570-578):
  *   scores[n,c,p] = scale * <q[n,c,:], key[n,p,c*pk:(c+1)*pk]>, attn = softmax over p, ctx[n,c,:] = sum_p attn * x[n,p,c*px:(c+1)*px]
  *   key [N][HW][ncon*pk], x [N][HW][ncon*px] (activation dtype); q, attn [N][ncon][HW], ctx [N][ncon][px] f32.

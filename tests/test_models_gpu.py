@@ -4,8 +4,10 @@ on the oracle's synthetic parameters and COCO-shaped batches.
 Tolerances: fp32 mode (f32 MFMA, exact products) -> logits/losses within 1e-3 relative (north-star bar; measured
 ~1e-6) and every gradient tensor within 5e-3 relative L2 (measured <= 3e-4).  bf16 mode (bf16 weights and
 activations, f32 accumulate) is compared with the SAME f32 oracle, so the figures include the quantisation of every
-weight and activation through ~25 layers of an untrained, batch-4 network: losses within 5e-2 (measured <= 2.6e-2),
-per-tensor gradients within 0.5 relative L2 (measured: D <= 0.15, G <= 0.36 on the smallest bias tensors)."""
+weight and activation through ~25 layers of an untrained, batch-4 network: losses within 5e-2 (measured <= 2.6e-2);
+gradients: all tensors of a backward taken as one vector within 0.2 relative L2, each single tensor within 1.0 (measured
+per tensor: D <= 0.25, G <= 0.36 on small tensors, with run-to-run variation because f32 atomics order changes bf16
+roundings downstream)."""
 import pytest
 import torch
 
@@ -17,7 +19,7 @@ if torch.cuda.is_available():
     from parity_util import (DEV, build_product, compare_grads, compare_losses, mean_abs_err, rel_err, run_oracle_steps,
                              run_product_steps, setup_cfg)
 
-TOL = {"fp32": dict(fwd=1e-3, loss=1e-3, grad=5e-3, latol=1e-4), "bf16": dict(fwd=3e-2, loss=5e-2, grad=5e-1, latol=1e-2)}
+TOL = {"fp32": dict(fwd=1e-3, loss=1e-3, grad=5e-3, latol=1e-4, agg=2e-3), "bf16": dict(fwd=3e-2, loss=5e-2, grad=1.0, latol=1e-2, agg=0.2)}
 # Adam eps used in the multi-phase parity runs: with the presets' beta1=0 the very first update is
 # lr*g/(|g|+eps), i.e. +-lr for ANY non-zero g, so a rounding-level sign difference in a near-zero gradient moves
 # that weight by 2*lr and the later phases (MA-GP, G step, next iteration) then differ at the 1e-2 level for reasons
@@ -109,11 +111,11 @@ def test_train_iteration_parity(yml, over, batch, steps, mode):
         k = 1.0 if s == 0 else 20.0
         worst["loss"] = max(worst["loss"], compare_losses(p_outs[s], o_outs[s], t["loss"] * k, t["latol"] * k))
         assert mean_abs_err(p_outs[s]["fake"], o_outs[s]["fake"]) < t["fwd"] * k
-        worst["D"] = max(worst["D"], compare_grads(tapD.records[di], o_outs[s]["grads_D"], t["grad"] * k, f"step{s} D ", fl)); di += 1
+        worst["D"] = max(worst["D"], compare_grads(tapD.records[di], o_outs[s]["grads_D"], t["grad"] * k, f"step{s} D ", fl, t["agg"] * k)); di += 1
         if h.magp:
-            worst["GP"] = max(worst["GP"], compare_grads(tapD.records[di], o_outs[s]["grads_GP"], t["grad"] * 2 * k, f"step{s} GP ", fl)); di += 1
+            worst["GP"] = max(worst["GP"], compare_grads(tapD.records[di], o_outs[s]["grads_GP"], t["grad"] * 2 * k, f"step{s} GP ", fl, t["agg"] * 2 * k)); di += 1
         if "grads_G" in o_outs[s]:
-            worst["G"] = max(worst["G"], compare_grads(tapG.records[gi], o_outs[s]["grads_G"], t["grad"] * k, f"step{s} G ", fl)); gi += 1
+            worst["G"] = max(worst["G"], compare_grads(tapG.records[gi], o_outs[s]["grads_G"], t["grad"] * k, f"step{s} G ", fl, t["agg"] * k)); gi += 1
     assert di == len(tapD.records) and gi == len(tapG.records)
     print(f"\n[parity {mode} {yml} {over}] worst rel err: " + ", ".join(f"{k}={v:.2e}" for k, v in worst.items()))
 

@@ -112,9 +112,22 @@ __global__ void gn_apply_kernel(const void* x, const float* stats, const float* 
         Vec8<DT>::store(y, i, v);
     }
 }
-// dx = rstd * ( w*dy' - (A_g + xhat*B_g)/m ),  A_g = sum_{c in g} w_c S1[n,c], B_g = sum_{c in g} w_c S2[n,c]
+// per (image, group): A_g = sum_{c in g} w_c S1[n,c], B_g = sum_{c in g} w_c S2[n,c]   (S = sums of dy', dy'*xhat)
+__global__ void gn_bwd_groupsums_kernel(const float* sums2, const float* w, float* ab, int N, int C, int cpg) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int G = C / cpg;
+    if (i >= N * G) return;
+    int n = i / G, g = i % G;
+    float A = 0.f, Bq = 0.f;
+    for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+        A += w[c] * sums2[((size_t)n * C + c) * 2];
+        Bq += w[c] * sums2[((size_t)n * C + c) * 2 + 1];
+    }
+    ab[(size_t)i * 2] = A; ab[(size_t)i * 2 + 1] = Bq;
+}
+// dx = rstd * ( w*dy' - (A_g + xhat*B_g)/m )
 template <int DT>
-__global__ void gn_bwd_apply_kernel(const void* x, const void* dy, const float* stats, const float* sums2, const float* w,
+__global__ void gn_bwd_apply_kernel(const void* x, const void* dy, const float* stats, const float* ab, const float* w,
                                     const float* b, void* dx, int N, int HW, int C8, int cpg, float slope) {
     const int C = C8 * 8, G = C / cpg;
     const float inv_m = 1.f / ((float)HW * cpg);
@@ -128,16 +141,12 @@ __global__ void gn_bwd_apply_kernel(const void* x, const void* dy, const float* 
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             int c = cc * 8 + k, grp = c / cpg;
-            float mean = stats[((size_t)n * G + grp) * 2], rstd = stats[((size_t)n * G + grp) * 2 + 1];
-            float A = 0.f, Bq = 0.f;
-            for (int c2 = grp * cpg; c2 < (grp + 1) * cpg; ++c2) {
-                A += w[c2] * sums2[((size_t)n * C + c2) * 2];
-                Bq += w[c2] * sums2[((size_t)n * C + c2) * 2 + 1];
-            }
+            const size_t gi = ((size_t)n * G + grp) * 2;
+            float mean = stats[gi], rstd = stats[gi + 1];
             float xh = (xv[k] - mean) * rstd;
             float d = dv[k];
             if (slope >= 0.f) d *= (xh * w[c] + b[c]) > 0.f ? 1.f : slope;
-            xv[k] = rstd * (w[c] * d - (A + xh * Bq) * inv_m);
+            xv[k] = rstd * (w[c] * d - (ab[gi] + xh * ab[gi + 1]) * inv_m);
         }
         Vec8<DT>::store(dx, i, xv);
     }
@@ -151,26 +160,57 @@ __global__ void gn_param_grads_kernel(const float* sums2, float* dw, float* db, 
     db[c] = a; dw[c] = bq;
 }
 
-// ---- region attention pooling, one workgroup per (image, concept)
-// key [N][HW][CK] (CK = ncon*pk), q f32 [N][ncon][pk], x [N][HW][CX] (CX = ncon*px); attn f32 [N][ncon][HW]; ctx f32 [N][ncon][px]
-template <int DT>
+// ---- region attention pooling, one workgroup per (image, concept); each thread moves whole per-concept vectors
+// (pk key channels, px value channels: 8 or 16 bytes) with one vector access per pixel
+template <int DT, int P> struct PVec;            // P consecutive channels of one pixel <-> floats
+template <int P> struct PVec<XMC_BF16, P> {
+    typedef __attribute__((ext_vector_type(P))) __bf16 vt;
+    __device__ static __forceinline__ void load(const void* base, size_t elem, float (&v)[8]) {
+        vt t = *reinterpret_cast<const vt*>(reinterpret_cast<const __bf16*>(base) + elem);
+#pragma unroll
+        for (int k = 0; k < P; ++k) v[k] = (float)t[k];
+    }
+    __device__ static __forceinline__ void store(void* base, size_t elem, const float (&v)[8]) {
+        vt t;
+#pragma unroll
+        for (int k = 0; k < P; ++k) t[k] = (__bf16)v[k];
+        *reinterpret_cast<vt*>(reinterpret_cast<__bf16*>(base) + elem) = t;
+    }
+};
+template <int P> struct PVec<XMC_F32, P> {
+    typedef __attribute__((ext_vector_type(P))) float vt;
+    __device__ static __forceinline__ void load(const void* base, size_t elem, float (&v)[8]) {
+        vt t = *reinterpret_cast<const vt*>(reinterpret_cast<const float*>(base) + elem);
+#pragma unroll
+        for (int k = 0; k < P; ++k) v[k] = t[k];
+    }
+    __device__ static __forceinline__ void store(void* base, size_t elem, const float (&v)[8]) {
+        vt t;
+#pragma unroll
+        for (int k = 0; k < P; ++k) t[k] = v[k];
+        *reinterpret_cast<vt*>(reinterpret_cast<float*>(base) + elem) = t;
+    }
+};
+
+// key [N][HW][CK] (CK = ncon*PK), q f32 [N][ncon][PK], x [N][HW][CX] (CX = ncon*PX); attn f32 [N][ncon][HW]; ctx f32 [N][ncon][PX]
+template <int DT, int PK, int PX>
 __global__ void attn_pool_fwd_kernel(const void* key, const float* q, const void* x, float* attn, float* ctx,
-                                     int HW, int ncon, int pk, int px, float scale) {
+                                     int HW, int ncon, float scale) {
     const int n = blockIdx.x / ncon, c = blockIdx.x % ncon;
     __shared__ float sh[NT / 64];
     __shared__ float red[NT * 8];
     float qv[8];
-    for (int k = 0; k < pk; ++k) qv[k] = q[((size_t)n * ncon + c) * pk + k] * scale;
-    const int CK = ncon * pk, CX = ncon * px;
+#pragma unroll
+    for (int k = 0; k < PK; ++k) qv[k] = q[((size_t)n * ncon + c) * PK + k] * scale;
+    const int CK = ncon * PK, CX = ncon * PX;
     float* arow = attn + ((size_t)n * ncon + c) * HW;
     float mx = -INFINITY;
     for (int p = threadIdx.x; p < HW; p += NT) {
+        float kv[8];
+        PVec<DT, PK>::load(key, ((size_t)n * HW + p) * CK + c * PK, kv);
         float s = 0.f;
-        for (int k = 0; k < pk; ++k) {
-            size_t e = ((size_t)n * HW + p) * CK + c * pk + k;
-            float kv = DT == XMC_BF16 ? (float)reinterpret_cast<const __bf16*>(key)[e] : reinterpret_cast<const float*>(key)[e];
-            s += qv[k] * kv;
-        }
+#pragma unroll
+        for (int k = 0; k < PK; ++k) s += qv[k] * kv[k];
         arow[p] = s;
         mx = fmaxf(mx, s);
     }
@@ -183,70 +223,69 @@ __global__ void attn_pool_fwd_kernel(const void* key, const float* q, const void
     for (int p = threadIdx.x; p < HW; p += NT) {
         float a = arow[p] * inv;
         arow[p] = a;
-        for (int k = 0; k < px; ++k) {
-            size_t e = ((size_t)n * HW + p) * CX + c * px + k;
-            float xv = DT == XMC_BF16 ? (float)reinterpret_cast<const __bf16*>(x)[e] : reinterpret_cast<const float*>(x)[e];
-            acc[k] += a * xv;
-        }
+        float xv[8];
+        PVec<DT, PX>::load(x, ((size_t)n * HW + p) * CX + c * PX, xv);
+#pragma unroll
+        for (int k = 0; k < PX; ++k) acc[k] += a * xv[k];
     }
     __syncthreads();
+#pragma unroll
     for (int k = 0; k < 8; ++k) red[threadIdx.x * 8 + k] = acc[k];
     __syncthreads();
-    if (threadIdx.x < px) {
+    if (threadIdx.x < PX) {
         float t = 0.f;
         for (int i = 0; i < NT; ++i) t += red[i * 8 + threadIdx.x];
-        ctx[((size_t)n * ncon + c) * px + threadIdx.x] = t;
+        ctx[((size_t)n * ncon + c) * PX + threadIdx.x] = t;
     }
 }
 // given dctx: dq, dkey (written, every element owned by exactly one workgroup), dx (written)
-template <int DT>
+template <int DT, int PK, int PX>
 __global__ void attn_pool_bwd_kernel(const void* key, const float* q, const void* x, const float* attn, const float* dctx,
-                                     float* dq, void* dkey, void* dx, int HW, int ncon, int pk, int px, float scale) {
+                                     float* dq, void* dkey, void* dx, int HW, int ncon, float scale) {
     const int n = blockIdx.x / ncon, c = blockIdx.x % ncon;
     __shared__ float sh[NT / 64];
     __shared__ float red[NT * 8];
-    const int CK = ncon * pk, CX = ncon * px;
+    const int CK = ncon * PK, CX = ncon * PX;
     float qv[8], dc[8];
-    for (int k = 0; k < pk; ++k) qv[k] = q[((size_t)n * ncon + c) * pk + k] * scale;
-    for (int k = 0; k < px; ++k) dc[k] = dctx[((size_t)n * ncon + c) * px + k];
+#pragma unroll
+    for (int k = 0; k < PK; ++k) qv[k] = q[((size_t)n * ncon + c) * PK + k] * scale;
+#pragma unroll
+    for (int k = 0; k < PX; ++k) dc[k] = dctx[((size_t)n * ncon + c) * PX + k];
     const float* arow = attn + ((size_t)n * ncon + c) * HW;
     float dot = 0.f;                                   // sum_hw attn * dattn
     for (int p = threadIdx.x; p < HW; p += NT) {
+        float xv[8];
+        PVec<DT, PX>::load(x, ((size_t)n * HW + p) * CX + c * PX, xv);
         float da = 0.f;
-        for (int k = 0; k < px; ++k) {
-            size_t e = ((size_t)n * HW + p) * CX + c * px + k;
-            float xv = DT == XMC_BF16 ? (float)reinterpret_cast<const __bf16*>(x)[e] : reinterpret_cast<const float*>(x)[e];
-            da += dc[k] * xv;
-        }
+#pragma unroll
+        for (int k = 0; k < PX; ++k) da += dc[k] * xv[k];
         dot += arow[p] * da;
     }
     dot = block_sum(dot, sh);
     float dqa[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int p = threadIdx.x; p < HW; p += NT) {
-        float a = arow[p], da = 0.f;
-        for (int k = 0; k < px; ++k) {
-            size_t e = ((size_t)n * HW + p) * CX + c * px + k;
-            float xv = DT == XMC_BF16 ? (float)reinterpret_cast<const __bf16*>(x)[e] : reinterpret_cast<const float*>(x)[e];
-            da += dc[k] * xv;
-            float g = a * dc[k];
-            if (DT == XMC_BF16) reinterpret_cast<__bf16*>(dx)[e] = (__bf16)g; else reinterpret_cast<float*>(dx)[e] = g;
-        }
-        float ds = a * (da - dot);
-        for (int k = 0; k < pk; ++k) {
-            size_t e = ((size_t)n * HW + p) * CK + c * pk + k;
-            float kv = DT == XMC_BF16 ? (float)reinterpret_cast<const __bf16*>(key)[e] : reinterpret_cast<const float*>(key)[e];
-            dqa[k] += ds * kv;
-            float g = ds * qv[k];
-            if (DT == XMC_BF16) reinterpret_cast<__bf16*>(dkey)[e] = (__bf16)g; else reinterpret_cast<float*>(dkey)[e] = g;
-        }
+        const float a = arow[p];
+        float xv[8], kv[8], g[8];
+        const size_t ex = ((size_t)n * HW + p) * CX + c * PX, ek = ((size_t)n * HW + p) * CK + c * PK;
+        PVec<DT, PX>::load(x, ex, xv);
+        PVec<DT, PK>::load(key, ek, kv);
+        float da = 0.f;
+#pragma unroll
+        for (int k = 0; k < PX; ++k) { da += dc[k] * xv[k]; g[k] = a * dc[k]; }
+        PVec<DT, PX>::store(dx, ex, g);
+        const float ds = a * (da - dot);
+#pragma unroll
+        for (int k = 0; k < PK; ++k) { dqa[k] += ds * kv[k]; g[k] = ds * qv[k]; }
+        PVec<DT, PK>::store(dkey, ek, g);
     }
     __syncthreads();
+#pragma unroll
     for (int k = 0; k < 8; ++k) red[threadIdx.x * 8 + k] = dqa[k];
     __syncthreads();
-    if (threadIdx.x < pk) {
+    if (threadIdx.x < PK) {
         float t = 0.f;
         for (int i = 0; i < NT; ++i) t += red[i * 8 + threadIdx.x];
-        dq[((size_t)n * ncon + c) * pk + threadIdx.x] = t * scale;
+        dq[((size_t)n * ncon + c) * PK + threadIdx.x] = t * scale;
     }
 }
 }  // namespace
@@ -284,13 +323,16 @@ extern "C" int xmc_groupnorm_bwd(const void* x, const void* dy, const float* w, 
     int ppb = (HW + bx - 1) / bx;
     hipError_t e = hipMemsetAsync(ws, 0, (size_t)N * C * 2 * 4, ST(s));
     if (e != hipSuccess) return (int)e;
+    float* ab = ws + (size_t)N * C * 2;              // [N][G][2], second part of the workspace
     int64_t total = (int64_t)N * HW * C8; int blocks = (int)((total + NT - 1) / NT); if (blocks > 4096) blocks = 4096;
     if (dtype == XMC_BF16) {
         hipLaunchKernelGGL((gn_sums_kernel<XMC_BF16, 1>), dim3(bx, N), dim3(NT), 0, ST(s), x, dy, stats, w, b, ws, HW, C8, cpg, slope, ppb);
-        hipLaunchKernelGGL((gn_bwd_apply_kernel<XMC_BF16>), dim3(blocks), dim3(NT), 0, ST(s), x, dy, stats, ws, w, b, dx, N, HW, C8, cpg, slope);
+        hipLaunchKernelGGL(gn_bwd_groupsums_kernel, dim3((N * G + NT - 1) / NT), dim3(NT), 0, ST(s), ws, w, ab, N, C, cpg);
+        hipLaunchKernelGGL((gn_bwd_apply_kernel<XMC_BF16>), dim3(blocks), dim3(NT), 0, ST(s), x, dy, stats, ab, w, b, dx, N, HW, C8, cpg, slope);
     } else if (dtype == XMC_F32) {
         hipLaunchKernelGGL((gn_sums_kernel<XMC_F32, 1>), dim3(bx, N), dim3(NT), 0, ST(s), x, dy, stats, w, b, ws, HW, C8, cpg, slope, ppb);
-        hipLaunchKernelGGL((gn_bwd_apply_kernel<XMC_F32>), dim3(blocks), dim3(NT), 0, ST(s), x, dy, stats, ws, w, b, dx, N, HW, C8, cpg, slope);
+        hipLaunchKernelGGL(gn_bwd_groupsums_kernel, dim3((N * G + NT - 1) / NT), dim3(NT), 0, ST(s), ws, w, ab, N, C, cpg);
+        hipLaunchKernelGGL((gn_bwd_apply_kernel<XMC_F32>), dim3(blocks), dim3(NT), 0, ST(s), x, dy, stats, ab, w, b, dx, N, HW, C8, cpg, slope);
     } else return XMC_EINVAL;
     hipLaunchKernelGGL(gn_param_grads_kernel, dim3((C + NT - 1) / NT), dim3(NT), 0, ST(s), ws, dw, db, N, C);
     XMC_LAUNCH_CHECK();
@@ -298,18 +340,18 @@ extern "C" int xmc_groupnorm_bwd(const void* x, const void* dy, const float* w, 
 }
 extern "C" int xmc_attn_pool_fwd(const void* key, const float* q, const void* x, float* attn, float* ctx, int N, int HW,
                                  int ncon, int pk, int px, float scale, int dtype, void* s) {
-    if (pk < 1 || pk > 8 || px < 1 || px > 8 || ncon < 1) return XMC_ESHAPE;
-    if (dtype == XMC_BF16) hipLaunchKernelGGL((attn_pool_fwd_kernel<XMC_BF16>), dim3(N * ncon), dim3(NT), 0, ST(s), key, q, x, attn, ctx, HW, ncon, pk, px, scale);
-    else if (dtype == XMC_F32) hipLaunchKernelGGL((attn_pool_fwd_kernel<XMC_F32>), dim3(N * ncon), dim3(NT), 0, ST(s), key, q, x, attn, ctx, HW, ncon, pk, px, scale);
+    if (pk != 4 || px != 8 || ncon < 1) return XMC_ESHAPE;          // state_dim 4, bottleneck width 8 (df_concept_gan.py:110,118)
+    if (dtype == XMC_BF16) hipLaunchKernelGGL((attn_pool_fwd_kernel<XMC_BF16, 4, 8>), dim3(N * ncon), dim3(NT), 0, ST(s), key, q, x, attn, ctx, HW, ncon, scale);
+    else if (dtype == XMC_F32) hipLaunchKernelGGL((attn_pool_fwd_kernel<XMC_F32, 4, 8>), dim3(N * ncon), dim3(NT), 0, ST(s), key, q, x, attn, ctx, HW, ncon, scale);
     else return XMC_EINVAL;
     XMC_LAUNCH_CHECK();
     return 0;
 }
 extern "C" int xmc_attn_pool_bwd(const void* key, const float* q, const void* x, const float* attn, const float* dctx, float* dq,
                                  void* dkey, void* dx, int N, int HW, int ncon, int pk, int px, float scale, int dtype, void* s) {
-    if (pk < 1 || pk > 8 || px < 1 || px > 8 || ncon < 1) return XMC_ESHAPE;
-    if (dtype == XMC_BF16) hipLaunchKernelGGL((attn_pool_bwd_kernel<XMC_BF16>), dim3(N * ncon), dim3(NT), 0, ST(s), key, q, x, attn, dctx, dq, dkey, dx, HW, ncon, pk, px, scale);
-    else if (dtype == XMC_F32) hipLaunchKernelGGL((attn_pool_bwd_kernel<XMC_F32>), dim3(N * ncon), dim3(NT), 0, ST(s), key, q, x, attn, dctx, dq, dkey, dx, HW, ncon, pk, px, scale);
+    if (pk != 4 || px != 8 || ncon < 1) return XMC_ESHAPE;
+    if (dtype == XMC_BF16) hipLaunchKernelGGL((attn_pool_bwd_kernel<XMC_BF16, 4, 8>), dim3(N * ncon), dim3(NT), 0, ST(s), key, q, x, attn, dctx, dq, dkey, dx, HW, ncon, scale);
+    else if (dtype == XMC_F32) hipLaunchKernelGGL((attn_pool_bwd_kernel<XMC_F32, 4, 8>), dim3(N * ncon), dim3(NT), 0, ST(s), key, q, x, attn, dctx, dq, dkey, dx, HW, ncon, scale);
     else return XMC_EINVAL;
     XMC_LAUNCH_CHECK();
     return 0;

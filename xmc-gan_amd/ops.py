@@ -857,7 +857,7 @@ class GroupNormFn(torch.autograd.Function):
         N, H, W, Cc = x.shape
         dx = torch.empty_like(x)
         dw, db = torch.empty_like(wf), torch.empty_like(bf)
-        ws = torch.empty((N, Cc, 2), dtype=torch.float32, device=x.device)
+        ws = torch.empty(N * Cc * 2 + N * ctx.groups * 2, dtype=torch.float32, device=x.device)
         L.call("xmc_groupnorm_bwd", _p(x), _p(dy), _p(wf), _p(bf), _p(stats), _p(dx), _p(dw), _p(db), _p(ws), N, H * W, Cc,
                ctx.groups, float(ctx.slope), _code(x.dtype), _st())
         return dx, dw, db, None, None, None
