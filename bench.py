@@ -46,6 +46,25 @@ def parse():
     return ap.parse_args()
 
 
+def pmc_traffic_lookup(imsize, batch, cfg_name, precision):
+    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC summary of THIS workload
+    (profiles/r01_pmc_hbm_traffic_<S>px_b<B>.csv: separate --pmc FETCH_SIZE / WRITE_SIZE passes of this script, FETCH_SIZE
+    doubled as MI355X_MICROARCH.md prescribes for gfx950; made by profiles/summarize.py).  Counters cannot be read from
+    inside the process, so the figure is None for workloads without a committed summary."""
+    import csv
+    path = os.path.join(ROOT, "profiles", f"r01_pmc_hbm_traffic_{imsize}px_b{batch}.csv")
+    if cfg_name != "df_gan_damsm_nomagp.yml" or precision != "bf16" or not os.path.exists(path):
+        return None
+    rows = list(csv.DictReader(open(path)))
+
+    def lookup(kernel):
+        for r in rows:
+            if kernel + "(" in r["kernel"]:
+                return round((float(r["fetch_MB_per_dispatch_corrected_x2"]) + float(r["write_MB_per_dispatch"])) * 2**20)
+        return None
+    return lookup
+
+
 def host_cores():
     """CPU threads this process may really use: affinity mask, capped by the cgroup CPU quota when there is one
     (os.cpu_count() reports the whole host and badly oversubscribes a container with a CPU share)."""
@@ -60,13 +79,14 @@ def host_cores():
     return max(1, min(n, 64))
 
 
-def cpu_baseline(cfg, cfg_name, imsize, seconds_budget=25.0):
-    """Time the CPU oracle (oracle/xmc_ref.py, the parity checker) on this host: same cfg and image size, batch 2."""
+def cpu_baseline(cfg, cfg_name, imsize, seconds_budget=15.0):
+    """Time the CPU oracle (oracle/xmc_ref.py, the parity checker) on this host: same cfg and image size, batch 8,
+    as many whole iterations as fit in ~15 s (at least 2)."""
     import xmc_ref as X
     h = X.Hyper.from_cfg(cfg)
     cores = host_cores()
     torch.set_num_threads(cores)
-    B = 2
+    B = 8
     PG, PD = X.synth_params(X.gen_shapes(h), 1), X.synth_params(X.netd_shapes(h), 2)
     optG, optD = X.AdamState(h.g_lr, h.g_betas), X.AdamState(h.d_lr, h.d_betas)
     batch = X.synth_batch(h, B, seed=1)
@@ -76,7 +96,7 @@ def cpu_baseline(cfg, cfg_name, imsize, seconds_budget=25.0):
         X.train_step(PG, PD, optG, optD, h, batch)
         n += 1
         dt = time.perf_counter() - t0
-        if dt > seconds_budget or n >= 5:
+        if n >= 2 and (dt > seconds_budget or n >= 40):
             break
     return dict(value=round(B * n / dt, 4), unit="images/s", cores=torch.get_num_threads(), kind="port",
                 sample=f"{n} full G+D iterations of oracle/xmc_ref.py (PyTorch CPU fp32), {imsize}x{imsize}, batch {B}, {cfg_name}")
@@ -178,7 +198,8 @@ def main():
         prof.enable()
         step(a.warmup + a.steps, force_eager=True)
         torch.cuda.synchronize()
-        roof = prof.summary(PEAK_BF16_TFLOPS if a.precision == "bf16" else PEAK_F32_TFLOPS)
+        roof = prof.summary(PEAK_BF16_TFLOPS if a.precision == "bf16" else PEAK_F32_TFLOPS,
+                            pmc_traffic_lookup(S, B, a.cfg, a.precision))
         if os.environ.get("XMC_PROF_SHAPES") and rank == 0:
             for fam, tag, n, ms, tf in prof.by_shape()[:60]:
                 print(f"{fam:14s} {tag:60s} n={n:3d} {ms:8.3f} ms {tf:8.1f} TF/s", file=sys.stderr)

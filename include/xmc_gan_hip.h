@@ -71,6 +71,9 @@ typedef struct XmcConvDesc {
 } XmcConvDesc;
 
 int xmc_abi_version(void);
+/* Name (template instantiation, as rocprof prints it) of the convolution kernel the calling thread dispatched last;
+ * "" before the first one.  Measurement aid for bench.py's roofline; not part of the reference's surface. */
+const char* xmc_last_kernel(void);
 
 /* forward / dgrad implicit GEMM on MFMA (bf16: v_mfma_f32_16x16x32_bf16; f32: v_mfma_f32_16x16x4_f32) */
 int xmc_conv_igemm(const XmcConvDesc* d, void* stream);

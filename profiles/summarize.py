@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 output directories into the small CSV summaries committed next to this script.
+
+    python profiles/summarize.py stats  <dir of `rocprofv3 --kernel-trace --stats`>            out.csv
+    python profiles/summarize.py pmc    <dir of `--pmc FETCH_SIZE`> <dir of `--pmc WRITE_SIZE`>  out.csv
+
+FETCH_SIZE / WRITE_SIZE are reported in KB per dispatch.  On gfx950 FETCH_SIZE counts the 128-byte requests of wide
+coalesced reads at 64 bytes, so it is doubled (MI355X_MICROARCH.md, "HBM"); WRITE_SIZE is exact for 16-byte-per-lane
+stores and float atomics.  The two counters do not fit one pass (TCC slots), hence two runs of the same command.
+"""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+
+def _one(d, suffix):
+    hits = glob.glob(os.path.join(d, "**", "*" + suffix), recursive=True)
+    if not hits:
+        sys.exit(f"no *{suffix} under {d}")
+    return max(hits, key=os.path.getsize)
+
+
+def stats(d, out):
+    rows = list(csv.DictReader(open(_one(d, "_kernel_stats.csv"))))
+    with open(out, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "calls", "total_ms", "avg_us", "pct"])
+        for r in rows:
+            w.writerow([r["Name"], r["Calls"], round(int(r["TotalDurationNs"]) / 1e6, 3),
+                        round(float(r["AverageNs"]) / 1e3, 2), r["Percentage"]])
+
+
+def _counter(d, name):
+    agg = defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(_one(d, "_counter_collection.csv"))):
+        if r["Counter_Name"] == name:
+            a = agg[r["Kernel_Name"]]
+            a[0] += 1
+            a[1] += float(r["Counter_Value"])
+    return agg
+
+
+def pmc(dfetch, dwrite, out):
+    fe, wr = _counter(dfetch, "FETCH_SIZE"), _counter(dwrite, "WRITE_SIZE")
+    names = sorted(set(fe) | set(wr), key=lambda k: -(2 * fe.get(k, [0, 0])[1] + wr.get(k, [0, 0])[1]))
+    with open(out, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "dispatches", "FETCH_SIZE_KB_sum_raw", "fetch_MB_per_dispatch_corrected_x2", "WRITE_SIZE_KB_sum",
+                    "write_MB_per_dispatch"])
+        for k in names:
+            nf, sf = fe.get(k, [0, 0.0])
+            nw, sw = wr.get(k, [0, 0.0])
+            n = max(nf, nw, 1)
+            w.writerow([k, n, round(sf, 1), round(2 * sf / 1024 / max(nf, 1), 3), round(sw, 1), round(sw / 1024 / max(nw, 1), 3)])
+
+
+if __name__ == "__main__":
+    if len(sys.argv) == 4 and sys.argv[1] == "stats":
+        stats(sys.argv[2], sys.argv[3])
+    elif len(sys.argv) == 5 and sys.argv[1] == "pmc":
+        pmc(sys.argv[2], sys.argv[3], sys.argv[4])
+    else:
+        sys.exit(__doc__)

@@ -15,6 +15,10 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
 static inline int xmc_esz(int dtype) { return dtype == XMC_BF16 ? 2 : 4; }
 
+// name of the kernel the calling thread dispatched last (xmc_last_kernel(), used by bench.py's roofline to attribute
+// its per-launch HIP-event timings to the instantiation rocprof reports)
+void xmc_note_kernel(const char* fmt, ...);
+
 #define XMC_LAUNCH_CHECK()                         \
     do {                                           \
         hipError_t e__ = hipGetLastError();        \

@@ -267,6 +267,7 @@ int launch(const XmcConvDesc& d, hipStream_t st) {
     const int64_t M = (int64_t)d.N * d.MH * d.MW;
     dim3 grid((unsigned)(((M + BM - 1) / BM) * (d.CDw / BN)), 1, (unsigned)d.nclass);
     hipLaunchKernelGGL((igemm_kernel<DT, BM, BN, WM, WN, KSUB>), grid, dim3(256), 0, st, d);
+    xmc_note_kernel("igemm_kernel<%d, %d, %d, %d, %d, %d>", DT, BM, BN, WM, WN, KSUB);
     XMC_LAUNCH_CHECK();
     return 0;
 }

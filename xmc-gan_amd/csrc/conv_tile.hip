@@ -479,6 +479,7 @@ int launch_ptile(const XmcConvDesc& d, const TileCfg& t, hipStream_t st) {
     if (gx > ntiles) gx = ntiles;
     dim3 grid((unsigned)gx, (unsigned)(d.CDw / BN), (unsigned)d.nclass);
     hipLaunchKernelGGL((ptile_kernel<BN>), grid, dim3(256), lds, st, d, t, ntiles);
+    xmc_note_kernel("ptile_kernel<%d>", BN);
     XMC_LAUNCH_CHECK();
     return 0;
 }
@@ -499,6 +500,7 @@ int launch_tile(const XmcConvDesc& d, const TileCfg& t, hipStream_t st) {
     }
     dim3 grid((unsigned)(d.N * t.tiles_y * t.tiles_x), (unsigned)(d.CDw / BN), (unsigned)d.nclass);
     hipLaunchKernelGGL((tile_kernel<BN, WM, WN>), grid, dim3(256), lds, st, d, t);
+    xmc_note_kernel("tile_kernel<%d, %d, %d>", BN, WM, WN);
     XMC_LAUNCH_CHECK();
     return 0;
 }

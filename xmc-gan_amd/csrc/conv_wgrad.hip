@@ -202,6 +202,7 @@ int launch(const XmcConvDesc& d, float* dwp, float* dbias, hipStream_t st) {
     nsplit = (P + ppb - 1) / ppb;
     dim3 grid((unsigned)nsplit, (unsigned)((d.CDw / BCO) * nci), (unsigned)d.ntaps);
     hipLaunchKernelGGL((wgrad_kernel<DT, BCO, BCI, WM, WN, KP>), grid, dim3(256), 0, st, d, dwp, dbias, (int)ppb);
+    xmc_note_kernel("wgrad_kernel<%d, %d, %d, %d, %d, %d>", DT, BCO, BCI, WM, WN, KP);
     XMC_LAUNCH_CHECK();
     return 0;
 }

@@ -170,6 +170,7 @@ int launch_wt(const XmcConvDesc& d, float* dwp, float* dbias, const WTCfg& t, hi
     int gx = 256 * per_cu;
     if (gx > t.ntiles) gx = t.ntiles;
     hipLaunchKernelGGL((wgrad_tile_kernel<NCO, NCI, NT>), dim3(gx), dim3(NT), lds, st, d, dwp, dbias, t);
+    xmc_note_kernel("wgrad_tile_kernel<%d, %d, %d>", NCO, NCI, NT);
     XMC_LAUNCH_CHECK();
     return 0;
 }

@@ -1,6 +1,8 @@
 // HBM-bound pointwise / small-reduction kernels (NHWC, 8-channel vectors, 16-byte accesses).
 // Each cites the reference op it replaces in include/xmc_gan_hip.h.
 #include "common.h"
+#include <cstdarg>
+#include <cstdio>
 
 namespace {
 
@@ -437,6 +439,15 @@ __global__ void unpack_wgrad_kernel(const float* dwp, float* gw, int Co, int Ci,
 #define ST(s) reinterpret_cast<hipStream_t>(s)
 
 extern "C" int xmc_abi_version(void) { return XMC_ABI_VERSION; }
+
+static thread_local char g_last_kernel[96] = "";
+void xmc_note_kernel(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_last_kernel, sizeof g_last_kernel, fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* xmc_last_kernel(void) { return g_last_kernel; }
 
 extern "C" int xmc_lrelu(const void* x, void* y, int64_t n, float slope, int dtype, void* s) { return run_map1(x, y, n, dtype, ST(s), FLrelu{slope}); }
 extern "C" int xmc_tanh(const void* x, void* y, int64_t n, int dtype, void* s) { return run_map1(x, y, n, dtype, ST(s), FTanh{}); }

@@ -34,6 +34,7 @@ class AdamEntry(C.Structure):
 # name -> argtypes  (restype is int unless listed in _RESTYPE)
 _SIGS = {
     "xmc_abi_version": [],
+    "xmc_last_kernel": [],
     "xmc_conv_igemm": [C.POINTER(ConvDesc), vp],
     "xmc_conv_wgrad": [C.POINTER(ConvDesc), vp, vp],
     "xmc_conv_wgrad_bias": [C.POINTER(ConvDesc), vp, vp, vp],
@@ -72,7 +73,7 @@ _SIGS = {
     "xmc_adam_chunk_elems": [],
     "xmc_adam_step": [vp, i32, vp, i32, f32, f32, f32, f32, vp],
 }
-_RESTYPE = {"xmc_contrastive_ws_bytes": i64}
+_RESTYPE = {"xmc_contrastive_ws_bytes": i64, "xmc_last_kernel": C.c_char_p}
 EXPORTS = tuple(_SIGS)
 
 _lib = None

@@ -324,6 +324,7 @@ def _conv_wgrad_raw(x, dy, geom, scale=None, up=False, want_bias=False):
     assert x.dtype == dy.dtype, (x.dtype, dy.dtype)
     rows = pad_to(CDy, 32)
     dwp = torch.zeros((geom.k * geom.k, rows, CS), dtype=torch.float32, device=x.device)
+    gb = torch.zeros((16, CDy), dtype=torch.float32, device=x.device) if want_bias else None     # XMC_BIAS_REPLICAS
     d = L.ConvDesc()
     d.src, d.dst = x.data_ptr(), dy.data_ptr()
     d.N, d.SH, d.SW, d.CS = N, H, W, CS
@@ -334,7 +335,6 @@ def _conv_wgrad_raw(x, dy, geom, scale=None, up=False, want_bias=False):
     _fill_taps(d, 0, [(kh - geom.p, kw - geom.p, kh * geom.k + kw) for kh in range(geom.k) for kw in range(geom.k)])
     with prof.launch("wgrad_kernel (conv weight gradient, MFMA + split-K atomics)", 2.0 * N * OH * OW * geom.cout * geom.cin * geom.k * geom.k,
                      f"wgrad {x.dtype} N{N} {H}x{W} {geom.cin}->{geom.cout} k{geom.k}s{geom.s}"):
-        gb = torch.zeros((16, CDy), dtype=torch.float32, device=x.device) if want_bias else None     # XMC_BIAS_REPLICAS
         L.check(L.load().xmc_conv_wgrad_bias(C.byref(d), _p(dwp), _p(gb), _st()), "xmc_conv_wgrad")
     gw = torch.empty((geom.cout, geom.cin, geom.k, geom.k), dtype=torch.float32, device=x.device)
     L.call("xmc_unpack_wgrad", _p(dwp), _p(gw), geom.cout, geom.cin, geom.k, geom.k, rows, CS, _p(scale),

@@ -37,35 +37,48 @@ class launch:
     def __exit__(self, *a):
         if _on:
             self.e1.record()
-            _recs.append((self.family, self.flops, self.e0, self.e1, self.tag))
+            from . import lib
+            kern = lib.load().xmc_last_kernel().decode()       # the instantiation the C dispatcher picked
+            _recs.append((self.family, self.flops, self.e0, self.e1, self.tag, kern))
 
 
-def summary(peak_tflops):
-    torch.cuda.synchronize()
-    fam = {}
-    for family, flops, e0, e1, _tag in _recs:
-        f = fam.setdefault(family, dict(launches=0, gflop=0.0, ms=0.0))
+def _aggregate(key):
+    agg = {}
+    for rec in _recs:
+        f = agg.setdefault(key(rec), dict(launches=0, gflop=0.0, ms=0.0))
         f["launches"] += 1
-        f["gflop"] += flops / 1e9
-        f["ms"] += e0.elapsed_time(e1)
-    for f in fam.values():
+        f["gflop"] += rec[1] / 1e9
+        f["ms"] += rec[2].elapsed_time(rec[3])
+    for f in agg.values():
         f["tflops"] = round(f["gflop"] / max(f["ms"], 1e-9), 2)
         f["avg_launch_us"] = round(1e3 * f["ms"] / f["launches"], 2)
+        f["gflop_per_launch"] = round(f["gflop"] / f["launches"], 3)
         f["gflop"], f["ms"] = round(f["gflop"], 1), round(f["ms"], 3)
-    dom = max(fam, key=lambda k: fam[k]["ms"]) if fam else None
-    if dom is None:
+    return agg
+
+
+def summary(peak_tflops, traffic_lookup=None):
+    """Roofline object for the dominant kernel = the instantiation (name as rocprof prints it) with the largest summed
+    duration in the profiled iteration.  achieved = algorithmic FLOPs of its launches / their HIP-event durations."""
+    torch.cuda.synchronize()
+    if not _recs:
         return None
-    d = fam[dom]
+    kern = _aggregate(lambda r: r[5])
+    fam = _aggregate(lambda r: r[0])
+    dom = max(kern, key=lambda k: kern[k]["ms"])
+    d = kern[dom]
+    traffic = traffic_lookup(dom) if traffic_lookup else None
     return dict(bound="mfma", kernel=dom, achieved=d["tflops"], peak=peak_tflops, unit="TFLOP/s",
-                frac=round(d["tflops"] / peak_tflops, 4), traffic=None, launches=d["launches"],
-                avg_launch_us=d["avg_launch_us"], algorithmic_gflop_per_step=d["gflop"], families=fam)
+                frac=round(d["tflops"] / peak_tflops, 4), traffic=traffic, launches=d["launches"],
+                avg_launch_us=d["avg_launch_us"], algorithmic_gflop_per_launch=d["gflop_per_launch"],
+                kernels=kern, families=fam)
 
 
 def by_shape():
     """[(family, tag, launches, total_ms, tflops)] sorted by time (debug aid)."""
     torch.cuda.synchronize()
     agg = {}
-    for family, flops, e0, e1, tag in _recs:
+    for family, flops, e0, e1, tag, _kern in _recs:
         a = agg.setdefault((family.split(" ")[0], tag), [0, 0.0, 0.0])
         a[0] += 1; a[1] += e0.elapsed_time(e1); a[2] += flops
     rows = [(k[0], k[1], v[0], v[1], v[2] / 1e9 / max(v[1], 1e-9)) for k, v in agg.items()]
