@@ -9,7 +9,7 @@ def main():
     N, H, cin, cout, k, s, p, reps = [int(v) for v in sys.argv[1:9]]
     mode = sys.argv[9] if len(sys.argv) > 9 else "fwd"
     g = torch.Generator().manual_seed(0)
-    x = torch.randn(N, H, H, cin, generator=g).to("cuda", torch.bfloat16).requires_grad_()
+    x = torch.randn(N, H, H, ops.chan_pad(cin, torch.bfloat16), generator=g).to("cuda", torch.bfloat16).requires_grad_()
     w = torch.nn.Parameter((torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).cuda())
     geom = ops.ConvGeom(cin, cout, k, s, p)
     y = ops.conv2d(x, w, None, geom)

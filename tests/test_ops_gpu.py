@@ -66,6 +66,9 @@ CONV_CASES = [
     (32, 32, 3, 1, 1, 32, 3),
     (64, 64, 3, 1, 1, 64, 1),
     (64, 32, 1, 1, 0, 32, 2),
+    # streaming kernel for 8-channel sources (conv_thin.hip): conv_img forward / conv_out dgrad on maps with H % 8 == 0, W % 32 == 0
+    (3, 64, 3, 1, 1, 64, 1),       # 64 output channels, several tiles per image
+    (64, 3, 3, 1, 1, 32, 3),       # its mirror: the dgrad has the 8-channel source
 ]
 
 

@@ -290,6 +290,7 @@ int dispatch(const XmcConvDesc& d, hipStream_t st) {
 }  // namespace
 
 int xmc_conv_tile_try(const XmcConvDesc* d, const float* const* pro, void* stream);   // conv_tile.hip
+int xmc_conv_thin_try(const XmcConvDesc* d, void* stream);                            // conv_thin.hip
 
 extern "C" int xmc_conv_igemm(const XmcConvDesc* d, void* stream) {
     if (!d || !d->src || !d->wpk || !d->dst) return XMC_EINVAL;
@@ -306,8 +307,10 @@ extern "C" int xmc_conv_igemm(const XmcConvDesc* d, void* stream) {
             return XMC_ESHAPE;
     if ((int64_t)d->N * d->MH * d->MW >= (1ll << 31)) return XMC_ESHAPE;
     static const bool no_tile = getenv("XMC_NO_TILE") != nullptr;
-    if (!no_tile) {                       // halo-tile kernel for unit-stride bf16 layers on >= 16x16 maps
-        int rc = xmc_conv_tile_try(d, nullptr, stream);
+    if (!no_tile) {                       // streaming kernel for 8-channel sources, halo-tile kernels for unit-stride bf16 layers
+        int rc = xmc_conv_thin_try(d, stream);
+        if (rc <= 0) return rc;
+        rc = xmc_conv_tile_try(d, nullptr, stream);
         if (rc <= 0) return rc;
     }
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);

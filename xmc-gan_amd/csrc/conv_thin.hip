@@ -1,0 +1,172 @@
+// Convolution whose SOURCE has 8 stored channels (an image: 3 channels padded to 8), unit stride, bf16 -- the discriminator's
+// first layer (df_gan.py:130 `conv_img`, 3 -> ndf) and the data gradient of the generator's last layer (df_gan.py:86-90,
+// ngf <- 3).  The generic implicit-GEMM kernel spends one 64-byte K sub-step per tap on 16 bytes of data and re-gathers every
+// pixel nine times (measured 29 TFLOP/s, 4x the HBM time of the layer); this kernel is built for what the layer is, a stream:
+//
+//   * a persistent workgroup walks 8x32-pixel output tiles; the (8+2)x(32+2) source patch is 5.4 KB of LDS;
+//   * K = taps x 8 channels: one 16-byte unit of a pixel IS one lane's 8 K-values of a 16x16x32 MFMA operand, so a 3x3 kernel
+//     is three MFMA K-steps (taps 0-3, 4-7, 8 + zero weights) whose pixel operand is a single ds_read_b128 at the tap-shifted
+//     patch position; the weights (<= 12 fragments) stay in registers for the life of the workgroup;
+//   * MFMA roles as in conv_tile.hip's ptile3: A = weight rows (permuted while loading), B = pixels, so each lane ends up with
+//     BN/4 consecutive output channels of one pixel and stores 16-byte units straight from registers.
+// HBM traffic = source once (+6 % halo) + destination once.
+#include "common.h"
+#include <stdlib.h>
+
+namespace {
+
+struct ThinCfg {
+    int tiles_y, tiles_x, PW, PH, dh0, dw0;
+};
+
+template <int BN>
+__global__ __launch_bounds__(256) void thin_in_kernel(const XmcConvDesc d, const ThinCfg t, int ntiles) {
+    constexpr int TH = 8, TW = 32, TN = BN / 16, UPL = BN / 32, KS = 3;
+    __shared__ __attribute__((aligned(16))) unsigned char patch[(TH + 4) * (TW + 4) * 16];
+    const int tid = threadIdx.x, lane = tid & 63, wm = tid >> 6;
+    const int fr = lane & 15, fc = lane >> 4;
+    const int PW = t.PW, PH = t.PH, dh0 = t.dh0, dw0 = t.dw0;
+    const u32x4* __restrict__ src16 = reinterpret_cast<const u32x4*>(d.src);
+    const u32x4* __restrict__ w16 = reinterpret_cast<const u32x4*>(d.wpk);
+
+    // weights -> registers.  K-step ks, lane group fc <-> tap 4*ks + fc; physical row (j, q) <-> channel (q/4)*(BN/4) + j*4 + q%4
+    u32x4 wf[KS][TN];
+    int toff[KS];                                 // byte offset of this lane's tap in the patch, per K-step
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int tap = ks * 4 + fc;
+        const bool live = tap < d.ntaps;
+        const int tt = live ? tap : 0;
+        toff[ks] = ((d.dh[0][tt] - dh0) * PW + (d.dw[0][tt] - dw0)) * 16;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int lrow = (fr >> 2) * (BN / 4) + j * 4 + (fr & 3);
+            wf[ks][j] = live ? w16[(size_t)d.wi[0][tt] * d.CDw + lrow] : u32x4{0, 0, 0, 0};
+        }
+    }
+    // patch staging: thread -> up to 2 patch pixels; halo bits as in ptile3 (1 top, 2 bottom, 4 left, 8 right)
+    int ppix[2], psrc[2];
+    unsigned halo[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int pp = tid + it * 256;
+        const int py = pp / PW, px = pp - py * PW;
+        const bool in = pp < PH * PW;
+        ppix[it] = in ? pp : -1;
+        psrc[it] = in ? (dh0 + py) * d.SW + (dw0 + px) : 0;
+        halo[it] = !in ? 0u : ((py < -dh0 ? 1u : 0u) | (py >= TH - dh0 ? 2u : 0u) | (px < -dw0 ? 4u : 0u) | (px >= TW - dw0 ? 8u : 0u));
+    }
+    int pbase[4], eoff[4];
+    const int cd8 = d.CD / 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = wm * 2 + (i >> 1), c = (i & 1) * 16 + fr;
+        pbase[i] = (r * PW + c) * 16;
+        eoff[i] = (r * d.DW + c) * cd8 + fc * UPL;
+    }
+    const int ch0 = fc * (BN / 4);
+    float bias8[UPL][8];
+#pragma unroll
+    for (int u = 0; u < UPL; ++u)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) bias8[u][c] = (d.bias && ch0 + u * 8 < d.CD) ? d.bias[ch0 + u * 8 + c] : 0.f;
+    const float slope = d.act == XMC_ACT_LRELU ? XMC_LRELU : 1.f;
+    const int tpi = t.tiles_y * t.tiles_x;
+    bf16x8* __restrict__ dst8 = reinterpret_cast<bf16x8*>(d.dst);
+
+    u32x4 pv[2];
+    unsigned okbits = 0;
+    auto issue = [&](int tile) {
+        const int img = tile / tpi, trem = tile - img * tpi;
+        const int ty = trem / t.tiles_x, tx = trem - ty * t.tiles_x;
+        const int a0 = ty * TH, b0 = tx * TW;
+        const int base = (img * d.SH + a0) * d.SW + b0;
+        const unsigned border = (a0 + dh0 < 0 ? 1u : 0u) | (a0 + PH + dh0 > d.SH ? 2u : 0u) | (b0 + dw0 < 0 ? 4u : 0u) | (b0 + PW + dw0 > d.SW ? 8u : 0u);
+        okbits = 0;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const bool ok = (halo[it] & border) == 0;
+            pv[it] = src16[(unsigned)(base + (ok ? psrc[it] : 0))];
+            okbits |= ok ? (1u << it) : 0u;
+        }
+    };
+    int tile = blockIdx.x;
+    if (tile < ntiles) issue(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int img = tile / tpi, trem = tile - img * tpi;
+        const int ty = trem / t.tiles_x, tx = trem - ty * t.tiles_x;
+        __syncthreads();                          // previous tile's reads are done
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            u32x4 v = pv[it];
+            if (!((okbits >> it) & 1)) v = u32x4{0, 0, 0, 0};
+            if (ppix[it] >= 0) *reinterpret_cast<u32x4*>(patch + ppix[it] * 16) = v;
+        }
+        __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x);
+        const int dbase = ((img * d.DH + ty * TH) * d.DW + tx * TW) * cd8;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x4 acc[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const u32x4 pf = *reinterpret_cast<const u32x4*>(patch + pbase[i] + toff[ks]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[ks][j]), __builtin_bit_cast(bf16x8, pf), acc[j], 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < UPL; ++u) {
+                if (ch0 + u * 8 >= d.CD) continue;
+                bf16x8 o;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float x0 = acc[2 * u][q] + bias8[u][q], x1 = acc[2 * u + 1][q] + bias8[u][4 + q];
+                    o[q] = (__bf16)fmaxf(x0, x0 * slope);
+                    o[4 + q] = (__bf16)fmaxf(x1, x1 * slope);
+                }
+                dst8[dbase + eoff[i] + u] = o;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// 0 = launched, 1 = not this kernel's case, < 0 = error
+int xmc_conv_thin_try(const XmcConvDesc* d, void* stream) {
+    static const bool off = getenv("XMC_NO_THIN") != nullptr;
+    if (off) return 1;
+    if (d->dtype != XMC_BF16 || d->out_dtype != XMC_BF16 || d->CS != 8) return 1;
+    if (d->SA != 1 || d->DA != 1 || d->src_shift != 0 || d->nclass != 1 || d->ntaps > 12) return 1;
+    if (d->CDw != 32 && d->CDw != 64) return 1;
+    if (d->res || d->alpha_dev || (d->act != XMC_ACT_NONE && d->act != XMC_ACT_LRELU)) return 1;
+    if (d->MH % 8 != 0 || d->MW % 32 != 0 || d->SH != d->MH || d->SW != d->MW || d->DH != d->MH || d->DW != d->MW) return 1;
+    if (d->dph[0] != 0 || d->dpw[0] != 0) return 1;
+    int hmin = 127, hmax = -128, wmin = 127, wmax = -128;
+    for (int k = 0; k < d->ntaps; ++k) {
+        const int h = d->dh[0][k], w = d->dw[0][k];
+        hmin = h < hmin ? h : hmin; hmax = h > hmax ? h : hmax;
+        wmin = w < wmin ? w : wmin; wmax = w > wmax ? w : wmax;
+    }
+    if (hmax - hmin > 4 || wmax - wmin > 4 || hmin > 0 || wmin > 0 || hmax < 0 || wmax < 0) return 1;
+    ThinCfg t;
+    t.tiles_y = d->MH / 8; t.tiles_x = d->MW / 32;
+    t.PH = 8 + (hmax - hmin); t.PW = 32 + (wmax - wmin);
+    t.dh0 = hmin; t.dw0 = wmin;
+    if (t.PH * t.PW > 512) return 1;
+    const int ntiles = d->N * t.tiles_y * t.tiles_x;
+    int gx = 256 * 5;
+    if (gx > ntiles) gx = ntiles;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (d->CDw == 32) {
+        hipLaunchKernelGGL((thin_in_kernel<32>), dim3(gx), dim3(256), 0, st, *d, t, ntiles);
+    } else {
+        hipLaunchKernelGGL((thin_in_kernel<64>), dim3(gx), dim3(256), 0, st, *d, t, ntiles);
+    }
+    xmc_note_kernel("thin_in_kernel<%d>", d->CDw);
+    XMC_LAUNCH_CHECK();
+    return 0;
+}
