@@ -69,6 +69,10 @@ CONV_CASES = [
     # streaming kernel for 8-channel sources (conv_thin.hip): conv_img forward / conv_out dgrad on maps with H % 8 == 0, W % 32 == 0
     (3, 64, 3, 1, 1, 64, 1),       # 64 output channels, several tiles per image
     (64, 3, 3, 1, 1, 32, 3),       # its mirror: the dgrad has the 8-channel source
+    # 256x128 tiles of the gather kernel: Cout % 128 == 0 and >= 65536 output pixels
+    (128, 128, 3, 1, 1, 72, 13),   # M = 67392: last 256-row tile is partial
+    (64, 128, 4, 2, 1, 128, 16),   # stride-2 forward; its dgrad = 4 parity classes
+    (32, 256, 1, 1, 0, 64, 16),    # 1x1: a single K step
 ]
 
 
@@ -83,7 +87,11 @@ def test_conv_fwd_dgrad_wgrad(case, mode):
     w = rt(torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k), mode)
     b = torch.randn(cout, generator=g) * 0.1
     xr, wr, br = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
-    yr = F.leaky_relu(F.conv2d(xr, wr, br, s, p), 0.2)
+    # Large cases run without the activation: among millions of pre-activations a few land within rounding of LeakyReLU's
+    # kink, the GPU and CPU masks then differ in one element and that moves k*k*Cin entries of dx and Cin*k*k of dW by
+    # 0.8*|r|*|x| -- the reference's kink, not a kernel error.  The fused activation is covered by the small cases.
+    big = N * cout * H * H > (1 << 20)
+    yr = F.conv2d(xr, wr, br, s, p) if big else F.leaky_relu(F.conv2d(xr, wr, br, s, p), 0.2)
     r = rt(torch.randn(yr.shape, generator=g), mode)
     (yr * r).sum().backward()
 
@@ -91,7 +99,7 @@ def test_conv_fwd_dgrad_wgrad(case, mode):
     xd = to_nhwc(x, ops.chan_pad(cin, dt), dt).requires_grad_()
     wd = torch.nn.Parameter(w.to(DEV))
     bd = torch.nn.Parameter(b.to(DEV))
-    y = ops.conv2d(xd, wd, bd, geom, act=L.ACT_LRELU)
+    y = ops.conv2d(xd, wd, bd, geom, act=L.ACT_NONE if big else L.ACT_LRELU)
     assert y.shape == (N, yr.shape[2], yr.shape[3], ops.pad_to(cout, 8))
     sc = yr.abs().max().item()
     torch.testing.assert_close(from_nhwc(y, cout), yr.detach(), **tol(mode, sc))

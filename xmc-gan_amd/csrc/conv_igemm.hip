@@ -21,6 +21,10 @@
 #include "common.h"
 #include <stdlib.h>
 
+#ifndef XMC_IGEMM_PIN
+#define XMC_IGEMM_PIN 1
+#endif
+
 namespace {
 
 template <int DT> struct Mma;
@@ -162,6 +166,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const XmcConvDesc d) {
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int fr = lane & 15, fc = lane >> 4;        // fragment row / 16-byte chunk
+    constexpr bool pin_reads = XMC_IGEMM_PIN;
     load_step(0);
     store_step(0);
     __syncthreads();
@@ -174,20 +179,26 @@ __global__ __launch_bounds__(256) void igemm_kernel(const XmcConvDesc d) {
 #pragma unroll
         for (int s = 0; s < KSUB; ++s) {
             u32x4 af[TM], bf[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                int r = wm * WTM + i * 16 + fr;
-                af[i] = la[(s * BM + r) * 4 + (fc ^ swz(r))];
-            }
+            // All fragment reads of the sub-step are issued first (weights, then pixel rows in the order the MFMAs consume
+            // them) and the order is pinned: left to itself the scheduler sinks each read to just before its first use and
+            // every group of MFMAs then waits a full LDS round trip on lgkmcnt(0).
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 int r = wn * WTN + j * 16 + fr;
                 bf[j] = lb[(s * BN + r) * 4 + (fc ^ swz(r))];
             }
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i) {
+                int r = wm * WTM + i * 16 + fr;
+                af[i] = la[(s * BM + r) * 4 + (fc ^ swz(r))];
+            }
+            if (pin_reads) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = Mma<DT>::run(af[i], bf[j], acc[i][j]);
+                if (pin_reads) __builtin_amdgcn_sched_barrier(0);
+            }
         }
         if (more) store_step(buf ^ 1);
         __syncthreads();
