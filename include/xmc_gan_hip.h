@@ -68,6 +68,16 @@ typedef struct XmcConvDesc {
     int8_t wi[XMC_MAX_CLASSES][XMC_MAX_TAPS];
     int8_t dph[XMC_MAX_CLASSES];
     int8_t dpw[XMC_MAX_CLASSES];
+    /* Epilogue extensions (all optional; a zeroed tail means "none").  Order: bias, act, alpha, mask, residual.
+     *  mask     : dst layout+dtype; the result is multiplied by LeakyReLU'(mask) = (mask > 0 ? 1 : 0.2).  Lets a data
+     *             gradient apply the activation mask of the layer below it (the tensor it is the gradient of).
+     *  res_mode : 0 = residual has the dst layout; 1 = residual is [N,MH,MW,CD] and indexed by the GEMM row, i.e. with
+     *             DA == 2 every residual pixel is added to its 2x2 block of dst (nearest upsample): the adjoint of the
+     *             average pool in front of the shortcut (df_gan.py:290) folded into the data gradient of conv_r[0].
+     *  res_scale: factor on the residual; 0 is read as 1. */
+    const void* mask;
+    float res_scale;
+    int32_t res_mode;
 } XmcConvDesc;
 
 int xmc_abi_version(void);
@@ -126,6 +136,9 @@ int xmc_axpby_up(const void* a, const void* b, const float* alpha_dev, void* y, 
 int xmc_scale(const void* x, const float* alpha_dev, void* y, int64_t n, int dtype, void* stream);
 /* *out (+)= sum(a*b)  (f32 scalar; out zeroed by caller when accumulate==0 is not desired) */
 int xmc_dot(const void* a, const void* b, float* out, int64_t n, int dtype, void* stream);
+/* g = alpha*dy*LeakyReLU'(ref) and dot += sum(dy*ref) in one pass: backward of `shortcut + gamma*residual` (df_gan.py:284)
+ * into a residual branch ending in LeakyReLU (ref = its output) together with d(gamma); dot is f32[1], zeroed by the caller */
+int xmc_scale_mask_dot(const void* dy, const void* ref, const float* alpha_dev, void* g, float* dot, int64_t n, int dtype, void* stream);
 /* out[c] = sum over rows of x[r][c]         (bias gradients) ; out is f32 [C], zeroed by the caller */
 int xmc_colsum(const void* x, float* out, int64_t rows, int C, int dtype, void* stream);
 /* 2x2 average pool (F.avg_pool2d(x,2) df_gan.py:290) and its adjoint (nearest x2 upsample * scale) */

@@ -26,7 +26,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     d = L.ConvDesc()
     assert lib.xmc_conv_igemm(ctypes.byref(d), None) == -1
     assert lib.xmc_conv_wgrad(ctypes.byref(d), None, None) == -1
-    assert ctypes.sizeof(L.ConvDesc) == 320 and ctypes.sizeof(L.AdamEntry) == 48
+    assert ctypes.sizeof(L.ConvDesc) == 336 and ctypes.sizeof(L.AdamEntry) == 48
 
 
 def test_missing_library_fails_loudly(monkeypatch):

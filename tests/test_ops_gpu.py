@@ -371,3 +371,38 @@ def test_rejects_cpu_tensors_and_bad_shapes():
     d = L.ConvDesc()
     import ctypes as C
     assert L.load().xmc_conv_igemm(C.byref(d), None) < 0          # null pointers -> XMC_EINVAL, nothing launched
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("cin,cout,H", [(32, 64, 32), (64, 64, 16), (8, 16, 64)])
+def test_fused_discriminator_block_equals_composed_block(cin, cout, H, mode):
+    """ops.ResDFn (one first-order node per resD block: masks, d(gamma) and the pooled shortcut gradient folded into the
+    convolution epilogues) against the same block built from the fine-grained Functions (df_gan.py:269-291)."""
+    from xmc_gan.model.df_gan import resD
+    ops.set_precision(mode)
+    dt = ops.act_dtype()
+    torch.manual_seed(cin + H)
+    blk = resD(cin, cout, downsample=True).to(DEV)
+    with torch.no_grad():
+        blk.gamma.fill_(0.37)
+    x0 = torch.randn(3, H, H, ops.chan_pad(cin, dt), device=DEV).to(dt)
+    r = torch.randn(3, H // 2, H // 2, ops.pad_to(cout, 8), device=DEV).to(dt)
+    got = {}
+    for name in ("fused", "composed"):
+        blk.zero_grad()
+        x = x0.clone().requires_grad_()
+        if name == "fused":
+            y = blk(x)
+        else:
+            with ops.composable():
+                y = blk(x)
+        (y.float() * r.float()).sum().backward()
+        got[name] = [y.detach().float(), x.grad.float()] + [p.grad.clone() if p.grad is not None else None for p in blk.parameters()]
+    names = ["y", "dx"] + [n for n, _ in blk.named_parameters()]
+    for n, a, b in zip(names, got["fused"], got["composed"]):
+        assert (a is None) == (b is None), n
+        if a is None:
+            continue
+        sc = b.abs().max().item() + 1e-12
+        # bf16: the composed path rounds dx of each branch to bf16 before adding them, the fused path adds in f32
+        torch.testing.assert_close(a, b, rtol=2e-2 if mode == "bf16" else 1e-4, atol=(2e-2 if mode == "bf16" else 1e-4) * sc, msg=lambda m: f"{n}: {m}")

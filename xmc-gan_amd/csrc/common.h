@@ -71,3 +71,22 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
+
+// Shared tail of the convolution epilogues: LeakyReLU' mask, (scaled, possibly row-indexed) residual, store.
+template <int ODT>
+__device__ __forceinline__ void epilogue_tail(const XmcConvDesc& d, size_t idx8, size_t ridx8, float (&v)[8]) {
+    if (d.mask) {
+        float mk[8];
+        Vec8<ODT>::load(d.mask, idx8, mk);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] *= lrelu_slope(mk[k]);
+    }
+    if (d.res) {
+        const float rs = d.res_scale == 0.f ? 1.f : d.res_scale;
+        float rr[8];
+        Vec8<ODT>::load(d.res, ridx8, rr);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] += rs * rr[k];
+    }
+    Vec8<ODT>::store(d.dst, idx8, v);
+}

@@ -252,23 +252,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const XmcConvDesc d) {
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[k] *= alpha;
-            if (d.out_dtype == XMC_BF16) {
-                if (d.res) {
-                    float rr[8];
-                    Vec8<XMC_BF16>::load(d.res, idx8, rr);
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] += rr[k];
-                }
-                Vec8<XMC_BF16>::store(d.dst, idx8, v);
-            } else {
-                if (d.res) {
-                    float rr[8];
-                    Vec8<XMC_F32>::load(d.res, idx8, rr);
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] += rr[k];
-                }
-                Vec8<XMC_F32>::store(d.dst, idx8, v);
-            }
+            const size_t ridx8 = d.res_mode ? ((size_t)m * d.CD + ch) >> 3 : idx8;
+            if (d.out_dtype == XMC_BF16) epilogue_tail<XMC_BF16>(d, idx8, ridx8, v);
+            else epilogue_tail<XMC_F32>(d, idx8, ridx8, v);
         }
     }
 }

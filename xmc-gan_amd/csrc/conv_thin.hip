@@ -142,7 +142,7 @@ int xmc_conv_thin_try(const XmcConvDesc* d, void* stream) {
     if (d->dtype != XMC_BF16 || d->out_dtype != XMC_BF16 || d->CS != 8) return 1;
     if (d->SA != 1 || d->DA != 1 || d->src_shift != 0 || d->nclass != 1 || d->ntaps > 12) return 1;
     if (d->CDw != 32 && d->CDw != 64) return 1;
-    if (d->res || d->alpha_dev || (d->act != XMC_ACT_NONE && d->act != XMC_ACT_LRELU)) return 1;
+    if (d->res || d->mask || d->alpha_dev || (d->act != XMC_ACT_NONE && d->act != XMC_ACT_LRELU)) return 1;
     if (d->MH % 8 != 0 || d->MW % 32 != 0 || d->SH != d->MH || d->SW != d->MW || d->DH != d->MH || d->DW != d->MW) return 1;
     if (d->dph[0] != 0 || d->dpw[0] != 0) return 1;
     int hmin = 127, hmax = -128, wmin = 127, wmax = -128;

@@ -222,23 +222,10 @@ __global__ __launch_bounds__(256) void tile_kernel(const XmcConvDesc d, const Ti
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[k] *= alpha;
-            if (d.out_dtype == XMC_BF16) {
-                if (d.res) {
-                    float rr[8];
-                    Vec8<XMC_BF16>::load(d.res, idx8, rr);
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] += rr[k];
-                }
-                Vec8<XMC_BF16>::store(d.dst, idx8, v);
-            } else {
-                if (d.res) {
-                    float rr[8];
-                    Vec8<XMC_F32>::load(d.res, idx8, rr);
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] += rr[k];
-                }
-                Vec8<XMC_F32>::store(d.dst, idx8, v);
-            }
+            // row-indexed residual: pixel (a0+ty, b0+tx) of the [N,MH,MW,CD] grid
+            const size_t ridx8 = d.res_mode ? (size_t)((((img * d.MH + a0 + ty) * d.MW) + b0 + tx) * (d.CD >> 3) + ((n0 >> 3) + cc)) : idx8;
+            if (d.out_dtype == XMC_BF16) epilogue_tail<XMC_BF16>(d, idx8, ridx8, v);
+            else epilogue_tail<XMC_F32>(d, idx8, ridx8, v);
         }
     }
 }
@@ -386,13 +373,14 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
         // ------------------------------------------------------------------------------------------------ compute role
         const int fr = lane & 15, fc = lane >> 4;
         const int cd8 = d.CD / 8;
-        int abyte[TM], eoff[TM];
+        int abyte[TM], eoff[TM], roff[TM];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int ml = wm * 64 + i * 16 + fr;
             const int ty = ml >> t.log2TW, tx = ml & (t.TW - 1);
             abyte[i] = (ty * PW + tx) * pstride + fc * 16;
             eoff[i] = ((ty * d.DA) * d.DW + tx * d.DA) * cd8 + fc * UPL;
+            roff[i] = (ty * d.MW + tx) * cd8 + fc * UPL;          // same pixel in the [N,MH,MW,CD] grid (res_mode 1)
         }
         const int bbyte = fr * pstride + fc * 16;
         const int dph = d.dph[cls], dpw = d.dpw[cls];
@@ -404,7 +392,7 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
 #pragma unroll
             for (int c = 0; c < 8; ++c) bias8[u][c] = (d.bias && ch0 + u * 8 < d.CD) ? d.bias[ch0 + u * 8 + c] : 0.f;
         // one uniform decision instead of a chain of branches per stored unit
-        const bool fast = d.out_dtype == XMC_BF16 && d.res == nullptr && d.alpha_dev == nullptr &&
+        const bool fast = d.out_dtype == XMC_BF16 && d.res == nullptr && d.mask == nullptr && d.alpha_dev == nullptr &&
                           (d.act == XMC_ACT_NONE || d.act == XMC_ACT_LRELU);
         const float slope = d.act == XMC_ACT_LRELU ? XMC_LRELU : 1.f;
         __syncthreads();                          // weights + first patch staged
@@ -483,6 +471,7 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
             __syncthreads();                      // B2: patch may be overwritten
             // epilogue from registers: acc[i][j][r] = pixel (m-block i, fr), channel ch0 + j*4 + r
             const int dbase = (((img * d.DH + a0 * d.DA + dph) * d.DW) + b0 * d.DA + dpw) * cd8 + (n0 >> 3);
+            const int rbase = ((img * d.MH + a0) * d.MW + b0) * cd8 + (n0 >> 3);
             if (fast) {
                 bf16x8* __restrict__ dst8 = reinterpret_cast<bf16x8*>(d.dst) + dbase;
 #pragma unroll
@@ -532,23 +521,9 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
 #pragma unroll
                             for (int q = 0; q < 8; ++q) v[q] *= alpha;
                         }
-                        if (d.out_dtype == XMC_BF16) {
-                            if (d.res) {
-                                float rr[8];
-                                Vec8<XMC_BF16>::load(d.res, idx8, rr);
-#pragma unroll
-                                for (int q = 0; q < 8; ++q) v[q] += rr[q];
-                            }
-                            Vec8<XMC_BF16>::store(d.dst, idx8, v);
-                        } else {
-                            if (d.res) {
-                                float rr[8];
-                                Vec8<XMC_F32>::load(d.res, idx8, rr);
-#pragma unroll
-                                for (int q = 0; q < 8; ++q) v[q] += rr[q];
-                            }
-                            Vec8<XMC_F32>::store(d.dst, idx8, v);
-                        }
+                        const size_t ridx8 = d.res_mode ? (size_t)(rbase + roff[i] + u) : idx8;
+                        if (d.out_dtype == XMC_BF16) epilogue_tail<XMC_BF16>(d, idx8, ridx8, v);
+                        else epilogue_tail<XMC_F32>(d, idx8, ridx8, v);
                     }
             }
         }

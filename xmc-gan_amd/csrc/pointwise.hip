@@ -98,6 +98,31 @@ __global__ void dot_kernel(const void* a, const void* b, float* out, int64_t n8)
     }
 }
 
+// g = alpha * dy * LeakyReLU'(ref)  and  dot += sum(dy * ref)  in one pass: the backward of `shortcut + gamma * residual`
+// (df_gan.py:284) towards the residual branch whose last op is a LeakyReLU (ref = its output), and d(gamma).
+template <int DT>
+__global__ void scale_mask_dot_kernel(const void* dy, const void* ref, const float* alpha, void* g, float* dot, int64_t n8) {
+    const float al = *alpha;
+    float s = 0.f;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        float u[8], v[8], o[8];
+        Vec8<DT>::load(dy, i, u);
+        Vec8<DT>::load(ref, i, v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { s += u[k] * v[k]; o[k] = al * u[k] * lrelu_slope(v[k]); }
+        Vec8<DT>::store(g, i, o);
+    }
+    s = wave_sum(s);
+    __shared__ float part[NT / 64];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < NT / 64; ++w) t += part[w];
+        atomicAdd(dot, t);
+    }
+}
+
 // out[c] += sum_r x[r][c];  thread owns one 8-channel chunk and strides over rows; blockIdx.y walks
 // over groups of NT chunks when C/8 > NT (e.g. the 4096-wide proj_noise bias)
 template <int DT>
@@ -484,6 +509,16 @@ extern "C" int xmc_dot(const void* a, const void* b, float* out, int64_t n, int 
     dim3 g(nblocks(n8, NT, 512)), blk(NT);
     if (dtype == XMC_BF16) hipLaunchKernelGGL((dot_kernel<XMC_BF16>), g, blk, 0, ST(s), a, b, out, n8);
     else if (dtype == XMC_F32) hipLaunchKernelGGL((dot_kernel<XMC_F32>), g, blk, 0, ST(s), a, b, out, n8);
+    else return XMC_EINVAL;
+    XMC_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int xmc_scale_mask_dot(const void* dy, const void* ref, const float* alpha, void* g, float* dot, int64_t n, int dtype, void* s) {
+    if (n % 8) return XMC_EALIGN;
+    int64_t n8 = n / 8;
+    dim3 grd(nblocks(n8, NT, 2048)), blk(NT);
+    if (dtype == XMC_BF16) hipLaunchKernelGGL((scale_mask_dot_kernel<XMC_BF16>), grd, blk, 0, ST(s), dy, ref, alpha, g, dot, n8);
+    else if (dtype == XMC_F32) hipLaunchKernelGGL((scale_mask_dot_kernel<XMC_F32>), grd, blk, 0, ST(s), dy, ref, alpha, g, dot, n8);
     else return XMC_EINVAL;
     XMC_LAUNCH_CHECK();
     return 0;

@@ -24,7 +24,8 @@ class ConvDesc(C.Structure):
                 ("ntaps", i32), ("nclass", i32), ("CDw", i32), ("act", i32), ("dtype", i32), ("out_dtype", i32),
                 ("dh", (C.c_int8 * MAX_TAPS) * MAX_CLASSES), ("dw", (C.c_int8 * MAX_TAPS) * MAX_CLASSES),
                 ("wi", (C.c_int8 * MAX_TAPS) * MAX_CLASSES),
-                ("dph", C.c_int8 * MAX_CLASSES), ("dpw", C.c_int8 * MAX_CLASSES)]
+                ("dph", C.c_int8 * MAX_CLASSES), ("dpw", C.c_int8 * MAX_CLASSES),
+                ("mask", vp), ("res_scale", f32), ("res_mode", i32)]
 
 
 class AdamEntry(C.Structure):
@@ -49,6 +50,7 @@ _SIGS = {
     "xmc_tanh": [vp, vp, i64, i32, vp],
     "xmc_tanh_bwd": [vp, vp, vp, i64, i32, vp],
     "xmc_axpby": [vp, vp, vp, vp, i64, i32, vp],
+    "xmc_scale_mask_dot": [vp, vp, vp, vp, vp, i64, i32, vp],
     "xmc_scale": [vp, vp, vp, i64, i32, vp],
     "xmc_dot": [vp, vp, vp, i64, i32, vp],
     "xmc_colsum": [vp, vp, i64, i32, i32, vp],

@@ -38,6 +38,22 @@ def act_dtype():
     return torch.bfloat16 if _PRECISION == "bf16" else torch.float32
 
 
+class composable:
+    """Context: build blocks from the fine-grained differentiable Functions instead of the fused first-order block Functions
+    (needed wherever the backward pass itself is differentiated: MA-GP, train_gan.py:231-252)."""
+
+    def __enter__(self):
+        self.prev = getattr(_state, "composable", False)
+        _state.composable = True
+
+    def __exit__(self, *a):
+        _state.composable = self.prev
+
+
+def fused_blocks():
+    return not getattr(_state, "composable", False) and not os.environ.get("XMC_NO_FUSED_BLOCKS")
+
+
 class no_wgrad:
     """Context: convolutions skip weight/bias gradients (used where the reference computes and
     then discards them, e.g. D's weight grads during the G step, train_gan.py:288 then 226-227)."""
@@ -278,8 +294,10 @@ def _conv_fwd_raw(x, w, bias, geom, act, out_dtype, res=None, alpha=None, up=Fal
     return y
 
 
-def _conv_dgrad_raw(dy, w, geom, in_hw, in_dtype):
-    """dx [N,H,W,cin_p] from dy [N,OH,OW,cout_p]."""
+def _conv_dgrad_raw(dy, w, geom, in_hw, in_dtype, mask=None, res=None, res_rows=False, res_scale=1.0):
+    """dx [N,H,W,cin_p] from dy [N,OH,OW,cout_p].  Epilogue options: ``mask`` (dx layout): dx *= LeakyReLU'(mask);
+    ``res``: dx += res_scale * res, with ``res_rows`` the residual is [N,H/s,W/s,cin_p] and every pixel of it is added to its
+    s x s block of dx (s == 2: the adjoint of avg_pool2d, df_gan.py:290)."""
     _need_cuda(dy, w)
     N, OH, OW, CDy = dy.shape
     H, W = in_hw
@@ -310,6 +328,14 @@ def _conv_dgrad_raw(dy, w, geom, in_hw, in_dtype):
             _fill_taps(d, cls, taps)
             d.dph[cls], d.dpw[cls] = ph, pw
     d.ntaps = ntaps
+    if mask is not None:
+        assert mask.shape == dx.shape and mask.dtype == dx.dtype and mask.is_contiguous()
+        d.mask = mask.data_ptr()
+    if res is not None:
+        want = (N, H // s, W // s, cs_p) if res_rows else tuple(dx.shape)
+        assert tuple(res.shape) == want and res.dtype == dx.dtype and res.is_contiguous(), (res.shape, want)
+        assert not res_rows or s == 2
+        d.res, d.res_mode, d.res_scale = res.data_ptr(), 1 if res_rows else 0, float(res_scale)
     with prof.launch("igemm_kernel (conv fwd+dgrad, MFMA implicit GEMM)", 2.0 * N * OH * OW * geom.cout * geom.cin * geom.k * geom.k,
                      f"dgrad {dy.dtype} N{N} {H}x{W} {geom.cin}->{geom.cout} k{geom.k}s{geom.s}"):
         L.check(L.load().xmc_conv_igemm(C.byref(d), _st()), "xmc_conv_igemm(dgrad)")
@@ -675,6 +701,82 @@ class AxpbyFn(torch.autograd.Function):
         db = ScaleFn.apply(dy, alpha) if ctx.needs_input_grad[1] else None
         dal = DotFn.apply(dy, b).reshape(alpha.shape) if ctx.needs_input_grad[2] else None
         return da, db, dal
+
+
+class ResDFn(torch.autograd.Function):
+    """One discriminator block, `shortcut(x) + gamma * residual(x)` (df_gan.py:269-291), as a single first-order node:
+    forward = the same launches as the composed block; backward fuses what autograd would run as separate passes:
+      * gamma*dout, the LeakyReLU mask of the residual output and d(gamma) = <dout, res> in one kernel (7 tensor passes -> 3),
+      * the LeakyReLU mask of conv_r[0]'s output in the epilogue of conv_r[2]'s data gradient,
+      * the shortcut's gradient (adjoint of the average pool: x0.25, nearest x2) as the row-indexed residual of conv_r[0]'s
+        data gradient, so neither the upsampled tensor nor the sum of the two branches is written separately.
+    Not differentiable a second time: MA-GP runs the composed block (ops.composable())."""
+
+    @staticmethod
+    def forward(ctx, x, w0, w2, ws, bs, gamma, g0, g2, gs):
+        x = x.contiguous()
+        dt = x.dtype
+        N, H, W, _ = x.shape
+        xp = torch.empty((N, H // 2, W // 2, x.shape[3]), dtype=dt, device=x.device)
+        L.call("xmc_sumpool2", _p(x), _p(xp), N, H, W, x.shape[3], 0.25, _code(dt), _st())
+        if ws is not None:
+            bp = None
+            if bs is not None:
+                bp = bs.detach().float()
+                cd_p = pad_to(gs.cout, 8)
+                if bp.numel() < cd_p:
+                    bp = torch.nn.functional.pad(bp, (0, cd_p - bp.numel()))
+                bp = bp.contiguous()
+            sc = _conv_fwd_raw(xp, ws, bp, gs, L.ACT_NONE, dt)
+        else:
+            sc = xp
+        h1 = _conv_fwd_raw(x, w0, None, g0, L.ACT_LRELU, dt)
+        res = _conv_fwd_raw(h1, w2, None, g2, L.ACT_LRELU, dt)
+        al = gamma.detach().reshape(-1).float()
+        out = torch.empty_like(res)
+        L.call("xmc_axpby", _p(sc), _p(res), _p(al), _p(out), res.numel(), _code(dt), _st())
+        ctx.geoms = (g0, g2, gs)
+        ctx.learned = ws is not None
+        ctx.has_bs = bs is not None
+        ctx.save_for_backward(x, xp if ws is not None else None, h1, res, w0, w2, ws, gamma)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dout):
+        x, xp, h1, res, w0, w2, ws, gamma = ctx.saved_tensors
+        g0, g2, gs = ctx.geoms
+        dout = dout.contiguous()
+        dt = x.dtype
+        if dout.dtype != dt:
+            dout = dout.to(dt)
+        skip_w = _skip_wgrad()
+        # residual branch: g2 = gamma * dout * LeakyReLU'(res), d(gamma) = <dout, res>
+        al = gamma.detach().reshape(-1).float()
+        gr = torch.empty_like(res)
+        dgam = torch.zeros(1, dtype=torch.float32, device=x.device)
+        L.call("xmc_scale_mask_dot", _p(dout), _p(res), _p(al), _p(gr), _p(dgam), res.numel(), _code(dt), _st())
+        dw2 = _conv_wgrad_raw(h1, gr, g2).view(w2.shape) if (ctx.needs_input_grad[2] and not skip_w) else None
+        gh = _conv_dgrad_raw(gr, w2, g2, (h1.shape[1], h1.shape[2]), dt, mask=h1)        # includes LeakyReLU'(h1)
+        dw0 = _conv_wgrad_raw(x, gh, g0).view(w0.shape) if (ctx.needs_input_grad[1] and not skip_w) else None
+        # shortcut branch
+        dws = dbs = None
+        if ctx.learned:
+            if ctx.needs_input_grad[3] and not skip_w:
+                if ctx.has_bs and ctx.needs_input_grad[4]:
+                    dws, dbs = _conv_wgrad_raw(xp, dout, gs, want_bias=True)
+                    dbs = dbs[: gs.cout]
+                else:
+                    dws = _conv_wgrad_raw(xp, dout, gs)
+                dws = dws.view(ws.shape)
+            dxp = _conv_dgrad_raw(dout, ws, gs, (xp.shape[1], xp.shape[2]), dt) if ctx.needs_input_grad[0] else None
+        else:
+            dxp = dout
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _conv_dgrad_raw(gh, w0, g0, (x.shape[1], x.shape[2]), dt, res=dxp, res_rows=True, res_scale=0.25)
+        dgamma = dgam.reshape(gamma.shape).to(gamma.dtype) if ctx.needs_input_grad[5] else None
+        return dx, dw0, dw2, dws, dbs, dgamma, None, None, None
 
 
 class ColSumFn(torch.autograd.Function):

@@ -164,8 +164,9 @@ def gan_iteration(netG, netD, optimizerG, optimizerD, imgs, sent_embs, words_emb
     if T.MAGP:
         interpolated = imgs.detach().requires_grad_()
         sent_inter = psent_embs.detach().requires_grad_()
-        features = netD(interpolated)
-        o = netD.COND_DNET(features, sent_inter)
+        with ops.composable():         # this forward's backward is differentiated again: no fused first-order block nodes
+            features = netD(interpolated)
+            o = netD.COND_DNET(features, sent_inter)
         with ops.no_wgrad():           # first-order pass only needs d(logit)/d(inputs)
             grads = torch.autograd.grad(outputs=o[0], inputs=(interpolated, sent_inter),
                                         grad_outputs=torch.ones_like(o[0]), retain_graph=True, create_graph=True,
