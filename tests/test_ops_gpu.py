@@ -73,6 +73,13 @@ CONV_CASES = [
     (128, 128, 3, 1, 1, 72, 13),   # M = 67392: last 256-row tile is partial
     (64, 128, 4, 2, 1, 128, 16),   # stride-2 forward; its dgrad = 4 parity classes
     (32, 256, 1, 1, 0, 64, 16),    # 1x1: a single K step
+    # weight gradient by kernel rows (conv_wgrad_row.hip): Cin, Cout % 128 == 0, W a power of two >= 16
+    (128, 128, 3, 1, 1, 32, 2),    # two 32-pixel row segments per K step
+    (128, 256, 3, 1, 1, 64, 1),    # one 64-pixel segment = one image row
+    (256, 128, 3, 1, 1, 128, 1),   # image rows longer than a K step (segments start inside a row)
+    (128, 128, 4, 2, 1, 32, 3),    # 4x4 stride 2: output rows of 16 pixels, 4 segments per step
+    (128, 256, 4, 2, 1, 64, 2),    # output rows of 32
+    (128, 128, 4, 2, 1, 128, 1),   # output rows of 64: 130 source pixels per segment
 ]
 
 

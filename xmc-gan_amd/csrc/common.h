@@ -19,10 +19,26 @@ static inline int xmc_esz(int dtype) { return dtype == XMC_BF16 ? 2 : 4; }
 // its per-launch HIP-event timings to the instantiation rocprof reports)
 void xmc_note_kernel(const char* fmt, ...);
 
-#define XMC_LAUNCH_CHECK()                         \
-    do {                                           \
-        hipError_t e__ = hipGetLastError();        \
-        if (e__ != hipSuccess) return (int)e__;    \
+// HIP errors are reported as -(1000 + code): positive 1 is taken by "not this kernel's case" in the *_try dispatch chain
+// (hipErrorInvalidValue == 1 once made a stale error look like "not eligible", and the next kernel in the chain ran as well).
+#define XMC_LAUNCH_CHECK()                                     \
+    do {                                                       \
+        hipError_t e__ = hipGetLastError();                    \
+        if (e__ != hipSuccess) return -(1000 + (int)e__);      \
+    } while (0)
+
+// Raise a kernel's dynamic-LDS limit to what gfx950 allows.  Static __shared__ of the kernel counts against the same 160 KiB, so
+// ask for a little less than all of it, and do not leave a failure behind as the thread's "last error".
+#define XMC_MAX_DYN_LDS (160 * 1024 - 1024)
+#define XMC_ALLOW_BIG_LDS(kernel)                                                                                              \
+    do {                                                                                                                       \
+        static bool once__ = false;                                                                                            \
+        if (!once__) {                                                                                                         \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&kernel), hipFuncAttributeMaxDynamicSharedMemorySize,      \
+                                      XMC_MAX_DYN_LDS);                                                                        \
+            (void)hipGetLastError();                                                                                           \
+            once__ = true;                                                                                                     \
+        }                                                                                                                      \
     } while (0)
 
 __device__ __forceinline__ float lrelu_f(float v) { return v > 0.f ? v : XMC_LRELU * v; }

@@ -538,7 +538,7 @@ int launch_ptile(const XmcConvDesc& d, const TileCfg& t, hipStream_t st) {
     const int pstride = t.slab * 2 + 32;
     const size_t pb = (size_t)((maxpatch * pstride + 15) & ~15);
     const size_t lds = pb + (size_t)d.ntaps * BN * pstride;
-    if (lds > 160 * 1024 - 256) return XMC_ESHAPE;
+    if (lds > XMC_MAX_DYN_LDS) return XMC_ESHAPE;
     const int ntiles = d.N * t.tiles_y * t.tiles_x;
     const int per_cu = (lds <= 80 * 1024 && BN == 32 && t.slab == 32) ? 2 : 1;    // 8-wave workgroups; 2 fit when <= 128 VGPRs
     int gx = 256 * per_cu / (int)((d.CDw / BN) * d.nclass);
@@ -547,12 +547,7 @@ int launch_ptile(const XmcConvDesc& d, const TileCfg& t, hipStream_t st) {
     dim3 grid((unsigned)gx, (unsigned)(d.CDw / BN), (unsigned)d.nclass);
 #define XMC_PT3(SL, NTP)                                                                                                      \
     do {                                                                                                                      \
-        static bool once = false;                                                                                             \
-        if (!once) {                                                                                                          \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ptile3_kernel<BN, SL, NTP>),                             \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                \
-            once = true;                                                                                                      \
-        }                                                                                                                     \
+        XMC_ALLOW_BIG_LDS((ptile3_kernel<BN, SL, NTP>));                                                                      \
         hipLaunchKernelGGL((ptile3_kernel<BN, SL, NTP>), grid, dim3(512), lds, st, d, t, ntiles);                             \
         xmc_note_kernel("ptile3_kernel<%d, %d, %d>", BN, SL, NTP);                                                            \
     } while (0)
@@ -574,12 +569,8 @@ int launch_tile(const XmcConvDesc& d, const TileCfg& t, hipStream_t st) {
     size_t lds = (size_t)((maxpatch * pstride + 15) & ~15) + 2 * (size_t)BN * pstride;
     size_t ep = (size_t)128 * (BN + 4) * 4;
     if (ep > lds) lds = ep;
-    if (lds > 160 * 1024) return XMC_ESHAPE;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_kernel<BN, WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    if (lds > XMC_MAX_DYN_LDS) return XMC_ESHAPE;
+    XMC_ALLOW_BIG_LDS((tile_kernel<BN, WM, WN>));
     dim3 grid((unsigned)(d.N * t.tiles_y * t.tiles_x), (unsigned)(d.CDw / BN), (unsigned)d.nclass);
     hipLaunchKernelGGL((tile_kernel<BN, WM, WN>), grid, dim3(256), lds, st, d, t);
     xmc_note_kernel("tile_kernel<%d, %d, %d>", BN, WM, WN);

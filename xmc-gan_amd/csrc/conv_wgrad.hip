@@ -124,23 +124,26 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const XmcConvDesc d, float* 
         __syncthreads();
         if (p0 + KP < p_end) load_tiles(p0 + KP);
         if constexpr (DT == XMC_BF16) {
-          // lane 4q+pp of each 16-lane group addresses row (8*fg + q [+4]), columns base + 4*pp .. +3
+          // lane 4q+pp of each 16-lane group addresses pixel row (4*fg + q [+16]), columns base + 4*pp .. +3.  (Any assignment
+          // of the 32 k-values of a step to lane groups is valid as long as both operands use it.  Rows 8*fg + q would put
+          // lane groups 0 and 1 -- which ds_read_b64_tr_b16 serves in the same LDS cycle -- 8 rows = 576 dwords apart, i.e.
+          // on the same banks: a 2-way conflict on every read.  With 4*fg + q the 32 lanes cover rows 0..7 = 8 x 8 dwords.)
           const int q = fr >> 2, pp = fr & 3;
 #pragma unroll
           for (int ks = 0; ks < KP / 32; ++ks) {
             bf16x8 af[TM], bfr[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                const __bf16* base = &s_dy[(ks * 32 + 8 * fg + q) * LDO + wm * WTM + i * 16 + 4 * pp];
+                const __bf16* base = &s_dy[(ks * 32 + 4 * fg + q) * LDO + wm * WTM + i * 16 + 4 * pp];
                 bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(base));
-                bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(base + 4 * LDO));
+                bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(base + 16 * LDO));
                 af[i] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const __bf16* base = &s_x[(ks * 32 + 8 * fg + q) * LDI + wn * WTN + j * 16 + 4 * pp];
+                const __bf16* base = &s_x[(ks * 32 + 4 * fg + q) * LDI + wn * WTN + j * 16 + 4 * pp];
                 bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(base));
-                bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(base + 4 * LDI));
+                bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(base + 16 * LDI));
                 bfr[j] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             }
 #pragma unroll
@@ -222,6 +225,7 @@ int dispatch(const XmcConvDesc& d, float* dwp, float* dbias, hipStream_t st) {
 }  // namespace
 
 int xmc_conv_wgrad_tile_try(const XmcConvDesc* d, float* dwp, float* dbias, void* stream);   // conv_wgrad_tile.hip
+int xmc_conv_wgrad_row_try(const XmcConvDesc* d, float* dwp, float* dbias, void* stream);    // conv_wgrad_row.hip
 
 extern "C" int xmc_conv_wgrad(const XmcConvDesc* d, float* dwp, void* stream) { return xmc_conv_wgrad_bias(d, dwp, nullptr, stream); }
 
@@ -236,6 +240,8 @@ extern "C" int xmc_conv_wgrad_bias(const XmcConvDesc* d, float* dwp, float* dbia
     if (d->src_shift < 0 || d->src_shift > 1 || d->SA < 1) return XMC_ESHAPE;
     {
         int rc = xmc_conv_wgrad_tile_try(d, dwp, dbias, stream);     // all-taps-per-tile kernel for the few-channel layers
+        if (rc != 1) return rc;
+        rc = xmc_conv_wgrad_row_try(d, dwp, dbias, stream);          // one kernel row of taps per workgroup for the wide layers
         if (rc != 1) return rc;
     }
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);

@@ -111,18 +111,20 @@ __global__ __launch_bounds__(NT) void wgrad_tile_kernel(const XmcConvDesc d, flo
 
         // K loop: one tile row (32 pixels) per step
         for (int r = 0; r < TH; ++r) {
-            // A' fragment: dy^T [co = cb*16 + lane&15][pix = r*32 + 8*fg + j]
-            const unsigned char* ab = ydy + (size_t)(r * TW + 8 * fg + q) * YS + (cb * 16 + 4 * pp4) * 2;
+            // A' fragment: dy^T [co = cb*16 + lane&15][pix = r*32 + 4*fg + j (+16)]: the 32 lanes one tr16 read serves together
+            // address 8 consecutive pixel rows, which the 96/160-byte strides spread over distinct banks (rows 8*fg + j would
+            // put lane groups 0 and 1 on the same banks)
+            const unsigned char* ab = ydy + (size_t)(r * TW + 4 * fg + q) * YS + (cb * 16 + 4 * pp4) * 2;
             bf16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(ab));
-            bf16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(ab + 4 * YS));
+            bf16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(ab + 16 * YS));
             const bf16x8 af = bf16x8{alo[0], alo[1], alo[2], alo[3], ahi[0], ahi[1], ahi[2], ahi[3]};
 #pragma unroll
             for (int j = 0; j < MAXI; ++j) {
                 const int item = slice + j * NS;
                 if (item < nitems) {                          // wave-uniform
-                    const unsigned char* bb = xp + (r * PW + 8 * fg + q) * XS + itoff[j] + (4 * pp4) * 2;
+                    const unsigned char* bb = xp + (r * PW + 4 * fg + q) * XS + itoff[j] + (4 * pp4) * 2;
                     bf16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(bb));
-                    bf16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(bb + 4 * XS));
+                    bf16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(bb + 16 * XS));
                     const bf16x8 bf = bf16x8{blo[0], blo[1], blo[2], blo[3], bhi[0], bhi[1], bhi[2], bhi[3]};
                     acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, acc[j], 0, 0, 0);
                 }
@@ -159,12 +161,8 @@ template <int NCO, int NCI, int NT = 256>
 int launch_wt(const XmcConvDesc& d, float* dwp, float* dbias, const WTCfg& t, hipStream_t st) {
     constexpr int YS = NCO * 32 + 32, XS = NCI * 32 + 32;
     size_t lds = (size_t)TH * TW * YS + (size_t)t.PH * t.PW * XS;
-    if (lds > 160 * 1024) return 1;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_tile_kernel<NCO, NCI, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    if (lds > XMC_MAX_DYN_LDS) return 1;
+    XMC_ALLOW_BIG_LDS((wgrad_tile_kernel<NCO, NCI, NT>));
     int per_cu = (int)(160 * 1024 / lds);
     if (per_cu > 2) per_cu = 2;
     int gx = 256 * per_cu;
