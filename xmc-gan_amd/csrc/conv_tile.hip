@@ -25,6 +25,7 @@ struct TileCfg {
     int tiles_y, tiles_x;        // tiles per image
     int PH[XMC_MAX_CLASSES], PW[XMC_MAX_CLASSES];        // patch size per class
     int dh0[XMC_MAX_CLASSES], dw0[XMC_MAX_CLASSES];      // min tap offsets per class
+    int PHu, PWu, dh0u, dw0u;    // union of the classes' patches (one staged patch serves all classes)
     int slab;                    // channels per slab (32 or 64)
     const float* pro[4];         // optional prologue params g0,b0,g1,b1 : f32 [N][CS]; pro[0]==nullptr -> none
 };
@@ -241,7 +242,9 @@ __global__ __launch_bounds__(256) void tile_kernel(const XmcConvDesc d, const Ti
 // Two barriers per tile, both reached by all 8 waves.  The MFMA roles are swapped (A = weight rows, B = pixels), so a lane's
 // accumulators are CONSECUTIVE output channels of ONE pixel (weight rows are permuted while they are copied to LDS) and the
 // epilogue runs straight from registers with 16-byte stores.  Tap loop fully unrolled when NTAPS > 0.
-template <int BN, int SLAB, int NTAPS>
+// MC > 1: the MC output-parity classes of a stride-2 data gradient / fused upsample-conv are done by ONE workgroup from one
+// staged patch (the union of their halos) instead of MC launches that each stage the same pixels: the source is read once.
+template <int BN, int SLAB, int NTAPS, int MC>
 __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const TileCfg t, int ntiles) {
     constexpr int NS = 256;                      // threads per role
     constexpr int TM = 4, TN = BN / 16;
@@ -256,14 +259,16 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
     const bool stager = wave >= 4;
     const int rt = tid & (NS - 1);               // thread index within the role
     const int wm = wave & 3;
-    const int cls = blockIdx.z;
+    const int cls = MC > 1 ? 0 : blockIdx.z;
     const int n0 = blockIdx.y * BN;
     const int tpi = t.tiles_y * t.tiles_x;
-    const int PH = t.PH[cls], PW = t.PW[cls], dh0 = t.dh0[cls], dw0 = t.dw0[cls];
-    __shared__ int s_toff[XMC_MAX_TAPS];
+    const int PH = MC > 1 ? t.PHu : t.PH[cls], PW = MC > 1 ? t.PWu : t.PW[cls];
+    const int dh0 = MC > 1 ? t.dh0u : t.dh0[cls], dw0 = MC > 1 ? t.dw0u : t.dw0[cls];
+    __shared__ int s_toff[XMC_MAX_TAPS];          // [class * ntaps + tap]
     if (tid < XMC_MAX_TAPS) {
-        const int tt = tid < d.ntaps ? tid : 0;
-        s_toff[tid] = ((d.dh[cls][tt] - dh0) * PW + (d.dw[cls][tt] - dw0)) * pstride;
+        const int sl = tid < MC * d.ntaps ? tid : 0;
+        const int c = MC > 1 ? sl / d.ntaps : cls, tt = MC > 1 ? sl % d.ntaps : sl;
+        s_toff[tid] = ((d.dh[c][tt] - dh0) * PW + (d.dw[c][tt] - dw0)) * pstride;
     }
     const int cs_units = d.CS / 8;
     unsigned char* patch = smem;
@@ -273,12 +278,12 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
     const u32x4* __restrict__ w16 = reinterpret_cast<const u32x4*>(d.wpk);
 
     // physical weight row (n-block j, row q) holds logical output channel (q/4)*(BN/4) + j*4 + q%4
-    for (int id = tid; id < d.ntaps * BN * cps; id += 512) {
-        const int ch = id % cps, prow = (id / cps) % BN, tap = id / (cps * BN);
+    for (int id = tid; id < MC * d.ntaps * BN * cps; id += 512) {
+        const int ch = id % cps, prow = (id / cps) % BN, tap = id / (cps * BN);          // tap = slice index c * ntaps + tap
         const int j = prow >> 4, q = prow & 15;
         const int lrow = (q >> 2) * (BN / 4) + j * 4 + (q & 3);
         *reinterpret_cast<u32x4*>(wall + (tap * BN + prow) * pstride + ch * 16) =
-            w16[((size_t)d.wi[cls][tap] * d.CDw + n0 + lrow) * cs_units + ch];
+            w16[((size_t)d.wi[MC > 1 ? tap / d.ntaps : cls][MC > 1 ? tap % d.ntaps : tap] * d.CDw + n0 + lrow) * cs_units + ch];
     }
     const int tile0 = blockIdx.x, tstep = gridDim.x;
 
@@ -383,7 +388,6 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
             roff[i] = (ty * d.MW + tx) * cd8 + fc * UPL;          // same pixel in the [N,MH,MW,CD] grid (res_mode 1)
         }
         const int bbyte = fr * pstride + fc * 16;
-        const int dph = d.dph[cls], dpw = d.dpw[cls];
         const int ch0 = n0 + fc * (BN / 4);
         const float alpha = d.alpha_dev ? *d.alpha_dev : 1.f;
         float bias8[UPL][8];
@@ -396,15 +400,19 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
                           (d.act == XMC_ACT_NONE || d.act == XMC_ACT_LRELU);
         const float slope = d.act == XMC_ACT_LRELU ? XMC_LRELU : 1.f;
         __syncthreads();                          // weights + first patch staged
-        int toffr[NTAPS > 0 ? NTAPS : 1];
+        int toffr[NTAPS > 0 ? MC * NTAPS : 1];
         if constexpr (NTAPS > 0) {
 #pragma unroll
-            for (int k = 0; k < NTAPS; ++k) toffr[k] = __builtin_amdgcn_readfirstlane(s_toff[k]);
+            for (int k = 0; k < MC * NTAPS; ++k) toffr[k] = __builtin_amdgcn_readfirstlane(s_toff[k]);
         }
         for (int tile = tile0; tile < ntiles; tile += tstep) {
             const int img = tile / tpi, trem = tile - img * tpi;
             const int a0 = (trem / t.tiles_x) * t.TH, b0 = (trem % t.tiles_x) * t.TW;
             __syncthreads();                      // B1: patch of this tile is in LDS
+#pragma unroll
+          for (int mc = 0; mc < MC; ++mc) {
+            const int ccls = MC > 1 ? mc : cls;
+            const int dph = d.dph[ccls], dpw = d.dpw[ccls];
             f32x4 acc[TM][TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -435,8 +443,8 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
                 u32x4 fr_[2][G];                 // [parity][0..TM) pixel fragments, [TM..G) weight fragments
                 auto rd = [&](int st, int g) -> u32x4 {
                     const int tap = st / S, sub = st % S;
-                    if (g < TM) return *reinterpret_cast<const u32x4*>(patch + toffr[tap] + sub * 64 + abyte[g]);
-                    return *reinterpret_cast<const u32x4*>(wall + tap * BN * pstride + bbyte + sub * 64 + (g - TM) * 16 * pstride);
+                    if (g < TM) return *reinterpret_cast<const u32x4*>(patch + toffr[mc * NTAPS + tap] + sub * 64 + abyte[g]);
+                    return *reinterpret_cast<const u32x4*>(wall + (mc * NTAPS + tap) * BN * pstride + bbyte + sub * 64 + (g - TM) * 16 * pstride);
                 };
                 // read order: p0, w0, p1, w1, ... so that the first MFMAs of the next step find their operands first
                 auto gslot = [&](int k) -> int { return (k < 2 * (TM < TN ? TM : TN)) ? ((k & 1) ? TM + k / 2 : k / 2) : (TM >= TN ? k - TN : k); };
@@ -468,7 +476,7 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
                     if (step + 1 < nsteps) mma(pf[1], wf[1]);
                 }
             }
-            __syncthreads();                      // B2: patch may be overwritten
+            if (mc == MC - 1) __syncthreads();    // B2: patch may be overwritten
             // epilogue from registers: acc[i][j][r] = pixel (m-block i, fr), channel ch0 + j*4 + r
             const int dbase = (((img * d.DH + a0 * d.DA + dph) * d.DW) + b0 * d.DA + dpw) * cd8 + (n0 >> 3);
             const int rbase = ((img * d.MH + a0) * d.MW + b0) * cd8 + (n0 >> 3);
@@ -526,6 +534,7 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
                         else epilogue_tail<XMC_F32>(d, idx8, ridx8, v);
                     }
             }
+          }
         }
     }
 }
@@ -545,11 +554,31 @@ int launch_ptile(const XmcConvDesc& d, const TileCfg& t, hipStream_t st) {
     if (gx < 1) gx = 1;
     if (gx > ntiles) gx = ntiles;
     dim3 grid((unsigned)gx, (unsigned)(d.CDw / BN), (unsigned)d.nclass);
+    // all 4 output-parity classes from one staged patch when their 16 weight slices fit beside it
+    if (d.nclass == 4 && d.ntaps == 4 && !t.pro[0] && t.PHu * t.PWu <= 384) {
+        const size_t ldsm = (size_t)((t.PHu * t.PWu * pstride + 15) & ~15) + (size_t)16 * BN * pstride;
+        static const bool no_merge = getenv("XMC_NO_CLASS_MERGE") != nullptr;
+        if (ldsm <= XMC_MAX_DYN_LDS && !no_merge) {
+            int gm = 256 / (int)(d.CDw / BN);
+            if (gm > ntiles) gm = ntiles;
+            dim3 gridm((unsigned)gm, (unsigned)(d.CDw / BN), 1);
+            if (t.slab == 64) {
+                XMC_ALLOW_BIG_LDS((ptile3_kernel<BN, 64, 4, 4>));
+                hipLaunchKernelGGL((ptile3_kernel<BN, 64, 4, 4>), gridm, dim3(512), ldsm, st, d, t, ntiles);
+            } else {
+                XMC_ALLOW_BIG_LDS((ptile3_kernel<BN, 32, 4, 4>));
+                hipLaunchKernelGGL((ptile3_kernel<BN, 32, 4, 4>), gridm, dim3(512), ldsm, st, d, t, ntiles);
+            }
+            xmc_note_kernel("ptile3_kernel<%d, %d, 4, 4>", BN, t.slab);
+            XMC_LAUNCH_CHECK();
+            return 0;
+        }
+    }
 #define XMC_PT3(SL, NTP)                                                                                                      \
     do {                                                                                                                      \
-        XMC_ALLOW_BIG_LDS((ptile3_kernel<BN, SL, NTP>));                                                                      \
-        hipLaunchKernelGGL((ptile3_kernel<BN, SL, NTP>), grid, dim3(512), lds, st, d, t, ntiles);                             \
-        xmc_note_kernel("ptile3_kernel<%d, %d, %d>", BN, SL, NTP);                                                            \
+        XMC_ALLOW_BIG_LDS((ptile3_kernel<BN, SL, NTP, 1>));                                                                   \
+        hipLaunchKernelGGL((ptile3_kernel<BN, SL, NTP, 1>), grid, dim3(512), lds, st, d, t, ntiles);                          \
+        xmc_note_kernel("ptile3_kernel<%d, %d, %d, 1>", BN, SL, NTP);                                                         \
     } while (0)
     if (t.slab == 64) {
         if (d.ntaps == 9) XMC_PT3(64, 9); else if (d.ntaps == 4) XMC_PT3(64, 4); else XMC_PT3(64, 0);
@@ -602,6 +631,15 @@ static int tile_plan(const XmcConvDesc* d, TileCfg* t) {
         t->dh0[z] = hmin; t->dw0[z] = wmin;
         t->PH[z] = TH + (hmax - hmin); t->PW[z] = TW + (wmax - wmin);
         if (t->PH[z] * t->PW[z] > 12 * (256 / (t->slab / 8))) return 0;   // staging registers (PIT)
+    }
+    {
+        int hmin = 127, hmax = -128, wmin = 127, wmax = -128;
+        for (int z = 0; z < d->nclass; ++z) {
+            hmin = t->dh0[z] < hmin ? t->dh0[z] : hmin; wmin = t->dw0[z] < wmin ? t->dw0[z] : wmin;
+            const int he = t->dh0[z] + t->PH[z] - TH, we = t->dw0[z] + t->PW[z] - TW;
+            hmax = he > hmax ? he : hmax; wmax = we > wmax ? we : wmax;
+        }
+        t->dh0u = hmin; t->dw0u = wmin; t->PHu = TH + (hmax - hmin); t->PWu = TW + (wmax - wmin);
     }
     for (int k = 0; k < 4; ++k) t->pro[k] = nullptr;
     return 1;
