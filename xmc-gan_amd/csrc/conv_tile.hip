@@ -17,6 +17,7 @@
 // to the patch while it is staged, so that tensor never makes a round trip through HBM.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -539,6 +540,236 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
     }
 }
 
+// Wide layers (Cin % 64 == 0, Cout % 128 == 0, 3x3-like tap sets, one class): the same halo-patch idea with the weights
+// STREAMED.  The gather kernel (conv_igemm.hip) pulls 48 KB through the CU's vector-memory path per 128 MFMAs of a wave
+// pair; measured with s_memtime, a CU accepts ~22 B/clk from L2, less than half of what that needs at the MFMA rate, so it
+// tops out near 700 TFLOP/s whatever its schedule (with loads AND LDS stores compiled out it reaches 970).  Here a workgroup
+// owns 256 pixels x 128 output channels; per 64-channel slab the patch is staged ONCE for all taps and only the weights
+// of each (slab, tap) stage -- 16 KB -- are streamed: ~21 KB per 128 MFMAs.
+//   waves 4-7 ("stage"):   weights of stage g+3 global -> registers, stage g+2 registers -> LDS ring (3 deep); the next slab's
+//                          patch is loaded into registers during a slab and written at the slab boundary;
+//   waves 0-3 ("compute"): 64 pixels x 128 channels each: 12 fragment reads + 32 MFMAs per K sub-step, the reads of the next
+//                          sub-step dealt out between the MFMAs (pinned), first fragments of the next stage prefetched
+//                          across the barrier;  epilogue from registers (lane = 32 consecutive channels of 4 pixels).
+// One barrier per stage, one more at a slab boundary.
+template <int NTAPS>
+__global__ __launch_bounds__(512) void wtile_kernel(const XmcConvDesc d, const TileCfg t) {
+    constexpr int BN = 128, TM = 4, TN = 8, NS = 256;
+    constexpr int cps = 8, pstride = 160, PIT = 12;
+    constexpr int WSTG = BN * pstride;           // bytes of one weight stage
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int s_toff[XMC_MAX_TAPS], s_twi[XMC_MAX_TAPS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.y * BN;
+    const int tpi = t.tiles_y * t.tiles_x;
+    const int PH = t.PH[0], PW = t.PW[0], dh0 = t.dh0[0], dw0 = t.dw0[0];
+    if (tid < XMC_MAX_TAPS) {
+        const int tt = tid < d.ntaps ? tid : 0;
+        s_toff[tid] = ((d.dh[0][tt] - dh0) * PW + (d.dw[0][tt] - dw0)) * pstride;
+        s_twi[tid] = d.wi[0][tt];
+    }
+    const int cs_units = d.CS / 8;
+    const int nslab = d.CS / 64;
+    const int G = nslab * d.ntaps;               // stages: slab-major, taps inside
+    unsigned char* patch = smem;
+    const int patch_bytes = (PH * PW * pstride + 15) & ~15;
+    unsigned char* wring = smem + patch_bytes;   // [3][BN][pstride]
+    const int tile = blockIdx.x;
+    const int img = tile / tpi, trem = tile - img * tpi;
+    const int a0 = (trem / t.tiles_x) * t.TH, b0 = (trem % t.tiles_x) * t.TW;
+    __syncthreads();
+
+    if (wave >= 4) {
+        // ================================================================================================ staging role
+        const int rt = tid - NS;
+        const int unit = rt & 7, r32 = rt >> 3;   // weights: 8 units per row, rows r32 + 32*i; patch: pixels r32 + 32*it
+        const u32x4* __restrict__ src16 = reinterpret_cast<const u32x4*>(d.src);
+        const u32x4* __restrict__ w16 = reinterpret_cast<const u32x4*>(d.wpk);
+        int psrc[PIT];
+        unsigned halo[PIT], inpatch = 0;
+#pragma unroll
+        for (int it = 0; it < PIT; ++it) {
+            const int pp = r32 + it * 32;
+            const int py = pp / PW, px = pp - py * PW;
+            const bool in = pp < PH * PW;
+            inpatch |= in ? (1u << it) : 0u;
+            psrc[it] = in ? ((dh0 + py) * d.SW + (dw0 + px)) * cs_units + unit : 0;
+            halo[it] = !in ? 0u : ((py < -dh0 ? 1u : 0u) | (py >= t.TH - dh0 ? 2u : 0u) | (px < -dw0 ? 4u : 0u) | (px >= t.TW - dw0 ? 8u : 0u));
+        }
+        const int base = ((img * d.SH + a0) * d.SW + b0) * cs_units;
+        const unsigned border = (a0 + dh0 < 0 ? 1u : 0u) | (a0 + PH + dh0 > d.SH ? 2u : 0u) | (b0 + dw0 < 0 ? 4u : 0u) | (b0 + PW + dw0 > d.SW ? 8u : 0u);
+        unsigned okmask = 0;
+#pragma unroll
+        for (int it = 0; it < PIT; ++it) okmask |= ((halo[it] & border) == 0) ? (1u << it) : 0u;
+        okmask &= inpatch;
+        int wrow[4], wdst[4];                     // weight rows of this thread: source row offset (units), LDS byte offset
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int prow = r32 + 32 * i;        // physical LDS row (n-block j, row q) <- logical channel (q/4)*32 + j*4 + q%4
+            const int j = prow >> 4, q = prow & 15;
+            const int lrow = (q >> 2) * (BN / 4) + j * 4 + (q & 3);
+            wrow[i] = (n0 + lrow) * cs_units + unit;
+            wdst[i] = prow * pstride + unit * 16;
+        }
+        u32x4 pv[PIT], wv[4];
+        auto issue_patch = [&](int sl) {
+#pragma unroll
+            for (int it = 0; it < PIT; ++it)
+                pv[it] = src16[(unsigned)(base + (((okmask >> it) & 1) ? psrc[it] + sl * 8 : 0))];
+        };
+        auto commit_patch = [&]() {
+#pragma unroll
+            for (int it = 0; it < PIT; ++it) {
+                u32x4 v = pv[it];
+                if (!((okmask >> it) & 1)) v = u32x4{0, 0, 0, 0};
+                if ((inpatch >> it) & 1) *reinterpret_cast<u32x4*>(patch + (r32 + it * 32) * pstride + unit * 16) = v;
+            }
+        };
+        auto issue_w = [&](int g) {
+            const int sl = g / d.ntaps, tap = g - sl * d.ntaps;
+            const int wb = s_twi[tap] * d.CDw * cs_units + sl * 8;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wv[i] = w16[(unsigned)(wb + wrow[i])];
+        };
+        auto commit_w = [&](int g) {
+            unsigned char* wb = wring + (g % 3) * WSTG;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(wb + wdst[i]) = wv[i];
+        };
+        issue_patch(0); commit_patch();
+        issue_w(0); commit_w(0);
+        if (G > 1) { issue_w(1); commit_w(1); }
+        if (G > 2) issue_w(2);
+        if (nslab > 1) issue_patch(1);
+        __syncthreads();                          // patch of slab 0 and weight stages 0, 1 are in LDS
+        for (int sl = 0, g = 0; sl < nslab; ++sl) {
+#pragma unroll
+            for (int tap = 0; tap < NTAPS; ++tap, ++g) {
+                if (g + 2 < G) commit_w(g + 2);   // loaded during stage g-1
+                const bool boundary = tap == NTAPS - 1 && sl + 1 < nslab;
+                if (!boundary && g + 3 < G) issue_w(g + 3);
+                __syncthreads();                  // end of stage g
+                if (boundary) {
+                    commit_patch();               // the compute waves are done with slab sl; nothing younger than these loads is
+                    __syncthreads();              // in flight, so the wait in front of the LDS stores is for them alone
+                    if (g + 3 < G) issue_w(g + 3);
+                    if (sl + 2 < nslab) issue_patch(sl + 2);
+                }
+            }
+        }
+    } else {
+        // ================================================================================================ compute role
+        const int wm = wave;
+        const int fr = lane & 15, fc = lane >> 4;
+        const int cd8 = d.CD / 8;
+        int abyte[TM], eoff[TM], roff[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int ml = wm * 64 + i * 16 + fr;
+            const int ty = ml >> t.log2TW, tx = ml & (t.TW - 1);
+            abyte[i] = (ty * PW + tx) * pstride + fc * 16;
+            eoff[i] = ((ty * d.DA) * d.DW + tx * d.DA) * cd8 + fc * 4;
+            roff[i] = (ty * d.MW + tx) * cd8 + fc * 4;
+        }
+        const int bbyte = fr * pstride + fc * 16;
+        f32x4 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        u32x4 F[2][TM + TN];                      // [set][pixel fragments 0..3, weight fragments 4..11]
+        auto rd = [&](const unsigned char* pa, const unsigned char* wb, int sub, int gi) -> u32x4 {
+            return gi < TM ? *reinterpret_cast<const u32x4*>(pa + sub * 64 + abyte[gi])
+                           : *reinterpret_cast<const u32x4*>(wb + bbyte + sub * 64 + (gi - TM) * 16 * pstride);
+        };
+        // read order: p0 w0 p1 w1 p2 w2 p3 w3 w4 w5 w6 w7
+        auto gslot = [](int k) -> int { return k < 8 ? ((k & 1) ? TM + k / 2 : k / 2) : k; };
+        __syncthreads();                          // patch of slab 0 and weight stages 0, 1 are in LDS
+        {
+            const unsigned char* pa0 = patch + s_toff[0];
+#pragma unroll
+            for (int k = 0; k < TM + TN; ++k) F[0][gslot(k)] = rd(pa0, wring, 0, gslot(k));
+        }
+        int toffr[NTAPS];                         // tap -> patch byte offset, in scalar registers
+#pragma unroll
+        for (int k = 0; k < NTAPS; ++k) toffr[k] = __builtin_amdgcn_readfirstlane(s_toff[k]);
+        // one stage: MFMAs of both K sub-steps; PF: prefetch the next stage's first fragments during the second sub-step
+        auto stage = [&](const unsigned char* pa, const unsigned char* wb, const unsigned char* npa, const unsigned char* nwb, auto pf) {
+            constexpr bool PF = decltype(pf)::value;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+                for (int k = 0; k < TM + TN; ++k) {
+                    if (sub == 0) F[1][gslot(k)] = rd(pa, wb, 1, gslot(k));
+                    else if (PF) F[0][gslot(k)] = rd(npa, nwb, 0, gslot(k));
+#pragma unroll
+                    for (int mm = k * (TM * TN) / (TM + TN); mm < (k + 1) * (TM * TN) / (TM + TN); ++mm) {
+                        const int mi = mm % TM, mj = mm / TM;
+                        acc[mi][mj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, F[sub][TM + mj]),
+                                                                               __builtin_bit_cast(bf16x8, F[sub][mi]), acc[mi][mj], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        };
+        for (int sl = 0, g = 0; sl < nslab; ++sl) {
+#pragma unroll
+            for (int tap = 0; tap < NTAPS; ++tap, ++g) {
+                const unsigned char* pa = patch + toffr[tap];
+                const unsigned char* wb = wring + (g % 3) * WSTG;
+                const unsigned char* npa = patch + toffr[tap + 1 < NTAPS ? tap + 1 : 0];
+                const unsigned char* nwb = wring + ((g + 1) % 3) * WSTG;
+                if (tap + 1 < NTAPS) stage(pa, wb, npa, nwb, std::true_type{});
+                else stage(pa, wb, npa, nwb, std::false_type{});      // next stage: new slab (patch not there yet) or none
+                __syncthreads();                  // end of stage g
+                if (tap == NTAPS - 1 && sl + 1 < nslab) {
+                    __syncthreads();              // the staging waves have written the next slab's patch
+#pragma unroll
+                    for (int k = 0; k < TM + TN; ++k) F[0][gslot(k)] = rd(npa, nwb, 0, gslot(k));
+                }
+            }
+        }
+
+        // ---- epilogue from registers: acc[i][j][q] = pixel (m-block i, fr), channel n0 + fc*32 + j*4 + q
+        const int ch0 = n0 + fc * (BN / 4);
+        const float alpha = d.alpha_dev ? *d.alpha_dev : 1.f;
+        const int dbase = (((img * d.DH + a0 * d.DA + d.dph[0]) * d.DW) + b0 * d.DA + d.dpw[0]) * cd8 + (n0 >> 3);
+        const int rbase = ((img * d.MH + a0) * d.MW + b0) * cd8 + (n0 >> 3);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (ch0 + u * 8 >= d.CD) continue;
+            float b8[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) b8[c] = d.bias ? d.bias[ch0 + u * 8 + c] : 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const size_t idx8 = (size_t)(dbase + eoff[i] + u);
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { v[q] = acc[i][2 * u][q] + b8[q]; v[4 + q] = acc[i][2 * u + 1][q] + b8[4 + q]; }
+                if (d.act == XMC_ACT_LRELU) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] = lrelu_f(v[q]);
+                } else if (d.act == XMC_ACT_RELU) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
+                } else if (d.act == XMC_ACT_TANH) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] = tanhf(v[q]);
+                }
+                if (d.alpha_dev) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] *= alpha;
+                }
+                const size_t ridx8 = d.res_mode ? (size_t)(rbase + roff[i] + u) : idx8;
+                if (d.out_dtype == XMC_BF16) epilogue_tail<XMC_BF16>(d, idx8, ridx8, v);
+                else epilogue_tail<XMC_F32>(d, idx8, ridx8, v);
+            }
+        }
+    }
+}
+
 template <int BN>
 int launch_ptile(const XmcConvDesc& d, const TileCfg& t, hipStream_t st) {
     int maxpatch = 0;
@@ -607,6 +838,18 @@ int launch_tile(const XmcConvDesc& d, const TileCfg& t, hipStream_t st) {
     return 0;
 }
 
+int launch_wtile(const XmcConvDesc& d, const TileCfg& t, hipStream_t st) {
+    if (t.PH[0] * t.PW[0] > 384) return XMC_ESHAPE;
+    const size_t lds = (size_t)((t.PH[0] * t.PW[0] * 160 + 15) & ~15) + (size_t)3 * 128 * 160;
+    if (lds > XMC_MAX_DYN_LDS) return XMC_ESHAPE;
+    XMC_ALLOW_BIG_LDS(wtile_kernel<9>);
+    dim3 grid((unsigned)(d.N * t.tiles_y * t.tiles_x), (unsigned)(d.CDw / 128), 1);
+    hipLaunchKernelGGL(wtile_kernel<9>, grid, dim3(512), lds, st, d, t);
+    xmc_note_kernel("wtile_kernel<9>");
+    XMC_LAUNCH_CHECK();
+    return 0;
+}
+
 }  // namespace
 
 // Returns 1 if the descriptor is eligible for the halo-tile kernel (and fills cfg), 0 otherwise.
@@ -614,7 +857,9 @@ static int tile_plan(const XmcConvDesc* d, TileCfg* t) {
     if (d->dtype != XMC_BF16 || d->SA != 1 || d->src_shift != 0) return 0;
     if (d->CS % 32 != 0 || d->MW % 16 != 0) return 0;
     if (d->ntaps < 2) return 0;                       // 1x1: nothing to reuse, the gather kernel streams it
-    if (d->CDw > 64 && d->CS > 64) return 0;          // wide layers are MFMA-bound: 128x128 gather tiles win
+    static const bool no_wt = getenv("XMC_NO_WTILE2") != nullptr;
+    const bool wide = d->CDw > 64 && d->CS > 64;
+    if (wide && (no_wt || d->CDw % 128 != 0 || d->CS % 64 != 0 || d->nclass != 1 || d->ntaps != 9)) return 0;   // gather kernel
     int TW = d->MW >= 32 ? 32 : 16;
     int TH = 256 / TW;
     if (d->MH % TH != 0 || d->MW % TW != 0) return 0;
@@ -652,6 +897,11 @@ int xmc_conv_tile_try(const XmcConvDesc* d, const float* const* pro, void* strea
     if (pro) for (int k = 0; k < 4; ++k) t.pro[k] = pro[k];
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     int rc;
+    if (d->CDw > 64 && d->CS > 64) {                  // wide: weights streamed through an LDS ring
+        if (pro) return 1;
+        rc = launch_wtile(*d, t, st);
+        return rc == XMC_ESHAPE ? 1 : rc;
+    }
     static const bool no_pt = getenv("XMC_NO_PTILE") != nullptr;
     if (!no_pt && d->CS <= 64 && t.slab == d->CS && d->CDw <= 64) {          // persistent, weights resident
         rc = d->CDw == 64 ? launch_ptile<64>(*d, t, st) : launch_ptile<32>(*d, t, st);
