@@ -113,6 +113,11 @@ int xmc_pack_weight_upconv(const float* w, void* wpk, int Co, int Ci, int rows_p
 /* grad unpack: gw[co][ci][kh][kw] (+)= scale * dwp[kh*KW+kw][co][ci] (dwp rows padded to rows_pad, cols to cols_pad) */
 int xmc_unpack_wgrad(const float* dwp, float* gw, int Co, int Ci, int KH, int KW, int rows_pad, int cols_pad,
                      const float* scale_dev, const int32_t* row_perm, int accumulate, void* stream);
+/* same, and gb[c] = sum over the XMC_BIAS_REPLICAS rows of gb_replicas[r][c] (c < CD): the bias gradient xmc_conv_wgrad_bias
+ * accumulated, reduced in the same launch */
+int xmc_unpack_wgrad_bias(const float* dwp, float* gw, int Co, int Ci, int KH, int KW, int rows_pad, int cols_pad,
+                          const float* scale_dev, const int32_t* row_perm, int accumulate,
+                          const float* gb_replicas, float* gb, int CD, void* stream);
 
 /* ---- layout conversion at the module boundary (NetD.forward input df_gan.py:127, NetG output df_gan.py:101) -- */
 int xmc_nchw_to_nhwc8(const float* src /*[N,C,H,W] f32*/, void* dst /*[N,H,W,8]*/, int N, int C, int H, int W,

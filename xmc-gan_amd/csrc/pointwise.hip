@@ -444,9 +444,20 @@ __global__ void axpby_up_kernel(const void* a, const void* b, const float* alpha
 }
 
 __global__ void unpack_wgrad_kernel(const float* dwp, float* gw, int Co, int Ci, int KHW, int rows_pad, int cols_pad,
-                                    const float* scale_dev, const int32_t* row_perm, int accumulate) {
+                                    const float* scale_dev, const int32_t* row_perm, int accumulate,
+                                    const float* gb_rep, float* gb, int CDb) {
     const float scale = scale_dev ? *scale_dev : 1.f;
     const int64_t total = (int64_t)Co * Ci * KHW;
+    // bias gradient: sum of the XMC_BIAS_REPLICAS partial column sums the weight-gradient kernels accumulate into
+    // (packed channel order, like the rows of dwp); rides along instead of a separate reduction launch
+    if (gb_rep) {
+        for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < CDb; c += gridDim.x * blockDim.x) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int r = 0; r < XMC_BIAS_REPLICAS; ++r) sacc += gb_rep[r * CDb + c];
+            gb[c] = sacc;
+        }
+    }
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         int t = (int)(i % KHW);
         int64_t q = i / KHW;
@@ -668,7 +679,17 @@ extern "C" int xmc_unpack_wgrad(const float* dwp, float* gw, int Co, int Ci, int
     if (!dwp || !gw || rows_pad < Co || cols_pad < Ci) return XMC_EINVAL;
     int64_t total = (int64_t)Co * Ci * KH * KW;
     hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(nblocks(total)), dim3(NT), 0, ST(s), dwp, gw, Co, Ci, KH * KW, rows_pad, cols_pad,
-                       scale_dev, row_perm, accumulate);
+                       scale_dev, row_perm, accumulate, (const float*)nullptr, (float*)nullptr, 0);
+    XMC_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int xmc_unpack_wgrad_bias(const float* dwp, float* gw, int Co, int Ci, int KH, int KW, int rows_pad, int cols_pad,
+                                     const float* scale_dev, const int32_t* row_perm, int accumulate,
+                                     const float* gb_replicas, float* gb, int CD, void* s) {
+    if (!dwp || !gw || rows_pad < Co || cols_pad < Ci || !gb_replicas || !gb || CD < 1) return XMC_EINVAL;
+    int64_t total = (int64_t)Co * Ci * KH * KW;
+    hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(nblocks(total)), dim3(NT), 0, ST(s), dwp, gw, Co, Ci, KH * KW, rows_pad, cols_pad,
+                       scale_dev, row_perm, accumulate, gb_replicas, gb, CD);
     XMC_LAUNCH_CHECK();
     return 0;
 }

@@ -43,6 +43,7 @@ _SIGS = {
     "xmc_pack_weight_upconv": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "xmc_axpby_up": [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "xmc_unpack_wgrad": [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp],
+    "xmc_unpack_wgrad_bias": [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, i32, vp],
     "xmc_nchw_to_nhwc8": [vp, vp, i32, i32, i32, i32, i32, vp],
     "xmc_nhwc8_to_nchw": [vp, vp, i32, i32, i32, i32, i32, vp],
     "xmc_lrelu": [vp, vp, i64, f32, i32, vp],

@@ -342,6 +342,46 @@ def _conv_dgrad_raw(dy, w, geom, in_hw, in_dtype, mask=None, res=None, res_rows=
     return dx
 
 
+class _ZeroArena:
+    """Zero-filled f32 scratch for the weight-gradient kernels (packed dW accumulators, bias replicas), which accumulate with
+    atomics and need zeros.  One memset per iteration (`new_iteration()`) instead of one fill launch per buffer -- ~400 launches
+    per G+D iteration.  Sized by the previous iteration's demand; anything beyond falls back to torch.zeros."""
+
+    def __init__(self):
+        self.buf, self.off, self.need = {}, {}, {}
+
+    def new_iteration(self, device):
+        key = (device.type, device.index)
+        need = self.need.get(key, 0)
+        buf = self.buf.get(key)
+        if need and (buf is None or buf.numel() < need):
+            buf = self.buf[key] = torch.empty(int(need * 1.05) + 1024, dtype=torch.float32, device=device)
+        if buf is not None:
+            buf.zero_()
+        self.off[key], self.need[key] = 0, 0
+
+    def zeros(self, shape, device):
+        key = (device.type, device.index)
+        n = 1
+        for s_ in shape:
+            n *= s_
+        n4 = (n + 3) // 4 * 4                                    # keep 16-byte alignment
+        self.need[key] = self.need.get(key, 0) + n4
+        buf, off = self.buf.get(key), self.off.get(key, 0)
+        if buf is None or off + n4 > buf.numel() or key not in self.off:
+            return torch.zeros(shape, dtype=torch.float32, device=device)
+        self.off[key] = off + n4
+        return buf[off:off + n].view(shape)
+
+
+_arena = _ZeroArena()
+
+
+def new_iteration(device):
+    """Call once at the start of a training iteration (before any backward): re-zeroes the weight-gradient scratch arena."""
+    _arena.new_iteration(torch.device(device))
+
+
 def _conv_wgrad_raw(x, dy, geom, scale=None, up=False, want_bias=False):
     """gw [Co,Ci,k,k] f32 from x [N,H,W,cs_p], dy [N,OH,OW,cd_p] (and the bias gradient [cd_p] f32 from the same launch)."""
     _need_cuda(x, dy)
@@ -349,8 +389,8 @@ def _conv_wgrad_raw(x, dy, geom, scale=None, up=False, want_bias=False):
     _, OH, OW, CDy = dy.shape
     assert x.dtype == dy.dtype, (x.dtype, dy.dtype)
     rows = pad_to(CDy, 32)
-    dwp = torch.zeros((geom.k * geom.k, rows, CS), dtype=torch.float32, device=x.device)
-    gb = torch.zeros((16, CDy), dtype=torch.float32, device=x.device) if want_bias else None     # XMC_BIAS_REPLICAS
+    dwp = _arena.zeros((geom.k * geom.k, rows, CS), x.device)
+    gb = _arena.zeros((16, CDy), x.device) if want_bias else None     # XMC_BIAS_REPLICAS
     d = L.ConvDesc()
     d.src, d.dst = x.data_ptr(), dy.data_ptr()
     d.N, d.SH, d.SW, d.CS = N, H, W, CS
@@ -363,9 +403,14 @@ def _conv_wgrad_raw(x, dy, geom, scale=None, up=False, want_bias=False):
                      f"wgrad {x.dtype} N{N} {H}x{W} {geom.cin}->{geom.cout} k{geom.k}s{geom.s}"):
         L.check(L.load().xmc_conv_wgrad_bias(C.byref(d), _p(dwp), _p(gb), _st()), "xmc_conv_wgrad")
     gw = torch.empty((geom.cout, geom.cin, geom.k, geom.k), dtype=torch.float32, device=x.device)
+    if want_bias:
+        gbs = torch.empty(CDy, dtype=torch.float32, device=x.device)
+        L.call("xmc_unpack_wgrad_bias", _p(dwp), _p(gw), geom.cout, geom.cin, geom.k, geom.k, rows, CS, _p(scale),
+               _p(geom.perm_dev(x.device)), 0, _p(gb), _p(gbs), CDy, _st())
+        return gw, gbs
     L.call("xmc_unpack_wgrad", _p(dwp), _p(gw), geom.cout, geom.cin, geom.k, geom.k, rows, CS, _p(scale),
            _p(geom.perm_dev(x.device)), 0, _st())
-    return (gw, gb.sum(0)) if want_bias else gw
+    return gw
 
 
 # ------------------------------------------------------------------------------------------ conv / linear

@@ -122,6 +122,7 @@ def gan_iteration(netG, netD, optimizerG, optimizerD, imgs, sent_embs, words_emb
     opts = opts or StepOptions()
     T, E = cfg.TRAIN, cfg.TRAIN.ENCODER_LOSS
     batch_size = mask.size(0)
+    ops.new_iteration(imgs.device)                 # one memset for all weight-gradient scratch of this iteration
     gather = parallel.gather_rows if opts.gather_negatives else (lambda t: t)
     out = {}
 
