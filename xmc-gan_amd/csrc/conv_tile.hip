@@ -637,9 +637,25 @@ __global__ __launch_bounds__(512) void wtile_kernel(const XmcConvDesc d, const T
 #pragma unroll
             for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(wb + wdst[i]) = wv[i];
         };
-        issue_patch(0); commit_patch();
-        issue_w(0); commit_w(0);
-        if (G > 1) { issue_w(1); commit_w(1); }
+        {   // all loads of the prologue in flight together (one memory latency instead of three in a row)
+            u32x4 w0[4], w1[4];
+            issue_patch(0);
+            issue_w(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) w0[i] = wv[i];
+            if (G > 1) issue_w(1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) w1[i] = wv[i];
+            commit_patch();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wv[i] = w0[i];
+            commit_w(0);
+            if (G > 1) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) wv[i] = w1[i];
+                commit_w(1);
+            }
+        }
         if (G > 2) issue_w(2);
         if (nslab > 1) issue_patch(1);
         __syncthreads();                          // patch of slab 0 and weight stages 0, 1 are in LDS
