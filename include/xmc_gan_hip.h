@@ -144,6 +144,10 @@ int xmc_dot(const void* a, const void* b, float* out, int64_t n, int dtype, void
 /* g = alpha*dy*LeakyReLU'(ref) and dot += sum(dy*ref) in one pass: backward of `shortcut + gamma*residual` (df_gan.py:284)
  * into a residual branch ending in LeakyReLU (ref = its output) together with d(gamma); dot is f32[1], zeroed by the caller */
 int xmc_scale_mask_dot(const void* dy, const void* ref, const float* alpha_dev, void* g, float* dot, int64_t n, int dtype, void* stream);
+/* Backward of y = a + alpha*b (up == 0; N,H,W,C = shape of dy) or y = up2(a) + alpha*b (up == 1; N,H,W,C = shape of a, dy and
+ * b are [N,2H,2W,C]) in one pass: db = alpha*dy, da = 2x2 sum pool of dy (up only), dot += <dy,b>; dot is f32[1], zeroed by the caller */
+int xmc_axpby_bwd(const void* dy, const void* b, const float* alpha_dev, void* db, void* da, float* dot,
+                  int N, int H, int W, int C, int up, int dtype, void* stream);
 /* out[c] = sum over rows of x[r][c]         (bias gradients) ; out is f32 [C], zeroed by the caller */
 int xmc_colsum(const void* x, float* out, int64_t rows, int C, int dtype, void* stream);
 /* 2x2 average pool (F.avg_pool2d(x,2) df_gan.py:290) and its adjoint (nearest x2 upsample * scale) */

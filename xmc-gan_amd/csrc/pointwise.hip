@@ -443,6 +443,56 @@ __global__ void axpby_up_kernel(const void* a, const void* b, const float* alpha
     }
 }
 
+// Backward of y = up2(a) + alpha*b (and of y = a + alpha*b when up == 0) in one pass over dy and b:
+//   db = alpha * dy,   da = 2x2 sum pool of dy (up) / nothing (plain: da is dy itself),   dot += <dy, b>  (= d alpha)
+// instead of a scale pass, a pool pass and a dot pass (reads of dy: 3 -> 1).
+template <int DT>
+__global__ void axpby_bwd_kernel(const void* dy, const void* b, const float* alpha, void* db, void* da, float* dot,
+                                 int N, int H, int W, int C8, int up) {
+    const float al = *alpha;
+    float s = 0.f;
+    const int64_t total = (int64_t)N * H * W * C8;                  // low-resolution positions (x channel units)
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        if (!up) {
+            float u[8], v[8], o[8];
+            Vec8<DT>::load(dy, idx, u);
+            Vec8<DT>::load(b, idx, v);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { s += u[k] * v[k]; o[k] = al * u[k]; }
+            Vec8<DT>::store(db, idx, o);
+            continue;
+        }
+        const int cc = (int)(idx % C8);
+        int64_t p = idx / C8;
+        const int w = (int)(p % W); p /= W;
+        const int h = (int)(p % H);
+        const int n = (int)(p / H);
+        float sum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int64_t hi = ((((int64_t)n * 2 * H + 2 * h + i) * 2 * W) + 2 * w + j) * C8 + cc;
+                float u[8], v[8], o[8];
+                Vec8<DT>::load(dy, hi, u);
+                Vec8<DT>::load(b, hi, v);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { s += u[k] * v[k]; o[k] = al * u[k]; sum[k] += u[k]; }
+                Vec8<DT>::store(db, hi, o);
+            }
+        Vec8<DT>::store(da, idx, sum);
+    }
+    s = wave_sum(s);
+    __shared__ float part[NT / 64];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w_ = 0; w_ < NT / 64; ++w_) t += part[w_];
+        atomicAdd(dot, t);
+    }
+}
+
 __global__ void unpack_wgrad_kernel(const float* dwp, float* gw, int Co, int Ci, int KHW, int rows_pad, int cols_pad,
                                     const float* scale_dev, const int32_t* row_perm, int accumulate,
                                     const float* gb_rep, float* gb, int CDb) {
@@ -702,6 +752,17 @@ extern "C" int xmc_pack_weight_upconv(const float* w, void* wpk, int Co, int Ci,
     dim3 g(nblocks(total)), blk(NT);
     if (dtype == XMC_BF16) hipLaunchKernelGGL((pack_upconv_kernel<XMC_BF16>), g, blk, 0, ST(s), w, wpk, Co, Ci, rows_pad, cols_pad, transpose);
     else if (dtype == XMC_F32) hipLaunchKernelGGL((pack_upconv_kernel<XMC_F32>), g, blk, 0, ST(s), w, wpk, Co, Ci, rows_pad, cols_pad, transpose);
+    else return XMC_EINVAL;
+    XMC_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int xmc_axpby_bwd(const void* dy, const void* b, const float* alpha, void* db, void* da, float* dot,
+                             int N, int H, int W, int C, int up, int dtype, void* s) {
+    if (!dy || !b || !alpha || !db || !dot || C % 8 || (up && !da)) return XMC_EINVAL;
+    int64_t total = (int64_t)N * H * W * (C / 8);
+    dim3 g(nblocks(total, NT, 2048)), blk(NT);
+    if (dtype == XMC_BF16) hipLaunchKernelGGL((axpby_bwd_kernel<XMC_BF16>), g, blk, 0, ST(s), dy, b, alpha, db, da, dot, N, H, W, C / 8, up);
+    else if (dtype == XMC_F32) hipLaunchKernelGGL((axpby_bwd_kernel<XMC_F32>), g, blk, 0, ST(s), dy, b, alpha, db, da, dot, N, H, W, C / 8, up);
     else return XMC_EINVAL;
     XMC_LAUNCH_CHECK();
     return 0;

@@ -583,6 +583,19 @@ class UpConvFn(torch.autograd.Function):
         return dx, dw, db, None
 
 
+def _axpby_bwd_fused(dy, b, alpha, up):
+    """(da, db, dalpha) of a + alpha*b / up2(a) + alpha*b from one pass over dy and b (not differentiable again)."""
+    dy = dy.contiguous()
+    N, OH, OW, Cc = dy.shape
+    H, W = (OH // 2, OW // 2) if up else (OH, OW)
+    al = alpha.detach().reshape(-1).float()
+    db = torch.empty_like(dy)
+    da = torch.empty((N, H, W, Cc), dtype=dy.dtype, device=dy.device) if up else None
+    dot = torch.zeros(1, dtype=torch.float32, device=dy.device)
+    L.call("xmc_axpby_bwd", _p(dy), _p(b), _p(al), _p(db), _p(da), _p(dot), N, H, W, Cc, 1 if up else 0, _code(dy.dtype), _st())
+    return da, db, dot.reshape(alpha.shape).to(alpha.dtype)
+
+
 class AxpbyUpFn(torch.autograd.Function):
     """up2(a) + alpha*b without materialising up2(a): the block output `upsample(shortcut) + gamma*residual`."""
 
@@ -600,6 +613,8 @@ class AxpbyUpFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         b, alpha = ctx.saved_tensors
+        if not torch.is_grad_enabled() and all(ctx.needs_input_grad) and fused_blocks():
+            return _axpby_bwd_fused(dy, b, alpha, up=True)      # first-order: one pass over dy and b
         da = SumPool2Fn.apply(dy, 1.0) if ctx.needs_input_grad[0] else None
         db = ScaleFn.apply(dy, alpha) if ctx.needs_input_grad[1] else None
         dal = DotFn.apply(dy, b).reshape(alpha.shape) if ctx.needs_input_grad[2] else None
@@ -742,6 +757,9 @@ class AxpbyFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         b, alpha = ctx.saved_tensors
+        if not torch.is_grad_enabled() and ctx.needs_input_grad[1] and ctx.needs_input_grad[2] and fused_blocks():
+            _, db, dal = _axpby_bwd_fused(dy, b, alpha, up=False)
+            return (dy if ctx.needs_input_grad[0] else None), db, dal
         da = dy if ctx.needs_input_grad[0] else None
         db = ScaleFn.apply(dy, alpha) if ctx.needs_input_grad[1] else None
         dal = DotFn.apply(dy, b).reshape(alpha.shape) if ctx.needs_input_grad[2] else None
