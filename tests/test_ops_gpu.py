@@ -120,7 +120,8 @@ def test_conv_fwd_dgrad_wgrad(case, mode):
 
 
 @pytest.mark.parametrize("mode", MODES)
-@pytest.mark.parametrize("cin,cout,H,N", [(64, 32, 16, 2), (32, 32, 32, 1), (128, 64, 8, 3), (256, 128, 4, 2), (8, 8, 16, 2)])
+@pytest.mark.parametrize("cin,cout,H,N", [(64, 32, 16, 2), (32, 32, 32, 1), (128, 64, 8, 3), (256, 128, 4, 2), (8, 8, 16, 2),
+                                           (128, 128, 16, 2), (256, 128, 8, 4)])   # wide: weight gradient by kernel rows through the upsample
 def test_upsample_conv_fusion(cin, cout, H, N, mode):
     """conv3x3(interpolate(x, 2), w) + b computed on the low-resolution tensor with pre-summed 2x2 weights
     (df_gan.py:202 + 187): forward, dgrad (4x4-tap stride-2 gather), wgrad (through the fused upsample), bias grad;

@@ -10,7 +10,8 @@
 //   grid.x = pixel ranges (split-K, f32 atomics into the packed gradient), grid.y = 128x128 (co, ci) blocks, grid.z = kh
 //   512 threads = 8 waves as 2 (co) x 4 (ci): a wave owns 64 co x 32 ci x KW taps  (96 / 128 accumulator registers)
 //   K step = 64 output pixels = `nseg` row segments of `seg` = min(W, 64) pixels; the x tile holds, per segment,
-//   SA*(seg-1)+KW source pixels (stride SA: 1 for the 3x3, 2 for the 4x4 stride-2 layers), zero filled outside the image.
+//   SA*(seg-1)+KW source pixels (stride SA: 1 for the 3x3, 2 for the 4x4 stride-2 layers), zero filled outside the image;
+//   with src_shift the source is read through a nearest x2 upsample (the fused upsample + 3x3 operator's weight gradient).
 //   Both operands are pixel-major, fragments come from ds_read_b64_tr_b16 exactly as in conv_wgrad.hip; the tap shift is a
 //   row offset in the x tile.  LDS is double buffered (one barrier per step), the next step's global loads are in flight
 //   during the MFMAs.
@@ -61,8 +62,8 @@ __global__ __launch_bounds__(WR_NT) void wgrad_row_kernel(const XmcConvDesc d, c
         const int64_t ps = p0 + (int64_t)s * t.seg;
         const int q = (int)(ps / d.MW);           // global output row n*MH + a
         const int n = q / d.MH, a = q - n * d.MH;
-        const int sh = a * SA + kh - t.pad;
-        return (unsigned)sh < (unsigned)d.SH ? (n * d.SH + sh) * d.SW : -1;
+        const int sh = a * SA + kh - t.pad;       // row at the (possibly x2-upsampled: src_shift) resolution the taps address
+        return (unsigned)sh < (unsigned)(d.SH << d.src_shift) ? (n * d.SH + (sh >> d.src_shift)) * d.SW : -1;
     };
     if (tid < t.nseg) {
         s_seg[0][tid] = seg_entry(p_begin, tid);
@@ -96,7 +97,8 @@ __global__ __launch_bounds__(WR_NT) void wgrad_row_kernel(const XmcConvDesc d, c
             if (xs[it] >= 0) {
                 const int base = s_seg[par][xs[it]];
                 const int col = (t.nseg == 1 ? b0 : 0) * SA + xj[it] - t.pad;
-                if (base >= 0 && (unsigned)col < (unsigned)d.SW) v = x16[(size_t)(base + col) * cs_ch + (ci0 >> 3) + dch];
+                if (base >= 0 && (unsigned)col < (unsigned)(d.SW << d.src_shift))
+                    v = x16[(size_t)(base + (col >> d.src_shift)) * cs_ch + (ci0 >> 3) + dch];
             }
             ri[it] = v;
         }
@@ -230,7 +232,7 @@ int launch_row(const XmcConvDesc& d, const RowCfg& t, float* dwp, float* dbias, 
 int xmc_conv_wgrad_row_try(const XmcConvDesc* d, float* dwp, float* dbias, void* stream) {
     static const bool off = getenv("XMC_NO_WROW") != nullptr;
     if (off) return 1;
-    if (d->dtype != XMC_BF16 || d->src_shift != 0) return 1;
+    if (d->dtype != XMC_BF16 || (d->src_shift != 0 && d->SA != 1)) return 1;
     if (d->CS % 128 != 0 || d->CD % 128 != 0 || d->CDw != d->CD) return 1;
     int kw, sa;
     if (d->ntaps == 9 && d->SA == 1) { kw = 3; sa = 1; }
