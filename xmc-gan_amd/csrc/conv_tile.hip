@@ -588,14 +588,17 @@ __global__ __launch_bounds__(512) void wtile_kernel(const XmcConvDesc d, const T
         const u32x4* __restrict__ w16 = reinterpret_cast<const u32x4*>(d.wpk);
         int psrc[PIT];
         unsigned halo[PIT], inpatch = 0;
+        int py = r32 / PW, px = r32 - (r32 / PW) * PW;       // pixel r32 + 32*it, stepped without a division per unit
 #pragma unroll
         for (int it = 0; it < PIT; ++it) {
             const int pp = r32 + it * 32;
-            const int py = pp / PW, px = pp - py * PW;
             const bool in = pp < PH * PW;
             inpatch |= in ? (1u << it) : 0u;
             psrc[it] = in ? ((dh0 + py) * d.SW + (dw0 + px)) * cs_units + unit : 0;
             halo[it] = !in ? 0u : ((py < -dh0 ? 1u : 0u) | (py >= t.TH - dh0 ? 2u : 0u) | (px < -dw0 ? 4u : 0u) | (px >= t.TW - dw0 ? 8u : 0u));
+            px += 32;
+            if (px >= PW) { px -= PW; ++py; }     // PW >= 32: at most one wrap
+            if (px >= PW) { px -= PW; ++py; }
         }
         const int base = ((img * d.SH + a0) * d.SW + b0) * cs_units;
         const unsigned border = (a0 + dh0 < 0 ? 1u : 0u) | (a0 + PH + dh0 > d.SH ? 2u : 0u) | (b0 + dw0 < 0 ? 4u : 0u) | (b0 + PW + dw0 > d.SW ? 8u : 0u);
@@ -606,9 +609,11 @@ __global__ __launch_bounds__(512) void wtile_kernel(const XmcConvDesc d, const T
         int wrow[4], wdst[4];                     // weight rows of this thread: source row offset (units), LDS byte offset
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int prow = r32 + 32 * i;        // physical LDS row (n-block j, row q) <- logical channel (q/4)*32 + j*4 + q%4
+            // physical LDS row (n-block j, row q) <- logical channel (j/2)*32 + (q/4)*8 + (j%2)*4 + q%4: lane group fc = q/4 then
+            // holds, for unit u = j/2, channels u*32 + fc*8 .. +7, so the four lane groups of a pixel store 64 contiguous bytes
+            const int prow = r32 + 32 * i;
             const int j = prow >> 4, q = prow & 15;
-            const int lrow = (q >> 2) * (BN / 4) + j * 4 + (q & 3);
+            const int lrow = (j >> 1) * 32 + (q >> 2) * 8 + (j & 1) * 4 + (q & 3);
             wrow[i] = (n0 + lrow) * cs_units + unit;
             wdst[i] = prow * pstride + unit * 16;
         }
@@ -685,8 +690,8 @@ __global__ __launch_bounds__(512) void wtile_kernel(const XmcConvDesc d, const T
             const int ml = wm * 64 + i * 16 + fr;
             const int ty = ml >> t.log2TW, tx = ml & (t.TW - 1);
             abyte[i] = (ty * PW + tx) * pstride + fc * 16;
-            eoff[i] = ((ty * d.DA) * d.DW + tx * d.DA) * cd8 + fc * 4;
-            roff[i] = (ty * d.MW + tx) * cd8 + fc * 4;
+            eoff[i] = ((ty * d.DA) * d.DW + tx * d.DA) * cd8 + fc;
+            roff[i] = (ty * d.MW + tx) * cd8 + fc;
         }
         const int bbyte = fr * pstride + fc * 16;
         f32x4 acc[TM][TN];
@@ -747,20 +752,20 @@ __global__ __launch_bounds__(512) void wtile_kernel(const XmcConvDesc d, const T
             }
         }
 
-        // ---- epilogue from registers: acc[i][j][q] = pixel (m-block i, fr), channel n0 + fc*32 + j*4 + q
-        const int ch0 = n0 + fc * (BN / 4);
+        // ---- epilogue from registers: acc[i][j][q] = pixel (m-block i, fr), channel n0 + (j/2)*32 + fc*8 + (j%2)*4 + q
+        const int ch0 = n0 + fc * 8;
         const float alpha = d.alpha_dev ? *d.alpha_dev : 1.f;
         const int dbase = (((img * d.DH + a0 * d.DA + d.dph[0]) * d.DW) + b0 * d.DA + d.dpw[0]) * cd8 + (n0 >> 3);
         const int rbase = ((img * d.MH + a0) * d.MW + b0) * cd8 + (n0 >> 3);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            if (ch0 + u * 8 >= d.CD) continue;
+            if (ch0 + u * 32 >= d.CD) continue;
             float b8[8];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) b8[c] = d.bias ? d.bias[ch0 + u * 8 + c] : 0.f;
+            for (int c = 0; c < 8; ++c) b8[c] = d.bias ? d.bias[ch0 + u * 32 + c] : 0.f;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                const size_t idx8 = (size_t)(dbase + eoff[i] + u);
+                const size_t idx8 = (size_t)(dbase + eoff[i] + u * 4);
                 float v[8];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) { v[q] = acc[i][2 * u][q] + b8[q]; v[4 + q] = acc[i][2 * u + 1][q] + b8[4 + q]; }
@@ -778,7 +783,7 @@ __global__ __launch_bounds__(512) void wtile_kernel(const XmcConvDesc d, const T
 #pragma unroll
                     for (int q = 0; q < 8; ++q) v[q] *= alpha;
                 }
-                const size_t ridx8 = d.res_mode ? (size_t)(rbase + roff[i] + u) : idx8;
+                const size_t ridx8 = d.res_mode ? (size_t)(rbase + roff[i] + u * 4) : idx8;
                 if (d.out_dtype == XMC_BF16) epilogue_tail<XMC_BF16>(d, idx8, ridx8, v);
                 else epilogue_tail<XMC_F32>(d, idx8, ridx8, v);
             }
