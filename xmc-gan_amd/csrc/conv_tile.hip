@@ -278,11 +278,12 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
     const u32x4* __restrict__ src16 = reinterpret_cast<const u32x4*>(d.src);
     const u32x4* __restrict__ w16 = reinterpret_cast<const u32x4*>(d.wpk);
 
-    // physical weight row (n-block j, row q) holds logical output channel (q/4)*(BN/4) + j*4 + q%4
+    // physical weight row (n-block j, row q) holds logical output channel (j/2)*32 + (q/4)*8 + (j%2)*4 + q%4: lane group fc = q/4
+    // then owns, for unit u = j/2, channels u*32 + fc*8 .. +7 and the four lane groups of a pixel store 64 contiguous bytes
     for (int id = tid; id < MC * d.ntaps * BN * cps; id += 512) {
         const int ch = id % cps, prow = (id / cps) % BN, tap = id / (cps * BN);          // tap = slice index c * ntaps + tap
         const int j = prow >> 4, q = prow & 15;
-        const int lrow = (q >> 2) * (BN / 4) + j * 4 + (q & 3);
+        const int lrow = (j >> 1) * 32 + (q >> 2) * 8 + (j & 1) * 4 + (q & 3);
         *reinterpret_cast<u32x4*>(wall + (tap * BN + prow) * pstride + ch * 16) =
             w16[((size_t)d.wi[MC > 1 ? tap / d.ntaps : cls][MC > 1 ? tap % d.ntaps : tap] * d.CDw + n0 + lrow) * cs_units + ch];
     }
@@ -385,17 +386,17 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
             const int ml = wm * 64 + i * 16 + fr;
             const int ty = ml >> t.log2TW, tx = ml & (t.TW - 1);
             abyte[i] = (ty * PW + tx) * pstride + fc * 16;
-            eoff[i] = ((ty * d.DA) * d.DW + tx * d.DA) * cd8 + fc * UPL;
-            roff[i] = (ty * d.MW + tx) * cd8 + fc * UPL;          // same pixel in the [N,MH,MW,CD] grid (res_mode 1)
+            eoff[i] = ((ty * d.DA) * d.DW + tx * d.DA) * cd8 + fc;
+            roff[i] = (ty * d.MW + tx) * cd8 + fc;                // same pixel in the [N,MH,MW,CD] grid (res_mode 1)
         }
         const int bbyte = fr * pstride + fc * 16;
-        const int ch0 = n0 + fc * (BN / 4);
+        const int ch0 = n0 + fc * 8;                          // unit u of this lane: channels ch0 + 32*u .. +7
         const float alpha = d.alpha_dev ? *d.alpha_dev : 1.f;
         float bias8[UPL][8];
 #pragma unroll
         for (int u = 0; u < UPL; ++u)
 #pragma unroll
-            for (int c = 0; c < 8; ++c) bias8[u][c] = (d.bias && ch0 + u * 8 < d.CD) ? d.bias[ch0 + u * 8 + c] : 0.f;
+            for (int c = 0; c < 8; ++c) bias8[u][c] = (d.bias && ch0 + u * 32 < d.CD) ? d.bias[ch0 + u * 32 + c] : 0.f;
         // one uniform decision instead of a chain of branches per stored unit
         const bool fast = d.out_dtype == XMC_BF16 && d.res == nullptr && d.mask == nullptr && d.alpha_dev == nullptr &&
                           (d.act == XMC_ACT_NONE || d.act == XMC_ACT_LRELU);
@@ -485,7 +486,7 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
                 bf16x8* __restrict__ dst8 = reinterpret_cast<bf16x8*>(d.dst) + dbase;
 #pragma unroll
                 for (int u = 0; u < UPL; ++u) {
-                    if (ch0 + u * 8 >= d.CD) continue;            // same for every pixel of the lane: one branch per unit column
+                    if (ch0 + u * 32 >= d.CD) continue;           // same for every pixel of the lane: one branch per unit column
 #pragma unroll
                     for (int i = 0; i < TM; ++i) {
                         bf16x8 o;
@@ -503,7 +504,7 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
                                 o[4 + q] = (__bf16)(acc[i][2 * u + 1][q] + bias8[u][4 + q]);
                             }
                         }
-                        dst8[eoff[i] + u] = o;
+                        dst8[eoff[i] + u * 4] = o;
                     }
                 }
             } else {
@@ -511,8 +512,8 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int u = 0; u < UPL; ++u) {
-                        if (ch0 + u * 8 >= d.CD) continue;
-                        const size_t idx8 = (size_t)(dbase + eoff[i] + u);
+                        if (ch0 + u * 32 >= d.CD) continue;
+                        const size_t idx8 = (size_t)(dbase + eoff[i] + u * 4);
                         float v[8];
 #pragma unroll
                         for (int q = 0; q < 4; ++q) { v[q] = acc[i][2 * u][q] + bias8[u][q]; v[4 + q] = acc[i][2 * u + 1][q] + bias8[u][4 + q]; }
@@ -530,7 +531,7 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
 #pragma unroll
                             for (int q = 0; q < 8; ++q) v[q] *= alpha;
                         }
-                        const size_t ridx8 = d.res_mode ? (size_t)(rbase + roff[i] + u) : idx8;
+                        const size_t ridx8 = d.res_mode ? (size_t)(rbase + roff[i] + u * 4) : idx8;
                         if (d.out_dtype == XMC_BF16) epilogue_tail<XMC_BF16>(d, idx8, ridx8, v);
                         else epilogue_tail<XMC_F32>(d, idx8, ridx8, v);
                     }
