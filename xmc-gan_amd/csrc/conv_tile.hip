@@ -700,19 +700,25 @@ __global__ __launch_bounds__(512) void wtile_kernel(const XmcConvDesc d, const T
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        u32x4 F[2][TM + TN];                      // [set][pixel fragments 0..3, weight fragments 4..11]
-        auto rd = [&](const unsigned char* pa, const unsigned char* wb, int sub, int gi) -> u32x4 {
-            return gi < TM ? *reinterpret_cast<const u32x4*>(pa + sub * 64 + abyte[gi])
-                           : *reinterpret_cast<const u32x4*>(wb + bbyte + sub * 64 + (gi - TM) * 16 * pstride);
+        // Fragment registers: pixel fragments double buffered (every MFMA column of a sub-step uses all four), weight fragments
+        // in ONE set of eight: the MFMAs run column by column (all four pixel blocks against weight fragment mj), and as soon as
+        // the four MFMAs of column mj have issued, slot mj is re-loaded with the NEXT sub-step's fragment -- 28 MFMAs ahead of
+        // its first use.  (64 instead of 96 fragment registers.)
+        u32x4 P[2][TM], Wf[TN];
+        auto rdp = [&](const unsigned char* pa, int sub, int mi) -> u32x4 {
+            return *reinterpret_cast<const u32x4*>(pa + sub * 64 + abyte[mi]);
         };
-        // read order: p0 w0 p1 w1 p2 w2 p3 w3 w4 w5 w6 w7
-        auto gslot = [](int k) -> int { return k < 8 ? ((k & 1) ? TM + k / 2 : k / 2) : k; };
-        __syncthreads();                          // patch of slab 0 and weight stages 0, 1 are in LDS
-        {
-            const unsigned char* pa0 = patch + s_toff[0];
+        auto rdw = [&](const unsigned char* wb, int sub, int mj) -> u32x4 {
+            return *reinterpret_cast<const u32x4*>(wb + bbyte + sub * 64 + mj * 16 * pstride);
+        };
+        auto load_all = [&](const unsigned char* pa, const unsigned char* wb) {      // sub-step 0 of a stage, nothing in flight
 #pragma unroll
-            for (int k = 0; k < TM + TN; ++k) F[0][gslot(k)] = rd(pa0, wring, 0, gslot(k));
-        }
+            for (int k = 0; k < TM; ++k) { P[0][k] = rdp(pa, 0, k); Wf[k] = rdw(wb, 0, k); }
+#pragma unroll
+            for (int k = TM; k < TN; ++k) Wf[k] = rdw(wb, 0, k);
+        };
+        __syncthreads();                          // patch of slab 0 and weight stages 0, 1 are in LDS
+        load_all(patch + s_toff[0], wring);
         int toffr[NTAPS];                         // tap -> patch byte offset, in scalar registers
 #pragma unroll
         for (int k = 0; k < NTAPS; ++k) toffr[k] = __builtin_amdgcn_readfirstlane(s_toff[k]);
@@ -721,16 +727,18 @@ __global__ __launch_bounds__(512) void wtile_kernel(const XmcConvDesc d, const T
             constexpr bool PF = decltype(pf)::value;
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) {
+                const bool rd_on = sub == 0 || PF;
+                const unsigned char* rpa = sub == 0 ? pa : npa;
+                const unsigned char* rwb = sub == 0 ? wb : nwb;
+                const int rsub = sub == 0 ? 1 : 0;
 #pragma unroll
-                for (int k = 0; k < TM + TN; ++k) {
-                    if (sub == 0) F[1][gslot(k)] = rd(pa, wb, 1, gslot(k));
-                    else if (PF) F[0][gslot(k)] = rd(npa, nwb, 0, gslot(k));
+                for (int mj = 0; mj < TN; ++mj) {
+                    if (rd_on && mj < TM) P[sub ^ 1][mj] = rdp(rpa, rsub, mj);
 #pragma unroll
-                    for (int mm = k * (TM * TN) / (TM + TN); mm < (k + 1) * (TM * TN) / (TM + TN); ++mm) {
-                        const int mi = mm % TM, mj = mm / TM;
-                        acc[mi][mj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, F[sub][TM + mj]),
-                                                                               __builtin_bit_cast(bf16x8, F[sub][mi]), acc[mi][mj], 0, 0, 0);
-                    }
+                    for (int mi = 0; mi < TM; ++mi)
+                        acc[mi][mj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, Wf[mj]),
+                                                                               __builtin_bit_cast(bf16x8, P[sub][mi]), acc[mi][mj], 0, 0, 0);
+                    if (rd_on) Wf[mj] = rdw(rwb, rsub, mj);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -747,8 +755,7 @@ __global__ __launch_bounds__(512) void wtile_kernel(const XmcConvDesc d, const T
                 __syncthreads();                  // end of stage g
                 if (tap == NTAPS - 1 && sl + 1 < nslab) {
                     __syncthreads();              // the staging waves have written the next slab's patch
-#pragma unroll
-                    for (int k = 0; k < TM + TN; ++k) F[0][gslot(k)] = rd(npa, nwb, 0, gslot(k));
+                    load_all(npa, nwb);
                 }
             }
         }
