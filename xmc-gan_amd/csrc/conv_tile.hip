@@ -554,7 +554,7 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
 //                          across the barrier;  epilogue from registers (lane = 32 consecutive channels of 4 pixels).
 // One barrier per stage, one more at a slab boundary.
 template <int NTAPS>
-__global__ __launch_bounds__(512) void wtile_kernel(const XmcConvDesc d, const TileCfg t) {
+__global__ __launch_bounds__(512) void wtile_kernel(const XmcConvDesc d, const TileCfg t, int ntiles) {
     constexpr int BN = 128, TM = 4, TN = 8, NS = 256;
     constexpr int cps = 8, pstride = 160, PIT = 12;
     constexpr int WSTG = BN * pstride;           // bytes of one weight stage
@@ -572,14 +572,18 @@ __global__ __launch_bounds__(512) void wtile_kernel(const XmcConvDesc d, const T
     }
     const int cs_units = d.CS / 8;
     const int nslab = d.CS / 64;
-    const int G = nslab * d.ntaps;               // stages: slab-major, taps inside
+    // Persistent: this workgroup's tiles are blockIdx.x, + gridDim.x, ...  The K stages of all of them form ONE stream
+    // (patch sequence q = (tile, slab), NTAPS stages each): the weight ring never drains, a tile change is a patch change plus
+    // the epilogue, the next tile's first patch is loaded while the current tile is still being multiplied, and the stores
+    // of the epilogue drain during the next tile (measured before: 12 k cycles of prologue + 16 k of epilogue per 57 k of K loop).
+    const int mytiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int Q = mytiles * nslab;
+    const int G = Q * NTAPS;
     unsigned char* patch = smem;
     const int patch_bytes = (PH * PW * pstride + 15) & ~15;
     unsigned char* wring = smem + patch_bytes;   // [3][BN][pstride]
-    const int tile = blockIdx.x;
-    const int img = tile / tpi, trem = tile - img * tpi;
-    const int a0 = (trem / t.tiles_x) * t.TH, b0 = (trem % t.tiles_x) * t.TW;
     __syncthreads();
+    if (mytiles <= 0) return;
 
     if (wave >= 4) {
         // ================================================================================================ staging role
@@ -601,12 +605,7 @@ __global__ __launch_bounds__(512) void wtile_kernel(const XmcConvDesc d, const T
             if (px >= PW) { px -= PW; ++py; }     // PW >= 32: at most one wrap
             if (px >= PW) { px -= PW; ++py; }
         }
-        const int base = ((img * d.SH + a0) * d.SW + b0) * cs_units;
-        const unsigned border = (a0 + dh0 < 0 ? 1u : 0u) | (a0 + PH + dh0 > d.SH ? 2u : 0u) | (b0 + dw0 < 0 ? 4u : 0u) | (b0 + PW + dw0 > d.SW ? 8u : 0u);
-        unsigned okmask = 0;
-#pragma unroll
-        for (int it = 0; it < PIT; ++it) okmask |= ((halo[it] & border) == 0) ? (1u << it) : 0u;
-        okmask &= inpatch;
+        unsigned okmask = 0;                      // of the patch held in pv
         int wrow[4], wdst[4];                     // weight rows of this thread: source row offset (units), LDS byte offset
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -619,10 +618,20 @@ __global__ __launch_bounds__(512) void wtile_kernel(const XmcConvDesc d, const T
             wdst[i] = prow * pstride + unit * 16;
         }
         u32x4 pv[PIT], wv[4];
-        auto issue_patch = [&](int sl) {
+        auto issue_patch = [&](int q) {
+            const int tk = q / nslab, sl = q - tk * nslab;
+            const int tile = (int)blockIdx.x + tk * (int)gridDim.x;
+            const int img = tile / tpi, trem = tile - img * tpi;
+            const int a0 = (trem / t.tiles_x) * t.TH, b0 = (trem % t.tiles_x) * t.TW;
+            const int base = ((img * d.SH + a0) * d.SW + b0) * cs_units + sl * 8;
+            const unsigned border = (a0 + dh0 < 0 ? 1u : 0u) | (a0 + PH + dh0 > d.SH ? 2u : 0u) | (b0 + dw0 < 0 ? 4u : 0u) | (b0 + PW + dw0 > d.SW ? 8u : 0u);
+            okmask = 0;
 #pragma unroll
-            for (int it = 0; it < PIT; ++it)
-                pv[it] = src16[(unsigned)(base + (((okmask >> it) & 1) ? psrc[it] + sl * 8 : 0))];
+            for (int it = 0; it < PIT; ++it) {
+                const bool ok = (halo[it] & border) == 0 && ((inpatch >> it) & 1);
+                okmask |= ok ? (1u << it) : 0u;
+                pv[it] = src16[(unsigned)(base + (ok ? psrc[it] : 0))];
+            }
         };
         auto commit_patch = [&]() {
 #pragma unroll
@@ -633,7 +642,8 @@ __global__ __launch_bounds__(512) void wtile_kernel(const XmcConvDesc d, const T
             }
         };
         auto issue_w = [&](int g) {
-            const int sl = g / d.ntaps, tap = g - sl * d.ntaps;
+            const int qq = g / NTAPS, tap = g - qq * NTAPS;          // stage g: slab (g / NTAPS) % nslab -- the same for every tile
+            const int sl = qq % nslab;
             const int wb = s_twi[tap] * d.CDw * cs_units + sl * 8;
 #pragma unroll
             for (int i = 0; i < 4; ++i) wv[i] = w16[(unsigned)(wb + wrow[i])];
@@ -663,20 +673,20 @@ __global__ __launch_bounds__(512) void wtile_kernel(const XmcConvDesc d, const T
             }
         }
         if (G > 2) issue_w(2);
-        if (nslab > 1) issue_patch(1);
+        if (Q > 1) issue_patch(1);
         __syncthreads();                          // patch of slab 0 and weight stages 0, 1 are in LDS
-        for (int sl = 0, g = 0; sl < nslab; ++sl) {
+        for (int q = 0, g = 0; q < Q; ++q) {
 #pragma unroll
             for (int tap = 0; tap < NTAPS; ++tap, ++g) {
                 if (g + 2 < G) commit_w(g + 2);   // loaded during stage g-1
-                const bool boundary = tap == NTAPS - 1 && sl + 1 < nslab;
+                const bool boundary = tap == NTAPS - 1 && q + 1 < Q;
                 if (!boundary && g + 3 < G) issue_w(g + 3);
                 __syncthreads();                  // end of stage g
                 if (boundary) {
                     commit_patch();               // the compute waves are done with slab sl; nothing younger than these loads is
                     __syncthreads();              // in flight, so the wait in front of the LDS stores is for them alone
                     if (g + 3 < G) issue_w(g + 3);
-                    if (sl + 2 < nslab) issue_patch(sl + 2);
+                    if (q + 2 < Q) issue_patch(q + 2);
                 }
             }
         }
@@ -685,14 +695,12 @@ __global__ __launch_bounds__(512) void wtile_kernel(const XmcConvDesc d, const T
         const int wm = wave;
         const int fr = lane & 15, fc = lane >> 4;
         const int cd8 = d.CD / 8;
-        int abyte[TM], eoff[TM], roff[TM];
+        int abyte[TM];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int ml = wm * 64 + i * 16 + fr;
             const int ty = ml >> t.log2TW, tx = ml & (t.TW - 1);
             abyte[i] = (ty * PW + tx) * pstride + fc * 16;
-            eoff[i] = ((ty * d.DA) * d.DW + tx * d.DA) * cd8 + fc;
-            roff[i] = (ty * d.MW + tx) * cd8 + fc;
         }
         const int bbyte = fr * pstride + fc * 16;
         f32x4 acc[TM][TN];
@@ -717,7 +725,64 @@ __global__ __launch_bounds__(512) void wtile_kernel(const XmcConvDesc d, const T
 #pragma unroll
             for (int k = TM; k < TN; ++k) Wf[k] = rdw(wb, 0, k);
         };
-        __syncthreads();                          // patch of slab 0 and weight stages 0, 1 are in LDS
+        // epilogue from registers: acc[i][j][q] = pixel (m-block i, fr), channel n0 + (j/2)*32 + fc*8 + (j%2)*4 + q; clears acc
+        const int ch0 = n0 + fc * 8;
+        const float alpha = d.alpha_dev ? *d.alpha_dev : 1.f;
+        auto epilogue = [&](int tile) {
+            // Everything the epilogue needs besides the accumulators is recomputed here from an opaque lane index: hoisted out
+            // of the tile loop as "invariant", the 16 store addresses and 32 bias values spill (scratch reloads in front of
+            // every store: measured 30 k cycles per epilogue instead of 8 k).
+            int lane_op = fr;
+            asm volatile("" : "+v"(lane_op) :: "memory");
+            const int img = tile / tpi, trem = tile - img * tpi;
+            const int a0 = (trem / t.tiles_x) * t.TH, b0 = (trem % t.tiles_x) * t.TW;
+            const int dbase = (((img * d.DH + a0 * d.DA + d.dph[0]) * d.DW) + b0 * d.DA + d.dpw[0]) * cd8 + (n0 >> 3);
+            const int rbase = ((img * d.MH + a0) * d.MW + b0) * cd8 + (n0 >> 3);
+            // pixel block outermost, one address at a time (4 x 64-bit bases kept across the unit loop were being spilled)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int ml = wm * 64 + i * 16 + lane_op;
+                const int ty = ml >> t.log2TW, tx = ml & (t.TW - 1);
+                const int eo = ((ty * d.DA) * d.DW + tx * d.DA) * cd8 + fc;
+                const int ro = (ty * d.MW + tx) * cd8 + fc;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (ch0 + u * 32 >= d.CD) continue;
+                    const size_t idx8 = (size_t)(dbase + eo + u * 4);
+                    float v[8];
+                    if (d.bias) {
+                        const f32x4 b0v = *reinterpret_cast<const f32x4*>(d.bias + ch0 + u * 32), b1v = *reinterpret_cast<const f32x4*>(d.bias + ch0 + u * 32 + 4);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { v[q] = acc[i][2 * u][q] + b0v[q]; v[4 + q] = acc[i][2 * u + 1][q] + b1v[q]; }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { v[q] = acc[i][2 * u][q]; v[4 + q] = acc[i][2 * u + 1][q]; }
+                    }
+                    if (d.act == XMC_ACT_LRELU) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v[q] = lrelu_f(v[q]);
+                    } else if (d.act == XMC_ACT_RELU) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
+                    } else if (d.act == XMC_ACT_TANH) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v[q] = tanhf(v[q]);
+                    }
+                    if (d.alpha_dev) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v[q] *= alpha;
+                    }
+                    const size_t ridx8 = d.res_mode ? (size_t)(rbase + ro + u * 4) : idx8;
+                    if (d.out_dtype == XMC_BF16) epilogue_tail<XMC_BF16>(d, idx8, ridx8, v);
+                    else epilogue_tail<XMC_F32>(d, idx8, ridx8, v);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        };
+        __syncthreads();                          // patch 0 and weight stages 0, 1 are in LDS
         load_all(patch + s_toff[0], wring);
         int toffr[NTAPS];                         // tap -> patch byte offset, in scalar registers
 #pragma unroll
@@ -743,7 +808,7 @@ __global__ __launch_bounds__(512) void wtile_kernel(const XmcConvDesc d, const T
                 }
             }
         };
-        for (int sl = 0, g = 0; sl < nslab; ++sl) {
+        for (int q = 0, g = 0, sl = 0, tk = 0; q < Q; ++q) {
 #pragma unroll
             for (int tap = 0; tap < NTAPS; ++tap, ++g) {
                 const unsigned char* pa = patch + toffr[tap];
@@ -753,51 +818,19 @@ __global__ __launch_bounds__(512) void wtile_kernel(const XmcConvDesc d, const T
                 if (tap + 1 < NTAPS) stage(pa, wb, npa, nwb, std::true_type{});
                 else stage(pa, wb, npa, nwb, std::false_type{});      // next stage: new slab (patch not there yet) or none
                 __syncthreads();                  // end of stage g
-                if (tap == NTAPS - 1 && sl + 1 < nslab) {
-                    __syncthreads();              // the staging waves have written the next slab's patch
-                    load_all(npa, nwb);
+                if (tap == NTAPS - 1) {
+                    if (sl == nslab - 1) epilogue((int)blockIdx.x + tk * (int)gridDim.x);     // while the staging waves write the next patch
+                    if (q + 1 < Q) {
+                        __syncthreads();          // the staging waves have written the next patch
+                        load_all(npa, nwb);
+                    }
                 }
             }
-        }
-
-        // ---- epilogue from registers: acc[i][j][q] = pixel (m-block i, fr), channel n0 + (j/2)*32 + fc*8 + (j%2)*4 + q
-        const int ch0 = n0 + fc * 8;
-        const float alpha = d.alpha_dev ? *d.alpha_dev : 1.f;
-        const int dbase = (((img * d.DH + a0 * d.DA + d.dph[0]) * d.DW) + b0 * d.DA + d.dpw[0]) * cd8 + (n0 >> 3);
-        const int rbase = ((img * d.MH + a0) * d.MW + b0) * cd8 + (n0 >> 3);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (ch0 + u * 32 >= d.CD) continue;
-            float b8[8];
-#pragma unroll
-            for (int c = 0; c < 8; ++c) b8[c] = d.bias ? d.bias[ch0 + u * 32 + c] : 0.f;
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const size_t idx8 = (size_t)(dbase + eoff[i] + u * 4);
-                float v[8];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) { v[q] = acc[i][2 * u][q] + b8[q]; v[4 + q] = acc[i][2 * u + 1][q] + b8[4 + q]; }
-                if (d.act == XMC_ACT_LRELU) {
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) v[q] = lrelu_f(v[q]);
-                } else if (d.act == XMC_ACT_RELU) {
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
-                } else if (d.act == XMC_ACT_TANH) {
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) v[q] = tanhf(v[q]);
-                }
-                if (d.alpha_dev) {
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) v[q] *= alpha;
-                }
-                const size_t ridx8 = d.res_mode ? (size_t)(rbase + roff[i] + u * 4) : idx8;
-                if (d.out_dtype == XMC_BF16) epilogue_tail<XMC_BF16>(d, idx8, ridx8, v);
-                else epilogue_tail<XMC_F32>(d, idx8, ridx8, v);
-            }
+            if (++sl == nslab) { sl = 0; ++tk; }
         }
     }
 }
+
 
 template <int BN>
 int launch_ptile(const XmcConvDesc& d, const TileCfg& t, hipStream_t st) {
@@ -872,8 +905,12 @@ int launch_wtile(const XmcConvDesc& d, const TileCfg& t, hipStream_t st) {
     const size_t lds = (size_t)((t.PH[0] * t.PW[0] * 160 + 15) & ~15) + (size_t)3 * 128 * 160;
     if (lds > XMC_MAX_DYN_LDS) return XMC_ESHAPE;
     XMC_ALLOW_BIG_LDS(wtile_kernel<9>);
-    dim3 grid((unsigned)(d.N * t.tiles_y * t.tiles_x), (unsigned)(d.CDw / 128), 1);
-    hipLaunchKernelGGL(wtile_kernel<9>, grid, dim3(512), lds, st, d, t);
+    const int ntiles = d.N * t.tiles_y * t.tiles_x, ny = d.CDw / 128;
+    int gx = 256 / ny;                            // one 8-wave workgroup per CU, persistent over its tiles
+    if (gx < 1) gx = 1;
+    if (gx > ntiles) gx = ntiles;
+    dim3 grid((unsigned)gx, (unsigned)ny, 1);
+    hipLaunchKernelGGL(wtile_kernel<9>, grid, dim3(512), lds, st, d, t, ntiles);
     xmc_note_kernel("wtile_kernel<9>");
     XMC_LAUNCH_CHECK();
     return 0;
