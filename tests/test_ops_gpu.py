@@ -80,6 +80,9 @@ CONV_CASES = [
     (128, 128, 4, 2, 1, 32, 3),    # 4x4 stride 2: output rows of 16 pixels, 4 segments per step
     (128, 256, 4, 2, 1, 64, 2),    # output rows of 32
     (128, 128, 4, 2, 1, 128, 1),   # output rows of 64: 130 source pixels per segment
+    # all-taps weight gradient of the 4x4 stride-2 layers with few channels (two column-parity planes in LDS)
+    (32, 64, 4, 2, 1, 64, 2),      # resD block 0 shape: 64 co x 32 ci x 16 taps, 8 waves
+    (16, 32, 4, 2, 1, 64, 3),      # 2 x 1 channel blocks, 4 waves
 ]
 
 

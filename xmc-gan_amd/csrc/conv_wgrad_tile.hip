@@ -25,30 +25,40 @@ template <int NCO, int NCI> struct WtOcc {
     static constexpr int v = (NCO == 2 && NCI == 1) ? 4 : ((NCO * NCI <= 2 || (NCO == 2 && NCI == 2)) ? 3 : 1);     // no spills at these caps
 };
 
-template <int NCO, int NCI, int NT>     // 16-wide blocks of (padded) Cout and Cin; NT threads (4 or 8 waves)
-__global__ __launch_bounds__(NT, (WtOcc<NCO, NCI>::v)) void wgrad_tile_kernel(const XmcConvDesc d, float* __restrict__ dwp, float* __restrict__ dbias, const WTCfg t) {
+// SA == 2 (the 4x4 stride-2 layers, KT = 16 taps): the x patch covers (2*TH+2) x (2*TW+2) source pixels and is stored as two
+// column-parity planes per patch row, so that the pixels of consecutive output columns for a fixed tap -- source columns 2k+kw --
+// are consecutive LDS rows and the tr16 fragment reads stay unit-stride (and bank-conflict free) exactly as for SA == 1.
+// CBW: 16-wide Cout blocks per wave.  Every (ci block, tap) item needs its own shifted x fragment (2 transposing reads); a wave
+// that multiplies it against CBW dy fragments instead of one does CBW MFMAs per 2 reads (CBW = 1: 2.1 LDS reads per MFMA, twice
+// what the LDS delivers at the MFMA rate).
+template <int NCO, int NCI, int NT, int SA = 1, int KT = 9, int CBW = 1>     // 16-wide blocks of (padded) Cout and Cin; NT threads
+__global__ __launch_bounds__(NT, (SA == 1 ? WtOcc<NCO, NCI>::v : 1)) void wgrad_tile_kernel(const XmcConvDesc d, float* __restrict__ dwp, float* __restrict__ dbias, const WTCfg t) {
     constexpr int CDP = NCO * 16, CSP = NCI * 16;
     constexpr int YS = CDP * 2 + 32, XS = CSP * 2 + 32;      // LDS row strides (bytes)
-    constexpr int NS = (NT / 64) / NCO;                       // waves sharing one co block
-    constexpr int MAXI = (NCI * 9 + NS - 1) / NS;             // (ci block, tap) items per wave
+    static_assert(NCO % CBW == 0, "co blocks per wave");
+    constexpr int NCG = NCO / CBW;                            // groups of co blocks
+    constexpr int NS = (NT / 64) / NCG;                       // waves sharing one group of co blocks
+    constexpr int MAXI = (NCI * KT + NS - 1) / NS;            // (ci block, tap) items per wave
     constexpr int YCH = CDP / 8, XCH = CSP / 8;               // 16-byte chunks per pixel
     constexpr int YIT = TH * TW * YCH / NT;                   // dy chunks per thread per tile (>= 2)
-    constexpr int XIT = (10 * 34 * XCH + NT - 1) / NT;        // patch chunks per thread per tile
+    constexpr int XIT = ((SA == 1 ? 10 * 34 : 18 * 66) * XCH + NT - 1) / NT;        // patch chunks per thread per tile
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* ydy = smem;                                // [256][YS]
     unsigned char* xp = smem + TH * TW * YS;                  // [PH*PW][XS]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int cb = wave % NCO, slice = wave / NCO;
+    const int cg = wave % NCG, slice = wave / NCG;
     const int tpi = t.tiles_y * t.tiles_x;
     const int PH = t.PH, PW = t.PW;
     const int cd_units = d.CD / 8, cs_units = d.CS / 8;
     const u32x4* __restrict__ x16 = reinterpret_cast<const u32x4*>(d.src);
     const u32x4* __restrict__ y16 = reinterpret_cast<const u32x4*>(d.dst);
 
-    f32x4 acc[MAXI];
+    f32x4 acc[MAXI][CBW];
 #pragma unroll
-    for (int j = 0; j < MAXI; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < MAXI; ++j)
+#pragma unroll
+        for (int c = 0; c < CBW; ++c) acc[j][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     u32x4 yv[YIT], xv[XIT];
     auto prefetch = [&](int tile) {
@@ -67,7 +77,7 @@ __global__ __launch_bounds__(NT, (WtOcc<NCO, NCI>::v)) void wgrad_tile_kernel(co
             int id = tid + it * NT;
             int pp = id / XCH, ch = id - pp * XCH;
             int py = pp / PW, px = pp - py * PW;
-            int sy = a0 + t.dh0 + py, sx = b0 + t.dw0 + px;          // coordinates at the (possibly x2-upsampled) resolution
+            int sy = a0 * SA + t.dh0 + py, sx = b0 * SA + t.dw0 + px;          // coordinates at the (possibly x2-upsampled) resolution
             bool ok = pp < PH * PW && ch < cs_units && (unsigned)sy < (unsigned)(d.SH << d.src_shift) &&
                       (unsigned)sx < (unsigned)(d.SW << d.src_shift);
             u32x4 z = {0, 0, 0, 0};
@@ -90,7 +100,8 @@ __global__ __launch_bounds__(NT, (WtOcc<NCO, NCI>::v)) void wgrad_tile_kernel(co
         const int item = slice + j * NS;
         int ib = 0, tap = 0;
         if (item < nitems) { ib = item / d.ntaps; tap = item - ib * d.ntaps; }
-        itoff[j] = ((d.dh[0][tap] - t.dh0) * PW + (d.dw[0][tap] - t.dw0)) * XS + (ib * 16) * 2;
+        const int th = d.dh[0][tap] - t.dh0, tw = d.dw[0][tap] - t.dw0;
+        itoff[j] = (SA == 1 ? th * PW + tw : (th * 2 + (tw & 1)) * (PW >> 1) + (tw >> 1)) * XS + (ib * 16) * 2;
     }
 
     for (; tile < t.ntiles; tile += gridDim.x) {
@@ -110,7 +121,12 @@ __global__ __launch_bounds__(NT, (WtOcc<NCO, NCI>::v)) void wgrad_tile_kernel(co
         for (int it = 0; it < XIT; ++it) {
             int id = tid + it * NT;
             int pp = id / XCH, ch = id - pp * XCH;
-            if (pp < PH * PW) *reinterpret_cast<u32x4*>(xp + pp * XS + ch * 16) = xv[it];
+            int lp = pp;
+            if (SA == 2) {                                    // patch pixel (py, px) -> row py, plane px & 1, column px >> 1
+                const int py = pp / PW, px = pp - py * PW;
+                lp = (py * 2 + (px & 1)) * (PW >> 1) + (px >> 1);
+            }
+            if (pp < PH * PW) *reinterpret_cast<u32x4*>(xp + lp * XS + ch * 16) = xv[it];
         }
         __syncthreads();
         if (tile + (int)gridDim.x < t.ntiles) prefetch(tile + gridDim.x);
@@ -120,19 +136,24 @@ __global__ __launch_bounds__(NT, (WtOcc<NCO, NCI>::v)) void wgrad_tile_kernel(co
             // A' fragment: dy^T [co = cb*16 + lane&15][pix = r*32 + 4*fg + j (+16)]: the 32 lanes one tr16 read serves together
             // address 8 consecutive pixel rows, which the 96/160-byte strides spread over distinct banks (rows 8*fg + j would
             // put lane groups 0 and 1 on the same banks)
-            const unsigned char* ab = ydy + (size_t)(r * TW + 4 * fg + q) * YS + (cb * 16 + 4 * pp4) * 2;
-            bf16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(ab));
-            bf16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(ab + 16 * YS));
-            const bf16x8 af = bf16x8{alo[0], alo[1], alo[2], alo[3], ahi[0], ahi[1], ahi[2], ahi[3]};
+            bf16x8 af[CBW];
+#pragma unroll
+            for (int c = 0; c < CBW; ++c) {
+                const unsigned char* ab = ydy + (size_t)(r * TW + 4 * fg + q) * YS + ((cg * CBW + c) * 16 + 4 * pp4) * 2;
+                bf16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(ab));
+                bf16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(ab + 16 * YS));
+                af[c] = bf16x8{alo[0], alo[1], alo[2], alo[3], ahi[0], ahi[1], ahi[2], ahi[3]};
+            }
 #pragma unroll
             for (int j = 0; j < MAXI; ++j) {
                 const int item = slice + j * NS;
                 if (item < nitems) {                          // wave-uniform
-                    const unsigned char* bb = xp + (r * PW + 4 * fg + q) * XS + itoff[j] + (4 * pp4) * 2;
+                    const unsigned char* bb = xp + ((SA == 1 ? r * PW : r * 2 * PW) + 4 * fg + q) * XS + itoff[j] + (4 * pp4) * 2;
                     bf16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(bb));
                     bf16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(bb + 16 * XS));
                     const bf16x8 bf = bf16x8{blo[0], blo[1], blo[2], blo[3], bhi[0], bhi[1], bhi[2], bhi[3]};
-                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, acc[j], 0, 0, 0);
+#pragma unroll
+                    for (int c = 0; c < CBW; ++c) acc[j][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[c], bf, acc[j][c], 0, 0, 0);
                 }
             }
         }
@@ -154,28 +175,30 @@ __global__ __launch_bounds__(NT, (WtOcc<NCO, NCI>::v)) void wgrad_tile_kernel(co
         if (item < nitems) {
             const int ib = item / d.ntaps, tap = item - ib * d.ntaps;
 #pragma unroll
+            for (int c = 0; c < CBW; ++c)
+#pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
-                int co = cb * 16 + fg * 4 + rr, ci = ib * 16 + fr;
+                int co = (cg * CBW + c) * 16 + fg * 4 + rr, ci = ib * 16 + fr;
                 if (co < d.CDw && co < CDP && ci < d.CS)
-                    atomicAdd(&dwp[((size_t)d.wi[0][tap] * d.CDw + co) * d.CS + ci], acc[j][rr]);
+                    atomicAdd(&dwp[((size_t)d.wi[0][tap] * d.CDw + co) * d.CS + ci], acc[j][c][rr]);
             }
         }
     }
 }
 
-template <int NCO, int NCI, int NT = 256>
+template <int NCO, int NCI, int NT = 256, int SA = 1, int KT = 9, int CBW = 1>
 int launch_wt(const XmcConvDesc& d, float* dwp, float* dbias, const WTCfg& t, hipStream_t st) {
     constexpr int YS = NCO * 32 + 32, XS = NCI * 32 + 32;
     size_t lds = (size_t)TH * TW * YS + (size_t)t.PH * t.PW * XS;
     if (lds > XMC_MAX_DYN_LDS) return 1;
-    XMC_ALLOW_BIG_LDS((wgrad_tile_kernel<NCO, NCI, NT>));
+    XMC_ALLOW_BIG_LDS((wgrad_tile_kernel<NCO, NCI, NT, SA, KT, CBW>));
     int per_cu = (int)(160 * 1024 / lds);
     const int cap = WtOcc<NCO, NCI>::v >= 3 ? 3 : 2;
     if (per_cu > cap) per_cu = cap;
     int gx = 256 * per_cu;
     if (gx > t.ntiles) gx = t.ntiles;
-    hipLaunchKernelGGL((wgrad_tile_kernel<NCO, NCI, NT>), dim3(gx), dim3(NT), lds, st, d, dwp, dbias, t);
-    xmc_note_kernel("wgrad_tile_kernel<%d, %d, %d>", NCO, NCI, NT);
+    hipLaunchKernelGGL((wgrad_tile_kernel<NCO, NCI, NT, SA, KT, CBW>), dim3(gx), dim3(NT), lds, st, d, dwp, dbias, t);
+    xmc_note_kernel("wgrad_tile_kernel<%d, %d, %d, %d, %d, %d>", NCO, NCI, NT, SA, KT, CBW);
     XMC_LAUNCH_CHECK();
     return 0;
 }
@@ -186,8 +209,10 @@ int launch_wt(const XmcConvDesc& d, float* dwp, float* dbias, const WTCfg& t, hi
 int xmc_conv_wgrad_tile_try(const XmcConvDesc* d, float* dwp, float* dbias, void* stream) {
     static const bool off = getenv("XMC_NO_WTILE") != nullptr;
     if (off) return 1;
-    if (d->dtype != XMC_BF16 || d->SA != 1 || d->src_shift < 0 || d->src_shift > 1) return 1;
-    if (d->CD > 64 || d->CS > 64 || d->ntaps > 9 || d->ntaps < 1) return 1;
+    if (d->dtype != XMC_BF16 || d->src_shift < 0 || d->src_shift > 1) return 1;
+    const bool s2 = d->SA == 2;                               // 4x4 stride-2 layers: 16 taps, no upsample, Cin <= 32 (patch size)
+    if (d->SA != 1 && !(s2 && d->ntaps == 16 && d->src_shift == 0 && d->CS <= 32)) return 1;
+    if (d->CD > 64 || d->CS > 64 || d->ntaps > (s2 ? 16 : 9) || d->ntaps < 1) return 1;
     if (d->MW % TW != 0 || d->MH % TH != 0) return 1;
     if (d->CD % 8 != 0 || d->CS % 8 != 0) return 1;
     WTCfg t;
@@ -198,17 +223,23 @@ int xmc_conv_wgrad_tile_try(const XmcConvDesc* d, float* dwp, float* dbias, void
         hmin = h < hmin ? h : hmin; hmax = h > hmax ? h : hmax;
         wmin = w < wmin ? w : wmin; wmax = w > wmax ? w : wmax;
     }
-    t.dh0 = hmin; t.dw0 = wmin; t.PH = TH + hmax - hmin; t.PW = TW + wmax - wmin;
-    if (t.PH > 10 || t.PW > 34) return 1;
+    t.dh0 = hmin; t.dw0 = wmin;
+    t.PH = d->SA * (TH - 1) + (hmax - hmin + 1); t.PW = d->SA * (TW - 1) + (wmax - wmin + 1);
+    if (s2 ? (t.PH > 18 || t.PW > 66 || (t.PW & 1)) : (t.PH > 10 || t.PW > 34)) return 1;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int nco = d->CD <= 16 ? 1 : (d->CD <= 32 ? 2 : 4);
     const int nci = d->CS <= 16 ? 1 : (d->CS <= 32 ? 2 : 4);
-#define WT_CASE(a, b) if (nco == a && nci == b) return launch_wt<a, b>(*d, dwp, dbias, t, st);
+    if (s2) {
+        if (nco == 4 && nci == 2) return launch_wt<4, 2, 512, 2, 16, 4>(*d, dwp, dbias, t, st);
+        if (nco == 2 && nci == 1) return launch_wt<2, 1, 256, 2, 16, 2>(*d, dwp, dbias, t, st);
+        return 1;
+    }
+#define WT_CASE(a, b) if (nco == a && nci == b) return launch_wt<a, b, 256, 1, 9, (a >= 2 ? 2 : 1)>(*d, dwp, dbias, t, st);
     // (4,4) = 64x64 channels with 4 waves needs 144 accumulator + 76 staging registers per lane and measured slower than
     // the split-K kernel (166 vs 230 TF/s); it runs with 8 waves instead (below)
     WT_CASE(1, 2) WT_CASE(1, 4) WT_CASE(2, 1) WT_CASE(2, 2) WT_CASE(2, 4) WT_CASE(4, 1) WT_CASE(4, 2)
     static const bool no44 = getenv("XMC_NO_WT44") != nullptr;
-    if (nco == 4 && nci == 4 && !no44) return launch_wt<4, 4, 512>(*d, dwp, dbias, t, st);   // 8 waves: 72 accumulator registers per lane
+    if (nco == 4 && nci == 4 && !no44) return launch_wt<4, 4, 512, 1, 9, 2>(*d, dwp, dbias, t, st);   // 8 waves: 72 accumulator registers per lane
 #undef WT_CASE
     return 1;
 }
