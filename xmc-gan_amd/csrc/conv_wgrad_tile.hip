@@ -51,6 +51,9 @@ __global__ __launch_bounds__(NT, (SA == 1 ? WtOcc<NCO, NCI>::v : 1)) void wgrad_
     const int tpi = t.tiles_y * t.tiles_x;
     const int PH = t.PH, PW = t.PW;
     const int cd_units = d.CD / 8, cs_units = d.CS / 8;
+    // channels beyond 64 are split over the grid: blockIdx.y = 64-wide Cin block, blockIdx.z = 64-wide Cout block
+    const int ci0 = blockIdx.y * 64, co0 = blockIdx.z * 64;
+    const int ciu0 = ci0 >> 3, cou0 = co0 >> 3;
     const u32x4* __restrict__ x16 = reinterpret_cast<const u32x4*>(d.src);
     const u32x4* __restrict__ y16 = reinterpret_cast<const u32x4*>(d.dst);
 
@@ -70,7 +73,7 @@ __global__ __launch_bounds__(NT, (SA == 1 ? WtOcc<NCO, NCI>::v : 1)) void wgrad_
             int pix = id / YCH, ch = id - pix * YCH;
             int py = pix / TW, px = pix - py * TW;
             u32x4 z = {0, 0, 0, 0};
-            yv[it] = ch < cd_units ? y16[(((size_t)img * d.MH + a0 + py) * d.MW + b0 + px) * cd_units + ch] : z;
+            yv[it] = cou0 + ch < cd_units ? y16[(((size_t)img * d.MH + a0 + py) * d.MW + b0 + px) * cd_units + cou0 + ch] : z;
         }
 #pragma unroll
         for (int it = 0; it < XIT; ++it) {
@@ -78,10 +81,10 @@ __global__ __launch_bounds__(NT, (SA == 1 ? WtOcc<NCO, NCI>::v : 1)) void wgrad_
             int pp = id / XCH, ch = id - pp * XCH;
             int py = pp / PW, px = pp - py * PW;
             int sy = a0 * SA + t.dh0 + py, sx = b0 * SA + t.dw0 + px;          // coordinates at the (possibly x2-upsampled) resolution
-            bool ok = pp < PH * PW && ch < cs_units && (unsigned)sy < (unsigned)(d.SH << d.src_shift) &&
+            bool ok = pp < PH * PW && ciu0 + ch < cs_units && (unsigned)sy < (unsigned)(d.SH << d.src_shift) &&
                       (unsigned)sx < (unsigned)(d.SW << d.src_shift);
             u32x4 z = {0, 0, 0, 0};
-            xv[it] = ok ? x16[(((size_t)img * d.SH + (sy >> d.src_shift)) * d.SW + (sx >> d.src_shift)) * cs_units + ch] : z;
+            xv[it] = ok ? x16[(((size_t)img * d.SH + (sy >> d.src_shift)) * d.SW + (sx >> d.src_shift)) * cs_units + ciu0 + ch] : z;
         }
     };
 
@@ -111,7 +114,7 @@ __global__ __launch_bounds__(NT, (SA == 1 ? WtOcc<NCO, NCI>::v : 1)) void wgrad_
             int id = tid + it * NT;
             int pix = id / YCH, ch = id - pix * YCH;
             *reinterpret_cast<u32x4*>(ydy + pix * YS + ch * 16) = yv[it];
-            if (dbias != nullptr) {                           // bias gradient: this thread always holds chunk tid % YCH
+            if (dbias != nullptr && blockIdx.y == 0) {        // bias gradient: this thread always holds chunk tid % YCH
                 bf16x8 h = __builtin_bit_cast(bf16x8, yv[it]);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) bsum[k] += (float)h[k];
@@ -159,12 +162,12 @@ __global__ __launch_bounds__(NT, (SA == 1 ? WtOcc<NCO, NCI>::v : 1)) void wgrad_
         }
     }
 
-    if (dbias != nullptr) {
+    if (dbias != nullptr && blockIdx.y == 0) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             float v = bsum[k];
             for (int o = 32; o >= YCH; o >>= 1) v += __shfl_xor(v, o, 64);
-            int ch = (lane % YCH) * 8 + k;
+            int ch = co0 + (lane % YCH) * 8 + k;
             if (lane < YCH && ch < d.CD) atomicAdd(&dbias[(blockIdx.x & (XMC_BIAS_REPLICAS - 1)) * d.CD + ch], v);
         }
     }
@@ -178,8 +181,8 @@ __global__ __launch_bounds__(NT, (SA == 1 ? WtOcc<NCO, NCI>::v : 1)) void wgrad_
             for (int c = 0; c < CBW; ++c)
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
-                int co = (cg * CBW + c) * 16 + fg * 4 + rr, ci = ib * 16 + fr;
-                if (co < d.CDw && co < CDP && ci < d.CS)
+                int co = co0 + (cg * CBW + c) * 16 + fg * 4 + rr, ci = ci0 + ib * 16 + fr;
+                if (co < d.CDw && co < co0 + CDP && ci < d.CS)
                     atomicAdd(&dwp[((size_t)d.wi[0][tap] * d.CDw + co) * d.CS + ci], acc[j][c][rr]);
             }
         }
@@ -195,9 +198,11 @@ int launch_wt(const XmcConvDesc& d, float* dwp, float* dbias, const WTCfg& t, hi
     int per_cu = (int)(160 * 1024 / lds);
     const int cap = WtOcc<NCO, NCI>::v >= 3 ? 3 : 2;
     if (per_cu > cap) per_cu = cap;
-    int gx = 256 * per_cu;
+    const int ny = (d.CS + 63) / 64, nz = (d.CD + 63) / 64;
+    int gx = 256 * per_cu / (ny * nz);
+    if (gx < 1) gx = 1;
     if (gx > t.ntiles) gx = t.ntiles;
-    hipLaunchKernelGGL((wgrad_tile_kernel<NCO, NCI, NT, SA, KT, CBW>), dim3(gx), dim3(NT), lds, st, d, dwp, dbias, t);
+    hipLaunchKernelGGL((wgrad_tile_kernel<NCO, NCI, NT, SA, KT, CBW>), dim3(gx, ny, nz), dim3(NT), lds, st, d, dwp, dbias, t);
     xmc_note_kernel("wgrad_tile_kernel<%d, %d, %d, %d, %d, %d>", NCO, NCI, NT, SA, KT, CBW);
     XMC_LAUNCH_CHECK();
     return 0;
@@ -212,7 +217,10 @@ int xmc_conv_wgrad_tile_try(const XmcConvDesc* d, float* dwp, float* dbias, void
     if (d->dtype != XMC_BF16 || d->src_shift < 0 || d->src_shift > 1) return 1;
     const bool s2 = d->SA == 2;                               // 4x4 stride-2 layers: 16 taps, no upsample, Cin <= 32 (patch size)
     if (d->SA != 1 && !(s2 && d->ntaps == 16 && d->src_shift == 0 && d->CS <= 32)) return 1;
-    if (d->CD > 64 || d->CS > 64 || d->ntaps > (s2 ? 16 : 9) || d->ntaps < 1) return 1;
+    static const bool no_wide = getenv("XMC_NO_WT_WIDE") != nullptr;
+    const bool wide = d->CD > 64 || d->CS > 64;              // 64-channel blocks over grid.y / grid.z
+    if (wide && (no_wide || s2 || (d->CD > 64 && d->CD % 64) || (d->CS > 64 && d->CS % 64))) return 1;
+    if (d->ntaps > (s2 ? 16 : 9) || d->ntaps < 1) return 1;
     if (d->MW % TW != 0 || d->MH % TH != 0) return 1;
     if (d->CD % 8 != 0 || d->CS % 8 != 0) return 1;
     WTCfg t;
