@@ -564,11 +564,12 @@ __global__ __launch_bounds__(512) void wtile_kernel(const XmcConvDesc d, const T
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n0 = blockIdx.y * BN;
     const int tpi = t.tiles_y * t.tiles_x;
-    const int PH = t.PH[0], PW = t.PW[0], dh0 = t.dh0[0], dw0 = t.dw0[0];
+    const int cls = blockIdx.z;                  // output-parity class (stride-2 data gradient, fused upsample conv): own patch
+    const int PH = t.PH[cls], PW = t.PW[cls], dh0 = t.dh0[cls], dw0 = t.dw0[cls];
     if (tid < XMC_MAX_TAPS) {
         const int tt = tid < d.ntaps ? tid : 0;
-        s_toff[tid] = ((d.dh[0][tt] - dh0) * PW + (d.dw[0][tt] - dw0)) * pstride;
-        s_twi[tid] = d.wi[0][tt];
+        s_toff[tid] = ((d.dh[cls][tt] - dh0) * PW + (d.dw[cls][tt] - dw0)) * pstride;
+        s_twi[tid] = d.wi[cls][tt];
     }
     const int cs_units = d.CS / 8;
     const int nslab = d.CS / 64;
@@ -736,7 +737,7 @@ __global__ __launch_bounds__(512) void wtile_kernel(const XmcConvDesc d, const T
             asm volatile("" : "+v"(lane_op) :: "memory");
             const int img = tile / tpi, trem = tile - img * tpi;
             const int a0 = (trem / t.tiles_x) * t.TH, b0 = (trem % t.tiles_x) * t.TW;
-            const int dbase = (((img * d.DH + a0 * d.DA + d.dph[0]) * d.DW) + b0 * d.DA + d.dpw[0]) * cd8 + (n0 >> 3);
+            const int dbase = (((img * d.DH + a0 * d.DA + d.dph[cls]) * d.DW) + b0 * d.DA + d.dpw[cls]) * cd8 + (n0 >> 3);
             const int rbase = ((img * d.MH + a0) * d.MW + b0) * cd8 + (n0 >> 3);
             // pixel block outermost, one address at a time (4 x 64-bit bases kept across the unit loop were being spilled)
 #pragma unroll
@@ -901,17 +902,24 @@ int launch_tile(const XmcConvDesc& d, const TileCfg& t, hipStream_t st) {
 }
 
 int launch_wtile(const XmcConvDesc& d, const TileCfg& t, hipStream_t st) {
-    if (t.PH[0] * t.PW[0] > 384) return XMC_ESHAPE;
-    const size_t lds = (size_t)((t.PH[0] * t.PW[0] * 160 + 15) & ~15) + (size_t)3 * 128 * 160;
+    int maxpatch = 0;
+    for (int z = 0; z < d.nclass; ++z) maxpatch = t.PH[z] * t.PW[z] > maxpatch ? t.PH[z] * t.PW[z] : maxpatch;
+    if (maxpatch > 384) return XMC_ESHAPE;
+    const size_t lds = (size_t)((maxpatch * 160 + 15) & ~15) + (size_t)3 * 128 * 160;
     if (lds > XMC_MAX_DYN_LDS) return XMC_ESHAPE;
-    XMC_ALLOW_BIG_LDS(wtile_kernel<9>);
     const int ntiles = d.N * t.tiles_y * t.tiles_x, ny = d.CDw / 128;
-    int gx = 256 / ny;                            // one 8-wave workgroup per CU, persistent over its tiles
+    int gx = 256 / (ny * d.nclass);               // one 8-wave workgroup per CU, persistent over its tiles
     if (gx < 1) gx = 1;
     if (gx > ntiles) gx = ntiles;
-    dim3 grid((unsigned)gx, (unsigned)ny, 1);
-    hipLaunchKernelGGL(wtile_kernel<9>, grid, dim3(512), lds, st, d, t, ntiles);
-    xmc_note_kernel("wtile_kernel<9>");
+    dim3 grid((unsigned)gx, (unsigned)ny, (unsigned)d.nclass);
+    if (d.ntaps == 9) {
+        XMC_ALLOW_BIG_LDS(wtile_kernel<9>);
+        hipLaunchKernelGGL(wtile_kernel<9>, grid, dim3(512), lds, st, d, t, ntiles);
+    } else {
+        XMC_ALLOW_BIG_LDS(wtile_kernel<4>);
+        hipLaunchKernelGGL(wtile_kernel<4>, grid, dim3(512), lds, st, d, t, ntiles);
+    }
+    xmc_note_kernel("wtile_kernel<%d>", d.ntaps);
     XMC_LAUNCH_CHECK();
     return 0;
 }
@@ -925,7 +933,7 @@ static int tile_plan(const XmcConvDesc* d, TileCfg* t) {
     if (d->ntaps < 2) return 0;                       // 1x1: nothing to reuse, the gather kernel streams it
     static const bool no_wt = getenv("XMC_NO_WTILE2") != nullptr;
     const bool wide = d->CDw > 64 && d->CS > 64;
-    if (wide && (no_wt || d->CDw % 128 != 0 || d->CS % 64 != 0 || d->nclass != 1 || d->ntaps != 9)) return 0;   // gather kernel
+    if (wide && (no_wt || d->CDw % 128 != 0 || d->CS % 64 != 0 || d->nclass != 1 || d->ntaps != 9)) return 0;   // gather kernel (the 4-class 2x2-tap form measured no faster: one patch per class)
     int TW = d->MW >= 32 ? 32 : 16;
     int TH = 256 / TW;
     if (d->MH % TH != 0 || d->MW % TW != 0) return 0;
