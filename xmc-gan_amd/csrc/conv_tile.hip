@@ -245,13 +245,16 @@ __global__ __launch_bounds__(256) void tile_kernel(const XmcConvDesc d, const Ti
 // epilogue runs straight from registers with 16-byte stores.  Tap loop fully unrolled when NTAPS > 0.
 // MC > 1: the MC output-parity classes of a stride-2 data gradient / fused upsample-conv are done by ONE workgroup from one
 // staged patch (the union of their halos) instead of MC launches that each stage the same pixels: the source is read once.
-template <int BN, int SLAB, int NTAPS, int MC>
+// SA == 2: stride-2 forward (the 4x4 stride-2 layer of a discriminator block with <= 64 channels): tiles of 8x16 output pixels
+// (two pixel blocks per compute wave), the (2*8+2) x (2*16+2) source patch stored as two column-parity planes per patch row so
+// that the pixels of consecutive output columns for a fixed tap are consecutive (and bank-conflict free) LDS rows.
+template <int BN, int SLAB, int NTAPS, int MC, int SA = 1>
 __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const TileCfg t, int ntiles) {
     constexpr int NS = 256;                      // threads per role
-    constexpr int TM = 4, TN = BN / 16;
+    constexpr int TM = SA == 1 ? 4 : 2, TN = BN / 16;
     constexpr int cps = SLAB / 8;
     constexpr int pstride = SLAB * 2 + 32;
-    constexpr int PIT = 384 * cps / NS;          // patch units per staging thread: patches of up to 384 pixels
+    constexpr int PIT = ((SA == 1 ? 384 : 18 * 34) * cps + NS - 1) / NS;     // patch units per staging thread (patches of <= 384 / 612 pixels)
     constexpr int UPL = BN / 32;
     constexpr int S = SLAB / 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -269,7 +272,8 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
     if (tid < XMC_MAX_TAPS) {
         const int sl = tid < MC * d.ntaps ? tid : 0;
         const int c = MC > 1 ? sl / d.ntaps : cls, tt = MC > 1 ? sl % d.ntaps : sl;
-        s_toff[tid] = ((d.dh[c][tt] - dh0) * PW + (d.dw[c][tt] - dw0)) * pstride;
+        const int th = d.dh[c][tt] - dh0, tw = d.dw[c][tt] - dw0;
+        s_toff[tid] = (SA == 1 ? th * PW + tw : (th * 2 + (tw & 1)) * (PW >> 1) + (tw >> 1)) * pstride;
     }
     const int cs_units = d.CS / 8;
     unsigned char* patch = smem;
@@ -309,7 +313,7 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
             const bool in = pp < PH * PW;
             inpatch |= in ? (1u << it) : 0u;
             psrc[it] = in ? ((dh0 + py) * d.SW + (dw0 + px)) * cs_units + pchunk : 0;
-            halo[it] = !in ? 0u : ((py < -dh0 ? 1u : 0u) | (py >= t.TH - dh0 ? 2u : 0u) | (px < -dw0 ? 4u : 0u) | (px >= t.TW - dw0 ? 8u : 0u));
+            halo[it] = !in ? 0u : ((py < -dh0 ? 1u : 0u) | (py >= t.TH * SA - dh0 ? 2u : 0u) | (px < -dw0 ? 4u : 0u) | (px >= t.TW * SA - dw0 ? 8u : 0u));
         }
         const bool has_pro = t.pro[0] != nullptr;
         u32x4 pv[PIT];
@@ -317,11 +321,11 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
         auto issue = [&](int tile) {
             const int img = tile / tpi, trem = tile - img * tpi;
             const int ty = trem / t.tiles_x, tx = trem - ty * t.tiles_x;
-            const int a0 = ty * t.TH, b0 = tx * t.TW;
+            const int a0 = ty * t.TH * SA, b0 = tx * t.TW * SA;        // tile origin in the source
             const int base = ((img * d.SH + a0) * d.SW + b0) * cs_units;
             // a halo row/column is outside the image only for tiles on that border (halo depth <= tile size)
-            const unsigned border = (a0 + dh0 < 0 ? 1u : 0u) | (a0 + t.TH + (PH - t.TH + dh0) > d.SH ? 2u : 0u) |
-                                    (b0 + dw0 < 0 ? 4u : 0u) | (b0 + t.TW + (PW - t.TW + dw0) > d.SW ? 8u : 0u);
+            const unsigned border = (a0 + dh0 < 0 ? 1u : 0u) | (a0 + PH + dh0 > d.SH ? 2u : 0u) |
+                                    (b0 + dw0 < 0 ? 4u : 0u) | (b0 + PW + dw0 > d.SW ? 8u : 0u);
             okmask = 0;
 #pragma unroll
             for (int it = 0; it < PIT; ++it) {
@@ -355,9 +359,14 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
 #pragma unroll
             for (int it = 0; it < PIT; ++it) {
                 const int pp = ppix0 + it * ppix_step;
+                int lp = pp;
+                if (SA == 2) {                    // patch pixel (py, px) -> row py, plane px & 1, column px >> 1
+                    const int py = pp / PW, px = pp - py * PW;
+                    lp = (py * 2 + (px & 1)) * (PW >> 1) + (px >> 1);
+                }
                 u32x4 v = pv[it];
                 if (!all_ok && !((okmask >> it) & 1)) v = u32x4{0, 0, 0, 0};       // padding (border tiles only)
-                if ((inpatch >> it) & 1) *reinterpret_cast<u32x4*>(patch + pp * pstride + pchunk * 16) = v;
+                if ((inpatch >> it) & 1) *reinterpret_cast<u32x4*>(patch + lp * pstride + pchunk * 16) = v;
             }
         };
         if (tile0 < ntiles) {
@@ -383,9 +392,9 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
         int abyte[TM], eoff[TM], roff[TM];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const int ml = wm * 64 + i * 16 + fr;
+            const int ml = wm * (16 * TM) + i * 16 + fr;
             const int ty = ml >> t.log2TW, tx = ml & (t.TW - 1);
-            abyte[i] = (ty * PW + tx) * pstride + fc * 16;
+            abyte[i] = ((SA == 1 ? ty * PW : 2 * ty * PW) + tx) * pstride + fc * 16;      // SA == 2: row 2*ty, plane 0, column tx
             eoff[i] = ((ty * d.DA) * d.DW + tx * d.DA) * cd8 + fc;
             roff[i] = (ty * d.MW + tx) * cd8 + fc;                // same pixel in the [N,MH,MW,CD] grid (res_mode 1)
         }
@@ -837,6 +846,18 @@ template <int BN>
 int launch_ptile(const XmcConvDesc& d, const TileCfg& t, hipStream_t st) {
     int maxpatch = 0;
     for (int z = 0; z < d.nclass; ++z) maxpatch = t.PH[z] * t.PW[z] > maxpatch ? t.PH[z] * t.PW[z] : maxpatch;
+    if (d.SA == 2) {                                                  // 4x4 stride 2, 32 input channels: 612-pixel patch in planes
+        const size_t lds2 = (size_t)((maxpatch * 96 + 15) & ~15) + (size_t)16 * BN * 96;
+        if (lds2 > XMC_MAX_DYN_LDS || t.slab != 32) return XMC_ESHAPE;
+        const int nt2 = d.N * t.tiles_y * t.tiles_x;
+        int g2 = 256 / (int)(d.CDw / BN);
+        if (g2 > nt2) g2 = nt2;
+        XMC_ALLOW_BIG_LDS((ptile3_kernel<BN, 32, 16, 1, 2>));
+        hipLaunchKernelGGL((ptile3_kernel<BN, 32, 16, 1, 2>), dim3(g2, d.CDw / BN, 1), dim3(512), lds2, st, d, t, nt2);
+        xmc_note_kernel("ptile3_kernel<%d, 32, 16, 1, 2>", BN);
+        XMC_LAUNCH_CHECK();
+        return 0;
+    }
     if (maxpatch > 384) return XMC_ESHAPE;                            // staging registers: PIT * 256 / cps pixels
     const int pstride = t.slab * 2 + 32;
     const size_t pb = (size_t)((maxpatch * pstride + 15) & ~15);
@@ -928,14 +949,17 @@ int launch_wtile(const XmcConvDesc& d, const TileCfg& t, hipStream_t st) {
 
 // Returns 1 if the descriptor is eligible for the halo-tile kernel (and fills cfg), 0 otherwise.
 static int tile_plan(const XmcConvDesc* d, TileCfg* t) {
-    if (d->dtype != XMC_BF16 || d->SA != 1 || d->src_shift != 0) return 0;
+    if (d->dtype != XMC_BF16 || d->src_shift != 0) return 0;
+    static const bool no_s2 = getenv("XMC_NO_PTILE_S2") != nullptr;
+    const bool s2 = d->SA == 2;                       // stride-2 forward: weights-resident persistent kernel only
+    if (d->SA != 1 && !(s2 && !no_s2 && d->nclass == 1 && d->ntaps == 16 && d->CS == 32 && d->CDw <= 64 && d->DA == 1)) return 0;
     if (d->CS % 32 != 0 || d->MW % 16 != 0) return 0;
     if (d->ntaps < 2) return 0;                       // 1x1: nothing to reuse, the gather kernel streams it
     static const bool no_wt = getenv("XMC_NO_WTILE2") != nullptr;
     const bool wide = d->CDw > 64 && d->CS > 64;
     if (wide && (no_wt || d->CDw % 128 != 0 || d->CS % 64 != 0 || d->nclass != 1 || d->ntaps != 9)) return 0;   // gather kernel (the 4-class 2x2-tap form measured no faster: one patch per class)
-    int TW = d->MW >= 32 ? 32 : 16;
-    int TH = 256 / TW;
+    int TW = (d->MW >= 32 && !s2) ? 32 : 16;
+    int TH = s2 ? 8 : 256 / TW;
     if (d->MH % TH != 0 || d->MW % TW != 0) return 0;
     t->TH = TH; t->TW = TW; t->log2TW = TW == 32 ? 5 : 4;
     t->tiles_y = d->MH / TH; t->tiles_x = d->MW / TW;
@@ -948,8 +972,8 @@ static int tile_plan(const XmcConvDesc* d, TileCfg* t) {
             wmin = w < wmin ? w : wmin; wmax = w > wmax ? w : wmax;
         }
         t->dh0[z] = hmin; t->dw0[z] = wmin;
-        t->PH[z] = TH + (hmax - hmin); t->PW[z] = TW + (wmax - wmin);
-        if (t->PH[z] * t->PW[z] > 12 * (256 / (t->slab / 8))) return 0;   // staging registers (PIT)
+        t->PH[z] = d->SA * (TH - 1) + (hmax - hmin + 1); t->PW[z] = d->SA * (TW - 1) + (wmax - wmin + 1);
+        if (s2 ? (t->PH[z] > 18 || t->PW[z] > 34 || (t->PW[z] & 1)) : (t->PH[z] * t->PW[z] > 12 * (256 / (t->slab / 8)))) return 0;   // staging registers (PIT)
     }
     {
         int hmin = 127, hmax = -128, wmin = 127, wmax = -128;
@@ -981,6 +1005,7 @@ int xmc_conv_tile_try(const XmcConvDesc* d, const float* const* pro, void* strea
         rc = d->CDw == 64 ? launch_ptile<64>(*d, t, st) : launch_ptile<32>(*d, t, st);
         if (rc != XMC_ESHAPE) return rc;
     }
+    if (d->SA != 1) return 1;                         // stride 2 exists only in the persistent kernel
     if (d->CDw % 128 == 0) rc = launch_tile<128, 2, 2>(*d, t, st);
     else if (d->CDw % 64 == 0) rc = launch_tile<64, 4, 1>(*d, t, st);
     else rc = launch_tile<32, 4, 1>(*d, t, st);
