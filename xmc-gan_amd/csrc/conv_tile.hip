@@ -408,7 +408,8 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
             for (int c = 0; c < 8; ++c) bias8[u][c] = (d.bias && ch0 + u * 32 < d.CD) ? d.bias[ch0 + u * 32 + c] : 0.f;
         // one uniform decision instead of a chain of branches per stored unit
         const bool fast = d.out_dtype == XMC_BF16 && d.res == nullptr && d.mask == nullptr && d.alpha_dev == nullptr &&
-                          (d.act == XMC_ACT_NONE || d.act == XMC_ACT_LRELU);
+                          (d.act == XMC_ACT_NONE || d.act == XMC_ACT_LRELU || d.act == XMC_ACT_TANH);
+        const bool do_tanh = d.act == XMC_ACT_TANH;
         const float slope = d.act == XMC_ACT_LRELU ? XMC_LRELU : 1.f;
         __syncthreads();                          // weights + first patch staged
         int toffr[NTAPS > 0 ? MC * NTAPS : 1];
@@ -505,6 +506,12 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
                                 const float x0 = acc[i][2 * u][q] + bias8[u][q], x1 = acc[i][2 * u + 1][q] + bias8[u][4 + q];
                                 o[q] = (__bf16)fmaxf(x0, x0 * slope);
                                 o[4 + q] = (__bf16)fmaxf(x1, x1 * slope);
+                            }
+                        } else if (do_tanh) {     // generator output layer (df_gan.py:88-90)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                o[q] = (__bf16)tanhf(acc[i][2 * u][q] + bias8[u][q]);
+                                o[4 + q] = (__bf16)tanhf(acc[i][2 * u + 1][q] + bias8[u][4 + q]);
                             }
                         } else {
 #pragma unroll

@@ -247,7 +247,7 @@ int xmc_conv_wgrad_tile_try(const XmcConvDesc* d, float* dwp, float* dbias, void
     // the split-K kernel (166 vs 230 TF/s); it runs with 8 waves instead (below)
     WT_CASE(1, 2) WT_CASE(1, 4) WT_CASE(2, 1) WT_CASE(2, 2) WT_CASE(2, 4) WT_CASE(4, 1) WT_CASE(4, 2)
     static const bool no44 = getenv("XMC_NO_WT44") != nullptr;
-    if (nco == 4 && nci == 4 && !no44) return launch_wt<4, 4, 512, 1, 9, 2>(*d, dwp, dbias, t, st);   // 8 waves: 72 accumulator registers per lane
+    if (nco == 4 && nci == 4 && !no44) return launch_wt<4, 4, 512, 1, 9, 4>(*d, dwp, dbias, t, st);   // all 4 Cout blocks per wave: 0.9 LDS reads per MFMA   // 8 waves: 72 accumulator registers per lane
 #undef WT_CASE
     return 1;
 }
