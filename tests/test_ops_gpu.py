@@ -83,6 +83,9 @@ CONV_CASES = [
     # all-taps weight gradient of the 4x4 stride-2 layers with few channels (two column-parity planes in LDS)
     (32, 64, 4, 2, 1, 64, 2),      # resD block 0 shape: 64 co x 32 ci x 16 taps, 8 waves
     (16, 32, 4, 2, 1, 64, 3),      # 2 x 1 channel blocks, 4 waves
+    # streaming 1x1 kernel (conv_thin.hip pw1x1): >= 16 k pixels, Cin <= 128, Cout <= 128
+    (32, 64, 1, 1, 0, 64, 4),      # shortcut conv of resD block 0 (on the pooled input): one K step
+    (64, 128, 1, 1, 0, 32, 16),    # two K steps, 8 row blocks; its dgrad: four K steps, 4 row blocks
 ]
 
 

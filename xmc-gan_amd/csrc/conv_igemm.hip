@@ -288,6 +288,7 @@ int dispatch(const XmcConvDesc& d, hipStream_t st) {
 
 int xmc_conv_tile_try(const XmcConvDesc* d, const float* const* pro, void* stream);   // conv_tile.hip
 int xmc_conv_thin_try(const XmcConvDesc* d, void* stream);                            // conv_thin.hip
+int xmc_conv_pw1x1_try(const XmcConvDesc* d, void* stream);                           // conv_thin.hip
 
 extern "C" int xmc_conv_igemm(const XmcConvDesc* d, void* stream) {
     if (!d || !d->src || !d->wpk || !d->dst) return XMC_EINVAL;
@@ -306,6 +307,8 @@ extern "C" int xmc_conv_igemm(const XmcConvDesc* d, void* stream) {
     static const bool no_tile = getenv("XMC_NO_TILE") != nullptr;
     if (!no_tile) {                       // streaming kernel for 8-channel sources, halo-tile kernels for unit-stride bf16 layers
         int rc = xmc_conv_thin_try(d, stream);
+        if (rc <= 0) return rc;
+        rc = xmc_conv_pw1x1_try(d, stream);
         if (rc <= 0) return rc;
         rc = xmc_conv_tile_try(d, nullptr, stream);
         if (rc <= 0) return rc;

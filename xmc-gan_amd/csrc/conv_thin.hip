@@ -133,6 +133,79 @@ __global__ __launch_bounds__(256) void thin_in_kernel(const XmcConvDesc d, const
     }
 }
 
+
+// 1x1 convolution with few channels (the discriminator's shortcut convolutions on the pooled input, df_gan.py:280,286-291, and
+// their data gradients): nothing to stage -- a lane's 16-byte unit of a pixel IS its K-fragment, so the source goes straight
+// from global memory into the MFMA B operand (16 pixels x 64 bytes per wave load, fully coalesced), the weights (<= 16
+// fragments) live in registers, and the result leaves in 64-byte-per-pixel contiguous stores.  Pure stream: HBM bound.
+template <int KS, int TN>                     // KS = Cin / 32 K-steps, TN = Cout(padded) / 16 row blocks
+__global__ __launch_bounds__(256) void pw1x1_kernel(const XmcConvDesc d, int ngroups) {
+    const int lane = threadIdx.x & 63, fr = lane & 15, fc = lane >> 4;
+    const int cs_units = d.CS >> 3, cd8 = d.CD >> 3;
+    const u32x4* __restrict__ src16 = reinterpret_cast<const u32x4*>(d.src);
+    const u32x4* __restrict__ w16 = reinterpret_cast<const u32x4*>(d.wpk);
+    bf16x8* __restrict__ dst8 = reinterpret_cast<bf16x8*>(d.dst);
+    u32x4 wf[KS][TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int lrow = (j >> 1) * 32 + (fr >> 2) * 8 + (j & 1) * 4 + (fr & 3);      // see conv_tile.hip: 64-byte stores per pixel
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) wf[ks][j] = w16[((size_t)d.wi[0][0] * d.CDw + lrow) * cs_units + ks * 4 + fc];
+    }
+    float bias8[TN / 2][8];
+#pragma unroll
+    for (int u = 0; u < TN / 2; ++u)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) bias8[u][c] = (d.bias && u * 32 + fc * 8 < d.CD) ? d.bias[u * 32 + fc * 8 + c] : 0.f;
+    const float slope = d.act == XMC_ACT_LRELU ? XMC_LRELU : 1.f;
+    const int wave_g = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    constexpr int UNR = 4;                     // pixel groups in flight per wave
+    for (int g0 = wave_g * UNR; g0 < ngroups; g0 += nwaves * UNR) {
+        u32x4 pf[UNR][KS];
+#pragma unroll
+        for (int r = 0; r < UNR; ++r) {
+            const int g = g0 + r < ngroups ? g0 + r : ngroups - 1;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) pf[r][ks] = src16[(size_t)(g * 16 + fr) * cs_units + ks * 4 + fc];
+        }
+#pragma unroll
+        for (int r = 0; r < UNR; ++r) {
+            if (g0 + r >= ngroups) break;
+            f32x4 acc[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[ks][j]), __builtin_bit_cast(bf16x8, pf[r][ks]), acc[j], 0, 0, 0);
+            const size_t pix = (size_t)(g0 + r) * 16 + fr;
+#pragma unroll
+            for (int u = 0; u < TN / 2; ++u) {
+                if (u * 32 + fc * 8 >= d.CD) continue;
+                bf16x8 o;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float x0 = acc[2 * u][q] + bias8[u][q], x1 = acc[2 * u + 1][q] + bias8[u][4 + q];
+                    o[q] = (__bf16)fmaxf(x0, x0 * slope);
+                    o[4 + q] = (__bf16)fmaxf(x1, x1 * slope);
+                }
+                dst8[pix * cd8 + u * 4 + fc] = o;
+            }
+        }
+    }
+}
+
+template <int KS, int TN>
+int launch_pw(const XmcConvDesc& d, int ngroups, hipStream_t st) {
+    int nb = (ngroups + 4 * 4 - 1) / (4 * 4);           // 4 waves per block, 4 groups per wave and iteration
+    if (nb > 256 * 8) nb = 256 * 8;
+    hipLaunchKernelGGL((pw1x1_kernel<KS, TN>), dim3(nb), dim3(256), 0, st, d, ngroups);
+    xmc_note_kernel("pw1x1_kernel<%d, %d>", KS, TN);
+    XMC_LAUNCH_CHECK();
+    return 0;
+}
+
 }  // namespace
 
 // 0 = launched, 1 = not this kernel's case, < 0 = error
@@ -169,4 +242,26 @@ int xmc_conv_thin_try(const XmcConvDesc* d, void* stream) {
     xmc_note_kernel("thin_in_kernel<%d>", d->CDw);
     XMC_LAUNCH_CHECK();
     return 0;
+}
+
+// 0 = launched, 1 = not this kernel's case, < 0 = error
+int xmc_conv_pw1x1_try(const XmcConvDesc* d, void* stream) {
+    static const bool off = getenv("XMC_NO_PW1X1") != nullptr;
+    if (off) return 1;
+    if (d->dtype != XMC_BF16 || d->out_dtype != XMC_BF16) return 1;
+    if (d->ntaps != 1 || d->nclass != 1 || d->SA != 1 || d->DA != 1 || d->src_shift != 0) return 1;
+    if (d->dh[0][0] != 0 || d->dw[0][0] != 0 || d->dph[0] != 0 || d->dpw[0] != 0) return 1;
+    if (d->SH != d->MH || d->SW != d->MW || d->DH != d->MH || d->DW != d->MW) return 1;
+    if (d->res || d->mask || d->alpha_dev || (d->act != XMC_ACT_NONE && d->act != XMC_ACT_LRELU)) return 1;
+    if (d->CS % 32 != 0 || d->CS > 128 || d->CDw % 32 != 0 || d->CDw > 128 || d->CD % 8 != 0) return 1;
+    const int ks = d->CS / 32, tn = d->CDw / 16;
+    if (ks * tn > 16 || ks == 3) return 1;
+    const int64_t M = (int64_t)d->N * d->MH * d->MW;
+    if (M % 16 != 0 || M / 16 >= (1ll << 31) || M < 16 * 1024) return 1;
+    const int ngroups = (int)(M / 16);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define PW_CASE(K, T) if (ks == K && tn == T) return launch_pw<K, T>(*d, ngroups, st);
+    PW_CASE(1, 2) PW_CASE(1, 4) PW_CASE(1, 8) PW_CASE(2, 2) PW_CASE(2, 4) PW_CASE(2, 8) PW_CASE(4, 2) PW_CASE(4, 4)
+#undef PW_CASE
+    return 1;
 }
