@@ -137,6 +137,8 @@ int xmc_tanh_bwd(const void* dy, const void* y, void* dx, int64_t n, int dtype, 
 int xmc_axpby(const void* a, const void* b, const float* alpha_dev, void* y, int64_t n, int dtype, void* stream);
 /* y[n,2h+i,2w+j] = a[n,h,w] + (*alpha_dev) * b[n,2h+i,2w+j]   (a is [N,H,W,C], b and y [N,2H,2W,C]) */
 int xmc_axpby_up(const void* a, const void* b, const float* alpha_dev, void* y, int N, int H, int W, int C, int dtype, void* stream);
+/* same with LeakyReLU(0.2) applied to the sum (the generator's last block feeds LeakyReLU -> conv_img, df_gan.py:84-86) */
+int xmc_axpby_up_lrelu(const void* a, const void* b, const float* alpha_dev, void* y, int N, int H, int W, int C, int dtype, void* stream);
 /* y = (*alpha_dev) * x */
 int xmc_scale(const void* x, const float* alpha_dev, void* y, int64_t n, int dtype, void* stream);
 /* *out (+)= sum(a*b)  (f32 scalar; out zeroed by caller when accumulate==0 is not desired) */
@@ -147,7 +149,8 @@ int xmc_scale_mask_dot(const void* dy, const void* ref, const float* alpha_dev, 
 /* Backward of y = a + alpha*b (up == 0; N,H,W,C = shape of dy) or y = up2(a) + alpha*b (up == 1; N,H,W,C = shape of a, dy and
  * b are [N,2H,2W,C]) in one pass: db = alpha*dy, da = 2x2 sum pool of dy (up only), dot += <dy,b>; dot is f32[1], zeroed by the caller */
 int xmc_axpby_bwd(const void* dy, const void* b, const float* alpha_dev, void* db, void* da, float* dot,
-                  int N, int H, int W, int C, int up, int dtype, void* stream);
+                  int N, int H, int W, int C, int up, const void* ymask /* NULL, or y of the LeakyReLU'd form: dy *= LeakyReLU'(y) first
+                  (then da is also written in the plain form: the masked dy) */, int dtype, void* stream);
 /* out[c] = sum over rows of x[r][c]         (bias gradients) ; out is f32 [C], zeroed by the caller */
 int xmc_colsum(const void* x, float* out, int64_t rows, int C, int dtype, void* stream);
 /* 2x2 average pool (F.avg_pool2d(x,2) df_gan.py:290) and its adjoint (nearest x2 upsample * scale) */

@@ -424,7 +424,7 @@ __global__ void pack_upconv_kernel(const float* w, void* wpk, int Co, int Ci, in
 }
 // y[n,2h+i,2w+j,:] = a[n,h,w,:] + alpha * b[n,2h+i,2w+j,:]      (up(shortcut) + gamma*residual without materialising up())
 template <int DT>
-__global__ void axpby_up_kernel(const void* a, const void* b, const float* alpha, void* y, int N, int H, int W, int C8) {
+__global__ void axpby_up_kernel(const void* a, const void* b, const float* alpha, void* y, int N, int H, int W, int C8, int lrelu) {
     const float al = *alpha;
     const int OH = 2 * H, OW = 2 * W;
     const int64_t total = (int64_t)N * OH * OW * C8;
@@ -439,6 +439,10 @@ __global__ void axpby_up_kernel(const void* a, const void* b, const float* alpha
         Vec8<DT>::load(b, idx, v);
 #pragma unroll
         for (int k = 0; k < 8; ++k) u[k] += al * v[k];
+        if (lrelu) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) u[k] = lrelu_f(u[k]);
+        }
         Vec8<DT>::store(y, idx, u);
     }
 }
@@ -448,7 +452,7 @@ __global__ void axpby_up_kernel(const void* a, const void* b, const float* alpha
 // instead of a scale pass, a pool pass and a dot pass (reads of dy: 3 -> 1).
 template <int DT>
 __global__ void axpby_bwd_kernel(const void* dy, const void* b, const float* alpha, void* db, void* da, float* dot,
-                                 int N, int H, int W, int C8, int up) {
+                                 int N, int H, int W, int C8, int up, const void* ymask) {
     const float al = *alpha;
     float s = 0.f;
     const int64_t total = (int64_t)N * H * W * C8;                  // low-resolution positions (x channel units)
@@ -457,6 +461,13 @@ __global__ void axpby_bwd_kernel(const void* dy, const void* b, const float* alp
             float u[8], v[8], o[8];
             Vec8<DT>::load(dy, idx, u);
             Vec8<DT>::load(b, idx, v);
+            if (ymask) {                              // y = LeakyReLU(a + alpha*b): dy <- dy * LeakyReLU'(y)
+                float mk[8];
+                Vec8<DT>::load(ymask, idx, mk);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) u[k] *= lrelu_slope(mk[k]);
+                Vec8<DT>::store(da, idx, u);          // plain form with a mask: da is the masked dy
+            }
 #pragma unroll
             for (int k = 0; k < 8; ++k) { s += u[k] * v[k]; o[k] = al * u[k]; }
             Vec8<DT>::store(db, idx, o);
@@ -476,6 +487,12 @@ __global__ void axpby_bwd_kernel(const void* dy, const void* b, const float* alp
                 float u[8], v[8], o[8];
                 Vec8<DT>::load(dy, hi, u);
                 Vec8<DT>::load(b, hi, v);
+                if (ymask) {
+                    float mk[8];
+                    Vec8<DT>::load(ymask, hi, mk);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) u[k] *= lrelu_slope(mk[k]);
+                }
 #pragma unroll
                 for (int k = 0; k < 8; ++k) { s += u[k] * v[k]; o[k] = al * u[k]; sum[k] += u[k]; }
                 Vec8<DT>::store(db, hi, o);
@@ -757,23 +774,29 @@ extern "C" int xmc_pack_weight_upconv(const float* w, void* wpk, int Co, int Ci,
     return 0;
 }
 extern "C" int xmc_axpby_bwd(const void* dy, const void* b, const float* alpha, void* db, void* da, float* dot,
-                             int N, int H, int W, int C, int up, int dtype, void* s) {
-    if (!dy || !b || !alpha || !db || !dot || C % 8 || (up && !da)) return XMC_EINVAL;
+                             int N, int H, int W, int C, int up, const void* ymask, int dtype, void* s) {
+    if (!dy || !b || !alpha || !db || !dot || C % 8 || ((up || ymask) && !da)) return XMC_EINVAL;
     int64_t total = (int64_t)N * H * W * (C / 8);
     dim3 g(nblocks(total, NT, 2048)), blk(NT);
-    if (dtype == XMC_BF16) hipLaunchKernelGGL((axpby_bwd_kernel<XMC_BF16>), g, blk, 0, ST(s), dy, b, alpha, db, da, dot, N, H, W, C / 8, up);
-    else if (dtype == XMC_F32) hipLaunchKernelGGL((axpby_bwd_kernel<XMC_F32>), g, blk, 0, ST(s), dy, b, alpha, db, da, dot, N, H, W, C / 8, up);
+    if (dtype == XMC_BF16) hipLaunchKernelGGL((axpby_bwd_kernel<XMC_BF16>), g, blk, 0, ST(s), dy, b, alpha, db, da, dot, N, H, W, C / 8, up, ymask);
+    else if (dtype == XMC_F32) hipLaunchKernelGGL((axpby_bwd_kernel<XMC_F32>), g, blk, 0, ST(s), dy, b, alpha, db, da, dot, N, H, W, C / 8, up, ymask);
+    else return XMC_EINVAL;
+    XMC_LAUNCH_CHECK();
+    return 0;
+}
+static int axpby_up_impl(const void* a, const void* b, const float* alpha, void* y, int N, int H, int W, int C, int lrelu, int dtype, void* s) {
+    if (!alpha || C % 8) return XMC_EINVAL;
+    int64_t total = (int64_t)N * 4 * H * W * (C / 8);
+    dim3 g(nblocks(total)), blk(NT);
+    if (dtype == XMC_BF16) hipLaunchKernelGGL((axpby_up_kernel<XMC_BF16>), g, blk, 0, ST(s), a, b, alpha, y, N, H, W, C / 8, lrelu);
+    else if (dtype == XMC_F32) hipLaunchKernelGGL((axpby_up_kernel<XMC_F32>), g, blk, 0, ST(s), a, b, alpha, y, N, H, W, C / 8, lrelu);
     else return XMC_EINVAL;
     XMC_LAUNCH_CHECK();
     return 0;
 }
 extern "C" int xmc_axpby_up(const void* a, const void* b, const float* alpha, void* y, int N, int H, int W, int C, int dtype, void* s) {
-    if (!alpha || C % 8) return XMC_EINVAL;
-    int64_t total = (int64_t)N * 4 * H * W * (C / 8);
-    dim3 g(nblocks(total)), blk(NT);
-    if (dtype == XMC_BF16) hipLaunchKernelGGL((axpby_up_kernel<XMC_BF16>), g, blk, 0, ST(s), a, b, alpha, y, N, H, W, C / 8);
-    else if (dtype == XMC_F32) hipLaunchKernelGGL((axpby_up_kernel<XMC_F32>), g, blk, 0, ST(s), a, b, alpha, y, N, H, W, C / 8);
-    else return XMC_EINVAL;
-    XMC_LAUNCH_CHECK();
-    return 0;
+    return axpby_up_impl(a, b, alpha, y, N, H, W, C, 0, dtype, s);
+}
+extern "C" int xmc_axpby_up_lrelu(const void* a, const void* b, const float* alpha, void* y, int N, int H, int W, int C, int dtype, void* s) {
+    return axpby_up_impl(a, b, alpha, y, N, H, W, C, 1, dtype, s);
 }

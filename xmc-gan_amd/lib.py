@@ -52,7 +52,8 @@ _SIGS = {
     "xmc_tanh_bwd": [vp, vp, vp, i64, i32, vp],
     "xmc_axpby": [vp, vp, vp, vp, i64, i32, vp],
     "xmc_scale_mask_dot": [vp, vp, vp, vp, vp, i64, i32, vp],
-    "xmc_axpby_bwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "xmc_axpby_bwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, i32, vp],
+    "xmc_axpby_up_lrelu": [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "xmc_scale": [vp, vp, vp, i64, i32, vp],
     "xmc_dot": [vp, vp, vp, i64, i32, vp],
     "xmc_colsum": [vp, vp, i64, i32, i32, vp],

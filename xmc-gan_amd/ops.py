@@ -583,16 +583,17 @@ class UpConvFn(torch.autograd.Function):
         return dx, dw, db, None
 
 
-def _axpby_bwd_fused(dy, b, alpha, up):
-    """(da, db, dalpha) of a + alpha*b / up2(a) + alpha*b from one pass over dy and b (not differentiable again)."""
+def _axpby_bwd_fused(dy, b, alpha, up, ymask=None):
+    """(da, db, dalpha) of a + alpha*b / up2(a) + alpha*b from one pass over dy and b (not differentiable again).
+    ``ymask``: the forward applied LeakyReLU to the sum; dy is multiplied by LeakyReLU'(y) first."""
     dy = dy.contiguous()
     N, OH, OW, Cc = dy.shape
     H, W = (OH // 2, OW // 2) if up else (OH, OW)
     al = alpha.detach().reshape(-1).float()
     db = torch.empty_like(dy)
-    da = torch.empty((N, H, W, Cc), dtype=dy.dtype, device=dy.device) if up else None
+    da = torch.empty((N, H, W, Cc), dtype=dy.dtype, device=dy.device) if (up or ymask is not None) else None
     dot = torch.zeros(1, dtype=torch.float32, device=dy.device)
-    L.call("xmc_axpby_bwd", _p(dy), _p(b), _p(al), _p(db), _p(da), _p(dot), N, H, W, Cc, 1 if up else 0, _code(dy.dtype), _st())
+    L.call("xmc_axpby_bwd", _p(dy), _p(b), _p(al), _p(db), _p(da), _p(dot), N, H, W, Cc, 1 if up else 0, _p(ymask), _code(dy.dtype), _st())
     return da, db, dot.reshape(alpha.shape).to(alpha.dtype)
 
 
@@ -600,25 +601,28 @@ class AxpbyUpFn(torch.autograd.Function):
     """up2(a) + alpha*b without materialising up2(a): the block output `upsample(shortcut) + gamma*residual`."""
 
     @staticmethod
-    def forward(ctx, a, b, alpha):
+    def forward(ctx, a, b, alpha, lrelu=False):
         a, b = a.contiguous(), b.contiguous()
         N, H, W, Cc = a.shape
         assert b.shape == (N, 2 * H, 2 * W, Cc)
         al = alpha.detach().reshape(-1).float()
         y = torch.empty_like(b)
-        L.call("xmc_axpby_up", _p(a), _p(b), _p(al), _p(y), N, H, W, Cc, _code(a.dtype), _st())
-        ctx.save_for_backward(b, alpha)
+        L.call("xmc_axpby_up_lrelu" if lrelu else "xmc_axpby_up", _p(a), _p(b), _p(al), _p(y), N, H, W, Cc, _code(a.dtype), _st())
+        ctx.lrelu = lrelu
+        ctx.save_for_backward(b, alpha, y if lrelu else None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        b, alpha = ctx.saved_tensors
-        if not torch.is_grad_enabled() and all(ctx.needs_input_grad) and fused_blocks():
-            return _axpby_bwd_fused(dy, b, alpha, up=True)      # first-order: one pass over dy and b
+        b, alpha, y = ctx.saved_tensors
+        if not torch.is_grad_enabled() and all(ctx.needs_input_grad[:3]) and fused_blocks():
+            return _axpby_bwd_fused(dy, b, alpha, up=True, ymask=y) + (None,)      # first-order: one pass over dy and b
+        if ctx.lrelu:
+            dy = MaskFn.apply(dy.contiguous(), y, 0.2)
         da = SumPool2Fn.apply(dy, 1.0) if ctx.needs_input_grad[0] else None
         db = ScaleFn.apply(dy, alpha) if ctx.needs_input_grad[1] else None
         dal = DotFn.apply(dy, b).reshape(alpha.shape) if ctx.needs_input_grad[2] else None
-        return da, db, dal
+        return da, db, dal, None
 
 
 def conv2d(x, w, b, geom, act=L.ACT_NONE, out_dtype=None):
@@ -1159,8 +1163,8 @@ def upconv3x3(x_lo, w, b, geom):
     return UpConvFn.apply(x_lo, w, b, geom)
 
 
-def axpby_up(a_lo, b_hi, alpha):
-    return AxpbyUpFn.apply(a_lo, b_hi, alpha)
+def axpby_up(a_lo, b_hi, alpha, lrelu=False):
+    return AxpbyUpFn.apply(a_lo, b_hi, alpha, lrelu)
 
 
 def affine_lrelu(x, g, b):

@@ -88,9 +88,10 @@ class NetG(nn.Module):
         out = self.proj_noise(noise.float(), out_dtype=ops.act_dtype())
         return out.view(noise.size(0), 4, 4, 8 * self.ngf)
 
-    def tail(self, out):
+    def tail(self, out, lrelu_done=False):
         """LeakyReLU -> Conv3x3(->3) -> Tanh (reference df_gan.py:84-88,101); tanh fused in the conv epilogue."""
-        out = ops.lrelu(out)
+        if not lrelu_done:
+            out = ops.lrelu(out)
         out = self.conv_out[1](out, act=ACT_TANH)
         return ops.to_nchw(out, 3)
 
@@ -113,17 +114,21 @@ class NetG(nn.Module):
         # through operators that commute with / absorb the upsample, so the 4x larger tensor is never written.
         pending_up = False
         fuse_up = os.environ.get("XMC_NO_UPCONV") is None
-        for gblock, m, ev in zip(self.upblocks, mods, events):
+        nblk = len(self.upblocks)
+        lrelu_done = False
+        for bi, (gblock, m, ev) in enumerate(zip(self.upblocks, mods, events)):
             main.wait_event(ev)
             for t in m:
                 t.record_stream(main)
-            out = gblock.forward_fused(out, m, pending_up)
+            last = bi == nblk - 1 and not gblock.upsample      # its output goes straight into the tail's LeakyReLU
+            out = gblock.forward_fused(out, m, pending_up, out_lrelu=last)
+            lrelu_done = last
             pending_up = gblock.upsample
             if pending_up and not fuse_up:
                 out, pending_up = ops.upsample2(out), False
         if pending_up:
             out = ops.upsample2(out)
-        return self.tail(out)
+        return self.tail(out, lrelu_done)
 
 
 class NetD(nn.Module):
@@ -224,17 +229,19 @@ class G_Block(nn.Module):
             out = ops.upsample2(out)
         return out
 
-    def forward_fused(self, x, mod, x_pending_up):
+    def forward_fused(self, x, mod, x_pending_up, out_lrelu=False):
         """Same function as ``forward`` on the logical input ``up2(x)`` when ``x_pending_up`` (else ``x``), returning the
         block output WITHOUT its trailing upsample.  With a pending upsample: the conditional affines and the 1x1 shortcut
         commute with nearest upsampling and run at low resolution, ``c1`` runs as the fused upsample+3x3 operator
         (4 parity classes of 2x2 taps: 4/9 of the MACs) and the shortcut is upsampled inside the final add."""
         if not x_pending_up:
-            return ops.axpby(self.shortcut(x), self.residual(x, None, mod), self.gamma)
+            out = ops.axpby(self.shortcut(x), self.residual(x, None, mod), self.gamma)
+            return ops.lrelu(out) if out_lrelu else out
         h = ops.affine2_lrelu(x, *mod[0:4])
         h = ops.upconv3x3(h, self.c1.weight, self.c1.bias, self.c1.geom)
         h = ops.affine2_lrelu(h, *mod[4:8])
-        return ops.axpby_up(self.shortcut(x), self.c2(h), self.gamma)
+        # out_lrelu: the tail's LeakyReLU (df_gan.py:84-85) applied while the block sum is written
+        return ops.axpby_up(self.shortcut(x), self.c2(h), self.gamma, lrelu=out_lrelu)
 
     def shortcut(self, x):
         return self.c_sc(x) if self.learnable_sc else x
