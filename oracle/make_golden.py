@@ -71,7 +71,10 @@ def golden_forward(name, yml, batch, seed, out_dir, **over):
         yml=yml, over=np.array([f"{k}={v}" for k, v in over.items()]), batch=batch, seed=seed,
         g_keys=shape_table(netG.state_dict()), d_keys=shape_table(netD.state_dict()),
         fake=fake.numpy(), feat=feat.numpy(), feat_fake_stats=stats(feat_f), logit=logit.numpy(),
-        img_emb=img_emb.numpy(), txt_emb=txt_emb.numpy(), psent=psent.numpy())
+        img_emb=img_emb.numpy(), txt_emb=txt_emb.numpy(), psent=psent.numpy(),
+        # spectral norm: the power-iteration buffers after these calls (each forward call in training mode updates them)
+        d_buf_names=np.array([n for n, _ in netD.named_buffers()]),
+        d_buf_after=np.stack([stats(b_) for _, b_ in netD.named_buffers()]) if len(list(netD.named_buffers())) else np.zeros((0, 5)))
     print(f"fwd_{name}: fake {tuple(fake.shape)} feat {tuple(feat.shape)}")
 
 
@@ -208,6 +211,8 @@ def golden_step(name, yml, batch, steps, seed, out_dir, **over):
     rec["d_names"] = np.array([n for n, _ in netD.named_parameters()])
     rec["g_final"] = np.stack([stats(p) for _, p in netG.named_parameters()])
     rec["d_final"] = np.stack([stats(p) for _, p in netD.named_parameters()])
+    rec["d_buf_names"] = np.array([n for n, _ in netD.named_buffers()])
+    rec["d_buf_final"] = np.stack([stats(b_) for _, b_ in netD.named_buffers()]) if len(list(netD.named_buffers())) else np.zeros((0, 5))
     np.savez_compressed(os.path.join(out_dir, f"step_{name}.npz"), **rec)
     print(f"step_{name}: {len(log)} optimizer steps, scalars:",
           [(n, round(v, 4)) for n, v in scal[: 12]])
@@ -216,8 +221,14 @@ def golden_step(name, yml, batch, steps, seed, out_dir, **over):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(HERE), "tests", "golden"))
+    ap.add_argument("--only", default="", help="regenerate only the fixtures whose name contains this substring")
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
+    if a.only:                                    # filter: wrap the generators
+        g = globals()
+        for fn in ("golden_forward", "golden_step"):
+            g[fn] = (lambda f: (lambda name, *args, **kw: f(name, *args, **kw) if a.only in name else None))(g[fn])
+        g["golden_labels"] = (lambda f: (lambda *args, **kw: f(*args, **kw) if a.only in "labels" else None))(g["golden_labels"])
     N8 = {"TRAIN.NCH": 8}
     golden_labels(a.out)
     golden_forward("df64_nch32", "df_gan_damsm.yml", 2, 11, a.out)
@@ -239,6 +250,12 @@ def main():
     golden_step("df64_ncrit2", "concept_in_df_gan_sbert_n2_damsm.yml", 3, 2, 24, a.out, **N8)
     golden_step("cout64", "concept_out_df_gan_sbert_damsm_nomagp.yml", 3, 1, 25, a.out, **N8)
     golden_step("df128_nomagp", "df_gan_damsm_nomagp.yml", 2, 1, 26, a.out, **{"IMG.SIZE": 128, **N8})
+    # DISC.SPEC_NORM: True (config/gan.py:62 default): weight_orig / weight_u / weight_v keys, one power
+    # iteration per forward call
+    SN = {"DISC.SPEC_NORM": True, **N8}
+    golden_forward("sn64_nch8", "df_gan_damsm.yml", 2, 31, a.out, **SN)
+    golden_step("sn64_nomagp", "df_gan_damsm_nomagp.yml", 4, 2, 32, a.out, **SN)
+    golden_step("sn64_magp", "df_gan_damsm.yml", 3, 1, 33, a.out, **SN)
 
 
 if __name__ == "__main__":

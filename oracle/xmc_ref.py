@@ -54,6 +54,7 @@ class Hyper:
     smooth_sent: float = 1.0
     smooth_disc: float = 1.0
     n_critic: int = 1
+    spec_norm: bool = False       # cfg.DISC.SPEC_NORM (every shipped yml: False; config/gan.py:62 default True)
     g_lr: float = 1e-4
     g_betas: tuple = (0.0, 0.9)
     d_lr: float = 4e-4
@@ -73,6 +74,7 @@ class Hyper:
             rmis=g(T, "RMIS_LOSS"), magp=g(T, "MAGP"), enc_sent=g(E, "SENT"), enc_disc=g(E, "DISC"),
             b_global=g(E, "B_GLOBAL"), smooth_mismatch=g(S, "MISMATCH"), smooth_global=g(S, "GLOBAL"),
             smooth_sent=g(S, "SENT"), smooth_disc=g(S, "DISC"), n_critic=g(T, "N_CRITIC"),
+            spec_norm=bool(g(D, "SPEC_NORM")),
             g_lr=g(O, "G_LR"), g_betas=(g(O, "G_BETA1"), g(O, "G_BETA2")),
             d_lr=g(O, "D_LR"), d_betas=(g(O, "D_BETA1"), g(O, "D_BETA2")))
 
@@ -162,6 +164,21 @@ def netd_shapes(h: Hyper):
         cond = h.text_dim
     s["COND_DNET.joint_conv.0.weight"] = (2 * h.nch, ndf16 + cond, 3, 3)
     s["COND_DNET.joint_conv.2.weight"] = (1, 2 * h.nch, 4, 4)
+    if h.spec_norm:
+        # torch.nn.utils.spectral_norm (modules.py:16-17,31-32): `weight` becomes the parameter `weight_orig` plus the
+        # power-iteration buffers `weight_u` [out] and `weight_v` [in * kh * kw]
+        sn = {}
+        for k, shp in s.items():
+            if k.endswith(".weight"):
+                n_in = 1
+                for d_ in shp[1:]:
+                    n_in *= d_
+                sn[k + "_orig"] = shp
+                sn[k + "_u"] = (shp[0],)
+                sn[k + "_v"] = (n_in,)
+            else:
+                sn[k] = shp
+        s = sn
     return s
 
 
@@ -434,16 +451,36 @@ def gen_forward(P, h: Hyper, noise, sent_embs, **kw):
 # ----------------------------------------------------------------------------------------
 # DF_DISC forward (model/df_gan.py:125-132, 283-294) and COND_DNET (162-176)
 # ----------------------------------------------------------------------------------------
+def sn_weight(P, name, train=True, eps=1e-12):
+    """Effective weight of a layer: P[name], or -- when the layer is spectrally normalised (P has name + "_orig") -- what the
+    forward pre-hook of torch.nn.utils.spectral_norm computes (the legacy hook implementation the reference imports,
+    modules.py:3,16-17): in training mode ONE power iteration per forward call, v <- normalize(W^T u), u <- normalize(W v),
+    written back into the buffers; sigma = u . (W v) with u, v treated as constants; W / sigma."""
+    if name + "_orig" not in P:
+        return P[name]
+    W, u, v = P[name + "_orig"], P[name + "_u"], P[name + "_v"]
+    Wm = W.reshape(W.size(0), -1)
+    if train:
+        with torch.no_grad():
+            v_new = F.normalize(torch.mv(Wm.t(), u), dim=0, eps=eps)
+            u_new = F.normalize(torch.mv(Wm, v_new), dim=0, eps=eps)
+            v.copy_(v_new)
+            u.copy_(u_new)
+        u, v = u.clone(), v.clone()
+    sigma = torch.dot(u, torch.mv(Wm, v))
+    return W / sigma
+
+
 def netd_forward(P, h: Hyper, x):
     a = disc_arch(h.img_size, h.nch)
-    out = F.conv2d(x, P["conv_img.weight"], P["conv_img.bias"], 1, 1)
+    out = F.conv2d(x, sn_weight(P, "conv_img.weight"), P["conv_img.bias"], 1, 1)
     for i in range(1, a["depth"]):
         p = f"downblocks.{i - 1}"
-        r = F.leaky_relu(F.conv2d(out, P[f"{p}.conv_r.0.weight"], None, 2, 1), LRELU)
-        r = F.leaky_relu(F.conv2d(r, P[f"{p}.conv_r.2.weight"], None, 1, 1), LRELU)
+        r = F.leaky_relu(F.conv2d(out, sn_weight(P, f"{p}.conv_r.0.weight"), None, 2, 1), LRELU)
+        r = F.leaky_relu(F.conv2d(r, sn_weight(P, f"{p}.conv_r.2.weight"), None, 1, 1), LRELU)
         s = out
         if a["cin"][i] != a["cout"][i]:                     # learned_shortcut (df_gan.py:270,287)
-            s = F.conv2d(s, P[f"{p}.conv_s.weight"], P[f"{p}.conv_s.bias"])
+            s = F.conv2d(s, sn_weight(P, f"{p}.conv_s.weight"), P[f"{p}.conv_s.bias"])
         s = F.avg_pool2d(s, 2)
         out = s + P[f"{p}.gamma"] * r
     return out
@@ -453,15 +490,15 @@ def cond_dnet(P, h: Hyper, feat, sent_embs):
     """D_GET_LOGITS.forward (df_gan.py:162-176) -> [logit[B,1,1,1], img_emb, txt_emb]."""
     B = feat.size(0)
     out = F.avg_pool2d(feat, 4).view(B, -1)
-    has_proj = "COND_DNET.proj_match.weight" in P
+    has_proj = "COND_DNET.proj_match.weight" in P or "COND_DNET.proj_match.weight_orig" in P
     if h.img_match:
-        out = F.linear(out, P["COND_DNET.proj_match.weight"], P["COND_DNET.proj_match.bias"])
+        out = F.linear(out, sn_weight(P, "COND_DNET.proj_match.weight"), P["COND_DNET.proj_match.bias"])
     elif has_proj:
-        sent_embs = F.linear(sent_embs, P["COND_DNET.proj_match.weight"], P["COND_DNET.proj_match.bias"])
+        sent_embs = F.linear(sent_embs, sn_weight(P, "COND_DNET.proj_match.weight"), P["COND_DNET.proj_match.bias"])
     c = sent_embs.view(B, -1, 1, 1).repeat(1, 1, 4, 4)
     hc = torch.cat((feat, c), 1)
-    m = F.leaky_relu(F.conv2d(hc, P["COND_DNET.joint_conv.0.weight"], None, 1, 1), LRELU)
-    m = F.conv2d(m, P["COND_DNET.joint_conv.2.weight"])
+    m = F.leaky_relu(F.conv2d(hc, sn_weight(P, "COND_DNET.joint_conv.0.weight"), None, 1, 1), LRELU)
+    m = F.conv2d(m, sn_weight(P, "COND_DNET.joint_conv.2.weight"))
     return [m, out, sent_embs]
 
 
@@ -535,7 +572,10 @@ class AdamState:
 # one training iteration (train_gan.py:174-293)
 # ----------------------------------------------------------------------------------------
 def _leaves(P):
-    return {k: v.detach().clone().requires_grad_(not k.endswith(".norm")) for k, v in P.items()}
+    """Differentiable leaf copies of the parameters; the spectral-norm power-iteration buffers are SHARED (not copied), so the
+    in-place updates every forward call makes to them persist like the reference's module buffers do."""
+    return {k: (v if k.endswith((".weight_u", ".weight_v")) else v.detach().clone().requires_grad_(not k.endswith(".norm")))
+            for k, v in P.items()}
 
 
 def _grads(loss, P, retain=False):

@@ -84,6 +84,38 @@ def test_presets_load_and_modules_match_reference_state_dict(yml):
             or cfg.GEN.ENCODER_NAME != "DF_GEN"
 
 
+def test_spectral_norm_layers_mirror_the_legacy_hook_state():
+    """DISC.SPEC_NORM=True: parameters/buffers named and shaped as torch.nn.utils.spectral_norm leaves them
+    (model/modules.py:16-17,31-32), u/v drawn in its RNG order, ``weight`` a plain attribute."""
+    from xmc_gan.config import gan
+    import xmc_gan.train_gan as tg
+    from xmc_gan.model.modules import conv2d_nxn, linear
+    gan.reset_cfg()
+    gan.cfg_from_file(os.path.join(CFG_DIR, "df_gan_damsm.yml"))
+    gan.cfg.DISC.SPEC_NORM = True
+    h = X.Hyper.from_cfg(gan.cfg)
+    assert h.spec_norm
+    netD = tg._DISC_ARCH["DF_DISC"](gan.cfg, is_disc=True)
+    assert {k: tuple(v.shape) for k, v in netD.state_dict().items()} == X.netd_shapes(h)
+    names = {n for n, _ in netD.named_parameters()}
+    assert "conv_img.weight_orig" in names and not any(n.endswith(".weight") for n in names)
+    assert {n for n, _ in netD.named_buffers()} == {k for k in X.netd_shapes(h) if k.endswith(("_u", "_v"))}
+    for mk, ref in ((lambda: conv2d_nxn(5, 7, 3, 1, 1, spec_norm=True), lambda: torch.nn.Conv2d(5, 7, 3, 1, 1)),
+                    (lambda: linear(6, 4, spec_norm=True), lambda: torch.nn.Linear(6, 4))):
+        torch.manual_seed(11)
+        mine = mk()
+        torch.manual_seed(11)
+        theirs = torch.nn.utils.spectral_norm(ref())
+        sd_m, sd_t = mine.state_dict(), theirs.state_dict()
+        assert list(sd_m.keys()) == list(sd_t.keys())
+        for k in sd_m:
+            assert torch.equal(sd_m[k], sd_t[k]), k
+        assert not isinstance(mine.weight, torch.nn.Parameter)
+        assert mine.weight.data_ptr() == mine.weight_orig.data_ptr()        # weight_init reaches weight_orig until .cuda()
+        theirs.load_state_dict(sd_m)
+        mine.load_state_dict(sd_t)
+
+
 def test_cli_flags_match_reference():
     import xmc_gan.train_gan as tg
     a = tg.parse_args([])

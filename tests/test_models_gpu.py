@@ -81,6 +81,9 @@ STEP_CASES = [
     ("concept_in_df_gan_damsm_nomagp.yml", {"TRAIN.NCH": 8}, 3, 1),                      # sentence->region attention G
     ("concept_out_df_gan_sbert_damsm_nomagp.yml", {"TRAIN.NCH": 8}, 3, 1),               # self-attention G, E=768
     ("concept_in_df_gan_sbert_n2_damsm.yml", {"TRAIN.NCH": 8}, 3, 2),                    # N_CRITIC=2 + MA-GP
+    # DISC.SPEC_NORM: every discriminator layer wrapped in the legacy spectral_norm hook (modules.py:16-17,31-32)
+    ("df_gan_damsm_nomagp.yml", {"TRAIN.NCH": 8, "DISC.SPEC_NORM": True}, 4, 2),
+    ("df_gan_damsm.yml", {"TRAIN.NCH": 8, "DISC.SPEC_NORM": True}, 4, 1),                # ... under the MA-GP double backward
 ]
 
 
@@ -118,6 +121,49 @@ def test_train_iteration_parity(yml, over, batch, steps, mode):
             worst["G"] = max(worst["G"], compare_grads(tapG.records[gi], o_outs[s]["grads_G"], t["grad"] * k, f"step{s} G ", fl, t["agg"] * k)); gi += 1
     assert di == len(tapD.records) and gi == len(tapG.records)
     print(f"\n[parity {mode} {yml} {over}] worst rel err: " + ", ".join(f"{k}={v:.2e}" for k, v in worst.items()))
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_spectral_norm_forward_and_power_iteration(mode):
+    """DISC.SPEC_NORM=True: state_dict layout, one power iteration per forward call in training mode (u/v buffers
+    equal to the oracle's afterwards -- the matrix-vector products run in f32 in both precision modes), none in eval."""
+    ops.set_precision(mode)
+    cfg, h = setup_cfg("df_gan_damsm.yml", **{"TRAIN.NCH": 8, "DISC.SPEC_NORM": True})
+    PG, PD = X.synth_params(X.gen_shapes(h), 3), X.synth_params(X.netd_shapes(h), 4)
+    PD_o = {k: v.clone() for k, v in PD.items()}
+    b = X.synth_batch(h, 3, seed=77, words_len=cfg.TEXT.MAX_LENGTH)
+    netG, netD, _, _ = build_product(h, PG, PD)
+    assert set(netD.state_dict().keys()) == set(PD.keys())
+    assert any(k.endswith("weight_orig") for k in PD) and not any(k.endswith(".weight") for k in PD)
+    assert {n for n, _ in netD.named_parameters()} == {k for k in PD if not k.endswith(("_u", "_v"))}
+    with torch.no_grad():
+        ps_o = X.proj_sent(PG, b["sent_embs"])
+        for _ in range(2):                                   # two calls = two power iterations on every layer
+            feat_o = X.netd_forward(PD_o, h, b["imgs"])
+            logit_o, ie_o, te_o = X.cond_dnet(PD_o, h, feat_o, ps_o)
+            feat = netD(b["imgs"].to(DEV))
+            logit, ie, te = netD.COND_DNET(feat, sent_embs=ps_o.to(DEV))
+    t = TOL[mode]["fwd"]
+    assert rel_err(feat, feat_o) < t, rel_err(feat, feat_o)
+    assert rel_err(logit, logit_o) < 2 * t, rel_err(logit, logit_o)
+    assert rel_err(ie, ie_o) < t
+    sd = netD.state_dict()
+    moved = 0
+    for k in PD:
+        if k.endswith(("_u", "_v")):
+            assert rel_err(sd[k], PD_o[k]) < 1e-4, (k, rel_err(sd[k], PD_o[k]))
+            assert abs(sd[k].norm().item() - 1.0) < 1e-5
+            moved += rel_err(PD[k], PD_o[k]) > 1e-3
+    assert moved > 10
+    netD.eval()
+    before = {k: v.clone() for k, v in sd.items()}
+    with torch.no_grad():
+        feat_e = netD(b["imgs"].to(DEV))
+    for k, v in netD.state_dict().items():
+        assert torch.equal(v, before[k]), k
+    # the power iteration has not converged after two steps, so sigma (and the output) differs from training mode
+    # only through u,v being one step newer than the ones sigma was computed with: same order of magnitude
+    assert 0.2 < (feat_e.float().norm() / feat.float().norm()).item() < 5.0
 
 
 def test_adam_matches_oracle_update():

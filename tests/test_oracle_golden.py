@@ -39,6 +39,9 @@ def test_forward_matches_reference(name):
     _close(img_emb, fx["img_emb"], atol=2e-4)
     _close(txt_emb, fx["txt_emb"])
     _close(stats(feat_f), fx["feat_fake_stats"], rtol=1e-3, atol=1e-3)
+    if "d_buf_names" in fx.files:                 # spectral norm: power-iteration buffers after the same sequence of forward calls
+        for j, n in enumerate(fx["d_buf_names"]):
+            _close(stats(PD[str(n)]), fx["d_buf_after"][j], rtol=1e-3, atol=1e-4)
 
 
 def test_labels_and_contrastive_losses():
@@ -121,3 +124,6 @@ def test_train_step_matches_reference_loop(name):
             tol = 4 * steps * lr
             assert abs(st[0] - ref[j][0]) <= tol * P[n].numel() * 0.02 + 1e-5, n
             assert np.allclose(st[2:], ref[j][2:], atol=tol), n
+    if "d_buf_names" in fx.files:                 # spectral norm: u / v after every forward call of the loop
+        for j, n in enumerate(fx["d_buf_names"]):
+            _close(stats(PD[str(n)]), fx["d_buf_final"][j], rtol=5e-3, atol=2e-3)

@@ -635,6 +635,42 @@ def linear(x, w, b, geom, act=L.ACT_NONE, out_dtype=None):
     return y.view(x.shape[0], -1)
 
 
+_sn_geoms = {}
+
+
+def spectral_weight(w, u, v, training, eps=1e-12):
+    """Effective weight W / sigma(W) of the legacy ``torch.nn.utils.spectral_norm`` hook the reference wraps its
+    discriminator layers in when DISC.SPEC_NORM is set (model/modules.py:3,16-17,31-32).
+
+    W is seen as the [R, C] matrix ``w.view(R, -1)``.  In training mode ONE power iteration updates the
+    ``u`` [R] / ``v`` [C] buffers in place (v <- normalize(W^T u), u <- normalize(W v)); then
+    sigma = u . (W v) with u, v held constant and W_eff = W / sigma, differentiable in W to any order.
+    Both matrix-vector products are the 1x1 convolution kernels with W as the layer weight (W^T u is that
+    layer's data gradient), the dot and the scaling are the pointwise kernels; nothing syncs the host."""
+    R = w.shape[0]
+    C = w.numel() // R
+    geom = _sn_geoms.get((C, R))
+    if geom is None:
+        geom = _sn_geoms[(C, R)] = ConvGeom(C, R, 1, 1, 0)
+    wm = w.reshape(R, C)
+    Rp, Cp = pad_to(R, 8), chan_pad(C, torch.float32)
+    pad = torch.nn.functional.pad
+    if training:
+        with torch.no_grad():
+            up = pad(u.float(), (0, Rp - R)).view(1, 1, 1, Rp)
+            t = _conv_dgrad_raw(up, wm, geom, (1, 1), torch.float32).view(-1)[:C]
+            v.copy_(t / t.norm().clamp_min(eps))
+    vp = pad(v.detach().float(), (0, Cp - C)).view(1, 1, 1, Cp).clone()
+    s = ConvFn.apply(vp, wm, None, geom, L.ACT_NONE, torch.float32)          # W v, [1,1,1,Rp]
+    if training:
+        with torch.no_grad():
+            sv = s.detach().view(-1)[:R]
+            u.copy_(sv / sv.norm().clamp_min(eps))
+    upad = pad(u.detach().float(), (0, Rp - R)).view(1, 1, 1, Rp).clone()
+    sigma = DotFn.apply(upad, s)
+    return ScaleFn.apply(w, 1.0 / sigma)
+
+
 # ------------------------------------------------------------------------------------------ pointwise
 class CastFn(torch.autograd.Function):
     @staticmethod

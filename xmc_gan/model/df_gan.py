@@ -308,7 +308,8 @@ class resD(nn.Module):
     def forward(self, x, c=None):
         if self.downsample and ops.fused_blocks() and x.is_cuda:
             r0, r2, s_ = self.conv_r[0], self.conv_r[2], self.conv_s
-            return ops.ResDFn.apply(x, r0.weight, r2.weight, s_.weight if self.learned_shortcut else None,
+            return ops.ResDFn.apply(x, r0.effective_weight(), r2.effective_weight(),
+                                    s_.effective_weight() if self.learned_shortcut else None,
                                     s_.bias if self.learned_shortcut else None, self.gamma, r0.geom, r2.geom, s_.geom)
         return ops.axpby(self.shortcut(x), self.residual(x), self.gamma)
 
