@@ -388,8 +388,8 @@ def main(argv=None):
     text_encoder = SyntheticTextEncoder(cfg.TEXT.EMBEDDING_DIM, cfg.TEXT.MAX_LENGTH, seed, device)
 
     netG, netD, optimizerG, optimizerD = build_models(device)
-    if world > 1:   # same initial weights on every rank
-        for p_ in list(netG.parameters()) + list(netD.parameters()):
+    if world > 1:   # same initial weights (and spectral-norm u/v vectors, which then evolve identically) on every rank
+        for p_ in list(netG.parameters()) + list(netD.parameters()) + list(netG.buffers()) + list(netD.buffers()):
             torch.distributed.broadcast(p_.data, 0)
     logger.info(f'netG # of parameters: {count_params(netG)}')
     logger.info(f'netD # of parameters: {count_params(netD)}')
