@@ -143,6 +143,18 @@ int xmc_axpby_up_lrelu(const void* a, const void* b, const float* alpha_dev, voi
 int xmc_scale(const void* x, const float* alpha_dev, void* y, int64_t n, int dtype, void* stream);
 /* *out (+)= sum(a*b)  (f32 scalar; out zeroed by caller when accumulate==0 is not desired) */
 int xmc_dot(const void* a, const void* b, float* out, int64_t n, int dtype, void* stream);
+/* Spectral normalisation of a layer weight: the legacy torch.nn.utils.spectral_norm hook the reference's layer factories apply
+ * when DISC.SPEC_NORM is set (model/modules.py:3,16-17,31-32).  W: f32 [R,C] row-major (the parameter weight_orig viewed as
+ * [out, in*k*k]); u [R], v [C]: the hook's weight_u / weight_v buffers.  training != 0: one power iteration, IN PLACE
+ * (v <- normalize(W^T u), u <- normalize(W v), normalize(x) = x / max(|x|, eps)); then sigma = u.(W v).  Leaves
+ * sig[0] = 1/sigma, sig[1] = sigma on the device and, when w_eff is not NULL, w_eff = W/sigma [R,C].
+ * scratch: >= R + C floats (16-byte aligned). */
+int xmc_spectral_sigma(const float* W, float* u, float* v, float* scratch, float* sig, float* w_eff, int R, int C, int training,
+                       float eps, void* stream);
+/* gradient of L(W/sigma) w.r.t. W with u, v held constant (as the hook does): dW = g*sig[0] - <g,W>*sig[0]^2 * u v^T.
+ * g: dL/d(W/sigma) [R,C]; u, v: the vectors sigma was computed with; dot: f32[1] scratch */
+int xmc_spectral_bwd(const float* g, const float* W, const float* u, const float* v, const float* sig, float* dot, float* dW,
+                     int R, int C, void* stream);
 /* g = alpha*dy*LeakyReLU'(ref) and dot += sum(dy*ref) in one pass: backward of `shortcut + gamma*residual` (df_gan.py:284)
  * into a residual branch ending in LeakyReLU (ref = its output) together with d(gamma); dot is f32[1], zeroed by the caller */
 int xmc_scale_mask_dot(const void* dy, const void* ref, const float* alpha_dev, void* g, float* dot, int64_t n, int dtype, void* stream);

@@ -420,3 +420,38 @@ def test_fused_discriminator_block_equals_composed_block(cin, cout, H, mode):
         sc = b.abs().max().item() + 1e-12
         # bf16: the composed path rounds dx of each branch to bf16 before adding them, the fused path adds in f32
         torch.testing.assert_close(a, b, rtol=2e-2 if mode == "bf16" else 1e-4, atol=(2e-2 if mode == "bf16" else 1e-4) * sc, msg=lambda m: f"{n}: {m}")
+
+
+@pytest.mark.parametrize("R,C", [(32, 27), (1, 1024), (64, 6912), (512, 8192), (256, 4096), (37, 53), (128, 128)])
+@pytest.mark.parametrize("training", [True, False])
+def test_spectral_weight_matches_legacy_hook_arithmetic(R, C, training):
+    """ops.spectral_weight vs the arithmetic of torch.nn.utils.spectral_norm's compute_weight (reference
+    model/modules.py:16-17,31-32) in f64 on the CPU: buffers after the power iteration, W/sigma, and dL/dW.
+    Tolerance: f32 sums over <= 8192 terms -> 2e-5 relative L2."""
+    g = torch.Generator().manual_seed(R * 131 + C)
+    W = torch.randn(R, C, generator=g) * (2.0 / C) ** 0.5
+    u0, v0 = torch.randn(R, generator=g), torch.randn(C, generator=g)
+    G = torch.randn(R, C, generator=g)
+    Wd = W.double().requires_grad_(True)
+    u, v = u0.double(), v0.double()
+    if training:
+        v = torch.nn.functional.normalize(Wd.detach().t() @ u, dim=0, eps=1e-12)
+        u = torch.nn.functional.normalize(Wd.detach() @ v, dim=0, eps=1e-12)
+    sigma = torch.dot(u, Wd @ v)
+    We = Wd / sigma
+    (We * G.double()).sum().backward()
+
+    Wp = W.to(DEV).requires_grad_(True)
+    up, vp = u0.to(DEV).clone(), v0.to(DEV).clone()
+    shape4 = (R, C, 1, 1) if C % 9 else (R, C // 9, 3, 3)
+    Wp4 = Wp.view(shape4)
+    Wep = ops.spectral_weight(Wp4, up, vp, training)
+    assert Wep.shape == Wp4.shape
+    (Wep * G.to(DEV).view(shape4)).sum().backward()
+    rel = lambda a, b: ((a.double().cpu().flatten() - b.flatten()).norm() / b.norm().clamp_min(1e-30)).item()
+    assert rel(Wep, We.detach()) < 2e-5
+    assert rel(Wp.grad, Wd.grad) < 2e-5
+    if training:
+        assert rel(up, u) < 2e-5 and rel(vp, v) < 2e-5
+    else:
+        assert torch.equal(up.cpu(), u0) and torch.equal(vp.cpu(), v0)

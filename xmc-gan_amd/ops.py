@@ -635,40 +635,49 @@ def linear(x, w, b, geom, act=L.ACT_NONE, out_dtype=None):
     return y.view(x.shape[0], -1)
 
 
-_sn_geoms = {}
+class SpectralNormFn(torch.autograd.Function):
+    """W / sigma(W) as the legacy ``torch.nn.utils.spectral_norm`` hook computes it (reference model/modules.py:3,16-17,
+    31-32): in training mode ONE power iteration updates ``u`` [R] / ``v`` [C] in place (v <- normalize(W^T u),
+    u <- normalize(W v)), then sigma = u . (W v) with u, v constants.  W is ``w.view(R, -1)``, f32.
+
+    Differentiable once in W (dW = g/sigma - <g,W>/sigma^2 u v^T).  That is all the iteration ever asks for: W reaches
+    the discriminator only through W/sigma, so even the MA-GP second-order pass crosses this node exactly once, with
+    the gradient w.r.t. W/sigma that the (twice differentiable) convolution Functions produce."""
+
+    @staticmethod
+    def forward(ctx, w, u, v, training, eps):
+        assert w.dtype == torch.float32 and u.dtype == torch.float32 and v.dtype == torch.float32
+        w = w.contiguous()
+        R = w.shape[0]
+        C = w.numel() // R
+        assert u.numel() == R and v.numel() == C and u.is_contiguous() and v.is_contiguous()
+        scratch = torch.empty(C + R + 4, dtype=torch.float32, device=w.device)
+        sig = torch.empty(2, dtype=torch.float32, device=w.device)
+        y = torch.empty_like(w)
+        L.call("xmc_spectral_sigma", _p(w), _p(u), _p(v), _p(scratch), _p(sig), _p(y), R, C, int(bool(training)), float(eps),
+               _st())
+        ctx.mark_non_differentiable(u, v)
+        ctx.save_for_backward(w, u.clone(), v.clone(), sig)
+        ctx.dims = (R, C)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        w, u, v, sig = ctx.saved_tensors
+        R, C = ctx.dims
+        g = g.contiguous().float()
+        dw = torch.empty_like(w)
+        dot = torch.empty(1, dtype=torch.float32, device=w.device)
+        L.call("xmc_spectral_bwd", _p(g), _p(w), _p(u), _p(v), _p(sig), _p(dot), _p(dw), R, C, _st())
+        return dw, None, None, None, None
 
 
 def spectral_weight(w, u, v, training, eps=1e-12):
-    """Effective weight W / sigma(W) of the legacy ``torch.nn.utils.spectral_norm`` hook the reference wraps its
-    discriminator layers in when DISC.SPEC_NORM is set (model/modules.py:3,16-17,31-32).
-
-    W is seen as the [R, C] matrix ``w.view(R, -1)``.  In training mode ONE power iteration updates the
-    ``u`` [R] / ``v`` [C] buffers in place (v <- normalize(W^T u), u <- normalize(W v)); then
-    sigma = u . (W v) with u, v held constant and W_eff = W / sigma, differentiable in W to any order.
-    Both matrix-vector products are the 1x1 convolution kernels with W as the layer weight (W^T u is that
-    layer's data gradient), the dot and the scaling are the pointwise kernels; nothing syncs the host."""
-    R = w.shape[0]
-    C = w.numel() // R
-    geom = _sn_geoms.get((C, R))
-    if geom is None:
-        geom = _sn_geoms[(C, R)] = ConvGeom(C, R, 1, 1, 0)
-    wm = w.reshape(R, C)
-    Rp, Cp = pad_to(R, 8), chan_pad(C, torch.float32)
-    pad = torch.nn.functional.pad
-    if training:
-        with torch.no_grad():
-            up = pad(u.float(), (0, Rp - R)).view(1, 1, 1, Rp)
-            t = _conv_dgrad_raw(up, wm, geom, (1, 1), torch.float32).view(-1)[:C]
-            v.copy_(t / t.norm().clamp_min(eps))
-    vp = pad(v.detach().float(), (0, Cp - C)).view(1, 1, 1, Cp).clone()
-    s = ConvFn.apply(vp, wm, None, geom, L.ACT_NONE, torch.float32)          # W v, [1,1,1,Rp]
-    if training:
-        with torch.no_grad():
-            sv = s.detach().view(-1)[:R]
-            u.copy_(sv / sv.norm().clamp_min(eps))
-    upad = pad(u.detach().float(), (0, Rp - R)).view(1, 1, 1, Rp).clone()
-    sigma = DotFn.apply(upad, s)
-    return ScaleFn.apply(w, 1.0 / sigma)
+    """effective weight of a spectrally normalised layer; updates the u / v buffers in place when ``training``."""
+    if not w.is_cuda:
+        raise RuntimeError("xmc_gan_amd.ops.spectral_weight: CPU tensors are not supported (no CPU fallback)")
+    return SpectralNormFn.apply(w, u, v, training, eps)
 
 
 # ------------------------------------------------------------------------------------------ pointwise
