@@ -1,5 +1,6 @@
 """CPU-only checks of the host side: C-ABI library exports, cfg schema/merge rules, module state_dict parity with the
 oracle's key tables (pinned to the reference by the golden test), preset loading."""
+import copy
 import ctypes
 import glob
 import os
@@ -114,6 +115,48 @@ def test_spectral_norm_layers_mirror_the_legacy_hook_state():
         assert mine.weight.data_ptr() == mine.weight_orig.data_ptr()        # weight_init reaches weight_orig until .cuda()
         theirs.load_state_dict(sd_m)
         mine.load_state_dict(sd_t)
+
+
+def test_adam_state_dict_interchanges_with_torch_adam():
+    """optimizerG.pth / optimizerD.pth written by the reference (torch.optim.Adam, train_gan.py:331-332) load into HipAdam
+    and vice versa (resume path, train_gan.py:492-493).  Host logic only: no step is taken here."""
+    from xmc_gan_amd.optim import HipAdam
+    torch.manual_seed(0)
+    ps_t = [torch.nn.Parameter(torch.randn(5, 3)), torch.nn.Parameter(torch.randn(7)), torch.nn.Parameter(torch.randn(2, 2))]
+    adam = torch.optim.Adam(ps_t, lr=4e-4, betas=(0.0, 0.9))
+    for _ in range(3):
+        for p in ps_t[:2]:                      # the third parameter never gets a gradient: no state, as upstream
+            p.grad = torch.randn_like(p)
+        adam.step()
+    sd_t = copy.deepcopy(adam.state_dict())     # as after torch.load: load_state_dict does not copy the state tensors
+    ps_h = [torch.nn.Parameter(p.detach().clone()) for p in ps_t]
+    hip = HipAdam(ps_h, lr=1e-3, betas=(0.5, 0.5))
+    hip.load_state_dict(sd_t)
+    assert hip.param_groups[0]["lr"] == 4e-4 and tuple(hip.param_groups[0]["betas"]) == (0.0, 0.9)
+    assert set(hip.state.keys()) == set(ps_h[:2])
+    for p_h, p_t in zip(ps_h[:2], ps_t[:2]):
+        st = hip.state[p_h]
+        assert st["step"].dtype == torch.int32 and st["step"].shape == (1,) and int(st["step"]) == 3
+        assert torch.equal(st["exp_avg"], adam.state[p_t]["exp_avg"]) and torch.equal(st["exp_avg_sq"], adam.state[p_t]["exp_avg_sq"])
+    sd_h = copy.deepcopy(hip.state_dict())
+    assert sd_h["state"].keys() == sd_t["state"].keys()
+    for k in sd_t["state"]:
+        assert sd_h["state"][k]["step"].dtype == torch.float32 and sd_h["state"][k]["step"].shape == ()
+        assert float(sd_h["state"][k]["step"]) == float(sd_t["state"][k]["step"]) == 3.0
+    ps_b = [torch.nn.Parameter(p.detach().clone()) for p in ps_t]
+    back = torch.optim.Adam(ps_b)
+    back.load_state_dict(sd_h)                  # torch.optim.Adam accepts ours and can keep stepping
+    for a, b in zip(ps_t[:2], ps_b[:2]):
+        a.grad = torch.ones_like(a)
+        b.grad = torch.ones_like(b)
+    adam.step()
+    back.step()
+    for a, b in zip(ps_t, ps_b):
+        assert torch.equal(a, b)
+    bad = copy.deepcopy(adam.state_dict())
+    bad["param_groups"][0]["weight_decay"] = 0.1
+    with pytest.raises(ValueError):
+        hip.load_state_dict(bad)
 
 
 def test_cli_flags_match_reference():

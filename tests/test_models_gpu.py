@@ -8,6 +8,8 @@ weight and activation through ~25 layers of an untrained, batch-4 network: losse
 gradients: all tensors of a backward taken as one vector within 0.2 relative L2, each single tensor within 1.0 (measured
 per tensor: D <= 0.25, G <= 0.36 on small tensors, with run-to-run variation because f32 atomics order changes bf16
 roundings downstream)."""
+import copy
+
 import pytest
 import torch
 
@@ -186,3 +188,63 @@ def test_adam_matches_oracle_update():
     for p, v in zip(ps, ps_o.values()):
         torch.testing.assert_close(p.detach().cpu(), v, rtol=1e-5, atol=1e-7)
     assert opt.state[ps[1]]["step"].item() == 3 and opt.state[ps[0]]["step"].item() == 4
+
+
+def test_resume_from_torch_adam_checkpoint_continues_identically():
+    """A torch.optim.Adam state dict (what the reference's optimizerD.pth holds, train_gan.py:331-332) loaded into HipAdam:
+    the next update equals torch.optim.Adam's own next update (ATen here is the checker, not the product)."""
+    from xmc_gan_amd.optim import HipAdam
+    g = torch.Generator().manual_seed(5)
+    shapes = [(64, 32, 3, 3), (64,), (1,), (300, 77)]
+    ps_t = [torch.nn.Parameter(torch.randn(s, generator=g).to(DEV)) for s in shapes]
+    adam = torch.optim.Adam(ps_t, lr=4e-4, betas=(0.0, 0.9))
+    grads = [[torch.randn(s, generator=g).to(DEV) for s in shapes] for _ in range(3)]
+    for k in range(2):
+        for p, gr in zip(ps_t, grads[k]):
+            p.grad = gr.clone()
+        adam.step()
+    ps_h = [torch.nn.Parameter(p.detach().clone()) for p in ps_t]
+    hip = HipAdam(ps_h, lr=4e-4, betas=(0.0, 0.9))
+    hip.load_state_dict(copy.deepcopy(adam.state_dict()))      # as after torch.load (no aliasing of the live state)
+    for p, q, gr in zip(ps_t, ps_h, grads[2]):
+        p.grad, q.grad = gr.clone(), gr.clone()
+    adam.step()
+    hip.step()
+    for p, q in zip(ps_t, ps_h):
+        assert rel_err(q, p) < 1e-6
+        assert int(hip.state[q]["step"]) == 3
+    sd = hip.state_dict()
+    assert all(float(st["step"]) == 3.0 for st in sd["state"].values())
+
+
+def test_checkpoint_resume_matches_uninterrupted_run(tmp_path):
+    """netG/netD/optimizerG/optimizerD .pth files as the reference writes them (train_gan.py:329-332) and reloads them
+    (489-493): iteration 2 after a reload equals iteration 2 of the uninterrupted run.  Spectral norm is on so that the
+    u / v buffers have to survive the round trip too.  Tolerance 1e-4: the weight-gradient atomics are not ordered."""
+    import xmc_gan.train_gan as tg
+    ops.set_precision("fp32")
+    cfg, h = setup_cfg("df_gan_damsm.yml", **{"TRAIN.NCH": 8, "DISC.SPEC_NORM": True})
+    PG, PD = X.synth_params(X.gen_shapes(h), 5), X.synth_params(X.netd_shapes(h), 6)
+    batches = [X.synth_batch(h, 4, seed=300 + i, words_len=cfg.TEXT.MAX_LENGTH) for i in range(2)]
+
+    def step(models, b, state):
+        o = tg.gan_iteration(*models, b["imgs"].to(DEV), b["sent_embs"].to(DEV), b["words_embs"].to(DEV), b["mask"].to(DEV),
+                             b["noise"].to(DEV), state)
+        return {k: float(v) for k, v in o.items() if k in ("errD", "errG", "d_loss_gp", "ds_loss", "gs_loss")}
+
+    A, st = build_product(h, PG, PD, eps=PARITY_EPS), {}
+    step(A, batches[0], st)
+    for name, obj in zip(("netG_051", "netD_051", "optimizerG", "optimizerD"), A):
+        torch.save(obj.state_dict(), tmp_path / f"{name}.pth")
+    out_a = step(A, batches[1], st)
+    # a differently initialised build: everything that matters must come from the files
+    B = build_product(h, X.synth_params(X.gen_shapes(h), 15), X.synth_params(X.netd_shapes(h), 16), eps=1e-8)
+    for name, obj in zip(("netG_051", "netD_051", "optimizerG", "optimizerD"), B):
+        obj.load_state_dict(torch.load(tmp_path / f"{name}.pth", map_location=DEV))
+    out_b = step(B, batches[1], {})
+    assert set(out_a) == set(out_b) and "errG" in out_a
+    for k in out_a:
+        assert abs(out_a[k] - out_b[k]) <= 1e-4 * abs(out_a[k]) + 1e-6, (k, out_a[k], out_b[k])
+    for (n, p), (_, q) in zip(list(A[0].state_dict().items()) + list(A[1].state_dict().items()),
+                              list(B[0].state_dict().items()) + list(B[1].state_dict().items())):
+        assert rel_err(q, p) < 1e-4, n

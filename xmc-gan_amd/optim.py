@@ -10,7 +10,9 @@ from . import ops
 
 class HipAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
-        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        # weight_decay / amsgrad are carried (at the only values the path uses) so that state dicts interchange with
+        # torch.optim.Adam's: the reference saves and resumes optimizerG.pth / optimizerD.pth (train_gan.py:331-332,492-493)
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False))
         self._tables = {}
         self._chunk = None
         self._arena, self._arena_off = None, 0
@@ -36,6 +38,27 @@ class HipAdam(torch.optim.Optimizer):
             st["exp_avg"] = torch.zeros_like(p, dtype=torch.float32, memory_format=torch.contiguous_format)
             st["exp_avg_sq"] = torch.zeros_like(p, dtype=torch.float32, memory_format=torch.contiguous_format)
         return st
+
+    def state_dict(self):
+        """torch.optim.Adam's layout: per parameter ``step`` (f32 scalar on the host), ``exp_avg``, ``exp_avg_sq``."""
+        sd = super().state_dict()
+        sd["state"] = {k: {**st, "step": st["step"].detach().to("cpu", torch.float32).reshape(())} if "step" in st else st
+                       for k, st in sd["state"].items()}
+        return sd
+
+    def load_state_dict(self, state_dict):
+        """Accepts a ``torch.optim.Adam`` state dict (a reference optimizerG.pth / optimizerD.pth) or our own."""
+        for g in state_dict["param_groups"]:
+            if g.get("weight_decay", 0) != 0 or g.get("amsgrad", False) or g.get("maximize", False):
+                raise ValueError("HipAdam implements Adam without weight decay / amsgrad / maximize (train_gan.py:483-484)")
+        super().load_state_dict(state_dict)
+        for p, st in self.state.items():
+            if "step" in st:
+                st["step"] = torch.as_tensor(st["step"]).detach().reshape(1).round().to(device=p.device, dtype=torch.int32)
+            for k in ("exp_avg", "exp_avg_sq"):
+                if k in st:
+                    st[k] = st[k].to(device=p.device, dtype=torch.float32).contiguous()
+        self._tables.clear()          # the tables hold raw pointers into the replaced state tensors
 
     def _table(self, ps, device):
         key = tuple((p.data_ptr(), p.grad.data_ptr()) for p in ps)

@@ -398,6 +398,8 @@ def main(argv=None):
     if state_epoch != 0:
         netG.load_state_dict(torch.load(f'{model_dir}/netG_{state_epoch:03d}.pth', map_location=device))
         netD.load_state_dict(torch.load(f'{model_dir}/netD_{state_epoch:03d}.pth', map_location=device))
+        optimizerG.load_state_dict(torch.load(f'{model_dir}/optimizerG.pth', map_location=device))
+        optimizerD.load_state_dict(torch.load(f'{model_dir}/optimizerD.pth', map_location=device))
         logger.info(f'Load models, epoch : {state_epoch}')
     elif cfg.DISC.ENCODER_DIR:
         netD.load_state_dict(torch.load(f'{PROJ_DIR}/{cfg.DISC.ENCODER_DIR}', map_location=device), strict=False)
