@@ -143,6 +143,16 @@ int xmc_axpby_up_lrelu(const void* a, const void* b, const float* alpha_dev, voi
 int xmc_scale(const void* x, const float* alpha_dev, void* y, int64_t n, int dtype, void* stream);
 /* *out (+)= sum(a*b)  (f32 scalar; out zeroed by caller when accumulate==0 is not desired) */
 int xmc_dot(const void* a, const void* b, float* out, int64_t n, int dtype, void* stream);
+/* Frozen text front end, RNN_ENCODER.forward in eval mode (reference model/encoder.py:118-153).
+ * xmc_embedding_gather: nn.Embedding lookup (encoder.py:132): out[n, :] = table[ids[n], :], f32, dim % 4 == 0; ids outside
+ *   [0, vocab) give a zero row (the host wrapper validates ids before the call).
+ * xmc_lstm_bidir: one-layer bidirectional nn.LSTM over captions of length lens[b] (pack_padded_sequence / pad_packed_sequence,
+ *   encoder.py:134-137), zero initial state (encoder.py:110-116,130).  xproj [B,T,2,4H]: x_t W_ih^T + b_ih + b_hh per direction
+ *   (gate rows i,f,g,o); w_hh [2,4H,H]; words [B,2H,T] (encoder.py:140: outputs transposed; zero at t >= len);
+ *   sent [B,2H] = [h_fwd(len-1), h_rev(0)] (encoder.py:142-147).  H must be 128. */
+int xmc_embedding_gather(const int64_t* ids, const float* table, float* out, int64_t n_tokens, int dim, int64_t vocab, void* stream);
+int xmc_lstm_bidir(const float* xproj, const float* w_hh, const int32_t* lens, float* words, float* sent, int B, int T, int H,
+                   void* stream);
 /* Spectral normalisation of a layer weight: the legacy torch.nn.utils.spectral_norm hook the reference's layer factories apply
  * when DISC.SPEC_NORM is set (model/modules.py:3,16-17,31-32).  W: f32 [R,C] row-major (the parameter weight_orig viewed as
  * [out, in*k*k]); u [R], v [C]: the hook's weight_u / weight_v buffers.  training != 0: one power iteration, IN PLACE

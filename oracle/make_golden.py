@@ -218,6 +218,24 @@ def golden_step(name, yml, batch, steps, seed, out_dir, **over):
           [(n, round(v, 4)) for n, v in scal[: 12]])
 
 
+def golden_rnn_encoder(name, yml, batch, seed, out_dir, **over):
+    """The reference's frozen RNN_ENCODER (encoder.py:73-153) in eval mode on synthetic parameters and captions."""
+    cfg = RH.load_cfg(yml, **over)
+    M = RH.modules()
+    enc = M.encoder.RNN_ENCODER(cfg)
+    shapes = X.rnn_encoder_shapes(cfg.TEXT.VOCA_SIZE, cfg.TEXT.EMBEDDING_DIM)
+    enc.load_state_dict(X.synth_rnn_params(shapes, seed), strict=True)
+    enc.eval()
+    caps, lens = X.synth_captions(batch, cfg.TEXT.MAX_LENGTH, cfg.TEXT.VOCA_SIZE, seed + 1)
+    with torch.no_grad():
+        words, sent, mask = enc(caps, lens)
+    np.savez_compressed(os.path.join(out_dir, f"rnn_{name}.npz"), yml=yml, batch=batch, seed=seed,
+                        over=np.array([f"{k}={v}" for k, v in over.items()]),
+                        keys=shape_table(enc.state_dict()), caps=caps.numpy(), lens=lens.numpy(),
+                        words=words.numpy(), sent=sent.numpy(), mask=mask.numpy())
+    print(f"rnn_{name}: words {tuple(words.shape)} sent {tuple(sent.shape)}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(HERE), "tests", "golden"))
@@ -226,7 +244,7 @@ def main():
     os.makedirs(a.out, exist_ok=True)
     if a.only:                                    # filter: wrap the generators
         g = globals()
-        for fn in ("golden_forward", "golden_step"):
+        for fn in ("golden_forward", "golden_step", "golden_rnn_encoder"):
             g[fn] = (lambda f: (lambda name, *args, **kw: f(name, *args, **kw) if a.only in name else None))(g[fn])
         g["golden_labels"] = (lambda f: (lambda *args, **kw: f(*args, **kw) if a.only in "labels" else None))(g["golden_labels"])
     N8 = {"TRAIN.NCH": 8}
@@ -256,6 +274,9 @@ def main():
     golden_forward("sn64_nch8", "df_gan_damsm.yml", 2, 31, a.out, **SN)
     golden_step("sn64_nomagp", "df_gan_damsm_nomagp.yml", 4, 2, 32, a.out, **SN)
     golden_step("sn64_magp", "df_gan_damsm.yml", 3, 1, 33, a.out, **SN)
+    # frozen text front end: embedding + bidirectional LSTM over packed captions
+    golden_rnn_encoder("enc_damsm", "df_gan_damsm.yml", 6, 41, a.out)
+    golden_rnn_encoder("enc_len12", "df_gan_damsm.yml", 5, 42, a.out, **{"TEXT.MAX_LENGTH": 12, "TEXT.VOCA_SIZE": 500})
 
 
 if __name__ == "__main__":

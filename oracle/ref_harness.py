@@ -133,4 +133,5 @@ def modules():
     import xmc_gan.train_gan as tg
     import xmc_gan.model.df_gan as df_gan
     import xmc_gan.model.df_concept_gan as df_concept_gan
-    return types.SimpleNamespace(train_gan=tg, df_gan=df_gan, df_concept_gan=df_concept_gan)
+    import xmc_gan.model.encoder as encoder
+    return types.SimpleNamespace(train_gan=tg, df_gan=df_gan, df_concept_gan=df_concept_gan, encoder=encoder)

@@ -505,6 +505,74 @@ def cond_dnet(P, h: Hyper, feat, sent_embs):
 # ----------------------------------------------------------------------------------------
 # contrastive head (train_gan.py:72-139)
 # ----------------------------------------------------------------------------------------
+# ------------------------------------------------------------------ frozen text front end (encoder.py:73-153)
+def rnn_encoder_shapes(voca_size: int, emb_dim: int = 256, ninput: int = 300) -> dict:
+    """state_dict of RNN_ENCODER: nn.Embedding(V, 300) + one-layer bidirectional nn.LSTM(300, emb_dim/2)
+    (encoder.py:75-104).  Gate rows are ordered i, f, g, o (torch.nn.LSTM)."""
+    H = emb_dim // 2
+    out = {"encoder.weight": (voca_size, ninput)}
+    for sfx in ("", "_reverse"):
+        out[f"rnn.weight_ih_l0{sfx}"] = (4 * H, ninput)
+        out[f"rnn.weight_hh_l0{sfx}"] = (4 * H, H)
+        out[f"rnn.bias_ih_l0{sfx}"] = (4 * H,)
+        out[f"rnn.bias_hh_l0{sfx}"] = (4 * H,)
+    return out
+
+
+def synth_rnn_params(shapes: dict, seed: int = 0) -> dict:
+    """embedding uniform(-0.1, 0.1) as _init_weights (encoder.py:106-108); LSTM tensors uniform(-1/sqrt(H), 1/sqrt(H))
+    as nn.LSTM.reset_parameters; per-key generators as in synth_params."""
+    H = shapes["rnn.weight_hh_l0"][1]
+    out = {}
+    for key, shape in shapes.items():
+        g = torch.Generator().manual_seed((zlib.crc32(key.encode()) + 7919 * seed) & 0x7FFFFFFF)
+        a = 0.1 if key == "encoder.weight" else 1.0 / math.sqrt(H)
+        out[key] = ((torch.rand(shape, generator=g) * 2 - 1) * a).to(torch.float32)
+    return out
+
+
+def synth_captions(batch: int, max_len: int, voca_size: int, seed: int = 0):
+    """token ids in [1, V) followed by zero padding, lengths in [1, max_len] (dataset.py:104-111: get_caption pads
+    with 0 and truncates to MAX_LENGTH); sample 0 has full length and sample 1 length 1 when the batch allows."""
+    g = torch.Generator().manual_seed(seed)
+    lens = torch.randint(1, max_len + 1, (batch,), generator=g)
+    lens[0] = max_len
+    if batch > 1:
+        lens[1] = 1
+    caps = torch.randint(1, voca_size, (batch, max_len), generator=g)
+    caps = caps * (torch.arange(max_len)[None, :] < lens[:, None])
+    return caps.to(torch.int64), lens.to(torch.int64)
+
+
+def rnn_encoder(P, caps, cap_lens, n_steps: int):
+    """RNN_ENCODER.forward in eval mode (encoder.py:118-153; dropout is the identity, train_gan.py:468), LSTM only.
+
+    The reference sorts by length, packs, runs nn.LSTM and un-sorts; per sample that is: the forward direction runs
+    t = 0..len-1, the reverse direction t = len-1..0, both from zero state; outputs at t >= len are zero
+    (pad_packed_sequence, total_length = n_steps); the sentence embedding is [h_fwd(len-1), h_rev(0)].
+    Returns words_embs [B, 2H, n_steps], sent_embs [B, 2H], mask [B, T] (True where the token id is 0)."""
+    B = caps.shape[0]
+    H = P["rnn.weight_hh_l0"].shape[1]
+    emb = P["encoder.weight"][caps]                                     # [B, T, 300]
+    words = torch.zeros(B, 2 * H, n_steps, dtype=emb.dtype)
+    sent = torch.zeros(B, 2 * H, dtype=emb.dtype)
+    for d, sfx in enumerate(("", "_reverse")):
+        w_ih, w_hh = P[f"rnn.weight_ih_l0{sfx}"], P[f"rnn.weight_hh_l0{sfx}"]
+        bias = P[f"rnn.bias_ih_l0{sfx}"] + P[f"rnn.bias_hh_l0{sfx}"]
+        for b in range(B):
+            n = int(cap_lens[b])
+            hcur, ccur = torch.zeros(H, dtype=emb.dtype), torch.zeros(H, dtype=emb.dtype)
+            for t in (range(n) if d == 0 else range(n - 1, -1, -1)):
+                gates = w_ih @ emb[b, t] + w_hh @ hcur + bias
+                i, f = torch.sigmoid(gates[:H]), torch.sigmoid(gates[H:2 * H])
+                gg, o = torch.tanh(gates[2 * H:3 * H]), torch.sigmoid(gates[3 * H:])
+                ccur = f * ccur + i * gg
+                hcur = o * torch.tanh(ccur)
+                words[b, d * H:(d + 1) * H, t] = hcur
+            sent[b, d * H:(d + 1) * H] = hcur
+    return words, sent, caps == 0
+
+
 def cosine_scores(a, b):
     """train_gan.py:85-91."""
     return F.normalize(a, p=2, dim=1) @ F.normalize(b, p=2, dim=1).t()

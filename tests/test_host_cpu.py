@@ -6,6 +6,7 @@ import glob
 import os
 import re
 
+import numpy as np
 import pytest
 import torch
 
@@ -157,6 +158,93 @@ def test_adam_state_dict_interchanges_with_torch_adam():
     bad["param_groups"][0]["weight_decay"] = 0.1
     with pytest.raises(ValueError):
         hip.load_state_dict(bad)
+
+
+def test_text_encoder_classes_mirror_reference_state():
+    """RNN_ENCODER: upstream's parameter names/shapes (encoder.py:93-104), so a DAMSM text_encoder100.pth (an nn.Embedding +
+    nn.LSTM state dict) loads strictly; GRU and SBERT fail loudly at construction."""
+    from xmc_gan.config import gan
+    from xmc_gan.model.encoder import RNN_ENCODER, SBERT_ENCODER
+    gan.reset_cfg()
+    gan.cfg_from_file(os.path.join(CFG_DIR, "df_gan_damsm.yml"))
+    cfg = gan.cfg
+    enc = RNN_ENCODER(cfg)
+    assert {k: tuple(v.shape) for k, v in enc.state_dict().items()} == X.rnn_encoder_shapes(cfg.TEXT.VOCA_SIZE, cfg.TEXT.EMBEDDING_DIM)
+    assert float(enc.encoder.weight.abs().max()) <= 0.1
+    ref = torch.nn.ModuleDict(dict(encoder=torch.nn.Embedding(cfg.TEXT.VOCA_SIZE, 300),
+                                   rnn=torch.nn.LSTM(300, 128, 1, batch_first=True, bidirectional=True)))
+    enc.load_state_dict(ref.state_dict(), strict=True)
+    with pytest.raises(RuntimeError):                    # no CPU fallback
+        enc.eval()(torch.ones(2, cfg.TEXT.MAX_LENGTH, dtype=torch.int64), torch.tensor([3, 4]))
+    cfg.TEXT.RNN_TYPE = "GRU"
+    with pytest.raises(NotImplementedError):
+        RNN_ENCODER(cfg)
+    with pytest.raises(ImportError):
+        SBERT_ENCODER(cfg)
+    gan.reset_cfg()
+
+
+def test_datasets_mirror_reference_item_layout(tmp_path):
+    """WordTextDataset / SentTextDataset on a miniature COCO-style tree (file layout of dataset.py:67-74,84-91,118-124):
+    item = (img [3,S,S] in [-1,1], [(caption, length)], key), caption index idx*CAPTIONS_PER_IMAGE+1 (dataset.py:49-51), zero
+    padding / truncation to MAX_LENGTH (104-111), and the default collate gives the batch tuple train() unpacks (train_gan.py:176-181)."""
+    import pickle
+    from PIL import Image
+    from xmc_gan.config import gan
+    from xmc_gan import dataset as D
+    gan.reset_cfg()
+    gan.cfg_from_file(os.path.join(CFG_DIR, "df_gan_damsm.yml"))
+    cfg = gan.cfg
+    cfg.IMG.SIZE, cfg.TEXT.MAX_LENGTH = 32, 6
+    root = tmp_path / "coco"
+    (root / "images").mkdir(parents=True)
+    rng = np.random.RandomState(0)
+    keys = [f"img{i}" for i in range(3)]
+    for k, (w, h) in zip(keys, ((80, 50), (40, 64), (38, 38))):
+        Image.fromarray(rng.randint(0, 256, (h, w, 3), dtype=np.uint8)).save(root / "images" / f"{k}.jpg")
+    for mode in ("train", "test"):
+        (root / mode).mkdir()
+        with open(root / mode / "filenames.pickle", "wb") as f:
+            pickle.dump(keys, f)
+    caps = [list(range(1 + j, 1 + j + (3 + j % 7))) for j in range(3 * 5)]          # lengths 3..9, ids >= 1
+    i2w = {i: f"w{i}" for i in range(40)}
+    with open(root / "captions.pickle", "wb") as f:
+        pickle.dump([caps, caps[::-1], i2w, {v: k for k, v in i2w.items()}], f)
+    sents = [f"a photo of thing number {j}" for j in range(15)]
+    with open(root / "bert_captions.pickle", "wb") as f:
+        pickle.dump([sents, sents[::-1]], f)
+
+    torch.manual_seed(0)
+    ds = D.WordTextDataset(str(root), "train", D.train_transform(32), cfg)
+    assert len(ds) == 3 and ds.voca_size == 40
+    for idx in range(3):
+        img, texts, key = ds[idx]
+        assert img.shape == (3, 32, 32) and img.dtype == torch.float32 and -1.0 <= float(img.min()) and float(img.max()) <= 1.0
+        assert key == keys[idx] and len(texts) == 1
+        cap, n = texts[0]
+        src = caps[idx * 5 + 1]
+        assert cap.dtype == np.int64 and cap.shape == (6,) and n == min(len(src), 6)
+        assert list(cap[:n]) == src[:n] and (cap[n:] == 0).all()
+    assert D.index_to_sent(i2w, [ds[0][1][0][0]]) == [" ".join(f"w{t}" for t in caps[1][:6])]
+    imgs, texts_lst, ks = next(iter(torch.utils.data.DataLoader(ds, batch_size=2, drop_last=True, shuffle=False)))
+    caps_b, lens_b = texts_lst[0]
+    assert imgs.shape == (2, 3, 32, 32) and caps_b.shape == (2, 6) and caps_b.dtype == torch.int64 and lens_b.shape == (2,)
+    assert list(ks) == keys[:2]
+    # test split: exact resize, reversed caption table
+    dt = D.WordTextDataset(str(root), "test", D.test_transform(32), cfg)
+    img, texts, _ = dt[2]
+    assert img.shape == (3, 32, 32) and list(texts[0][0][:texts[0][1]]) == caps[::-1][2 * 5 + 1][:6]
+    # transforms: shorter side -> 76/64 of the crop, as train_gan.py:443-447
+    im = D.Resize(38)(Image.new("RGB", (80, 50)))
+    assert im.size == (60, 38)
+    assert D.Resize((32, 32))(Image.new("RGB", (80, 50))).size == (32, 32)
+    t = D.to_normalized_tensor(Image.fromarray(np.array([[[0, 255, 51]]], dtype=np.uint8)))
+    assert torch.allclose(t.flatten(), torch.tensor([-1.0, 1.0, -0.6]), atol=1e-6)
+    sd = D.SentTextDataset(str(root), "train", D.test_transform(32), cfg)
+    assert sd[1][1] == [(sents[6], 6)]
+    with pytest.raises(NotImplementedError):
+        D.WordTextDataset(str(tmp_path / "nowhere"), "train", None, cfg)
+    gan.reset_cfg()
 
 
 def test_cli_flags_match_reference():

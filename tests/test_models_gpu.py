@@ -248,3 +248,54 @@ def test_checkpoint_resume_matches_uninterrupted_run(tmp_path):
     for (n, p), (_, q) in zip(list(A[0].state_dict().items()) + list(A[1].state_dict().items()),
                               list(B[0].state_dict().items()) + list(B[1].state_dict().items())):
         assert rel_err(q, p) < 1e-4, n
+
+
+@pytest.mark.parametrize("name", ["rnn_enc_damsm.npz", "rnn_enc_len12.npz"])
+def test_rnn_encoder_matches_reference_golden(name):
+    """RNN_ENCODER on the HIP kernels vs the reference's own outputs (tests/golden/rnn_*.npz, made by
+    oracle/make_golden.py from encoder.py:73-153 on CPU).  f32 throughout: 1e-4 relative / 2e-5 absolute; the mask is exact."""
+    import numpy as np
+    from golden_util import load
+    from xmc_gan.model.encoder import RNN_ENCODER
+    fx = load(name)
+    over = {k: int(v) for k, v in (kv.split("=") for kv in map(str, fx["over"]))}
+    cfg, _ = setup_cfg(str(fx["yml"]), **over)
+    enc = RNN_ENCODER(cfg)
+    shapes = X.rnn_encoder_shapes(cfg.TEXT.VOCA_SIZE, cfg.TEXT.EMBEDDING_DIM)
+    assert {k: tuple(v.shape) for k, v in enc.state_dict().items()} == shapes
+    enc.load_state_dict(X.synth_rnn_params(shapes, int(fx["seed"])), strict=True)
+    enc = enc.to(DEV).eval()
+    words, sent, mask = enc(torch.from_numpy(fx["caps"]), torch.from_numpy(fx["lens"]))
+    assert words.is_cuda and words.shape == fx["words"].shape and sent.shape == fx["sent"].shape
+    assert np.array_equal(mask.cpu().numpy(), fx["mask"])
+    np.testing.assert_allclose(words.cpu().numpy(), fx["words"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(sent.cpu().numpy(), fx["sent"], rtol=1e-4, atol=2e-5)
+    assert (words.cpu().numpy()[1, :, 1:] == 0).all()                 # caption of length 1: everything after t=0 is padding
+
+
+@pytest.mark.parametrize("batch", [1, 7, 256, 300])
+def test_rnn_encoder_matches_oracle_at_batch(batch):
+    """both workgroup shapes of the recurrence kernel (1 and 2 samples per workgroup), ragged last workgroup, device-resident
+    inputs; against the CPU oracle on the same synthetic captions."""
+    from xmc_gan.model.encoder import RNN_ENCODER
+    cfg, _ = setup_cfg("df_gan_damsm.yml", **{"TEXT.VOCA_SIZE": 1000})
+    T, V = cfg.TEXT.MAX_LENGTH, cfg.TEXT.VOCA_SIZE
+    shapes = X.rnn_encoder_shapes(V, cfg.TEXT.EMBEDDING_DIM)
+    P = X.synth_rnn_params(shapes, 3)
+    caps, lens = X.synth_captions(batch, T, V, seed=batch)
+    w_o, s_o, m_o = X.rnn_encoder(P, caps, lens, T)
+    enc = RNN_ENCODER(cfg)
+    enc.load_state_dict(P)
+    enc = enc.to(DEV).eval()
+    w, s, m = enc(caps.to(DEV), lens.to(DEV))
+    assert torch.equal(m.cpu(), m_o)
+    assert rel_err(w, w_o) < 1e-5 and rel_err(s, s_o) < 1e-5
+    assert (w.cpu() - w_o).abs().max().item() < 2e-5
+    with pytest.raises(NotImplementedError):
+        enc.train()(caps, lens)
+    with pytest.raises(ValueError):
+        enc.eval()(caps, lens * 0)
+    bad = caps.clone()
+    bad[0, 0] = V
+    with pytest.raises(IndexError):
+        enc(bad, lens)

@@ -44,6 +44,27 @@ def test_forward_matches_reference(name):
             _close(stats(PD[str(n)]), fx["d_buf_after"][j], rtol=1e-3, atol=1e-4)
 
 
+@pytest.mark.parametrize("name", fixtures("rnn_"))
+def test_rnn_encoder_matches_reference(name):
+    """frozen text front end (encoder.py:73-153): state_dict layout and outputs of the reference's RNN_ENCODER."""
+    fx = load(name)
+    over = dict(kv.split("=") for kv in map(str, fx["over"]))
+    T = int(over.get("TEXT.MAX_LENGTH", 20))
+    V = int(over.get("TEXT.VOCA_SIZE", 27297))
+    shapes = X.rnn_encoder_shapes(V, 256)
+    tab = lambda s: sorted(f"{k}:{','.join(map(str, v))}" for k, v in s.items())
+    assert tab(shapes) == sorted(map(str, fx["keys"]))
+    P = X.synth_rnn_params(shapes, int(fx["seed"]))
+    caps, lens = X.synth_captions(int(fx["batch"]), T, V, int(fx["seed"]) + 1)
+    assert np.array_equal(caps.numpy(), fx["caps"]) and np.array_equal(lens.numpy(), fx["lens"])
+    assert int(lens[0]) == T and int(lens[1]) == 1                    # full-length and single-token captions are covered
+    words, sent, mask = X.rnn_encoder(P, caps, lens, T)
+    assert np.array_equal(mask.numpy(), fx["mask"])
+    _close(words, fx["words"], rtol=1e-5, atol=1e-6)
+    _close(sent, fx["sent"], rtol=1e-5, atol=1e-6)
+    assert (fx["words"][1, :, 1:] == 0).all()                        # padded positions are exactly zero
+
+
 def test_labels_and_contrastive_losses():
     fx = load("labels.npz")
     sent, a, b = (torch.from_numpy(fx[k]) for k in ("sent", "a", "b"))

@@ -635,6 +635,36 @@ def linear(x, w, b, geom, act=L.ACT_NONE, out_dtype=None):
     return y.view(x.shape[0], -1)
 
 
+# ------------------------------------------------------------------------------------------ text front end
+def embedding(ids, table):
+    """nn.Embedding lookup (encoder.py:132), forward only (the encoder is frozen, train_gan.py:466-468).
+    ids: int64 [...] on the device; table f32 [V, D] with D % 4 == 0.  Returns f32 [..., D]."""
+    if not table.is_cuda or not ids.is_cuda:
+        raise RuntimeError("xmc_gan_amd.ops.embedding: CPU tensors are not supported (no CPU fallback)")
+    assert ids.dtype == torch.int64 and table.dtype == torch.float32 and table.dim() == 2
+    ids = ids.contiguous()
+    table = table.detach().contiguous()
+    out = torch.empty(*ids.shape, table.shape[1], dtype=torch.float32, device=table.device)
+    L.call("xmc_embedding_gather", _p(ids), _p(table), _p(out), ids.numel(), table.shape[1], table.shape[0], _st())
+    return out
+
+
+def lstm_bidir(xproj, w_hh, lens, T):
+    """One-layer bidirectional LSTM recurrence over length-packed sequences (encoder.py:134-147), forward only.
+    xproj f32 [B,T,2,4H] (input projections + both biases), w_hh f32 [2,4H,H], lens int32 [B].
+    Returns words [B,2H,T] (zero at t >= len) and sent [B,2H] = [h_fwd(len-1), h_rev(0)]."""
+    if not xproj.is_cuda:
+        raise RuntimeError("xmc_gan_amd.ops.lstm_bidir: CPU tensors are not supported (no CPU fallback)")
+    B, H = xproj.shape[0], w_hh.shape[2]
+    assert xproj.dtype == torch.float32 and xproj.is_contiguous() and xproj.shape == (B, T, 2, 4 * H)
+    assert w_hh.dtype == torch.float32 and w_hh.is_contiguous() and w_hh.shape == (2, 4 * H, H)
+    assert lens.dtype == torch.int32 and lens.is_contiguous() and lens.numel() == B
+    words = torch.empty(B, 2 * H, T, dtype=torch.float32, device=xproj.device)
+    sent = torch.empty(B, 2 * H, dtype=torch.float32, device=xproj.device)
+    L.call("xmc_lstm_bidir", _p(xproj), _p(w_hh), _p(lens), _p(words), _p(sent), B, T, H, _st())
+    return words, sent
+
+
 class SpectralNormFn(torch.autograd.Function):
     """W / sigma(W) as the legacy ``torch.nn.utils.spectral_norm`` hook computes it (reference model/modules.py:3,16-17,
     31-32): in training mode ONE power iteration updates ``u`` [R] / ``v`` [C] in place (v <- normalize(W^T u),

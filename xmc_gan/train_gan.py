@@ -25,6 +25,8 @@ import torch
 from xmc_gan.config.gan import cfg, cfg_from_file
 from xmc_gan.model.df_gan import NetG as DF_GEN, NetD as DF_DISC
 from xmc_gan.model.df_concept_gan import InNetG as CONCEPT_IN_DF_GEN, OutNetG as CONCEPT_OUT_DF_GEN, NetD as CONCEPT_NETD
+from xmc_gan.dataset import SentTextDataset, WordTextDataset, test_transform, train_transform
+from xmc_gan.model.encoder import RNN_ENCODER, SBERT_ENCODER
 from xmc_gan.utils.logger import setup_logger
 from xmc_gan.utils.miscc import count_params
 from xmc_gan_amd import ops, parallel
@@ -32,6 +34,8 @@ from xmc_gan_amd.optim import HipAdam
 
 _GEN_ARCH = {"DF_GEN": DF_GEN, "CONCEPT_IN_DF_GEN": CONCEPT_IN_DF_GEN, "CONCEPT_OUT_DF_GEN": CONCEPT_OUT_DF_GEN}
 _DISC_ARCH = {"DF_DISC": DF_DISC, "CONCEPT_NETD": CONCEPT_NETD}
+_TEXT_DATASET = {"WORD": WordTextDataset, "SENT": SentTextDataset}
+_TEXT_ARCH = {"RNN": RNN_ENCODER, "SBERT": SBERT_ENCODER}
 
 
 def parse_args(argv=None):
@@ -239,12 +243,12 @@ def _bias_on_logit_path(netD, name):
 
 # --------------------------------------------------------------------------------------- synthetic front end
 class SyntheticCOCO:
-    """COCO-shaped random batches with the tuple layout of the reference loader
-    ``(imgs, [(caps, cap_lens)], keys)`` (dataset.py:64); `caps` is the batch index used by
-    :class:`SyntheticTextEncoder`.  Images are uniform in [-1,1] like Normalize(0.5,0.5) output (dataset.py:34-37)."""
+    """COCO-shaped random batches with the tuple layout of the reference loader ``(imgs, [(caps, cap_lens)], keys)``
+    (dataset.py:64): images uniform in [-1,1] like Normalize(0.5,0.5) output (dataset.py:34-37), captions as WordTextDataset
+    pads them (int64 token ids in [1, V), zeros after the length; dataset.py:104-111)."""
 
-    def __init__(self, n_batches, batch_size, img_size, max_len, seed):
-        self.n, self.bs, self.size, self.max_len, self.seed = n_batches, batch_size, img_size, max_len, seed
+    def __init__(self, n_batches, batch_size, img_size, max_len, seed, voca_size=27297):
+        self.n, self.bs, self.size, self.max_len, self.seed, self.voca = n_batches, batch_size, img_size, max_len, seed, voca_size
 
     def __len__(self):
         return self.n
@@ -254,19 +258,22 @@ class SyntheticCOCO:
             g = torch.Generator().manual_seed(self.seed * 100003 + i)
             imgs = torch.rand(self.bs, 3, self.size, self.size, generator=g) * 2 - 1
             lens = torch.randint(5, self.max_len + 1, (self.bs,), generator=g)
-            yield imgs, [((i,), lens)], [f'syn{i}_{j}' for j in range(self.bs)]
+            caps = torch.randint(1, self.voca, (self.bs, self.max_len), generator=g)
+            caps = caps * (torch.arange(self.max_len)[None, :] < lens[:, None])
+            yield imgs, [(caps, lens)], [f'syn{i}_{j}' for j in range(self.bs)]
 
 
 class SyntheticTextEncoder(torch.nn.Module):
-    """Stands in for the frozen RNN/SBERT encoder (encoder.py:70,154): returns
-    words_embs [B,E,T], sent_embs [B,E], mask [B,T] (True = padding) as deterministic random tensors."""
+    """Stands in for the frozen SBERT encoder (encoder.py:24-70; third-party package + checkpoint): returns
+    words_embs [B,E,T], sent_embs [B,E], mask [B,T] (True = padding) as random tensors that are a function of the captions."""
 
     def __init__(self, emb_dim, max_len, seed, device):
         super().__init__()
         self.e, self.t, self.seed, self.device = emb_dim, max_len, seed, device
 
     def forward(self, caps, cap_lens):
-        g = torch.Generator().manual_seed(self.seed * 7919 + int(caps[0]))
+        caps = torch.as_tensor(caps).cpu()
+        g = torch.Generator().manual_seed(self.seed * 7919 + int(caps[0, :4].sum()))
         B = cap_lens.size(0)
         words = torch.randn(B, self.e, self.t, generator=g)
         sent = torch.randn(B, self.e, generator=g)
@@ -306,6 +313,8 @@ def train(train_loader, test_loader, state_epoch, text_encoder, netG, netD, opti
             torch.save(optimizerG.state_dict(), f'{model_dir}/optimizerG.pth')
             torch.save(optimizerD.state_dict(), f'{model_dir}/optimizerD.pth')
             logger.info('Save models')
+            if test_loader is not None:
+                eval(loader=test_loader, state_epoch=epoch, text_encoder=text_encoder, netG=netG, logger=logger, num_samples=6000)
     return last
 
 
@@ -380,12 +389,35 @@ def main(argv=None):
     logger.info(cfg)
     logger.info(f'seed now is : {args.seed}')
 
-    if args.synthetic <= 0:
-        raise RuntimeError(
-            'real-data front end (dataset.py COCO pickles + frozen DAMSM/SBERT encoder weights) is not part of this '
-            'build; run with --synthetic N for COCO-shaped random batches')
-    train_loader = SyntheticCOCO(args.synthetic, cfg.TRAIN.BATCH_SIZE, cfg.IMG.SIZE, cfg.TEXT.MAX_LENGTH, seed)
-    text_encoder = SyntheticTextEncoder(cfg.TEXT.EMBEDDING_DIM, cfg.TEXT.MAX_LENGTH, seed, device)
+    test_loader = None
+    if args.synthetic > 0:
+        train_loader = SyntheticCOCO(args.synthetic, cfg.TRAIN.BATCH_SIZE, cfg.IMG.SIZE, cfg.TEXT.MAX_LENGTH, seed,
+                                     cfg.TEXT.VOCA_SIZE)
+    else:       # the reference's loaders (train_gan.py:440-457); each rank draws its own shuffled batches
+        data_dir = f'{PROJ_DIR}/data/{cfg.DATASET_NAME}'
+        data_arch = _TEXT_DATASET[cfg.TEXT.TYPE]
+        train_set = data_arch(data_dir=data_dir, mode='train', transform=train_transform(cfg.IMG.SIZE), cfg=cfg)
+        test_set = data_arch(data_dir=data_dir, mode='test', transform=test_transform(cfg.IMG.SIZE), cfg=cfg)
+        sampler = torch.utils.data.distributed.DistributedSampler(train_set, world, rank, shuffle=True, drop_last=True) \
+            if world > 1 else None
+        train_loader = torch.utils.data.DataLoader(train_set, batch_size=cfg.TRAIN.BATCH_SIZE, drop_last=True,
+                                                   shuffle=sampler is None, sampler=sampler,
+                                                   num_workers=int(cfg.TRAIN.NUM_WORKERS), pin_memory=True)
+        test_loader = torch.utils.data.DataLoader(test_set, batch_size=cfg.TRAIN.BATCH_SIZE, drop_last=True, shuffle=False,
+                                                  num_workers=int(cfg.TRAIN.NUM_WORKERS))
+    if args.synthetic > 0 and cfg.TEXT.ENCODER_NAME != 'RNN':
+        text_encoder = SyntheticTextEncoder(cfg.TEXT.EMBEDDING_DIM, cfg.TEXT.MAX_LENGTH, seed, device)
+    else:       # train_gan.py:459-468
+        text_encoder = _TEXT_ARCH[cfg.TEXT.ENCODER_NAME](cfg=cfg).to(device)
+        enc_path = f'{PROJ_DIR}/{cfg.TEXT.ENCODER_DIR}'
+        if cfg.TEXT.ENCODER_DIR != '' and (args.synthetic <= 0 or os.path.isfile(enc_path)):
+            text_encoder.load_state_dict(torch.load(enc_path, map_location=device))
+        elif world > 1:     # random (synthetic-run) encoder weights must agree across ranks
+            for p_ in text_encoder.parameters():
+                torch.distributed.broadcast(p_.data, 0)
+        for p_ in text_encoder.parameters():
+            p_.requires_grad = False
+        text_encoder.eval()
 
     netG, netD, optimizerG, optimizerD = build_models(device)
     if world > 1:   # same initial weights (and spectral-norm u/v vectors, which then evolve identically) on every rank
@@ -404,7 +436,7 @@ def main(argv=None):
     elif cfg.DISC.ENCODER_DIR:
         netD.load_state_dict(torch.load(f'{PROJ_DIR}/{cfg.DISC.ENCODER_DIR}', map_location=device), strict=False)
 
-    last = train(train_loader=train_loader, test_loader=None, state_epoch=state_epoch, text_encoder=text_encoder,
+    last = train(train_loader=train_loader, test_loader=test_loader, state_epoch=state_epoch, text_encoder=text_encoder,
                  netG=netG, netD=netD, optimizerG=optimizerG, optimizerD=optimizerD, logger=logger, model_dir=model_dir,
                  opts=StepOptions(gather_negatives=args.gather_negatives), img_dir=img_dir)
     torch.cuda.synchronize()
