@@ -1,0 +1,81 @@
+"""The cfg-driven entry point (``xmc_gan/train_gan.py``, reference train_gan.py:398-498) end to end on the GPU: synthetic
+batches through the real RNN_ENCODER, the real-data path (WordTextDataset + DataLoader + RNN_ENCODER) on a miniature
+COCO-style tree, and checkpoint save (epoch > 50, train_gan.py:328-334) followed by ``--resume_epoch``."""
+import math
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from golden_util import CFG_DIR
+
+
+def _mini_yml(tmp_path, **subst):
+    """df_gan_damsm.yml shrunk for a test run (thin network, tiny vocabulary, no pretrained encoder file)."""
+    txt = open(os.path.join(CFG_DIR, "df_gan_damsm.yml")).read()
+    rep = {"NCH: 32": "NCH: 8", "VOCA_SIZE: 27297": "VOCA_SIZE: 40", "BATCH_SIZE: 88": "BATCH_SIZE: 4",
+           "NUM_WORKERS: 8": "NUM_WORKERS: 0", "ENCODER_DIR: data/DAMSMencoders/coco/text_encoder100.pth": "ENCODER_DIR: ''",
+           "MAX_LENGTH: 20": "MAX_LENGTH: 8", "MAGP: true": "MAGP: false"}
+    rep.update(subst)
+    for a, b in rep.items():
+        assert a in txt, a
+        txt = txt.replace(a, b)
+    path = tmp_path / "mini.yml"
+    path.write_text(txt)
+    return str(path)
+
+
+def _mini_coco(root, n_img=8):
+    from PIL import Image
+    rng = np.random.RandomState(1)
+    (root / "images").mkdir(parents=True)
+    keys = [f"k{i:03d}" for i in range(n_img)]
+    for k in keys:
+        Image.fromarray(rng.randint(0, 256, (90, 100, 3), dtype=np.uint8)).save(root / "images" / f"{k}.jpg")
+    for mode in ("train", "test"):
+        (root / mode).mkdir()
+        with open(root / mode / "filenames.pickle", "wb") as f:
+            pickle.dump(keys, f)
+    caps = [list(rng.randint(1, 40, size=rng.randint(2, 12))) for _ in range(n_img * 5)]
+    i2w = {i: f"w{i}" for i in range(40)}
+    with open(root / "captions.pickle", "wb") as f:
+        pickle.dump([caps, caps, i2w, {v: k for k, v in i2w.items()}], f)
+    return str(root)
+
+
+def _finite(last):
+    assert {"errD", "errG"} <= set(last)
+    for k, v in last.items():
+        if torch.is_tensor(v) and v.numel() == 1:
+            assert math.isfinite(float(v)), k
+
+
+def test_synthetic_run_uses_the_hip_rnn_encoder(tmp_path):
+    import xmc_gan.train_gan as tg
+    last = tg.main(["--cfg", _mini_yml(tmp_path), "--synthetic", "3", "--max_epoch", "1", "--precision", "bf16",
+                    "--output_dir", str(tmp_path / "run")])
+    _finite(last)
+
+
+def test_real_data_path_and_resume(tmp_path):
+    import xmc_gan.train_gan as tg
+    data, run = _mini_coco(tmp_path / "coco"), str(tmp_path / "run")
+    yml = _mini_yml(tmp_path, **{"MAX_EPOCH: 121": "MAX_EPOCH: 52"})
+    last = tg.main(["--cfg", yml, "--data_dir", data, "--output_dir", run, "--precision", "fp32", "--seed", "3"])
+    _finite(last)
+    saved = sorted(os.listdir(os.path.join(run, "model")))
+    assert saved == ["netD_051.pth", "netD_052.pth", "netG_051.pth", "netG_052.pth", "optimizerD.pth", "optimizerG.pth"]
+    sd = torch.load(os.path.join(run, "model", "optimizerD.pth"), map_location="cpu")
+    assert all(float(st["step"]) == 52 * 2 for st in sd["state"].values())           # 2 batches of 4 per epoch, 52 epochs
+    # resume: loads the four files and trains epoch 53 only
+    yml2 = _mini_yml(tmp_path, **{"MAX_EPOCH: 121": "MAX_EPOCH: 53"})
+    last2 = tg.main(["--cfg", yml2, "--data_dir", data, "--output_dir", run, "--precision", "fp32", "--seed", "3",
+                     "--resume_epoch", "52"])
+    _finite(last2)
+    sd2 = torch.load(os.path.join(run, "model", "optimizerD.pth"), map_location="cpu")
+    assert all(float(st["step"]) == 53 * 2 for st in sd2["state"].values())
+    assert "netG_053.pth" in os.listdir(os.path.join(run, "model"))

@@ -60,12 +60,21 @@ __global__ __launch_bounds__(LG) void lstm_bidir_kernel(const float* __restrict_
     float c_state = 0.f;
     __syncthreads();
 
+    // input projection of (sample nb, step): fetched one step ahead so its HBM/L2 latency hides behind the mat-vec
+    auto xin = [&](int nb, int step) -> float {
+        const int t = dir == 0 ? step : len[nb] - 1 - step;
+        return step < len[nb] ? xproj[(((size_t)(b0 + nb) * T + t) * 2 + dir) * LG + j] : 0.f;
+    };
+    float xnext[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) xnext[nb] = xin(nb, 0);
+
     for (int step = 0; step < T; ++step) {
         float acc[NB];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
-            const int t = dir == 0 ? step : len[nb] - 1 - step;
-            acc[nb] = step < len[nb] ? xproj[(((size_t)(b0 + nb) * T + t) * 2 + dir) * LG + j] : 0.f;
+            acc[nb] = xnext[nb];
+            xnext[nb] = xin(nb, step + 1);
         }
 #pragma unroll
         for (int k = 0; k < LH; k += 4) {

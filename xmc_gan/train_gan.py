@@ -51,6 +51,8 @@ def parse_args(argv=None):
     parser.add_argument('--synthetic', type=int, default=0, metavar='N',
                         help='train on N COCO-shaped random batches per epoch instead of data/<DATASET_NAME>')
     parser.add_argument('--max_epoch', type=int, default=-1)
+    parser.add_argument('--data_dir', type=str, default='', help='dataset root (default: <repo>/data/<DATASET_NAME>)')
+    parser.add_argument('--output_dir', type=str, default='', help='run directory (default: <repo>/output/<name>)')
     parser.add_argument('--precision', type=str, default=None, choices=['bf16', 'fp32'])
     parser.add_argument('--gather_negatives', action='store_true',
                         help='data parallel: all-gather embeddings so the contrastive losses see world*batch negatives')
@@ -379,7 +381,7 @@ def main(argv=None):
     torch.manual_seed(seed)
     torch.cuda.manual_seed_all(seed)
 
-    output_dir = f'{PROJ_DIR}/output/{cfg.DATASET_NAME}{cfg.IMG.SIZE}_{cfg.CONFIG_NAME}_{args.seed}'
+    output_dir = args.output_dir or f'{PROJ_DIR}/output/{cfg.DATASET_NAME}{cfg.IMG.SIZE}_{cfg.CONFIG_NAME}_{args.seed}'
     img_dir, log_dir, model_dir = output_dir + '/img', output_dir + '/log', output_dir + '/model'
     if rank == 0:
         for d_ in (output_dir, img_dir, log_dir, model_dir):
@@ -394,7 +396,7 @@ def main(argv=None):
         train_loader = SyntheticCOCO(args.synthetic, cfg.TRAIN.BATCH_SIZE, cfg.IMG.SIZE, cfg.TEXT.MAX_LENGTH, seed,
                                      cfg.TEXT.VOCA_SIZE)
     else:       # the reference's loaders (train_gan.py:440-457); each rank draws its own shuffled batches
-        data_dir = f'{PROJ_DIR}/data/{cfg.DATASET_NAME}'
+        data_dir = args.data_dir or f'{PROJ_DIR}/data/{cfg.DATASET_NAME}'
         data_arch = _TEXT_DATASET[cfg.TEXT.TYPE]
         train_set = data_arch(data_dir=data_dir, mode='train', transform=train_transform(cfg.IMG.SIZE), cfg=cfg)
         test_set = data_arch(data_dir=data_dir, mode='test', transform=test_transform(cfg.IMG.SIZE), cfg=cfg)
