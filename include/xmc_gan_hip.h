@@ -143,6 +143,28 @@ int xmc_axpby_up_lrelu(const void* a, const void* b, const float* alpha_dev, voi
 int xmc_scale(const void* x, const float* alpha_dev, void* y, int64_t n, int dtype, void* stream);
 /* *out (+)= sum(a*b)  (f32 scalar; out zeroed by caller when accumulate==0 is not desired) */
 int xmc_dot(const void* a, const void* b, float* out, int64_t n, int dtype, void* stream);
+/* Grouped small f32 GEMMs: all conditioning MLPs of the generator (df_gan.py:232-241, two per `affine`, 213-222: four affines
+ * per G_Block) in one launch per layer and direction.  Problem g computes C[i,j] = sum_r A(i,r) * B(j,r) for i < M, j < N, r < K
+ * with A(i,r) = A[i*sa_i + r*sa_r], B(j,r) = B[j*sb_j + r*sb_r] (element strides, so y = x W^T, dx = dy W and dW = dy^T x are all
+ * expressible), C row-major [M,N]; then, by flags: + bias[j]; ReLU; zero where mask[i*N+j] <= 0 (ReLU' of a saved output);
+ * atomicAdd into C instead of a store.  rowsum (may be NULL): rowsum[i] = sum_r A(i,r) (bias gradient riding on the weight
+ * gradient).  The table is HOST memory (it is passed on in kernel arguments, 32 problems per launch); tile0 is filled in by the
+ * call. */
+enum { XMC_GP_BIAS = 1, XMC_GP_RELU = 2, XMC_GP_MASK = 4, XMC_GP_ATOMIC = 8 };
+typedef struct XmcGemmProblem {
+    const float* A;
+    const float* B;
+    const float* bias;
+    const float* mask;
+    float* C;
+    float* rowsum;
+    int32_t M, N, K;
+    int32_t sa_i, sa_r, sb_j, sb_r;
+    int32_t flags;
+    int32_t tile0;
+    int32_t reserved;
+} XmcGemmProblem;
+int xmc_gemm_group(const XmcGemmProblem* problems, int nproblems, void* stream);
 /* Frozen text front end, RNN_ENCODER.forward in eval mode (reference model/encoder.py:118-153).
  * xmc_embedding_gather: nn.Embedding lookup (encoder.py:132): out[n, :] = table[ids[n], :], f32, dim % 4 == 0; ids outside
  *   [0, vocab) give a zero row (the host wrapper validates ids before the call).

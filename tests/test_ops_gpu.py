@@ -455,3 +455,44 @@ def test_spectral_weight_matches_legacy_hook_arithmetic(R, C, training):
         assert rel(up, u) < 2e-5 and rel(vp, v) < 2e-5
     else:
         assert torch.equal(up.cpu(), u0) and torch.equal(vp.cpu(), v0)
+
+
+@pytest.mark.parametrize("B,K,Hd,Cs,c_grad", [(256, 256, 256, [256, 256, 128, 64, 32, 32], False),
+                                                (7, 20, 24, [5, 64, 65, 130], True),
+                                                (64, 256, 256, [32] * 40, True)])
+def test_cond_mlp_bank_matches_per_layer_reference(B, K, Hd, Cs, c_grad):
+    """grouped-GEMM bank of conditioning MLPs (df_gan.py:232-241) vs Linear-ReLU-Linear in f64 on the CPU: outputs and
+    every parameter gradient (and dc), including sizes that are not multiples of the 64x64 tile / 16-wide K chunk and more
+    problems than one kernel-argument chunk (40 > 32).  f32 FMA sums over <= 256 terms: 1e-5 relative L2."""
+    g = torch.Generator().manual_seed(B + K + len(Cs))
+    c = torch.randn(B, K, generator=g)
+    mk = lambda *s: torch.randn(*s, generator=g) * 0.2
+    P = [(mk(Hd, K), mk(Hd), mk(C, Hd), mk(C)) for C in Cs]
+    dY = [torch.randn(B, C, generator=g) for C in Cs]
+    # reference
+    cd = c.double().requires_grad_(c_grad)
+    Pd = [tuple(t.double().requires_grad_(True) for t in m) for m in P]
+    loss = 0
+    ys_ref = []
+    for (w1, b1, w2, b2), dy in zip(Pd, dY):
+        y = torch.relu(cd @ w1.t() + b1) @ w2.t() + b2
+        ys_ref.append(y.detach())
+        loss = loss + (y * dy.double()).sum()
+    loss.backward()
+    # product
+    cp = c.to(DEV).requires_grad_(c_grad)
+    Pp = [tuple(t.to(DEV).requires_grad_(True) for t in m) for m in P]
+    ys = ops.cond_mlp_bank(cp, Pp)
+    assert len(ys) == len(Cs)
+    sum((y * dy.to(DEV)).sum() for y, dy in zip(ys, dY)).backward()
+    rel = lambda a, b: ((a.detach().double().cpu() - b).norm() / b.norm().clamp_min(1e-30)).item()
+    for y, yr in zip(ys, ys_ref):
+        assert y.shape == yr.shape and y.is_contiguous() and rel(y, yr) < 1e-5
+    for mp, md in zip(Pp, Pd):
+        for tp, td in zip(mp, md):
+            assert tp.grad.shape == td.grad.shape and tp.grad.is_contiguous()
+            assert rel(tp.grad, td.grad) < 1e-5
+    if c_grad:
+        assert rel(cp.grad, cd.grad) < 1e-5
+    else:
+        assert cp.grad is None

@@ -272,6 +272,10 @@ int launch(const XmcConvDesc& d, hipStream_t st) {
 template <int DT>
 int dispatch(const XmcConvDesc& d, hipStream_t st) {
     static const int variant = getenv("XMC_IGEMM_VARIANT") ? atoi(getenv("XMC_IGEMM_VARIANT")) : 0;
+    // batch-sized GEMMs (the conditioning MLPs: M = batch, K = N = 256): a 128-wide N tile leaves 4 workgroups on the
+    // chip and each walks all of K alone; 32-wide tiles give 4x the workgroups and a 4x shorter critical path
+    static const bool no_small = getenv("XMC_NO_SMALL_M") != nullptr;
+    if (!no_small && (int64_t)d.N * d.MH * d.MW <= 1024) return launch<DT, 128, 32, 4, 1, 2>(d, st);
     if (d.CDw % 128 == 0) {
         const int64_t M = (int64_t)d.N * d.MH * d.MW;
         if (variant == 1) return launch<DT, 128, 128, 2, 2, 2>(d, st);

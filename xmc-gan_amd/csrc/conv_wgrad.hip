@@ -214,6 +214,11 @@ template <int DT>
 int dispatch(const XmcConvDesc& d, float* dwp, float* dbias, hipStream_t st) {
     const bool wide_ci = d.CS > 32;
     constexpr int KPB = DT == XMC_BF16 ? 64 : 32;     // pixels per K step for the big tiles
+    // batch-sized reductions (the conditioning MLPs: 256 "pixels"): small tiles so that the few K steps are spread
+    // over 64+ workgroups instead of 16
+    static const bool no_small = getenv("XMC_NO_SMALL_M") != nullptr;
+    if (!no_small && (int64_t)d.N * d.MH * d.MW <= 1024)
+        return wide_ci ? launch<DT, 32, 64, 1, 4, 32>(d, dwp, dbias, st) : launch<DT, 32, 32, 2, 2, 32>(d, dwp, dbias, st);
     if (d.CDw % 128 == 0) {
         if (d.CS % 128 == 0 && DT == XMC_BF16) return launch<DT, 128, 128, 2, 2, KPB>(d, dwp, dbias, st);
         return wide_ci ? launch<DT, 128, 64, 4, 1, KPB>(d, dwp, dbias, st) : launch<DT, 128, 32, 4, 1, KPB>(d, dwp, dbias, st);

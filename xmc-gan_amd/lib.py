@@ -28,6 +28,13 @@ class ConvDesc(C.Structure):
                 ("mask", vp), ("res_scale", f32), ("res_mode", i32)]
 
 
+# XmcGemmProblem as a numpy record (filled vectorised on the host, handed to xmc_gemm_group by pointer)
+GEMM_PROBLEM = [("A", "u8"), ("B", "u8"), ("bias", "u8"), ("mask", "u8"), ("C", "u8"), ("rowsum", "u8"),
+                ("M", "i4"), ("N", "i4"), ("K", "i4"), ("sa_i", "i4"), ("sa_r", "i4"), ("sb_j", "i4"), ("sb_r", "i4"),
+                ("flags", "i4"), ("tile0", "i4"), ("reserved", "i4")]
+GP_BIAS, GP_RELU, GP_MASK, GP_ATOMIC = 1, 2, 4, 8
+
+
 class AdamEntry(C.Structure):
     _fields_ = [("param", vp), ("grad", vp), ("m", vp), ("v", vp), ("step", vp), ("n", i64)]
 
@@ -56,6 +63,7 @@ _SIGS = {
     "xmc_axpby_up_lrelu": [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "xmc_scale": [vp, vp, vp, i64, i32, vp],
     "xmc_dot": [vp, vp, vp, i64, i32, vp],
+    "xmc_gemm_group": [vp, i32, vp],
     "xmc_embedding_gather": [vp, vp, vp, i64, i32, i64, vp],
     "xmc_lstm_bidir": [vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "xmc_spectral_sigma": [vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp],

@@ -13,6 +13,7 @@ import os
 import threading
 import weakref
 
+import numpy as np
 import torch
 
 from . import lib as L
@@ -633,6 +634,126 @@ def linear(x, w, b, geom, act=L.ACT_NONE, out_dtype=None):
     """x [B,K] -> [B,cout_p] through the 1x1 path (nn.Linear: df_gan.py:73-74,144,233-240)."""
     y = ConvFn.apply(x.contiguous().view(x.shape[0], 1, 1, x.shape[1]), w, b, geom, act, out_dtype or x.dtype)
     return y.view(x.shape[0], -1)
+
+
+# ------------------------------------------------------------------------------------------ conditioning MLP bank
+def _gemm_group(tab):
+    L.call("xmc_gemm_group", C.c_void_p(tab.ctypes.data), len(tab), _st())
+
+
+def _offsets(sizes):
+    off = np.zeros(len(sizes) + 1, dtype=np.int64)
+    np.cumsum(sizes, out=off[1:])
+    return off
+
+
+class CondMLPBankFn(torch.autograd.Function):
+    """All G conditioning MLPs  y_g = Linear2_g(ReLU(Linear1_g(c)))  (df_gan.py:232-241; two per `affine`, four affines per
+    G_Block, every block reads the same sentence embedding c) as grouped GEMM launches: 2 forward (x ceil(G/32) kernel-argument
+    chunks), 3 backward (+1 when c needs a gradient) instead of 2 / 4-5 launches PER MLP.
+
+    apply(c, w1_0, b1_0, w2_0, b2_0, w1_1, ...) -> (y_0 [B,C_0], y_1, ...), all f32.  Once differentiable (the generator is
+    never differentiated twice: MA-GP is a discriminator-only term, train_gan.py:232-252)."""
+
+    @staticmethod
+    def forward(ctx, c, *params):
+        assert len(params) % 4 == 0 and c.dtype == torch.float32 and c.is_cuda
+        c = c.contiguous()
+        G = len(params) // 4
+        w1, b1, w2, b2 = params[0::4], params[1::4], params[2::4], params[3::4]
+        B, K = c.shape
+        Hd = w1[0].shape[0]
+        for g in range(G):
+            assert w1[g].shape == (Hd, K) and w2[g].shape[1] == Hd and w1[g].is_contiguous() and w2[g].is_contiguous()
+            assert w1[g].dtype == torch.float32 and w2[g].dtype == torch.float32
+        Cs = np.array([w.shape[0] for w in w2], dtype=np.int64)
+        yoff = _offsets(Cs * B)
+        h = torch.empty(G, B, Hd, dtype=torch.float32, device=c.device)
+        y = torch.empty(int(yoff[-1]), dtype=torch.float32, device=c.device)
+        ptr = lambda ts: np.array([t.data_ptr() for t in ts], dtype=np.uint64)
+        pw1, pb1, pw2, pb2 = ptr(w1), ptr(b1), ptr(w2), ptr(b2)
+        ph = (h.data_ptr() + np.arange(G, dtype=np.int64) * (B * Hd * 4)).astype(np.uint64)
+        py = (y.data_ptr() + yoff[:-1] * 4).astype(np.uint64)
+        t = np.zeros(G, dtype=L.GEMM_PROBLEM)            # h_g = relu(c W1_g^T + b1_g)
+        t["A"], t["B"], t["bias"], t["C"] = c.data_ptr(), pw1, pb1, ph
+        t["M"], t["N"], t["K"] = B, Hd, K
+        t["sa_i"], t["sa_r"], t["sb_j"], t["sb_r"] = K, 1, K, 1
+        t["flags"] = L.GP_BIAS | L.GP_RELU
+        _gemm_group(t)
+        t = np.zeros(G, dtype=L.GEMM_PROBLEM)            # y_g = h_g W2_g^T + b2_g
+        t["A"], t["B"], t["bias"], t["C"] = ph, pw2, pb2, py
+        t["M"], t["N"], t["K"] = B, Cs, Hd
+        t["sa_i"], t["sa_r"], t["sb_j"], t["sb_r"] = Hd, 1, Hd, 1
+        t["flags"] = L.GP_BIAS
+        _gemm_group(t)
+        ctx.save_for_backward(c, h, *w1, *w2)
+        ctx.dims = (G, B, K, Hd, Cs, yoff)
+        outs = tuple(y[int(yoff[g]):int(yoff[g + 1])].view(B, int(Cs[g])) for g in range(G))
+        return outs
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, *dys):
+        G, B, K, Hd, Cs, yoff = ctx.dims
+        saved = ctx.saved_tensors
+        c, h, w1, w2 = saved[0], saved[1], saved[2:2 + G], saved[2 + G:2 + 2 * G]
+        dev = c.device
+        dys = [torch.zeros(B, int(Cs[g]), dtype=torch.float32, device=dev) if d is None else d.contiguous().float()
+               for g, d in enumerate(dys)]
+        ptr = lambda ts: np.array([t.data_ptr() for t in ts], dtype=np.uint64)
+        pdy, pw1, pw2 = ptr(dys), ptr(w1), ptr(w2)
+        steps = np.arange(G, dtype=np.int64)
+        ph = (h.data_ptr() + steps * (B * Hd * 4)).astype(np.uint64)
+        dh = torch.empty(G, B, Hd, dtype=torch.float32, device=dev)
+        pdh = (dh.data_ptr() + steps * (B * Hd * 4)).astype(np.uint64)
+        w2off = _offsets(Cs * Hd)
+        dw2 = torch.empty(int(w2off[-1]), dtype=torch.float32, device=dev)
+        boff = _offsets(Cs)
+        db2 = torch.empty(int(boff[-1]), dtype=torch.float32, device=dev)
+        dw1 = torch.empty(G, Hd, K, dtype=torch.float32, device=dev)
+        db1 = torch.empty(G, Hd, dtype=torch.float32, device=dev)
+        t = np.zeros(G, dtype=L.GEMM_PROBLEM)            # dh_g = (dy_g W2_g) * relu'(h_g)
+        t["A"], t["B"], t["mask"], t["C"] = pdy, pw2, ph, pdh
+        t["M"], t["N"], t["K"] = B, Hd, Cs
+        t["sa_i"], t["sa_r"], t["sb_j"], t["sb_r"] = Cs, 1, 1, Hd
+        t["flags"] = L.GP_MASK
+        _gemm_group(t)
+        t = np.zeros(G, dtype=L.GEMM_PROBLEM)            # dW2_g = dy_g^T h_g, db2_g = colsum(dy_g)
+        t["A"], t["B"] = pdy, ph
+        t["C"] = (dw2.data_ptr() + w2off[:-1] * 4).astype(np.uint64)
+        t["rowsum"] = (db2.data_ptr() + boff[:-1] * 4).astype(np.uint64)
+        t["M"], t["N"], t["K"] = Cs, Hd, B
+        t["sa_i"], t["sa_r"], t["sb_j"], t["sb_r"] = 1, Cs, 1, Hd
+        _gemm_group(t)
+        t = np.zeros(G, dtype=L.GEMM_PROBLEM)            # dW1_g = dh_g^T c, db1_g = colsum(dh_g)
+        t["A"], t["B"] = pdh, c.data_ptr()
+        t["C"] = (dw1.data_ptr() + steps * (Hd * K * 4)).astype(np.uint64)
+        t["rowsum"] = (db1.data_ptr() + steps * (Hd * 4)).astype(np.uint64)
+        t["M"], t["N"], t["K"] = Hd, K, B
+        t["sa_i"], t["sa_r"], t["sb_j"], t["sb_r"] = 1, Hd, 1, K
+        _gemm_group(t)
+        dc = None
+        if ctx.needs_input_grad[0]:                      # dc = sum_g dh_g W1_g
+            dc = torch.zeros(B, K, dtype=torch.float32, device=dev)
+            t = np.zeros(G, dtype=L.GEMM_PROBLEM)
+            t["A"], t["B"], t["C"] = pdh, pw1, dc.data_ptr()
+            t["M"], t["N"], t["K"] = B, K, Hd
+            t["sa_i"], t["sa_r"], t["sb_j"], t["sb_r"] = Hd, 1, 1, K
+            t["flags"] = L.GP_ATOMIC
+            _gemm_group(t)
+        grads = [dc]
+        for g in range(G):
+            Cg = int(Cs[g])
+            grads += [dw1[g], db1[g], dw2[int(w2off[g]):int(w2off[g + 1])].view(Cg, Hd), db2[int(boff[g]):int(boff[g + 1])]]
+        return tuple(grads)
+
+
+def cond_mlp_bank(c, mlps):
+    """mlps: sequence of (w1, b1, w2, b2) parameter tuples -> tuple of f32 [B, C_g] outputs."""
+    if not c.is_cuda:
+        raise RuntimeError("xmc_gan_amd.ops.cond_mlp_bank: CPU tensors are not supported (no CPU fallback)")
+    flat = [t for m in mlps for t in m]
+    return CondMLPBankFn.apply(c.float(), *flat)
 
 
 # ------------------------------------------------------------------------------------------ text front end

@@ -98,28 +98,36 @@ class NetG(nn.Module):
     def forward(self, noise, sent_embs, **kwargs):
         out = self.stem(noise)
         sent_embs = self.proj_sent(sent_embs.float())
-        # The 8 conditioning MLPs of every block depend only on the sentence embedding: enqueue them on a side stream
-        # so their ~100 tiny launches (and, through autograd, their backward) overlap the convolution stream.
-        main = torch.cuda.current_stream()
-        side = _side_stream(sent_embs.device)
-        side.wait_stream(main)
-        mods, events = [], []
-        with torch.cuda.stream(side):
-            for gblock in self.upblocks:
-                mods.append(gblock.modulation(sent_embs))
-                ev = torch.cuda.Event()
-                ev.record(side)
-                events.append(ev)
+        # The 8 conditioning MLPs of every block depend only on the sentence embedding: all of them (40-56 two-layer MLPs)
+        # run as grouped GEMM launches up front.  (XMC_NO_MLP_BANK=1: one launch per Linear on a side stream, the earlier
+        # form, kept for ablation -- its ~700 tiny kernels per iteration queue behind the one-workgroup-per-CU convolution
+        # kernels instead of overlapping them.)
+        nblk = len(self.upblocks)
+        if os.environ.get("XMC_NO_MLP_BANK") is None:
+            flat = ops.cond_mlp_bank(sent_embs, [m for g in self.upblocks for m in g.modulation_mlps()])
+            mods, events = [flat[8 * i:8 * i + 8] for i in range(nblk)], [None] * nblk
+            main = None
+        else:
+            main = torch.cuda.current_stream()
+            side = _side_stream(sent_embs.device)
+            side.wait_stream(main)
+            mods, events = [], []
+            with torch.cuda.stream(side):
+                for gblock in self.upblocks:
+                    mods.append(gblock.modulation(sent_embs))
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                    events.append(ev)
         # Blocks hand over their output BEFORE the nearest x2 upsample (df_gan.py:201-202); the next block consumes it
         # through operators that commute with / absorb the upsample, so the 4x larger tensor is never written.
         pending_up = False
         fuse_up = os.environ.get("XMC_NO_UPCONV") is None
-        nblk = len(self.upblocks)
         lrelu_done = False
         for bi, (gblock, m, ev) in enumerate(zip(self.upblocks, mods, events)):
-            main.wait_event(ev)
-            for t in m:
-                t.record_stream(main)
+            if ev is not None:
+                main.wait_event(ev)
+                for t in m:
+                    t.record_stream(main)
             last = bi == nblk - 1 and not gblock.upsample      # its output goes straight into the tail's LeakyReLU
             out = gblock.forward_fused(out, m, pending_up, out_lrelu=last)
             lrelu_done = last
@@ -217,6 +225,14 @@ class G_Block(nn.Module):
         self.gamma = nn.Parameter(torch.zeros(1))
         if self.learnable_sc:
             self.c_sc = HipConv2d(in_dim, out_dim, 1, stride=1, padding=0)
+
+    def modulation_mlps(self):
+        """(w1, b1, w2, b2) of the eight conditioning MLPs, in the order ``modulation`` returns their outputs"""
+        out = []
+        for a in (self.affine0, self.affine1, self.affine2, self.affine3):
+            for m in (a.fc_gamma, a.fc_beta):
+                out.append((m.linear1.weight, m.linear1.bias, m.linear2.weight, m.linear2.bias))
+        return out
 
     def modulation(self, c):
         """the eight per-sample (scale, shift) vectors of this block, f32 [B,C] each"""
