@@ -37,10 +37,9 @@ def allreduce_mean_grads(params, bucket_elems=16 * 1024 * 1024):
         flat = torch.cat([g.reshape(-1) for g in bucket])
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
         flat.mul_(1.0 / W)
-        off = 0
-        for g in bucket:
-            g.copy_(flat[off:off + g.numel()].view_as(g))
-            off += g.numel()
+        # one multi-tensor copy back instead of a copy kernel per parameter (~100 per bucket)
+        parts = [v.view_as(g) for v, g in zip(flat.split([g.numel() for g in bucket]), bucket)]
+        torch._foreach_copy_(bucket, parts)
         bucket, n = [], 0
 
     for g in grads:
