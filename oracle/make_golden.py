@@ -41,7 +41,9 @@ def build_ref(cfg, M, seed):
     """Reference models with deterministic synthetic parameters (strict load pins keys+shapes)."""
     h = X.Hyper.from_cfg(cfg)
     gen_cls = {"DF_GEN": M.df_gan.NetG, "CONCEPT_IN_DF_GEN": M.df_concept_gan.InNetG,
-               "CONCEPT_OUT_DF_GEN": M.df_concept_gan.OutNetG}[cfg.GEN.ENCODER_NAME]
+               "CONCEPT_OUT_DF_GEN": M.df_concept_gan.OutNetG,
+               # un-wired upstream (its registry entry is commented out, train_gan.py:31,44): the class itself is importable
+               "CONCEPT_OUTATTN_GEN": M.concept_gan.OutNetG}[cfg.GEN.ENCODER_NAME]
     netG = gen_cls(cfg)
     netD = M.df_gan.NetD(cfg, is_disc=True)
     PG = X.synth_params(X.gen_shapes(h), seed)
@@ -73,6 +75,9 @@ def golden_forward(name, yml, batch, seed, out_dir, **over):
         fake=fake.numpy(), feat=feat.numpy(), feat_fake_stats=stats(feat_f), logit=logit.numpy(),
         img_emb=img_emb.numpy(), txt_emb=txt_emb.numpy(), psent=psent.numpy(),
         # spectral norm: the power-iteration buffers after these calls (each forward call in training mode updates them)
+        # BatchNorm generators: running statistics after this one training-mode forward
+        g_buf_names=np.array([n for n, _ in netG.named_buffers()]),
+        g_buf_after=np.stack([stats(b_) for _, b_ in netG.named_buffers()]) if len(list(netG.named_buffers())) else np.zeros((0, 5)),
         d_buf_names=np.array([n for n, _ in netD.named_buffers()]),
         d_buf_after=np.stack([stats(b_) for _, b_ in netD.named_buffers()]) if len(list(netD.named_buffers())) else np.zeros((0, 5)))
     print(f"fwd_{name}: fake {tuple(fake.shape)} feat {tuple(feat.shape)}")
@@ -211,6 +216,8 @@ def golden_step(name, yml, batch, steps, seed, out_dir, **over):
     rec["d_names"] = np.array([n for n, _ in netD.named_parameters()])
     rec["g_final"] = np.stack([stats(p) for _, p in netG.named_parameters()])
     rec["d_final"] = np.stack([stats(p) for _, p in netD.named_parameters()])
+    rec["g_buf_names"] = np.array([n for n, _ in netG.named_buffers()])
+    rec["g_buf_final"] = np.stack([stats(b_) for _, b_ in netG.named_buffers()]) if len(list(netG.named_buffers())) else np.zeros((0, 5))
     rec["d_buf_names"] = np.array([n for n, _ in netD.named_buffers()])
     rec["d_buf_final"] = np.stack([stats(b_) for _, b_ in netD.named_buffers()]) if len(list(netD.named_buffers())) else np.zeros((0, 5))
     np.savez_compressed(os.path.join(out_dir, f"step_{name}.npz"), **rec)
@@ -274,6 +281,11 @@ def main():
     golden_forward("sn64_nch8", "df_gan_damsm.yml", 2, 31, a.out, **SN)
     golden_step("sn64_nomagp", "df_gan_damsm_nomagp.yml", 4, 2, 32, a.out, **SN)
     golden_step("sn64_magp", "df_gan_damsm.yml", 3, 1, 33, a.out, **SN)
+    # word-attention generator concept_gan.OutNetG: BatchNorm blocks + word<->concept attention with mask
+    WG = {"GEN.ENCODER_NAME": "CONCEPT_OUTATTN_GEN", **N8}
+    golden_forward("wordg64_nch8", "df_gan_damsm_nomagp.yml", 3, 51, a.out, **WG)
+    golden_forward("wordg128_nonorm", "df_gan_sbert_damsm_nomagp.yml", 2, 52, a.out, **{"IMG.SIZE": 128, "GEN.NORMALIZE": False, **WG})
+    golden_step("wordg64", "df_gan_damsm_nomagp.yml", 4, 2, 53, a.out, **WG)
     # frozen text front end: embedding + bidirectional LSTM over packed captions
     golden_rnn_encoder("enc_damsm", "df_gan_damsm.yml", 6, 41, a.out)
     golden_rnn_encoder("enc_len12", "df_gan_damsm.yml", 5, 42, a.out, **{"TEXT.MAX_LENGTH": 12, "TEXT.VOCA_SIZE": 500})

@@ -134,4 +134,6 @@ def modules():
     import xmc_gan.model.df_gan as df_gan
     import xmc_gan.model.df_concept_gan as df_concept_gan
     import xmc_gan.model.encoder as encoder
-    return types.SimpleNamespace(train_gan=tg, df_gan=df_gan, df_concept_gan=df_concept_gan, encoder=encoder)
+    import xmc_gan.model.concept_gan as concept_gan
+    return types.SimpleNamespace(train_gan=tg, df_gan=df_gan, df_concept_gan=df_concept_gan, encoder=encoder,
+                                 concept_gan=concept_gan)

@@ -233,7 +233,69 @@ def concept_netg_shapes(h: Hyper):
     return s
 
 
+def word_gen_arch(img_size: int, nch: int):
+    """channel tables of the word-attention generators (concept_gan.py:11-37)"""
+    mult = {256: ([16, 16, 8, 8, 4, 2, 1], [16, 8, 8, 4, 2, 1, 1]),
+            128: ([16, 8, 8, 4, 2, 1], [8, 8, 4, 2, 1, 1]),
+            64: ([8, 8, 4, 2, 1], [8, 4, 2, 1, 1])}[img_size]
+    depth = len(mult[0])
+    return dict(in_channels=[m * nch for m in mult[0]], out_channels=[m * nch for m in mult[1]],
+                upsample=[True] * (depth - 1) + [False], depth=depth)
+
+
+def _bn_shapes(s, p, n):
+    s[f"{p}.weight"] = (n,); s[f"{p}.bias"] = (n,)
+    s[f"{p}.running_mean"] = (n,); s[f"{p}.running_var"] = (n,); s[f"{p}.num_batches_tracked"] = ()
+
+
+def word_netg_shapes(h: Hyper):
+    """state_dict of concept_gan.OutNetG (concept_gan.py:244-279): two BatchNorm-conditional ResBlockUp (454-476), then
+    OCAttnResBlockUp (300-318) with the word-attention OutConceptBlock (346-371)."""
+    a = word_gen_arch(h.img_size, h.nch)
+    gc = h.noise_dim + h.nef
+    gw, sw = CARD * PW, CARD * SD
+    s = {"proj_sent.weight": (h.nef, h.text_dim), "proj_sent.bias": (h.nef,),
+         "proj_word.weight": (h.nef, h.text_dim, 1), "proj_word.bias": (h.nef,),
+         "proj_cond.weight": (a["in_channels"][0] * 16, gc), "proj_cond.bias": (a["in_channels"][0] * 16,)}
+    for i in range(a["depth"]):
+        p, ci, co = f"upblocks.{i}", a["in_channels"][i], a["out_channels"][i]
+        if i < 2:
+            s[f"{p}.c1.weight"] = (co, ci, 3, 3); s[f"{p}.c1.bias"] = (co,)
+            s[f"{p}.c2.weight"] = (co, co, 3, 3); s[f"{p}.c2.bias"] = (co,)
+            if h.normalize:
+                _bn_shapes(s, f"{p}.bn1", ci)
+                _bn_shapes(s, f"{p}.bn2", co)
+            s[f"{p}.linear_gamma1.weight"] = (ci, gc); s[f"{p}.linear_beta1.weight"] = (ci, gc)
+            s[f"{p}.linear_gamma2.weight"] = (co, gc); s[f"{p}.linaer_beta2.weight"] = (co, gc)     # sic (473)
+        else:
+            q = f"{p}.concept1"
+            s[f"{q}.split_conv.weight"] = (gw, ci, 1, 1)
+            s[f"{q}.trans_gconv.weight"] = (gw, PW, 3, 3)
+            if h.normalize:
+                s[f"{q}.gn.weight"] = (gw,); s[f"{q}.gn.bias"] = (gw,)
+            for j in (1, 2):
+                for nm in ("query", "key", "value"):
+                    s[f"{q}.concept_sampler{j}.{nm}_gconv.weight"] = (sw, PW, 1, 1)
+                if h.normalize:
+                    for g_ in ("gn1", "gn2"):
+                        s[f"{q}.concept_sampler{j}.{g_}.weight"] = (sw,); s[f"{q}.concept_sampler{j}.{g_}.bias"] = (sw,)
+                s[f"{q}.concept_sampler{j}.norm"] = ()
+                s[f"{q}.concept_reasoner{j}.proj_edge.weight"] = (CARD, SD)
+                if h.normalize:
+                    _bn_shapes(s, f"{q}.concept_reasoner{j}.bn", CARD)
+                s[f"{q}.word_conv{j}.weight"] = (SD, h.nef, 1)
+                for nm in ("gamma", "beta"):
+                    s[f"{q}.{nm}{j}_gconv.weight"] = (gw, gc + SD, 1, 1); s[f"{q}.{nm}{j}_gconv.bias"] = (gw,)
+            s[f"{p}.conv_out1.weight"] = (co, gw, 1, 1); s[f"{p}.conv_out1.bias"] = (co,)
+        if ci != co:
+            s[f"{p}.c_sc.weight"] = (co, ci, 1, 1); s[f"{p}.c_sc.bias"] = (co,)
+    s["conv_out.1.weight"] = (3, a["out_channels"][-1], 3, 3); s["conv_out.1.bias"] = (3,)
+    return s
+
+
 def gen_shapes(h: Hyper):
+    if h.gen == "CONCEPT_OUTATTN_GEN":
+        return word_netg_shapes(h)
     return netg_shapes(h) if h.gen == "DF_GEN" else concept_netg_shapes(h)
 
 
@@ -250,6 +312,14 @@ def synth_params(shapes: dict, seed: int = 0) -> dict:
         leaf = key.rsplit(".", 1)[-1]
         if key.endswith(".norm"):
             t = torch.rsqrt(torch.tensor(float(SD)))
+        elif leaf == "num_batches_tracked":
+            t = torch.zeros((), dtype=torch.int64)
+        elif leaf == "running_var":
+            t = 0.5 + torch.rand(shape, generator=g)
+        elif leaf == "running_mean":
+            t = 0.1 * torch.randn(shape, generator=g)
+        elif ".bn" in key and leaf == "weight":
+            t = 1.0 + 0.1 * torch.randn(shape, generator=g)
         elif leaf == "gamma":
             t = 0.25 + 0.5 * torch.rand(shape, generator=g)
         elif ".gn" in key and leaf == "weight":
@@ -267,7 +337,7 @@ def synth_params(shapes: dict, seed: int = 0) -> dict:
                 t = t * 0.15                                       # keep activations O(1) through 5-7 blocks
             if key == "conv_out.1.weight":
                 t = t * 0.35                                       # tanh mostly unsaturated
-        out[key] = t.to(torch.float32)
+        out[key] = t if leaf == "num_batches_tracked" else t.to(torch.float32)
     return out
 
 
@@ -443,7 +513,112 @@ def concept_netg_forward(P, h: Hyper, noise, sent_embs, **_):
     return _tail(P, out)
 
 
+# ----------------------------------------------------------------------------------------
+# word-attention generator (model/concept_gan.py OutNetG; un-wired upstream: its registry names are commented out,
+# train_gan.py:31,44)
+# ----------------------------------------------------------------------------------------
+def _bn(P, p, x, train):
+    """nn.BatchNorm{1,2}d: batch statistics + running-stat update (momentum 0.1, unbiased variance) when training"""
+    if train:
+        P[f"{p}.num_batches_tracked"] += 1
+    return F.batch_norm(x, P[f"{p}.running_mean"], P[f"{p}.running_var"], P[f"{p}.weight"], P[f"{p}.bias"], train, 0.1, 1e-5)
+
+
+def _word_reasoner(P, p, x, normalize, train):
+    """concept_gan.ConceptReasoner.forward (640-653): unlike df_concept_gan's, BatchNorm1d over the 16 concepts is live"""
+    B = x.size(0)
+    x = x.view(B, CARD, -1)
+    adj = torch.tanh(F.linear(x, P[f"{p}.proj_edge.weight"]))
+    out = x + torch.matmul(adj, x)
+    if normalize:
+        out = _bn(P, f"{p}.bn", out, train)
+    return F.relu(out).view(B, -1, 1, 1)
+
+
+def _word_context(state, words, mask):
+    """OutConceptBlock.get_context_embs (374-394).  state [B,C,p'] is L2-normalised over dim 1 -- the CONCEPT axis, as
+    written upstream -- words [B,p',T] over p'; cosine-like scores [B,C,T], padded words masked to -inf, softmax over T,
+    attention-weighted sum of the normalised word vectors -> [B,C,p']."""
+    st = F.normalize(state, p=2, dim=1)
+    wd = F.normalize(words, p=2, dim=1)
+    sim = torch.matmul(st, wd).masked_fill(mask.view(mask.size(0), 1, -1), float("-inf"))
+    return torch.matmul(torch.softmax(sim, dim=2), wd.transpose(1, 2))
+
+
+def _word_concept_block(P, p, x, gcond, words, mask, h: Hyper, upsample, train):
+    """OutConceptBlock.forward (396-449).  Second stage as upstream has it: concept_sampler2's result is discarded, and
+    concept_reasoner2 is applied to the first CONTEXT but its result is discarded too (431-433) -- its only effect is the
+    BatchNorm running-statistics update; the second word attention queries with the first context."""
+    B = x.size(0)
+    e = F.relu(F.conv2d(x, P[f"{p}.split_conv.weight"]))
+    e = F.conv2d(e, P[f"{p}.trans_gconv.weight"], None, 1, 1, 1, CARD)
+    if h.normalize:
+        e = _gn(P, f"{p}.gn", e, CARD)
+    e = F.relu(e)
+    st = _self_sampler(P, f"{p}.concept_sampler1", e, h.normalize)
+    st = _word_reasoner(P, f"{p}.concept_reasoner1", st, h.normalize, train).view(B, CARD, -1)
+    ctx = _word_context(st, F.conv1d(words, P[f"{p}.word_conv1.weight"]), mask)                       # [B,C,p']
+    gc = gcond.view(B, 1, -1).repeat(1, CARD, 1)
+    cond = torch.cat([gc, ctx], dim=2).reshape(B, -1, 1, 1)
+    gamma = F.conv2d(cond, P[f"{p}.gamma1_gconv.weight"], P[f"{p}.gamma1_gconv.bias"], groups=CARD)
+    beta = F.conv2d(cond, P[f"{p}.beta1_gconv.weight"], P[f"{p}.beta1_gconv.bias"], groups=CARD)
+    out = F.relu(gamma * e + beta)
+    if upsample:
+        out = F.interpolate(out, scale_factor=2)
+    if h.normalize and train:
+        with torch.no_grad():
+            _word_reasoner(P, f"{p}.concept_reasoner2", ctx.reshape(B, -1, 1, 1), True, True)
+    ctx2 = _word_context(ctx, F.conv1d(words, P[f"{p}.word_conv2.weight"]), mask)
+    cond = torch.cat([gc, ctx2], dim=2).reshape(B, -1, 1, 1)
+    gamma = F.conv2d(cond, P[f"{p}.gamma2_gconv.weight"], P[f"{p}.gamma2_gconv.bias"], groups=CARD)
+    beta = F.conv2d(cond, P[f"{p}.beta2_gconv.weight"], P[f"{p}.beta2_gconv.bias"], groups=CARD)
+    return F.relu(gamma * out + beta)
+
+
+def _res_block_up(P, p, x, gcond, h: Hyper, train):
+    """ResBlockUp (454-512) as OutNetG builds its first two blocks: `upsample` receives the whole arch list (262), which
+    is truthy, so both upsample."""
+    g1 = F.linear(gcond, P[f"{p}.linear_gamma1.weight"])[:, :, None, None]
+    b1 = F.linear(gcond, P[f"{p}.linear_beta1.weight"])[:, :, None, None]
+    o = _bn(P, f"{p}.bn1", x, train) if h.normalize else x
+    o = F.interpolate(F.relu(g1 * o + b1), scale_factor=2)
+    o = F.conv2d(o, P[f"{p}.c1.weight"], P[f"{p}.c1.bias"], 1, 1)
+    g2 = F.linear(gcond, P[f"{p}.linear_gamma2.weight"])[:, :, None, None]
+    b2 = F.linear(gcond, P[f"{p}.linaer_beta2.weight"])[:, :, None, None]
+    if h.normalize:
+        o = _bn(P, f"{p}.bn2", o, train)
+    o = F.conv2d(F.relu(g2 * o + b2), P[f"{p}.c2.weight"], P[f"{p}.c2.bias"], 1, 1)
+    sc = F.interpolate(x, scale_factor=2)
+    if f"{p}.c_sc.weight" in P:
+        sc = F.conv2d(sc, P[f"{p}.c_sc.weight"], P[f"{p}.c_sc.bias"])
+    return o + sc
+
+
+def word_netg_forward(P, h: Hyper, noise, sent_embs, words_embs=None, mask=None, train=True, **_):
+    """concept_gan.OutNetG.forward (281-298)"""
+    a = word_gen_arch(h.img_size, h.nch)
+    sent = F.linear(sent_embs, P["proj_sent.weight"], P["proj_sent.bias"])
+    words = F.conv1d(words_embs, P["proj_word.weight"], P["proj_word.bias"])
+    gcond = torch.cat([noise, sent], dim=1)
+    out = F.linear(gcond, P["proj_cond.weight"], P["proj_cond.bias"]).view(noise.size(0), -1, 4, 4)
+    for i in range(a["depth"]):
+        p = f"upblocks.{i}"
+        if i < 2:
+            out = _res_block_up(P, p, out, gcond, h, train)
+            continue
+        up = a["upsample"][i]
+        r = _word_concept_block(P, f"{p}.concept1", out, gcond, words, mask, h, up, train)
+        r = F.conv2d(r, P[f"{p}.conv_out1.weight"], P[f"{p}.conv_out1.bias"])
+        sc = F.interpolate(out, scale_factor=2) if up else out
+        if f"{p}.c_sc.weight" in P:
+            sc = F.conv2d(sc, P[f"{p}.c_sc.weight"], P[f"{p}.c_sc.bias"])
+        out = r + sc
+    return _tail(P, out)
+
+
 def gen_forward(P, h: Hyper, noise, sent_embs, **kw):
+    if h.gen == "CONCEPT_OUTATTN_GEN":
+        return word_netg_forward(P, h, noise, sent_embs, **kw)
     f = netg_forward if h.gen == "DF_GEN" else concept_netg_forward
     return f(P, h, noise, sent_embs, **kw)
 
@@ -642,7 +817,8 @@ class AdamState:
 def _leaves(P):
     """Differentiable leaf copies of the parameters; the spectral-norm power-iteration buffers are SHARED (not copied), so the
     in-place updates every forward call makes to them persist like the reference's module buffers do."""
-    return {k: (v if k.endswith((".weight_u", ".weight_v")) else v.detach().clone().requires_grad_(not k.endswith(".norm")))
+    shared = (".weight_u", ".weight_v", ".running_mean", ".running_var", ".num_batches_tracked")   # module buffers updated in place
+    return {k: (v if k.endswith(shared) else v.detach().clone().requires_grad_(not k.endswith(".norm")))
             for k, v in P.items()}
 
 

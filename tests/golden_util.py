@@ -41,7 +41,13 @@ def hyper_for(fix):
         parts = k.split(".")
         for p in parts[:-1]:
             node = node[p]
-        node[parts[-1]] = {"True": True, "False": False}.get(v, None) if v in ("True", "False") else int(v)
+        if v in ("True", "False"):
+            node[parts[-1]] = v == "True"
+        else:
+            try:
+                node[parts[-1]] = int(v)
+            except ValueError:
+                node[parts[-1]] = v                  # a name, e.g. GEN.ENCODER_NAME=CONCEPT_OUTATTN_GEN
     return X.Hyper.from_cfg(cfg), cfg
 
 

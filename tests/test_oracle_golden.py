@@ -42,6 +42,11 @@ def test_forward_matches_reference(name):
     if "d_buf_names" in fx.files:                 # spectral norm: power-iteration buffers after the same sequence of forward calls
         for j, n in enumerate(fx["d_buf_names"]):
             _close(stats(PD[str(n)]), fx["d_buf_after"][j], rtol=1e-3, atol=1e-4)
+    if "g_buf_names" in fx.files:                 # BatchNorm generators: running statistics after one training-mode forward
+        assert len(fx["g_buf_names"]) == sum(k.endswith((".running_mean", ".running_var", ".num_batches_tracked", ".norm"))
+                                              for k in PG)
+        for j, n in enumerate(fx["g_buf_names"]):
+            _close(stats(PG[str(n)]), fx["g_buf_after"][j], rtol=1e-3, atol=1e-4)
 
 
 @pytest.mark.parametrize("name", fixtures("rnn_"))
@@ -148,3 +153,6 @@ def test_train_step_matches_reference_loop(name):
     if "d_buf_names" in fx.files:                 # spectral norm: u / v after every forward call of the loop
         for j, n in enumerate(fx["d_buf_names"]):
             _close(stats(PD[str(n)]), fx["d_buf_final"][j], rtol=5e-3, atol=2e-3)
+    if "g_buf_names" in fx.files:                 # BatchNorm generators: running statistics after the loop
+        for j, n in enumerate(fx["g_buf_names"]):
+            _close(stats(PG[str(n)]), fx["g_buf_final"][j], rtol=5e-3, atol=2e-3)
