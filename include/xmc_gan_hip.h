@@ -218,6 +218,13 @@ int xmc_affine2_lrelu_bwd(const void* x, const void* dy, const float* g0, const 
                           const float* b1, void* dx, float* dg0, float* db0, float* dg1, float* db1,
                           int N, int HW, int C, int dtype, void* stream);
 
+/* the same with the activation slope as an argument: slope 0 = ReLU, the activation of the word-attention generator's
+ * conditional BatchNorm / concept modulation (concept_gan.py:419-421,446-447,496-497,508-509) */
+int xmc_affine2_act_fwd(const void* x, const float* g0, const float* b0, const float* g1, const float* b1,
+                        void* y, int N, int HW, int C, float slope, int dtype, void* stream);
+int xmc_affine2_act_bwd(const void* x, const void* dy, const float* g0, const float* b0, const float* g1,
+                        const float* b1, void* dx, float* dg0, float* db0, float* dg1, float* db1,
+                        int N, int HW, int C, float slope, int dtype, void* stream);
 /* single-stage form of the same kernels: pass g1 = b1 = NULL (and dg1 = db1 = NULL) -> y = lrelu(x*g0 + b0), the
  * concept blocks' modulation `gamma * img_embs + beta` + LeakyReLU (df_concept_gan.py:238-239,250-251) */
 

@@ -247,10 +247,34 @@ def test_datasets_mirror_reference_item_layout(tmp_path):
     gan.reset_cfg()
 
 
+def test_word_attention_generator_state_dict_and_registry():
+    """concept_gan.OutNetG: state_dict keys/shapes equal the reference's (pinned through
+    fwd_wordg*.npz's key table by test_oracle_golden) for every image size, with and without normalisation; InNetG raises."""
+    from xmc_gan.config import gan
+    import xmc_gan.train_gan as tg
+    gan.reset_cfg()
+    gan.cfg_from_file(os.path.join(CFG_DIR, "df_gan_damsm_nomagp.yml"))
+    cfg = gan.cfg
+    cfg.GEN.ENCODER_NAME, cfg.TRAIN.NCH = "CONCEPT_OUTATTN_GEN", 8
+    for size in (64, 128, 256):
+        for norm in (True, False):
+            cfg.IMG.SIZE, cfg.GEN.NORMALIZE = size, norm
+            h = X.Hyper.from_cfg(cfg)
+            netG = tg._GEN_ARCH[cfg.GEN.ENCODER_NAME](cfg)
+            sd = netG.state_dict()
+            assert {k: tuple(v.shape) for k, v in sd.items()} == X.gen_shapes(h)
+            assert all(v.dtype == torch.int64 for k, v in sd.items() if k.endswith("num_batches_tracked"))
+            netG.load_state_dict(X.synth_params(X.gen_shapes(h), 1), strict=True)
+    with pytest.raises(NotImplementedError):
+        tg._GEN_ARCH["CONCEPT_INATTN_GEN"](cfg)
+    gan.reset_cfg()
+
+
 def test_cli_flags_match_reference():
     import xmc_gan.train_gan as tg
     a = tg.parse_args([])
     assert (a.cfg, a.gpu_id, a.seed, a.resume_epoch, a.log_type, a.bs, a.imsize) == \
         ('xmc_gan/cfg/df_gan_sbert_seperate.yml', 0, 100, 0, 'tb', -1, -1)
-    assert set(tg._GEN_ARCH) == {"DF_GEN", "CONCEPT_IN_DF_GEN", "CONCEPT_OUT_DF_GEN"}
+    # the reference's live registry (train_gan.py:42-49) plus the two word-attention names it keeps commented out
+    assert set(tg._GEN_ARCH) == {"DF_GEN", "CONCEPT_IN_DF_GEN", "CONCEPT_OUT_DF_GEN", "CONCEPT_OUTATTN_GEN", "CONCEPT_INATTN_GEN"}
     assert set(tg._DISC_ARCH) == {"DF_DISC", "CONCEPT_NETD"}

@@ -267,7 +267,7 @@ __global__ void nhwc8_to_nchw_kernel(const void* src, float* dst, int N, int C, 
 // block = (pixel range, image n); thread owns channel chunk cc = tid % C8 and strides over pixels
 template <int DT>
 __global__ void affine2_fwd_kernel(const void* x, const float* g0, const float* b0, const float* g1, const float* b1,
-                                   void* y, int HW, int C8, int pix_per_block) {
+                                   void* y, int HW, int C8, int pix_per_block, float slope) {
     const int n = blockIdx.y, groups = NT / C8;
     const int cc = threadIdx.x % C8, g = threadIdx.x / C8;
     if (g >= groups) return;
@@ -283,8 +283,10 @@ __global__ void affine2_fwd_kernel(const void* x, const float* g0, const float* 
         Vec8<DT>::load(x, idx, v);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            float u = lrelu_f(v[k] * G0[k] + B0[k]);
-            v[k] = two ? lrelu_f(u * G1[k] + B1[k]) : u;
+            float u = v[k] * G0[k] + B0[k];
+            u = u > 0.f ? u : slope * u;
+            const float t = u * G1[k] + B1[k];
+            v[k] = two ? (t > 0.f ? t : slope * t) : u;
         }
         Vec8<DT>::store(y, idx, v);
     }
@@ -292,7 +294,7 @@ __global__ void affine2_fwd_kernel(const void* x, const float* g0, const float* 
 template <int DT>
 __global__ void affine2_bwd_kernel(const void* x, const void* dy, const float* g0, const float* b0, const float* g1,
                                    const float* b1, void* dx, float* dg0, float* db0, float* dg1, float* db1,
-                                   int HW, int C8, int pix_per_block) {
+                                   int HW, int C8, int pix_per_block, float slope) {
     const int n = blockIdx.y, groups = NT / C8;
     const int cc = threadIdx.x % C8, g = threadIdx.x / C8;
     float G0[8], B0[8], G1[8], B1[8];
@@ -314,11 +316,11 @@ __global__ void affine2_bwd_kernel(const void* x, const void* dy, const float* g
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 float u = xv[k] * G0[k] + B0[k];
-                float a1 = lrelu_f(u);
+                float a1 = u > 0.f ? u : slope * u;
                 float v = a1 * G1[k] + B1[k];
-                float dvv = two ? dv[k] * lrelu_slope(v) : dv[k];
+                float dvv = two ? dv[k] * (v > 0.f ? 1.f : slope) : dv[k];
                 sg1[k] += dvv * a1; sb1[k] += dvv;
-                float du = dvv * G1[k] * lrelu_slope(u);
+                float du = dvv * G1[k] * (u > 0.f ? 1.f : slope);
                 sg0[k] += du * xv[k]; sb0[k] += du;
                 xv[k] = du * G0[k];
             }
@@ -685,30 +687,39 @@ static inline int affine_grid(int HW, int C8, int N, dim3& g, int& ppb) {
     g = dim3(bx, N);
     return 0;
 }
-extern "C" int xmc_affine2_lrelu_fwd(const void* x, const float* g0, const float* b0, const float* g1, const float* b1,
-                                     void* y, int N, int HW, int C, int dtype, void* s) {
+extern "C" int xmc_affine2_act_fwd(const void* x, const float* g0, const float* b0, const float* g1, const float* b1,
+                                   void* y, int N, int HW, int C, float slope, int dtype, void* s) {
     if (C % 8 || C / 8 > NT) return XMC_EALIGN;
     dim3 g; int ppb;
     affine_grid(HW, C / 8, N, g, ppb);
-    if (dtype == XMC_BF16) hipLaunchKernelGGL((affine2_fwd_kernel<XMC_BF16>), g, dim3(NT), 0, ST(s), x, g0, b0, g1, b1, y, HW, C / 8, ppb);
-    else if (dtype == XMC_F32) hipLaunchKernelGGL((affine2_fwd_kernel<XMC_F32>), g, dim3(NT), 0, ST(s), x, g0, b0, g1, b1, y, HW, C / 8, ppb);
+    if (dtype == XMC_BF16) hipLaunchKernelGGL((affine2_fwd_kernel<XMC_BF16>), g, dim3(NT), 0, ST(s), x, g0, b0, g1, b1, y, HW, C / 8, ppb, slope);
+    else if (dtype == XMC_F32) hipLaunchKernelGGL((affine2_fwd_kernel<XMC_F32>), g, dim3(NT), 0, ST(s), x, g0, b0, g1, b1, y, HW, C / 8, ppb, slope);
     else return XMC_EINVAL;
     XMC_LAUNCH_CHECK();
     return 0;
 }
-extern "C" int xmc_affine2_lrelu_bwd(const void* x, const void* dy, const float* g0, const float* b0, const float* g1,
-                                     const float* b1, void* dx, float* dg0, float* db0, float* dg1, float* db1,
-                                     int N, int HW, int C, int dtype, void* s) {
+extern "C" int xmc_affine2_act_bwd(const void* x, const void* dy, const float* g0, const float* b0, const float* g1,
+                                   const float* b1, void* dx, float* dg0, float* db0, float* dg1, float* db1,
+                                   int N, int HW, int C, float slope, int dtype, void* s) {
     if (C % 8 || C / 8 > NT) return XMC_EALIGN;
     dim3 g; int ppb;
     affine_grid(HW, C / 8, N, g, ppb);
     if (dtype == XMC_BF16)
-        hipLaunchKernelGGL((affine2_bwd_kernel<XMC_BF16>), g, dim3(NT), 0, ST(s), x, dy, g0, b0, g1, b1, dx, dg0, db0, dg1, db1, HW, C / 8, ppb);
+        hipLaunchKernelGGL((affine2_bwd_kernel<XMC_BF16>), g, dim3(NT), 0, ST(s), x, dy, g0, b0, g1, b1, dx, dg0, db0, dg1, db1, HW, C / 8, ppb, slope);
     else if (dtype == XMC_F32)
-        hipLaunchKernelGGL((affine2_bwd_kernel<XMC_F32>), g, dim3(NT), 0, ST(s), x, dy, g0, b0, g1, b1, dx, dg0, db0, dg1, db1, HW, C / 8, ppb);
+        hipLaunchKernelGGL((affine2_bwd_kernel<XMC_F32>), g, dim3(NT), 0, ST(s), x, dy, g0, b0, g1, b1, dx, dg0, db0, dg1, db1, HW, C / 8, ppb, slope);
     else return XMC_EINVAL;
     XMC_LAUNCH_CHECK();
     return 0;
+}
+extern "C" int xmc_affine2_lrelu_fwd(const void* x, const float* g0, const float* b0, const float* g1, const float* b1,
+                                     void* y, int N, int HW, int C, int dtype, void* s) {
+    return xmc_affine2_act_fwd(x, g0, b0, g1, b1, y, N, HW, C, XMC_LRELU, dtype, s);
+}
+extern "C" int xmc_affine2_lrelu_bwd(const void* x, const void* dy, const float* g0, const float* b0, const float* g1,
+                                     const float* b1, void* dx, float* dg0, float* db0, float* dg1, float* db1,
+                                     int N, int HW, int C, int dtype, void* s) {
+    return xmc_affine2_act_bwd(x, dy, g0, b0, g1, b1, dx, dg0, db0, dg1, db1, N, HW, C, XMC_LRELU, dtype, s);
 }
 extern "C" int xmc_hinge_fwd(const void* x, int stride, float sign, float* out, int64_t n, int dtype, void* s) {
     if (n < 1 || stride < 1) return XMC_ESHAPE;

@@ -74,6 +74,8 @@ _SIGS = {
     "xmc_sumpool2": [vp, vp, i32, i32, i32, i32, f32, i32, vp],
     "xmc_global_avgpool": [vp, vp, i32, i32, i32, i32, i32, vp],
     "xmc_global_avgpool_bwd": [vp, vp, i32, i32, i32, i32, i32, vp],
+    "xmc_affine2_act_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp],
+    "xmc_affine2_act_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp],
     "xmc_affine2_lrelu_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "xmc_affine2_lrelu_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "xmc_groupnorm_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, i32, vp],

@@ -1166,7 +1166,7 @@ class Affine2LreluFn(torch.autograd.Function):
     single modulation lrelu(x*g0+b0) of the concept blocks (df_concept_gan.py:238-239)."""
 
     @staticmethod
-    def forward(ctx, x, g0, b0, g1, b1):
+    def forward(ctx, x, g0, b0, g1, b1, slope=0.2):
         x = x.contiguous()
         N, H, W, Cc = x.shape
         two = g1 is not None
@@ -1175,8 +1175,8 @@ class Affine2LreluFn(torch.autograd.Function):
             assert t.shape == (N, Cc), (t.shape, (N, Cc))
         y = torch.empty_like(x)
         ptrs = [_p(t) for t in ps] + ([] if two else [None, None])
-        L.call("xmc_affine2_lrelu_fwd", _p(x), *ptrs, _p(y), N, H * W, Cc, _code(x.dtype), _st())
-        ctx.two = two
+        L.call("xmc_affine2_act_fwd", _p(x), *ptrs, _p(y), N, H * W, Cc, float(slope), _code(x.dtype), _st())
+        ctx.two, ctx.slope = two, float(slope)
         ctx.save_for_backward(x, *ps)
         return y
 
@@ -1191,10 +1191,10 @@ class Affine2LreluFn(torch.autograd.Function):
         red = torch.zeros((nred, N, Cc), dtype=torch.float32, device=x.device)
         ptrs = [_p(t) for t in ps] + ([] if ctx.two else [None, None])
         rptrs = [_p(red[i]) for i in range(nred)] + ([] if ctx.two else [None, None])
-        L.call("xmc_affine2_lrelu_bwd", _p(x), _p(dy), *ptrs, _p(dx), *rptrs, N, H * W, Cc, _code(x.dtype), _st())
+        L.call("xmc_affine2_act_bwd", _p(x), _p(dy), *ptrs, _p(dx), *rptrs, N, H * W, Cc, ctx.slope, _code(x.dtype), _st())
         if ctx.two:
-            return dx, red[0], red[1], red[2], red[3]
-        return dx, red[0], red[1], None, None
+            return dx, red[0], red[1], red[2], red[3], None
+        return dx, red[0], red[1], None, None, None
 
 
 class GroupNormFn(torch.autograd.Function):
@@ -1226,6 +1226,44 @@ class GroupNormFn(torch.autograd.Function):
         L.call("xmc_groupnorm_bwd", _p(x), _p(dy), _p(wf), _p(bf), _p(stats), _p(dx), _p(dw), _p(db), _p(ws), N, H * W, Cc,
                ctx.groups, float(ctx.slope), _code(x.dtype), _st())
         return dx, dw, db, None, None, None
+
+
+class BatchNormTrainFn(torch.autograd.Function):
+    """nn.BatchNorm2d in training mode over NHWC (concept_gan.py:467-468,499-500,507-508): per-channel statistics over
+    the whole batch = the GroupNorm kernels with one channel per group on the batch viewed as ONE sample of N*H*W pixels.
+    Returns (y, stats) with stats f32 [C,2] = (batch mean, rstd) for the caller's running-statistics update."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, eps):
+        x = x.contiguous()
+        N, H, W, Cc = x.shape
+        wf, bf = w.detach().float().contiguous(), b.detach().float().contiguous()
+        y = torch.empty_like(x)
+        stats = torch.empty((1, Cc, 2), dtype=torch.float32, device=x.device)
+        ws = torch.empty((1, Cc, 2), dtype=torch.float32, device=x.device)
+        L.call("xmc_groupnorm_fwd", _p(x), _p(wf), _p(bf), _p(y), _p(stats), _p(ws), 1, N * H * W, Cc, Cc, float(eps), -1.0,
+               _code(x.dtype), _st())
+        ctx.save_for_backward(x, wf, bf, stats)
+        out_stats = stats.view(Cc, 2)
+        ctx.mark_non_differentiable(out_stats)
+        return y, out_stats
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy, _dstats):
+        x, wf, bf, stats = ctx.saved_tensors
+        dy = dy.contiguous()
+        N, H, W, Cc = x.shape
+        dx = torch.empty_like(x)
+        dw, db = torch.empty_like(wf), torch.empty_like(bf)
+        ws = torch.empty(Cc * 2 + Cc * 2, dtype=torch.float32, device=x.device)
+        L.call("xmc_groupnorm_bwd", _p(x), _p(dy), _p(wf), _p(bf), _p(stats), _p(dx), _p(dw), _p(db), _p(ws), 1, N * H * W, Cc,
+               Cc, -1.0, _code(x.dtype), _st())
+        return dx, dw, db, None
+
+
+def batchnorm_train(x, w, b, eps=1e-5):
+    return BatchNormTrainFn.apply(x, w, b, eps)
 
 
 class AttnPoolFn(torch.autograd.Function):
@@ -1365,6 +1403,11 @@ def axpby_up(a_lo, b_hi, alpha, lrelu=False):
 
 def affine_lrelu(x, g, b):
     return Affine2LreluFn.apply(x, g, b, None, None)
+
+
+def affine_act(x, g, b, slope):
+    """act(x * g[n,c] + b[n,c]); slope 0 = ReLU (the word-attention generator, concept_gan.py:421,447,497,509)"""
+    return Affine2LreluFn.apply(x, g, b, None, None, slope)
 
 
 def groupnorm(x, w, b, groups, slope=-1.0, eps=1e-5):

@@ -1,0 +1,280 @@
+"""Word-attention generator with the reference's module API (model/concept_gan.py): ``OutNetG`` -- two BatchNorm-conditional
+``ResBlockUp`` stages followed by ``OCAttnResBlockUp`` stages whose ``OutConceptBlock`` lets 16 image concepts attend over
+the (masked) caption words.  Upstream leaves these classes out of ``_GEN_ARCH`` (their names are commented out,
+train_gan.py:31,44); here ``OutNetG`` is registered as ``CONCEPT_OUTATTN_GEN``.  ``InNetG`` cannot run upstream
+(its word-region sampler is built for ``noise_dim + nef`` channels and fed ``nef``, concept_gan.py:137,183,527 vs 570-573), so
+the name exists and raises.
+
+Same constructor/forward signatures and ``state_dict()`` keys (incl. the ``linaer_beta2`` spelling and the BatchNorm
+buffers).  Per-pixel work runs on the HIP kernels (MFMA convolutions incl. the fused upsample+3x3, BatchNorm/GroupNorm,
+region attention, conditional modulation); the per-sample concept algebra on [B,16,<=360] tensors (reasoner, word
+attention over T <= 20 words, grouped 1x1 modulation heads) stays in ATen like in ``df_concept_gan``.
+
+Behaviour kept because it changes results (concept_gan.py): the first two blocks receive the whole ``upsample`` list as
+their flag, i.e. both upsample (262); in ``OutConceptBlock`` the second sampler's output is discarded and the second reasoner
+is applied to the first context only to be discarded as well (431-433) -- all that survives is its BatchNorm1d
+running-statistics update, which is reproduced; the state vectors are L2-normalised over the CONCEPT axis (378).
+Restructured, same function: everything after the block's grouped 3x3 conv is pointwise or 1x1 and therefore commutes
+with the nearest x2 upsample, so the block runs at the input resolution and is upsampled once at the end.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from xmc_gan_amd import ops
+from xmc_gan_amd.lib import ACT_RELU, ACT_TANH
+
+from .df_concept_gan import ConceptSampler, _GroupedConv, _grouped_vec
+from .df_gan import nhwc_feature_perm
+from .modules import HipConv2d, HipLinear
+
+
+def gen_arch(img_size, nch):
+    """channel / resolution tables (concept_gan.py:11-37)"""
+    assert img_size in [64, 128, 256]
+    mult_in, mult_out = {256: ([16, 16, 8, 8, 4, 2, 1], [16, 8, 8, 4, 2, 1, 1]),
+                         128: ([16, 8, 8, 4, 2, 1], [8, 8, 4, 2, 1, 1]),
+                         64: ([8, 8, 4, 2, 1], [8, 4, 2, 1, 1])}[img_size]
+    depth = len(mult_in)
+    res = [8 * 2 ** i for i in range(depth - 1)]
+    return {'in_channels': [m * nch for m in mult_in], 'out_channels': [m * nch for m in mult_out],
+            'upsample': [True] * (depth - 1) + [False], 'resolution': res + [res[-1]],
+            'attention': [False] * 2 + [True] * (depth - 2), 'depth': depth}
+
+
+class _Pad8Linear(HipLinear):
+    """nn.Linear parameters whose input width is not a multiple of 8 (noise_dim + nef = 356): the kernels' data-gradient
+    path wants 8-channel units, so input and weight are zero-padded to the next multiple of 8 on the way in (the gradient
+    flows back through the pad to the [out, in] parameter)."""
+
+    def __init__(self, in_dim, out_dim, bias=True, row_perm=None):
+        super().__init__(in_dim, out_dim, bias=bias, row_perm=row_perm)
+        self._pad = (-in_dim) % 8
+        self.geom = ops.ConvGeom(in_dim + self._pad, out_dim, 1, 1, 0, row_perm=row_perm)
+
+    def forward(self, x, act=None, out_dtype=None):
+        w = self.weight
+        if self._pad:
+            x, w = F.pad(x, (0, self._pad)), F.pad(w, (0, self._pad))
+        y = ops.linear(x, w, self.bias, self.geom, self.act if act is None else act, out_dtype)
+        return y[:, : self.out_features] if y.shape[1] != self.out_features else y
+
+
+_ONES = {}
+
+
+def _one(device):
+    t = _ONES.get(device)
+    if t is None:
+        t = _ONES[device] = torch.ones(1, dtype=torch.float32, device=device)
+    return t
+
+
+def _cond_bn_relu(x, bn, gamma, beta):
+    """relu(gamma[n,c] * BatchNorm(x) + beta[n,c]) on NHWC (concept_gan.py:494-497, 506-509); bn None = no normalisation."""
+    if bn is None:
+        return ops.affine_act(x, gamma, beta, 0.0)
+    if bn.training:
+        y, stats = ops.batchnorm_train(x, bn.weight, bn.bias, bn.eps)
+        with torch.no_grad():       # running statistics as nn.BatchNorm2d keeps them: momentum 0.1, unbiased variance
+            n = x.numel() // x.shape[-1]
+            mean, var = stats[:, 0], stats[:, 1].pow(-2) - bn.eps
+            bn.running_mean.mul_(1 - bn.momentum).add_(mean, alpha=bn.momentum)
+            bn.running_var.mul_(1 - bn.momentum).add_(var * (n / max(n - 1, 1)), alpha=bn.momentum)
+            bn.num_batches_tracked += 1
+        return ops.affine_act(y, gamma, beta, 0.0)
+    # eval: BatchNorm is a per-channel scale/shift, folded into the conditional one
+    s = bn.weight.float() * torch.rsqrt(bn.running_var.float() + bn.eps)
+    t = bn.bias.float() - bn.running_mean.float() * s
+    return ops.affine_act(x, gamma * s, gamma * t + beta, 0.0)
+
+
+class ResBlockUp(nn.Module):
+    def __init__(self, in_dim, out_dim, cond_dim, upsample, normalize=True):
+        super(ResBlockUp, self).__init__()
+        self.learnable_sc = (in_dim != out_dim)
+        self.normalize = normalize
+        self.upsample = upsample
+        self.c1 = HipConv2d(in_dim, out_dim, 3, 1, 1)
+        self.c2 = HipConv2d(out_dim, out_dim, 3, 1, 1)
+        if normalize:
+            self.bn1 = nn.BatchNorm2d(in_dim)
+            self.bn2 = nn.BatchNorm2d(out_dim)
+        self.linear_gamma1 = _Pad8Linear(cond_dim, in_dim, bias=False)
+        self.linear_beta1 = _Pad8Linear(cond_dim, in_dim, bias=False)
+        self.linear_gamma2 = _Pad8Linear(cond_dim, out_dim, bias=False)
+        self.linaer_beta2 = _Pad8Linear(cond_dim, out_dim, bias=False)          # sic (concept_gan.py:473)
+        if self.learnable_sc:
+            self.c_sc = HipConv2d(in_dim, out_dim, 1, stride=1, padding=0)
+
+    def forward(self, x, global_cond, **kwargs):
+        """x NHWC [B,h,w,Cin] -> [B,2h,2w,Cout] (or same size when ``upsample`` is falsy)."""
+        h = _cond_bn_relu(x, self.bn1 if self.normalize else None,
+                          self.linear_gamma1(global_cond), self.linear_beta1(global_cond))
+        if self.upsample:       # F.interpolate(x2) -> c1 as one operator (4 parity classes of 2x2 taps)
+            h = ops.upconv3x3(h, self.c1.weight, self.c1.bias, self.c1.geom)
+        else:
+            h = self.c1(h)
+        h = _cond_bn_relu(h, self.bn2 if self.normalize else None,
+                          self.linear_gamma2(global_cond), self.linaer_beta2(global_cond))
+        r = self.c2(h)
+        sc = self.c_sc(x) if self.learnable_sc else x                         # the 1x1 shortcut commutes with the upsample
+        one = _one(x.device)
+        return ops.axpby_up(sc, r, one) if self.upsample else ops.axpby(sc, r, one)
+
+
+class ConceptReasoner(nn.Module):
+    """concept graph step on [B,16,p'] states (concept_gan.py:632-654); BatchNorm1d over the concepts is live here."""
+
+    def __init__(self, cardinality, state_dim, normalize=True):
+        super(ConceptReasoner, self).__init__()
+        self.cardinality = cardinality
+        self.normalize = normalize
+        self.proj_edge = nn.Linear(state_dim, cardinality, bias=False)
+        if self.normalize:
+            self.bn = nn.BatchNorm1d(num_features=cardinality)
+
+    def forward(self, x, **kwargs):
+        adj = torch.tanh(F.linear(x, self.proj_edge.weight))
+        out = x + torch.matmul(adj, x)
+        if self.normalize:
+            out = self._batchnorm(out)
+        return F.relu(out)
+
+    def _batchnorm(self, x):
+        """nn.BatchNorm1d over [B, C, L] written out with elementwise / reduction ops.  (``self.bn(x)`` dispatches to the
+        vendor BatchNorm on the GPU, whose training-mode result on this 16-samples-per-channel tensor left every generator
+        gradient ~0.5 % away from the f64 evaluation of the same network; this form agrees to 4e-6.)"""
+        bn = self.bn
+        if bn.training:
+            mean = x.mean(dim=(0, 2))
+            var = x.var(dim=(0, 2), unbiased=False)
+            with torch.no_grad():
+                n = x.size(0) * x.size(2)
+                bn.running_mean.mul_(1 - bn.momentum).add_(mean, alpha=bn.momentum)
+                bn.running_var.mul_(1 - bn.momentum).add_(var * (n / max(n - 1, 1)), alpha=bn.momentum)
+                bn.num_batches_tracked += 1
+        else:
+            mean, var = bn.running_mean, bn.running_var
+        scale = bn.weight * torch.rsqrt(var + bn.eps)
+        return (x - mean.view(1, -1, 1)) * scale.view(1, -1, 1) + bn.bias.view(1, -1, 1)
+
+
+def _word_context(state, words, mask):
+    """state [B,C,p'], words [B,T,p'], mask [B,T] (True = padding) -> attention of every concept over the words
+    (OutConceptBlock.get_context_embs, concept_gan.py:374-394): [B,C,p']."""
+    st = F.normalize(state, p=2, dim=1)                       # over the concept axis, as upstream
+    wd = F.normalize(words, p=2, dim=2)
+    sim = torch.matmul(st, wd.transpose(1, 2)).masked_fill(mask.view(mask.size(0), 1, -1), float('-inf'))
+    return torch.matmul(torch.softmax(sim, dim=2), wd)
+
+
+class OutConceptBlock(nn.Module):
+    def __init__(self, in_dim, cardinality, bottleneck_width, state_dim, text_dim, cond_dim, upsample, normalize=False):
+        super(OutConceptBlock, self).__init__()
+        self.cardinality, self.normalize, self.upsample = cardinality, normalize, upsample
+        gw = cardinality * bottleneck_width
+        cgw = cardinality * (cond_dim + state_dim)
+        self.split_conv = HipConv2d(in_dim, gw, 1, 1, 0, bias=False)
+        self.trans_gconv = _GroupedConv(gw, gw, 3, 1, groups=cardinality)
+        if normalize:
+            self.gn = nn.GroupNorm(cardinality, gw)
+        self.concept_sampler1 = ConceptSampler(cardinality, bottleneck_width, state_dim, normalize=normalize)
+        self.concept_reasoner1 = ConceptReasoner(cardinality, state_dim, normalize=normalize)
+        self.word_conv1 = nn.Conv1d(text_dim, state_dim, 1, 1, 0, bias=False)
+        self.concept_sampler2 = ConceptSampler(cardinality, bottleneck_width, state_dim, normalize=normalize)
+        self.concept_reasoner2 = ConceptReasoner(cardinality, state_dim, normalize=normalize)
+        self.word_conv2 = nn.Conv1d(text_dim, state_dim, 1, 1, 0, bias=False)
+        self.gamma1_gconv = nn.Conv2d(cgw, gw, 1, 1, 0, groups=cardinality)
+        self.beta1_gconv = nn.Conv2d(cgw, gw, 1, 1, 0, groups=cardinality)
+        self.gamma2_gconv = nn.Conv2d(cgw, gw, 1, 1, 0, groups=cardinality)
+        self.beta2_gconv = nn.Conv2d(cgw, gw, 1, 1, 0, groups=cardinality)
+
+    def forward(self, x, global_cond, words_embs, mask):
+        """x NHWC [B,h,w,Cin]; global_cond f32 [B,gc]; words_embs f32 [B,T,nef]; mask [B,T].  Returns the block output at the
+        INPUT resolution (the caller applies the x2 upsample after the 1x1 output conv, see the module docstring)."""
+        B = x.size(0)
+        e = self.split_conv(x, act=ACT_RELU)
+        e = self.trans_gconv(e)
+        e = ops.groupnorm(e, self.gn.weight, self.gn.bias, self.cardinality, slope=0.0) if self.normalize else ops.lrelu(e, 0.0)
+        st = self.concept_reasoner1(self.concept_sampler1(e))                                    # [B,C,p']
+        ctx = _word_context(st, F.linear(words_embs, self.word_conv1.weight[:, :, 0]), mask)
+        gc = global_cond.view(B, 1, -1).expand(B, self.cardinality, -1)
+        cond = torch.cat([gc, ctx], dim=2)
+        g1 = _grouped_vec(cond, self.gamma1_gconv).reshape(B, -1)
+        b1 = _grouped_vec(cond, self.beta1_gconv).reshape(B, -1)
+        if self.normalize and self.concept_reasoner2.training:
+            with torch.no_grad():       # upstream's discarded call (432): only the BatchNorm1d running statistics remain
+                self.concept_reasoner2(ctx)
+        ctx2 = _word_context(ctx, F.linear(words_embs, self.word_conv2.weight[:, :, 0]), mask)
+        cond2 = torch.cat([gc, ctx2], dim=2)
+        g2 = _grouped_vec(cond2, self.gamma2_gconv).reshape(B, -1)
+        b2 = _grouped_vec(cond2, self.beta2_gconv).reshape(B, -1)
+        # relu(g2 * up(relu(g1*e+b1)) + b2) == up(relu(g2 * relu(g1*e+b1) + b2)): one two-stage pass at low resolution
+        return ops.Affine2LreluFn.apply(e, g1, b1, g2, b2, 0.0)
+
+
+class OCAttnResBlockUp(nn.Module):
+    def __init__(self, in_dim, out_dim, gc_dim, text_dim, upsample, cardinality, bottleneck_width, normalize=True):
+        super(OCAttnResBlockUp, self).__init__()
+        self.learnable_sc = (in_dim != out_dim)
+        self.normalize, self.upsample, self.cardinality = normalize, upsample, cardinality
+        state_dim = 4
+        gw = cardinality * bottleneck_width
+        self.concept1 = OutConceptBlock(in_dim=in_dim, cardinality=cardinality, bottleneck_width=bottleneck_width,
+                                        state_dim=state_dim, text_dim=text_dim, cond_dim=gc_dim, upsample=upsample,
+                                        normalize=normalize)
+        self.conv_out1 = HipConv2d(gw, out_dim, 1, 1, 0)
+        if self.learnable_sc:
+            self.c_sc = HipConv2d(in_dim, out_dim, 1, stride=1, padding=0)
+
+    def forward(self, x, global_cond, words_embs, mask):
+        r = self.conv_out1(self.concept1(x, global_cond, words_embs, mask))
+        out = ops.axpby(self.c_sc(x) if self.learnable_sc else x, r, _one(x.device))
+        return ops.upsample2(out) if self.upsample else out
+
+
+class OutNetG(nn.Module):
+    def __init__(self, cfg, **kwargs):
+        super(OutNetG, self).__init__()
+        self.ngf = cfg.TRAIN.NCH
+        noise_dim, nef = cfg.TRAIN.NOISE_DIM, cfg.TRAIN.NEF
+        arch = gen_arch(img_size=cfg.IMG.SIZE, nch=self.ngf)
+        c0 = arch['in_channels'][0]
+        self.proj_sent = HipLinear(cfg.TEXT.EMBEDDING_DIM, nef)
+        self.proj_word = nn.Conv1d(cfg.TEXT.EMBEDDING_DIM, nef, 1, 1, 0)      # parameter holder; runs as one GEMM over B*T words
+        self._word_geom = ops.ConvGeom(cfg.TEXT.EMBEDDING_DIM, nef, 1, 1, 0)
+        self.proj_cond = _Pad8Linear(noise_dim + nef, c0 * 4 * 4, row_perm=nhwc_feature_perm(c0))
+        self.upblocks = nn.ModuleList(
+            [ResBlockUp(in_dim=arch['in_channels'][i], out_dim=arch['out_channels'][i], cond_dim=noise_dim + nef,
+                        upsample=arch['upsample'], normalize=cfg.GEN.NORMALIZE) for i in range(2)] +        # the LIST: truthy (262)
+            [OCAttnResBlockUp(in_dim=arch['in_channels'][i], out_dim=arch['out_channels'][i], gc_dim=noise_dim + nef,
+                              text_dim=nef, upsample=arch['upsample'][i], cardinality=16, bottleneck_width=8,
+                              normalize=cfg.GEN.NORMALIZE) for i in range(2, arch['depth'])])
+        self.conv_out = nn.Sequential(
+            nn.LeakyReLU(0.2, inplace=True),
+            HipConv2d(arch['out_channels'][-1], 3, 3, 1, 1),
+            nn.Tanh(),
+        )
+
+    def forward(self, noise, sent_embs, words_embs, mask):
+        """noise [B,noise_dim], sent_embs [B,E], words_embs [B,E,T], mask [B,T] bool (True = padding) -> [B,3,S,S] f32."""
+        B, E, T = words_embs.shape
+        sent = self.proj_sent(sent_embs.float())
+        w = ops.linear(words_embs.float().transpose(1, 2).reshape(B * T, E), self.proj_word.weight.view(-1, E),
+                       self.proj_word.bias, self._word_geom, out_dtype=torch.float32)
+        words = w[:, : self.proj_word.out_channels].reshape(B, T, -1)                             # [B,T,nef]
+        global_cond = torch.cat([noise.float(), sent], dim=1)
+        out = self.proj_cond(global_cond, out_dtype=ops.act_dtype()).view(B, 4, 4, -1)
+        for gblock in self.upblocks:
+            out = gblock(out, global_cond=global_cond, words_embs=words, mask=mask)
+        out = self.conv_out[1](ops.lrelu(out), act=ACT_TANH)
+        return ops.to_nchw(out, 3)
+
+
+class InNetG(nn.Module):
+    def __init__(self, cfg, **kwargs):
+        super(InNetG, self).__init__()
+        raise NotImplementedError(
+            "concept_gan.InNetG does not run in the reference either: its CondConceptSampler is built for noise_dim+nef "
+            "word channels and receives nef (concept_gan.py:137,183,527 vs 570-573).  Use CONCEPT_OUTATTN_GEN (OutNetG).")

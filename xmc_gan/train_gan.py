@@ -26,13 +26,16 @@ from xmc_gan.config.gan import cfg, cfg_from_file
 from xmc_gan.model.df_gan import NetG as DF_GEN, NetD as DF_DISC
 from xmc_gan.model.df_concept_gan import InNetG as CONCEPT_IN_DF_GEN, OutNetG as CONCEPT_OUT_DF_GEN, NetD as CONCEPT_NETD
 from xmc_gan.dataset import SentTextDataset, WordTextDataset, test_transform, train_transform
+from xmc_gan.model.concept_gan import InNetG as CONCEPT_INATTN_GEN, OutNetG as CONCEPT_OUTATTN_GEN
 from xmc_gan.model.encoder import RNN_ENCODER, SBERT_ENCODER
 from xmc_gan.utils.logger import setup_logger
 from xmc_gan.utils.miscc import count_params
 from xmc_gan_amd import ops, parallel
 from xmc_gan_amd.optim import HipAdam
 
-_GEN_ARCH = {"DF_GEN": DF_GEN, "CONCEPT_IN_DF_GEN": CONCEPT_IN_DF_GEN, "CONCEPT_OUT_DF_GEN": CONCEPT_OUT_DF_GEN}
+_GEN_ARCH = {"DF_GEN": DF_GEN, "CONCEPT_IN_DF_GEN": CONCEPT_IN_DF_GEN, "CONCEPT_OUT_DF_GEN": CONCEPT_OUT_DF_GEN,
+             # word-attention generators of model/concept_gan.py; upstream keeps these two names commented out (train_gan.py:44)
+             "CONCEPT_OUTATTN_GEN": CONCEPT_OUTATTN_GEN, "CONCEPT_INATTN_GEN": CONCEPT_INATTN_GEN}
 _DISC_ARCH = {"DF_DISC": DF_DISC, "CONCEPT_NETD": CONCEPT_NETD}
 _TEXT_DATASET = {"WORD": WordTextDataset, "SENT": SentTextDataset}
 _TEXT_ARCH = {"RNN": RNN_ENCODER, "SBERT": SBERT_ENCODER}
