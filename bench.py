@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--precision", type=str, default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--gather_negatives", action="store_true", help="BASELINE config 5: all-gather contrastive negatives")
     ap.add_argument("--graph", type=int, default=-1, help="replay the iteration as a hipGraph (default: on for 1 GPU)")
+    ap.add_argument("--gen", type=str, default="", help="variant: override GEN.ENCODER_NAME (e.g. CONCEPT_OUTATTN_GEN)")
     ap.add_argument("--spec_norm", action="store_true", help="variant: DISC.SPEC_NORM=True (off in the headline cfg)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_roofline", action="store_true")
@@ -132,6 +133,8 @@ def main():
     cfg.IMG.SIZE, cfg.TRAIN.BATCH_SIZE = a.imsize, a.batch
     if a.spec_norm:
         cfg.DISC.SPEC_NORM = True
+    if a.gen:
+        cfg.GEN.ENCODER_NAME = a.gen
     torch.manual_seed(100 + rank)
     netG, netD, optG, optD = tg.build_models(dev)
     if world > 1:
@@ -219,7 +222,8 @@ def main():
                    vs_baseline=None, dtype=a.precision if a.precision == "bf16" else "f32", data="synthetic",
                    config=dict(workload=f"{S}x{S} COCO-shaped synthetic batch, {B} images per GPU, one full G+D iteration "
                                         f"(D step{' + MA-GP' if magp else ''} + G step + Adam x{3 if magp else 2}), {a.cfg}"
-                                        + (" with DISC.SPEC_NORM=True" if a.spec_norm else ""),
+                                        + (" with DISC.SPEC_NORM=True" if a.spec_norm else "")
+                                        + (f" with GEN.ENCODER_NAME={a.gen}" if a.gen else ""),
                                per_gpu_batch=B, global_batch=B * world, image_size=S, cfg=a.cfg,
                                parallelism=f"dp{world}" + ("+gather" if a.gather_negatives else ""), hipgraph=bool(use_graph),
                                losses_finite=finite),
