@@ -29,6 +29,19 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert lib.xmc_conv_igemm(ctypes.byref(d), None) == -1
     assert lib.xmc_conv_wgrad(ctypes.byref(d), None, None) == -1
     assert ctypes.sizeof(L.ConvDesc) == 336 and ctypes.sizeof(L.AdamEntry) == 48
+    # the entry points added for the callers either side of the step reject bad arguments the same way (nothing launched)
+    import numpy as np
+    assert np.dtype(L.GEMM_PROBLEM).itemsize == 88                    # sizeof(XmcGemmProblem)
+    one = ctypes.c_void_p(8)                                           # any non-NULL value; never dereferenced on these paths
+    assert lib.xmc_gemm_group(None, 1, None) == -1 and lib.xmc_gemm_group(one, 0, None) == -1
+    tab = np.zeros(1, dtype=L.GEMM_PROBLEM)                            # NULL operand pointers inside the table
+    assert lib.xmc_gemm_group(ctypes.c_void_p(tab.ctypes.data), 1, None) == -1
+    assert lib.xmc_embedding_gather(one, one, one, 4, 302, 10, None) == -2        # width not a multiple of 4 floats
+    assert lib.xmc_embedding_gather(None, one, one, 4, 300, 10, None) == -1
+    assert lib.xmc_lstm_bidir(one, one, one, one, one, 4, 20, 64, None) == -1     # only H = 128 is built
+    assert lib.xmc_spectral_sigma(None, one, one, one, one, None, 8, 8, 1, 1e-12, None) == -1
+    assert lib.xmc_spectral_bwd(one, one, one, one, one, one, None, 8, 8, None) == -1
+    assert lib.xmc_affine2_act_fwd(one, one, one, None, None, one, 1, 16, 12, 0.0, 0, None) == -2   # channels % 8
 
 
 def test_missing_library_fails_loudly(monkeypatch):
