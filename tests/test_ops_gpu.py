@@ -73,6 +73,11 @@ CONV_CASES = [
     (128, 128, 3, 1, 1, 72, 13),   # M = 67392: last 256-row tile is partial
     (64, 128, 4, 2, 1, 128, 16),   # stride-2 forward; its dgrad = 4 parity classes
     (32, 256, 1, 1, 0, 64, 16),    # 1x1: a single K step
+    # 256x256 tiles (8 waves) of the gather kernel: Cout % 256 == 0 and >= 65536 output pixels
+    (128, 256, 4, 2, 1, 64, 72),   # stride-2 forward, M = 73728: partial last tile; dgrad: 4 classes with Cout 128
+    (64, 512, 1, 1, 0, 32, 67),    # 1x1, two column tiles, M = 68608
+    (512, 256, 4, 2, 1, 16, 8),    # small forward; its dgrad (512 -> ... no: 256-ch dy, 512-ch dx) stays on 128-wide tiles
+    (256, 512, 4, 2, 1, 32, 258),  # dgrad: dy 512 ch -> dx 256 ch in 4 parity classes of 66048 pixels each on the 256x256 tile
     # weight gradient by kernel rows (conv_wgrad_row.hip): Cin, Cout % 128 == 0, W a power of two >= 16
     (128, 128, 3, 1, 1, 32, 2),    # two 32-pixel row segments per K step
     (128, 256, 3, 1, 1, 64, 1),    # one 64-pixel segment = one image row

@@ -49,20 +49,31 @@ __device__ __forceinline__ int swz(int row) {  // {0,2,3,1}[(row>>2)&3]
     return (((q ^ (q >> 1)) & 1) << 1) | (q >> 1);
 }
 
+template <int BM, int BN, int KSUB>
+struct IgemmLds {                                    // LDS plan shared by the kernel and its launcher
+    static constexpr int STAGE_U = 2 * KSUB * (BM + BN) * 4;            // 16-byte units
+    static constexpr int EP_LD = BN + 4;
+    // the f32 staging of the epilogue is done EP_ROWS rows at a time
+    static constexpr int EP_ROWS = BN > 128 ? 64 : (BM > 128 ? 128 : BM);
+    static constexpr int EP_U = (EP_ROWS * EP_LD * 4 + 15) / 16;
+    static constexpr int SMEM_U = STAGE_U > EP_U ? STAGE_U : EP_U;
+    static constexpr bool DYNAMIC = SMEM_U * 16 + 4 * XMC_MAX_TAPS > 64 * 1024;      // beyond the static-LDS limit
+};
+
 template <int DT, int BM, int BN, int WM, int WN, int KSUB>
-__global__ __launch_bounds__(256) void igemm_kernel(const XmcConvDesc d) {
-    constexpr int NT = 256;
-    static_assert(WM * WN == 4, "4 waves");
+__global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const XmcConvDesc d) {
+    constexpr int NT = 64 * WM * WN;                 // 4 waves, or 8 for the 256x256 tile
+    static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves");
+    constexpr int RP = NT / 4;                       // tile rows staged per pass (4 threads per 64-byte row piece)
     constexpr int WTM = BM / WM, WTN = BN / WN;      // wave tile
     constexpr int TM = WTM / 16, TN = WTN / 16;      // 16x16 MFMA tiles per wave
     constexpr int AL = BM * 4 / NT;                  // A chunks per thread per sub-step
     constexpr int BL = (BN * 4 + NT - 1) / NT;       // B chunks per thread per sub-step
-    constexpr int STAGE_U = 2 * KSUB * (BM + BN) * 4;            // 16-byte units
-    constexpr int EP_LD = BN + 4;
-    constexpr int EP_ROWS = BM > 128 ? 128 : BM;     // the f32 staging of the epilogue is done 128 rows at a time
-    constexpr int EP_U = (EP_ROWS * EP_LD * 4 + 15) / 16;
-    constexpr int SMEM_U = STAGE_U > EP_U ? STAGE_U : EP_U;
-    __shared__ u32x4 smem[SMEM_U];
+    using Lds = IgemmLds<BM, BN, KSUB>;
+    constexpr int EP_LD = Lds::EP_LD, EP_ROWS = Lds::EP_ROWS;
+    extern __shared__ u32x4 smem_dyn[];
+    __shared__ u32x4 smem_static[Lds::DYNAMIC ? 1 : Lds::SMEM_U];
+    u32x4* const smem = Lds::DYNAMIC ? smem_dyn : smem_static;
     __shared__ int s_tap[XMC_MAX_TAPS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -98,7 +109,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const XmcConvDesc d) {
     int ph[AL], pw[AL], pn[AL];
 #pragma unroll
     for (int i = 0; i < AL; ++i) {
-        int m = m0 + r0 + 64 * i;
+        int m = m0 + r0 + RP * i;
         if (m < M) {
             int n = m / MHW, rem = m - n * MHW;
             int a = rem / d.MW, b = rem - a * d.MW;
@@ -130,7 +141,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const XmcConvDesc d) {
             }
 #pragma unroll
             for (int j = 0; j < BL; ++j) {
-                int rn = r0 + 64 * j;
+                int rn = r0 + RP * j;
                 u32x4 z = {0, 0, 0, 0};
                 bool ok = tapok && rn < BN;
                 size_t off = ((size_t)twi * d.CDw + n0 + rn) * upt + cu;
@@ -148,12 +159,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const XmcConvDesc d) {
         for (int s = 0; s < KSUB; ++s) {
 #pragma unroll
             for (int i = 0; i < AL; ++i) {
-                int r = r0 + 64 * i;
+                int r = r0 + RP * i;
                 la[(s * BM + r) * 4 + (c ^ swz(r))] = ra[s][i];
             }
 #pragma unroll
             for (int j = 0; j < BL; ++j) {
-                int r = r0 + 64 * j;
+                int r = r0 + RP * j;
                 if (r < BN) lb[(s * BN + r) * 4 + (c ^ swz(r))] = rb[s][j];
             }
         }
@@ -263,7 +274,13 @@ template <int DT, int BM, int BN, int WM, int WN, int KSUB>
 int launch(const XmcConvDesc& d, hipStream_t st) {
     const int64_t M = (int64_t)d.N * d.MH * d.MW;
     dim3 grid((unsigned)(((M + BM - 1) / BM) * (d.CDw / BN)), 1, (unsigned)d.nclass);
-    hipLaunchKernelGGL((igemm_kernel<DT, BM, BN, WM, WN, KSUB>), grid, dim3(256), 0, st, d);
+    using Lds = IgemmLds<BM, BN, KSUB>;
+    size_t dyn = 0;
+    if (Lds::DYNAMIC) {
+        dyn = (size_t)Lds::SMEM_U * 16;
+        XMC_ALLOW_BIG_LDS((igemm_kernel<DT, BM, BN, WM, WN, KSUB>));
+    }
+    hipLaunchKernelGGL((igemm_kernel<DT, BM, BN, WM, WN, KSUB>), grid, dim3(64 * WM * WN), dyn, st, d);
     xmc_note_kernel("igemm_kernel<%d, %d, %d, %d, %d, %d>", DT, BM, BN, WM, WN, KSUB);
     XMC_LAUNCH_CHECK();
     return 0;
@@ -281,6 +298,10 @@ int dispatch(const XmcConvDesc& d, hipStream_t st) {
         if (variant == 1) return launch<DT, 128, 128, 2, 2, 2>(d, st);
         // 256x128 tile, each wave a 128x64 patch: 1.33x fewer LDS fragment bytes per MFMA than 64x64 patches (the
         // 128x128 structure measures 600-650 TF/s against a no-global-load ceiling of ~800 TF/s: LDS-read bound)
+        // 256x256 tile, 8 waves of the same 128x64 patches: the A rows are shared by twice as many columns, 32 KB instead of
+        // 48 KB through the vector-memory path per 2 x (256x128x32) MACs (that path bounds this kernel)
+        static const bool no_big = getenv("XMC_NO_IGEMM256") != nullptr;
+        if (DT == XMC_BF16 && M >= 256 * 256 && d.CDw % 256 == 0 && !no_big) return launch<DT, 256, 256, 2, 4, 1>(d, st);
         if (DT == XMC_BF16 && M >= 256 * 256) return launch<DT, 256, 128, 2, 2, 1>(d, st);
         return launch<DT, 128, 128, 2, 2, 2>(d, st);
     }
