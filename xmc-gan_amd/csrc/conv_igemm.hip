@@ -301,7 +301,7 @@ int dispatch(const XmcConvDesc& d, hipStream_t st) {
         // 256x256 tile, 8 waves of the same 128x64 patches: the A rows are shared by twice as many columns, 32 KB instead of
         // 48 KB through the vector-memory path per 2 x (256x128x32) MACs (that path bounds this kernel)
         static const bool no_big = getenv("XMC_NO_IGEMM256") != nullptr;
-        if (DT == XMC_BF16 && M >= 256 * 256 && d.CDw % 256 == 0 && !no_big) return launch<DT, 256, 256, 2, 4, 1>(d, st);
+        if (DT == XMC_BF16 && M >= 256 * 256 && d.CDw % 256 == 0 && !no_big) return launch<DT, 256, 256, 2, 4, 2>(d, st);
         if (DT == XMC_BF16 && M >= 256 * 256) return launch<DT, 256, 128, 2, 2, 1>(d, st);
         return launch<DT, 128, 128, 2, 2, 2>(d, st);
     }
