@@ -235,17 +235,20 @@ int xmc_affine2_act_bwd(const void* x, const void* dy, const float* g0, const fl
  *   [N][C][2] + [N][G][2] for bwd.
  * Region attention pooling (CondConceptSampler.forward 293-299 / ConceptSampler.forward 570-578):
  *   scores[n,c,p] = scale * <q[n,c,:], key[n,p,c*pk:(c+1)*pk]>, attn = softmax over p, ctx[n,c,:] = sum_p attn * x[n,p,c*px:(c+1)*px]
- *   key [N][HW][ncon*pk], x [N][HW][ncon*px] (activation dtype); q, attn [N][ncon][HW], ctx [N][ncon][px] f32.
- *   bwd writes dq, dkey, dx (every element exactly once).
+ *   key [N][HW][ncon*pk], x [N][HW][ncon*px] (activation dtype); q [N][ncon][pk], ctx [N][ncon][px] f32; ncon = 16, pk = 4, px = 8.
+ *   The attention weights are not materialised: fwd leaves stats [N][ncon][2] = (max_p score, sum_p exp(score - max)) from which
+ *   bwd recomputes them; ws: xmc_attn_pool_ws_floats(N, HW) floats of scratch for fwd.  bwd writes dq, dkey, dx (dkey / dx:
+ *   every element exactly once).
  */
 int xmc_groupnorm_fwd(const void* x, const float* w, const float* b, void* y, float* stats, float* ws,
                       int N, int HW, int C, int G, float eps, float slope, int dtype, void* stream);
 int xmc_groupnorm_bwd(const void* x, const void* dy, const float* w, const float* b, const float* stats, void* dx,
                       float* dw, float* db, float* ws, int N, int HW, int C, int G, float slope, int dtype, void* stream);
-int xmc_attn_pool_fwd(const void* key, const float* q, const void* x, float* attn, float* ctx, int N, int HW,
+int64_t xmc_attn_pool_ws_floats(int N, int HW);
+int xmc_attn_pool_fwd(const void* key, const float* q, const void* x, float* stats, float* ctx, float* ws, int N, int HW,
                       int ncon, int pk, int px, float scale, int dtype, void* stream);
-int xmc_attn_pool_bwd(const void* key, const float* q, const void* x, const float* attn, const float* dctx, float* dq,
-                      void* dkey, void* dx, int N, int HW, int ncon, int pk, int px, float scale, int dtype, void* stream);
+int xmc_attn_pool_bwd(const void* key, const float* q, const void* x, const float* stats, const float* ctx, const float* dctx,
+                      float* dq, void* dkey, void* dx, int N, int HW, int ncon, int pk, int px, float scale, int dtype, void* stream);
 
 /*
  * Contrastive head (cosine_scores + sent_loss/img_loss, train_gan.py:85-139), fused:

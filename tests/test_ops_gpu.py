@@ -501,3 +501,34 @@ def test_cond_mlp_bank_matches_per_layer_reference(B, K, Hd, Cs, c_grad):
         assert rel(cp.grad, cd.grad) < 1e-5
     else:
         assert cp.grad is None
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("N,H,W", [(3, 4, 4), (2, 10, 10), (5, 64, 64), (64, 32, 32), (1, 128, 128)])
+def test_region_attention_pooling(N, H, W, mode):
+    """ops.attn_pool (CondConceptSampler / ConceptSampler, df_concept_gan.py:293-299, 570-578): per (sample, concept) softmax
+    over H*W of scale * <q, key>, attention-weighted sum of x -- forward and the gradients w.r.t. key, q and x against an f64
+    evaluation on the CPU.  Sizes cover one run per image, ragged runs (100 pixels), several runs per image and the
+    many-images regime; the kernel recomputes the attention weights in backward instead of storing them."""
+    ops.set_precision(mode)
+    dt = ops.act_dtype()
+    g = torch.Generator().manual_seed(N * 1000 + H)
+    ncon, pk, px, scale = 16, 4, 8, 0.5
+    key = rt(torch.randn(N, H, W, ncon * pk, generator=g), mode)
+    x = rt(torch.randn(N, H, W, ncon * px, generator=g), mode)
+    q = torch.randn(N, ncon, pk, generator=g) * 2
+    R = torch.randn(N, ncon, px, generator=g)
+    kd, xd, qd = key.double().requires_grad_(), x.double().requires_grad_(), q.double().requires_grad_()
+    sc = scale * torch.einsum("nck,npck->ncp", qd, kd.view(N, H * W, ncon, pk))
+    a = torch.softmax(sc, dim=2)
+    ctx_ref = torch.einsum("ncp,npcj->ncj", a, xd.view(N, H * W, ncon, px))
+    (ctx_ref * R.double()).sum().backward()
+    kp, xp = key.to(DEV, dt).requires_grad_(), x.to(DEV, dt).requires_grad_()
+    qp = q.to(DEV).requires_grad_()
+    ctx = ops.attn_pool(kp, qp, xp, ncon, scale)
+    assert ctx.shape == (N, ncon, px) and ctx.dtype == torch.float32
+    (ctx * R.to(DEV)).sum().backward()
+    rel = lambda u, v: ((u.detach().double().cpu() - v).norm() / v.norm().clamp_min(1e-30)).item()
+    t = 1e-5 if mode == "fp32" else 1e-2          # bf16: the gradients are stored in bf16
+    assert rel(ctx, ctx_ref.detach()) < (1e-5 if mode == "fp32" else 1e-5), rel(ctx, ctx_ref.detach())
+    assert rel(kp.grad, kd.grad) < t and rel(xp.grad, xd.grad) < t and rel(qp.grad, qd.grad) < 1e-4 + t

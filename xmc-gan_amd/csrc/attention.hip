@@ -192,101 +192,137 @@ template <int P> struct PVec<XMC_F32, P> {
     }
 };
 
-// key [N][HW][CK] (CK = ncon*PK), q f32 [N][ncon][PK], x [N][HW][CX] (CX = ncon*PX); attn f32 [N][ncon][HW]; ctx f32 [N][ncon][PX]
-template <int DT, int PK, int PX>
-__global__ void attn_pool_fwd_kernel(const void* key, const float* q, const void* x, float* attn, float* ctx,
-                                     int HW, int ncon, float scale) {
-    const int n = blockIdx.x / ncon, c = blockIdx.x % ncon;
-    __shared__ float sh[NT / 64];
-    __shared__ float red[NT * 8];
-    float qv[8];
+// ---- region attention pooling (CondConceptSampler.forward 293-299 / ConceptSampler.forward 570-578), coalesced form.
+// key [N][HW][16*4], x [N][HW][16*8], q f32 [N][16][4]; ctx f32 [N][16][8]; stats f32 [N][16][2] = (row max, sum of exp).
+// A workgroup owns a run of pixels of ONE image for ALL 16 concepts: lane = (pixel slot, concept), so a wave reads 4 whole
+// pixels -- 4 x 128 contiguous bytes of key, 4 x 256 of x -- instead of one 8/16-byte piece out of every 256-byte pixel per
+// lane (which also made the 16 workgroups of an image, dealt over the 8 XCDs, each pull every line into its own L2).
+// Forward: one pass with a running softmax (max, sum, weighted sum re-scaled when the max moves), the 16 pixel slots merged
+// through LDS, one partial per (image, run, concept), then a tiny merge kernel.  The attention weights are never stored:
+// backward recomputes exp(s - max) / sum from key and q, and the softmax-Jacobian term sum_p a_p <dctx, x_p> is simply
+// <dctx, ctx> (ctx being that very sum), so backward is ONE pass too: read key and x, write dkey and dx.
+constexpr int AP_CON = 16;                 // concepts (cardinality, df_concept_gan.py:110)
+constexpr int AP_SLOTS = NT / AP_CON;      // pixels in flight per workgroup
+constexpr int AP_PK = 4, AP_PX = 8;        // state_dim, bottleneck width (df_concept_gan.py:110,118)
+constexpr int AP_REC = 2 + AP_PX;          // partial record: max, sum, weighted sum[8]
+
+template <int DT>
+__global__ __launch_bounds__(NT) void attn_pool_part_kernel(const void* key, const float* q, const void* x, float* part,
+                                                            int HW, float scale, int ppc) {
+    __shared__ float sm[AP_SLOTS][AP_CON][AP_REC + 1];
+    const int n = blockIdx.y, chunk = blockIdx.x, c = threadIdx.x & (AP_CON - 1), slot = threadIdx.x / AP_CON;
+    float qv[AP_PK];
 #pragma unroll
-    for (int k = 0; k < PK; ++k) qv[k] = q[((size_t)n * ncon + c) * PK + k] * scale;
-    const int CK = ncon * PK, CX = ncon * PX;
-    float* arow = attn + ((size_t)n * ncon + c) * HW;
-    float mx = -INFINITY;
-    for (int p = threadIdx.x; p < HW; p += NT) {
-        float kv[8];
-        PVec<DT, PK>::load(key, ((size_t)n * HW + p) * CK + c * PK, kv);
-        float s = 0.f;
+    for (int k = 0; k < AP_PK; ++k) qv[k] = q[((size_t)n * AP_CON + c) * AP_PK + k] * scale;
+    float m = -INFINITY, l = 0.f, acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int p1 = min(HW, (chunk + 1) * ppc);
+    for (int p = chunk * ppc + slot; p < p1; p += AP_SLOTS) {
+        float kv[8], xv[8];
+        PVec<DT, AP_PK>::load(key, ((size_t)n * HW + p) * (AP_CON * AP_PK) + c * AP_PK, kv);
+        PVec<DT, AP_PX>::load(x, ((size_t)n * HW + p) * (AP_CON * AP_PX) + c * AP_PX, xv);
+        float sc = 0.f;
 #pragma unroll
-        for (int k = 0; k < PK; ++k) s += qv[k] * kv[k];
-        arow[p] = s;
-        mx = fmaxf(mx, s);
+        for (int k = 0; k < AP_PK; ++k) sc += qv[k] * kv[k];
+        const float mn = fmaxf(m, sc), f = __expf(m - mn), e = __expf(sc - mn);
+        l = l * f + e;
+#pragma unroll
+        for (int k = 0; k < AP_PX; ++k) acc[k] = acc[k] * f + e * xv[k];
+        m = mn;
     }
-    mx = block_max(mx, sh);
-    float se = 0.f;
-    for (int p = threadIdx.x; p < HW; p += NT) { float e = __expf(arow[p] - mx); arow[p] = e; se += e; }
-    se = block_sum(se, sh);
-    const float inv = 1.f / se;
-    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int p = threadIdx.x; p < HW; p += NT) {
-        float a = arow[p] * inv;
-        arow[p] = a;
-        float xv[8];
-        PVec<DT, PX>::load(x, ((size_t)n * HW + p) * CX + c * PX, xv);
+    sm[slot][c][0] = m; sm[slot][c][1] = l;
 #pragma unroll
-        for (int k = 0; k < PX; ++k) acc[k] += a * xv[k];
-    }
+    for (int k = 0; k < AP_PX; ++k) sm[slot][c][2 + k] = acc[k];
     __syncthreads();
+    if (threadIdx.x < AP_CON) {
+        float M = -INFINITY;
+        for (int sl = 0; sl < AP_SLOTS; ++sl) M = fmaxf(M, sm[sl][c][0]);
+        float Lq = 0.f, A[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int sl = 0; sl < AP_SLOTS; ++sl) {
+            const float ms = sm[sl][c][0];
+            if (ms == -INFINITY) continue;                       // slot saw no pixel
+            const float f = __expf(ms - M);
+            Lq += sm[sl][c][1] * f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) red[threadIdx.x * 8 + k] = acc[k];
-    __syncthreads();
-    if (threadIdx.x < PX) {
-        float t = 0.f;
-        for (int i = 0; i < NT; ++i) t += red[i * 8 + threadIdx.x];
-        ctx[((size_t)n * ncon + c) * PX + threadIdx.x] = t;
+            for (int k = 0; k < AP_PX; ++k) A[k] += sm[sl][c][2 + k] * f;
+        }
+        float* o = part + (((size_t)n * gridDim.x + chunk) * AP_CON + c) * AP_REC;
+        o[0] = M; o[1] = Lq;
+#pragma unroll
+        for (int k = 0; k < AP_PX; ++k) o[2 + k] = A[k];
     }
 }
-// given dctx: dq, dkey (written, every element owned by exactly one workgroup), dx (written)
-template <int DT, int PK, int PX>
-__global__ void attn_pool_bwd_kernel(const void* key, const float* q, const void* x, const float* attn, const float* dctx,
-                                     float* dq, void* dkey, void* dx, int HW, int ncon, float scale) {
-    const int n = blockIdx.x / ncon, c = blockIdx.x % ncon;
-    __shared__ float sh[NT / 64];
-    __shared__ float red[NT * 8];
-    const int CK = ncon * PK, CX = ncon * PX;
-    float qv[8], dc[8];
+
+__global__ void attn_pool_merge_kernel(const float* part, float* stats, float* ctx, int N, int chunks) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;       // (n, c)
+    if (i >= N * AP_CON) return;
+    const int n = i / AP_CON, c = i % AP_CON;
+    float M = -INFINITY;
+    for (int ch = 0; ch < chunks; ++ch) M = fmaxf(M, part[(((size_t)n * chunks + ch) * AP_CON + c) * AP_REC]);
+    float Lq = 0.f, A[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int ch = 0; ch < chunks; ++ch) {
+        const float* r = part + (((size_t)n * chunks + ch) * AP_CON + c) * AP_REC;
+        const float f = __expf(r[0] - M);
+        Lq += r[1] * f;
 #pragma unroll
-    for (int k = 0; k < PK; ++k) qv[k] = q[((size_t)n * ncon + c) * PK + k] * scale;
-#pragma unroll
-    for (int k = 0; k < PX; ++k) dc[k] = dctx[((size_t)n * ncon + c) * PX + k];
-    const float* arow = attn + ((size_t)n * ncon + c) * HW;
-    float dot = 0.f;                                   // sum_hw attn * dattn
-    for (int p = threadIdx.x; p < HW; p += NT) {
-        float xv[8];
-        PVec<DT, PX>::load(x, ((size_t)n * HW + p) * CX + c * PX, xv);
-        float da = 0.f;
-#pragma unroll
-        for (int k = 0; k < PX; ++k) da += dc[k] * xv[k];
-        dot += arow[p] * da;
+        for (int k = 0; k < AP_PX; ++k) A[k] += r[2 + k] * f;
     }
-    dot = block_sum(dot, sh);
-    float dqa[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int p = threadIdx.x; p < HW; p += NT) {
-        const float a = arow[p];
-        float xv[8], kv[8], g[8];
-        const size_t ex = ((size_t)n * HW + p) * CX + c * PX, ek = ((size_t)n * HW + p) * CK + c * PK;
-        PVec<DT, PX>::load(x, ex, xv);
-        PVec<DT, PK>::load(key, ek, kv);
-        float da = 0.f;
+    stats[(size_t)i * 2] = M; stats[(size_t)i * 2 + 1] = Lq;
+    const float inv = 1.f / Lq;
 #pragma unroll
-        for (int k = 0; k < PX; ++k) { da += dc[k] * xv[k]; g[k] = a * dc[k]; }
-        PVec<DT, PX>::store(dx, ex, g);
+    for (int k = 0; k < AP_PX; ++k) ctx[(size_t)i * AP_PX + k] = A[k] * inv;
+}
+
+// dq must be zero on entry (partial sums of the runs are added atomically); dkey, dx: every element written exactly once
+template <int DT>
+__global__ __launch_bounds__(NT) void attn_pool_bwd_kernel(const void* key, const float* q, const void* x, const float* stats,
+                                                           const float* ctx, const float* dctx, float* dq, void* dkey, void* dx,
+                                                           int HW, float scale, int ppc) {
+    __shared__ float sm[AP_SLOTS][AP_CON][AP_PK + 1];
+    const int n = blockIdx.y, chunk = blockIdx.x, c = threadIdx.x & (AP_CON - 1), slot = threadIdx.x / AP_CON;
+    const size_t nc = (size_t)n * AP_CON + c;
+    float qv[AP_PK], dc[AP_PX];
+#pragma unroll
+    for (int k = 0; k < AP_PK; ++k) qv[k] = q[nc * AP_PK + k] * scale;
+    float dot = 0.f;                                           // sum_p a_p <dctx, x_p> = <dctx, ctx>
+#pragma unroll
+    for (int k = 0; k < AP_PX; ++k) { dc[k] = dctx[nc * AP_PX + k]; dot += dc[k] * ctx[nc * AP_PX + k]; }
+    const float M = stats[nc * 2], invL = 1.f / stats[nc * 2 + 1];
+    float dqa[AP_PK] = {0, 0, 0, 0};
+    const int p1 = min(HW, (chunk + 1) * ppc);
+    for (int p = chunk * ppc + slot; p < p1; p += AP_SLOTS) {
+        float kv[8], xv[8], g[8];
+        const size_t ek = ((size_t)n * HW + p) * (AP_CON * AP_PK) + c * AP_PK, ex = ((size_t)n * HW + p) * (AP_CON * AP_PX) + c * AP_PX;
+        PVec<DT, AP_PK>::load(key, ek, kv);
+        PVec<DT, AP_PX>::load(x, ex, xv);
+        float sc = 0.f, da = 0.f;
+#pragma unroll
+        for (int k = 0; k < AP_PK; ++k) sc += qv[k] * kv[k];
+        const float a = __expf(sc - M) * invL;
+#pragma unroll
+        for (int k = 0; k < AP_PX; ++k) { da += dc[k] * xv[k]; g[k] = a * dc[k]; }
+        PVec<DT, AP_PX>::store(dx, ex, g);
         const float ds = a * (da - dot);
 #pragma unroll
-        for (int k = 0; k < PK; ++k) { dqa[k] += ds * kv[k]; g[k] = ds * qv[k]; }
-        PVec<DT, PK>::store(dkey, ek, g);
+        for (int k = 0; k < AP_PK; ++k) { dqa[k] += ds * kv[k]; g[k] = ds * qv[k]; }
+        PVec<DT, AP_PK>::store(dkey, ek, g);
     }
-    __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 8; ++k) red[threadIdx.x * 8 + k] = dqa[k];
+    for (int k = 0; k < AP_PK; ++k) sm[slot][c][k] = dqa[k];
     __syncthreads();
-    if (threadIdx.x < PK) {
+    if (threadIdx.x < AP_CON * AP_PK) {
+        const int cc = threadIdx.x / AP_PK, k = threadIdx.x % AP_PK;
         float t = 0.f;
-        for (int i = 0; i < NT; ++i) t += red[i * 8 + threadIdx.x];
-        dq[((size_t)n * ncon + c) * PK + threadIdx.x] = t * scale;
+        for (int sl = 0; sl < AP_SLOTS; ++sl) t += sm[sl][cc][k];
+        atomicAdd(&dq[((size_t)n * AP_CON + cc) * AP_PK + k], t * scale);
     }
+}
+
+// pixels per workgroup run: ~2048 workgroups over the whole batch, at least 64 pixels each, a multiple of the 16 slots
+static inline int ap_pixels_per_chunk(int N, int HW) {
+    int64_t ppc = ((int64_t)N * HW + 2047) / 2048;
+    if (ppc < 64) ppc = 64;
+    ppc = (ppc + AP_SLOTS - 1) / AP_SLOTS * AP_SLOTS;
+    return (int)ppc;
 }
 }  // namespace
 
@@ -338,20 +374,34 @@ extern "C" int xmc_groupnorm_bwd(const void* x, const void* dy, const float* w, 
     XMC_LAUNCH_CHECK();
     return 0;
 }
-extern "C" int xmc_attn_pool_fwd(const void* key, const float* q, const void* x, float* attn, float* ctx, int N, int HW,
+extern "C" int64_t xmc_attn_pool_ws_floats(int N, int HW) {
+    if (N < 1 || HW < 1) return 0;
+    const int ppc = ap_pixels_per_chunk(N, HW), chunks = (HW + ppc - 1) / ppc;
+    return (int64_t)N * chunks * AP_CON * AP_REC;
+}
+extern "C" int xmc_attn_pool_fwd(const void* key, const float* q, const void* x, float* stats, float* ctx, float* ws, int N, int HW,
                                  int ncon, int pk, int px, float scale, int dtype, void* s) {
-    if (pk != 4 || px != 8 || ncon < 1) return XMC_ESHAPE;          // state_dim 4, bottleneck width 8 (df_concept_gan.py:110,118)
-    if (dtype == XMC_BF16) hipLaunchKernelGGL((attn_pool_fwd_kernel<XMC_BF16, 4, 8>), dim3(N * ncon), dim3(NT), 0, ST(s), key, q, x, attn, ctx, HW, ncon, scale);
-    else if (dtype == XMC_F32) hipLaunchKernelGGL((attn_pool_fwd_kernel<XMC_F32, 4, 8>), dim3(N * ncon), dim3(NT), 0, ST(s), key, q, x, attn, ctx, HW, ncon, scale);
+    if (!key || !q || !x || !stats || !ctx || !ws || N < 1 || HW < 1) return XMC_EINVAL;
+    if (pk != AP_PK || px != AP_PX || ncon != AP_CON) return XMC_ESHAPE;   // cardinality 16, state_dim 4, bottleneck width 8 (df_concept_gan.py:110,118)
+    const int ppc = ap_pixels_per_chunk(N, HW), chunks = (HW + ppc - 1) / ppc;
+    dim3 grid(chunks, N);
+    if (dtype == XMC_BF16) hipLaunchKernelGGL((attn_pool_part_kernel<XMC_BF16>), grid, dim3(NT), 0, ST(s), key, q, x, ws, HW, scale, ppc);
+    else if (dtype == XMC_F32) hipLaunchKernelGGL((attn_pool_part_kernel<XMC_F32>), grid, dim3(NT), 0, ST(s), key, q, x, ws, HW, scale, ppc);
     else return XMC_EINVAL;
+    hipLaunchKernelGGL(attn_pool_merge_kernel, dim3((N * AP_CON + NT - 1) / NT), dim3(NT), 0, ST(s), ws, stats, ctx, N, chunks);
     XMC_LAUNCH_CHECK();
     return 0;
 }
-extern "C" int xmc_attn_pool_bwd(const void* key, const float* q, const void* x, const float* attn, const float* dctx, float* dq,
-                                 void* dkey, void* dx, int N, int HW, int ncon, int pk, int px, float scale, int dtype, void* s) {
-    if (pk != 4 || px != 8 || ncon < 1) return XMC_ESHAPE;
-    if (dtype == XMC_BF16) hipLaunchKernelGGL((attn_pool_bwd_kernel<XMC_BF16, 4, 8>), dim3(N * ncon), dim3(NT), 0, ST(s), key, q, x, attn, dctx, dq, dkey, dx, HW, ncon, scale);
-    else if (dtype == XMC_F32) hipLaunchKernelGGL((attn_pool_bwd_kernel<XMC_F32, 4, 8>), dim3(N * ncon), dim3(NT), 0, ST(s), key, q, x, attn, dctx, dq, dkey, dx, HW, ncon, scale);
+extern "C" int xmc_attn_pool_bwd(const void* key, const float* q, const void* x, const float* stats, const float* ctx,
+                                 const float* dctx, float* dq, void* dkey, void* dx, int N, int HW, int ncon, int pk, int px,
+                                 float scale, int dtype, void* s) {
+    if (!key || !q || !x || !stats || !ctx || !dctx || !dq || !dkey || !dx || N < 1 || HW < 1) return XMC_EINVAL;
+    if (pk != AP_PK || px != AP_PX || ncon != AP_CON) return XMC_ESHAPE;
+    if (hipMemsetAsync(dq, 0, sizeof(float) * (size_t)N * AP_CON * AP_PK, ST(s)) != hipSuccess) return XMC_EINVAL;
+    const int ppc = ap_pixels_per_chunk(N, HW), chunks = (HW + ppc - 1) / ppc;
+    dim3 grid(chunks, N);
+    if (dtype == XMC_BF16) hipLaunchKernelGGL((attn_pool_bwd_kernel<XMC_BF16>), grid, dim3(NT), 0, ST(s), key, q, x, stats, ctx, dctx, dq, dkey, dx, HW, scale, ppc);
+    else if (dtype == XMC_F32) hipLaunchKernelGGL((attn_pool_bwd_kernel<XMC_F32>), grid, dim3(NT), 0, ST(s), key, q, x, stats, ctx, dctx, dq, dkey, dx, HW, scale, ppc);
     else return XMC_EINVAL;
     XMC_LAUNCH_CHECK();
     return 0;

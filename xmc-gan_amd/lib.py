@@ -80,8 +80,9 @@ _SIGS = {
     "xmc_affine2_lrelu_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "xmc_groupnorm_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, i32, vp],
     "xmc_groupnorm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp],
-    "xmc_attn_pool_fwd": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp],
-    "xmc_attn_pool_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp],
+    "xmc_attn_pool_ws_floats": [i32, i32],
+    "xmc_attn_pool_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp],
+    "xmc_attn_pool_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp],
     "xmc_contrastive_ws_bytes": [i32, i32],
     "xmc_contrastive_fwd": [vp, vp, vp, vp, i32, i32, vp, vp, vp],
     "xmc_contrastive_bwd": [vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp],
@@ -92,7 +93,7 @@ _SIGS = {
     "xmc_adam_chunk_elems": [],
     "xmc_adam_step": [vp, i32, vp, i32, f32, f32, f32, f32, vp],
 }
-_RESTYPE = {"xmc_contrastive_ws_bytes": i64, "xmc_last_kernel": C.c_char_p}
+_RESTYPE = {"xmc_contrastive_ws_bytes": i64, "xmc_attn_pool_ws_floats": i64, "xmc_last_kernel": C.c_char_p}
 EXPORTS = tuple(_SIGS)
 
 _lib = None

@@ -1277,24 +1277,25 @@ class AttnPoolFn(torch.autograd.Function):
         q = q.contiguous().float()
         N, H, W, CK = key.shape
         pk, px = CK // ncon, x.shape[3] // ncon
-        attn = torch.empty((N, ncon, H * W), dtype=torch.float32, device=x.device)
+        stats = torch.empty((N, ncon, 2), dtype=torch.float32, device=x.device)     # (max, sum of exp): the weights are recomputed
         out = torch.empty((N, ncon, px), dtype=torch.float32, device=x.device)
-        L.call("xmc_attn_pool_fwd", _p(key), _p(q), _p(x), _p(attn), _p(out), N, H * W, ncon, pk, px, float(scale),
+        ws = torch.empty(int(L.load().xmc_attn_pool_ws_floats(N, H * W)), dtype=torch.float32, device=x.device)
+        L.call("xmc_attn_pool_fwd", _p(key), _p(q), _p(x), _p(stats), _p(out), _p(ws), N, H * W, ncon, pk, px, float(scale),
                _code(x.dtype), _st())
         ctx.ncon, ctx.scale = ncon, scale
-        ctx.save_for_backward(key, q, x, attn)
+        ctx.save_for_backward(key, q, x, stats, out)
         return out
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, dctx):
-        key, q, x, attn = ctx.saved_tensors
+        key, q, x, stats, out = ctx.saved_tensors
         N, H, W, CK = key.shape
         pk, px = CK // ctx.ncon, x.shape[3] // ctx.ncon
         dq = torch.empty_like(q)
         dkey, dx = torch.empty_like(key), torch.empty_like(x)
-        L.call("xmc_attn_pool_bwd", _p(key), _p(q), _p(x), _p(attn), _p(dctx.contiguous().float()), _p(dq), _p(dkey), _p(dx),
-               N, H * W, ctx.ncon, pk, px, float(ctx.scale), _code(x.dtype), _st())
+        L.call("xmc_attn_pool_bwd", _p(key), _p(q), _p(x), _p(stats), _p(out), _p(dctx.contiguous().float()), _p(dq), _p(dkey),
+               _p(dx), N, H * W, ctx.ncon, pk, px, float(ctx.scale), _code(x.dtype), _st())
         return dkey, dq, dx, None, None
 
 
