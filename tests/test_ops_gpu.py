@@ -532,3 +532,22 @@ def test_region_attention_pooling(N, H, W, mode):
     t = 1e-5 if mode == "fp32" else 1e-2          # bf16: the gradients are stored in bf16
     assert rel(ctx, ctx_ref.detach()) < (1e-5 if mode == "fp32" else 1e-5), rel(ctx, ctx_ref.detach())
     assert rel(kp.grad, kd.grad) < t and rel(xp.grad, xd.grad) < t and rel(qp.grad, qd.grad) < 1e-4 + t
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("N,H,W,C", [(3, 16, 16, 128), (2, 100, 7, 64), (64, 32, 32, 128), (1, 128, 128, 128), (2, 20, 20, 8)])
+def test_global_avgpool_large_maps(N, H, W, C, mode):
+    """F.adaptive_avg_pool2d(x, 1) on the maps the concept samplers pool (df_concept_gan.py:557): the many-workgroup kernel
+    (H*W >= 256) against the CPU, forward and backward."""
+    ops.set_precision(mode)
+    dt = ops.act_dtype()
+    g = torch.Generator().manual_seed(H * W + C)
+    x = rt(torch.randn(N, H, W, C, generator=g) + 0.3, mode)
+    r = torch.randn(N, C, generator=g)
+    xd = x.to(DEV, dt).requires_grad_()
+    y = ops.global_avgpool(xd)
+    assert y.shape == (N, C) and y.dtype == torch.float32
+    torch.testing.assert_close(y.cpu(), x.double().mean(dim=(1, 2)).float(), rtol=1e-5, atol=1e-5)
+    (y * r.to(DEV)).sum().backward()
+    ref = (r / (H * W))[:, None, None, :].expand(N, H, W, C)
+    torch.testing.assert_close(xd.grad.float().cpu(), rt(ref, mode), rtol=1e-2 if mode == "bf16" else 1e-6, atol=1e-8)

@@ -226,6 +226,35 @@ __global__ void gap_kernel(const void* x, void* y, int N, int HW, int C8) {
         Vec8<OD>::store(y, i, acc);
     }
 }
+// Large maps (the concept samplers pool [B,128,128,128] activations, df_concept_gan.py:557): block = (pixel run, image), thread =
+// (channel chunk, pixel lane); partial means are added atomically into the zeroed f32 output.  (gap_kernel above walks all of
+// H*W in ONE thread per channel chunk: fine for the discriminator's 4x4 maps it was written for, 1.2 ms per call on these.)
+template <int DT>
+__global__ void gap_big_kernel(const void* x, float* y, int HW, int C8, int pix_per_block) {
+    const int n = blockIdx.y, groups = NT / C8;
+    const int cc = threadIdx.x % C8, g = threadIdx.x / C8;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, v[8];
+    const int p_end = min(HW, (int)(blockIdx.x + 1) * pix_per_block);
+    if (g < groups)
+        for (int p = blockIdx.x * pix_per_block + g; p < p_end; p += groups) {
+            Vec8<DT>::load(x, ((size_t)n * HW + p) * C8 + cc, v);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] += v[k];
+        }
+    __shared__ float red[NT * 8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[threadIdx.x * 8 + k] = acc[k];
+    __syncthreads();
+    if (threadIdx.x < C8) {
+        const float inv = 1.f / HW;
+        float t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int gg = 0; gg < groups; ++gg)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t[k] += red[(gg * C8 + threadIdx.x) * 8 + k];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) atomicAdd(&y[((size_t)n * C8 + threadIdx.x) * 8 + k], t[k] * inv);
+    }
+}
 template <int DT, int ID>
 __global__ void gap_bwd_kernel(const void* dy, void* dx, int N, int HW, int C8) {
     const int64_t total = (int64_t)N * HW * C8;
@@ -641,6 +670,17 @@ extern "C" int xmc_upsample2(const void* x, void* y, int N, int H, int W, int C,
 }
 extern "C" int xmc_global_avgpool(const void* x, void* y, int N, int HW, int C, int dtype, int out_dtype, void* s) {
     if (C % 8) return XMC_EALIGN;
+    if (HW >= 256 && out_dtype == XMC_F32 && C / 8 <= NT && (dtype == XMC_BF16 || dtype == XMC_F32)) {
+        const int C8 = C / 8, groups = NT / C8;
+        int64_t ppb = ((int64_t)N * HW + 2047) / 2048;          // ~2048 workgroups over the batch, >= 4 pixels per lane
+        if (ppb < 4 * groups) ppb = 4 * groups;
+        const int bx = (int)((HW + ppb - 1) / ppb);
+        if (hipMemsetAsync(y, 0, sizeof(float) * (size_t)N * C, ST(s)) != hipSuccess) return XMC_EINVAL;
+        if (dtype == XMC_BF16) hipLaunchKernelGGL((gap_big_kernel<XMC_BF16>), dim3(bx, N), dim3(NT), 0, ST(s), x, (float*)y, HW, C8, (int)ppb);
+        else hipLaunchKernelGGL((gap_big_kernel<XMC_F32>), dim3(bx, N), dim3(NT), 0, ST(s), x, (float*)y, HW, C8, (int)ppb);
+        XMC_LAUNCH_CHECK();
+        return 0;
+    }
     dim3 g(nblocks((int64_t)N * (C / 8))), blk(NT);
     if (dtype == XMC_BF16 && out_dtype == XMC_F32) hipLaunchKernelGGL((gap_kernel<XMC_BF16, XMC_F32>), g, blk, 0, ST(s), x, y, N, HW, C / 8);
     else if (dtype == XMC_BF16 && out_dtype == XMC_BF16) hipLaunchKernelGGL((gap_kernel<XMC_BF16, XMC_BF16>), g, blk, 0, ST(s), x, y, N, HW, C / 8);
