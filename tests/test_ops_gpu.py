@@ -347,7 +347,8 @@ def test_axpby_scale_dot_hinge(mode):
         assert lgd.grad[..., 1:].abs().max().item() == 0
 
 
-@pytest.mark.parametrize("n,D", [(8, 256), (5, 48), (64, 512), (200, 256)])
+@pytest.mark.parametrize("n,D", [(8, 256), (5, 48), (64, 512), (200, 256),
+                                 (256, 256), (2048, 256), (2048, 512)])     # one GPU's batch; 8 x 256 all-gathered rows (BASELINE config 5)
 @pytest.mark.parametrize("labels_kind", ["identity", "global_adaptive", "global_smooth"])
 def test_contrastive_head(n, D, labels_kind):
     """fused cosine-similarity + symmetric InfoNCE vs the oracle (train_gan.py:85-139); f32, logits/loss 1e-3 rel."""
