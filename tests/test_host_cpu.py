@@ -283,6 +283,24 @@ def test_word_attention_generator_state_dict_and_registry():
     gan.reset_cfg()
 
 
+def test_product_never_touches_the_oracle_or_a_cpu_fallback():
+    """The oracle is test infrastructure: nothing under xmc_gan/ or xmc-gan_amd/ may import it (only tests/, smoke() and
+    bench.py's cpu_baseline leg do), and nothing there may read the reference tree."""
+    bad = []
+    for top in ("xmc_gan", "xmc-gan_amd"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, top)):
+            for f in files:
+                if f.endswith((".py", ".hip", ".h")):
+                    txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                    if re.search(r"^\s*(import|from)\s+(xmc_ref|ref_harness|oracle)\b", txt, re.M) or "/root/reference" in txt:
+                        bad.append(os.path.join(dirpath, f))
+    assert not bad, bad
+    entry = open(os.path.join(ROOT, "__graft_entry__.py")).read()
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    assert "xmc_ref" in entry and "xmc_ref" in bench                      # the two sanctioned users
+    assert "/root/reference" not in bench                                  # nothing at run time reads the reference
+
+
 def test_cli_flags_match_reference():
     import xmc_gan.train_gan as tg
     a = tg.parse_args([])
