@@ -303,6 +303,9 @@ int dispatch(const XmcConvDesc& d, hipStream_t st) {
         static const bool no_big = getenv("XMC_NO_IGEMM256") != nullptr;
         if (DT == XMC_BF16 && M >= 256 * 256 && d.CDw % 256 == 0 && !no_big) return launch<DT, 256, 256, 2, 4, 2>(d, st);
         if (DT == XMC_BF16 && M >= 256 * 256) return launch<DT, 256, 128, 2, 2, 1>(d, st);
+        // few output pixels (the 4x4 / 8x8 maps at the end of D, K = 4608-8192): 128-row tiles would leave half the CUs idle
+        static const bool no_m64 = getenv("XMC_NO_IGEMM_M64") != nullptr;
+        if (DT == XMC_BF16 && !no_m64 && (M + 127) / 128 * (d.CDw / 128) * d.nclass < 256) return launch<DT, 64, 128, 2, 2, 2>(d, st);
         return launch<DT, 128, 128, 2, 2, 2>(d, st);
     }
     if (d.CDw % 64 == 0) return launch<DT, 128, 64, 4, 1, 2>(d, st);
