@@ -104,20 +104,57 @@ def cpu_baseline(cfg, cfg_name, imsize, seconds_budget=15.0):
                 sample=f"{n} full G+D iterations of oracle/xmc_ref.py (PyTorch CPU fp32), {imsize}x{imsize}, batch {B}, {cfg_name}")
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD `torch.distributed.run` (this process has
+    not initialised the GPU and never does), relay the ranks' output, pass rank 0's JSON line through, and fail unless the
+    line reports n_gpus == N."""
+    import socket
+    import subprocess
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC (RCCL across processes)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout:
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln.strip()
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if rc != 0:
+        raise SystemExit(rc)
+    if line is None or json.loads(line).get("n_gpus") != n:
+        raise SystemExit(f"bench.py --gpus {n}: the launched ranks did not report n_gpus == {n}")
+    print(line, flush=True)
+    return 0
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(a.gpus)                       # before anything touches the GPU in this process
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: start {a.gpus} ranks (python bench.py --gpus {a.gpus} "
+                         "launches them itself) or pass --gpus equal to the number of ranks")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU path (the CPU oracle is only the baseline leg)")
-    local_rank %= max(torch.cuda.device_count(), 1)      # (rehearsals with more ranks than GPUs share a device over gloo)
+    backend = os.environ.get("XMC_DIST_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
+    ndev = torch.cuda.device_count()
+    if local_rank >= ndev:
+        if backend == "nccl":
+            raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {ndev} GPU(s) visible; RCCL needs one GPU per rank "
+                             "(XMC_DIST_BACKEND=gloo lets rehearsal ranks share a card)")
+        local_rank %= max(ndev, 1)                       # gloo rehearsal: several ranks on one card
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        backend = os.environ.get("XMC_DIST_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
         if backend == "nccl":
             torch.distributed.init_process_group("nccl", device_id=dev)
         else:

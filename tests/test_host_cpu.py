@@ -5,6 +5,7 @@ import ctypes
 import glob
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -309,3 +310,21 @@ def test_cli_flags_match_reference():
     # the reference's live registry (train_gan.py:42-49) plus the two word-attention names it keeps commented out
     assert set(tg._GEN_ARCH) == {"DF_GEN", "CONCEPT_IN_DF_GEN", "CONCEPT_OUT_DF_GEN", "CONCEPT_OUTATTN_GEN", "CONCEPT_INATTN_GEN"}
     assert set(tg._DISC_ARCH) == {"DF_DISC", "CONCEPT_NETD"}
+
+
+def test_bench_gpus_n_without_launcher_starts_n_ranks():
+    """`python bench.py --gpus 2` outside torchrun must start two ranks itself (child process) instead of silently timing one:
+    without a GPU each rank stops at the "needs an MI355X" check, which proves both were started with WORLD_SIZE=2."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    if torch.cuda.is_available():
+        pytest.skip("covered by the GPU rehearsal")
+    assert r.returncode != 0
+    assert r.stderr.count("needs an MI355X") >= 2, r.stderr[-2000:]
+    # and a mismatching launcher is refused instead of being ignored
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], env=env2, capture_output=True, text=True,
+                        timeout=300)
+    assert r2.returncode != 0 and "WORLD_SIZE=1" in (r2.stderr + r2.stdout)

@@ -92,6 +92,10 @@ STEP_CASES = [
     # DISC.SPEC_NORM: every discriminator layer wrapped in the legacy spectral_norm hook (modules.py:16-17,31-32)
     ("df_gan_damsm_nomagp.yml", {"TRAIN.NCH": 8, "DISC.SPEC_NORM": True}, 4, 2),
     ("df_gan_damsm.yml", {"TRAIN.NCH": 8, "DISC.SPEC_NORM": True}, 4, 1),                # ... under the MA-GP double backward
+    # real widths (NCH=32, BASELINE configs 1/2): 256/512-channel layers, so the streamed-weights halo kernel, the 8-wave gather
+    # tile and the row / all-taps weight-gradient kernels run under compare_grads, not only in the operator tests
+    ("df_gan_damsm_nomagp.yml", {}, 8, 1),
+    ("df_gan_damsm.yml", {}, 8, 1),
 ]
 
 
@@ -383,3 +387,39 @@ def test_word_attention_generator_gradients_match_f64_evaluation():
                 continue
             err = (p_.grad.double().cpu() - ref[n]).norm().item() / max(ref[n].norm().item(), 1e-5 * big)
             assert err < 1e-2, (seed, n, err)
+
+
+def test_make_labels_and_cosine_scores_match_reference_fixture():
+    """Product `make_labels` / `cosine_scores` (xmc_gan/train_gan.py, running on the HIP cosine-similarity kernel) on the inputs
+    of tests/golden/labels.npz, which the REFERENCE's make_labels / cosine_scores produced (train_gan.py:72-91): the 0/1/weight
+    pattern comes out of exact comparisons and must be bit-equal in all three label modes; scores within 1e-6."""
+    import numpy as np
+    from golden_util import load
+    import xmc_gan.train_gan as tg
+    fx = load("labels.npz")
+    sent, a, b = (torch.from_numpy(fx[k]).to(DEV) for k in ("sent", "a", "b"))
+    ops.set_precision("bf16")                      # label construction is f32 in either engine mode
+    cfg, _ = setup_cfg("df_gan_damsm.yml")
+    s = tg.cosine_scores(a, b)
+    assert s.dtype == torch.float32 and s.shape == (12, 12)
+    assert np.abs(s.cpu().numpy() - fx["scores"]).max() <= 1e-6
+    for tag, bg, sg in (("local", False, 0.0), ("adaptive", True, 0.0), ("smooth", True, 0.5)):
+        cfg.TRAIN.SMOOTH.GLOBAL = sg
+        labels = tg.make_labels(12, sent, bg)
+        assert labels.dtype == torch.float32 and not labels.requires_grad
+        assert np.array_equal(labels.cpu().numpy(), fx[f"labels_{tag}"]), tag
+        # and the losses the reference computed from them (sent_loss / img_loss share one body, train_gan.py:93-139)
+        for nm, fn in (("sent_loss", tg.sent_loss), ("img_loss", tg.img_loss)):
+            got = fn(a, b, labels, bg).item()
+            assert abs(got - fx[f"{nm}_{tag}"].item()) <= 1e-5 * abs(fx[f"{nm}_{tag}"].item()) + 1e-6, (nm, tag, got)
+    # thresholds sit on exact comparisons: a similarity well inside (0.6, 3) flips exactly the entries the oracle flips
+    g = torch.Generator().manual_seed(11)
+    base = torch.randn(5, 256, generator=g)
+    sent2 = base.repeat(8, 1)[:37] + 0.3 * torch.randn(37, 256, generator=g)
+    for sg in (0.0, 0.5):
+        cfg.TRAIN.SMOOTH.GLOBAL = sg
+        want = X.make_labels(37, sent2, True, sg)
+        got = tg.make_labels(37, sent2.to(DEV), True)
+        sim = X.cosine_scores(sent2, sent2)
+        assert (sim - 0.6).abs().min().item() > 1e-4           # no entry within rounding of the threshold
+        assert torch.equal(got.cpu(), want), sg

@@ -1,5 +1,6 @@
 """Adam on the multi-tensor HIP kernel (torch.optim.Adam semantics of train_gan.py:483-484: eps 1e-8, no weight
 decay, parameters whose ``.grad`` is None are skipped and keep their step count)."""
+import collections
 import ctypes as C
 
 import torch
@@ -13,21 +14,28 @@ class HipAdam(torch.optim.Optimizer):
         # weight_decay / amsgrad are carried (at the only values the path uses) so that state dicts interchange with
         # torch.optim.Adam's: the reference saves and resumes optimizerG.pth / optimizerD.pth (train_gan.py:331-332,492-493)
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False))
-        self._tables = {}
+        self._tables = collections.OrderedDict()      # (param ptr, grad ptr)* -> _Table, least recently used first
         self._chunk = None
-        self._arena, self._arena_off = None, 0
+        self._arenas, self._arena_off = [], 0         # pinned staging; never freed (a captured graph re-reads its slices)
+        self._free = {}                               # nbytes -> recycled pinned slices of evicted eager-mode tables
+
+    MAX_TABLES = 8     # eager-mode bound: a new (param, grad) address pattern beyond this evicts the least recently used one
 
     def _pinned(self, nbytes):
-        """slice of a pinned host arena that was allocated before any stream capture started"""
-        if self._arena is None or self._arena_off + nbytes > self._arena.numel():
+        """slice of a pinned host arena.  Arenas are only ever added (a hipGraph that captured the upload of a table replays
+        the copy FROM its pinned slice, so a slice that a capture has seen is never reused or freed), and only outside capture."""
+        free = self._free.get(nbytes)
+        if free:
+            return free.pop()
+        if not self._arenas or self._arena_off + nbytes > self._arenas[-1].numel():
             if torch.cuda.is_current_stream_capturing():
                 raise RuntimeError("HipAdam: pinned staging arena exhausted during graph capture; run a warm-up step first")
             total = sum(p.numel() for g in self.param_groups for p in g["params"])
             nparams = sum(len(g["params"]) for g in self.param_groups)
             per_table = 64 * nparams + 8 * (total // 4096 + nparams) + 256
-            self._arena = torch.empty(max(16 * per_table, nbytes), dtype=torch.uint8).pin_memory()
+            self._arenas.append(torch.empty(max(16 * per_table, nbytes), dtype=torch.uint8).pin_memory())
             self._arena_off = 0
-        out = self._arena[self._arena_off: self._arena_off + nbytes]
+        out = self._arenas[-1][self._arena_off: self._arena_off + nbytes]
         self._arena_off += nbytes
         return out
 
@@ -64,7 +72,8 @@ class HipAdam(torch.optim.Optimizer):
         key = tuple((p.data_ptr(), p.grad.data_ptr()) for p in ps)
         hit = self._tables.get(key)
         if hit is not None:
-            return hit
+            self._tables.move_to_end(key)
+            return hit[:4]
         if self._chunk is None:
             self._chunk = L.load().xmc_adam_chunk_elems()
         ents = (L.AdamEntry * len(ps))()
@@ -87,8 +96,22 @@ class HipAdam(torch.optim.Optimizer):
         ch_h[: len(chb)].copy_(torch.frombuffer(bytearray(chb), dtype=torch.uint8))
         tab = tab_h.to(device, non_blocking=True)
         ch = ch_h.to(device, non_blocking=True).view(torch.int32)
-        self._tables[key] = (tab, ch, len(ps), len(chunks))
-        return self._tables[key]
+        capturing = torch.cuda.is_current_stream_capturing()
+        self._tables[key] = (tab, ch, len(ps), len(chunks), tab_h, ch_h, capturing)
+        # Gradients are re-allocated by every backward; when their addresses move (allocator churn at epoch boundaries,
+        # evaluation, checkpointing) a new table is built.  Keep the working set bounded: evict the least recently used table
+        # that no graph capture has seen and recycle its pinned slices.
+        if len(self._tables) > self.MAX_TABLES and not capturing:
+            torch.cuda.current_stream().synchronize()      # rare; the evicted table's upload must be done before its slice is reused
+            for k in list(self._tables):
+                if len(self._tables) <= self.MAX_TABLES:
+                    break
+                ent = self._tables[k]
+                if k != key and not ent[6]:
+                    del self._tables[k]
+                    for h in (ent[4], ent[5]):
+                        self._free.setdefault(h.numel(), []).append(h)
+        return self._tables[key][:4]
 
     @torch.no_grad()
     def step(self, closure=None):

@@ -295,6 +295,9 @@ def train(train_loader, test_loader, state_epoch, text_encoder, netG, netD, opti
     for epoch in range(state_epoch + 1, cfg.TRAIN.MAX_EPOCH + 1):
         netG.train()
         netD.train()
+        sampler = getattr(train_loader, 'sampler', None)
+        if isinstance(sampler, torch.utils.data.distributed.DistributedSampler):
+            sampler.set_epoch(epoch)             # data parallel: a new permutation (and new per-rank shards) every epoch
         for step, data in enumerate(train_loader):
             imgs, texts_lst, keys = data
             caps, cap_lens = texts_lst[0]
