@@ -18,6 +18,8 @@ static inline int xmc_esz(int dtype) { return dtype == XMC_BF16 ? 2 : 4; }
 // name of the kernel the calling thread dispatched last (xmc_last_kernel(), used by bench.py's roofline to attribute
 // its per-launch HIP-event timings to the instantiation rocprof reports)
 void xmc_note_kernel(const char* fmt, ...);
+// true when `token` is listed in the XMC_DEBUG_DISPATCH environment variable (kernel A/B experiments; unset in production)
+bool xmc_debug_off(const char* token);
 
 // HIP errors are reported as -(1000 + code): positive 1 is taken by "not this kernel's case" in the *_try dispatch chain
 // (hipErrorInvalidValue == 1 once made a stale error look like "not eligible", and the next kernel in the chain ran as well).

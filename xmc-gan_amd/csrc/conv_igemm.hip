@@ -288,10 +288,10 @@ int launch(const XmcConvDesc& d, hipStream_t st) {
 
 template <int DT>
 int dispatch(const XmcConvDesc& d, hipStream_t st) {
-    static const int variant = getenv("XMC_IGEMM_VARIANT") ? atoi(getenv("XMC_IGEMM_VARIANT")) : 0;
+    static const int variant = xmc_debug_off("igemm128") ? 1 : 0;
     // batch-sized GEMMs (the conditioning MLPs: M = batch, K = N = 256): a 128-wide N tile leaves 4 workgroups on the
     // chip and each walks all of K alone; 32-wide tiles give 4x the workgroups and a 4x shorter critical path
-    static const bool no_small = getenv("XMC_NO_SMALL_M") != nullptr;
+    static const bool no_small = xmc_debug_off("no_small_m");
     if (!no_small && (int64_t)d.N * d.MH * d.MW <= 1024) return launch<DT, 128, 32, 4, 1, 2>(d, st);
     if (d.CDw % 128 == 0) {
         const int64_t M = (int64_t)d.N * d.MH * d.MW;
@@ -300,11 +300,11 @@ int dispatch(const XmcConvDesc& d, hipStream_t st) {
         // 128x128 structure measures 600-650 TF/s against a no-global-load ceiling of ~800 TF/s: LDS-read bound)
         // 256x256 tile, 8 waves of the same 128x64 patches: the A rows are shared by twice as many columns, 32 KB instead of
         // 48 KB through the vector-memory path per 2 x (256x128x32) MACs (that path bounds this kernel)
-        static const bool no_big = getenv("XMC_NO_IGEMM256") != nullptr;
+        static const bool no_big = xmc_debug_off("no_igemm256");
         if (DT == XMC_BF16 && M >= 256 * 256 && d.CDw % 256 == 0 && !no_big) return launch<DT, 256, 256, 2, 4, 2>(d, st);
         if (DT == XMC_BF16 && M >= 256 * 256) return launch<DT, 256, 128, 2, 2, 1>(d, st);
         // few output pixels (the 4x4 / 8x8 maps at the end of D, K = 4608-8192): 128-row tiles would leave half the CUs idle
-        static const bool no_m64 = getenv("XMC_NO_IGEMM_M64") != nullptr;
+        static const bool no_m64 = xmc_debug_off("no_igemm_m64");
         if (DT == XMC_BF16 && !no_m64 && (M + 127) / 128 * (d.CDw / 128) * d.nclass < 256) return launch<DT, 64, 128, 2, 2, 2>(d, st);
         return launch<DT, 128, 128, 2, 2, 2>(d, st);
     }
@@ -317,6 +317,7 @@ int dispatch(const XmcConvDesc& d, hipStream_t st) {
 int xmc_conv_tile_try(const XmcConvDesc* d, const float* const* pro, void* stream);   // conv_tile.hip
 int xmc_conv_thin_try(const XmcConvDesc* d, void* stream);                            // conv_thin.hip
 int xmc_conv_pw1x1_try(const XmcConvDesc* d, void* stream);                           // conv_thin.hip
+int xmc_conv_wtile_try(const XmcConvDesc* d, void* stream);                           // conv_wtile.hip
 
 extern "C" int xmc_conv_igemm(const XmcConvDesc* d, void* stream) {
     if (!d || !d->src || !d->wpk || !d->dst) return XMC_EINVAL;
@@ -332,12 +333,17 @@ extern "C" int xmc_conv_igemm(const XmcConvDesc* d, void* stream) {
         if ((d->MH - 1) * d->DA + d->dph[z] >= d->DH || (d->MW - 1) * d->DA + d->dpw[z] >= d->DW || d->dph[z] < 0 || d->dpw[z] < 0)
             return XMC_ESHAPE;
     if ((int64_t)d->N * d->MH * d->MW >= (1ll << 31)) return XMC_ESHAPE;
-    static const bool no_tile = getenv("XMC_NO_TILE") != nullptr;
+    static const bool no_tile = xmc_debug_off("no_tile");
     if (!no_tile) {                       // streaming kernel for 8-channel sources, halo-tile kernels for unit-stride bf16 layers
         int rc = xmc_conv_thin_try(d, stream);
         if (rc <= 0) return rc;
         rc = xmc_conv_pw1x1_try(d, stream);
         if (rc <= 0) return rc;
+        static const bool no_wt2 = xmc_debug_off("no_wtile_v2");
+        if (!no_wt2) {
+            rc = xmc_conv_wtile_try(d, stream);
+            if (rc <= 0) return rc;
+        }
         rc = xmc_conv_tile_try(d, nullptr, stream);
         if (rc <= 0) return rc;
     }

@@ -210,7 +210,7 @@ int launch_pw(const XmcConvDesc& d, int ngroups, hipStream_t st) {
 
 // 0 = launched, 1 = not this kernel's case, < 0 = error
 int xmc_conv_thin_try(const XmcConvDesc* d, void* stream) {
-    static const bool off = getenv("XMC_NO_THIN") != nullptr;
+    static const bool off = xmc_debug_off("no_thin");
     if (off) return 1;
     if (d->dtype != XMC_BF16 || d->out_dtype != XMC_BF16 || d->CS != 8) return 1;
     if (d->SA != 1 || d->DA != 1 || d->src_shift != 0 || d->nclass != 1 || d->ntaps > 12) return 1;
@@ -246,7 +246,7 @@ int xmc_conv_thin_try(const XmcConvDesc* d, void* stream) {
 
 // 0 = launched, 1 = not this kernel's case, < 0 = error
 int xmc_conv_pw1x1_try(const XmcConvDesc* d, void* stream) {
-    static const bool off = getenv("XMC_NO_PW1X1") != nullptr;
+    static const bool off = xmc_debug_off("no_pw1x1");
     if (off) return 1;
     if (d->dtype != XMC_BF16 || d->out_dtype != XMC_BF16) return 1;
     if (d->ntaps != 1 || d->nclass != 1 || d->SA != 1 || d->DA != 1 || d->src_shift != 0) return 1;

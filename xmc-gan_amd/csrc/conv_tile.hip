@@ -879,7 +879,7 @@ int launch_ptile(const XmcConvDesc& d, const TileCfg& t, hipStream_t st) {
     // all 4 output-parity classes from one staged patch when their 16 weight slices fit beside it
     if (d.nclass == 4 && d.ntaps == 4 && !t.pro[0] && t.PHu * t.PWu <= 384) {
         const size_t ldsm = (size_t)((t.PHu * t.PWu * pstride + 15) & ~15) + (size_t)16 * BN * pstride;
-        static const bool no_merge = getenv("XMC_NO_CLASS_MERGE") != nullptr;
+        static const bool no_merge = xmc_debug_off("no_class_merge");
         if (ldsm <= XMC_MAX_DYN_LDS && !no_merge) {
             int gm = 256 / (int)(d.CDw / BN);
             if (gm > ntiles) gm = ntiles;
@@ -957,12 +957,12 @@ int launch_wtile(const XmcConvDesc& d, const TileCfg& t, hipStream_t st) {
 // Returns 1 if the descriptor is eligible for the halo-tile kernel (and fills cfg), 0 otherwise.
 static int tile_plan(const XmcConvDesc* d, TileCfg* t) {
     if (d->dtype != XMC_BF16 || d->src_shift != 0) return 0;
-    static const bool no_s2 = getenv("XMC_NO_PTILE_S2") != nullptr;
+    static const bool no_s2 = xmc_debug_off("no_ptile_s2");
     const bool s2 = d->SA == 2;                       // stride-2 forward: weights-resident persistent kernel only
     if (d->SA != 1 && !(s2 && !no_s2 && d->nclass == 1 && d->ntaps == 16 && d->CS == 32 && d->CDw <= 64 && d->DA == 1)) return 0;
     if (d->CS % 32 != 0 || d->MW % 16 != 0) return 0;
     if (d->ntaps < 2) return 0;                       // 1x1: nothing to reuse, the gather kernel streams it
-    static const bool no_wt = getenv("XMC_NO_WTILE2") != nullptr;
+    static const bool no_wt = xmc_debug_off("no_wtile2");
     const bool wide = d->CDw > 64 && d->CS > 64;
     if (wide && (no_wt || d->CDw % 128 != 0 || d->CS % 64 != 0 || d->nclass != 1 || d->ntaps != 9)) return 0;   // gather kernel (the 4-class 2x2-tap form measured no faster: one patch per class)
     int TW = (d->MW >= 32 && !s2) ? 32 : 16;
@@ -1007,7 +1007,7 @@ int xmc_conv_tile_try(const XmcConvDesc* d, const float* const* pro, void* strea
         rc = launch_wtile(*d, t, st);
         return rc == XMC_ESHAPE ? 1 : rc;
     }
-    static const bool no_pt = getenv("XMC_NO_PTILE") != nullptr;
+    static const bool no_pt = xmc_debug_off("no_ptile");
     if (!no_pt && d->CS <= 64 && t.slab == d->CS && d->CDw <= 64) {          // persistent, weights resident
         rc = d->CDw == 64 ? launch_ptile<64>(*d, t, st) : launch_ptile<32>(*d, t, st);
         if (rc != XMC_ESHAPE) return rc;

@@ -216,7 +216,7 @@ int dispatch(const XmcConvDesc& d, float* dwp, float* dbias, hipStream_t st) {
     constexpr int KPB = DT == XMC_BF16 ? 64 : 32;     // pixels per K step for the big tiles
     // batch-sized reductions (the conditioning MLPs: 256 "pixels"): small tiles so that the few K steps are spread
     // over 64+ workgroups instead of 16
-    static const bool no_small = getenv("XMC_NO_SMALL_M") != nullptr;
+    static const bool no_small = xmc_debug_off("no_small_m");
     if (!no_small && (int64_t)d.N * d.MH * d.MW <= 1024)
         return wide_ci ? launch<DT, 32, 64, 1, 4, 32>(d, dwp, dbias, st) : launch<DT, 32, 32, 2, 2, 32>(d, dwp, dbias, st);
     if (d.CDw % 128 == 0) {

@@ -230,7 +230,7 @@ int launch_row(const XmcConvDesc& d, const RowCfg& t, float* dwp, float* dbias, 
 
 // 0 = launched, 1 = not this kernel's case, < 0 = error
 int xmc_conv_wgrad_row_try(const XmcConvDesc* d, float* dwp, float* dbias, void* stream) {
-    static const bool off = getenv("XMC_NO_WROW") != nullptr;
+    static const bool off = xmc_debug_off("no_wrow");
     if (off) return 1;
     if (d->dtype != XMC_BF16 || (d->src_shift != 0 && d->SA != 1)) return 1;
     if (d->CS % 128 != 0 || d->CD % 128 != 0 || d->CDw != d->CD) return 1;

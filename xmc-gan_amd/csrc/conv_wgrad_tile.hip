@@ -212,12 +212,12 @@ int launch_wt(const XmcConvDesc& d, float* dwp, float* dbias, const WTCfg& t, hi
 
 // 0 = launched, 1 = not eligible (caller falls back to the generic kernel), other = error
 int xmc_conv_wgrad_tile_try(const XmcConvDesc* d, float* dwp, float* dbias, void* stream) {
-    static const bool off = getenv("XMC_NO_WTILE") != nullptr;
+    static const bool off = xmc_debug_off("no_wtile");
     if (off) return 1;
     if (d->dtype != XMC_BF16 || d->src_shift < 0 || d->src_shift > 1) return 1;
     const bool s2 = d->SA == 2;                               // 4x4 stride-2 layers: 16 taps, no upsample, Cin <= 32 (patch size)
     if (d->SA != 1 && !(s2 && d->ntaps == 16 && d->src_shift == 0 && d->CS <= 32)) return 1;
-    static const bool no_wide = getenv("XMC_NO_WT_WIDE") != nullptr;
+    static const bool no_wide = xmc_debug_off("no_wt_wide");
     const bool wide = d->CD > 64 || d->CS > 64;              // 64-channel blocks over grid.y / grid.z
     if (wide && (no_wide || s2 || (d->CD > 64 && d->CD % 64) || (d->CS > 64 && d->CS % 64))) return 1;
     if (d->ntaps > (s2 ? 16 : 9) || d->ntaps < 1) return 1;
@@ -246,7 +246,7 @@ int xmc_conv_wgrad_tile_try(const XmcConvDesc* d, float* dwp, float* dbias, void
     // (4,4) = 64x64 channels with 4 waves needs 144 accumulator + 76 staging registers per lane and measured slower than
     // the split-K kernel (166 vs 230 TF/s); it runs with 8 waves instead (below)
     WT_CASE(1, 2) WT_CASE(1, 4) WT_CASE(2, 1) WT_CASE(2, 2) WT_CASE(2, 4) WT_CASE(4, 1) WT_CASE(4, 2)
-    static const bool no44 = getenv("XMC_NO_WT44") != nullptr;
+    static const bool no44 = xmc_debug_off("no_wt44");
     if (nco == 4 && nci == 4 && !no44) return launch_wt<4, 4, 512, 1, 9, 4>(*d, dwp, dbias, t, st);   // all 4 Cout blocks per wave: 0.9 LDS reads per MFMA   // 8 waves: 72 accumulator registers per lane
 #undef WT_CASE
     return 1;

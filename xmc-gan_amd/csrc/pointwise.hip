@@ -1,6 +1,8 @@
 // HBM-bound pointwise / small-reduction kernels (NHWC, 8-channel vectors, 16-byte accesses).
 // Each cites the reference op it replaces in include/xmc_gan_hip.h.
 #include "common.h"
+#include <stdlib.h>
+#include <string.h>
 #include <cstdarg>
 #include <cstdio>
 
@@ -582,6 +584,17 @@ void xmc_note_kernel(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* xmc_last_kernel(void) { return g_last_kernel; }
+
+// One debugging switch for the kernel dispatchers: XMC_DEBUG_DISPATCH="tok1,tok2,..." disables the named specialised kernels
+// (the dispatcher then falls through to the next, more general one).  Unset in production: every call returns false.
+bool xmc_debug_off(const char* token) {
+    static const char* env = getenv("XMC_DEBUG_DISPATCH");
+    if (!env || !*env) return false;
+    const size_t n = strlen(token);
+    for (const char* p = env; (p = strstr(p, token)) != nullptr; p += n)
+        if ((p == env || p[-1] == ',') && (p[n] == 0 || p[n] == ',')) return true;
+    return false;
+}
 
 extern "C" int xmc_lrelu(const void* x, void* y, int64_t n, float slope, int dtype, void* s) { return run_map1(x, y, n, dtype, ST(s), FLrelu{slope}); }
 extern "C" int xmc_tanh(const void* x, void* y, int64_t n, int dtype, void* s) { return run_map1(x, y, n, dtype, ST(s), FTanh{}); }

@@ -64,6 +64,8 @@ def nhwc_feature_perm(channels, hw=16):
 
 
 class NetG(nn.Module):
+    nhwc_out = True       # forward(..., return_nhwc=True) -> (image NCHW f32, the same image in the engine layout)
+
     def __init__(self, cfg, **kwargs):
         super(NetG, self).__init__()
         self.ngf = cfg.TRAIN.NCH
@@ -88,14 +90,17 @@ class NetG(nn.Module):
         out = self.proj_noise(noise.float(), out_dtype=ops.act_dtype())
         return out.view(noise.size(0), 4, 4, 8 * self.ngf)
 
-    def tail(self, out, lrelu_done=False):
-        """LeakyReLU -> Conv3x3(->3) -> Tanh (reference df_gan.py:84-88,101); tanh fused in the conv epilogue."""
+    def tail(self, out, lrelu_done=False, return_nhwc=False):
+        """LeakyReLU -> Conv3x3(->3) -> Tanh (reference df_gan.py:84-88,101); tanh fused in the conv epilogue.
+        ``return_nhwc``: also hand out the engine-layout image [B,S,S,8] the NCHW f32 result was converted from, so a
+        discriminator call on this image (``netD(fake, nhwc8=...)``) skips the NHWC->NCHW->NHWC round trip in both directions."""
         if not lrelu_done:
             out = ops.lrelu(out)
         out = self.conv_out[1](out, act=ACT_TANH)
-        return ops.to_nchw(out, 3)
+        img = ops.to_nchw(out, 3)
+        return (img, out) if return_nhwc else img
 
-    def forward(self, noise, sent_embs, **kwargs):
+    def forward(self, noise, sent_embs, return_nhwc=False, **kwargs):
         out = self.stem(noise)
         sent_embs = self.proj_sent(sent_embs.float())
         # The 8 conditioning MLPs of every block depend only on the sentence embedding: all of them (40-56 two-layer MLPs)
@@ -136,7 +141,7 @@ class NetG(nn.Module):
                 out, pending_up = ops.upsample2(out), False
         if pending_up:
             out = ops.upsample2(out)
-        return self.tail(out, lrelu_done)
+        return self.tail(out, lrelu_done, return_nhwc)
 
 
 class NetD(nn.Module):
@@ -152,9 +157,10 @@ class NetD(nn.Module):
                   downsample=arch['downsample'][i], spec_norm=spec_norm) for i in range(1, arch['depth'])])
         self.COND_DNET = D_GET_LOGITS(cfg, ndf=ndf, spec_norm=spec_norm)
 
-    def forward(self, x, **kwargs):
-        """x: [B,3,S,S] f32 image -> [B,16*ndf,4,4] feature map (channels-last view)."""
-        out = self.conv_img(ops.to_nhwc8(x))
+    def forward(self, x, nhwc8=None, **kwargs):
+        """x: [B,3,S,S] f32 image -> [B,16*ndf,4,4] feature map (channels-last view).  ``nhwc8``: the same image already in
+        the engine layout [B,S,S,8] (``ops.to_nhwc8(x)`` or NetG's ``return_nhwc`` output); ``x`` is then not read."""
+        out = self.conv_img(ops.to_nhwc8(x) if nhwc8 is None else nhwc8)
         for block in self.downblocks:
             out = block(out)
         return as_nchw_view(out)

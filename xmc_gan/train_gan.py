@@ -137,19 +137,45 @@ def gan_iteration(netG, netD, optimizerG, optimizerD, imgs, sent_embs, words_emb
 
     # ---- discriminator step (train_gan.py:187-229)
     psent_embs = sent_embs if cfg.DISC.SEPERATE else netG.proj_sent(sent_embs.float())
-    real_features = netD(imgs)
-    outputs_real = netD.COND_DNET(real_features, sent_embs=psent_embs.detach())
-    errD_real = ops.hinge(outputs_real[0], -1.0)
-    fake = netG(noise=noise, sent_embs=sent_embs, words_embs=words_embs, mask=mask)
-    fake_features = netD(fake.detach())
-    outputs_fake = netD.COND_DNET(fake_features, sent_embs=psent_embs.detach())
-    errD_fake = ops.hinge(outputs_fake[0], 1.0)
-    mis_loss = errD_fake
-    if T.RMIS_LOSS:
-        outputs_mis = netD.COND_DNET(real_features[:(batch_size - 1)], sent_embs=psent_embs[1:batch_size].detach())
-        errD_mismatch = ops.hinge(outputs_mis[0], 1.0)
-        mis_loss = mis_loss + errD_mismatch
-        out['errD_mismatch'] = errD_mismatch.detach()
+    nhwc_g = bool(getattr(netG, 'nhwc_out', False))             # generator can hand out its image in the engine layout
+    if nhwc_g:
+        fake, fake_h = netG(noise=noise, sent_embs=sent_embs, words_embs=words_embs, mask=mask, return_nhwc=True)
+    else:
+        fake, fake_h = netG(noise=noise, sent_embs=sent_embs, words_embs=words_embs, mask=mask), None
+    imgs_h = ops.to_nhwc8(imgs) if isinstance(netD, DF_DISC) else None      # converted once, used by both steps
+    # The discriminator does not couple the samples of a batch, so its passes over the real and the generated images
+    # (193, 202) run as ONE pass over 2B images and the three COND_DNET calls (194, 203, 208) as one over 3B-1 rows: same
+    # values, half the launches, twice the work per launch on the small maps at the end of D.  Not with spectral norm: there
+    # every forward CALL advances the power iteration (modules.py:16-17), so the call pattern is part of the result.
+    if imgs_h is not None and fake_h is not None and not cfg.DISC.SPEC_NORM and ops.fused_blocks():
+        B = batch_size
+        feats = netD(None, nhwc8=torch.cat((imgs_h, fake_h.detach())))
+        real_features, fake_features = feats[:B], feats[B:]
+        ps_d = psent_embs.detach()
+        rows = [feats, real_features[:B - 1]] if T.RMIS_LOSS else [feats]
+        sents = [ps_d, ps_d, ps_d[1:B]] if T.RMIS_LOSS else [ps_d, ps_d]
+        o_all = netD.COND_DNET(torch.cat(rows) if T.RMIS_LOSS else feats, sent_embs=torch.cat(sents))
+        outputs_real = [o[:B] for o in o_all]
+        errD_real = ops.hinge(o_all[0][:B], -1.0)
+        errD_fake = ops.hinge(o_all[0][B:2 * B], 1.0)
+        mis_loss = errD_fake
+        if T.RMIS_LOSS:
+            errD_mismatch = ops.hinge(o_all[0][2 * B:], 1.0)
+            mis_loss = mis_loss + errD_mismatch
+            out['errD_mismatch'] = errD_mismatch.detach()
+    else:
+        real_features = netD(imgs, nhwc8=imgs_h) if imgs_h is not None else netD(imgs)
+        outputs_real = netD.COND_DNET(real_features, sent_embs=psent_embs.detach())
+        errD_real = ops.hinge(outputs_real[0], -1.0)
+        fake_features = netD(fake.detach(), nhwc8=fake_h.detach()) if fake_h is not None and imgs_h is not None else netD(fake.detach())
+        outputs_fake = netD.COND_DNET(fake_features, sent_embs=psent_embs.detach())
+        errD_fake = ops.hinge(outputs_fake[0], 1.0)
+        mis_loss = errD_fake
+        if T.RMIS_LOSS:
+            outputs_mis = netD.COND_DNET(real_features[:(batch_size - 1)], sent_embs=psent_embs[1:batch_size].detach())
+            errD_mismatch = ops.hinge(outputs_mis[0], 1.0)
+            mis_loss = mis_loss + errD_mismatch
+            out['errD_mismatch'] = errD_mismatch.detach()
     labels = None
     if E.SENT or E.WORD or E.DISC or E.VGG:
         labels = make_labels(batch_size * (parallel.world() if opts.gather_negatives else 1),
@@ -203,7 +229,7 @@ def gan_iteration(netG, netD, optimizerG, optimizerD, imgs, sent_embs, words_emb
     if it_state['i'] % T.N_CRITIC == 0:
         _set_requires_grad(netD, False)          # D's weight grads would be discarded (zero_grad at 226-227)
         try:
-            features = netD(fake)
+            features = netD(fake, nhwc8=fake_h) if fake_h is not None and imgs_h is not None else netD(fake)
             outputs = netD.COND_DNET(features, sent_embs=psent_embs)
             errG_fake = -outputs[0].float().mean()
             enc_loss = 0.0
@@ -215,7 +241,8 @@ def gan_iteration(netG, netD, optimizerG, optimizerD, imgs, sent_embs, words_emb
                 raise NotImplementedError
             if E.DISC:
                 with torch.no_grad():
-                    real_pooled = ops.global_avgpool(netD(imgs).permute(0, 2, 3, 1).contiguous())
+                    real_again = netD(imgs, nhwc8=imgs_h) if imgs_h is not None else netD(imgs)
+                    real_pooled = ops.global_avgpool(real_again.permute(0, 2, 3, 1).contiguous())
                 fake_pooled = ops.global_avgpool(features.permute(0, 2, 3, 1).contiguous())
                 disc_loss = img_loss(real_imgs=gather(real_pooled), fake_imgs=gather(fake_pooled), labels=labels,
                                      b_global=E.B_GLOBAL)
