@@ -29,6 +29,71 @@ CARD, PW, SD = 16, 8, 4  # cardinality, bottleneck width p, state dim p' (df_con
 
 
 # ----------------------------------------------------------------------------------------
+# quantisation-aware mode (checks the engine's bf16 path)
+# ----------------------------------------------------------------------------------------
+# The reference computes in fp32 throughout.  The MI355X engine's default mode stores every activation tensor and the packed
+# convolution weights in bf16 (f32 accumulation, f32 parameters / gradients of parameters / reductions).  With `quant(True)`
+# the SAME restatement rounds to bf16 at exactly those storage points -- forward values where the engine writes an activation,
+# gradient values where it writes a gradient tensor, convolution weights where it packs them (straight-through for the weight
+# gradient, which the engine accumulates in f32) -- and keeps all arithmetic in f32.  What then remains between this oracle and
+# the engine is summation order, i.e. kernel error proper, which separates it from the error of the number format.
+# Covers DF_GEN + DF_DISC (the benched path); the mode is off unless a test turns it on, the goldens never see it.
+_QUANT = False
+
+
+class quant:
+    """context manager / switch: `with X.quant(True): ...`"""
+
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        global _QUANT
+        self.prev, _QUANT = _QUANT, self.on
+        return self
+
+    def __exit__(self, *a):
+        global _QUANT
+        _QUANT = self.prev
+
+
+def _bf16(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+class _QAct(torch.autograd.Function):
+    """an activation tensor as the engine stores it: value and gradient both rounded to bf16"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return _bf16(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _bf16(g)
+
+
+class _QWeight(torch.autograd.Function):
+    """a packed convolution weight: rounded for the forward / data-gradient kernels, f32 weight gradient passed through"""
+
+    @staticmethod
+    def forward(ctx, w):
+        return _bf16(w)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def q(x):
+    return _QAct.apply(x) if _QUANT else x
+
+
+def qw(w):
+    return _QWeight.apply(w) if _QUANT else w
+
+
+# ----------------------------------------------------------------------------------------
 # hyper-parameters
 # ----------------------------------------------------------------------------------------
 @dataclass
@@ -367,6 +432,8 @@ def _affine(P, p, x, c):
 
 def _g_block(P, p, x, c, upsample):
     """G_Block.forward (df_gan.py:199-224)."""
+    if _QUANT:
+        return _g_block_q(P, p, x, c, upsample)
     hdn = F.leaky_relu(_affine(P, f"{p}.affine0", x, c), LRELU)
     hdn = F.leaky_relu(_affine(P, f"{p}.affine1", hdn, c), LRELU)
     hdn = F.conv2d(hdn, P[f"{p}.c1.weight"], P[f"{p}.c1.bias"], 1, 1)
@@ -380,6 +447,49 @@ def _g_block(P, p, x, c, upsample):
     return out
 
 
+def _upconv3x3_q(x_lo, w, b):
+    """conv3x3(nearest_up2(x_lo), w) + b the way the engine evaluates it: per output parity (i, j) a 2x2-tap convolution on the
+    LOW-resolution tensor whose weights are sums of the 3x3 taps that read the same low-resolution pixel, summed in f32 and
+    rounded to bf16 once (the same function as the reference's interpolate -> conv; only the weight rounding differs)."""
+    B, C, H, W = x_lo.shape
+    out = x_lo.new_zeros(B, w.size(0), 2 * H, 2 * W)
+    rows = {0: ((0, 0), (1, 2)), 1: ((0, 1), (2, 2))}          # parity -> (kh range of th=0, kh range of th=1)
+    parts = []
+    for i in (0, 1):
+        for j in (0, 1):
+            taps = []
+            for th in (0, 1):
+                for tw in (0, 1):
+                    (h0, h1), (w0, w1) = rows[i][th], rows[j][tw]
+                    taps.append(w[:, :, h0:h1 + 1, w0:w1 + 1].sum(dim=(2, 3)))
+            wc = qw(torch.stack(taps, dim=2).view(w.size(0), C, 2, 2))
+            xp = F.pad(x_lo, (1 - j, j, 1 - i, i))              # rows a-1..a (i=0) or a..a+1 (i=1), same for columns
+            parts.append((i, j, F.conv2d(xp, wc)))
+    out = torch.stack([torch.stack([parts[0][2], parts[1][2]], dim=-1), torch.stack([parts[2][2], parts[3][2]], dim=-1)], dim=-3)
+    out = out.reshape(B, w.size(0), 2 * H, 2 * W)               # [B,Co,H,2(i),W,2(j)] -> [B,Co,2H,2W]
+    return out + b[None, :, None, None]
+
+
+def _g_block_q(P, p, x, c, upsample, x_is_lo=False):
+    """G_Block with the engine's storage points: one bf16 rounding after each affine-affine-LeakyReLU pass, after each
+    convolution, after the 1x1 shortcut and after the block sum; `x_is_lo`: x is the previous block's output BEFORE its nearest
+    upsample (the engine never writes the upsampled tensor; affines and the 1x1 shortcut commute with it, c1 runs as the fused
+    upsample convolution)."""
+    hdn = F.leaky_relu(_affine(P, f"{p}.affine0", x, c), LRELU)
+    hdn = q(F.leaky_relu(_affine(P, f"{p}.affine1", hdn, c), LRELU))
+    if x_is_lo:
+        hdn = q(_upconv3x3_q(hdn, P[f"{p}.c1.weight"], P[f"{p}.c1.bias"]))
+    else:
+        hdn = q(F.conv2d(hdn, qw(P[f"{p}.c1.weight"]), P[f"{p}.c1.bias"], 1, 1))
+    hdn = F.leaky_relu(_affine(P, f"{p}.affine2", hdn, c), LRELU)
+    hdn = q(F.leaky_relu(_affine(P, f"{p}.affine3", hdn, c), LRELU))
+    res = q(F.conv2d(hdn, qw(P[f"{p}.c2.weight"]), P[f"{p}.c2.bias"], 1, 1))
+    sc = q(F.conv2d(x, qw(P[f"{p}.c_sc.weight"]), P[f"{p}.c_sc.bias"])) if f"{p}.c_sc.weight" in P else x
+    if x_is_lo:
+        sc = F.interpolate(sc, scale_factor=2)
+    return sc, res            # the caller forms sc + gamma * res (the last block fuses the tail's LeakyReLU into that pass)
+
+
 def proj_sent(P, sent):
     """netG.proj_sent: Linear(E->NEF) or Identity (df_gan.py:74-75)."""
     if "proj_sent.weight" in P:
@@ -388,19 +498,33 @@ def proj_sent(P, sent):
 
 
 def _stem(P, h: Hyper, noise):
-    out = F.linear(noise, P["proj_noise.weight"], P["proj_noise.bias"])
+    out = q(F.linear(noise, P["proj_noise.weight"], P["proj_noise.bias"]))      # f32 GEMM in the engine, stored as activation
     return out.view(out.size(0), 8 * h.nch, 4, 4)
 
 
-def _tail(P, x):
+def _tail(P, x, lrelu_done=False):
     """conv_out = LeakyReLU -> Conv3x3(->3) -> Tanh (df_gan.py:84-88)."""
-    return torch.tanh(F.conv2d(F.leaky_relu(x, LRELU), P["conv_out.1.weight"], P["conv_out.1.bias"], 1, 1))
+    if not lrelu_done:
+        x = q(F.leaky_relu(x, LRELU))
+    return q(torch.tanh(F.conv2d(x, qw(P["conv_out.1.weight"]), P["conv_out.1.bias"], 1, 1)))
 
 
 def netg_forward(P, h: Hyper, noise, sent_embs, **_):
     a = gen_arch(h.img_size, h.nch)
     out = _stem(P, h, noise)
     c = proj_sent(P, sent_embs)
+    if _QUANT:
+        lo = False
+        for i in range(a["depth"]):
+            p = f"upblocks.{i}"
+            sc, res = _g_block_q(P, p, out, c, a["upsample"][i], x_is_lo=lo)
+            out = sc + P[f"{p}.gamma"] * res
+            last = i == a["depth"] - 1 and not a["upsample"][i]
+            out = q(F.leaky_relu(out, LRELU)) if last else q(out)
+            lo = a["upsample"][i]
+        if lo:
+            out = F.interpolate(out, scale_factor=2)
+        return _tail(P, out, lrelu_done=last)
     for i in range(a["depth"]):
         out = _g_block(P, f"upblocks.{i}", out, c, a["upsample"][i])
     return _tail(P, out)
@@ -648,6 +772,8 @@ def sn_weight(P, name, train=True, eps=1e-12):
 
 def netd_forward(P, h: Hyper, x):
     a = disc_arch(h.img_size, h.nch)
+    if _QUANT:
+        return _netd_forward_q(P, h, x, a)
     out = F.conv2d(x, sn_weight(P, "conv_img.weight"), P["conv_img.bias"], 1, 1)
     for i in range(1, a["depth"]):
         p = f"downblocks.{i - 1}"
@@ -661,6 +787,21 @@ def netd_forward(P, h: Hyper, x):
     return out
 
 
+def _netd_forward_q(P, h: Hyper, x, a):
+    """DF_DISC with the engine's storage points (image, every convolution output, the pooled shortcut input, the block sum) and
+    its order on the shortcut: average pool first, then the 1x1 convolution (they commute; df_gan.py:286-291)."""
+    out = q(F.conv2d(q(x), qw(sn_weight(P, "conv_img.weight")), P["conv_img.bias"], 1, 1))
+    for i in range(1, a["depth"]):
+        p = f"downblocks.{i - 1}"
+        r = q(F.leaky_relu(F.conv2d(out, qw(sn_weight(P, f"{p}.conv_r.0.weight")), None, 2, 1), LRELU))
+        r = q(F.leaky_relu(F.conv2d(r, qw(sn_weight(P, f"{p}.conv_r.2.weight")), None, 1, 1), LRELU))
+        s = q(F.avg_pool2d(out, 2))
+        if a["cin"][i] != a["cout"][i]:
+            s = q(F.conv2d(s, qw(sn_weight(P, f"{p}.conv_s.weight")), P[f"{p}.conv_s.bias"]))
+        out = q(s + P[f"{p}.gamma"] * r)
+    return out
+
+
 def cond_dnet(P, h: Hyper, feat, sent_embs):
     """D_GET_LOGITS.forward (df_gan.py:162-176) -> [logit[B,1,1,1], img_emb, txt_emb]."""
     B = feat.size(0)
@@ -670,10 +811,10 @@ def cond_dnet(P, h: Hyper, feat, sent_embs):
         out = F.linear(out, sn_weight(P, "COND_DNET.proj_match.weight"), P["COND_DNET.proj_match.bias"])
     elif has_proj:
         sent_embs = F.linear(sent_embs, sn_weight(P, "COND_DNET.proj_match.weight"), P["COND_DNET.proj_match.bias"])
-    c = sent_embs.view(B, -1, 1, 1).repeat(1, 1, 4, 4)
+    c = q(sent_embs).view(B, -1, 1, 1).repeat(1, 1, 4, 4)        # engine: the condition joins the bf16 feature map
     hc = torch.cat((feat, c), 1)
-    m = F.leaky_relu(F.conv2d(hc, sn_weight(P, "COND_DNET.joint_conv.0.weight"), None, 1, 1), LRELU)
-    m = F.conv2d(m, sn_weight(P, "COND_DNET.joint_conv.2.weight"))
+    m = q(F.leaky_relu(F.conv2d(hc, qw(sn_weight(P, "COND_DNET.joint_conv.0.weight")), None, 1, 1), LRELU))
+    m = F.conv2d(m, qw(sn_weight(P, "COND_DNET.joint_conv.2.weight")))         # the logit itself leaves the engine in f32
     return [m, out, sent_embs]
 
 

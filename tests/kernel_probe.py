@@ -29,9 +29,12 @@ def run(spec):
         OH = geom.out_hw(H, H)[0]
     dy = torch.randn(N, OH, OH, ops.pad_to(cout, 8), generator=g).to("cuda", bf)
 
+    clk = os.environ.get("XMC_PROBE_CLOCK")      # ablation libraries built with WT_ABL & 32 write (cycles, 100 MHz ticks) per
+    dbg = torch.zeros(1 << 16, dtype=torch.float32, device="cuda") if clk else None   # workgroup into the bias pointer
+
     def once():
         if mode == "fwd":
-            return ops._conv_fwd_raw(x, w, None, geom, 0, bf)
+            return ops._conv_fwd_raw(x, w, dbg, geom, 0, bf)
         if mode == "dgrad":
             return ops._conv_dgrad_raw(dy, w, geom, (H, H), bf)
         if mode == "wgrad":
@@ -56,7 +59,14 @@ def run(spec):
         torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1) / reps)
     fl = 2.0 * N * OH * OH * cin * cout * k * k
-    print(f"{mode:7s} N{N} {H}x{H} {cin}->{cout} k{k}s{s}: {best:7.3f} ms {fl / best / 1e9:7.1f} TF/s  [{kern}]", flush=True)
+    extra = ""
+    if clk:
+        v = dbg.view(torch.int64)[:512].cpu().view(-1, 2)
+        v = v[(v[:, 1] > 0)]
+        if len(v):
+            mhz = (v[:, 0].double() / v[:, 1].double() * 100.0)
+            extra = f"  clock {mhz.median().item():.0f} MHz (min {mhz.min().item():.0f}, max {mhz.max().item():.0f}; {len(v)} wgs, {v[:,0].double().median().item():.0f} cycles)"
+    print(f"{mode:7s} N{N} {H}x{H} {cin}->{cout} k{k}s{s}: {best:7.3f} ms {fl / best / 1e9:7.1f} TF/s  [{kern}]{extra}", flush=True)
 
 
 if __name__ == "__main__":

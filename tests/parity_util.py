@@ -75,7 +75,13 @@ def run_product_steps(h, PG, PD, batches, eps=1e-8):
     return netG, netD, outs, tapG, tapD
 
 
-def run_oracle_steps(h, PG, PD, batches, eps=1e-8):
+def run_oracle_steps(h, PG, PD, batches, eps=1e-8, quant=False):
+    """`quant`: the oracle's quantisation-aware mode (bf16 rounding at the engine's storage points, f32 arithmetic)."""
+    with X.quant(quant):
+        return _run_oracle_steps(h, PG, PD, batches, eps)
+
+
+def _run_oracle_steps(h, PG, PD, batches, eps):
     PG = {k: v.clone() for k, v in PG.items()}
     PD = {k: v.clone() for k, v in PD.items()}
     optG, optD = X.AdamState(h.g_lr, h.g_betas, eps), X.AdamState(h.d_lr, h.d_betas, eps)

@@ -322,7 +322,8 @@ def test_bench_gpus_n_without_launcher_starts_n_ranks():
     if torch.cuda.is_available():
         pytest.skip("covered by the GPU rehearsal")
     assert r.returncode != 0
-    assert r.stderr.count("needs an MI355X") >= 2, r.stderr[-2000:]
+    # (torchrun tears the other rank down as soon as the first one has failed, so one message is guaranteed, two are not)
+    assert "needs an MI355X" in r.stderr and "torch.distributed" in r.stderr, r.stderr[-2000:]
     # and a mismatching launcher is refused instead of being ignored
     env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], env=env2, capture_output=True, text=True,

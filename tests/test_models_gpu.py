@@ -1,13 +1,17 @@
 """GPU parity of the module API (NetG / NetD / COND_DNET) and of whole G+D iterations against the CPU oracle,
 on the oracle's synthetic parameters and COCO-shaped batches.
 
-Tolerances: fp32 mode (f32 MFMA, exact products) -> logits/losses within 1e-3 relative (north-star bar; measured
-~1e-6) and every gradient tensor within 5e-3 relative L2 (measured <= 3e-4).  bf16 mode (bf16 weights and
-activations, f32 accumulate) is compared with the SAME f32 oracle, so the figures include the quantisation of every
-weight and activation through ~25 layers of an untrained, batch-4 network: losses within 5e-2 (measured <= 2.6e-2);
-gradients: all tensors of a backward taken as one vector within 0.3 relative L2 (measured <= 0.21), each single tensor within 1.0 (measured
-per tensor: D <= 0.25, G <= 0.36 on small tensors, with run-to-run variation because f32 atomics order changes bf16
-roundings downstream)."""
+Tolerances.  fp32 mode (f32 MFMA, exact products): logits/losses within 1e-3 relative (north-star bar; measured ~1e-6) and
+every gradient tensor within 5e-3 relative L2 (measured <= 3e-4).
+
+bf16 mode (the benched mode: bf16 activations + packed conv weights, f32 accumulate, f32 parameters) is checked twice:
+  * against the oracle's QUANTISATION-AWARE mode (`X.quant`: the same f32 restatement, rounding to bf16 exactly where the
+    engine stores a tensor), which separates KERNEL error from the error of the number format (DF_GEN + DF_DISC, the benched
+    path): layer by layer the engine reproduces it bit for bit in >= 99 % of the elements (test_bf16_blocks_...); what is
+    left after ~25 layers of an untrained, high-gain network is the amplification of those rare one-ulp differences: QTOL;
+  * against the plain f32 oracle, which measures the format itself: losses within 5e-2 (measured <= 2.6e-2), all gradient
+    tensors of a backward as one vector within 0.3 (measured <= 0.21), single tensors within 0.5.  These figures are the stated
+    cost of bf16 storage, not a kernel tolerance."""
 import copy
 
 import pytest
@@ -21,7 +25,11 @@ if torch.cuda.is_available():
     from parity_util import (DEV, build_product, compare_grads, compare_losses, mean_abs_err, rel_err, run_oracle_steps,
                              run_product_steps, setup_cfg)
 
-TOL = {"fp32": dict(fwd=1e-3, loss=1e-3, grad=5e-3, latol=1e-4, agg=2e-3), "bf16": dict(fwd=3e-2, loss=5e-2, grad=1.0, latol=1e-2, agg=0.3)}
+TOL = {"fp32": dict(fwd=1e-3, loss=1e-3, grad=5e-3, latol=1e-4, agg=2e-3), "bf16": dict(fwd=3e-2, loss=5e-2, grad=0.5, latol=1e-2, agg=0.3)}
+# bf16 engine vs the quantisation-aware oracle (first iteration, identical weights on both sides)
+# measured on MI355X: losses <= 5.6e-3 (terms near zero: 8e-4 absolute), image 1.4e-4 .. 2.0e-3 mean abs, gradient tensors
+# D <= 4.4e-2, G <= 1.9e-1 (worst single tensor), MA-GP <= 7.7e-2
+QTOL = dict(fwd=4e-3, loss=1e-2, latol=2e-3, grad=0.25, agg=8e-2)
 # Adam eps used in the multi-phase parity runs: with the presets' beta1=0 the very first update is
 # lr*g/(|g|+eps), i.e. +-lr for ANY non-zero g, so a rounding-level sign difference in a near-zero gradient moves
 # that weight by 2*lr and the later phases (MA-GP, G step, next iteration) then differ at the 1e-2 level for reasons
@@ -112,6 +120,17 @@ def test_train_iteration_parity(yml, over, batch, steps, mode):
             b["sent_embs"][4] = b["sent_embs"][3] + 0.05 * b["sent_embs"][4]
     _, _, o_outs = run_oracle_steps(h, PG, PD, batches, eps=PARITY_EPS)
     netG, netD, p_outs, tapG, tapD = run_product_steps(h, PG, PD, batches, eps=PARITY_EPS)
+    if mode == "bf16" and h.gen == "DF_GEN" and not h.spec_norm:
+        # kernel error proper: first iteration against the oracle that rounds where the engine rounds
+        _, _, q_outs = run_oracle_steps(h, PG, PD, batches[:1], eps=PARITY_EPS, quant=True)
+        ql = compare_losses(p_outs[0], q_outs[0], QTOL["loss"], QTOL["latol"])
+        qf = mean_abs_err(p_outs[0]["fake"], q_outs[0]["fake"])
+        assert qf <= QTOL["fwd"], qf
+        qd = compare_grads(tapD.records[0], q_outs[0]["grads_D"], QTOL["grad"], "quant D ", 2e-2, QTOL["agg"])
+        qg = compare_grads(tapG.records[0], q_outs[0]["grads_G"], QTOL["grad"], "quant G ", 2e-2, QTOL["agg"]) if "grads_G" in q_outs[0] else 0.0
+        # second-order term: the rounding points of the double backward are only approximately those of the engine
+        qgp = compare_grads(tapD.records[1], q_outs[0]["grads_GP"], QTOL["grad"], "quant GP ", 2e-2, 2 * QTOL["agg"]) if h.magp else 0.0
+        print(f"\n[bf16 vs quantisation-aware oracle {yml} {over}] loss={ql:.2e} image={qf:.2e} D={qd:.2e} GP={qgp:.2e} G={qg:.2e}")
     t = TOL[mode]
     gi = di = 0
     worst = dict(loss=0.0, D=0.0, GP=0.0, G=0.0)
@@ -423,3 +442,52 @@ def test_make_labels_and_cosine_scores_match_reference_fixture():
         sim = X.cosine_scores(sent2, sent2)
         assert (sim - 0.6).abs().min().item() > 1e-4           # no entry within rounding of the threshold
         assert torch.equal(got.cpu(), want), sg
+
+
+def test_bf16_blocks_reproduce_quantisation_aware_oracle():
+    """Kernel error separated from format error, layer by layer: given the SAME bf16 input, every discriminator stage of the
+    bf16 engine must reproduce the quantisation-aware oracle (f32 arithmetic, bf16 rounding where the engine stores a tensor)
+    bit for bit in >= 99 % of the output elements (measured 99.6 .. 100 %: the fraction falls with the length of the sums, K up to 8192) and within a few bf16 ulps in the rest (pre-rounding values that sit within
+    f32 summation-order noise of a rounding boundary: one ulp per rounded term of the block sum, plus what a flipped element of the
+    intermediate activation moves through the second convolution; measured: 2 ulps).  Real widths (NCH=32, 64 px): the streamed-weights halo kernel,
+    the stride-2 space-to-depth form, the weights-resident tile kernel and the gather kernel are all on this path."""
+    import torch.nn.functional as F
+    ops.set_precision("bf16")
+    cfg, h = setup_cfg("df_gan_damsm_nomagp.yml")
+    PG, PD = X.synth_params(X.gen_shapes(h), 5), X.synth_params(X.netd_shapes(h), 6)
+    b = X.synth_batch(h, 4, seed=200, words_len=cfg.TEXT.MAX_LENGTH)
+    netG, netD, _, _ = build_product(h, PG, PD)
+    a = X.disc_arch(h.img_size, h.nch)
+
+    def check(got_nhwc, want_nchw, what, mag=None):
+        got = got_nhwc.permute(0, 3, 1, 2).float().cpu()[:, : want_nchw.size(1)]
+        same = (got == want_nchw).float().mean().item()
+        # one unit in the last place of bf16 (8 significant bits) at the magnitude of the LARGEST rounded operand of the element:
+        # a block output is shortcut + gamma * residual, and one ulp of either term is many ulps of a sum that nearly cancels
+        mag = want_nchw.abs() if mag is None else torch.maximum(want_nchw.abs(), mag)
+        ulp = (mag.clamp_min(1e-30).log2().floor() - 7).exp2()
+        worst = ((got - want_nchw).abs() / ulp).max().item()
+        assert same >= 0.99 and worst <= 4.0, (what, same, worst)
+        return same
+
+    with torch.no_grad(), X.quant(True):
+        x = b["imgs"]
+        out = X.q(F.conv2d(X.q(x), X.qw(PD["conv_img.weight"]), PD["conv_img.bias"], 1, 1))
+        fr = [check(netD.conv_img(ops.to_nhwc8(x.to(DEV))), out, "conv_img")]
+        for i, blk in enumerate(netD.downblocks):
+            p = f"downblocks.{i}"
+            xin = out
+            r = X.q(F.leaky_relu(F.conv2d(xin, X.qw(PD[f"{p}.conv_r.0.weight"]), None, 2, 1), 0.2))
+            r = X.q(F.leaky_relu(F.conv2d(r, X.qw(PD[f"{p}.conv_r.2.weight"]), None, 1, 1), 0.2))
+            sc = X.q(F.avg_pool2d(xin, 2))
+            if a["cin"][i + 1] != a["cout"][i + 1]:
+                sc = X.q(F.conv2d(sc, X.qw(PD[f"{p}.conv_s.weight"]), PD[f"{p}.conv_s.bias"]))
+            out = X.q(sc + PD[f"{p}.gamma"] * r)
+            got = blk(xin.permute(0, 2, 3, 1).contiguous().to(DEV, torch.bfloat16))
+            fr.append(check(got, out, p, torch.maximum(sc.abs(), (PD[f"{p}.gamma"] * r).abs())))
+        # the generator as a whole (no per-stage hook): image within 3e-3 mean abs of the quantisation-aware oracle
+        fq = X.gen_forward(PG, h, b["noise"], b["sent_embs"])
+        fp = netG(noise=b["noise"].to(DEV), sent_embs=b["sent_embs"].to(DEV))
+        assert mean_abs_err(fp, fq) < 3e-3, mean_abs_err(fp, fq)
+    print("\n[bf16 blocks vs quantisation-aware oracle] bit-equal fraction per stage: " + ", ".join(f"{v:.5f}" for v in fr),
+          f"; generator image mean abs err {mean_abs_err(fp, fq):.2e}")

@@ -207,7 +207,7 @@ class D_GET_LOGITS(nn.Module):
         c = c.view(B, 1, 1, -1).expand(B, xh.size(1), xh.size(2), c.size(-1))
         h_c_code = torch.cat((xh, c), 3)
         m = self.joint_conv[0](h_c_code, act=ACT_LRELU)
-        m = self.joint_conv[2](m)                                  # [B,1,1,8], channel 0 is the logit
+        m = self.joint_conv[2](m, out_dtype=torch.float32)         # [B,1,1,8] f32, channel 0 is the logit (losses are f32)
         match = as_nchw_view(m[..., :1])
         return [match, out, sent_embs]
 
