@@ -199,15 +199,30 @@ def main():
     def eager(imgs, sent, words, mask, noise, st):
         return tg.gan_iteration(netG, netD, optG, optD, imgs, sent, words, mask, noise, st, opts)
 
-    use_graph = (world == 1) if a.graph < 0 else bool(a.graph)
+    # hipGraph replay for any number of ranks: the collectives are eager seams between captured segments (xmc_gan_amd/graph.py)
+    use_graph = True if a.graph < 0 else bool(a.graph)
     graphed = None
     if use_graph:
         from xmc_gan_amd.graph import GraphedIteration
         d0 = data[0]
-        graphed = GraphedIteration(eager, (d0["imgs"], d0["sent"], d0["words"], d0["mask"], d0["noise"]),
-                                   n_critic=cfg.TRAIN.N_CRITIC, warmup=2)
-        for i in range(3):                       # 2 eager warm-ups + the capture itself, outside the timed region
-            graphed(d0["imgs"], d0["sent"], d0["words"], d0["mask"], d0["noise"])
+        ok = 1
+        try:
+            graphed = GraphedIteration(eager, (d0["imgs"], d0["sent"], d0["words"], d0["mask"], d0["noise"]),
+                                       n_critic=cfg.TRAIN.N_CRITIC, warmup=2)
+            for i in range(3):                   # 2 eager warm-ups + the capture itself, outside the timed region
+                graphed(d0["imgs"], d0["sent"], d0["words"], d0["mask"], d0["noise"])
+            torch.cuda.synchronize()
+        except Exception as e:                   # noqa: BLE001 -- any capture problem: every rank falls back together
+            import traceback
+            print(f"[bench rank {rank}] graph capture failed ({type(e).__name__}: {e}); running eager\n"
+                  + "".join(traceback.format_exc().splitlines(True)[-12:]), file=sys.stderr)
+            ok = 0
+        if world > 1:
+            flag = torch.tensor([ok], device=dev, dtype=torch.int32)
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+            ok = int(flag.item())
+        if not ok:
+            graphed, use_graph = None, False
 
     def step(i, force_eager=False):
         d = data[i % nb]

@@ -8,6 +8,7 @@ torch.distributed.run, see below).  Checks SURVEY.md 8e's contract on the GPU pa
   B.  --gather_negatives (all-gathered contrastive rows): the 2-rank iteration == ONE single-process iteration on the
       concatenated batch, contrastive losses included (RMIS_LOSS off: that term couples neighbours inside a local batch only
       and is the documented difference).
+  C.  three iterations replayed as hipGraph segments with the collectives as eager seams == three eager iterations.
 
     XMC_DIST_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 \
         --master-port 29511 tests/dp_rehearsal.py [--out profiles/r02_dp2_rehearsal.json]
@@ -106,6 +107,35 @@ def main():
             report["cases"][name] = res
             assert all(v <= 2e-3 for v in res.values()), (name, res)
         dist.barrier()
+    # C. the captured form (graph segments with the collectives as eager seams, xmc_gan_amd/graph.py) == the eager form:
+    #    three iterations of the gathered-negatives configuration each way, same shards, weights compared afterwards
+    from parity_util import DEV, build_product
+    from xmc_gan_amd.graph import GraphedIteration
+    cfg, h = setup_cfg("df_gan_damsm_nomagp.yml", **{"TRAIN.NCH": a.nch})
+    PG, PD = X.synth_params(X.gen_shapes(h), 5), X.synth_params(X.netd_shapes(h), 6)
+    batches = []
+    for i in range(3):
+        full = X.synth_batch(h, a.batch * world, seed=400 + i, words_len=cfg.TEXT.MAX_LENGTH)
+        batches.append([full[k][rank * a.batch:(rank + 1) * a.batch].to(DEV) for k in ("imgs", "sent_embs", "words_embs", "mask", "noise")])
+    finals = []
+    for graphed in (False, True):
+        netG, netD, optG, optD = build_product(h, PG, PD, 1e-3)
+        opts = tg.StepOptions(gather_negatives=True)
+        fn = lambda i_, s_, w_, m_, n_, st: tg.gan_iteration(netG, netD, optG, optD, i_, s_, w_, m_, n_, st, opts)
+        runner = GraphedIteration(fn, batches[0], n_critic=cfg.TRAIN.N_CRITIC, warmup=1) if graphed else None
+        st = {}
+        for b_ in batches:
+            o = runner(*b_) if graphed else fn(*b_, st)
+        torch.cuda.synchronize()
+        W = {"G." + k: v.detach().float().cpu().clone() for k, v in netG.state_dict().items()}
+        W.update({"D." + k: v.detach().float().cpu().clone() for k, v in netD.state_dict().items()})
+        finals.append((W, {k: float(v) for k, v in o.items() if k != "fake"}))
+    if rank == 0:
+        res = dict(weights_after_3_iterations=worst_rel(finals[1][0], finals[0][0]),
+                   losses_of_iteration_3=max(abs(finals[1][1][k] - finals[0][1][k]) / (abs(finals[0][1][k]) + 1e-6) for k in finals[0][1]))
+        report["cases"]["C_graph_segments_equal_eager"] = res
+        assert all(v <= 2e-3 for v in res.values()), res
+    dist.barrier()
     if rank == 0:
         print(json.dumps(report))
         if a.out:

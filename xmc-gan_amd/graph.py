@@ -1,22 +1,36 @@
-"""hipGraph replay of the whole G+D iteration.
+"""hipGraph replay of the whole G+D iteration, with eager seams for the collectives.
 
-The iteration enqueues ~1.5k short kernels; launched eagerly from Python the host becomes the bottleneck
-(~55 ms per iteration regardless of batch).  Everything the step does is stream-ordered and free of host
-synchronisation (kernels take device scalars for gamma / loss seeds, Adam keeps its step counters on the
-device), so one iteration can be captured into a hipGraph once and replayed with new inputs copied into
-static buffers.  Capture goes through ``torch.cuda.graph`` so PyTorch's caching allocator hands every
-intermediate tensor a graph-private, replay-stable address.
+The iteration enqueues ~1 k short kernels; launched eagerly from Python the host becomes the bottleneck (~55 ms per iteration
+regardless of batch).  Everything the step does is stream-ordered and free of host synchronisation (kernels take device scalars
+for gamma / loss seeds, Adam keeps its step counters on the device), so it can be captured once and replayed with new inputs
+copied into static buffers.  PyTorch's caching allocator hands every intermediate tensor a graph-private, replay-stable address.
+
+Data parallel: a collective cannot live inside the capture (gloo has no device-side form, and an RCCL launch inside a graph
+ties the replay to one communicator state), so the iteration is captured as a SEQUENCE of graphs that share one memory pool,
+cut at every collective: `seam(fn)` ends the running capture, runs `fn` (the all-reduce / all-gather on tensors that live in
+the pool, hence at fixed addresses) eagerly on the same stream, and opens the next capture.  A replay launches the graphs and
+calls the recorded collectives in the recorded order: 3-4 graph launches and 2-3 collective calls of host work per iteration
+instead of ~1 k kernel launches, for any number of ranks.
 """
 import torch
 
 from . import ops
+
+_active = None          # the GraphedIteration whose capture is running (collectives consult it through seam())
+
+
+def seam(fn):
+    """Run the collective ``fn()`` now; under capture: between two graphs, and again at every replay."""
+    if _active is None:
+        return fn()
+    return _active._seam(fn)
 
 
 class GraphedIteration:
     """Callable with the signature of ``xmc_gan.train_gan.gan_iteration`` minus the modules.
 
     ``fn(imgs, sent_embs, words_embs, mask, noise) -> dict of 0-d loss tensors`` is captured after
-    ``warmup`` eager iterations (which also populate the weight-pack / Adam-table caches).  One graph per
+    ``warmup`` eager iterations (which also populate the weight-pack / Adam-table caches).  One sequence per
     N_CRITIC phase (whether the G step runs) is kept.
     """
 
@@ -24,14 +38,72 @@ class GraphedIteration:
         self.step_fn = step_fn
         self.n_critic = max(1, int(n_critic))
         self.static_in = [t.clone() for t in example_inputs]
-        self.graphs = {}
+        self.seqs = {}          # phase -> [callable, ...]  (graph.replay and collectives, in order)
         self.static_out = {}
         self.it_state = {}
         self.warmup_left = warmup
         self.pool = None
+        self.stream = None
+        self._graphs = []       # keep the CUDAGraph objects alive
+        self._cur = None
+        self._seq = None
 
     def _phase(self):
         return (self.it_state.get('i', 0) + 1) % self.n_critic == 0
+
+    # ---- capture plumbing (what torch.cuda.graph does, split so that a capture can be ended and re-opened)
+    def _begin(self):
+        g = torch.cuda.CUDAGraph()
+        if self.pool is None:
+            self.pool = torch.cuda.graph_pool_handle()
+        g.capture_begin(pool=self.pool)
+        self._cur = g
+
+    def _end(self):
+        self._cur.capture_end()
+        self._graphs.append(self._cur)
+        self._seq.append(self._cur.replay)
+        self._cur = None
+
+    def _seam(self, fn):
+        def eager():                 # replays run outside the autograd context the collective was first issued in
+            with torch.no_grad():
+                return fn()
+        self._end()
+        out = eager()
+        self._seq.append(eager)
+        self._begin()
+        return out
+
+    def _capture(self, phase):
+        global _active
+        import gc
+        torch.cuda.synchronize()
+        gc.collect()
+        if self.stream is None:
+            self.stream = torch.cuda.Stream()
+        self.stream.wait_stream(torch.cuda.current_stream())
+        state = dict(self.it_state)
+        self._seq = []
+        with torch.cuda.stream(self.stream):
+            _active = self
+            try:
+                self._begin()
+                out = self.step_fn(*self.static_in, state)
+                self._end()
+            finally:
+                _active = None
+                if self._cur is not None:           # an exception inside the step: leave capture mode before it propagates
+                    try:
+                        self._cur.capture_end()
+                    except Exception:
+                        pass
+                    self._cur = None
+        torch.cuda.current_stream().wait_stream(self.stream)
+        self.seqs[phase] = self._seq
+        self.static_out[phase] = out
+        self._seq = None
+        ops.bump_weights_epoch()        # packed-weight cache entries now live in graph-private memory
 
     def __call__(self, *inputs):
         for s, t in zip(self.static_in, inputs):
@@ -41,17 +113,10 @@ class GraphedIteration:
             self.warmup_left -= 1
             return self.step_fn(*self.static_in, self.it_state)
         phase = self._phase()
-        if phase not in self.graphs:
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            state = dict(self.it_state)
-            with torch.cuda.graph(g, pool=self.pool):
-                out = self.step_fn(*self.static_in, state)
-            self.pool = g.pool()
-            self.graphs[phase] = g
-            self.static_out[phase] = out
-            ops.bump_weights_epoch()        # packed-weight cache entries now live in graph-private memory
-        self.graphs[phase].replay()
+        if phase not in self.seqs:
+            self._capture(phase)
+        for item in self.seqs[phase]:
+            item()
         i = self.it_state.get('i', 0) + 1
         self.it_state['i'] = 0 if i % self.n_critic == 0 else i
         return self.static_out[phase]
