@@ -78,6 +78,19 @@ typedef struct XmcConvDesc {
     const void* mask;
     float res_scale;
     int32_t res_mode;
+    /* Second and third outputs of the epilogue (optional), so that a residual block is ONE pass over its last convolution
+     * instead of conv + axpby + pool (df_gan.py:284-291: `shortcut + gamma * residual`, then the next block pools its input):
+     *  dst2     : dst layout+dtype; receives act(acc + bias), i.e. the value BEFORE alpha / mask / residual -- the residual
+     *             branch the backward pass needs (LeakyReLU' mask and d(gamma) = <dout, residual>) while dst gets the block sum.
+     *  dst_pool : [N, DH/2, DW/2, CD], dst dtype; receives the 2x2 average of the final dst values (rounded to the dst dtype
+     *             first, so it equals F.avg_pool2d of dst).  Needs DA == 1, one class and even DH, DW.
+     *  res_mode 2: the residual is [N, DH/2, DW/2, CD] and dst pixel (y, x) reads residual pixel (y/2, x/2): nearest x2
+     *             upsample of the generator block's shortcut folded into c2's epilogue (df_gan.py:200-202). */
+    void* dst2;
+    void* dst_pool;
+    /* round_act != 0 (implied by dst2): act(acc + bias) is rounded to the dst dtype before alpha / mask / residual, so that a
+     * fused block sum equals, bit for bit, the unfused sequence that stores the residual branch first. */
+    int32_t round_act;
 } XmcConvDesc;
 
 int xmc_abi_version(void);

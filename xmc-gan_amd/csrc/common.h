@@ -90,9 +90,19 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-// Shared tail of the convolution epilogues: LeakyReLU' mask, (scaled, possibly row-indexed) residual, store.
+// Shared tail of the convolution epilogues: second output, alpha, LeakyReLU' mask, (scaled, possibly re-indexed) residual, store.
+// v holds act(acc + bias).
 template <int ODT>
-__device__ __forceinline__ void epilogue_tail(const XmcConvDesc& d, size_t idx8, size_t ridx8, float (&v)[8]) {
+__device__ __forceinline__ void epilogue_tail(const XmcConvDesc& d, size_t idx8, size_t ridx8, float (&v)[8], float alpha) {
+    if (d.dst2) Vec8<ODT>::store(d.dst2, idx8, v);
+    if (ODT == XMC_BF16 && (d.dst2 || d.round_act)) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (float)(__bf16)v[k];
+    }
+    if (d.alpha_dev) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] *= alpha;
+    }
     if (d.mask) {
         float mk[8];
         Vec8<ODT>::load(d.mask, idx8, mk);
@@ -107,4 +117,12 @@ __device__ __forceinline__ void epilogue_tail(const XmcConvDesc& d, size_t idx8,
         for (int k = 0; k < 8; ++k) v[k] += rs * rr[k];
     }
     Vec8<ODT>::store(d.dst, idx8, v);
+}
+
+// residual index (in 8-channel units) of destination pixel (n, y, x) for the three residual layouts; (a, b) is the pixel's
+// position in the [MH, MW] GEMM grid
+__device__ __forceinline__ size_t res_index8(const XmcConvDesc& d, size_t idx8, int n, int y, int x, int a, int b, int ch8) {
+    if (d.res_mode == 0) return idx8;
+    if (d.res_mode == 1) return ((size_t)(n * d.MH + a) * d.MW + b) * (d.CD >> 3) + ch8;
+    return ((size_t)(n * (d.DH >> 1) + (y >> 1)) * (d.DW >> 1) + (x >> 1)) * (d.CD >> 3) + ch8;
 }

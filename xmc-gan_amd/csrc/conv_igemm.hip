@@ -261,11 +261,9 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const XmcConvDesc d
 #pragma unroll
                 for (int k = 0; k < 8; ++k) v[k] = tanhf(v[k]);
             }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] *= alpha;
-            const size_t ridx8 = d.res_mode ? ((size_t)m * d.CD + ch) >> 3 : idx8;
-            if (d.out_dtype == XMC_BF16) epilogue_tail<XMC_BF16>(d, idx8, ridx8, v);
-            else epilogue_tail<XMC_F32>(d, idx8, ridx8, v);
+            const size_t ridx8 = res_index8(d, idx8, n, a * d.DA + dph, b * d.DA + dpw, a, b, ch >> 3);
+            if (d.out_dtype == XMC_BF16) epilogue_tail<XMC_BF16>(d, idx8, ridx8, v, alpha);
+            else epilogue_tail<XMC_F32>(d, idx8, ridx8, v, alpha);
         }
     }
 }
@@ -318,6 +316,7 @@ int xmc_conv_tile_try(const XmcConvDesc* d, const float* const* pro, void* strea
 int xmc_conv_thin_try(const XmcConvDesc* d, void* stream);                            // conv_thin.hip
 int xmc_conv_pw1x1_try(const XmcConvDesc* d, void* stream);                           // conv_thin.hip
 int xmc_conv_wtile_try(const XmcConvDesc* d, void* stream);                           // conv_wtile.hip
+int xmc_conv_ptile_pool_try(const XmcConvDesc* d, void* stream);                      // conv_tile.hip
 
 extern "C" int xmc_conv_igemm(const XmcConvDesc* d, void* stream) {
     if (!d || !d->src || !d->wpk || !d->dst) return XMC_EINVAL;
@@ -333,20 +332,30 @@ extern "C" int xmc_conv_igemm(const XmcConvDesc* d, void* stream) {
         if ((d->MH - 1) * d->DA + d->dph[z] >= d->DH || (d->MW - 1) * d->DA + d->dpw[z] >= d->DW || d->dph[z] < 0 || d->dpw[z] < 0)
             return XMC_ESHAPE;
     if ((int64_t)d->N * d->MH * d->MW >= (1ll << 31)) return XMC_ESHAPE;
+    if (d->dst_pool && (d->DA != 1 || d->nclass != 1 || (d->DH & 1) || (d->DW & 1) || d->out_dtype != d->dtype)) return XMC_ESHAPE;
+    if (d->res_mode < 0 || d->res_mode > 2 || (d->res_mode == 2 && (d->DA != 1 || (d->DH & 1) || (d->DW & 1)))) return XMC_ESHAPE;
     static const bool no_tile = xmc_debug_off("no_tile");
-    if (!no_tile) {                       // streaming kernel for 8-channel sources, halo-tile kernels for unit-stride bf16 layers
-        int rc = xmc_conv_thin_try(d, stream);
-        if (rc <= 0) return rc;
-        rc = xmc_conv_pw1x1_try(d, stream);
-        if (rc <= 0) return rc;
-        static const bool no_wt2 = xmc_debug_off("no_wtile_v2");
-        if (!no_wt2) {
-            rc = xmc_conv_wtile_try(d, stream);
-            if (rc <= 0) return rc;
-        }
-        rc = xmc_conv_tile_try(d, nullptr, stream);
+    static const bool no_wt2 = xmc_debug_off("no_wtile_v2");
+    int rc = 1;
+    if (!no_tile && d->dst_pool) {        // kernels that write the pooled third output from their epilogue
+        if (!no_wt2) rc = xmc_conv_wtile_try(d, stream);
+        if (rc > 0) rc = xmc_conv_ptile_pool_try(d, stream);
         if (rc <= 0) return rc;
     }
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    return d->dtype == XMC_BF16 ? dispatch<XMC_BF16>(*d, st) : dispatch<XMC_F32>(*d, st);
+    XmcConvDesc dd = *d;                  // every other kernel: plain launch, then the pool as its own pass
+    dd.dst_pool = nullptr;
+    if (!no_tile) {                       // streaming kernel for 8-channel sources, halo-tile kernels for unit-stride bf16 layers
+        rc = xmc_conv_thin_try(&dd, stream);
+        if (rc > 0) rc = xmc_conv_pw1x1_try(&dd, stream);
+        if (rc > 0 && !no_wt2) rc = xmc_conv_wtile_try(&dd, stream);
+        if (rc > 0) rc = xmc_conv_tile_try(&dd, nullptr, stream);
+        if (rc < 0) return rc;
+    }
+    if (rc > 0) {
+        hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+        rc = dd.dtype == XMC_BF16 ? dispatch<XMC_BF16>(dd, st) : dispatch<XMC_F32>(dd, st);
+        if (rc != 0) return rc;
+    }
+    if (d->dst_pool) return xmc_sumpool2(d->dst, d->dst_pool, d->N, d->DH, d->DW, d->CD, 0.25f, d->out_dtype, stream);
+    return 0;
 }

@@ -222,12 +222,9 @@ __global__ __launch_bounds__(256) void tile_kernel(const XmcConvDesc d, const Ti
 #pragma unroll
                 for (int k = 0; k < 8; ++k) v[k] = tanhf(v[k]);
             }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] *= alpha;
-            // row-indexed residual: pixel (a0+ty, b0+tx) of the [N,MH,MW,CD] grid
-            const size_t ridx8 = d.res_mode ? (size_t)((((img * d.MH + a0 + ty) * d.MW) + b0 + tx) * (d.CD >> 3) + ((n0 >> 3) + cc)) : idx8;
-            if (d.out_dtype == XMC_BF16) epilogue_tail<XMC_BF16>(d, idx8, ridx8, v);
-            else epilogue_tail<XMC_F32>(d, idx8, ridx8, v);
+            const size_t ridx8 = res_index8(d, idx8, img, (a0 + ty) * d.DA + dph, (b0 + tx) * d.DA + dpw, a0 + ty, b0 + tx, (n0 >> 3) + cc);
+            if (d.out_dtype == XMC_BF16) epilogue_tail<XMC_BF16>(d, idx8, ridx8, v, alpha);
+            else epilogue_tail<XMC_F32>(d, idx8, ridx8, v, alpha);
         }
     }
 }
@@ -407,7 +404,7 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
 #pragma unroll
             for (int c = 0; c < 8; ++c) bias8[u][c] = (d.bias && ch0 + u * 32 < d.CD) ? d.bias[ch0 + u * 32 + c] : 0.f;
         // one uniform decision instead of a chain of branches per stored unit
-        const bool fast = d.out_dtype == XMC_BF16 && d.res == nullptr && d.mask == nullptr && d.alpha_dev == nullptr &&
+        const bool fast = d.out_dtype == XMC_BF16 && d.res == nullptr && d.mask == nullptr && d.alpha_dev == nullptr && d.dst2 == nullptr && d.dst_pool == nullptr &&
                           (d.act == XMC_ACT_NONE || d.act == XMC_ACT_LRELU || d.act == XMC_ACT_TANH);
         const bool do_tanh = d.act == XMC_ACT_TANH;
         const float slope = d.act == XMC_ACT_LRELU ? XMC_LRELU : 1.f;
@@ -525,10 +522,28 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
                 }
             } else {
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+                for (int u = 0; u < UPL; ++u) {
+                    if (ch0 + u * 32 >= d.CD) continue;
+                    float fin[TM][8];
+                    // bf16: mask / residual vectors of the whole unit are requested before the first is used (one memory latency
+                    // per unit instead of one per vector)
+                    const bool pre = d.out_dtype == XMC_BF16;
+                    bf16x8 mkv[TM], rrv[TM];
+                    size_t rix[TM];
 #pragma unroll
-                    for (int u = 0; u < UPL; ++u) {
-                        if (ch0 + u * 32 >= d.CD) continue;
+                    for (int i = 0; i < TM; ++i) {
+                        const size_t idx8 = (size_t)(dbase + eoff[i] + u * 4);
+                        rix[i] = d.res_mode == 1 ? (size_t)(rbase + roff[i] + u * 4) : idx8;
+                        if (d.res_mode == 2) {
+                            const int ml_ = wm * (16 * TM) + i * 16 + fr;
+                            const int y_ = (a0 + (ml_ >> t.log2TW)) * d.DA + dph, x_ = (b0 + (ml_ & (t.TW - 1))) * d.DA + dpw;
+                            rix[i] = res_index8(d, idx8, img, y_, x_, 0, 0, (n0 >> 3) + fc + u * 4);
+                        }
+                        if (pre && d.mask) mkv[i] = reinterpret_cast<const bf16x8*>(d.mask)[idx8];
+                        if (pre && d.res) rrv[i] = reinterpret_cast<const bf16x8*>(d.res)[rix[i]];
+                    }
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
                         const size_t idx8 = (size_t)(dbase + eoff[i] + u * 4);
                         float v[8];
 #pragma unroll
@@ -543,14 +558,58 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
 #pragma unroll
                             for (int q = 0; q < 8; ++q) v[q] = tanhf(v[q]);
                         }
-                        if (d.alpha_dev) {
+                        if (pre) {      // epilogue_tail<XMC_BF16> with the loads hoisted
+                            bf16x8* __restrict__ dst8 = reinterpret_cast<bf16x8*>(d.dst);
+                            if (d.dst2 || d.round_act) {
+                                bf16x8 o2;
 #pragma unroll
-                            for (int q = 0; q < 8; ++q) v[q] *= alpha;
+                                for (int q = 0; q < 8; ++q) { o2[q] = (__bf16)v[q]; v[q] = (float)o2[q]; }
+                                if (d.dst2) reinterpret_cast<bf16x8*>(d.dst2)[idx8] = o2;
+                            }
+                            if (d.alpha_dev) {
+#pragma unroll
+                                for (int q = 0; q < 8; ++q) v[q] *= alpha;
+                            }
+                            if (d.mask) {
+#pragma unroll
+                                for (int q = 0; q < 8; ++q) v[q] *= lrelu_slope((float)mkv[i][q]);
+                            }
+                            if (d.res) {
+                                const float rs = d.res_scale == 0.f ? 1.f : d.res_scale;
+#pragma unroll
+                                for (int q = 0; q < 8; ++q) v[q] += rs * (float)rrv[i][q];
+                            }
+                            bf16x8 o;
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) { o[q] = (__bf16)v[q]; fin[i][q] = (float)o[q]; }
+                            dst8[idx8] = o;
+                        } else {
+                            epilogue_tail<XMC_F32>(d, idx8, rix[i], v, alpha);
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) fin[i][q] = v[q];
                         }
-                        const size_t ridx8 = d.res_mode ? (size_t)(rbase + roff[i] + u * 4) : idx8;
-                        if (d.out_dtype == XMC_BF16) epilogue_tail<XMC_BF16>(d, idx8, ridx8, v);
-                        else epilogue_tail<XMC_F32>(d, idx8, ridx8, v);
                     }
+                    if (SA == 1 && MC == 1 && TM == 4 && d.dst_pool) {
+                        // third output: 2x2 average of the rounded block output (the launcher admits it for bf16, DA == 1 only).
+                        // Vertical neighbour = pixel block i+2 (8x32 tiles) / i+1 (16x16 tiles) of this lane, horizontal = lane ^ 1.
+                        bf16x8* __restrict__ pool8 = reinterpret_cast<bf16x8*>(d.dst_pool);
+#pragma unroll
+                        for (int pr = 0; pr < 2; ++pr) {
+                            const int i0 = t.log2TW == 5 ? pr : 2 * pr;
+                            const int ml_ = wm * 64 + i0 * 16 + fr;
+                            const int ty_ = ml_ >> t.log2TW, tx_ = ml_ & (t.TW - 1);
+                            bf16x8 o;
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) {
+                                float sm = t.log2TW == 5 ? fin[pr][q] + fin[(pr + 2) % TM][q] : fin[(2 * pr) % TM][q] + fin[(2 * pr + 1) % TM][q];
+                                sm += __shfl_xor(sm, 1, 64);
+                                o[q] = (__bf16)(0.25f * sm);
+                            }
+                            if ((fr & 1) == 0)
+                                pool8[((img * (d.DH >> 1) + ((a0 + ty_) >> 1)) * (d.DW >> 1) + ((b0 + tx_) >> 1)) * cd8 + (n0 >> 3) + fc + u * 4] = o;
+                        }
+                    }
+                }
             }
           }
         }
@@ -785,13 +844,10 @@ __global__ __launch_bounds__(512) void wtile_kernel(const XmcConvDesc d, const T
 #pragma unroll
                         for (int q = 0; q < 8; ++q) v[q] = tanhf(v[q]);
                     }
-                    if (d.alpha_dev) {
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) v[q] *= alpha;
-                    }
-                    const size_t ridx8 = d.res_mode ? (size_t)(rbase + ro + u * 4) : idx8;
-                    if (d.out_dtype == XMC_BF16) epilogue_tail<XMC_BF16>(d, idx8, ridx8, v);
-                    else epilogue_tail<XMC_F32>(d, idx8, ridx8, v);
+                    size_t ridx8 = d.res_mode == 1 ? (size_t)(rbase + ro + u * 4) : idx8;
+                    if (d.res_mode == 2) ridx8 = res_index8(d, idx8, img, (a0 + ty) * d.DA + d.dph[cls], (b0 + tx) * d.DA + d.dpw[cls], 0, 0, (n0 >> 3) + fc + u * 4);
+                    if (d.out_dtype == XMC_BF16) epilogue_tail<XMC_BF16>(d, idx8, ridx8, v, alpha);
+                    else epilogue_tail<XMC_F32>(d, idx8, ridx8, v, alpha);
                 }
             }
 #pragma unroll
@@ -993,6 +1049,17 @@ static int tile_plan(const XmcConvDesc* d, TileCfg* t) {
     }
     for (int k = 0; k < 4; ++k) t->pro[k] = nullptr;
     return 1;
+}
+
+// the weights-resident persistent kernel writes the pooled third output (XmcConvDesc.dst_pool) from its epilogue for these cases
+int xmc_conv_ptile_pool_try(const XmcConvDesc* d, void* stream) {
+    TileCfg t;
+    if (!d->dst_pool || d->out_dtype != XMC_BF16 || d->SA != 1 || d->DA != 1 || d->nclass != 1 || (d->DH & 1) || (d->DW & 1)) return 1;
+    if (!tile_plan(d, &t)) return 1;
+    if (!(d->CS <= 64 && t.slab == d->CS && d->CDw <= 64) || xmc_debug_off("no_ptile")) return 1;
+    const int rc = d->CDw == 64 ? launch_ptile<64>(*d, t, reinterpret_cast<hipStream_t>(stream))
+                                : launch_ptile<32>(*d, t, reinterpret_cast<hipStream_t>(stream));
+    return rc == XMC_ESHAPE ? 1 : rc;
 }
 
 // entry used by xmc_conv_igemm's dispatcher (conv_igemm.hip) and by the fused-prologue ABI call

@@ -291,19 +291,40 @@ __global__ __launch_bounds__(512) void wtile2_kernel(const XmcConvDesc d, const 
             bf16x8* __restrict__ dst8 = reinterpret_cast<bf16x8*>(d.dst);
             const bf16x8* __restrict__ mask8 = reinterpret_cast<const bf16x8*>(d.mask);
             const bf16x8* __restrict__ res8 = reinterpret_cast<const bf16x8*>(d.res);
+            bf16x8* __restrict__ dst2_8 = reinterpret_cast<bf16x8*>(d.dst2);
+            bf16x8* __restrict__ pool8 = reinterpret_cast<bf16x8*>(d.dst_pool);
+            int eo[TM], ro[TM];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int ml = wm * 64 + i * 16 + lane_op;
                 const int ty = ml >> t.log2TW, tx = ml & (t.TW - 1);
-                const int eo = dbase + ((ty * d.DA) * d.DW + tx * d.DA) * cd8 + fc;
-                const int ro = rbase + (ty * rsy + tx * rsx) * cd8 + fc;
+                eo[i] = dbase + ((ty * d.DA) * d.DW + tx * d.DA) * cd8 + fc;
+                if (d.res_mode == 2)      // residual at half resolution, nearest-upsampled (DA == 1)
+                    ro[i] = ((img * (d.DH >> 1) + ((a0 + ty) >> 1)) * (d.DW >> 1) + ((b0 + tx) >> 1)) * cd8 + (n0 >> 3) + fc;
+                else
+                    ro[i] = rbase + (ty * rsy + tx * rsx) * cd8 + fc;
+            }
 #pragma unroll
-                for (int u = 0; u < TN / 2; ++u) {
-                    if (ch0 + u * 32 >= d.CD) continue;
+            for (int u = 0; u < TN / 2; ++u) {
+                if (ch0 + u * 32 >= d.CD) continue;
+                float fin[TM][8];
+                // every mask / residual vector of this channel unit is requested before the first one is used: one memory latency
+                // per unit instead of one per vector (they were 2 x 16 dependent round trips per tile, longer than its MFMAs)
+                bf16x8 mkv[TM], rrv[TM];
+                if (mask8) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) mkv[i] = mask8[eo[i] + u * 4];
+                }
+                if (res8) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) rrv[i] = res8[ro[i] + u * 4];
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
                     float v[8];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { v[r] = acc[i][2 * u][r]; v[4 + r] = acc[i][2 * u + 1][r]; }
-                    if (d.bias) {
+                    if (d.bias && !(WT_ABL & 32)) {
                         const f32x4 b0v = *reinterpret_cast<const f32x4*>(d.bias + ch0 + u * 32), b1v = *reinterpret_cast<const f32x4*>(d.bias + ch0 + u * 32 + 4);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) { v[r] += b0v[r]; v[4 + r] += b1v[r]; }
@@ -315,25 +336,49 @@ __global__ __launch_bounds__(512) void wtile2_kernel(const XmcConvDesc d, const 
 #pragma unroll
                         for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], v[r] * slope);
                     }
+                    if (dst2_8 || d.round_act) {
+                        bf16x8 o2;
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) { o2[r] = (__bf16)v[r]; v[r] = (float)o2[r]; }
+                        if (dst2_8) dst2_8[eo[i] + u * 4] = o2;
+                    }
                     if (d.alpha_dev) {
 #pragma unroll
                         for (int r = 0; r < 8; ++r) v[r] *= alpha;
                     }
                     if (mask8) {
-                        const bf16x8 mk = mask8[eo + u * 4];
 #pragma unroll
-                        for (int r = 0; r < 8; ++r) v[r] *= lrelu_slope((float)mk[r]);
+                        for (int r = 0; r < 8; ++r) v[r] *= lrelu_slope((float)mkv[i][r]);
                     }
                     if (res8) {
-                        const bf16x8 rr = res8[ro + u * 4];
 #pragma unroll
-                        for (int r = 0; r < 8; ++r) v[r] += rs * (float)rr[r];
+                        for (int r = 0; r < 8; ++r) v[r] += rs * (float)rrv[i][r];
                     }
                     bf16x8 o;
 #pragma unroll
-                    for (int r = 0; r < 8; ++r) o[r] = (__bf16)v[r];
-                    if (!(WT_ABL & 16)) dst8[eo + u * 4] = o;
+                    for (int r = 0; r < 8; ++r) { o[r] = (__bf16)v[r]; fin[i][r] = (float)o[r]; }
+                    if (!(WT_ABL & 16)) dst8[eo[i] + u * 4] = o;
                     else asm volatile("" :: "v"(o));
+                }
+                if (pool8) {
+                    // 2x2 average of the ROUNDED block output (== F.avg_pool2d of dst): the vertical neighbour is pixel block
+                    // i+2 (8x32 tiles) or i+1 (16x16 tiles) of the same lane, the horizontal one the same block of lane ^ 1
+#pragma unroll
+                    for (int pr = 0; pr < 2; ++pr) {
+                        const int i0 = t.log2TW == 5 ? pr : 2 * pr, i1 = t.log2TW == 5 ? pr + 2 : 2 * pr + 1;
+                        const int ml = wm * 64 + i0 * 16 + lane_op;
+                        const int ty = ml >> t.log2TW, tx = ml & (t.TW - 1);
+                        bf16x8 o;
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) {
+                            float sm = (t.log2TW == 5 ? fin[pr][r] + fin[pr + 2][r] : fin[2 * pr][r] + fin[2 * pr + 1][r]);
+                            sm += __shfl_xor(sm, 1, 64);
+                            o[r] = (__bf16)(0.25f * sm);
+                        }
+                        (void)i1;
+                        if ((lane_op & 1) == 0)
+                            pool8[((img * (d.DH >> 1) + ((a0 + ty) >> 1)) * (d.DW >> 1) + ((b0 + tx) >> 1)) * cd8 + (n0 >> 3) + fc + u * 4] = o;
+                    }
                 }
             }
 #pragma unroll
@@ -445,6 +490,8 @@ int plan(const XmcConvDesc* d, WtCfg* t, int* mode, int* tn) {
     } else {
         return 0;
     }
+    if (d->dst_pool && (d->DA != 1 || d->nclass != 1 || (d->DH & 1) || (d->DW & 1))) return 0;
+    if (d->res_mode == 2 && d->DA != 1) return 0;
     t->patch_bytes = (maxpix * kPStride + 15) & ~15;
     // 32-bit unit offsets in the kernel
     if ((int64_t)d->N * d->SH * d->SW * (d->CS / 8) >= (1ll << 31) || (int64_t)d->N * d->DH * d->DW * (d->CD / 8) >= (1ll << 31)) return 0;

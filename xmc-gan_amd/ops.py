@@ -263,8 +263,11 @@ def _upconv_dgrad_raw(dy, w, geom, in_dtype):
     return dx
 
 
-def _conv_fwd_raw(x, w, bias, geom, act, out_dtype, res=None, alpha=None, up=False):
-    """y = act(conv(x, w) + bias) [*alpha] [+ res]; x [N,H,W,Cs]. ``up``: x is read through a fused nearest x2."""
+def _conv_fwd_raw(x, w, bias, geom, act, out_dtype, res=None, alpha=None, up=False, res_mode=0, want2=False, want_pool=False,
+                  round_act=False):
+    """y = act(conv(x, w) + bias) [*alpha] [+ res]; x [N,H,W,Cs]. ``up``: x is read through a fused nearest x2.
+    ``res_mode`` 2: res is [N,OH/2,OW/2,C] and read through a nearest x2.  ``want2``: also return act(conv + bias) itself (the
+    branch value before alpha / res);  ``want_pool``: also return avg_pool2d(y, 2).  Extras are appended: (y[, y2][, ypool])."""
     _need_cuda(x, w)
     N, H, W, CS = x.shape
     sh = 1 if up else 0
@@ -284,15 +287,27 @@ def _conv_fwd_raw(x, w, bias, geom, act, out_dtype, res=None, alpha=None, up=Fal
     d.MH, d.MW, d.SA, d.DA, d.src_shift = OH, OW, geom.s, 1, sh
     d.ntaps, d.nclass, d.CDw = geom.k * geom.k, 1, wpk.shape[1]
     d.act, d.dtype, d.out_dtype = act, _code(x.dtype), _code(out_dtype)
+    d.res_mode, d.round_act = res_mode, int(bool(round_act))
     _fill_taps(d, 0, [(kh - geom.p, kw - geom.p, kh * geom.k + kw) for kh in range(geom.k) for kw in range(geom.k)])
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.numel() >= cd_p, "bias must be f32 and padded to the stored channels"
     if res is not None:
-        assert res.shape == y.shape and res.dtype == out_dtype and res.is_contiguous()
+        want = (N, OH // 2, OW // 2, cd_p) if res_mode == 2 else tuple(y.shape)
+        assert tuple(res.shape) == want and res.dtype == out_dtype and res.is_contiguous(), (res.shape, want)
+    outs = [y]
+    if want2:
+        y2 = torch.empty_like(y)
+        d.dst2 = y2.data_ptr()
+        outs.append(y2)
+    if want_pool:
+        assert OH % 2 == 0 and OW % 2 == 0 and out_dtype == x.dtype
+        yp = torch.empty((N, OH // 2, OW // 2, cd_p), dtype=out_dtype, device=x.device)
+        d.dst_pool = yp.data_ptr()
+        outs.append(yp)
     with prof.launch("igemm_kernel (conv fwd+dgrad, MFMA implicit GEMM)", 2.0 * N * OH * OW * geom.cout * geom.cin * geom.k * geom.k,
                      f"fwd {x.dtype} N{N} {H}x{W} {geom.cin}->{geom.cout} k{geom.k}s{geom.s}"):
         L.check(L.load().xmc_conv_igemm(C.byref(d), _st()), "xmc_conv_igemm(fwd)")
-    return y
+    return y if len(outs) == 1 else tuple(outs)
 
 
 def _conv_dgrad_raw(dy, w, geom, in_hw, in_dtype, mask=None, res=None, res_rows=False, res_scale=1.0):
@@ -624,6 +639,52 @@ class AxpbyUpFn(torch.autograd.Function):
         db = ScaleFn.apply(dy, alpha) if ctx.needs_input_grad[1] else None
         dal = DotFn.apply(dy, b).reshape(alpha.shape) if ctx.needs_input_grad[2] else None
         return da, db, dal, None
+
+
+class ConvAxpbyUpFn(torch.autograd.Function):
+    """The end of a generator block as ONE pass: up2(shortcut) + gamma * (conv3x3(h) + b)  (df_gan.py:197-202: c2, the block
+    sum, F.interpolate of the previous block's output folded in as a half-resolution residual read, XmcConvDesc.res_mode 2).
+    The convolution output itself (needed for d(gamma)) is the epilogue's second output.  First order only (generator path)."""
+
+    @staticmethod
+    def forward(ctx, h, w, b, geom, sc_lo, gamma):
+        h, sc_lo = h.contiguous(), sc_lo.contiguous()
+        bp = None
+        if b is not None:
+            cd_p = pad_to(geom.cout, 8)
+            bp = b.detach().float()
+            if bp.numel() < cd_p:
+                bp = torch.nn.functional.pad(bp, (0, cd_p - bp.numel()))
+            bp = bp.contiguous()
+        al = gamma.detach().reshape(-1).float()
+        y, res = _conv_fwd_raw(h, w, bp, geom, L.ACT_NONE, h.dtype, res=sc_lo, alpha=al, res_mode=2, want2=True)
+        ctx.geom, ctx.has_b = geom, b is not None
+        ctx.save_for_backward(h, w, res, gamma)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        h, w, res, gamma = ctx.saved_tensors
+        geom = ctx.geom
+        dsc, dres, dgamma = _axpby_bwd_fused(dy, res, gamma, up=True)      # one pass over dy and res
+        dh = _conv_dgrad_raw(dres, w, geom, (h.shape[1], h.shape[2]), h.dtype) if ctx.needs_input_grad[0] else None
+        dw = db = None
+        if not _skip_wgrad():
+            want_b = ctx.has_b and ctx.needs_input_grad[2]
+            if ctx.needs_input_grad[1]:
+                r = _conv_wgrad_raw(h, dres, geom, want_bias=want_b)
+                dw, db = (r if want_b else (r, None))
+                dw = dw.view(w.shape)
+            elif want_b:
+                db = ColSumFn.apply(dres)
+            if db is not None:
+                db = db[: geom.cout]
+        return dh, dw, db, None, (dsc if ctx.needs_input_grad[4] else None), (dgamma if ctx.needs_input_grad[5] else None)
+
+
+def conv_axpby_up(h, w, b, geom, sc_lo, gamma):
+    return ConvAxpbyUpFn.apply(h, w, b, geom, sc_lo, gamma)
 
 
 def conv2d(x, w, b, geom, act=L.ACT_NONE, out_dtype=None):
@@ -976,12 +1037,18 @@ class ResDFn(torch.autograd.Function):
     Not differentiable a second time: MA-GP runs the composed block (ops.composable())."""
 
     @staticmethod
-    def forward(ctx, x, w0, w2, ws, bs, gamma, g0, g2, gs):
+    def forward(ctx, x, w0, w2, ws, bs, gamma, g0, g2, gs, xp_hint=None, want_pool=False):
+        """``xp_hint``: avg_pool2d(x, 2) if the producer of x already wrote it (the previous block's third output);
+        ``want_pool``: return (out, avg_pool2d(out, 2)) -- the pooled tensor is a by-product for the NEXT block's shortcut and
+        carries no gradient of its own (that block returns the full gradient of its input, pool path included)."""
         x = x.contiguous()
         dt = x.dtype
         N, H, W, _ = x.shape
-        xp = torch.empty((N, H // 2, W // 2, x.shape[3]), dtype=dt, device=x.device)
-        L.call("xmc_sumpool2", _p(x), _p(xp), N, H, W, x.shape[3], 0.25, _code(dt), _st())
+        if xp_hint is not None:
+            xp = xp_hint
+        else:
+            xp = torch.empty((N, H // 2, W // 2, x.shape[3]), dtype=dt, device=x.device)
+            L.call("xmc_sumpool2", _p(x), _p(xp), N, H, W, x.shape[3], 0.25, _code(dt), _st())
         if ws is not None:
             bp = None
             if bs is not None:
@@ -994,19 +1061,31 @@ class ResDFn(torch.autograd.Function):
         else:
             sc = xp
         h1 = _conv_fwd_raw(x, w0, None, g0, L.ACT_LRELU, dt)
-        res = _conv_fwd_raw(h1, w2, None, g2, L.ACT_LRELU, dt)
         al = gamma.detach().reshape(-1).float()
-        out = torch.empty_like(res)
-        L.call("xmc_axpby", _p(sc), _p(res), _p(al), _p(out), res.numel(), _code(dt), _st())
+        # conv_r[2], LeakyReLU, `shortcut + gamma * residual` (df_gan.py:276-277,284) and the next block's pool in ONE pass: the
+        # residual branch itself is kept (second output) only when a backward pass will ask for it
+        keep = any(ctx.needs_input_grad[:6])
+        pool_ok = want_pool and res_pool_ok(h1, g2)
+        r = _conv_fwd_raw(h1, w2, None, g2, L.ACT_LRELU, dt, res=sc, alpha=al, want2=keep, want_pool=pool_ok, round_act=True)
+        r = r if isinstance(r, tuple) else (r,)
+        out = r[0]
+        res = r[1] if keep else None
+        outp = r[-1] if pool_ok else None
         ctx.geoms = (g0, g2, gs)
         ctx.learned = ws is not None
         ctx.has_bs = bs is not None
         ctx.save_for_backward(x, xp if ws is not None else None, h1, res, w0, w2, ws, gamma)
+        if want_pool:
+            if outp is None:
+                outp = torch.empty((N, out.shape[1] // 2, out.shape[2] // 2, out.shape[3]), dtype=dt, device=x.device)
+                L.call("xmc_sumpool2", _p(out), _p(outp), N, out.shape[1], out.shape[2], out.shape[3], 0.25, _code(dt), _st())
+            ctx.mark_non_differentiable(outp)
+            return out, outp
         return out
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, dout):
+    def backward(ctx, dout, _doutp=None):
         x, xp, h1, res, w0, w2, ws, gamma = ctx.saved_tensors
         g0, g2, gs = ctx.geoms
         dout = dout.contiguous()
@@ -1039,7 +1118,13 @@ class ResDFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = _conv_dgrad_raw(gh, w0, g0, (x.shape[1], x.shape[2]), dt, res=dxp, res_rows=True, res_scale=0.25)
         dgamma = dgam.reshape(gamma.shape).to(gamma.dtype) if ctx.needs_input_grad[5] else None
-        return dx, dw0, dw2, dws, dbs, dgamma, None, None, None
+        return dx, dw0, dw2, dws, dbs, dgamma, None, None, None, None, None
+
+
+def res_pool_ok(h1, g2):
+    """the pooled third output needs an even-sized map (the C side falls back to its own pool pass where the kernel cannot)"""
+    OH, OW = g2.out_hw(h1.shape[1], h1.shape[2])
+    return OH % 2 == 0 and OW % 2 == 0
 
 
 class ColSumFn(torch.autograd.Function):

@@ -161,8 +161,10 @@ class NetD(nn.Module):
         """x: [B,3,S,S] f32 image -> [B,16*ndf,4,4] feature map (channels-last view).  ``nhwc8``: the same image already in
         the engine layout [B,S,S,8] (``ops.to_nhwc8(x)`` or NetG's ``return_nhwc`` output); ``x`` is then not read."""
         out = self.conv_img(ops.to_nhwc8(x) if nhwc8 is None else nhwc8)
-        for block in self.downblocks:
-            out = block(out)
+        pooled = None               # avg_pool2d of `out`, written by the block that produced it (third output of its last conv)
+        nblk = len(self.downblocks)
+        for i, block in enumerate(self.downblocks):
+            out, pooled = block(out, xp_hint=pooled, want_pool=i + 1 < nblk)
         return as_nchw_view(out)
 
 
@@ -262,6 +264,9 @@ class G_Block(nn.Module):
         h = ops.affine2_lrelu(x, *mod[0:4])
         h = ops.upconv3x3(h, self.c1.weight, self.c1.bias, self.c1.geom)
         h = ops.affine2_lrelu(h, *mod[4:8])
+        if not out_lrelu and ops.fused_blocks() and h.shape[1] % 2 == 0:
+            # c2, the block sum and the upsample of the shortcut in one pass (third epilogue form, res_mode 2)
+            return ops.conv_axpby_up(h, self.c2.weight, self.c2.bias, self.c2.geom, self.shortcut(x), self.gamma)
         # out_lrelu: the tail's LeakyReLU (df_gan.py:84-85) applied while the block sum is written
         return ops.axpby_up(self.shortcut(x), self.c2(h), self.gamma, lrelu=out_lrelu)
 
@@ -327,13 +332,20 @@ class resD(nn.Module):
         self.conv_s = conv2d_nxn(in_dim=in_dim, out_dim=out_dim, kernel_size=1, stride=1, padding=0, spec_norm=spec_norm)
         self.gamma = nn.Parameter(torch.zeros(1))
 
-    def forward(self, x, c=None):
+    def forward(self, x, c=None, xp_hint=None, want_pool=None):
+        """`want_pool` given (NetD's loop): returns (out, avg_pool2d(out, 2) or None); `xp_hint`: avg_pool2d(x, 2) if the previous
+        block already produced it.  Called the upstream way (`block(x)`), returns `out` alone."""
         if self.downsample and ops.fused_blocks() and x.is_cuda:
             r0, r2, s_ = self.conv_r[0], self.conv_r[2], self.conv_s
-            return ops.ResDFn.apply(x, r0.effective_weight(), r2.effective_weight(),
-                                    s_.effective_weight() if self.learned_shortcut else None,
-                                    s_.bias if self.learned_shortcut else None, self.gamma, r0.geom, r2.geom, s_.geom)
-        return ops.axpby(self.shortcut(x), self.residual(x), self.gamma)
+            r = ops.ResDFn.apply(x, r0.effective_weight(), r2.effective_weight(),
+                                 s_.effective_weight() if self.learned_shortcut else None,
+                                 s_.bias if self.learned_shortcut else None, self.gamma, r0.geom, r2.geom, s_.geom,
+                                 xp_hint, bool(want_pool))
+            if want_pool is None:
+                return r
+            return r if want_pool else (r, None)
+        out = ops.axpby(self.shortcut(x), self.residual(x), self.gamma)
+        return out if want_pool is None else (out, None)
 
     def shortcut(self, x):
         # upstream: avg_pool2d(conv_s(x), 2) (df_gan.py:286-291).  A 1x1 convolution (and its bias) commutes with
