@@ -12,8 +12,8 @@
  *     enqueued, never synchronised, so every call is hipGraph-capturable;
  *   - activations are NHWC, channel count a multiple of 8, element type bf16 (XMC_BF16) or
  *     f32 (XMC_F32); parameters/gradients of parameters are f32;
- *   - return value: 0 on success, a positive hipError_t from the launch, or a negative XMC_E* code
- *     for a rejected argument (nothing is launched in that case).
+ *   - return value: 0 on success; XMC_EINVAL / XMC_EALIGN / XMC_ESHAPE (-1 .. -3) for a rejected argument (nothing is
+ *     launched in that case); -(1000 + hipError_t) when the HIP runtime refused a launch or a memset.  Never positive.
  */
 #ifndef XMC_GAN_HIP_H
 #define XMC_GAN_HIP_H

@@ -172,7 +172,7 @@ extern "C" int xmc_contrastive_fwd(const float* A, const float* B, const float* 
     int rc = xmc_conv_igemm(&d, stream);
     if (rc) return rc;
     hipError_t e = hipMemsetAsync(loss, 0, sizeof(float), st);
-    if (e != hipSuccess) return (int)e;
+    if (e != hipSuccess) return -(1000 + (int)e);
     const int lb = (n + NT / 64 - 1) / (NT / 64);
     hipLaunchKernelGGL(lse_loss_kernel, dim3(lb), dim3(NT), 0, st, w.S, labels, inv_num_pos, n, w.n8, 1, w.lse_c, loss);
     hipLaunchKernelGGL(lse_loss_kernel, dim3(lb), dim3(NT), 0, st, w.S, labels, inv_num_pos, n, w.n8, 0, w.lse_r, loss);
@@ -203,7 +203,7 @@ extern "C" int xmc_contrastive_bwd(const float* A, const float* B, const float* 
     // dAh[i][d] = sum_j dST[j][i] * Bh[j][d] ; dBh[j][d] = sum_i dS[i][j] * Ah[i][d]    (wgrad form, K = n rows)
     hipError_t e = hipMemsetAsync(w.dAh, 0, (size_t)w.n32 * D * 4, st);
     if (e == hipSuccess) e = hipMemsetAsync(w.dBh, 0, (size_t)w.n32 * D * 4, st);
-    if (e != hipSuccess) return (int)e;
+    if (e != hipSuccess) return -(1000 + (int)e);
     XmcConvDesc d;
     fill_linear_desc(d, w.Bh, nullptr, w.dST, n, D, w.n8, w.n32);
     int rc = xmc_conv_wgrad(&d, w.dAh, stream);

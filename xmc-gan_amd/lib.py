@@ -128,7 +128,8 @@ _ECODES = {-1: "XMC_EINVAL (bad argument)", -2: "XMC_EALIGN (alignment / channel
 
 def check(rc, what):
     if rc != 0:
-        raise XmcHipError(f"{what} failed: {_ECODES.get(rc, f'hipError_t {rc}')}")
+        msg = _ECODES.get(rc) or (f"hipError_t {-rc - 1000}" if rc <= -1000 else f"unexpected return code {rc}")
+        raise XmcHipError(f"{what} failed: {msg}")
 
 
 def call(name, *args):
