@@ -337,7 +337,7 @@ extern "C" int xmc_groupnorm_fwd(const void* x, const float* w, const float* b, 
     int bx = (HW + groups * 16 - 1) / (groups * 16); if (bx < 1) bx = 1;
     int ppb = (HW + bx - 1) / bx;
     hipError_t e = hipMemsetAsync(ws, 0, (size_t)N * C * 2 * 4, ST(s));
-    if (e != hipSuccess) return (int)e;
+    if (e != hipSuccess) return -(1000 + (int)e);
     int64_t total = (int64_t)N * HW * C8; int blocks = (int)((total + NT - 1) / NT); if (blocks > 4096) blocks = 4096;
     if (dtype == XMC_BF16) {
         hipLaunchKernelGGL((gn_sums_kernel<XMC_BF16, 0>), dim3(bx, N), dim3(NT), 0, ST(s), x, nullptr, nullptr, nullptr, nullptr, ws, HW, C8, cpg, -1.f, ppb);
@@ -358,7 +358,7 @@ extern "C" int xmc_groupnorm_bwd(const void* x, const void* dy, const float* w, 
     int bx = (HW + groups * 16 - 1) / (groups * 16); if (bx < 1) bx = 1;
     int ppb = (HW + bx - 1) / bx;
     hipError_t e = hipMemsetAsync(ws, 0, (size_t)N * C * 2 * 4, ST(s));
-    if (e != hipSuccess) return (int)e;
+    if (e != hipSuccess) return -(1000 + (int)e);
     float* ab = ws + (size_t)N * C * 2;              // [N][G][2], second part of the workspace
     int64_t total = (int64_t)N * HW * C8; int blocks = (int)((total + NT - 1) / NT); if (blocks > 4096) blocks = 4096;
     if (dtype == XMC_BF16) {
