@@ -308,6 +308,14 @@ int xmc_adam_chunk_elems(void);
 int xmc_adam_step(const XmcAdamEntry* table_dev, int ntensors, const int32_t* chunks_dev, int nchunks,
                   float lr, float beta1, float beta2, float eps, void* stream);
 
+/* ---- matching-aware gradient penalty, train_gan.py:241-247:  2 * mean_b ||[d logit / d img_b, d logit / d sent_b]||_2^6 ---------
+ * ss[b] += sum_k x[b][k]^2 over an f32 block [B, cols] (cols % 4 == 0; ss zeroed by the caller, blocks accumulate);
+ * gp = mean_b ss[b]^3 and coef[b] = 6 ss[b]^2 / B (so that d gp / d x[b][k] = coef[b] * x[b][k]);
+ * y = (*g) * coef[b] * x : the gradient of gp w.r.t. one block, scaled by the incoming gradient *g (device scalar). */
+int xmc_rows_sumsq(const float* x, float* ss, int B, int64_t cols, void* stream);
+int xmc_gp_finish(const float* ss, int B, float* gp, float* coef, void* stream);
+int xmc_rows_scale(const float* x, const float* coef, const float* g, float* y, int B, int64_t cols, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

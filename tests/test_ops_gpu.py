@@ -552,3 +552,20 @@ def test_global_avgpool_large_maps(N, H, W, C, mode):
     (y * r.to(DEV)).sum().backward()
     ref = (r / (H * W))[:, None, None, :].expand(N, H, W, C)
     torch.testing.assert_close(xd.grad.float().cpu(), rt(ref, mode), rtol=1e-2 if mode == "bf16" else 1e-6, atol=1e-8)
+
+
+def test_grad_penalty_matches_reference_expression():
+    """ops.grad_penalty == mean(sqrt(sum(cat(g0, g1)**2, 1))**6) (train_gan.py:241-247) and its gradient, f64 reference;
+    block widths that are and are not multiples of 4, a 3*64*64-wide image block."""
+    g = torch.Generator().manual_seed(3)
+    for B, shapes in ((5, [(3, 8, 8), (6,)]), (4, [(3, 64, 64), (256,)]), (3, [(10,), (7,)])):
+        blocks = [torch.randn(B, *s, generator=g) * 0.3 for s in shapes]
+        ref_in = [b.double().requires_grad_() for b in blocks]
+        ref = (torch.cat([b.reshape(B, -1) for b in ref_in], 1).pow(2).sum(1).sqrt() ** 6).mean()
+        ref.backward()
+        dev = [b.to(DEV).requires_grad_() for b in blocks]
+        gp = ops.grad_penalty(*dev)
+        (2.0 * gp).backward()
+        assert abs(gp.item() - ref.item()) <= 1e-5 * abs(ref.item())
+        for d_, r_ in zip(dev, ref_in):
+            torch.testing.assert_close(d_.grad.cpu().double(), 2.0 * r_.grad, rtol=1e-5, atol=1e-7 * float(r_.grad.abs().max()))

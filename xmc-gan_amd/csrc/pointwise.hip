@@ -570,6 +570,56 @@ __global__ void unpack_wgrad_kernel(const float* dwp, float* gw, int Co, int Ci,
     }
 }
 
+// ------------------------------------------------------------------ matching-aware gradient penalty (train_gan.py:241-247)
+// ss[b] += sum_k x[b][k]^2 : f32 rows of `cols` elements (cols % 4 == 0), blockIdx.y = row, blockIdx.x strides over the row
+__global__ void rows_sumsq_kernel(const float* __restrict__ x, float* __restrict__ ss, int64_t cols4) {
+    const f32x4* row = reinterpret_cast<const f32x4*>(x) + (int64_t)blockIdx.y * cols4;
+    float s = 0.f;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < cols4; i += (int64_t)gridDim.x * blockDim.x) {
+        const f32x4 v = row[i];
+        s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    s = wave_sum(s);
+    __shared__ float part[NT / 64];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < NT / 64; ++w) t += part[w];
+        atomicAdd(&ss[blockIdx.y], t);
+    }
+}
+// gp = mean_b ss[b]^3 (= mean ||g_b||^6), coef[b] = d gp / d ss[b] * 2 = 6 ss[b]^2 / B   (so that d gp / d g = coef[b] * g)
+__global__ void gp_finish_kernel(const float* __restrict__ ss, int B, float* __restrict__ gp, float* __restrict__ coef) {
+    float s = 0.f;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        const float v = ss[b];
+        s += v * v * v;
+        coef[b] = 6.f * v * v / (float)B;
+    }
+    s = wave_sum(s);
+    __shared__ float part[NT / 64];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < NT / 64; ++w) t += part[w];
+        *gp = t / (float)B;
+    }
+}
+// y[b][k] = (*g) * coef[b] * x[b][k]
+__global__ void rows_scale_kernel(const float* __restrict__ x, const float* __restrict__ coef, const float* __restrict__ g,
+                                  float* __restrict__ y, int64_t cols4) {
+    const float c = coef[blockIdx.y] * (*g);
+    const f32x4* row = reinterpret_cast<const f32x4*>(x) + (int64_t)blockIdx.y * cols4;
+    f32x4* out = reinterpret_cast<f32x4*>(y) + (int64_t)blockIdx.y * cols4;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < cols4; i += (int64_t)gridDim.x * blockDim.x) {
+        f32x4 v = row[i];
+        v[0] *= c; v[1] *= c; v[2] *= c; v[3] *= c;
+        out[i] = v;
+    }
+}
+
 }  // namespace
 
 #define ST(s) reinterpret_cast<hipStream_t>(s)
@@ -863,4 +913,35 @@ extern "C" int xmc_axpby_up(const void* a, const void* b, const float* alpha, vo
 }
 extern "C" int xmc_axpby_up_lrelu(const void* a, const void* b, const float* alpha, void* y, int N, int H, int W, int C, int dtype, void* s) {
     return axpby_up_impl(a, b, alpha, y, N, H, W, C, 1, dtype, s);
+}
+
+// Matching-aware gradient penalty (train_gan.py:241-247): grad_l2norm^6 averaged over the batch, from the f32 gradient blocks
+// [B, cols] (image gradient [B, 3*S*S], sentence gradient [B, cond]) without concatenating them.
+extern "C" int xmc_rows_sumsq(const float* x, float* ss, int B, int64_t cols, void* s) {
+    if (!x || !ss || B < 1 || cols < 4) return XMC_EINVAL;
+    if (cols % 4) return XMC_EALIGN;
+    const int64_t c4 = cols / 4;
+    int gx = (int)((c4 + NT * 8 - 1) / (NT * 8));
+    if (gx < 1) gx = 1;
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(rows_sumsq_kernel, dim3(gx, B), dim3(NT), 0, ST(s), x, ss, c4);
+    XMC_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int xmc_gp_finish(const float* ss, int B, float* gp, float* coef, void* s) {
+    if (!ss || !gp || !coef || B < 1) return XMC_EINVAL;
+    hipLaunchKernelGGL(gp_finish_kernel, dim3(1), dim3(NT), 0, ST(s), ss, B, gp, coef);
+    XMC_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int xmc_rows_scale(const float* x, const float* coef, const float* g, float* y, int B, int64_t cols, void* s) {
+    if (!x || !coef || !g || !y || B < 1 || cols < 4) return XMC_EINVAL;
+    if (cols % 4) return XMC_EALIGN;
+    const int64_t c4 = cols / 4;
+    int gx = (int)((c4 + NT * 8 - 1) / (NT * 8));
+    if (gx < 1) gx = 1;
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(rows_scale_kernel, dim3(gx, B), dim3(NT), 0, ST(s), x, coef, g, y, c4);
+    XMC_LAUNCH_CHECK();
+    return 0;
 }

@@ -1435,6 +1435,54 @@ class ContrastiveFn(torch.autograd.Function):
         return da, db, None, None
 
 
+class GradPenaltyFn(torch.autograd.Function):
+    """mean_b ||[g0_b, g1_b, ...]||_2^6 over f32 gradient blocks [B, ...] (train_gan.py:241-247: cat, **2, sum, sqrt, **6,
+    mean) in two passes over the data: per-sample sums of squares, then -- in the backward -- one scaled copy per block.
+    Once differentiable, which is what `d_loss.backward()` asks of it: the blocks are themselves outputs of
+    `autograd.grad(create_graph=True)`, so the gradients returned here continue into the second-order graph of D."""
+
+    @staticmethod
+    def forward(ctx, *blocks):
+        B = blocks[0].shape[0]
+        flat = []
+        for g in blocks:
+            g = g.contiguous().float().reshape(B, -1)
+            if g.shape[1] % 4:
+                g = torch.nn.functional.pad(g, (0, 4 - g.shape[1] % 4))
+            flat.append(g)
+        _need_cuda(*flat)
+        ss = torch.zeros(B, dtype=torch.float32, device=flat[0].device)
+        for g in flat:
+            L.call("xmc_rows_sumsq", _p(g), _p(ss), B, g.shape[1], _st())
+        gp = torch.empty(1, dtype=torch.float32, device=ss.device)
+        coef = torch.empty(B, dtype=torch.float32, device=ss.device)
+        L.call("xmc_gp_finish", _p(ss), B, _p(gp), _p(coef), _st())
+        ctx.shapes = [tuple(b.shape) for b in blocks]
+        ctx.dtypes = [b.dtype for b in blocks]
+        ctx.save_for_backward(coef, *flat)
+        return gp.reshape(())
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dgp):
+        coef, *flat = ctx.saved_tensors
+        B = coef.numel()
+        gdev = dgp.reshape(1).float().contiguous()
+        outs = []
+        for g, shp, dt in zip(flat, ctx.shapes, ctx.dtypes):
+            y = torch.empty_like(g)
+            L.call("xmc_rows_scale", _p(g), _p(coef), _p(gdev), _p(y), B, g.shape[1], _st())
+            n = 1
+            for v in shp[1:]:
+                n *= v
+            outs.append(y[:, :n].reshape(shp).to(dt))
+        return tuple(outs)
+
+
+def grad_penalty(*blocks):
+    return GradPenaltyFn.apply(*blocks)
+
+
 def cosine_scores(a, b):
     """normalize(a) @ normalize(b).T -> f32 [n,n] (train_gan.py:85-91); not differentiable (label construction only)."""
     a, b = a.detach().contiguous().float(), b.detach().contiguous().float()
