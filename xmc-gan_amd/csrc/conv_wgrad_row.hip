@@ -20,7 +20,7 @@
 
 namespace {
 
-constexpr int WR_BCO = 128, WR_BCI = 128, WR_KP = 64, WR_NT = 512;
+constexpr int WR_BCO = 128, WR_KP = 64, WR_NT = 512;      // BCI (ci block) is a template parameter: 128, or 64 for Cin == 64
 constexpr int WR_LD = 128 + 16;                   // dy tile row stride in elements: 72 dwords, rows 0..7 land 8 banks apart
 // x tile row stride: consecutive K pixels are SA rows apart, and the 32 lanes one tr16 read serves together (pixels
 // 0..7) must land on 8 distinct bank octets: SA == 1: 72 dwords; SA == 2: 68 dwords (2 rows = 136 = 8 mod 64)
@@ -32,11 +32,12 @@ struct RowCfg {
     int lds_bytes;
 };
 
-template <int KW, int SA>
+template <int KW, int SA, int WR_BCI>
 __global__ __launch_bounds__(WR_NT) void wgrad_row_kernel(const XmcConvDesc d, const RowCfg t, float* __restrict__ dwp,
                                                           float* __restrict__ dbias, int pix_per_block) {
     constexpr int NT = WR_NT, KP = WR_KP, LD = WR_LD, LDX = XLd<SA>::v;
-    constexpr int TM = 4, TN = 2;                 // 16x16 tiles per wave: 64 co x 32 ci
+    constexpr int TM = 4, TN = WR_BCI / 64;       // 16x16 tiles per wave: 64 co x 32 ci (x 16 ci for the 64-wide ci block)
+    constexpr int XCH = WR_BCI / 8;               // 16-byte chunks per x pixel row
     constexpr int XIT = ((SA * 63 + KW) * 16 + NT - 1) / NT + 1;      // x chunks per thread per step (upper bound over seg)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int s_seg[2][16];                  // per (step parity, segment): source pixel index of (n, row, col 0) or -1
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(WR_NT) void wgrad_row_kernel(const XmcConvDesc d, c
 #pragma unroll
         for (int it = 0; it < XIT; ++it) {
             u32x4 v = {0, 0, 0, 0};
-            if (xs[it] >= 0) {
+            if (xs[it] >= 0 && dch < XCH) {
                 const int base = s_seg[par][xs[it]];
                 const int col = (t.nseg == 1 ? b0 : 0) * SA + xj[it] - t.pad;
                 if (base >= 0 && (unsigned)col < (unsigned)(d.SW << d.src_shift))
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(WR_NT) void wgrad_row_kernel(const XmcConvDesc d, c
         }
 #pragma unroll
         for (int it = 0; it < XIT; ++it)
-            if (xs[it] >= 0) *reinterpret_cast<u32x4*>(sx + (((tid >> 4) + 32 * it) * LDX + dch * 8) * 2) = ri[it];
+            if (xs[it] >= 0 && dch < XCH) *reinterpret_cast<u32x4*>(sx + (((tid >> 4) + 32 * it) * LDX + dch * 8) * 2) = ri[it];
     };
 
     f32x4 acc[KW][TM][TN];
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(WR_NT) void wgrad_row_kernel(const XmcConvDesc d, c
     for (int ks = 0; ks < 2; ++ks) {
         const int k = ks * 32 + 4 * fg + q;
         dyoff[ks] = (k * LD + wm * 64 + 4 * pp) * 2;
-        xoff[ks] = (((k / t.seg) * t.xseg + SA * (k % t.seg)) * LDX + wn * 32 + 4 * pp) * 2;
+        xoff[ks] = (((k / t.seg) * t.xseg + SA * (k % t.seg)) * LDX + wn * (WR_BCI / 4) + 4 * pp) * 2;
     }
     const int xhi = (t.seg == 16 ? t.xseg : 16 * SA) * LDX * 2;     // pixel k+16: next segment when segments are 16 long
 
@@ -202,15 +203,15 @@ __global__ __launch_bounds__(WR_NT) void wgrad_row_kernel(const XmcConvDesc d, c
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int co = co0 + wm * 64 + i * 16 + fg * 4 + r;
-                    const int ci = ci0 + wn * 32 + j * 16 + fr;
+                    const int ci = ci0 + wn * (WR_BCI / 4) + j * 16 + fr;
                     atomicAdd(&dwp[((size_t)twi * d.CDw + co) * d.CS + ci], acc[w][i][j][r]);
                 }
     }
 }
 
-template <int KW, int SA>
+template <int KW, int SA, int WR_BCI>
 int launch_row(const XmcConvDesc& d, const RowCfg& t, float* dwp, float* dbias, hipStream_t st) {
-    XMC_ALLOW_BIG_LDS((wgrad_row_kernel<KW, SA>));
+    XMC_ALLOW_BIG_LDS((wgrad_row_kernel<KW, SA, WR_BCI>));
     const int64_t P = (int64_t)d.N * d.MH * d.MW;
     const int tiles = (d.CDw / WR_BCO) * (d.CS / WR_BCI) * KW;          // KW = KH for the square kernels handled here
     int64_t nsplit = (256 + tiles - 1) / tiles;                         // one workgroup of 8 waves per CU (accumulators: > 128 VGPRs)
@@ -220,8 +221,8 @@ int launch_row(const XmcConvDesc& d, const RowCfg& t, float* dwp, float* dbias, 
     ppb = (ppb + WR_KP - 1) / WR_KP * WR_KP;
     nsplit = (P + ppb - 1) / ppb;
     dim3 grid((unsigned)nsplit, (unsigned)((d.CDw / WR_BCO) * (d.CS / WR_BCI)), (unsigned)KW);
-    hipLaunchKernelGGL((wgrad_row_kernel<KW, SA>), grid, dim3(WR_NT), (size_t)t.lds_bytes, st, d, t, dwp, dbias, (int)ppb);
-    xmc_note_kernel("wgrad_row_kernel<%d, %d>", KW, SA);
+    hipLaunchKernelGGL((wgrad_row_kernel<KW, SA, WR_BCI>), grid, dim3(WR_NT), (size_t)t.lds_bytes, st, d, t, dwp, dbias, (int)ppb);
+    xmc_note_kernel("wgrad_row_kernel<%d, %d, %d>", KW, SA, WR_BCI);
     XMC_LAUNCH_CHECK();
     return 0;
 }
@@ -233,7 +234,7 @@ int xmc_conv_wgrad_row_try(const XmcConvDesc* d, float* dwp, float* dbias, void*
     static const bool off = xmc_debug_off("no_wrow");
     if (off) return 1;
     if (d->dtype != XMC_BF16 || (d->src_shift != 0 && d->SA != 1)) return 1;
-    if (d->CS % 128 != 0 || d->CD % 128 != 0 || d->CDw != d->CD) return 1;
+    if ((d->CS % 128 != 0 && d->CS != 64) || d->CD % 128 != 0 || d->CDw != d->CD) return 1;
     int kw, sa;
     if (d->ntaps == 9 && d->SA == 1) { kw = 3; sa = 1; }
     else if (d->ntaps == 16 && d->SA == 2) { kw = 4; sa = 2; }
@@ -257,5 +258,6 @@ int xmc_conv_wgrad_row_try(const XmcConvDesc* d, float* dwp, float* dbias, void*
     t.lds_bytes = 2 * (WR_KP * WR_LD + t.xrows * (sa == 1 ? XLd<1>::v : XLd<2>::v)) * 2;
     if (t.lds_bytes > XMC_MAX_DYN_LDS) return 1;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    return kw == 3 ? launch_row<3, 1>(*d, t, dwp, dbias, st) : launch_row<4, 2>(*d, t, dwp, dbias, st);
+    if (d->CS == 64) return kw == 3 ? launch_row<3, 1, 64>(*d, t, dwp, dbias, st) : launch_row<4, 2, 64>(*d, t, dwp, dbias, st);
+    return kw == 3 ? launch_row<3, 1, 128>(*d, t, dwp, dbias, st) : launch_row<4, 2, 128>(*d, t, dwp, dbias, st);
 }

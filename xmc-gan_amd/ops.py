@@ -364,13 +364,17 @@ class _ZeroArena:
     per G+D iteration.  Sized by the previous iteration's demand; anything beyond falls back to torch.zeros."""
 
     def __init__(self):
-        self.buf, self.off, self.need = {}, {}, {}
+        self.buf, self.off, self.need, self.retired = {}, {}, {}, []
 
     def new_iteration(self, device):
         key = (device.type, device.index)
         need = self.need.get(key, 0)
         buf = self.buf.get(key)
-        if need and (buf is None or buf.numel() < need):
+        # grow only outside stream capture (a buffer allocated inside a capture would live in that graph's private pool), and
+        # keep outgrown buffers alive: an earlier captured graph may still memset / accumulate into them on replay
+        if need and (buf is None or buf.numel() < need) and not (device.type == "cuda" and torch.cuda.is_current_stream_capturing()):
+            if buf is not None:
+                self.retired.append(buf)
             buf = self.buf[key] = torch.empty(int(need * 1.05) + 1024, dtype=torch.float32, device=device)
         if buf is not None:
             buf.zero_()
