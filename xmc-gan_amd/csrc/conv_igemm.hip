@@ -338,7 +338,8 @@ extern "C" int xmc_conv_igemm(const XmcConvDesc* d, void* stream) {
     static const bool no_wt2 = xmc_debug_off("no_wtile_v2");
     int rc = 1;
     if (!no_tile && d->dst_pool) {        // kernels that write the pooled third output from their epilogue
-        if (!no_wt2) rc = xmc_conv_wtile_try(d, stream);
+        rc = xmc_conv_thin_try(d, stream);
+        if (rc > 0 && !no_wt2) rc = xmc_conv_wtile_try(d, stream);
         if (rc > 0) rc = xmc_conv_ptile_pool_try(d, stream);
         if (rc <= 0) return rc;
     }

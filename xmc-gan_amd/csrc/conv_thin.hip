@@ -105,29 +105,55 @@ __global__ __launch_bounds__(256) void thin_in_kernel(const XmcConvDesc d, const
         __syncthreads();
         if (tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x);
         const int dbase = ((img * d.DH + ty * TH) * d.DW + tx * TW) * cd8;
+        // pixel blocks i and i+2 are vertical neighbours (rows 2*wm and 2*wm+1, same columns) of the same lane: they are
+        // finished together so that the optional third output (2x2 average of the rounded result, XmcConvDesc.dst_pool) is a
+        // sum of two registers plus one exchange with lane ^ 1
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            f32x4 acc[TN];
+        for (int ip = 0; ip < 2; ++ip) {
+            float fin[2][UPL][8];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int h = 0; h < 2; ++h) {
+                const int i = ip + 2 * h;
+                f32x4 acc[TN];
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const u32x4 pf = *reinterpret_cast<const u32x4*>(patch + pbase[i] + toff[ks]);
+                for (int j = 0; j < TN; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[ks][j]), __builtin_bit_cast(bf16x8, pf), acc[j], 0, 0, 0);
-            }
+                for (int ks = 0; ks < KS; ++ks) {
+                    const u32x4 pf = *reinterpret_cast<const u32x4*>(patch + pbase[i] + toff[ks]);
 #pragma unroll
-            for (int u = 0; u < UPL; ++u) {
-                if (ch0 + u * 8 >= d.CD) continue;
-                bf16x8 o;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float x0 = acc[2 * u][q] + bias8[u][q], x1 = acc[2 * u + 1][q] + bias8[u][4 + q];
-                    o[q] = (__bf16)fmaxf(x0, x0 * slope);
-                    o[4 + q] = (__bf16)fmaxf(x1, x1 * slope);
+                    for (int j = 0; j < TN; ++j)
+                        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[ks][j]), __builtin_bit_cast(bf16x8, pf), acc[j], 0, 0, 0);
                 }
-                dst8[dbase + eoff[i] + u] = o;
+#pragma unroll
+                for (int u = 0; u < UPL; ++u) {
+                    if (ch0 + u * 8 >= d.CD) continue;
+                    bf16x8 o;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float x0 = acc[2 * u][q] + bias8[u][q], x1 = acc[2 * u + 1][q] + bias8[u][4 + q];
+                        o[q] = (__bf16)fmaxf(x0, x0 * slope);
+                        o[4 + q] = (__bf16)fmaxf(x1, x1 * slope);
+                    }
+                    dst8[dbase + eoff[i] + u] = o;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) fin[h][u][q] = (float)o[q];
+                }
+            }
+            if (d.dst_pool) {
+                bf16x8* __restrict__ pool8 = reinterpret_cast<bf16x8*>(d.dst_pool);
+                const int prow = ty * (TH / 2) + wm, pcol = tx * (TW / 2) + ((ip * 16 + fr) >> 1);
+#pragma unroll
+                for (int u = 0; u < UPL; ++u) {
+                    if (ch0 + u * 8 >= d.CD) continue;
+                    bf16x8 o;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        float sm = fin[0][u][q] + fin[1][u][q];
+                        sm += __shfl_xor(sm, 1, 64);
+                        o[q] = (__bf16)(0.25f * sm);
+                    }
+                    if ((fr & 1) == 0) pool8[((img * (d.DH >> 1) + prow) * (d.DW >> 1) + pcol) * cd8 + fc * UPL + u] = o;
+                }
             }
         }
     }

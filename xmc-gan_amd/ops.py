@@ -439,7 +439,9 @@ class ConvFn(torch.autograd.Function):
     197,233-240,273,276,280."""
 
     @staticmethod
-    def forward(ctx, x, w, b, geom, act, out_dtype):
+    def forward(ctx, x, w, b, geom, act, out_dtype, want_pool=False):
+        """``want_pool``: returns (y, avg_pool2d(y, 2)); the pooled tensor is a by-product for the consumer's shortcut branch
+        (written from the epilogue where the kernel can) and carries no gradient of its own."""
         x = x.contiguous()
         bp = None
         if b is not None:
@@ -450,13 +452,19 @@ class ConvFn(torch.autograd.Function):
             if bp.numel() < cd_p:
                 bp = torch.nn.functional.pad(bp, (0, cd_p - bp.numel()))
             bp = bp.contiguous()
-        y = _conv_fwd_raw(x, w, bp, geom, act, out_dtype)
+        y = _conv_fwd_raw(x, w, bp, geom, act, out_dtype, want_pool=want_pool)
+        yp = None
+        if want_pool:
+            y, yp = y
         ctx.geom, ctx.act, ctx.has_b = geom, act, b is not None
         ctx.save_for_backward(x, w, y if act != L.ACT_NONE else None)
+        if want_pool:
+            ctx.mark_non_differentiable(yp)
+            return y, yp
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dyp=None):
         x, w, y = ctx.saved_tensors
         geom = ctx.geom
         dy = dy.contiguous()
@@ -483,7 +491,7 @@ class ConvFn(torch.autograd.Function):
                 if geom.row_perm is not None:
                     db = torch.zeros_like(db).index_copy(0, geom.perm_dev(db.device).long(), db)
                 db = db[: geom.cout]
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None
 
 
 class ConvDgradFn(torch.autograd.Function):
@@ -691,8 +699,8 @@ def conv_axpby_up(h, w, b, geom, sc_lo, gamma):
     return ConvAxpbyUpFn.apply(h, w, b, geom, sc_lo, gamma)
 
 
-def conv2d(x, w, b, geom, act=L.ACT_NONE, out_dtype=None):
-    return ConvFn.apply(x, w, b, geom, act, out_dtype or x.dtype)
+def conv2d(x, w, b, geom, act=L.ACT_NONE, out_dtype=None, want_pool=False):
+    return ConvFn.apply(x, w, b, geom, act, out_dtype or x.dtype, want_pool)
 
 
 def linear(x, w, b, geom, act=L.ACT_NONE, out_dtype=None):

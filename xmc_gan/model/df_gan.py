@@ -160,8 +160,12 @@ class NetD(nn.Module):
     def forward(self, x, nhwc8=None, **kwargs):
         """x: [B,3,S,S] f32 image -> [B,16*ndf,4,4] feature map (channels-last view).  ``nhwc8``: the same image already in
         the engine layout [B,S,S,8] (``ops.to_nhwc8(x)`` or NetG's ``return_nhwc`` output); ``x`` is then not read."""
-        out = self.conv_img(ops.to_nhwc8(x) if nhwc8 is None else nhwc8)
-        pooled = None               # avg_pool2d of `out`, written by the block that produced it (third output of its last conv)
+        pooled = None               # avg_pool2d of `out`, written by the layer that produced it (third output of its epilogue)
+        xin = ops.to_nhwc8(x) if nhwc8 is None else nhwc8
+        if ops.fused_blocks() and xin.is_cuda and xin.shape[1] % 2 == 0:
+            out, pooled = self.conv_img(xin, want_pool=True)
+        else:
+            out = self.conv_img(xin)
         nblk = len(self.downblocks)
         for i, block in enumerate(self.downblocks):
             out, pooled = block(out, xp_hint=pooled, want_pool=i + 1 < nblk)
