@@ -44,6 +44,13 @@ bool xmc_debug_off(const char* token);
     } while (0)
 
 __device__ __forceinline__ float lrelu_f(float v) { return v > 0.f ? v : XMC_LRELU * v; }
+// tanh for results that are stored as bf16: 1 - 2 / (exp(2x) + 1) on the hardware exp2 / rcp (absolute error ~1e-7, far below
+// half a bf16 ulp of the result; libm's tanhf costs ~0.7 ms on the generator's 256x256 output layer).  The f32 parity mode
+// keeps tanhf.
+__device__ __forceinline__ float tanh_fast(float v) {
+    const float e = __builtin_amdgcn_exp2f(v * 2.8853900817779268f);      // exp(2v)
+    return 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
+}
 __device__ __forceinline__ float lrelu_slope(float ref) { return ref > 0.f ? 1.f : XMC_LRELU; }
 
 // 8 consecutive channels <-> 8 floats, for either storage type

@@ -507,8 +507,8 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
                         } else if (do_tanh) {     // generator output layer (df_gan.py:88-90)
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
-                                o[q] = (__bf16)tanhf(acc[i][2 * u][q] + bias8[u][q]);
-                                o[4 + q] = (__bf16)tanhf(acc[i][2 * u + 1][q] + bias8[u][4 + q]);
+                                o[q] = (__bf16)tanh_fast(acc[i][2 * u][q] + bias8[u][q]);
+                                o[4 + q] = (__bf16)tanh_fast(acc[i][2 * u + 1][q] + bias8[u][4 + q]);
                             }
                         } else {
 #pragma unroll

@@ -47,16 +47,6 @@ def disc_arch(img_size, nch):
     }
 
 
-_SIDE = {}
-
-
-def _side_stream(device):
-    key = (device.type, device.index)
-    if key not in _SIDE:
-        _SIDE[key] = torch.cuda.Stream(device=device)
-    return _SIDE[key]
-
-
 def nhwc_feature_perm(channels, hw=16):
     """row permutation that makes Linear(...)->view(B,C,4,4) come out as NHWC [B,4,4,C] directly:
     packed row r = p*C + c  <-  parameter row c*hw + p."""
@@ -104,41 +94,19 @@ class NetG(nn.Module):
         out = self.stem(noise)
         sent_embs = self.proj_sent(sent_embs.float())
         # The 8 conditioning MLPs of every block depend only on the sentence embedding: all of them (40-56 two-layer MLPs)
-        # run as grouped GEMM launches up front.  (XMC_NO_MLP_BANK=1: one launch per Linear on a side stream, the earlier
-        # form, kept for ablation -- its ~700 tiny kernels per iteration queue behind the one-workgroup-per-CU convolution
-        # kernels instead of overlapping them.)
+        # run as grouped GEMM launches up front.
         nblk = len(self.upblocks)
-        if os.environ.get("XMC_NO_MLP_BANK") is None:
-            flat = ops.cond_mlp_bank(sent_embs, [m for g in self.upblocks for m in g.modulation_mlps()])
-            mods, events = [flat[8 * i:8 * i + 8] for i in range(nblk)], [None] * nblk
-            main = None
-        else:
-            main = torch.cuda.current_stream()
-            side = _side_stream(sent_embs.device)
-            side.wait_stream(main)
-            mods, events = [], []
-            with torch.cuda.stream(side):
-                for gblock in self.upblocks:
-                    mods.append(gblock.modulation(sent_embs))
-                    ev = torch.cuda.Event()
-                    ev.record(side)
-                    events.append(ev)
+        flat = ops.cond_mlp_bank(sent_embs, [m for g in self.upblocks for m in g.modulation_mlps()])
+        mods = [flat[8 * i:8 * i + 8] for i in range(nblk)]
         # Blocks hand over their output BEFORE the nearest x2 upsample (df_gan.py:201-202); the next block consumes it
         # through operators that commute with / absorb the upsample, so the 4x larger tensor is never written.
         pending_up = False
-        fuse_up = os.environ.get("XMC_NO_UPCONV") is None
         lrelu_done = False
-        for bi, (gblock, m, ev) in enumerate(zip(self.upblocks, mods, events)):
-            if ev is not None:
-                main.wait_event(ev)
-                for t in m:
-                    t.record_stream(main)
+        for bi, (gblock, m) in enumerate(zip(self.upblocks, mods)):
             last = bi == nblk - 1 and not gblock.upsample      # its output goes straight into the tail's LeakyReLU
             out = gblock.forward_fused(out, m, pending_up, out_lrelu=last)
             lrelu_done = last
             pending_up = gblock.upsample
-            if pending_up and not fuse_up:
-                out, pending_up = ops.upsample2(out), False
         if pending_up:
             out = ops.upsample2(out)
         return self.tail(out, lrelu_done, return_nhwc)
