@@ -428,7 +428,12 @@ __global__ __launch_bounds__(512) void wtile2_kernel(const XmcConvDesc d, const 
                 const unsigned char* npa = tap + 1 < NTAPS ? pcur + toffr[tap + 1 < NTAPS ? tap + 1 : 0] : pnxt + toffr[0];
                 stage(pcur + toffr[tap], wring + slot * WSTG, npa, wring + nslot * WSTG);
                 slot = nslot;
-                if (!(WT_ABL & 8)) __syncthreads();                  // end of stage g
+                // End of stage g.  A bare s_barrier: __syncthreads() would first wait for every outstanding LDS read
+                // (s_waitcnt lgkmcnt(0)), i.e. for the next stage's fragments fetched just above, and drain the MFMA pipe once
+                // per stage.  Nothing needs that wait: the reads of THIS stage's ring slot and patch have been consumed by
+                // MFMAs already issued, and what the staging waves overwrite after this barrier (ring slot g % 3; the other
+                // patch buffer at a slab start) is not what the outstanding reads address (slot (g+1) % 3, the live patch).
+                if (!(WT_ABL & 8)) __builtin_amdgcn_s_barrier();
             }
             if (++sl == nslab) {
                 epilogue((int)blockIdx.x + tk * (int)gridDim.x);

@@ -6,7 +6,6 @@ and ``state_dict()`` keys as the reference, so it is a drop-in for ``train_gan.p
 Internally activations are NHWC in the engine's activation dtype; the public tensors keep the
 reference's logical NCHW shapes (``netD(x)`` returns a channels-last view, ``netG`` an f32 NCHW image).
 """
-import os
 from collections import OrderedDict
 
 import torch
