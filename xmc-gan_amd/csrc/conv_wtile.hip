@@ -55,9 +55,14 @@ struct WtCfg {
 constexpr int kPStride = 160;       // bytes between patch pixels
 constexpr int kPIT = 12;            // patch pixels per staging thread (32 pixel rows of 8 units per pass): <= 384 pixels
 
-template <int NTAPS, int MODE, int TN>
-__global__ __launch_bounds__(512) void wtile2_kernel(const XmcConvDesc d, const WtCfg t, int ntiles) {
-    constexpr int BN = 16 * TN, TM = 4, NS = 256;
+// CW = number of compute waves: 4 (one per SIMD, 64 pixels x BN channels each) or 8 (two per SIMD, 64 pixels x BN/2 channels each:
+// the two waves of a SIMD interleave their MFMAs, so one's LDS latency and barrier skew are covered by the other's matrix work)
+template <int NTAPS, int MODE, int TN, int CW>
+__global__ __launch_bounds__(64 * CW + 256) void wtile2_kernel(const XmcConvDesc d, const WtCfg t, int ntiles) {
+    constexpr int BN = 16 * TN, TM = 4, NS = 64 * CW;
+    constexpr int TNW = TN * 4 / CW;             // 16-channel blocks per compute wave
+    static_assert(CW == 4 || CW == 8, "4 or 8 compute waves");
+    static_assert(TNW % 2 == 0, "a lane's 8-channel unit needs a pair of blocks");
     constexpr int WL = BN / 32;                  // weight rows per staging thread and stage
     constexpr int WSTG = BN * 128;               // bytes of one weight stage in the ring
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -101,7 +106,7 @@ __global__ __launch_bounds__(512) void wtile2_kernel(const XmcConvDesc d, const 
     __syncthreads();
     if (mytiles <= 0) return;
 
-    if (wave >= 4) {
+    if (wave >= CW) {
         // ================================================================================================ staging role
         const int rt = tid - NS;
         const int unit = rt & 7, r32 = rt >> 3;   // weights: 8 units per row, rows r32 + 32*i; patch: pixels r32 + 32*it
@@ -245,7 +250,7 @@ __global__ __launch_bounds__(512) void wtile2_kernel(const XmcConvDesc d, const 
         }
     } else {
         // ================================================================================================ compute role
-        const int wm = wave;
+        const int wm = wave & 3, wn = wave >> 2;  // pixel group (64 pixels), channel half (CW == 8)
         const int fr = lane & 15, fc = lane >> 4;
         const int cd8 = d.CD / 8;
         int abyte[TM];
@@ -256,23 +261,24 @@ __global__ __launch_bounds__(512) void wtile2_kernel(const XmcConvDesc d, const 
             abyte[i] = (ty * PW + tx) * kPStride + fc * 16;
         }
         // weight fragment (n-block mj, row fr, chunk sub*4+fc) of a ring slot: chunk index XOR (row & 7)
-        const int bb0 = fr * 128 + ((fc ^ (fr & 7)) << 4), bb1 = bb0 ^ 64;
-        f32x4 acc[TM][TN];
+        const int bb0 = fr * 128 + ((fc ^ (fr & 7)) << 4) + wn * TNW * 2048, bb1 = bb0 ^ 64;
+        f32x4 acc[TM][TNW];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < TNW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         // Fragment registers: pixel fragments double buffered (every MFMA column of a sub-step uses all four), weight fragments
         // in ONE set: the MFMAs run column by column (all four pixel blocks against weight fragment mj), and as soon as the four
         // MFMAs of column mj have issued, slot mj is re-loaded with the NEXT sub-step's fragment.
-        u32x4 P[2][TM], Wf[TN];
+        u32x4 P[2][TM], Wf[TNW];
         auto rdp = [&](const unsigned char* pa, int sub, int mi) -> u32x4 {
             return *reinterpret_cast<const u32x4*>(pa + sub * 64 + abyte[mi]);
         };
         auto rdw = [&](const unsigned char* wb, int sub, int mj) -> u32x4 {
             return *reinterpret_cast<const u32x4*>(wb + (sub ? bb1 : bb0) + mj * 2048);
         };
-        const int ch0 = n0 + fc * 8;
+        const int ch0 = n0 + wn * (BN / 2) * (CW / 4 - 1) + fc * 8;      // first channel of this lane's unit 0
+        const int nw8 = (n0 + wn * (BN / 2) * (CW / 4 - 1)) >> 3;         // ... in 8-channel units
         // epilogue from registers: acc[i][j][r] = pixel (m-block i, fr), channel n0 + (j/2)*32 + fc*8 + (j%2)*4 + r; clears acc.
         // bf16 destination only (plan()); order: bias, activation, alpha, LeakyReLU' mask, (row-indexed, scaled) residual.
         auto epilogue = [&](int tile) {
@@ -282,8 +288,8 @@ __global__ __launch_bounds__(512) void wtile2_kernel(const XmcConvDesc d, const 
             asm volatile("" : "+v"(lane_op) :: "memory");
             const int img = tile / tpi, trem = tile - img * tpi;
             const int a0 = (trem / t.tiles_x) * t.TH, b0 = (trem % t.tiles_x) * t.TW;
-            const int dbase = (((img * d.DH + a0 * d.DA + d.dph[cls]) * d.DW) + b0 * d.DA + d.dpw[cls]) * cd8 + (n0 >> 3);
-            const int rbase = d.res_mode ? ((img * d.MH + a0) * d.MW + b0) * cd8 + (n0 >> 3) : dbase;
+            const int dbase = (((img * d.DH + a0 * d.DA + d.dph[cls]) * d.DW) + b0 * d.DA + d.dpw[cls]) * cd8 + nw8;
+            const int rbase = d.res_mode ? ((img * d.MH + a0) * d.MW + b0) * cd8 + nw8 : dbase;
             const int rsy = d.res_mode ? d.MW : d.DA * d.DW, rsx = d.res_mode ? 1 : d.DA;
             const float slope = d.act == XMC_ACT_LRELU ? XMC_LRELU : (d.act == XMC_ACT_RELU ? 0.f : 1.f);
             const float alpha = d.alpha_dev ? *d.alpha_dev : 1.f;
@@ -300,12 +306,12 @@ __global__ __launch_bounds__(512) void wtile2_kernel(const XmcConvDesc d, const 
                 const int ty = ml >> t.log2TW, tx = ml & (t.TW - 1);
                 eo[i] = dbase + ((ty * d.DA) * d.DW + tx * d.DA) * cd8 + fc;
                 if (d.res_mode == 2)      // residual at half resolution, nearest-upsampled (DA == 1)
-                    ro[i] = ((img * (d.DH >> 1) + ((a0 + ty) >> 1)) * (d.DW >> 1) + ((b0 + tx) >> 1)) * cd8 + (n0 >> 3) + fc;
+                    ro[i] = ((img * (d.DH >> 1) + ((a0 + ty) >> 1)) * (d.DW >> 1) + ((b0 + tx) >> 1)) * cd8 + nw8 + fc;
                 else
                     ro[i] = rbase + (ty * rsy + tx * rsx) * cd8 + fc;
             }
 #pragma unroll
-            for (int u = 0; u < TN / 2; ++u) {
+            for (int u = 0; u < TNW / 2; ++u) {
                 if (ch0 + u * 32 >= d.CD) continue;
                 float fin[TM][8];
                 // every mask / residual vector of this channel unit is requested before the first one is used: one memory latency
@@ -377,14 +383,14 @@ __global__ __launch_bounds__(512) void wtile2_kernel(const XmcConvDesc d, const 
                         }
                         (void)i1;
                         if ((lane_op & 1) == 0)
-                            pool8[((img * (d.DH >> 1) + ((a0 + ty) >> 1)) * (d.DW >> 1) + ((b0 + tx) >> 1)) * cd8 + (n0 >> 3) + fc + u * 4] = o;
+                            pool8[((img * (d.DH >> 1) + ((a0 + ty) >> 1)) * (d.DW >> 1) + ((b0 + tx) >> 1)) * cd8 + nw8 + fc + u * 4] = o;
                     }
                 }
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int j = 0; j < TNW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         };
         int toffr[NTAPS];                         // tap -> patch byte offset, in scalar registers
 #pragma unroll
@@ -395,7 +401,7 @@ __global__ __launch_bounds__(512) void wtile2_kernel(const XmcConvDesc d, const 
 #pragma unroll
             for (int k = 0; k < TM; ++k) P[0][k] = rdp(pa, 0, k);
 #pragma unroll
-            for (int k = 0; k < TN; ++k) Wf[k] = rdw(wring, 0, k);
+            for (int k = 0; k < TNW; ++k) Wf[k] = rdw(wring, 0, k);
         }
         // one stage: the MFMAs of both K sub-steps; during the second, the first fragments of the NEXT stage are fetched (its
         // weights were committed a stage ago, its patch -- at a slab change -- NTAPS-1 stages ago).  Past the end of the stream
@@ -407,8 +413,10 @@ __global__ __launch_bounds__(512) void wtile2_kernel(const XmcConvDesc d, const 
                 const unsigned char* rwb = sub == 0 ? wb : nwb;
                 const int rsub = sub == 0 ? 1 : 0;
 #pragma unroll
-                for (int mj = 0; mj < TN; ++mj) {
-                    if (mj < TM && !(WT_ABL & 4)) P[sub ^ 1][mj] = rdp(rpa, rsub, mj);
+                for (int mj = 0; mj < TNW; ++mj) {
+#pragma unroll
+                    for (int k = mj; k < TM; k += TNW)          // the TM pixel-fragment reads of the sub-step, dealt over its columns
+                        if (!(WT_ABL & 4)) P[sub ^ 1][k] = rdp(rpa, rsub, k);
 #pragma unroll
                     for (int mi = 0; mi < TM; ++mi)
                         acc[mi][mj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, Wf[mj]),
@@ -503,7 +511,7 @@ int plan(const XmcConvDesc* d, WtCfg* t, int* mode, int* tn) {
     return 1;
 }
 
-template <int NTAPS, int MODE, int TN>
+template <int NTAPS, int MODE, int TN, int CW>
 int launch(const XmcConvDesc& d, const WtCfg& t, hipStream_t st) {
     constexpr int BN = 16 * TN;
     const size_t lds = (size_t)3 * BN * 128 + 2 * (size_t)t.patch_bytes;
@@ -512,10 +520,10 @@ int launch(const XmcConvDesc& d, const WtCfg& t, hipStream_t st) {
     int gx = 256 / (ny * d.nclass);               // one 8-wave workgroup per CU, persistent over its tiles
     if (gx < 1) gx = 1;
     if (gx > ntiles) gx = ntiles;
-    XMC_ALLOW_BIG_LDS((wtile2_kernel<NTAPS, MODE, TN>));
-    hipLaunchKernelGGL((wtile2_kernel<NTAPS, MODE, TN>), dim3((unsigned)gx, (unsigned)ny, (unsigned)d.nclass), dim3(512), lds, st, d, t,
+    XMC_ALLOW_BIG_LDS((wtile2_kernel<NTAPS, MODE, TN, CW>));
+    hipLaunchKernelGGL((wtile2_kernel<NTAPS, MODE, TN, CW>), dim3((unsigned)gx, (unsigned)ny, (unsigned)d.nclass), dim3(64 * CW + 256), lds, st, d, t,
                        ntiles);
-    xmc_note_kernel("wtile2_kernel<%d, %d, %d>", NTAPS, MODE, TN);
+    xmc_note_kernel("wtile2_kernel<%d, %d, %d, %d>", NTAPS, MODE, TN, CW);
     XMC_LAUNCH_CHECK();
     return 0;
 }
@@ -529,8 +537,11 @@ int xmc_conv_wtile_try(const XmcConvDesc* d, void* stream) {
     if (!plan(d, &t, &mode, &tn)) return 1;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     int rc;
-    if (mode == 1) rc = tn == 8 ? launch<4, 1, 8>(*d, t, st) : launch<4, 1, 4>(*d, t, st);
-    else if (d->ntaps == 9) rc = tn == 8 ? launch<9, 0, 8>(*d, t, st) : launch<9, 0, 4>(*d, t, st);
-    else rc = tn == 8 ? launch<4, 0, 8>(*d, t, st) : launch<4, 0, 4>(*d, t, st);
+    static const bool cw4 = xmc_debug_off("wtile_cw4");      // A/B: one compute wave per SIMD
+#define WT_GO(NT_, MD_, TN_) (cw4 ? launch<NT_, MD_, TN_, 4>(*d, t, st) : launch<NT_, MD_, TN_, 8>(*d, t, st))
+    if (mode == 1) rc = tn == 8 ? WT_GO(4, 1, 8) : WT_GO(4, 1, 4);
+    else if (d->ntaps == 9) rc = tn == 8 ? WT_GO(9, 0, 8) : WT_GO(9, 0, 4);
+    else rc = tn == 8 ? WT_GO(4, 0, 8) : WT_GO(4, 0, 4);
+#undef WT_GO
     return rc == XMC_ESHAPE ? 1 : rc;
 }
