@@ -283,7 +283,7 @@ def main():
                    step_frac_of_bf16_peak=None if gf is None else round(imgs_s * gf / 1e3 / (PEAK_BF16_TFLOPS * world), 4))
         if roof is not None:
             out["roofline"] = roof
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:       # the CPU leg is timed on rank 0 of the single-GPU run only
             out["cpu_baseline"] = cpu_baseline(cfg, a.cfg, S)
         print(json.dumps(out), flush=True)
     if world > 1:
