@@ -316,6 +316,25 @@ int xmc_rows_sumsq(const float* x, float* ss, int B, int64_t cols, void* stream)
 int xmc_gp_finish(const float* ss, int B, float* gp, float* coef, void* stream);
 int xmc_rows_scale(const float* x, const float* coef, const float* g, float* y, int B, int64_t cols, void* stream);
 
+/* ---- per-sample concept algebra of the sentence-conditioned attention-modulation block (df_concept_gan.py:213-253, 273-326) ----
+ * One workgroup per sample.  Parameter-gradient buffers have the parameters' own shapes and must be ZEROED by the caller (the small
+ * ones are accumulated over the batch with f32 atomics; the sentence columns of the big ones are written by one thread each).
+ * E = TRAIN.NEF (<= 1024).  `hid` [B, 256]: the MLPs' layer-1 pre-activations, produced by head_fwd and consumed by head_bwd.
+ * `scratch`: B*64 (query_bwd) / B*256 (head_bwd) floats of workspace.
+ *  query: q[b, g*4+o] = GroupNorm_4(Wq[g*4+o, :] . sent[b])   (CondConceptSampler.query_gconv + gn1; gnw = gnb = NULL: no norm)
+ *  head : v = value_gconv(ctx); r = ConceptReasoner(v); gamma / beta = grouped MLP([sent ; r])   (238-253, 291-326)
+ *         params / grads: 10 pointers in the order value_gconv.weight [64,8], proj_edge.weight [16,4], then for gamma and for
+ *         beta: layer-1 weight [128, E+4], bias [128], layer-2 weight [128, 8], bias [128]. */
+int xmc_concept_query_fwd(const float* sent, const float* Wq, const float* gnw, const float* gnb, float* q, float* qraw,
+                          int B, int E, float eps, void* stream);
+int xmc_concept_query_bwd(const float* sent, const float* Wq, const float* gnw, const float* qraw, const float* dq, float* dsent,
+                          float* dWq, float* dgnw, float* dgnb, float* scratch, int B, int E, float eps, void* stream);
+int xmc_concept_head_fwd(const float* ctx, const float* sent, const float* const* params, float* gamma, float* beta, float* hid,
+                         int B, int E, void* stream);
+int xmc_concept_head_bwd(const float* ctx, const float* sent, const float* hid, const float* const* params, const float* dgamma,
+                         const float* dbeta, float* dctx, float* dsent, float* const* grads, float* scratch, int B, int E,
+                         void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -112,10 +112,12 @@ def compare_losses(prod, orac, rtol, atol):
     return worst
 
 
-def compare_grads(tap_rec, oracle_grads, rtol, name="", floor=1e-5, agg_rtol=None):
+def compare_grads(tap_rec, oracle_grads, rtol, name="", floor=1e-5, agg_rtol=None, loose=None):
     """Per-tensor relative L2 error of every gradient; None-ness must match.  Parameters with <= 4 elements (the block
     gammas: d/dgamma = <dout, residual>, and conv_out's 3-channel bias: heavily cancelling sums over every pixel) are
-    compared on the scale of the largest such gradient in the same backward instead of their own magnitude."""
+    compared on the scale of the largest such gradient in the same backward instead of their own magnitude.
+    `loose` = (predicate on the parameter name, factor): per-tensor tolerance x factor for the tensors it selects (they still
+    count in the aggregate)."""
     worst = 0.0
     num2 = den2 = 0.0
     sc_scale = max([go.abs().max().item() for go in oracle_grads.values() if go is not None and go.numel() <= 4] + [0.0])
@@ -136,7 +138,8 @@ def compare_grads(tap_rec, oracle_grads, rtol, name="", floor=1e-5, agg_rtol=Non
         worst = max(worst, err)
         num2 += (gp - go).double().pow(2).sum().item()
         den2 += go.double().pow(2).sum().item()
-        assert err <= rtol, f"{name}{n}: rel error {err:.3e} > {rtol}"
+        tol = rtol * (loose[1] if loose is not None and loose[0](n) else 1.0)
+        assert err <= tol, f"{name}{n}: rel error {err:.3e} > {tol}"
     if agg_rtol is not None:      # all gradient tensors of this backward taken as one vector
         agg = (num2 / max(den2, 1e-300)) ** 0.5
         assert agg <= agg_rtol, f"{name}aggregate gradient error {agg:.3e} > {agg_rtol}"

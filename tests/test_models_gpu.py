@@ -135,6 +135,18 @@ def test_train_iteration_parity(yml, over, batch, steps, mode):
     gi = di = 0
     worst = dict(loss=0.0, D=0.0, GP=0.0, G=0.0)
     fl = 1e-5 if mode == "fp32" else 2e-2      # gradient tensors below this fraction of the largest norm are compared on that scale
+    loose = None
+    if mode == "bf16" and h.gen != "DF_GEN":
+        # Parameters upstream of the region-attention LOGITS (query / key projections and their GroupNorms).  Their gradient is
+        # sum_p a_p (<dctx, x_p> - <dctx, ctx>) k_p over up to 16 384 regions: with the synthetic weights the attention is close
+        # to uniform, the bracket cancels almost completely, and what is left of it at bf16 storage of x has a signal-to-noise
+        # ratio around 1 at this size (3 samples, 8 channels).  Measured with tests/diag/concept_grad_probe.py: these tensors
+        # sit 0.4-0.9 from the f32 oracle AND 0.2-1.7 from the product's own previous run on identical inputs (the f32 atomics
+        # order of the GroupNorm sums flips a few bf16 roundings, which redraws every rounding downstream), both before and
+        # after the concept algebra moved into csrc/concept.hip, while in fp32 mode the same kernels on the same shapes agree
+        # with the oracle to 1e-3 (this test, mode fp32).  The per-tensor bound for them is therefore a guard against gross
+        # errors only (sign, scale, NaN); they stay in the aggregate bound with everything else.
+        loose = (lambda n: "concept_sampler" in n and n.split(".")[-2] in ("query_gconv", "key_gconv", "gn1", "gn2"), 6.0)
     for s in range(steps):
         # Step 0 is the strict kernel-accuracy check (identical weights on both sides).  Later steps start from weights
         # that differ in the last bits (f32 atomics order in the weight-gradient kernels is not deterministic), and the
@@ -157,7 +169,7 @@ def test_train_iteration_parity(yml, over, batch, steps, mode):
         if h.magp:      # (aggregate tolerance x4: the loss is ||g||^6, the relative error of the norm enters 5-fold)
             worst["GP"] = max(worst["GP"], compare_grads(tapD.records[di], o_outs[s]["grads_GP"], t["grad"] * 2 * k, f"step{s} GP ", fl, t["agg"] * 4 * k)); di += 1
         if "grads_G" in o_outs[s]:
-            worst["G"] = max(worst["G"], compare_grads(tapG.records[gi], o_outs[s]["grads_G"], t["grad"] * k, f"step{s} G ", fl, t["agg"] * k)); gi += 1
+            worst["G"] = max(worst["G"], compare_grads(tapG.records[gi], o_outs[s]["grads_G"], t["grad"] * k, f"step{s} G ", fl, t["agg"] * k, loose)); gi += 1
     assert di == len(tapD.records) and gi == len(tapG.records)
     print(f"\n[parity {mode} {yml} {over}] worst rel err: " + ", ".join(f"{k}={v:.2e}" for k, v in worst.items()))
 

@@ -569,3 +569,54 @@ def test_grad_penalty_matches_reference_expression():
         assert abs(gp.item() - ref.item()) <= 1e-5 * abs(ref.item())
         for d_, r_ in zip(dev, ref_in):
             torch.testing.assert_close(d_.grad.cpu().double(), 2.0 * r_.grad, rtol=1e-5, atol=1e-7 * float(r_.grad.abs().max()))
+
+
+def test_concept_algebra_kernels_match_composed_reference():
+    """xmc_concept_query / xmc_concept_head (csrc/concept.hip) against the composed f64 expressions of the reference
+    (df_concept_gan.py:238-253, 273-326): outputs and every gradient (inputs and all parameters)."""
+    g = torch.Generator().manual_seed(5)
+    B, E = 5, 256
+    rnd = lambda *s, sc=1.0: torch.randn(*s, generator=g) * sc
+    sent = rnd(B, E)
+    wq, gnw, gnb = rnd(64, E, 1, 1, sc=E ** -0.5), 1 + 0.1 * rnd(64), 0.1 * rnd(64)
+    pooled = rnd(B, 16, 8)
+    P = [rnd(64, 8, 1, 1, sc=0.4), rnd(16, 4, sc=0.5)]
+    for _ in range(2):
+        P += [rnd(128, E + 4, 1, 1, sc=(E + 4) ** -0.5), 0.1 * rnd(128), rnd(128, 8, 1, 1, sc=0.35), 0.1 * rnd(128)]
+
+    def ref(sent, wq, gnw, gnb, pooled, P, norm):
+        q = torch.einsum('bi,goi->bgo', sent, wq.view(16, 4, E))
+        if norm:
+            q = F.group_norm(q.reshape(B, 64), 16, gnw, gnb).view(B, 16, 4)
+        v = torch.einsum('bgi,goi->bgo', pooled, P[0].view(16, 4, 8))
+        adj = torch.tanh(F.linear(v, P[1]))
+        r = F.relu(v + torch.matmul(adj, v))
+        cond = torch.cat([sent.view(B, 1, E).expand(B, 16, E), r], dim=2)
+        outs = []
+        for t in range(2):
+            w1, b1, w2, b2 = P[2 + 4 * t: 6 + 4 * t]
+            h = F.leaky_relu(torch.einsum('bgi,goi->bgo', cond, w1.view(16, 8, E + 4)) + b1.view(1, 16, 8), 0.2)
+            outs.append((torch.einsum('bgi,goi->bgo', h, w2.view(16, 8, 8)) + b2.view(1, 16, 8)).reshape(B, 128))
+        return q, outs[0], outs[1]
+
+    for norm in (True, False):
+        ins64 = [t.double().requires_grad_() for t in (sent, wq, gnw, gnb, pooled)] + [[p.double().requires_grad_() for p in P]]
+        q_r, ga_r, be_r = ref(*ins64, norm)
+        wts = [rnd(*t.shape).double() for t in (q_r, ga_r, be_r)]
+        (q_r * wts[0]).sum().add((ga_r * wts[1]).sum()).add((be_r * wts[2]).sum()).backward()
+        d = lambda t: t.to(DEV).requires_grad_()
+        sent_d, wq_d, gnw_d, gnb_d, pooled_d = d(sent), d(wq), d(gnw), d(gnb), d(pooled)
+        P_d = [d(p) for p in P]
+        q = ops.concept_query(sent_d, wq_d, gnw_d if norm else None, gnb_d if norm else None)
+        ga, be = ops.concept_head(pooled_d, sent_d, P_d)
+        ((q * wts[0].float().to(DEV)).sum() + (ga * wts[1].float().to(DEV)).sum() + (be * wts[2].float().to(DEV)).sum()).backward()
+        tol_ = dict(rtol=2e-4, atol=2e-5)
+        torch.testing.assert_close(q.detach().cpu().double(), q_r.detach(), **tol_)
+        torch.testing.assert_close(ga.detach().cpu().double(), ga_r.detach(), **tol_)
+        torch.testing.assert_close(be.detach().cpu().double(), be_r.detach(), **tol_)
+        pairs = [(sent_d, ins64[0]), (wq_d, ins64[1]), (pooled_d, ins64[4])] + list(zip(P_d, ins64[5]))
+        if norm:
+            pairs += [(gnw_d, ins64[2]), (gnb_d, ins64[3])]
+        for got, want in pairs:
+            sc_ = float(want.grad.abs().max())
+            torch.testing.assert_close(got.grad.cpu().double(), want.grad, rtol=5e-4, atol=5e-5 * max(sc_, 1e-3))

@@ -1,0 +1,393 @@
+// Per-sample "concept algebra" of the sentence-conditioned attention-modulation block (InConceptBlock, df_concept_gan.py:213-253
+// with CondConceptSampler 273-302, ConceptReasoner 313-326 and the gamma/beta grouped MLPs 178-200), forward and backward.
+//
+// Everything here lives on [16 concepts x <= 260] numbers per sample.  The reference (and round 1 of this build) runs it as ~80
+// tiny framework launches per sampler (einsum, linear, tanh, matmul, relu, cat, leaky_relu, group_norm and their backward
+// nodes): ~1 900 launches of 4-5 us per iteration at 128 px, a quarter of the iteration.  Here a stage is one or two launches:
+//
+//   xmc_concept_query_fwd/bwd : q[g,:] = GroupNorm_4( Wq[g] (4 x nef) . sent )                        (273-286; gn1)
+//   xmc_concept_head_fwd/bwd  : v = Wv[g] ctx[g];  adj = tanh(v We^T);  r = relu(v + adj v);                (291-302, 313-326)
+//                               for t in {gamma, beta}:  a = W1_t[g] [sent ; r[g]] + b1_t;  out_t = W2_t[g] lrelu(a) + b2_t   (238-253)
+//
+// The only part with any arithmetic in it is the sentence vector against the 64 (query) / 256 (MLP layer 1) weight rows of nef
+// columns.  Forward: one workgroup per sample, lanes ALONG the nef columns (coalesced 16-byte weight loads, the L2-resident
+// matrix is read once per sample), 64 rows' partial sums per wave reduced by a 63-shuffle transpose-reduce that leaves row l's
+// sum in lane l.  Backward: the per-sample kernel writes d(pre-activation) [B, rows]; a second launch forms the two batch
+// products  dW[r, i] = sum_b d[b, r] sent[b, i]  and  dsent[b, i] = sum_r d[b, r] W[r, i]  with lanes along i and one writer per
+// element (no atomics).  The remaining parameter gradients (a few hundred numbers) are accumulated with f32 atomics into
+// buffers the caller zeroed.
+#include "common.h"
+
+namespace {
+
+constexpr int CARD = 16, SD = 4, PWD = 8;     // concepts, state dim p', bottleneck width p (df_concept_gan.py:110,118)
+constexpr int HID = CARD * 2 * SD;            // 128 layer-1 units per MLP
+
+__device__ __forceinline__ float lrelu02(float v) { return v > 0.f ? v : 0.2f * v; }
+
+template <int S>
+__device__ __forceinline__ void tr_step(float (&p)[64], int lane) {
+    const bool hi = (lane & S) != 0;
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+        const float send = hi ? p[j] : p[j + S];
+        const float keep = hi ? p[j + S] : p[j];
+        p[j] = keep + __shfl_xor(send, S, 64);
+    }
+}
+
+// one wave: returns in lane l  sum_i W[l*ld + i] * x[i]  (i < E; x in shared memory)
+__device__ __forceinline__ float rows_dot64(const float* __restrict__ W, int ld, const float* x, int E, int lane) {
+    float p[64];
+#pragma unroll
+    for (int j = 0; j < 64; ++j) p[j] = 0.f;
+    if (((E | ld) & 3) == 0) {
+        for (int i0 = lane * 4; i0 < E; i0 += 256) {
+            const float4 s = *reinterpret_cast<const float4*>(x + i0);
+#pragma unroll
+            for (int j = 0; j < 64; ++j) {
+                const float4 w = *reinterpret_cast<const float4*>(W + (size_t)j * ld + i0);
+                p[j] += w.x * s.x + w.y * s.y + w.z * s.z + w.w * s.w;
+            }
+        }
+    } else {
+        for (int i0 = lane; i0 < E; i0 += 64) {
+            const float s = x[i0];
+#pragma unroll
+            for (int j = 0; j < 64; ++j) p[j] += W[(size_t)j * ld + i0] * s;
+        }
+    }
+    tr_step<32>(p, lane); tr_step<16>(p, lane); tr_step<8>(p, lane);
+    tr_step<4>(p, lane);  tr_step<2>(p, lane);  tr_step<1>(p, lane);
+    return p[0];
+}
+
+// ------------------------------------------------------------------------------------------------ batch products of a backward
+// D [B, R] (d pre-activation), X [B, C] (the sentence vectors); rows [k*Rp, (k+1)*Rp) of D belong to weight W[k] [Rp, ldw].
+// blocks [0, R/2): dW rows 2*blk, 2*blk+1 (written: columns [0, C));   blocks [R/2, R/2+B): dX[b, :] (written)
+struct OuterArgs {
+    const float* D; const float* X; const float* W[2]; float* dW[2]; float* dX;
+    int B, R, Rp, C, ldw;
+};
+__global__ __launch_bounds__(256) void concept_outer_kernel(OuterArgs a) {
+    const int blk = blockIdx.x;
+    if (blk < a.R / 2) {
+        const int r0 = blk * 2, k = r0 / a.Rp, rr = r0 - k * a.Rp;
+        for (int c = threadIdx.x; c < a.C; c += 256) {
+            float s0 = 0.f, s1 = 0.f;
+            for (int b = 0; b < a.B; ++b) {
+                const float x = a.X[(size_t)b * a.C + c];
+                s0 += a.D[(size_t)b * a.R + r0] * x;
+                s1 += a.D[(size_t)b * a.R + r0 + 1] * x;
+            }
+            a.dW[k][(size_t)rr * a.ldw + c] = s0;
+            a.dW[k][(size_t)(rr + 1) * a.ldw + c] = s1;
+        }
+    } else {
+        const int b = blk - a.R / 2;
+        for (int c = threadIdx.x; c < a.C; c += 256) {
+            float s = 0.f;
+            for (int k = 0; k * a.Rp < a.R; ++k) {
+                const float* w = a.W[k];
+                const float* dd = a.D + (size_t)b * a.R + k * a.Rp;
+#pragma unroll 8
+                for (int r = 0; r < a.Rp; ++r) s += dd[r] * w[(size_t)r * a.ldw + c];
+            }
+            a.dX[(size_t)b * a.C + c] = s;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ query
+// sent [B, E]; Wq [CARD*SD, E] (grouped 1x1: row g*SD+o is group g's output o over the WHOLE sentence vector: the reference
+// feeds every group the same sentence, 276-280); gnw/gnb [CARD*SD] or NULL (GEN.NORMALIZE False); q, qraw [B, CARD*SD]
+__global__ __launch_bounds__(64) void concept_query_fwd_kernel(const float* __restrict__ sent, const float* __restrict__ Wq,
+                                                              const float* __restrict__ gnw, const float* __restrict__ gnb,
+                                                              float* __restrict__ q, float* __restrict__ qraw, int E, float eps) {
+    __shared__ __attribute__((aligned(16))) float s_sent[1024];
+    const int b = blockIdx.x, c = threadIdx.x;        // c = g*SD + o
+    for (int i = c; i < E; i += 64) s_sent[i] = sent[(size_t)b * E + i];
+    __syncthreads();
+    float x = rows_dot64(Wq, E, s_sent, E, c);
+    qraw[(size_t)b * 64 + c] = x;
+    if (gnw) {                                        // GroupNorm over the SD values of a concept
+        float m = x + __shfl_xor(x, 1, 64); m += __shfl_xor(m, 2, 64); m *= 0.25f;
+        const float dx = x - m;
+        float v = dx * dx; v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v *= 0.25f;
+        x = dx * rsqrtf(v + eps) * gnw[c] + gnb[c];
+    }
+    q[(size_t)b * 64 + c] = x;
+}
+
+// dq [B,64] -> dx [B,64] (d of the grouped 1x1's output, for concept_outer_kernel); dgnw/dgnb [64] atomically accumulated
+__global__ __launch_bounds__(64) void concept_query_bwd_kernel(const float* __restrict__ gnw, const float* __restrict__ qraw,
+                                                              const float* __restrict__ dq, float* __restrict__ dx,
+                                                              float* __restrict__ dgnw, float* __restrict__ dgnb, float eps) {
+    const int b = blockIdx.x, c = threadIdx.x;
+    const float x = qraw[(size_t)b * 64 + c];
+    float g = dq[(size_t)b * 64 + c];
+    if (gnw) {
+        float m = x + __shfl_xor(x, 1, 64); m += __shfl_xor(m, 2, 64); m *= 0.25f;
+        const float dxm = x - m;
+        float v = dxm * dxm; v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v *= 0.25f;
+        const float rstd = rsqrtf(v + eps), xh = dxm * rstd;
+        atomicAdd(&dgnw[c], g * xh);
+        atomicAdd(&dgnb[c], g);
+        const float gh = g * gnw[c];
+        float s1 = gh + __shfl_xor(gh, 1, 64); s1 += __shfl_xor(s1, 2, 64); s1 *= 0.25f;
+        float s2 = gh * xh; s2 += __shfl_xor(s2, 1, 64); s2 += __shfl_xor(s2, 2, 64); s2 *= 0.25f;
+        g = rstd * (gh - s1 - xh * s2);
+    }
+    dx[(size_t)b * 64 + c] = g;
+}
+
+// ------------------------------------------------------------------------------------------------ head
+struct HeadParams {
+    const float* Wv;       // [CARD*SD, PWD]     value_gconv (grouped 1x1, no bias)
+    const float* We;       // [CARD, SD]         ConceptReasoner.proj_edge
+    const float* W1[2];    // [HID, E+SD]        gamma / beta MLP layer 1 (grouped): columns [0,E) sentence, [E,E+SD) concept state
+    const float* b1[2];    // [HID]
+    const float* W2[2];    // [CARD*PWD, 2*SD]   layer 2 (grouped)
+    const float* b2[2];    // [CARD*PWD]
+};
+struct HeadGrads {
+    float* Wv; float* We; float* W1[2]; float* b1[2]; float* W2[2]; float* b2[2];
+};
+
+// reasoner state of one sample in shared memory; every array is indexed [g][.]
+struct HeadState {
+    float ctx[CARD][PWD];      // input
+    float v[CARD][SD];
+    float adj[CARD][CARD];
+    float pre[CARD][SD];       // v + adj v  (before the ReLU)
+    float r[CARD][SD];
+    float a[2][CARD][2 * SD];  // layer-1 pre-activations
+};
+
+// value projection + ConceptReasoner by the first wave of the workgroup (tid < 64: lane = (g, d)); ends with a barrier for all
+__device__ __forceinline__ void reasoner_forward(HeadState& S, const HeadParams& P, int tid) {
+    const int g = (tid >> 2) & 15, d = tid & 3;
+    if (tid < 64) {   // v[g][d] = sum_i Wv[g*SD+d][i] ctx[g][i]
+        float x = 0.f;
+#pragma unroll
+        for (int i = 0; i < PWD; ++i) x += P.Wv[(g * SD + d) * PWD + i] * S.ctx[g][i];
+        S.v[g][d] = x;
+    }
+    __syncthreads();
+    if (tid < 64) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {      // adj[g][k] = tanh(sum_d v[g][d] We[k][d]); lane (g, d) does k = d*4 + kk
+            const int k = d * 4 + kk;
+            float e = 0.f;
+#pragma unroll
+            for (int dd = 0; dd < SD; ++dd) e += S.v[g][dd] * P.We[k * SD + dd];
+            S.adj[g][k] = tanhf(e);
+        }
+    }
+    __syncthreads();
+    if (tid < 64) {
+        float m = 0.f;
+#pragma unroll
+        for (int k = 0; k < CARD; ++k) m += S.adj[g][k] * S.v[k][d];
+        const float p = S.v[g][d] + m;
+        S.pre[g][d] = p;
+        S.r[g][d] = fmaxf(p, 0.f);
+    }
+    __syncthreads();
+}
+
+// ctx [B,CARD,PWD], sent [B,E] -> gamma, beta [B, CARD*PWD], hid [B, 2*HID] (layer-1 pre-activations, kept for the backward)
+__global__ __launch_bounds__(256) void concept_head_fwd_kernel(const float* __restrict__ ctx, const float* __restrict__ sent,
+                                                              HeadParams P, float* __restrict__ gamma, float* __restrict__ beta,
+                                                              float* __restrict__ hid, int E) {
+    __shared__ HeadState S;
+    __shared__ __attribute__((aligned(16))) float s_sent[1024];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < CARD * PWD) (&S.ctx[0][0])[tid] = ctx[(size_t)b * CARD * PWD + tid];
+    for (int i = tid; i < E; i += 256) s_sent[i] = sent[(size_t)b * E + i];
+    __syncthreads();
+    // thread tid owns layer-1 unit (t, row) = (tid >> 7, tid & 127), row = g*8 + o
+    const int t = wave >> 1, row = (wave & 1) * 64 + lane, ld = E + SD;
+    float a = rows_dot64(P.W1[t] + (size_t)(wave & 1) * 64 * ld, ld, s_sent, E, lane) + P.b1[t][row];
+    reasoner_forward(S, P, tid);
+    {
+        const int g = row >> 3;
+        const float* w = P.W1[t] + (size_t)row * ld + E;
+#pragma unroll
+        for (int dd = 0; dd < SD; ++dd) a += w[dd] * S.r[g][dd];
+        (&S.a[t][0][0])[row] = a;
+        hid[(size_t)b * 2 * HID + tid] = a;
+    }
+    __syncthreads();
+    {   // out[t][g][o]: the same (t, row) indexing, row = g*PWD + o
+        const int g = row >> 3;
+        float x = P.b2[t][row];
+#pragma unroll
+        for (int i = 0; i < 2 * SD; ++i) x += P.W2[t][row * 2 * SD + i] * lrelu02(S.a[t][g][i]);
+        (t == 0 ? gamma : beta)[(size_t)b * CARD * PWD + row] = x;
+    }
+}
+
+// dgamma, dbeta [B, CARD*PWD], hid -> dctx [B,CARD,PWD] (written), da [B, 2*HID] (written: d of the layer-1 pre-activations,
+// for concept_outer_kernel), small parameter gradients (atomics)
+__global__ __launch_bounds__(64) void concept_head_bwd_kernel(const float* __restrict__ ctx, const float* __restrict__ hid,
+                                                             HeadParams P, const float* __restrict__ dgamma,
+                                                             const float* __restrict__ dbeta, float* __restrict__ dctx,
+                                                             float* __restrict__ da_out, HeadGrads G, int E) {
+    __shared__ HeadState S;
+    __shared__ float s_do[2][CARD][PWD], s_da[2][CARD][2 * SD], s_dr[CARD][SD], s_dm[CARD][SD], s_de[CARD][CARD], s_dv[CARD][SD];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int g = tid >> 2, d = tid & 3;
+    for (int i = tid; i < CARD * PWD; i += 64) {
+        (&S.ctx[0][0])[i] = ctx[(size_t)b * CARD * PWD + i];
+        (&s_do[0][0][0])[i] = dgamma[(size_t)b * CARD * PWD + i];
+        (&s_do[1][0][0])[i] = dbeta[(size_t)b * CARD * PWD + i];
+    }
+    for (int i = tid; i < 2 * HID; i += 64) (&S.a[0][0][0])[i] = hid[(size_t)b * 2 * HID + i];
+    __syncthreads();
+    reasoner_forward(S, P, tid);
+    const int ld = E + SD;
+    // ---- layer 2: out = W2 lrelu(a) + b2
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {     // lane owns hidden unit i = d*2+h of group g: dh_i = sum_o W2[o][i] do[o]
+            const int i = d * 2 + h;
+            float dh = 0.f;
+#pragma unroll
+            for (int o = 0; o < PWD; ++o) dh += P.W2[t][(g * PWD + o) * 2 * SD + i] * s_do[t][g][o];
+            const float ai = S.a[t][g][i];
+            const float da = dh * (ai > 0.f ? 1.f : 0.2f);
+            s_da[t][g][i] = da;
+            da_out[(size_t)b * 2 * HID + t * HID + g * 2 * SD + i] = da;
+            // dW2[o][i] += do[o] * lrelu(a_i)  for all o;  db2 via i running over 0..7 = the PWD outputs as well
+            const float hi = lrelu02(ai);
+#pragma unroll
+            for (int o = 0; o < PWD; ++o) atomicAdd(&G.W2[t][(g * PWD + o) * 2 * SD + i], s_do[t][g][o] * hi);
+            atomicAdd(&G.b2[t][g * PWD + i], s_do[t][g][i]);
+            // layer 1's concept-state columns and bias
+            float* gw = G.W1[t] + (size_t)(g * 2 * SD + i) * ld;
+#pragma unroll
+            for (int dd = 0; dd < SD; ++dd) atomicAdd(&gw[E + dd], da * S.r[g][dd]);
+            atomicAdd(&G.b1[t][g * 2 * SD + i], da);
+        }
+    }
+    __syncthreads();
+    {   // d r[g][d] through layer 1's concept-state columns
+        float dr = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int o = 0; o < 2 * SD; ++o) dr += P.W1[t][(size_t)(g * 2 * SD + o) * ld + E + d] * s_da[t][g][o];
+        s_dr[g][d] = dr;
+        // ---- reasoner: r = relu(pre), pre = v + adj v, adj = tanh(v We^T)
+        s_dm[g][d] = S.pre[g][d] > 0.f ? dr : 0.f;          // d pre (= d m, and the direct part of d v)
+    }
+    __syncthreads();
+    {
+        float dv = s_dm[g][d];    // direct
+#pragma unroll
+        for (int gg = 0; gg < CARD; ++gg) dv += S.adj[gg][g] * s_dm[gg][d];      // through m[gg] = sum_k adj[gg][k] v[k]
+        s_dv[g][d] = dv;
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {      // d adj[g][k] = sum_d dm[g][d] v[k][d];  de = dadj * (1 - adj^2)
+        const int k = d * 4 + kk;
+        float da = 0.f;
+#pragma unroll
+        for (int dd = 0; dd < SD; ++dd) da += s_dm[g][dd] * S.v[k][dd];
+        const float aj = S.adj[g][k];
+        s_de[g][k] = da * (1.f - aj * aj);
+    }
+    __syncthreads();
+    {
+        float dv = s_dv[g][d];
+#pragma unroll
+        for (int k = 0; k < CARD; ++k) dv += s_de[g][k] * P.We[k * SD + d];       // e[g][k] = sum_d v[g][d] We[k][d]
+        s_dv[g][d] = dv;
+        // dWe[k][d] += sum_g de[g][k] v[g][d]: lane (g, d) reused as (k = g, d)
+        float dwe = 0.f;
+#pragma unroll
+        for (int gg = 0; gg < CARD; ++gg) dwe += s_de[gg][g] * S.v[gg][d];
+        atomicAdd(&G.We[g * SD + d], dwe);
+    }
+    __syncthreads();
+    // ---- value projection: v[g][d] = sum_i Wv[g*SD+d][i] ctx[g][i]
+    {
+        const float dv = s_dv[g][d];
+#pragma unroll
+        for (int i = 0; i < PWD; ++i) atomicAdd(&G.Wv[(g * SD + d) * PWD + i], dv * S.ctx[g][i]);
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int i = d * 2 + h;
+        float dc = 0.f;
+#pragma unroll
+        for (int dd = 0; dd < SD; ++dd) dc += P.Wv[(g * SD + dd) * PWD + i] * s_dv[g][dd];
+        dctx[(size_t)b * CARD * PWD + g * PWD + i] = dc;
+    }
+}
+
+}  // namespace
+
+#define ST(s) reinterpret_cast<hipStream_t>(s)
+
+extern "C" int xmc_concept_query_fwd(const float* sent, const float* Wq, const float* gnw, const float* gnb, float* q, float* qraw,
+                                     int B, int E, float eps, void* stream) {
+    if (!sent || !Wq || !q || !qraw || B < 1 || E < 1 || E > 1024 || (gnw == nullptr) != (gnb == nullptr)) return XMC_EINVAL;
+    hipLaunchKernelGGL(concept_query_fwd_kernel, dim3(B), dim3(64), 0, ST(stream), sent, Wq, gnw, gnb, q, qraw, E, eps);
+    XMC_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int xmc_concept_query_bwd(const float* sent, const float* Wq, const float* gnw, const float* qraw, const float* dq,
+                                     float* dsent, float* dWq, float* dgnw, float* dgnb, float* scratch, int B, int E, float eps,
+                                     void* stream) {
+    if (!sent || !Wq || !qraw || !dq || !dsent || !dWq || !scratch || B < 1 || E < 1) return XMC_EINVAL;
+    if (gnw && (!dgnw || !dgnb)) return XMC_EINVAL;
+    hipLaunchKernelGGL(concept_query_bwd_kernel, dim3(B), dim3(64), 0, ST(stream), gnw, qraw, dq, scratch, dgnw, dgnb, eps);
+    XMC_LAUNCH_CHECK();
+    OuterArgs a;
+    a.D = scratch; a.X = sent; a.W[0] = Wq; a.W[1] = nullptr; a.dW[0] = dWq; a.dW[1] = nullptr; a.dX = dsent;
+    a.B = B; a.R = 64; a.Rp = 64; a.C = E; a.ldw = E;
+    hipLaunchKernelGGL(concept_outer_kernel, dim3(a.R / 2 + B), dim3(256), 0, ST(stream), a);
+    XMC_LAUNCH_CHECK();
+    return 0;
+}
+
+// params / grads: 10 pointers each in the order Wv, We, W1g, b1g, W2g, b2g, W1b, b1b, W2b, b2b
+static int head_params(const float* const* p, HeadParams& P) {
+    for (int i = 0; i < 10; ++i) if (!p[i]) return 0;
+    P.Wv = p[0]; P.We = p[1];
+    P.W1[0] = p[2]; P.b1[0] = p[3]; P.W2[0] = p[4]; P.b2[0] = p[5];
+    P.W1[1] = p[6]; P.b1[1] = p[7]; P.W2[1] = p[8]; P.b2[1] = p[9];
+    return 1;
+}
+extern "C" int xmc_concept_head_fwd(const float* ctx, const float* sent, const float* const* params, float* gamma, float* beta,
+                                    float* hid, int B, int E, void* stream) {
+    HeadParams P;
+    if (!ctx || !sent || !params || !gamma || !beta || !hid || B < 1 || E < 1 || E > 1024 || !head_params(params, P)) return XMC_EINVAL;
+    hipLaunchKernelGGL(concept_head_fwd_kernel, dim3(B), dim3(256), 0, ST(stream), ctx, sent, P, gamma, beta, hid, E);
+    XMC_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int xmc_concept_head_bwd(const float* ctx, const float* sent, const float* hid, const float* const* params,
+                                    const float* dgamma, const float* dbeta, float* dctx, float* dsent, float* const* grads,
+                                    float* scratch, int B, int E, void* stream) {
+    HeadParams P;
+    if (!ctx || !sent || !hid || !params || !dgamma || !dbeta || !dctx || !dsent || !grads || !scratch || B < 1 || E < 1 || E > 1024 ||
+        !head_params(params, P))
+        return XMC_EINVAL;
+    for (int i = 0; i < 10; ++i) if (!grads[i]) return XMC_EINVAL;
+    HeadGrads G;
+    G.Wv = grads[0]; G.We = grads[1];
+    G.W1[0] = grads[2]; G.b1[0] = grads[3]; G.W2[0] = grads[4]; G.b2[0] = grads[5];
+    G.W1[1] = grads[6]; G.b1[1] = grads[7]; G.W2[1] = grads[8]; G.b2[1] = grads[9];
+    hipLaunchKernelGGL(concept_head_bwd_kernel, dim3(B), dim3(64), 0, ST(stream), ctx, hid, P, dgamma, dbeta, dctx, scratch, G, E);
+    XMC_LAUNCH_CHECK();
+    OuterArgs a;
+    a.D = scratch; a.X = sent; a.W[0] = P.W1[0]; a.W[1] = P.W1[1]; a.dW[0] = G.W1[0]; a.dW[1] = G.W1[1]; a.dX = dsent;
+    a.B = B; a.R = 2 * HID; a.Rp = HID; a.C = E; a.ldw = E + SD;
+    hipLaunchKernelGGL(concept_outer_kernel, dim3(a.R / 2 + B), dim3(256), 0, ST(stream), a);
+    XMC_LAUNCH_CHECK();
+    return 0;
+}

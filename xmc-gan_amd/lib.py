@@ -90,6 +90,10 @@ _SIGS = {
     "xmc_hinge_fwd": [vp, i32, f32, vp, i64, i32, vp],
     "xmc_hinge_bwd": [vp, i32, f32, vp, vp, i64, i32, vp],
     "xmc_cast": [vp, vp, i64, i32, i32, vp],
+    "xmc_concept_query_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, f32, vp],
+    "xmc_concept_query_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp],
+    "xmc_concept_head_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, vp],
+    "xmc_concept_head_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
     "xmc_rows_sumsq": [vp, vp, i32, i64, vp],
     "xmc_gp_finish": [vp, i32, vp, vp, vp],
     "xmc_rows_scale": [vp, vp, vp, vp, i32, i64, vp],

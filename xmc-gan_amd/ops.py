@@ -1447,6 +1447,90 @@ class ContrastiveFn(torch.autograd.Function):
         return da, db, None, None
 
 
+class ConceptQueryFn(torch.autograd.Function):
+    """Sentence query of CondConceptSampler (df_concept_gan.py:273-286): grouped 1x1 on the sentence vector that every concept
+    receives + GroupNorm over each concept's 4 state values.  sent f32 [B,E], wq [64,E,1,1] -> q f32 [B,16,4]."""
+
+    @staticmethod
+    def forward(ctx, sent, wq, gnw, gnb, eps):
+        sent = sent.contiguous().float()
+        _need_cuda(sent, wq)
+        B, E = sent.shape
+        w = wq.detach().contiguous().float().view(64, E)
+        q = torch.empty(B, 64, dtype=torch.float32, device=sent.device)
+        qraw = torch.empty_like(q)
+        L.call("xmc_concept_query_fwd", _p(sent), _p(w), _p(gnw), _p(gnb), _p(q), _p(qraw), B, E, float(eps), _st())
+        ctx.eps, ctx.wshape = float(eps), tuple(wq.shape)
+        ctx.save_for_backward(sent, w, gnw, qraw)
+        return q.view(B, 16, 4)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dq):
+        sent, w, gnw, qraw = ctx.saved_tensors
+        B, E = sent.shape
+        dq = dq.contiguous().float()
+        dsent = torch.empty_like(sent)
+        flat = torch.zeros(64 * E + 128, dtype=torch.float32, device=sent.device)      # one fill for all accumulators
+        dw = flat[:64 * E].view(64, E)
+        dgw = flat[64 * E:64 * E + 64] if gnw is not None else None
+        dgb = flat[64 * E + 64:] if gnw is not None else None
+        scratch = torch.empty(B, 64, dtype=torch.float32, device=sent.device)
+        L.call("xmc_concept_query_bwd", _p(sent), _p(w), _p(gnw), _p(qraw), _p(dq), _p(dsent), _p(dw), _p(dgw), _p(dgb), _p(scratch),
+               B, E, ctx.eps, _st())
+        return dsent, dw.view(ctx.wshape), dgw, dgb, None
+
+
+class ConceptHeadFn(torch.autograd.Function):
+    """Everything between the region attention and the channel modulation of one sampler stage of InConceptBlock
+    (df_concept_gan.py:238-253, 291-326): value projection, ConceptReasoner, the gamma and beta grouped MLPs on
+    [sentence ; concept state].  pooled f32 [B,16,8], sent f32 [B,E], ten parameters -> (gamma, beta) f32 [B,128]."""
+
+    @staticmethod
+    def forward(ctx, pooled, sent, *params):
+        assert len(params) == 10
+        pooled, sent = pooled.contiguous().float(), sent.contiguous().float()
+        _need_cuda(pooled, sent)
+        B, E = sent.shape
+        ps = [p_.detach().contiguous().float() for p_ in params]
+        tab = (C.c_void_p * 10)(*[p_.data_ptr() for p_ in ps])
+        gamma = torch.empty(B, 128, dtype=torch.float32, device=sent.device)
+        beta = torch.empty_like(gamma)
+        hid = torch.empty(B, 256, dtype=torch.float32, device=sent.device)
+        L.call("xmc_concept_head_fwd", _p(pooled), _p(sent), tab, _p(gamma), _p(beta), _p(hid), B, E, _st())
+        ctx.shapes = [tuple(p_.shape) for p_ in params]
+        ctx.save_for_backward(pooled, sent, hid, *ps)
+        return gamma, beta
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dgamma, dbeta):
+        pooled, sent, hid, *ps = ctx.saved_tensors
+        B, E = sent.shape
+        dgamma, dbeta = dgamma.contiguous().float(), dbeta.contiguous().float()
+        dpooled, dsent = torch.empty_like(pooled), torch.empty_like(sent)
+        sizes = [(p_.numel() + 3) // 4 * 4 for p_ in ps]                      # 16-byte aligned slices of ONE zero-filled buffer
+        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=sent.device)
+        grads, off = [], 0
+        for p_, n_ in zip(ps, sizes):
+            grads.append(flat[off:off + p_.numel()].view(p_.shape))
+            off += n_
+        tab = (C.c_void_p * 10)(*[p_.data_ptr() for p_ in ps])
+        gtab = (C.c_void_p * 10)(*[g_.data_ptr() for g_ in grads])
+        scratch = torch.empty(B, 256, dtype=torch.float32, device=sent.device)
+        L.call("xmc_concept_head_bwd", _p(pooled), _p(sent), _p(hid), tab, _p(dgamma), _p(dbeta), _p(dpooled), _p(dsent), gtab,
+               _p(scratch), B, E, _st())
+        return (dpooled, dsent) + tuple(g_.view(sh) for g_, sh in zip(grads, ctx.shapes))
+
+
+def concept_query(sent, wq, gnw=None, gnb=None, eps=1e-5):
+    return ConceptQueryFn.apply(sent, wq, gnw, gnb, eps)
+
+
+def concept_head(pooled, sent, params):
+    return ConceptHeadFn.apply(pooled, sent, *params)
+
+
 class GradPenaltyFn(torch.autograd.Function):
     """mean_b ||[g0_b, g1_b, ...]||_2^6 over f32 gradient blocks [B, ...] (train_gan.py:241-247: cat, **2, sum, sqrt, **6,
     mean) in two passes over the data: per-sample sums of squares, then -- in the backward -- one scaled copy per block.

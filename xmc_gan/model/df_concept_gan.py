@@ -87,16 +87,19 @@ class _SamplerBase(nn.Module):
             self.gn1 = nn.GroupNorm(cardinality, sw)
             self.gn2 = nn.GroupNorm(cardinality, sw)
 
+    def pool(self, x, q, scale):
+        """region attention with an already normalised query: x [B,H,W,128], q [B,16,4] f32 -> pooled x [B,16,8]."""
+        key = self.key_gconv(x)
+        if self.normalize:
+            key = ops.groupnorm(key, self.gn2.weight, self.gn2.bias, self.cardinality)
+        return ops.attn_pool(key, q, x, self.cardinality, scale)
+
     def _attend(self, x, q, scale):
         """x [B,H,W,128], q [B,16,4] f32 -> value-projected context [B,16,4]."""
         B = x.size(0)
         if self.normalize:
             q = F.group_norm(q.reshape(B, -1), self.cardinality, self.gn1.weight, self.gn1.bias).view(B, self.cardinality, -1)
-        key = self.key_gconv(x)
-        if self.normalize:
-            key = ops.groupnorm(key, self.gn2.weight, self.gn2.bias, self.cardinality)
-        ctx = ops.attn_pool(key, q, x, self.cardinality, scale)            # [B,16,8]
-        return _grouped_vec(ctx, self.value_gconv)
+        return _grouped_vec(self.pool(x, q, scale), self.value_gconv)
 
 
 class CondConceptSampler(_SamplerBase):
@@ -165,11 +168,21 @@ class InConceptBlock(_ConceptBlockBase):
     def forward(self, x, sent_embs):
         B = x.size(0)
         out = self._trunk(x)
-        gc = sent_embs.view(B, 1, -1).expand(B, self.cardinality, -1)
+        sent = sent_embs.float()
         for samp, reas, gm, bm in ((self.concept_sampler1, self.concept_reasoner1, self.gamma1_gconv, self.beta1_gconv),
                                    (self.concept_sampler2, self.concept_reasoner2, self.gamma2_gconv, self.beta2_gconv)):
-            ctx = reas(samp(out, sent_embs))
-            out = self._modulate(out, gc, ctx, gm, bm)
+            if not x.is_cuda:
+                raise RuntimeError("InConceptBlock runs on the GPU only (no CPU fallback)")
+            # per-sample concept algebra in two kernels per stage (csrc/concept.hip) around the region attention:
+            #   sentence query + GroupNorm                                   (273-286)
+            #   value projection, ConceptReasoner, gamma / beta grouped MLPs (238-253, 291-326)
+            q = ops.concept_query(sent, samp.query_gconv.weight, samp.gn1.weight if samp.normalize else None,
+                                  samp.gn1.bias if samp.normalize else None)
+            pooled = samp.pool(out, q, 1.0)                                            # [B,16,8]
+            gamma, beta = ops.concept_head(pooled, sent, (
+                samp.value_gconv.weight, reas.proj_edge.weight,
+                gm[0].weight, gm[0].bias, gm[2].weight, gm[2].bias, bm[0].weight, bm[0].bias, bm[2].weight, bm[2].bias))
+            out = ops.affine_lrelu(out, gamma, beta)
         return out
 
 
