@@ -118,6 +118,12 @@ int xmc_conv_wgrad_bias(const XmcConvDesc* d, float* dwp, float* dbias, void* st
 /* dgrad pack: wpk[kh*KW+kw][ci][co]     (rows padded to CSw, cols to CDp)                                       */
 int xmc_pack_weight(const float* w, void* wpk, int Co, int Ci, int KH, int KW, int rows_pad, int cols_pad,
                     int transpose /*0 fwd, 1 dgrad*/, int dtype, const int32_t* row_perm /*NULL or [Co]*/, void* stream);
+/* same for an nn.Conv2d(groups=g) weight [Co][Ci/g][KH][KW] (df_concept_gan.py:146,267,546: 16 groups of 8 channels): the packed
+ * matrix is the block-diagonal expansion; xmc_unpack_wgrad_grouped reads the diagonal blocks back into gw [Co][Ci/g][KH][KW] */
+int xmc_pack_weight_grouped(const float* w, void* wpk, int Co, int Ci, int KH, int KW, int rows_pad, int cols_pad, int transpose,
+                            int dtype, const int32_t* row_perm, int groups, void* stream);
+int xmc_unpack_wgrad_grouped(const float* dwp, float* gw, int Co, int Ci, int KH, int KW, int rows_pad, int cols_pad,
+                             const float* scale_dev, const int32_t* row_perm, int accumulate, int groups, void* stream);
 /* Fused nearest-x2 upsample + 3x3 conv (F.interpolate(scale_factor=2) at df_gan.py:202 followed by the next block's c1, 187):
  * 16 slices wpk[(i*2+j)*4 + th*2+tw][...] of pre-summed weights, one 2x2-tap convolution per output parity (i,j) on the
  * LOW-resolution tensor -> 4/9 of the MACs and no materialised upsampled tensor.  Used with a 4-class tap table. */

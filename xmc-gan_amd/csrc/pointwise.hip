@@ -411,7 +411,9 @@ __global__ void hinge_bwd_kernel(const void* x, int stride, float sign, const fl
 // ------------------------------------------------------------------ weight pack / unpack
 template <int DT>
 __global__ void pack_weight_kernel(const float* w, void* wpk, int Co, int Ci, int KHW, int rows_pad, int cols_pad,
-                                   int transpose, const int32_t* row_perm) {
+                                   int transpose, const int32_t* row_perm, int groups) {
+    // groups > 1: w is a grouped-convolution weight [Co][Ci/groups][KHW]; the packed matrix is its block-diagonal expansion
+    const int cog = Co / groups, cig = Ci / groups;
     const int64_t total = (int64_t)KHW * rows_pad * cols_pad;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         int c = (int)(i % cols_pad);
@@ -422,7 +424,8 @@ __global__ void pack_weight_kernel(const float* w, void* wpk, int Co, int Ci, in
         float v = 0.f;
         if (co < Co && ci < Ci) {
             int sco = row_perm ? row_perm[co] : co;
-            v = w[((int64_t)sco * Ci + ci) * KHW + t];
+            if (groups == 1) v = w[((int64_t)sco * Ci + ci) * KHW + t];
+            else if (sco / cog == ci / cig) v = w[((int64_t)sco * cig + ci % cig) * KHW + t];
         }
         if (DT == XMC_BF16) reinterpret_cast<__bf16*>(wpk)[i] = (__bf16)v;
         else reinterpret_cast<float*>(wpk)[i] = v;
@@ -545,9 +548,11 @@ __global__ void axpby_bwd_kernel(const void* dy, const void* b, const float* alp
 
 __global__ void unpack_wgrad_kernel(const float* dwp, float* gw, int Co, int Ci, int KHW, int rows_pad, int cols_pad,
                                     const float* scale_dev, const int32_t* row_perm, int accumulate,
-                                    const float* gb_rep, float* gb, int CDb) {
+                                    const float* gb_rep, float* gb, int CDb, int groups) {
+    // groups > 1: gw is a grouped-convolution weight gradient [Co][Ci/groups][KHW] = the diagonal blocks of the dense one
     const float scale = scale_dev ? *scale_dev : 1.f;
-    const int64_t total = (int64_t)Co * Ci * KHW;
+    const int cog = Co / groups, cig = Ci / groups;
+    const int64_t total = (int64_t)Co * cig * KHW;
     // bias gradient: sum of the XMC_BIAS_REPLICAS partial column sums the weight-gradient kernels accumulate into
     // (packed channel order, like the rows of dwp); rides along instead of a separate reduction launch
     if (gb_rep) {
@@ -561,11 +566,11 @@ __global__ void unpack_wgrad_kernel(const float* dwp, float* gw, int Co, int Ci,
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         int t = (int)(i % KHW);
         int64_t q = i / KHW;
-        int ci = (int)(q % Ci);
-        int r = (int)(q / Ci);              // packed row r holds parameter row row_perm[r]
-        float v = scale * dwp[((int64_t)t * rows_pad + r) * cols_pad + ci];
+        int ci = (int)(q % cig);
+        int r = (int)(q / cig);             // packed row r holds parameter row row_perm[r]
         int dco = row_perm ? row_perm[r] : r;
-        int64_t o = ((int64_t)dco * Ci + ci) * KHW + t;
+        float v = scale * dwp[((int64_t)t * rows_pad + r) * cols_pad + (dco / cog) * cig + ci];
+        int64_t o = ((int64_t)dco * cig + ci) * KHW + t;
         gw[o] = accumulate ? gw[o] + v : v;
     }
 }
@@ -841,28 +846,36 @@ extern "C" int xmc_hinge_bwd(const void* x, int stride, float sign, const float*
     XMC_LAUNCH_CHECK();
     return 0;
 }
-extern "C" int xmc_pack_weight(const float* w, void* wpk, int Co, int Ci, int KH, int KW, int rows_pad, int cols_pad,
-                               int transpose, int dtype, const int32_t* row_perm, void* s) {
-    if (!w || !wpk) return XMC_EINVAL;
+extern "C" int xmc_pack_weight_grouped(const float* w, void* wpk, int Co, int Ci, int KH, int KW, int rows_pad, int cols_pad,
+                                       int transpose, int dtype, const int32_t* row_perm, int groups, void* s) {
+    if (!w || !wpk || groups < 1 || Co % groups || Ci % groups) return XMC_EINVAL;
     if (transpose ? (rows_pad < Ci || cols_pad < Co) : (rows_pad < Co || cols_pad < Ci)) return XMC_ESHAPE;
     int64_t total = (int64_t)KH * KW * rows_pad * cols_pad;
     dim3 g(nblocks(total)), blk(NT);
     if (dtype == XMC_BF16)
-        hipLaunchKernelGGL((pack_weight_kernel<XMC_BF16>), g, blk, 0, ST(s), w, wpk, Co, Ci, KH * KW, rows_pad, cols_pad, transpose, row_perm);
+        hipLaunchKernelGGL((pack_weight_kernel<XMC_BF16>), g, blk, 0, ST(s), w, wpk, Co, Ci, KH * KW, rows_pad, cols_pad, transpose, row_perm, groups);
     else if (dtype == XMC_F32)
-        hipLaunchKernelGGL((pack_weight_kernel<XMC_F32>), g, blk, 0, ST(s), w, wpk, Co, Ci, KH * KW, rows_pad, cols_pad, transpose, row_perm);
+        hipLaunchKernelGGL((pack_weight_kernel<XMC_F32>), g, blk, 0, ST(s), w, wpk, Co, Ci, KH * KW, rows_pad, cols_pad, transpose, row_perm, groups);
     else return XMC_EINVAL;
+    XMC_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int xmc_pack_weight(const float* w, void* wpk, int Co, int Ci, int KH, int KW, int rows_pad, int cols_pad,
+                               int transpose, int dtype, const int32_t* row_perm, void* s) {
+    return xmc_pack_weight_grouped(w, wpk, Co, Ci, KH, KW, rows_pad, cols_pad, transpose, dtype, row_perm, 1, s);
+}
+extern "C" int xmc_unpack_wgrad_grouped(const float* dwp, float* gw, int Co, int Ci, int KH, int KW, int rows_pad, int cols_pad,
+                                        const float* scale_dev, const int32_t* row_perm, int accumulate, int groups, void* s) {
+    if (!dwp || !gw || rows_pad < Co || cols_pad < Ci || groups < 1 || Co % groups || Ci % groups) return XMC_EINVAL;
+    int64_t total = (int64_t)Co * (Ci / groups) * KH * KW;
+    hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(nblocks(total)), dim3(NT), 0, ST(s), dwp, gw, Co, Ci, KH * KW, rows_pad, cols_pad,
+                       scale_dev, row_perm, accumulate, (const float*)nullptr, (float*)nullptr, 0, groups);
     XMC_LAUNCH_CHECK();
     return 0;
 }
 extern "C" int xmc_unpack_wgrad(const float* dwp, float* gw, int Co, int Ci, int KH, int KW, int rows_pad, int cols_pad,
                                 const float* scale_dev, const int32_t* row_perm, int accumulate, void* s) {
-    if (!dwp || !gw || rows_pad < Co || cols_pad < Ci) return XMC_EINVAL;
-    int64_t total = (int64_t)Co * Ci * KH * KW;
-    hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(nblocks(total)), dim3(NT), 0, ST(s), dwp, gw, Co, Ci, KH * KW, rows_pad, cols_pad,
-                       scale_dev, row_perm, accumulate, (const float*)nullptr, (float*)nullptr, 0);
-    XMC_LAUNCH_CHECK();
-    return 0;
+    return xmc_unpack_wgrad_grouped(dwp, gw, Co, Ci, KH, KW, rows_pad, cols_pad, scale_dev, row_perm, accumulate, 1, s);
 }
 extern "C" int xmc_unpack_wgrad_bias(const float* dwp, float* gw, int Co, int Ci, int KH, int KW, int rows_pad, int cols_pad,
                                      const float* scale_dev, const int32_t* row_perm, int accumulate,
@@ -870,7 +883,7 @@ extern "C" int xmc_unpack_wgrad_bias(const float* dwp, float* gw, int Co, int Ci
     if (!dwp || !gw || rows_pad < Co || cols_pad < Ci || !gb_replicas || !gb || CD < 1) return XMC_EINVAL;
     int64_t total = (int64_t)Co * Ci * KH * KW;
     hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(nblocks(total)), dim3(NT), 0, ST(s), dwp, gw, Co, Ci, KH * KW, rows_pad, cols_pad,
-                       scale_dev, row_perm, accumulate, gb_replicas, gb, CD);
+                       scale_dev, row_perm, accumulate, gb_replicas, gb, CD, 1);
     XMC_LAUNCH_CHECK();
     return 0;
 }

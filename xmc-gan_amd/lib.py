@@ -47,9 +47,11 @@ _SIGS = {
     "xmc_conv_wgrad": [C.POINTER(ConvDesc), vp, vp],
     "xmc_conv_wgrad_bias": [C.POINTER(ConvDesc), vp, vp, vp],
     "xmc_pack_weight": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp],
+    "xmc_pack_weight_grouped": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp],
     "xmc_pack_weight_upconv": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "xmc_axpby_up": [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "xmc_unpack_wgrad": [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp],
+    "xmc_unpack_wgrad_grouped": [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, i32, vp],
     "xmc_unpack_wgrad_bias": [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, i32, vp],
     "xmc_nchw_to_nhwc8": [vp, vp, i32, i32, i32, i32, i32, vp],
     "xmc_nhwc8_to_nchw": [vp, vp, i32, i32, i32, i32, i32, vp],

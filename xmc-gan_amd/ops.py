@@ -122,11 +122,15 @@ def bump_weights_epoch():
 class ConvGeom:
     """Geometry of one convolution / linear layer (square kernel k, stride s, padding p)."""
 
-    __slots__ = ("cin", "cout", "k", "s", "p", "row_perm", "_perm_dev")
+    __slots__ = ("cin", "cout", "k", "s", "p", "row_perm", "_perm_dev", "groups")
 
-    def __init__(self, cin, cout, k=1, s=1, p=0, row_perm=None):
+    def __init__(self, cin, cout, k=1, s=1, p=0, row_perm=None, groups=1):
         assert k * k <= L.MAX_TAPS and k % s == 0
+        assert cin % groups == 0 and cout % groups == 0
         self.cin, self.cout, self.k, self.s, self.p = cin, cout, k, s, p
+        # groups > 1: nn.Conv2d(groups=g) weight [cout, cin/g, k, k]; the kernels see its block-diagonal expansion, which the
+        # pack kernel writes and the gradient unpack kernel reads back (diagonal blocks only)
+        self.groups = groups
         self.row_perm = row_perm          # optional LongTensor/list: packed output row r <- parameter row perm[r]
         self._perm_dev = None
 
@@ -162,8 +166,8 @@ def _pack(w, geom, transpose, dtype):
     wf = w.detach()
     if wf.dtype != torch.float32 or not wf.is_contiguous():
         wf = wf.float().contiguous()
-    L.call("xmc_pack_weight", _p(wf), _p(out), geom.cout, geom.cin, geom.k, geom.k, rows, cols, int(transpose),
-           _code(dtype), _p(geom.perm_dev(w.device)), _st())
+    L.call("xmc_pack_weight_grouped", _p(wf), _p(out), geom.cout, geom.cin, geom.k, geom.k, rows, cols, int(transpose),
+           _code(dtype), _p(geom.perm_dev(w.device)), geom.groups, _st())
     return out
 
 
@@ -422,14 +426,15 @@ def _conv_wgrad_raw(x, dy, geom, scale=None, up=False, want_bias=False):
     with prof.launch("wgrad_kernel (conv weight gradient, MFMA + split-K atomics)", 2.0 * N * OH * OW * geom.cout * geom.cin * geom.k * geom.k,
                      f"wgrad {x.dtype} N{N} {H}x{W} {geom.cin}->{geom.cout} k{geom.k}s{geom.s}"):
         L.check(L.load().xmc_conv_wgrad_bias(C.byref(d), _p(dwp), _p(gb), _st()), "xmc_conv_wgrad")
-    gw = torch.empty((geom.cout, geom.cin, geom.k, geom.k), dtype=torch.float32, device=x.device)
+    gw = torch.empty((geom.cout, geom.cin // geom.groups, geom.k, geom.k), dtype=torch.float32, device=x.device)
     if want_bias:
+        assert geom.groups == 1
         gbs = torch.empty(CDy, dtype=torch.float32, device=x.device)
         L.call("xmc_unpack_wgrad_bias", _p(dwp), _p(gw), geom.cout, geom.cin, geom.k, geom.k, rows, CS, _p(scale),
                _p(geom.perm_dev(x.device)), 0, _p(gb), _p(gbs), CDy, _st())
         return gw, gbs
-    L.call("xmc_unpack_wgrad", _p(dwp), _p(gw), geom.cout, geom.cin, geom.k, geom.k, rows, CS, _p(scale),
-           _p(geom.perm_dev(x.device)), 0, _st())
+    L.call("xmc_unpack_wgrad_grouped", _p(dwp), _p(gw), geom.cout, geom.cin, geom.k, geom.k, rows, CS, _p(scale),
+           _p(geom.perm_dev(x.device)), 0, geom.groups, _st())
     return gw
 
 
@@ -535,7 +540,7 @@ class ConvWgradFn(torch.autograd.Function):
     def backward(ctx, ggw):
         x, dy = ctx.saved_tensors
         geom = ctx.geom
-        ggw = ggw.contiguous().view(geom.cout, geom.cin, geom.k, geom.k)
+        ggw = ggw.contiguous().view(geom.cout, geom.cin // geom.groups, geom.k, geom.k)
         dx = ddy = None
         if ctx.needs_input_grad[0]:
             dx = ConvDgradFn.apply(dy, ggw, geom, (x.shape[1], x.shape[2]), x.dtype)
@@ -560,7 +565,7 @@ class ConvWgradBiasFn(torch.autograd.Function):
     def backward(ctx, ggw, _ggb):
         x, dy = ctx.saved_tensors
         geom = ctx.geom
-        ggw = ggw.contiguous().view(geom.cout, geom.cin, geom.k, geom.k)
+        ggw = ggw.contiguous().view(geom.cout, geom.cin // geom.groups, geom.k, geom.k)
         dx = ddy = None
         if ctx.needs_input_grad[0]:
             dx = ConvDgradFn.apply(dy, ggw, geom, (x.shape[1], x.shape[2]), x.dtype)

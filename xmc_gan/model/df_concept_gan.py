@@ -4,8 +4,9 @@ self region attention + sentence->concept attention), plus the ``NetD`` stub tha
 
 Same class names, constructor/forward signatures and ``state_dict()`` keys.  Heavy per-pixel work runs in HIP kernels:
 1x1 / 3x3 / block-diagonal grouped convolutions on the MFMA implicit-GEMM kernels, GroupNorm(+LeakyReLU), the region
-attention (scores, softmax over H*W, weighted sum) and the per-sample channel modulation.  What remains in ATen is the
-per-sample concept algebra on ``[B,16,<=260]`` tensors (query/value projections, ConceptReasoner, the gamma/beta MLPs).
+attention (scores, softmax over H*W, weighted sum), the per-sample channel modulation and -- for the sentence-conditioned
+block -- the per-sample concept algebra on ``[B,16,<=260]`` numbers (csrc/concept.hip).  The self-attention variant
+(OutConceptBlock) still composes that algebra from ATen ops.
 """
 import torch
 import torch.nn as nn
@@ -20,25 +21,17 @@ from .modules import HipConv2d, HipLinear
 CARD, PW, SD = 16, 8, 4          # cardinality, bottleneck width, state dim (hard-coded upstream: 110,118)
 
 
-def _blockdiag(w, groups):
-    """grouped conv weight [Co, Ci/g, k, k] -> dense block-diagonal [Co, Ci, k, k] (differentiable)."""
-    co, cig, k, _ = w.shape
-    cog = co // groups
-    eye = torch.eye(groups, device=w.device, dtype=w.dtype)
-    w6 = w.view(groups, cog, 1, cig, k, k) * eye.view(groups, 1, groups, 1, 1, 1)
-    return w6.reshape(co, groups * cig, k, k)
-
-
 class _GroupedConv(nn.Conv2d):
-    """nn.Conv2d(groups=16) parameter holder whose forward runs the dense MFMA kernel on the block-diagonal expansion
-    (16 groups of 8 channels are far too thin for their own GEMMs)."""
+    """nn.Conv2d(groups=16) parameter holder.  The kernels work on the block-diagonal expansion of the weight, written by the
+    weight-pack kernel (cached per parameter version) and read back, diagonal blocks only, by the gradient-unpack kernel
+    (ops.ConvGeom.groups)."""
 
     def __init__(self, in_dim, out_dim, k, pad, groups=CARD, bias=False):
         super().__init__(in_dim, out_dim, k, 1, pad, groups=groups, bias=bias)
-        self.geom = ops.ConvGeom(in_dim, out_dim, k, 1, pad)
+        self.geom = ops.ConvGeom(in_dim, out_dim, k, 1, pad, groups=groups)
 
     def forward(self, x):
-        return ops.conv2d(x, _blockdiag(self.weight, self.groups), self.bias, self.geom)
+        return ops.conv2d(x, self.weight, self.bias, self.geom)
 
 
 def _grouped_vec(x, conv):
