@@ -91,6 +91,9 @@ typedef struct XmcConvDesc {
     /* round_act != 0 (implied by dst2): act(acc + bias) is rounded to the dst dtype before alpha / mask / residual, so that a
      * fused block sum equals, bit for bit, the unfused sequence that stores the residual branch first. */
     int32_t round_act;
+    /* groups > 1: wpk is the block-diagonal expansion of an nn.Conv2d(groups=g) weight (xmc_pack_weight_grouped); kernels that
+     * know the structure skip the zero blocks (conv_group.hip), the others multiply them.  0 is read as 1. */
+    int32_t groups;
 } XmcConvDesc;
 
 int xmc_abi_version(void);

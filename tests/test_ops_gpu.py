@@ -131,6 +131,35 @@ def test_conv_fwd_dgrad_wgrad(case, mode):
 
 
 @pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("cin,cout,k,H,W,N", [(128, 128, 3, 4, 4, 3), (128, 128, 3, 32, 32, 2), (128, 128, 3, 20, 12, 2),
+                                              (128, 64, 1, 16, 16, 3), (128, 64, 1, 7, 5, 1), (64, 64, 3, 8, 8, 2)])
+def test_grouped_conv_fwd_dgrad_wgrad(cin, cout, k, H, W, N, mode):
+    """nn.Conv2d(groups=16) of the attention-modulation blocks (df_concept_gan.py:146,267): the grouped kernel (bf16) or the
+    dense kernels on the packed block-diagonal expansion (fp32 mode, shapes the grouped kernel declines) vs F.conv2d(groups=16)."""
+    ops.set_precision(mode)
+    dt = ops.act_dtype()
+    G = 16
+    g = torch.Generator().manual_seed(cin * 7 + cout + k + H * W)
+    x = rt(torch.randn(N, cin, H, W, generator=g), mode)
+    w = rt(torch.randn(cout, cin // G, k, k, generator=g) / math.sqrt(cin // G * k * k), mode)
+    xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
+    yr = F.conv2d(xr, wr, None, 1, k // 2, groups=G)
+    r = rt(torch.randn(yr.shape, generator=g), mode)
+    (yr * r).sum().backward()
+    geom = ops.ConvGeom(cin, cout, k, 1, k // 2, groups=G)
+    xd = to_nhwc(x, cin, dt).requires_grad_()
+    wd = torch.nn.Parameter(w.to(DEV))
+    y = ops.conv2d(xd, wd, None, geom)
+    if mode == "bf16":
+        assert L.load().xmc_last_kernel().decode().startswith("gconv_"), L.load().xmc_last_kernel()
+    torch.testing.assert_close(from_nhwc(y, cout), yr.detach(), **tol(mode, yr.abs().max().item()))
+    (y.float() * to_nhwc(r, cout, dt).float()).sum().backward()
+    torch.testing.assert_close(from_nhwc(xd.grad, cin), xr.grad, **tol(mode, xr.grad.abs().max().item()))
+    assert wd.grad.shape == wr.grad.shape
+    torch.testing.assert_close(wd.grad.cpu(), wr.grad, **tol(mode, wr.grad.abs().max().item()))
+
+
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("cin,cout,H,N", [(64, 32, 16, 2), (32, 32, 32, 1), (128, 64, 8, 3), (256, 128, 4, 2), (8, 8, 16, 2),
                                            (128, 128, 16, 2), (256, 128, 8, 4)])   # wide: weight gradient by kernel rows through the upsample
 def test_upsample_conv_fusion(cin, cout, H, N, mode):

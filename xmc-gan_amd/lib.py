@@ -25,7 +25,7 @@ class ConvDesc(C.Structure):
                 ("dh", (C.c_int8 * MAX_TAPS) * MAX_CLASSES), ("dw", (C.c_int8 * MAX_TAPS) * MAX_CLASSES),
                 ("wi", (C.c_int8 * MAX_TAPS) * MAX_CLASSES),
                 ("dph", C.c_int8 * MAX_CLASSES), ("dpw", C.c_int8 * MAX_CLASSES),
-                ("mask", vp), ("res_scale", f32), ("res_mode", i32), ("dst2", vp), ("dst_pool", vp), ("round_act", i32)]
+                ("mask", vp), ("res_scale", f32), ("res_mode", i32), ("dst2", vp), ("dst_pool", vp), ("round_act", i32), ("groups", i32)]
 
 
 # XmcGemmProblem as a numpy record (filled vectorised on the host, handed to xmc_gemm_group by pointer)

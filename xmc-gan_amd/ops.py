@@ -292,6 +292,7 @@ def _conv_fwd_raw(x, w, bias, geom, act, out_dtype, res=None, alpha=None, up=Fal
     d.ntaps, d.nclass, d.CDw = geom.k * geom.k, 1, wpk.shape[1]
     d.act, d.dtype, d.out_dtype = act, _code(x.dtype), _code(out_dtype)
     d.res_mode, d.round_act = res_mode, int(bool(round_act))
+    d.groups = geom.groups
     _fill_taps(d, 0, [(kh - geom.p, kw - geom.p, kh * geom.k + kw) for kh in range(geom.k) for kw in range(geom.k)])
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.numel() >= cd_p, "bias must be f32 and padded to the stored channels"
@@ -335,6 +336,7 @@ def _conv_dgrad_raw(dy, w, geom, in_hw, in_dtype, mask=None, res=None, res_rows=
     d.MH, d.MW, d.SA, d.DA, d.src_shift = H // s, W // s, 1, s, 0
     d.nclass, d.CDw = s * s, wpk.shape[1]
     d.act, d.dtype, d.out_dtype = L.ACT_NONE, _code(dy.dtype), _code(in_dtype)
+    d.groups = geom.groups
     assert H % s == 0 and W % s == 0
     ntaps = None
     for ph in range(s):
