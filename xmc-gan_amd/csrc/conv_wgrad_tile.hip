@@ -31,7 +31,10 @@ template <int NCO, int NCI> struct WtOcc {
 // CBW: 16-wide Cout blocks per wave.  Every (ci block, tap) item needs its own shifted x fragment (2 transposing reads); a wave
 // that multiplies it against CBW dy fragments instead of one does CBW MFMAs per 2 reads (CBW = 1: 2.1 LDS reads per MFMA, twice
 // what the LDS delivers at the MFMA rate).
-template <int NCO, int NCI, int NT, int SA = 1, int KT = 9, int CBW = 1>     // 16-wide blocks of (padded) Cout and Cin; NT threads
+// DIAG (grouped convolutions whose groups sit inside the diagonal 16x16 channel blocks, df_concept_gan.py:146): only the diagonal
+// 64-channel blocks are visited (blockIdx.y; Cin block == Cout block) and an item (ci block, tap) multiplies the ONE Cout block
+// with the same index: 1/8 of the dense MFMAs and half the staging.
+template <int NCO, int NCI, int NT, int SA = 1, int KT = 9, int CBW = 1, bool DIAG = false>     // 16-wide blocks of (padded) Cout and Cin; NT threads
 __global__ __launch_bounds__(NT, (SA == 1 ? WtOcc<NCO, NCI>::v : 1)) void wgrad_tile_kernel(const XmcConvDesc d, float* __restrict__ dwp, float* __restrict__ dbias, const WTCfg t) {
     constexpr int CDP = NCO * 16, CSP = NCI * 16;
     constexpr int YS = CDP * 2 + 32, XS = CSP * 2 + 32;      // LDS row strides (bytes)
@@ -52,16 +55,17 @@ __global__ __launch_bounds__(NT, (SA == 1 ? WtOcc<NCO, NCI>::v : 1)) void wgrad_
     const int PH = t.PH, PW = t.PW;
     const int cd_units = d.CD / 8, cs_units = d.CS / 8;
     // channels beyond 64 are split over the grid: blockIdx.y = 64-wide Cin block, blockIdx.z = 64-wide Cout block
-    const int ci0 = blockIdx.y * 64, co0 = blockIdx.z * 64;
+    const int ci0 = blockIdx.y * 64, co0 = (DIAG ? blockIdx.y : blockIdx.z) * 64;
     const int ciu0 = ci0 >> 3, cou0 = co0 >> 3;
     const u32x4* __restrict__ x16 = reinterpret_cast<const u32x4*>(d.src);
     const u32x4* __restrict__ y16 = reinterpret_cast<const u32x4*>(d.dst);
 
-    f32x4 acc[MAXI][CBW];
+    constexpr int ACB = DIAG ? 1 : CBW;                      // accumulator blocks per item
+    f32x4 acc[MAXI][ACB];
 #pragma unroll
     for (int j = 0; j < MAXI; ++j)
 #pragma unroll
-        for (int c = 0; c < CBW; ++c) acc[j][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < ACB; ++c) acc[j][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     u32x4 yv[YIT], xv[XIT];
     auto prefetch = [&](int tile) {
@@ -97,12 +101,13 @@ __global__ __launch_bounds__(NT, (SA == 1 ? WtOcc<NCO, NCI>::v : 1)) void wgrad_
     // per-item LDS byte offset of the shifted x fragment, computed ONCE: indexing the tap tables of the kernel-argument
     // struct with a run-time tap inside the MFMA loop makes the compiler fetch them with vector memory loads
     // (rocprof: 223 VMEM reads per wave per tile instead of 10, SQ_WAIT_ANY 69 %)
-    int itoff[MAXI];
+    int itoff[MAXI], itib[MAXI];
 #pragma unroll
     for (int j = 0; j < MAXI; ++j) {
         const int item = slice + j * NS;
         int ib = 0, tap = 0;
         if (item < nitems) { ib = item / d.ntaps; tap = item - ib * d.ntaps; }
+        itib[j] = ib;
         const int th = d.dh[0][tap] - t.dh0, tw = d.dw[0][tap] - t.dw0;
         itoff[j] = (SA == 1 ? th * PW + tw : (th * 2 + (tw & 1)) * (PW >> 1) + (tw >> 1)) * XS + (ib * 16) * 2;
     }
@@ -141,7 +146,7 @@ __global__ __launch_bounds__(NT, (SA == 1 ? WtOcc<NCO, NCI>::v : 1)) void wgrad_
             // put lane groups 0 and 1 on the same banks)
             bf16x8 af[CBW];
 #pragma unroll
-            for (int c = 0; c < CBW; ++c) {
+            for (int c = 0; c < (DIAG ? 0 : CBW); ++c) {
                 const unsigned char* ab = ydy + (size_t)(r * TW + 4 * fg + q) * YS + ((cg * CBW + c) * 16 + 4 * pp4) * 2;
                 bf16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(ab));
                 bf16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(ab + 16 * YS));
@@ -155,8 +160,16 @@ __global__ __launch_bounds__(NT, (SA == 1 ? WtOcc<NCO, NCI>::v : 1)) void wgrad_
                     bf16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(bb));
                     bf16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(bb + 16 * XS));
                     const bf16x8 bf = bf16x8{blo[0], blo[1], blo[2], blo[3], bhi[0], bhi[1], bhi[2], bhi[3]};
+                    if (DIAG) {                               // the dy fragment of the Cout block with this item's index
+                        const unsigned char* ab = ydy + (size_t)(r * TW + 4 * fg + q) * YS + (itib[j] * 16 + 4 * pp4) * 2;
+                        bf16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(ab));
+                        bf16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(ab + 16 * YS));
+                        const bf16x8 a1 = bf16x8{alo[0], alo[1], alo[2], alo[3], ahi[0], ahi[1], ahi[2], ahi[3]};
+                        acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bf, acc[j][0], 0, 0, 0);
+                    } else {
 #pragma unroll
-                    for (int c = 0; c < CBW; ++c) acc[j][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[c], bf, acc[j][c], 0, 0, 0);
+                        for (int c = 0; c < CBW; ++c) acc[j][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[c], bf, acc[j][c], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -178,10 +191,10 @@ __global__ __launch_bounds__(NT, (SA == 1 ? WtOcc<NCO, NCI>::v : 1)) void wgrad_
         if (item < nitems) {
             const int ib = item / d.ntaps, tap = item - ib * d.ntaps;
 #pragma unroll
-            for (int c = 0; c < CBW; ++c)
+            for (int c = 0; c < ACB; ++c)
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
-                int co = co0 + (cg * CBW + c) * 16 + fg * 4 + rr, ci = ci0 + ib * 16 + fr;
+                int co = co0 + (DIAG ? ib : cg * CBW + c) * 16 + fg * 4 + rr, ci = ci0 + ib * 16 + fr;
                 if (co < d.CDw && co < co0 + CDP && ci < d.CS)
                     atomicAdd(&dwp[((size_t)d.wi[0][tap] * d.CDw + co) * d.CS + ci], acc[j][c][rr]);
             }
@@ -189,21 +202,21 @@ __global__ __launch_bounds__(NT, (SA == 1 ? WtOcc<NCO, NCI>::v : 1)) void wgrad_
     }
 }
 
-template <int NCO, int NCI, int NT = 256, int SA = 1, int KT = 9, int CBW = 1>
+template <int NCO, int NCI, int NT = 256, int SA = 1, int KT = 9, int CBW = 1, bool DIAG = false>
 int launch_wt(const XmcConvDesc& d, float* dwp, float* dbias, const WTCfg& t, hipStream_t st) {
     constexpr int YS = NCO * 32 + 32, XS = NCI * 32 + 32;
     size_t lds = (size_t)TH * TW * YS + (size_t)t.PH * t.PW * XS;
     if (lds > XMC_MAX_DYN_LDS) return 1;
-    XMC_ALLOW_BIG_LDS((wgrad_tile_kernel<NCO, NCI, NT, SA, KT, CBW>));
+    XMC_ALLOW_BIG_LDS((wgrad_tile_kernel<NCO, NCI, NT, SA, KT, CBW, DIAG>));
     int per_cu = (int)(160 * 1024 / lds);
     const int cap = WtOcc<NCO, NCI>::v >= 3 ? 3 : 2;
     if (per_cu > cap) per_cu = cap;
-    const int ny = (d.CS + 63) / 64, nz = (d.CD + 63) / 64;
+    const int ny = (d.CS + 63) / 64, nz = DIAG ? 1 : (d.CD + 63) / 64;
     int gx = 256 * per_cu / (ny * nz);
     if (gx < 1) gx = 1;
     if (gx > t.ntiles) gx = t.ntiles;
-    hipLaunchKernelGGL((wgrad_tile_kernel<NCO, NCI, NT, SA, KT, CBW>), dim3(gx, ny, nz), dim3(NT), lds, st, d, dwp, dbias, t);
-    xmc_note_kernel("wgrad_tile_kernel<%d, %d, %d, %d, %d, %d>", NCO, NCI, NT, SA, KT, CBW);
+    hipLaunchKernelGGL((wgrad_tile_kernel<NCO, NCI, NT, SA, KT, CBW, DIAG>), dim3(gx, ny, nz), dim3(NT), lds, st, d, dwp, dbias, t);
+    xmc_note_kernel(DIAG ? "wgrad_tile_kernel<%d, %d, %d, %d, %d, %d, true>" : "wgrad_tile_kernel<%d, %d, %d, %d, %d, %d>", NCO, NCI, NT, SA, KT, CBW);
     XMC_LAUNCH_CHECK();
     return 0;
 }
@@ -246,6 +259,11 @@ int xmc_conv_wgrad_tile_try(const XmcConvDesc* d, float* dwp, float* dbias, void
     // (4,4) = 64x64 channels with 4 waves needs 144 accumulator + 76 staging registers per lane and measured slower than
     // the split-K kernel (166 vs 230 TF/s); it runs with 8 waves instead (below)
     WT_CASE(1, 2) WT_CASE(1, 4) WT_CASE(2, 1) WT_CASE(2, 2) WT_CASE(2, 4) WT_CASE(4, 1) WT_CASE(4, 2)
+    // grouped layer with its groups inside the diagonal 16x16 blocks (8 -> 8 channels per group): diagonal blocks only
+    static const bool no_diag = xmc_debug_off("no_wt_diag");
+    if (!no_diag && d->groups > 1 && nco == 4 && nci == 4 && d->CD == d->CS && d->CD % 64 == 0 && d->CD % d->groups == 0 &&
+        16 % (d->CD / d->groups) == 0 && dbias == nullptr)
+        return launch_wt<4, 4, 512, 1, 9, 4, true>(*d, dwp, dbias, t, st);
     static const bool no44 = xmc_debug_off("no_wt44");
     if (nco == 4 && nci == 4 && !no44) return launch_wt<4, 4, 512, 1, 9, 4>(*d, dwp, dbias, t, st);   // all 4 Cout blocks per wave: 0.9 LDS reads per MFMA   // 8 waves: 72 accumulator registers per lane
 #undef WT_CASE

@@ -424,6 +424,7 @@ def _conv_wgrad_raw(x, dy, geom, scale=None, up=False, want_bias=False):
     d.MH, d.MW, d.SA, d.DA, d.src_shift = OH, OW, geom.s, 1, 1 if up else 0
     d.ntaps, d.nclass, d.CDw = geom.k * geom.k, 1, rows
     d.dtype, d.out_dtype = _code(x.dtype), L.F32
+    d.groups = geom.groups
     _fill_taps(d, 0, [(kh - geom.p, kw - geom.p, kh * geom.k + kw) for kh in range(geom.k) for kw in range(geom.k)])
     with prof.launch("wgrad_kernel (conv weight gradient, MFMA + split-K atomics)", 2.0 * N * OH * OW * geom.cout * geom.cin * geom.k * geom.k,
                      f"wgrad {x.dtype} N{N} {H}x{W} {geom.cin}->{geom.cout} k{geom.k}s{geom.s}"):
