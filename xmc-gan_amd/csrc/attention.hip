@@ -81,83 +81,86 @@ __global__ void gn_sums_kernel(const void* a, const void* b, const float* stats,
         }
     }
 }
-// sums [N][C][2] -> stats [N][G][2] = (mean, rstd)
-__global__ void gn_finalize_kernel(const float* sums, float* stats, int N, int C, int cpg, int HW, float eps) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    int G = C / cpg;
-    if (i >= N * G) return;
-    int n = i / G, g = i % G;
-    float s1 = 0.f, s2 = 0.f;
-    for (int c = g * cpg; c < (g + 1) * cpg; ++c) { s1 += sums[((size_t)n * C + c) * 2]; s2 += sums[((size_t)n * C + c) * 2 + 1]; }
-    float m = (float)HW * cpg, mean = s1 / m;
-    float var = fmaxf(s2 / m - mean * mean, 0.f);
-    stats[(size_t)i * 2] = mean; stats[(size_t)i * 2 + 1] = rsqrtf(var + eps);
-}
+// Everything per (image, channel) is loaded ONCE per thread: blockIdx.y = image, and the grid stride keeps a thread on its
+// 8-channel unit (the first version re-read mean / rstd / w / b / A / B per element: 48 dependent loads per 16-byte vector).
+// y = lrelu?((x - mean) * rstd * w + b) with (mean, rstd) formed from the per-channel sums; block x == 0 of every image also
+// writes stats [N][G][2] = (mean, rstd) for the backward
 template <int DT>
-__global__ void gn_apply_kernel(const void* x, const float* stats, const float* w, const float* b, void* y,
-                                int N, int HW, int C8, int cpg, float slope) {
-    const int C = C8 * 8, G = C / cpg;
-    const int64_t total = (int64_t)N * HW * C8;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        int cc = (int)(i % C8);
-        int n = (int)(i / ((int64_t)HW * C8));
+__global__ void gn_apply_kernel(const void* x, const float* sums, float* stats, const float* w, const float* b, void* y,
+                                int HW, int C8, int cpg, float slope, float eps) {
+    const int C = C8 * 8, G = C / cpg, n = blockIdx.y;
+    const int stride = gridDim.x * blockDim.x;               // a multiple of C8 (host)
+    const int i0 = blockIdx.x * blockDim.x + threadIdx.x, cc = i0 % C8;
+    float sc[8], sh[8];
+    const float m = (float)HW * cpg;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int c = cc * 8 + k, grp = c / cpg;
+        float s1 = 0.f, s2 = 0.f;
+        for (int q = grp * cpg; q < (grp + 1) * cpg; ++q) { s1 += sums[((size_t)n * C + q) * 2]; s2 += sums[((size_t)n * C + q) * 2 + 1]; }
+        const float mean = s1 / m, rstd = rsqrtf(fmaxf(s2 / m - mean * mean, 0.f) + eps);
+        sc[k] = rstd * w[c];
+        sh[k] = b[c] - mean * sc[k];
+        if (blockIdx.x == 0 && i0 < C8 && c == grp * cpg) { stats[((size_t)n * G + grp) * 2] = mean; stats[((size_t)n * G + grp) * 2 + 1] = rstd; }
+    }
+    const int total = HW * C8;
+    for (int i = i0; i < total; i += stride) {
         float v[8];
-        Vec8<DT>::load(x, i, v);
+        const size_t idx = (size_t)n * total + i;
+        Vec8<DT>::load(x, idx, v);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            int c = cc * 8 + k, grp = c / cpg;
-            float o = (v[k] - stats[((size_t)n * G + grp) * 2]) * stats[((size_t)n * G + grp) * 2 + 1] * w[c] + b[c];
+            const float o = v[k] * sc[k] + sh[k];
             v[k] = slope >= 0.f ? (o > 0.f ? o : slope * o) : o;
         }
-        Vec8<DT>::store(y, i, v);
+        Vec8<DT>::store(y, idx, v);
     }
 }
-// per (image, group): A_g = sum_{c in g} w_c S1[n,c], B_g = sum_{c in g} w_c S2[n,c]   (S = sums of dy', dy'*xhat)
-__global__ void gn_bwd_groupsums_kernel(const float* sums2, const float* w, float* ab, int N, int C, int cpg) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    int G = C / cpg;
-    if (i >= N * G) return;
-    int n = i / G, g = i % G;
-    float A = 0.f, Bq = 0.f;
-    for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
-        A += w[c] * sums2[((size_t)n * C + c) * 2];
-        Bq += w[c] * sums2[((size_t)n * C + c) * 2 + 1];
-    }
-    ab[(size_t)i * 2] = A; ab[(size_t)i * 2 + 1] = Bq;
-}
-// dx = rstd * ( w*dy' - (A_g + xhat*B_g)/m )
+// dx = rstd * ( w*dy' - (A_g + xhat*B_g)/m ),  A_g = sum_{c in g} w_c S1[n,c], B_g = sum_{c in g} w_c S2[n,c]
+// (S = sums of dy', dy'*xhat).  blockIdx.y == N: dw[c] = sum_n S2[n][c], db[c] = sum_n S1[n][c] (one wave per channel).
 template <int DT>
-__global__ void gn_bwd_apply_kernel(const void* x, const void* dy, const float* stats, const float* ab, const float* w,
-                                    const float* b, void* dx, int N, int HW, int C8, int cpg, float slope) {
-    const int C = C8 * 8, G = C / cpg;
+__global__ void gn_bwd_apply_kernel(const void* x, const void* dy, const float* stats, const float* sums2, const float* w,
+                                    const float* b, void* dx, float* dw, float* db, int N, int HW, int C8, int cpg, float slope) {
+    const int C = C8 * 8, G = C / cpg, n = blockIdx.y;
+    if (n == N) {
+        const int lane = threadIdx.x & 63;
+        for (int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); c < C; c += gridDim.x * (blockDim.x >> 6)) {
+            float a = 0.f, bq = 0.f;
+            for (int q = lane; q < N; q += 64) { a += sums2[((size_t)q * C + c) * 2]; bq += sums2[((size_t)q * C + c) * 2 + 1]; }
+            a = wave_sum(a); bq = wave_sum(bq);
+            if (lane == 0) { db[c] = a; dw[c] = bq; }
+        }
+        return;
+    }
+    const int stride = gridDim.x * blockDim.x;
+    const int i0 = blockIdx.x * blockDim.x + threadIdx.x, cc = i0 % C8;
     const float inv_m = 1.f / ((float)HW * cpg);
-    const int64_t total = (int64_t)N * HW * C8;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        int cc = (int)(i % C8);
-        int n = (int)(i / ((int64_t)HW * C8));
+    float mean[8], rstd[8], wv[8], bv[8], A[8], B[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int c = cc * 8 + k, grp = c / cpg;
+        mean[k] = stats[((size_t)n * G + grp) * 2];
+        rstd[k] = stats[((size_t)n * G + grp) * 2 + 1];
+        wv[k] = w[c]; bv[k] = b[c];
+        float a = 0.f, bq = 0.f;
+        for (int q = grp * cpg; q < (grp + 1) * cpg; ++q) { a += w[q] * sums2[((size_t)n * C + q) * 2]; bq += w[q] * sums2[((size_t)n * C + q) * 2 + 1]; }
+        A[k] = a * inv_m; B[k] = bq * inv_m;
+    }
+    const int total = HW * C8;
+    for (int i = i0; i < total; i += stride) {
         float xv[8], dv[8];
-        Vec8<DT>::load(x, i, xv);
-        Vec8<DT>::load(dy, i, dv);
+        const size_t idx = (size_t)n * total + i;
+        Vec8<DT>::load(x, idx, xv);
+        Vec8<DT>::load(dy, idx, dv);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            int c = cc * 8 + k, grp = c / cpg;
-            const size_t gi = ((size_t)n * G + grp) * 2;
-            float mean = stats[gi], rstd = stats[gi + 1];
-            float xh = (xv[k] - mean) * rstd;
+            const float xh = (xv[k] - mean[k]) * rstd[k];
             float d = dv[k];
-            if (slope >= 0.f) d *= (xh * w[c] + b[c]) > 0.f ? 1.f : slope;
-            xv[k] = rstd * (w[c] * d - (ab[gi] + xh * ab[gi + 1]) * inv_m);
+            if (slope >= 0.f) d *= (xh * wv[k] + bv[k]) > 0.f ? 1.f : slope;
+            xv[k] = rstd[k] * (wv[k] * d - (A[k] + xh * B[k]));
         }
-        Vec8<DT>::store(dx, i, xv);
+        Vec8<DT>::store(dx, idx, xv);
     }
-}
-// dw[c] = sum_n S2[n][c], db[c] = sum_n S1[n][c]
-__global__ void gn_param_grads_kernel(const float* sums2, float* dw, float* db, int N, int C) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float a = 0.f, bq = 0.f;
-    for (int n = 0; n < N; ++n) { a += sums2[((size_t)n * C + c) * 2]; bq += sums2[((size_t)n * C + c) * 2 + 1]; }
-    db[c] = a; dw[c] = bq;
 }
 
 // ---- region attention pooling, one workgroup per (image, concept); each thread moves whole per-concept vectors
@@ -324,6 +327,17 @@ static inline int ap_pixels_per_chunk(int N, int HW) {
     ppc = (ppc + AP_SLOTS - 1) / AP_SLOTS * AP_SLOTS;
     return (int)ppc;
 }
+// blocks per image of the apply kernels: ~2048 workgroups over the batch, each thread >= 2 vectors, grid stride a multiple of C8
+static inline int gn_apply_blocks(int N, int HW, int C8) {
+    int64_t per = ((int64_t)HW * C8 + 2 * NT - 1) / (2 * NT);
+    int64_t cap = (2048 + N - 1) / N;
+    int b = (int)(per < cap ? per : cap);
+    if (b < 1) b = 1;
+    int g = NT, r = C8;                               // blocks * NT must be a multiple of C8
+    while (r) { int t = g % r; g = r; r = t; }
+    const int q = C8 / g;
+    return (b + q - 1) / q * q;
+}
 }  // namespace
 
 #define ST(s) reinterpret_cast<hipStream_t>(s)
@@ -338,15 +352,13 @@ extern "C" int xmc_groupnorm_fwd(const void* x, const float* w, const float* b, 
     int ppb = (HW + bx - 1) / bx;
     hipError_t e = hipMemsetAsync(ws, 0, (size_t)N * C * 2 * 4, ST(s));
     if (e != hipSuccess) return -(1000 + (int)e);
-    int64_t total = (int64_t)N * HW * C8; int blocks = (int)((total + NT - 1) / NT); if (blocks > 4096) blocks = 4096;
+    const int blocks = gn_apply_blocks(N, HW, C8);
     if (dtype == XMC_BF16) {
         hipLaunchKernelGGL((gn_sums_kernel<XMC_BF16, 0>), dim3(bx, N), dim3(NT), 0, ST(s), x, nullptr, nullptr, nullptr, nullptr, ws, HW, C8, cpg, -1.f, ppb);
-        hipLaunchKernelGGL(gn_finalize_kernel, dim3((N * G + NT - 1) / NT), dim3(NT), 0, ST(s), ws, stats, N, C, cpg, HW, eps);
-        hipLaunchKernelGGL((gn_apply_kernel<XMC_BF16>), dim3(blocks), dim3(NT), 0, ST(s), x, stats, w, b, y, N, HW, C8, cpg, slope);
+        hipLaunchKernelGGL((gn_apply_kernel<XMC_BF16>), dim3(blocks, N), dim3(NT), 0, ST(s), x, ws, stats, w, b, y, HW, C8, cpg, slope, eps);
     } else if (dtype == XMC_F32) {
         hipLaunchKernelGGL((gn_sums_kernel<XMC_F32, 0>), dim3(bx, N), dim3(NT), 0, ST(s), x, nullptr, nullptr, nullptr, nullptr, ws, HW, C8, cpg, -1.f, ppb);
-        hipLaunchKernelGGL(gn_finalize_kernel, dim3((N * G + NT - 1) / NT), dim3(NT), 0, ST(s), ws, stats, N, C, cpg, HW, eps);
-        hipLaunchKernelGGL((gn_apply_kernel<XMC_F32>), dim3(blocks), dim3(NT), 0, ST(s), x, stats, w, b, y, N, HW, C8, cpg, slope);
+        hipLaunchKernelGGL((gn_apply_kernel<XMC_F32>), dim3(blocks, N), dim3(NT), 0, ST(s), x, ws, stats, w, b, y, HW, C8, cpg, slope, eps);
     } else return XMC_EINVAL;
     XMC_LAUNCH_CHECK();
     return 0;
@@ -359,18 +371,14 @@ extern "C" int xmc_groupnorm_bwd(const void* x, const void* dy, const float* w, 
     int ppb = (HW + bx - 1) / bx;
     hipError_t e = hipMemsetAsync(ws, 0, (size_t)N * C * 2 * 4, ST(s));
     if (e != hipSuccess) return -(1000 + (int)e);
-    float* ab = ws + (size_t)N * C * 2;              // [N][G][2], second part of the workspace
-    int64_t total = (int64_t)N * HW * C8; int blocks = (int)((total + NT - 1) / NT); if (blocks > 4096) blocks = 4096;
+    const int blocks = gn_apply_blocks(N, HW, C8);   // grid.y = N images + one slice of blocks for the parameter gradients
     if (dtype == XMC_BF16) {
         hipLaunchKernelGGL((gn_sums_kernel<XMC_BF16, 1>), dim3(bx, N), dim3(NT), 0, ST(s), x, dy, stats, w, b, ws, HW, C8, cpg, slope, ppb);
-        hipLaunchKernelGGL(gn_bwd_groupsums_kernel, dim3((N * G + NT - 1) / NT), dim3(NT), 0, ST(s), ws, w, ab, N, C, cpg);
-        hipLaunchKernelGGL((gn_bwd_apply_kernel<XMC_BF16>), dim3(blocks), dim3(NT), 0, ST(s), x, dy, stats, ab, w, b, dx, N, HW, C8, cpg, slope);
+        hipLaunchKernelGGL((gn_bwd_apply_kernel<XMC_BF16>), dim3(blocks, N + 1), dim3(NT), 0, ST(s), x, dy, stats, ws, w, b, dx, dw, db, N, HW, C8, cpg, slope);
     } else if (dtype == XMC_F32) {
         hipLaunchKernelGGL((gn_sums_kernel<XMC_F32, 1>), dim3(bx, N), dim3(NT), 0, ST(s), x, dy, stats, w, b, ws, HW, C8, cpg, slope, ppb);
-        hipLaunchKernelGGL(gn_bwd_groupsums_kernel, dim3((N * G + NT - 1) / NT), dim3(NT), 0, ST(s), ws, w, ab, N, C, cpg);
-        hipLaunchKernelGGL((gn_bwd_apply_kernel<XMC_F32>), dim3(blocks), dim3(NT), 0, ST(s), x, dy, stats, ab, w, b, dx, N, HW, C8, cpg, slope);
+        hipLaunchKernelGGL((gn_bwd_apply_kernel<XMC_F32>), dim3(blocks, N + 1), dim3(NT), 0, ST(s), x, dy, stats, ws, w, b, dx, dw, db, N, HW, C8, cpg, slope);
     } else return XMC_EINVAL;
-    hipLaunchKernelGGL(gn_param_grads_kernel, dim3((C + NT - 1) / NT), dim3(NT), 0, ST(s), ws, dw, db, N, C);
     XMC_LAUNCH_CHECK();
     return 0;
 }
