@@ -127,6 +127,16 @@ int xmc_pack_weight_grouped(const float* w, void* wpk, int Co, int Ci, int KH, i
                             int dtype, const int32_t* row_perm, int groups, void* stream);
 int xmc_unpack_wgrad_grouped(const float* dwp, float* gw, int Co, int Ci, int KH, int KW, int rows_pad, int cols_pad,
                              const float* scale_dev, const int32_t* row_perm, int accumulate, int groups, void* stream);
+/* Any number of the packs above (and of xmc_pack_weight_upconv below: upconv != 0, KHW ignored) in one launch per
+ * XMC_PACK_MULTI_MAX jobs: the optimizer step re-packs every cached copy of the weights it changed (ops.repack_params). */
+#define XMC_PACK_MULTI_MAX 48
+typedef struct XmcPackJob {
+    const float* w;
+    void* wpk;
+    const int32_t* row_perm;
+    int32_t Co, Ci, KHW, rows_pad, cols_pad, transpose, dtype, groups, upconv;
+} XmcPackJob;
+int xmc_pack_weight_multi(const XmcPackJob* jobs /* host array */, int njobs, void* stream);
 /* Fused nearest-x2 upsample + 3x3 conv (F.interpolate(scale_factor=2) at df_gan.py:202 followed by the next block's c1, 187):
  * 16 slices wpk[(i*2+j)*4 + th*2+tw][...] of pre-summed weights, one 2x2-tap convolution per output parity (i,j) on the
  * LOW-resolution tensor -> 4/9 of the MACs and no materialised upsampled tensor.  Used with a 4-class tap table. */

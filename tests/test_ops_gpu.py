@@ -649,3 +649,40 @@ def test_concept_algebra_kernels_match_composed_reference():
         for got, want in pairs:
             sc_ = float(want.grad.abs().max())
             torch.testing.assert_close(got.grad.cpu().double(), want.grad, rtol=5e-4, atol=5e-5 * max(sc_, 1e-3))
+
+
+def test_optimizer_step_repacks_cached_weights_in_bulk():
+    """HipAdam.step changes the parameters behind autograd's back; every cached packed copy (forward, data-gradient, fused
+    upsample, grouped) must be re-packed by the step itself -- same buffers, marked valid -- and give the new weights' result."""
+    from xmc_gan_amd.optim import HipAdam
+    ops.set_precision("bf16")
+    g = torch.Generator().manual_seed(5)
+    geoms = [ops.ConvGeom(32, 64, 3, 1, 1), ops.ConvGeom(64, 32, 3, 1, 1), ops.ConvGeom(128, 128, 3, 1, 1, groups=16)]
+    ws = [torch.nn.Parameter((torch.randn(gm.cout, gm.cin // gm.groups, 3, 3, generator=g) * 0.1).to(DEV)) for gm in geoms]
+    xs = [torch.randn(2, 16, 16, gm.cin, generator=g).to(DEV, torch.bfloat16).requires_grad_() for gm in geoms]
+    opt = HipAdam(ws, lr=0.05)
+
+    def run():
+        ys = [ops.conv2d(xs[0], ws[0], None, geoms[0]), ops.upconv3x3(xs[1], ws[1], None, geoms[1]),
+              ops.conv2d(xs[2], ws[2], None, geoms[2])]
+        sum((y.float() ** 2).sum() for y in ys).backward()
+        return [y.detach().float() for y in ys]
+
+    run()                                                    # creates the forward and data-gradient entries
+    ents = {k: e for k, e in ops._pack_cache.items() if k[0] in {id(w) for w in ws}}
+    assert len(ents) >= 6
+    ptrs = {k: e.out.data_ptr() for k, e in ents.items()}
+    before = [w.detach().clone() for w in ws]
+    opt.step()
+    assert all(not torch.equal(b, w.detach()) for b, w in zip(before, ws))
+    for k, e in ents.items():
+        w = e.ref()
+        assert ops._pack_cache[k] is e and e.out.data_ptr() == ptrs[k] and e.valid(w, e.geom), k
+    n_before = len(ops._pack_cache)
+    ys = run()
+    assert len(ops._pack_cache) == n_before and all(ops._pack_cache[k] is e for k, e in ents.items())     # no lazy re-pack happened
+    # ... and the buffers really hold the new weights: same result as a freshly packed non-Parameter copy
+    y_ref = ops.conv2d(xs[0].detach(), ws[0].detach().clone(), None, geoms[0]).float()
+    assert torch.equal(ys[0], y_ref)
+    y_ref = ops.conv2d(xs[2].detach(), ws[2].detach().clone(), None, geoms[2]).float()
+    assert torch.equal(ys[2], y_ref)

@@ -409,53 +409,77 @@ __global__ void hinge_bwd_kernel(const void* x, int stride, float sign, const fl
 }
 
 // ------------------------------------------------------------------ weight pack / unpack
-template <int DT>
-__global__ void pack_weight_kernel(const float* w, void* wpk, int Co, int Ci, int KHW, int rows_pad, int cols_pad,
-                                   int transpose, const int32_t* row_perm, int groups) {
-    // groups > 1: w is a grouped-convolution weight [Co][Ci/groups][KHW]; the packed matrix is its block-diagonal expansion
+// value of packed element i of [KHW][rows_pad][cols_pad].  groups > 1: w is a grouped-convolution weight [Co][Ci/groups][KHW];
+// the packed matrix is its block-diagonal expansion
+__device__ __forceinline__ float pack_value(const float* __restrict__ w, int Co, int Ci, int KHW, int rows_pad, int cols_pad,
+                                            int transpose, const int32_t* __restrict__ row_perm, int groups, int64_t i) {
     const int cog = Co / groups, cig = Ci / groups;
-    const int64_t total = (int64_t)KHW * rows_pad * cols_pad;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        int c = (int)(i % cols_pad);
-        int64_t q = i / cols_pad;
-        int r = (int)(q % rows_pad);
-        int t = (int)(q / rows_pad);
-        int co = transpose ? c : r, ci = transpose ? r : c;
-        float v = 0.f;
-        if (co < Co && ci < Ci) {
-            int sco = row_perm ? row_perm[co] : co;
-            if (groups == 1) v = w[((int64_t)sco * Ci + ci) * KHW + t];
-            else if (sco / cog == ci / cig) v = w[((int64_t)sco * cig + ci % cig) * KHW + t];
-        }
-        if (DT == XMC_BF16) reinterpret_cast<__bf16*>(wpk)[i] = (__bf16)v;
-        else reinterpret_cast<float*>(wpk)[i] = v;
+    int c = (int)(i % cols_pad);
+    int64_t q = i / cols_pad;
+    int r = (int)(q % rows_pad);
+    int t = (int)(q / rows_pad);
+    int co = transpose ? c : r, ci = transpose ? r : c;
+    float v = 0.f;
+    if (co < Co && ci < Ci) {
+        int sco = row_perm ? row_perm[co] : co;
+        if (groups == 1) v = w[((int64_t)sco * Ci + ci) * KHW + t];
+        else if (sco / cog == ci / cig) v = w[((int64_t)sco * cig + ci % cig) * KHW + t];
     }
+    return v;
 }
 // Fused nearest-x2 upsample + 3x3 convolution: output parity class (i,j) sees only a 2x2 neighbourhood of the
 // low-resolution input, with weights that are sums of the 3x3 taps landing on the same low-res pixel:
 //   rows: i=0: {kh=0} | {kh=1,2}     i=1: {kh=0,1} | {kh=2}        (same for columns)
 // slice index = (i*2+j)*4 + th*2+tw.  Summation in f32, one rounding to the kernel dtype.
+__device__ __forceinline__ float pack_upconv_value(const float* __restrict__ w, int Co, int Ci, int rows_pad, int cols_pad,
+                                                   int transpose, int64_t idx) {
+    int c = (int)(idx % cols_pad);
+    int64_t q = idx / cols_pad;
+    int r = (int)(q % rows_pad);
+    int sl = (int)(q / rows_pad);
+    int cls = sl >> 2, t = sl & 3;
+    int i = cls >> 1, j = cls & 1, th = t >> 1, tw = t & 1;
+    int co = transpose ? c : r, ci = transpose ? r : c;
+    float v = 0.f;
+    if (co < Co && ci < Ci) {
+        int kh0 = (i == 0) ? (th == 0 ? 0 : 1) : (th == 0 ? 0 : 2), kh1 = (i == 0) ? (th == 0 ? 0 : 2) : (th == 0 ? 1 : 2);
+        int kw0 = (j == 0) ? (tw == 0 ? 0 : 1) : (tw == 0 ? 0 : 2), kw1 = (j == 0) ? (tw == 0 ? 0 : 2) : (tw == 0 ? 1 : 2);
+        const float* wp = w + ((int64_t)co * Ci + ci) * 9;
+        for (int kh = kh0; kh <= kh1; ++kh)
+            for (int kw = kw0; kw <= kw1; ++kw) v += wp[kh * 3 + kw];
+    }
+    return v;
+}
+template <int DT>
+__global__ void pack_weight_kernel(const float* w, void* wpk, int Co, int Ci, int KHW, int rows_pad, int cols_pad,
+                                   int transpose, const int32_t* row_perm, int groups) {
+    const int64_t total = (int64_t)KHW * rows_pad * cols_pad;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = pack_value(w, Co, Ci, KHW, rows_pad, cols_pad, transpose, row_perm, groups, i);
+        if (DT == XMC_BF16) reinterpret_cast<__bf16*>(wpk)[i] = (__bf16)v;
+        else reinterpret_cast<float*>(wpk)[i] = v;
+    }
+}
 template <int DT>
 __global__ void pack_upconv_kernel(const float* w, void* wpk, int Co, int Ci, int rows_pad, int cols_pad, int transpose) {
     const int64_t total = (int64_t)16 * rows_pad * cols_pad;
     for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-        int c = (int)(idx % cols_pad);
-        int64_t q = idx / cols_pad;
-        int r = (int)(q % rows_pad);
-        int sl = (int)(q / rows_pad);
-        int cls = sl >> 2, t = sl & 3;
-        int i = cls >> 1, j = cls & 1, th = t >> 1, tw = t & 1;
-        int co = transpose ? c : r, ci = transpose ? r : c;
-        float v = 0.f;
-        if (co < Co && ci < Ci) {
-            int kh0 = (i == 0) ? (th == 0 ? 0 : 1) : (th == 0 ? 0 : 2), kh1 = (i == 0) ? (th == 0 ? 0 : 2) : (th == 0 ? 1 : 2);
-            int kw0 = (j == 0) ? (tw == 0 ? 0 : 1) : (tw == 0 ? 0 : 2), kw1 = (j == 0) ? (tw == 0 ? 0 : 2) : (tw == 0 ? 1 : 2);
-            const float* wp = w + ((int64_t)co * Ci + ci) * 9;
-            for (int kh = kh0; kh <= kh1; ++kh)
-                for (int kw = kw0; kw <= kw1; ++kw) v += wp[kh * 3 + kw];
-        }
+        const float v = pack_upconv_value(w, Co, Ci, rows_pad, cols_pad, transpose, idx);
         if (DT == XMC_BF16) reinterpret_cast<__bf16*>(wpk)[idx] = (__bf16)v;
         else reinterpret_cast<float*>(wpk)[idx] = v;
+    }
+}
+// All packed copies of a network's weights in one launch (after the optimizer step that changed them): blockIdx.y = job; the
+// job table travels in the kernel arguments, so the launch is capturable and needs no device-side table.
+struct PackJobs { XmcPackJob j[XMC_PACK_MULTI_MAX]; };
+__global__ void pack_multi_kernel(const PackJobs J) {
+    const XmcPackJob& job = J.j[blockIdx.y];
+    const int64_t total = (int64_t)(job.upconv ? 16 : job.KHW) * job.rows_pad * job.cols_pad;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = job.upconv ? pack_upconv_value(job.w, job.Co, job.Ci, job.rows_pad, job.cols_pad, job.transpose, i)
+                                   : pack_value(job.w, job.Co, job.Ci, job.KHW, job.rows_pad, job.cols_pad, job.transpose, job.row_perm, job.groups, i);
+        if (job.dtype == XMC_BF16) reinterpret_cast<__bf16*>(job.wpk)[i] = (__bf16)v;
+        else reinterpret_cast<float*>(job.wpk)[i] = v;
     }
 }
 // y[n,2h+i,2w+j,:] = a[n,h,w,:] + alpha * b[n,2h+i,2w+j,:]      (up(shortcut) + gamma*residual without materialising up())
@@ -858,6 +882,24 @@ extern "C" int xmc_pack_weight_grouped(const float* w, void* wpk, int Co, int Ci
         hipLaunchKernelGGL((pack_weight_kernel<XMC_F32>), g, blk, 0, ST(s), w, wpk, Co, Ci, KH * KW, rows_pad, cols_pad, transpose, row_perm, groups);
     else return XMC_EINVAL;
     XMC_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int xmc_pack_weight_multi(const XmcPackJob* jobs, int njobs, void* s) {
+    if (!jobs || njobs < 0) return XMC_EINVAL;
+    for (int j0 = 0; j0 < njobs; j0 += XMC_PACK_MULTI_MAX) {
+        PackJobs J;
+        const int n = njobs - j0 < XMC_PACK_MULTI_MAX ? njobs - j0 : XMC_PACK_MULTI_MAX;
+        for (int k = 0; k < n; ++k) {
+            const XmcPackJob& q = jobs[j0 + k];
+            if (!q.w || !q.wpk || (q.dtype != XMC_BF16 && q.dtype != XMC_F32) || q.groups < 1 || q.Co % q.groups || q.Ci % q.groups ||
+                (q.upconv && (q.groups != 1 || q.row_perm)))
+                return XMC_EINVAL;
+            if (q.transpose ? (q.rows_pad < q.Ci || q.cols_pad < q.Co) : (q.rows_pad < q.Co || q.cols_pad < q.Ci)) return XMC_ESHAPE;
+            J.j[k] = q;
+        }
+        hipLaunchKernelGGL(pack_multi_kernel, dim3(48, n), dim3(NT), 0, ST(s), J);
+        XMC_LAUNCH_CHECK();
+    }
     return 0;
 }
 extern "C" int xmc_pack_weight(const float* w, void* wpk, int Co, int Ci, int KH, int KW, int rows_pad, int cols_pad,

@@ -103,7 +103,7 @@ class GraphedIteration:
         self.seqs[phase] = self._seq
         self.static_out[phase] = out
         self._seq = None
-        ops.bump_weights_epoch()        # packed-weight cache entries now live in graph-private memory
+        ops.end_of_capture()            # packed-weight entries created inside the capture live in graph-private memory
 
     def __call__(self, *inputs):
         for s, t in zip(self.static_in, inputs):

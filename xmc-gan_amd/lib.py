@@ -35,6 +35,11 @@ GEMM_PROBLEM = [("A", "u8"), ("B", "u8"), ("bias", "u8"), ("mask", "u8"), ("C", 
 GP_BIAS, GP_RELU, GP_MASK, GP_ATOMIC = 1, 2, 4, 8
 
 
+class PackJob(C.Structure):
+    _fields_ = [("w", vp), ("wpk", vp), ("row_perm", vp), ("Co", i32), ("Ci", i32), ("KHW", i32), ("rows_pad", i32),
+                ("cols_pad", i32), ("transpose", i32), ("dtype", i32), ("groups", i32), ("upconv", i32)]
+
+
 class AdamEntry(C.Structure):
     _fields_ = [("param", vp), ("grad", vp), ("m", vp), ("v", vp), ("step", vp), ("n", i64)]
 
@@ -49,6 +54,7 @@ _SIGS = {
     "xmc_pack_weight": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp],
     "xmc_pack_weight_grouped": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp],
     "xmc_pack_weight_upconv": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "xmc_pack_weight_multi": [C.POINTER(PackJob), i32, vp],
     "xmc_axpby_up": [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "xmc_unpack_wgrad": [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp],
     "xmc_unpack_wgrad_grouped": [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, i32, vp],

@@ -114,7 +114,7 @@ _weights_epoch = [0]
 
 
 def bump_weights_epoch():
-    """Called by the optimizer kernels' wrapper: parameters changed behind autograd's back."""
+    """Invalidate EVERY cached packed weight (parameters replaced wholesale behind autograd's back)."""
     _weights_epoch[0] += 1
 
 
@@ -152,60 +152,111 @@ def _fill_taps(d, cls, taps):
         d.wi[cls][t] = wi
 
 
-_pack_cache = {}
+_pack_cache = {}          # (id(param), kind, transpose, dtype) -> _PackEntry
 
 
-def _pack(w, geom, transpose, dtype):
+class _PackEntry:
+    """One packed copy of a parameter.  Valid while the parameter has not changed: autograd-visible writes move
+    ``w._version``; the optimizer kernels write behind autograd's back and bump ``w._xmc_epoch`` (optim.HipAdam.step), then
+    re-pack every entry of the parameters they changed in ONE launch (``repack_params``) -- so after the first iteration the
+    forward / backward passes find every pack valid and launch no pack kernel of their own (~100-200 launches of ~6 us per
+    iteration before).  ``gepoch``: bumped when entries may point into graph-private memory (graph._capture)."""
+    __slots__ = ("ref", "version", "pepoch", "gepoch", "geom", "out", "up", "transpose", "wf", "private")
+
+    def valid(self, w, geom):
+        return (self.ref() is w and self.version == w._version and self.pepoch == getattr(w, "_xmc_epoch", 0) and
+                self.gepoch == _weights_epoch[0] and self.geom is geom)
+
+
+def _pack_shape(geom, transpose, dtype, up):
     cs_p = chan_pad(geom.cin, dtype)          # stored channels of x
     cd_p = pad_to(geom.cout, 8)               # stored channels of y
-    if transpose:
-        rows, cols = pad_to(cs_p, 32), cd_p
-    else:
-        rows, cols = pad_to(cd_p, 32), cs_p
-    out = torch.empty((geom.k * geom.k, rows, cols), dtype=dtype, device=w.device)
-    wf = w.detach()
-    if wf.dtype != torch.float32 or not wf.is_contiguous():
-        wf = wf.float().contiguous()
-    L.call("xmc_pack_weight_grouped", _p(wf), _p(out), geom.cout, geom.cin, geom.k, geom.k, rows, cols, int(transpose),
-           _code(dtype), _p(geom.perm_dev(w.device)), geom.groups, _st())
-    return out
-
-
-def _packed_cached(w, geom, transpose, dtype):
-    """Packed copy of ``w`` ([Co,Ci,k,k] / [Co,Ci]) for the forward (transpose=0: [tap][co][ci]) or the
-    data-gradient (transpose=1: [tap][ci][co]) kernel; cached per nn.Parameter until it changes."""
-    if not isinstance(w, torch.nn.Parameter):
-        return _pack(w, geom, transpose, dtype)
-    k = (id(w), transpose, dtype)
-    hit = _pack_cache.get(k)
-    if hit is not None and hit[0]() is w and hit[1] == w._version and hit[2] == _weights_epoch[0] and hit[3] is geom:
-        return hit[4]
-    out = _pack(w, geom, transpose, dtype)
-    _pack_cache[k] = (weakref.ref(w), w._version, _weights_epoch[0], geom, out)
-    return out
-
-
-def _pack_upconv(w, geom, transpose, dtype):
-    cs_p, cd_p = chan_pad(geom.cin, dtype), pad_to(geom.cout, 8)
     rows, cols = (pad_to(cs_p, 32), cd_p) if transpose else (pad_to(cd_p, 32), cs_p)
-    out = torch.empty((16, rows, cols), dtype=dtype, device=w.device)
+    return (16 if up else geom.k * geom.k), rows, cols
+
+
+def _pack_job(wf, out, geom, transpose, up):
+    j = L.PackJob()
+    j.w, j.wpk = wf.data_ptr(), out.data_ptr()
+    perm = None if up else geom.perm_dev(wf.device)
+    j.row_perm = perm.data_ptr() if perm is not None else None
+    j.Co, j.Ci, j.KHW = geom.cout, geom.cin, geom.k * geom.k
+    j.rows_pad, j.cols_pad = out.shape[1], out.shape[2]
+    j.transpose, j.dtype, j.groups, j.upconv = int(transpose), _code(out.dtype), (1 if up else geom.groups), int(up)
+    return j
+
+
+def _pack(w, geom, transpose, dtype, up=False):
+    assert not up or geom.groups == 1
+    out = torch.empty(_pack_shape(geom, transpose, dtype, up), dtype=dtype, device=w.device)
     wf = w.detach()
     if wf.dtype != torch.float32 or not wf.is_contiguous():
         wf = wf.float().contiguous()
-    L.call("xmc_pack_weight_upconv", _p(wf), _p(out), geom.cout, geom.cin, rows, cols, int(transpose), _code(dtype), _st())
+    job = _pack_job(wf, out, geom, transpose, up)
+    L.check(L.load().xmc_pack_weight_multi(C.byref(job), 1, _st()), "xmc_pack_weight_multi")
     return out
+
+
+def _packed_cached(w, geom, transpose, dtype, up=False):
+    """Packed copy of ``w`` ([Co,Ci,k,k] / [Co,Ci]) for the forward (transpose=0: [tap][co][ci]) or the data-gradient
+    (transpose=1: [tap][ci][co]) kernel; ``up``: the 16 pre-summed 2x2-tap slices of the fused upsample convolution.  Cached per
+    nn.Parameter until it changes."""
+    if not isinstance(w, torch.nn.Parameter):
+        return _pack(w, geom, transpose, dtype, up)
+    k = (id(w), bool(up), int(transpose), dtype)
+    hit = _pack_cache.get(k)
+    if hit is not None and hit.valid(w, geom):
+        return hit.out
+    e = _PackEntry()
+    e.ref, e.geom, e.up, e.transpose = weakref.ref(w), geom, bool(up), int(transpose)
+    e.version, e.pepoch, e.gepoch = w._version, getattr(w, "_xmc_epoch", 0), _weights_epoch[0]
+    wd = w.detach()
+    e.wf = wd if (wd.dtype == torch.float32 and wd.is_contiguous()) else None      # None: re-packed lazily, never in bulk
+    e.out = _pack(w, geom, transpose, dtype, up)
+    e.private = w.is_cuda and torch.cuda.is_current_stream_capturing()       # buffer lives in that graph's memory pool
+    if hit is not None and _graphs_alive[0]:
+        _retired_packs.append(hit.out)        # a captured graph may still write / read the buffer it saw
+    _pack_cache[k] = e
+    return e.out
 
 
 def _packed_upconv_cached(w, geom, transpose, dtype):
-    if not isinstance(w, torch.nn.Parameter):
-        return _pack_upconv(w, geom, transpose, dtype)
-    k = (id(w), "up", transpose, dtype)
-    hit = _pack_cache.get(k)
-    if hit is not None and hit[0]() is w and hit[1] == w._version and hit[2] == _weights_epoch[0] and hit[3] is geom:
-        return hit[4]
-    out = _pack_upconv(w, geom, transpose, dtype)
-    _pack_cache[k] = (weakref.ref(w), w._version, _weights_epoch[0], geom, out)
-    return out
+    return _packed_cached(w, geom, transpose, dtype, up=True)
+
+
+_graphs_alive = [0]       # set by graph.GraphedIteration: pack buffers a capture has seen must outlive it
+_retired_packs = []
+
+
+def end_of_capture():
+    """graph.GraphedIteration: a capture has ended.  Entries it created point into its private pool and are dropped (eager
+    code must not use them); every other entry stays valid -- the captured re-pack launches keep writing the same buffers, in
+    the same place of the iteration, as the eager ones."""
+    _graphs_alive[0] += 1
+    for k in [k for k, e in _pack_cache.items() if e.private]:
+        del _pack_cache[k]
+
+
+def repack_params(params):
+    """Re-pack, in one launch per XMC_PACK_MULTI_MAX copies, every cached packed copy of ``params`` (which the caller has just
+    changed and whose ``_xmc_epoch`` it has bumped) into the buffers the entries already own, and mark them valid."""
+    ids = {id(p): p for p in params}
+    jobs, ents = [], []
+    for (pid, _up, _tr, _dt), e in _pack_cache.items():
+        w = ids.get(pid)
+        if w is None or e.ref() is not w or e.wf is None or e.gepoch != _weights_epoch[0] or e.version != w._version:
+            continue
+        if e.wf.data_ptr() != w.data_ptr():
+            continue
+        jobs.append(_pack_job(e.wf, e.out, e.geom, e.transpose, e.up))
+        ents.append((e, w))
+    if not jobs:
+        return 0
+    arr = (L.PackJob * len(jobs))(*jobs)
+    L.check(L.load().xmc_pack_weight_multi(arr, len(jobs), _st()), "xmc_pack_weight_multi")
+    for e, w in ents:
+        e.pepoch = getattr(w, "_xmc_epoch", 0)
+    return len(jobs)
 
 
 def _upconv_fwd_raw(x, w, bias, geom, act, out_dtype):

@@ -127,4 +127,9 @@ class HipAdam(torch.optim.Optimizer):
             L.call("xmc_adam_step", C.c_void_p(tab.data_ptr()), nt, C.c_void_p(ch.data_ptr()), nc,
                    float(group["lr"]), float(b1), float(b2), float(group["eps"]),
                    C.c_void_p(torch.cuda.current_stream().cuda_stream))
-        ops.bump_weights_epoch()
+        # the kernels wrote the parameters behind autograd's back: invalidate their packed copies and re-pack, in one launch,
+        # the ones that exist (ops._PackEntry)
+        changed = [p for group in self.param_groups for p in group["params"] if p.grad is not None]
+        for p in changed:
+            p._xmc_epoch = getattr(p, "_xmc_epoch", 0) + 1
+        ops.repack_params(changed)
