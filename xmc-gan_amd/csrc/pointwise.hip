@@ -469,18 +469,61 @@ __global__ void pack_upconv_kernel(const float* w, void* wpk, int Co, int Ci, in
         else reinterpret_cast<float*>(wpk)[idx] = v;
     }
 }
-// All packed copies of a network's weights in one launch (after the optimizer step that changed them): blockIdx.y = job; the
-// job table travels in the kernel arguments, so the launch is capturable and needs no device-side table.
-struct PackJobs { XmcPackJob j[XMC_PACK_MULTI_MAX]; };
-__global__ void pack_multi_kernel(const PackJobs J) {
-    const XmcPackJob& job = J.j[blockIdx.y];
-    const int64_t total = (int64_t)(job.upconv ? 16 : job.KHW) * job.rows_pad * job.cols_pad;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const float v = job.upconv ? pack_upconv_value(job.w, job.Co, job.Ci, job.rows_pad, job.cols_pad, job.transpose, i)
-                                   : pack_value(job.w, job.Co, job.Ci, job.KHW, job.rows_pad, job.cols_pad, job.transpose, job.row_perm, job.groups, i);
-        if (job.dtype == XMC_BF16) reinterpret_cast<__bf16*>(job.wpk)[i] = (__bf16)v;
-        else reinterpret_cast<float*>(job.wpk)[i] = v;
+// All packed copies of a network's weights in one launch (after the optimizer step that changed them).  The job table travels
+// in the kernel arguments (capturable, no device-side table).  Work is cut into chunks of PM_CHUNK (row, column) positions of
+// the packed matrix; first[j] = first chunk of job j, so blocks are dealt in proportion to the size of a job.  A thread owns one
+// (row, column) position for ALL taps: its KHW source values are contiguous (a wave reads one contiguous piece of the weight),
+// and each tap's store is contiguous across the wave.
+constexpr int PM_CHUNK = 2048;
+struct PackJobs { XmcPackJob j[XMC_PACK_MULTI_MAX]; int32_t first[XMC_PACK_MULTI_MAX + 1]; int32_t njobs; };
+template <int DT>
+__device__ __forceinline__ void pack_store(void* p, int64_t i, float v) {
+    if (DT == XMC_BF16) reinterpret_cast<__bf16*>(p)[i] = (__bf16)v;
+    else reinterpret_cast<float*>(p)[i] = v;
+}
+template <int DT>
+__device__ __forceinline__ void pack_position(const XmcPackJob& job, int pos) {
+    const int c = pos % job.cols_pad, r = pos / job.cols_pad;
+    const int co = job.transpose ? c : r, ci = job.transpose ? r : c;
+    const int64_t plane = (int64_t)job.rows_pad * job.cols_pad;
+    const bool in = co < job.Co && ci < job.Ci;
+    if (job.upconv) {
+        float w9[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) w9[t] = in ? job.w[((int64_t)co * job.Ci + ci) * 9 + t] : 0.f;
+#pragma unroll
+        for (int sl = 0; sl < 16; ++sl) {      // slice (i*2+j)*4 + th*2+tw: rows i=0: {0} | {1,2}, i=1: {0,1} | {2}; same for columns
+            const int i = sl >> 3, j = (sl >> 2) & 1, th = (sl >> 1) & 1, tw = sl & 1;
+            const int kh0 = (i == 0) ? (th == 0 ? 0 : 1) : (th == 0 ? 0 : 2), kh1 = (i == 0) ? (th == 0 ? 0 : 2) : (th == 0 ? 1 : 2);
+            const int kw0 = (j == 0) ? (tw == 0 ? 0 : 1) : (tw == 0 ? 0 : 2), kw1 = (j == 0) ? (tw == 0 ? 0 : 2) : (tw == 0 ? 1 : 2);
+            float v = 0.f;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw)
+                    if (kh >= kh0 && kh <= kh1 && kw >= kw0 && kw <= kw1) v += w9[kh * 3 + kw];
+            pack_store<DT>(job.wpk, sl * plane + pos, v);
+        }
+        return;
     }
+    const int cog = job.Co / job.groups, cig = job.Ci / job.groups;
+    const float* src = nullptr;
+    if (in) {
+        const int sco = job.row_perm ? job.row_perm[co] : co;
+        if (job.groups == 1) src = job.w + ((int64_t)sco * job.Ci + ci) * job.KHW;
+        else if (sco / cog == ci / cig) src = job.w + ((int64_t)sco * cig + ci % cig) * job.KHW;
+    }
+    for (int t = 0; t < job.KHW; ++t) pack_store<DT>(job.wpk, t * plane + pos, src ? src[t] : 0.f);
+}
+__global__ __launch_bounds__(256) void pack_multi_kernel(const PackJobs J) {
+    int jb = 0;
+    while (jb + 1 < J.njobs && (int)blockIdx.x >= J.first[jb + 1]) ++jb;      // uniform; <= 47 steps
+    const XmcPackJob& job = J.j[jb];
+    const int total = job.rows_pad * job.cols_pad;
+    const int p0 = ((int)blockIdx.x - J.first[jb]) * PM_CHUNK;
+    const int p1 = p0 + PM_CHUNK < total ? p0 + PM_CHUNK : total;
+    if (job.dtype == XMC_BF16) for (int pos = p0 + threadIdx.x; pos < p1; pos += 256) pack_position<XMC_BF16>(job, pos);
+    else for (int pos = p0 + threadIdx.x; pos < p1; pos += 256) pack_position<XMC_F32>(job, pos);
 }
 // y[n,2h+i,2w+j,:] = a[n,h,w,:] + alpha * b[n,2h+i,2w+j,:]      (up(shortcut) + gamma*residual without materialising up())
 template <int DT>
@@ -889,15 +932,21 @@ extern "C" int xmc_pack_weight_multi(const XmcPackJob* jobs, int njobs, void* s)
     for (int j0 = 0; j0 < njobs; j0 += XMC_PACK_MULTI_MAX) {
         PackJobs J;
         const int n = njobs - j0 < XMC_PACK_MULTI_MAX ? njobs - j0 : XMC_PACK_MULTI_MAX;
+        int nblk = 0;
         for (int k = 0; k < n; ++k) {
             const XmcPackJob& q = jobs[j0 + k];
             if (!q.w || !q.wpk || (q.dtype != XMC_BF16 && q.dtype != XMC_F32) || q.groups < 1 || q.Co % q.groups || q.Ci % q.groups ||
-                (q.upconv && (q.groups != 1 || q.row_perm)))
+                q.rows_pad < 1 || q.cols_pad < 1 || q.KHW < 1 || (q.upconv && (q.groups != 1 || q.row_perm)))
                 return XMC_EINVAL;
             if (q.transpose ? (q.rows_pad < q.Ci || q.cols_pad < q.Co) : (q.rows_pad < q.Co || q.cols_pad < q.Ci)) return XMC_ESHAPE;
+            if ((int64_t)q.rows_pad * q.cols_pad >= (1ll << 30)) return XMC_ESHAPE;
             J.j[k] = q;
+            J.first[k] = nblk;
+            nblk += (q.rows_pad * q.cols_pad + PM_CHUNK - 1) / PM_CHUNK;
         }
-        hipLaunchKernelGGL(pack_multi_kernel, dim3(48, n), dim3(NT), 0, ST(s), J);
+        J.first[n] = nblk;
+        J.njobs = n;
+        hipLaunchKernelGGL(pack_multi_kernel, dim3(nblk), dim3(256), 0, ST(s), J);
         XMC_LAUNCH_CHECK();
     }
     return 0;
