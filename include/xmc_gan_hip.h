@@ -339,15 +339,23 @@ int xmc_rows_scale(const float* x, const float* coef, const float* g, float* y, 
  * One workgroup per sample.  Parameter-gradient buffers have the parameters' own shapes and must be ZEROED by the caller (the small
  * ones are accumulated over the batch with f32 atomics; the sentence columns of the big ones are written by one thread each).
  * E = TRAIN.NEF (<= 1024).  `hid` [B, 256]: the MLPs' layer-1 pre-activations, produced by head_fwd and consumed by head_bwd.
- * `scratch`: B*64 (query_bwd) / B*256 (head_bwd) floats of workspace.
+ * `scratch`: B*64 (query_bwd) / B*260 (head_bwd) floats of workspace.
+ *  gquery: the self-attention block's query (555-569): q[b, g*4+o] = GroupNorm_4(Wq[g*4+o, :8] . q0[b, g*8 : g*8+8]), q0 = global
+ *         average of the block input.
+ *  head with params[10] = sent_linear.weight [4, E] (self-attention block, 471-478; NULL otherwise): the reasoner's states are
+ *         re-weighted by softmax over the concepts of <Ws sent, r[g]> before the MLPs; grads[10] receives d(Ws).
  *  query: q[b, g*4+o] = GroupNorm_4(Wq[g*4+o, :] . sent[b])   (CondConceptSampler.query_gconv + gn1; gnw = gnb = NULL: no norm)
  *  head : v = value_gconv(ctx); r = ConceptReasoner(v); gamma / beta = grouped MLP([sent ; r])   (238-253, 291-326)
- *         params / grads: 10 pointers in the order value_gconv.weight [64,8], proj_edge.weight [16,4], then for gamma and for
- *         beta: layer-1 weight [128, E+4], bias [128], layer-2 weight [128, 8], bias [128]. */
+ *         params / grads: 11 pointers in the order value_gconv.weight [64,8], proj_edge.weight [16,4], then for gamma and for
+ *         beta: layer-1 weight [128, E+4], bias [128], layer-2 weight [128, 8], bias [128]; then sent_linear.weight or NULL. */
 int xmc_concept_query_fwd(const float* sent, const float* Wq, const float* gnw, const float* gnb, float* q, float* qraw,
                           int B, int E, float eps, void* stream);
 int xmc_concept_query_bwd(const float* sent, const float* Wq, const float* gnw, const float* qraw, const float* dq, float* dsent,
                           float* dWq, float* dgnw, float* dgnb, float* scratch, int B, int E, float eps, void* stream);
+int xmc_concept_gquery_fwd(const float* q0, const float* Wq, const float* gnw, const float* gnb, float* q, float* qraw, int B,
+                           float eps, void* stream);
+int xmc_concept_gquery_bwd(const float* q0, const float* Wq, const float* gnw, const float* qraw, const float* dq, float* dq0,
+                           float* dWq, float* dgnw, float* dgnb, int B, float eps, void* stream);
 int xmc_concept_head_fwd(const float* ctx, const float* sent, const float* const* params, float* gamma, float* beta, float* hid,
                          int B, int E, void* stream);
 int xmc_concept_head_bwd(const float* ctx, const float* sent, const float* hid, const float* const* params, const float* dgamma,

@@ -651,6 +651,58 @@ def test_concept_algebra_kernels_match_composed_reference():
             torch.testing.assert_close(got.grad.cpu().double(), want.grad, rtol=5e-4, atol=5e-5 * max(sc_, 1e-3))
 
 
+@pytest.mark.parametrize("E", [256, 768])
+def test_self_attention_concept_algebra_matches_composed_reference(E):
+    """xmc_concept_gquery / xmc_concept_head with sent_linear (the self-attention block, df_concept_gan.py:443-478, 555-581)
+    against the composed f64 expressions: outputs and every gradient."""
+    g = torch.Generator().manual_seed(9)
+    B = 6
+    rnd = lambda *s, sc=1.0: torch.randn(*s, generator=g) * sc
+    sent, q0, pooled = rnd(B, E), rnd(B, 128), rnd(B, 16, 8)
+    wq, gnw, gnb = rnd(64, 8, 1, 1, sc=0.4), 1 + 0.1 * rnd(64), 0.1 * rnd(64)
+    P = [rnd(64, 8, 1, 1, sc=0.4), rnd(16, 4, sc=0.5)]
+    for _ in range(2):
+        P += [rnd(128, E + 4, 1, 1, sc=(E + 4) ** -0.5), 0.1 * rnd(128), rnd(128, 8, 1, 1, sc=0.35), 0.1 * rnd(128)]
+    P += [rnd(4, E, sc=2.0 * E ** -0.5)]                      # sent_linear
+
+    def ref(sent, q0, wq, gnw, gnb, pooled, P):
+        q = torch.einsum('bgi,goi->bgo', q0.view(B, 16, 8), wq.view(16, 4, 8))
+        q = F.group_norm(q.reshape(B, 64), 16, gnw, gnb).view(B, 16, 4)
+        v = torch.einsum('bgi,goi->bgo', pooled, P[0].view(16, 4, 8))
+        adj = torch.tanh(F.linear(v, P[1]))
+        st = F.relu(v + torch.matmul(adj, v)).transpose(1, 2)               # [B,4,16]
+        s = F.linear(sent, P[10]).view(B, -1, 1)
+        attn = F.softmax(torch.matmul(s.transpose(1, 2), st), dim=2)
+        ctx = (st * attn).transpose(1, 2)
+        cond = torch.cat([sent.view(B, 1, E).expand(B, 16, E), ctx], dim=2)
+        outs = []
+        for t in range(2):
+            w1, b1, w2, b2 = P[2 + 4 * t: 6 + 4 * t]
+            h = F.leaky_relu(torch.einsum('bgi,goi->bgo', cond, w1.view(16, 8, E + 4)) + b1.view(1, 16, 8), 0.2)
+            outs.append((torch.einsum('bgi,goi->bgo', h, w2.view(16, 8, 8)) + b2.view(1, 16, 8)).reshape(B, 128))
+        return q, outs[0], outs[1]
+
+    ins64 = [t.double().requires_grad_() for t in (sent, q0, wq, gnw, gnb, pooled)] + [[p.double().requires_grad_() for p in P]]
+    q_r, ga_r, be_r = ref(*ins64)
+    wts = [rnd(*t.shape).double() for t in (q_r, ga_r, be_r)]
+    (q_r * wts[0]).sum().add((ga_r * wts[1]).sum()).add((be_r * wts[2]).sum()).backward()
+    d = lambda t: t.to(DEV).requires_grad_()
+    sent_d, q0_d, wq_d, gnw_d, gnb_d, pooled_d = d(sent), d(q0), d(wq), d(gnw), d(gnb), d(pooled)
+    P_d = [d(p) for p in P]
+    q = ops.concept_gquery(q0_d, wq_d, gnw_d, gnb_d)
+    ga, be = ops.concept_head(pooled_d, sent_d, P_d)
+    ((q * wts[0].float().to(DEV)).sum() + (ga * wts[1].float().to(DEV)).sum() + (be * wts[2].float().to(DEV)).sum()).backward()
+    tol_ = dict(rtol=2e-4, atol=2e-5)
+    torch.testing.assert_close(q.detach().cpu().double(), q_r.detach(), **tol_)
+    torch.testing.assert_close(ga.detach().cpu().double(), ga_r.detach(), **tol_)
+    torch.testing.assert_close(be.detach().cpu().double(), be_r.detach(), **tol_)
+    pairs = [(sent_d, ins64[0]), (q0_d, ins64[1]), (wq_d, ins64[2]), (gnw_d, ins64[3]), (gnb_d, ins64[4]), (pooled_d, ins64[5])]
+    pairs += list(zip(P_d, ins64[6]))
+    for got, want in pairs:
+        sc_ = float(want.grad.abs().max())
+        torch.testing.assert_close(got.grad.cpu().double(), want.grad, rtol=5e-4, atol=5e-5 * max(sc_, 1e-3))
+
+
 def test_optimizer_step_repacks_cached_weights_in_bulk():
     """HipAdam.step changes the parameters behind autograd's back; every cached packed copy (forward, data-gradient, fused
     upsample, grouped) must be re-packed by the step itself -- same buffers, marked valid -- and give the new weights' result."""

@@ -6,7 +6,9 @@
 // nodes): ~1 900 launches of 4-5 us per iteration at 128 px, a quarter of the iteration.  Here a stage is one or two launches:
 //
 //   xmc_concept_query_fwd/bwd : q[g,:] = GroupNorm_4( Wq[g] (4 x nef) . sent )                        (273-286; gn1)
+//   xmc_concept_gquery_fwd/bwd: q[g,:] = GroupNorm_4( Wq[g] (4 x 8) . avgpool(x)[g] )                   (555-569: the self-attention block)
 //   xmc_concept_head_fwd/bwd  : v = Wv[g] ctx[g];  adj = tanh(v We^T);  r = relu(v + adj v);                (291-302, 313-326)
+//                               [self-attention block, 471-478: s = Ws sent; att = softmax_g <s, r[g]>; r[g] <- att[g] r[g]]
 //                               for t in {gamma, beta}:  a = W1_t[g] [sent ; r[g]] + b1_t;  out_t = W2_t[g] lrelu(a) + b2_t   (238-253)
 //
 // The only part with any arithmetic in it is the sentence vector against the 64 (query) / 256 (MLP layer 1) weight rows of nef
@@ -67,7 +69,7 @@ __device__ __forceinline__ float rows_dot64(const float* __restrict__ W, int ld,
 // blocks [0, R/2): dW rows 2*blk, 2*blk+1 (written: columns [0, C));   blocks [R/2, R/2+B): dX[b, :] (written)
 struct OuterArgs {
     const float* D; const float* X; const float* W[2]; float* dW[2]; float* dX;
-    int B, R, Rp, C, ldw;
+    int B, R, Rp, C, ldw, acc_dx;       // acc_dx: dX += instead of =
 };
 __global__ __launch_bounds__(256) void concept_outer_kernel(OuterArgs a) {
     const int blk = blockIdx.x;
@@ -93,6 +95,7 @@ __global__ __launch_bounds__(256) void concept_outer_kernel(OuterArgs a) {
 #pragma unroll 8
                 for (int r = 0; r < a.Rp; ++r) s += dd[r] * w[(size_t)r * a.ldw + c];
             }
+            if (a.acc_dx) s += a.dX[(size_t)b * a.C + c];
             a.dX[(size_t)b * a.C + c] = s;
         }
     }
@@ -141,6 +144,59 @@ __global__ __launch_bounds__(64) void concept_query_bwd_kernel(const float* __re
     dx[(size_t)b * 64 + c] = g;
 }
 
+// query of the self-attention sampler: q0 [B, CARD*PWD] (global average of x), Wq [CARD*SD, PWD] grouped 1x1 (555-569)
+__global__ __launch_bounds__(64) void concept_gquery_fwd_kernel(const float* __restrict__ q0, const float* __restrict__ Wq,
+                                                               const float* __restrict__ gnw, const float* __restrict__ gnb,
+                                                               float* __restrict__ q, float* __restrict__ qraw, float eps) {
+    const int b = blockIdx.x, c = threadIdx.x, g = c >> 2;
+    float x = 0.f;
+#pragma unroll
+    for (int i = 0; i < PWD; ++i) x += Wq[c * PWD + i] * q0[(size_t)b * CARD * PWD + g * PWD + i];
+    qraw[(size_t)b * 64 + c] = x;
+    if (gnw) {
+        float m = x + __shfl_xor(x, 1, 64); m += __shfl_xor(m, 2, 64); m *= 0.25f;
+        const float dx = x - m;
+        float v = dx * dx; v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v *= 0.25f;
+        x = dx * rsqrtf(v + eps) * gnw[c] + gnb[c];
+    }
+    q[(size_t)b * 64 + c] = x;
+}
+// dq [B,64] -> dq0 [B, CARD*PWD] (written); dWq [64, PWD], dgnw, dgnb atomically accumulated
+__global__ __launch_bounds__(64) void concept_gquery_bwd_kernel(const float* __restrict__ q0, const float* __restrict__ Wq,
+                                                               const float* __restrict__ gnw, const float* __restrict__ qraw,
+                                                               const float* __restrict__ dq, float* __restrict__ dq0,
+                                                               float* __restrict__ dWq, float* __restrict__ dgnw,
+                                                               float* __restrict__ dgnb, float eps) {
+    __shared__ float s_dx[64];
+    const int b = blockIdx.x, c = threadIdx.x, g = c >> 2, d = c & 3;
+    const float x = qraw[(size_t)b * 64 + c];
+    float gr = dq[(size_t)b * 64 + c];
+    if (gnw) {
+        float m = x + __shfl_xor(x, 1, 64); m += __shfl_xor(m, 2, 64); m *= 0.25f;
+        const float dxm = x - m;
+        float v = dxm * dxm; v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v *= 0.25f;
+        const float rstd = rsqrtf(v + eps), xh = dxm * rstd;
+        atomicAdd(&dgnw[c], gr * xh);
+        atomicAdd(&dgnb[c], gr);
+        const float gh = gr * gnw[c];
+        float s1 = gh + __shfl_xor(gh, 1, 64); s1 += __shfl_xor(s1, 2, 64); s1 *= 0.25f;
+        float s2 = gh * xh; s2 += __shfl_xor(s2, 1, 64); s2 += __shfl_xor(s2, 2, 64); s2 *= 0.25f;
+        gr = rstd * (gh - s1 - xh * s2);
+    }
+    s_dx[c] = gr;
+#pragma unroll
+    for (int i = 0; i < PWD; ++i) atomicAdd(&dWq[c * PWD + i], gr * q0[(size_t)b * CARD * PWD + g * PWD + i]);
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {         // lane (g, d) writes d q0[g][i], i = d*2 + h
+        const int i = d * 2 + h;
+        float a = 0.f;
+#pragma unroll
+        for (int o = 0; o < SD; ++o) a += s_dx[g * SD + o] * Wq[(g * SD + o) * PWD + i];
+        dq0[(size_t)b * CARD * PWD + g * PWD + i] = a;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ head
 struct HeadParams {
     const float* Wv;       // [CARD*SD, PWD]     value_gconv (grouped 1x1, no bias)
@@ -149,6 +205,7 @@ struct HeadParams {
     const float* b1[2];    // [HID]
     const float* W2[2];    // [CARD*PWD, 2*SD]   layer 2 (grouped)
     const float* b2[2];    // [CARD*PWD]
+    const float* Ws;       // [SD, E] sent_linear of the self-attention block (471-478), or NULL
 };
 struct HeadGrads {
     float* Wv; float* We; float* W1[2]; float* b1[2]; float* W2[2]; float* b2[2];
@@ -162,6 +219,8 @@ struct HeadState {
     float pre[CARD][SD];       // v + adj v  (before the ReLU)
     float r[CARD][SD];
     float a[2][CARD][2 * SD];  // layer-1 pre-activations
+    float s[SD], att[CARD];    // sentence->concept attention (P.Ws != NULL): s = Ws sent, att = softmax_g <s, r[g]>
+    float c[CARD][SD];         // what the MLPs see: r, or att[g] * r[g]
 };
 
 // value projection + ConceptReasoner by the first wave of the workgroup (tid < 64: lane = (g, d)); ends with a barrier for all
@@ -196,6 +255,40 @@ __device__ __forceinline__ void reasoner_forward(HeadState& S, const HeadParams&
     __syncthreads();
 }
 
+// S.c = the concept state the MLPs are conditioned on.  sent in shared memory; NW waves; ends with a barrier
+template <int NW>
+__device__ __forceinline__ void context_forward(HeadState& S, const HeadParams& P, const float* s_sent, int E, int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+    if (P.Ws) {
+        for (int d = wave; d < SD; d += NW) {                // one wave per row of Ws
+            float x = 0.f;
+            for (int i = lane; i < E; i += 64) x += P.Ws[(size_t)d * E + i] * s_sent[i];
+            x = wave_sum(x);
+            if (lane == 0) S.s[d] = x;
+        }
+        __syncthreads();
+        if (tid < CARD) {                                     // 16 lanes of wave 0: softmax over the concepts
+            float l = 0.f;
+#pragma unroll
+            for (int d = 0; d < SD; ++d) l += S.s[d] * S.r[tid][d];
+            float m = l;
+#pragma unroll
+            for (int o = 8; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+            const float e = __expf(l - m);
+            float z = e;
+#pragma unroll
+            for (int o = 8; o >= 1; o >>= 1) z += __shfl_xor(z, o, 64);
+            S.att[tid] = e / z;
+        }
+        __syncthreads();
+    }
+    if (tid < 64) {
+        const int g = tid >> 2, d = tid & 3;
+        S.c[g][d] = P.Ws ? S.att[g] * S.r[g][d] : S.r[g][d];
+    }
+    __syncthreads();
+}
+
 // ctx [B,CARD,PWD], sent [B,E] -> gamma, beta [B, CARD*PWD], hid [B, 2*HID] (layer-1 pre-activations, kept for the backward)
 __global__ __launch_bounds__(256) void concept_head_fwd_kernel(const float* __restrict__ ctx, const float* __restrict__ sent,
                                                               HeadParams P, float* __restrict__ gamma, float* __restrict__ beta,
@@ -210,11 +303,12 @@ __global__ __launch_bounds__(256) void concept_head_fwd_kernel(const float* __re
     const int t = wave >> 1, row = (wave & 1) * 64 + lane, ld = E + SD;
     float a = rows_dot64(P.W1[t] + (size_t)(wave & 1) * 64 * ld, ld, s_sent, E, lane) + P.b1[t][row];
     reasoner_forward(S, P, tid);
+    context_forward<4>(S, P, s_sent, E, tid);
     {
         const int g = row >> 3;
         const float* w = P.W1[t] + (size_t)row * ld + E;
 #pragma unroll
-        for (int dd = 0; dd < SD; ++dd) a += w[dd] * S.r[g][dd];
+        for (int dd = 0; dd < SD; ++dd) a += w[dd] * S.c[g][dd];
         (&S.a[t][0][0])[row] = a;
         hid[(size_t)b * 2 * HID + tid] = a;
     }
@@ -230,11 +324,13 @@ __global__ __launch_bounds__(256) void concept_head_fwd_kernel(const float* __re
 
 // dgamma, dbeta [B, CARD*PWD], hid -> dctx [B,CARD,PWD] (written), da [B, 2*HID] (written: d of the layer-1 pre-activations,
 // for concept_outer_kernel), small parameter gradients (atomics)
-__global__ __launch_bounds__(64) void concept_head_bwd_kernel(const float* __restrict__ ctx, const float* __restrict__ hid,
-                                                             HeadParams P, const float* __restrict__ dgamma,
-                                                             const float* __restrict__ dbeta, float* __restrict__ dctx,
-                                                             float* __restrict__ da_out, HeadGrads G, int E) {
+__global__ __launch_bounds__(64) void concept_head_bwd_kernel(const float* __restrict__ ctx, const float* __restrict__ sent,
+                                                             const float* __restrict__ hid, HeadParams P,
+                                                             const float* __restrict__ dgamma, const float* __restrict__ dbeta,
+                                                             float* __restrict__ dctx, float* __restrict__ da_out,
+                                                             float* __restrict__ ds_out, HeadGrads G, int E) {
     __shared__ HeadState S;
+    __shared__ __attribute__((aligned(16))) float s_sent[1024];
     __shared__ float s_do[2][CARD][PWD], s_da[2][CARD][2 * SD], s_dr[CARD][SD], s_dm[CARD][SD], s_de[CARD][CARD], s_dv[CARD][SD];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int g = tid >> 2, d = tid & 3;
@@ -244,8 +340,10 @@ __global__ __launch_bounds__(64) void concept_head_bwd_kernel(const float* __res
         (&s_do[1][0][0])[i] = dbeta[(size_t)b * CARD * PWD + i];
     }
     for (int i = tid; i < 2 * HID; i += 64) (&S.a[0][0][0])[i] = hid[(size_t)b * 2 * HID + i];
+    if (P.Ws) for (int i = tid; i < E; i += 64) s_sent[i] = sent[(size_t)b * E + i];
     __syncthreads();
     reasoner_forward(S, P, tid);
+    context_forward<1>(S, P, s_sent, E, tid);
     const int ld = E + SD;
     // ---- layer 2: out = W2 lrelu(a) + b2
 #pragma unroll
@@ -268,7 +366,7 @@ __global__ __launch_bounds__(64) void concept_head_bwd_kernel(const float* __res
             // layer 1's concept-state columns and bias
             float* gw = G.W1[t] + (size_t)(g * 2 * SD + i) * ld;
 #pragma unroll
-            for (int dd = 0; dd < SD; ++dd) atomicAdd(&gw[E + dd], da * S.r[g][dd]);
+            for (int dd = 0; dd < SD; ++dd) atomicAdd(&gw[E + dd], da * S.c[g][dd]);
             atomicAdd(&G.b1[t][g * 2 * SD + i], da);
         }
     }
@@ -279,6 +377,20 @@ __global__ __launch_bounds__(64) void concept_head_bwd_kernel(const float* __res
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int o = 0; o < 2 * SD; ++o) dr += P.W1[t][(size_t)(g * 2 * SD + o) * ld + E + d] * s_da[t][g][o];
+        if (P.Ws) {                       // c[g][d] = att[g] r[g][d], att = softmax_g(l), l[g] = <s, r[g]>, s = Ws sent
+            const float dc = dr;
+            float da_g = dc * S.r[g][d];                          // d att[g] = <dc[g], r[g]>
+            da_g += __shfl_xor(da_g, 1, 64); da_g += __shfl_xor(da_g, 2, 64);
+            float dot = (d == 0) ? S.att[g] * da_g : 0.f;         // sum_g att[g] d att[g]
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) dot += __shfl_xor(dot, o, 64);
+            const float dl = S.att[g] * (da_g - dot);             // d l[g]
+            dr = dc * S.att[g] + dl * S.s[d];
+            float dsd = dl * S.r[g][d];                           // d s[d] = sum_g dl[g] r[g][d]: lanes with the same d
+#pragma unroll
+            for (int o = 32; o >= 4; o >>= 1) dsd += __shfl_xor(dsd, o, 64);
+            if (g == 0) ds_out[(size_t)b * SD + d] = dsd;
+        }
         s_dr[g][d] = dr;
         // ---- reasoner: r = relu(pre), pre = v + adj v, adj = tanh(v We^T)
         s_dm[g][d] = S.pre[g][d] > 0.f ? dr : 0.f;          // d pre (= d m, and the direct part of d v)
@@ -348,14 +460,31 @@ extern "C" int xmc_concept_query_bwd(const float* sent, const float* Wq, const f
     XMC_LAUNCH_CHECK();
     OuterArgs a;
     a.D = scratch; a.X = sent; a.W[0] = Wq; a.W[1] = nullptr; a.dW[0] = dWq; a.dW[1] = nullptr; a.dX = dsent;
-    a.B = B; a.R = 64; a.Rp = 64; a.C = E; a.ldw = E;
+    a.B = B; a.R = 64; a.Rp = 64; a.C = E; a.ldw = E; a.acc_dx = 0;
     hipLaunchKernelGGL(concept_outer_kernel, dim3(a.R / 2 + B), dim3(256), 0, ST(stream), a);
     XMC_LAUNCH_CHECK();
     return 0;
 }
 
-// params / grads: 10 pointers each in the order Wv, We, W1g, b1g, W2g, b2g, W1b, b1b, W2b, b2b
+extern "C" int xmc_concept_gquery_fwd(const float* q0, const float* Wq, const float* gnw, const float* gnb, float* q, float* qraw,
+                                      int B, float eps, void* stream) {
+    if (!q0 || !Wq || !q || !qraw || B < 1 || (gnw == nullptr) != (gnb == nullptr)) return XMC_EINVAL;
+    hipLaunchKernelGGL(concept_gquery_fwd_kernel, dim3(B), dim3(64), 0, ST(stream), q0, Wq, gnw, gnb, q, qraw, eps);
+    XMC_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int xmc_concept_gquery_bwd(const float* q0, const float* Wq, const float* gnw, const float* qraw, const float* dq,
+                                      float* dq0, float* dWq, float* dgnw, float* dgnb, int B, float eps, void* stream) {
+    if (!q0 || !Wq || !qraw || !dq || !dq0 || !dWq || B < 1 || (gnw && (!dgnw || !dgnb))) return XMC_EINVAL;
+    hipLaunchKernelGGL(concept_gquery_bwd_kernel, dim3(B), dim3(64), 0, ST(stream), q0, Wq, gnw, qraw, dq, dq0, dWq, dgnw, dgnb, eps);
+    XMC_LAUNCH_CHECK();
+    return 0;
+}
+
+// params / grads: 11 pointers each in the order Wv, We, W1g, b1g, W2g, b2g, W1b, b1b, W2b, b2b, Ws (Ws: sent_linear of the
+// self-attention block or NULL, then grads[10] is not used)
 static int head_params(const float* const* p, HeadParams& P) {
+    P.Ws = p[10];
     for (int i = 0; i < 10; ++i) if (!p[i]) return 0;
     P.Wv = p[0]; P.We = p[1];
     P.W1[0] = p[2]; P.b1[0] = p[3]; P.W2[0] = p[4]; P.b2[0] = p[5];
@@ -378,16 +507,24 @@ extern "C" int xmc_concept_head_bwd(const float* ctx, const float* sent, const f
         !head_params(params, P))
         return XMC_EINVAL;
     for (int i = 0; i < 10; ++i) if (!grads[i]) return XMC_EINVAL;
+    if (P.Ws && !grads[10]) return XMC_EINVAL;
     HeadGrads G;
     G.Wv = grads[0]; G.We = grads[1];
     G.W1[0] = grads[2]; G.b1[0] = grads[3]; G.W2[0] = grads[4]; G.b2[0] = grads[5];
     G.W1[1] = grads[6]; G.b1[1] = grads[7]; G.W2[1] = grads[8]; G.b2[1] = grads[9];
-    hipLaunchKernelGGL(concept_head_bwd_kernel, dim3(B), dim3(64), 0, ST(stream), ctx, hid, P, dgamma, dbeta, dctx, scratch, G, E);
+    float* ds = scratch + (size_t)B * 2 * HID;       // [B, SD]: d (Ws sent)
+    hipLaunchKernelGGL(concept_head_bwd_kernel, dim3(B), dim3(64), 0, ST(stream), ctx, sent, hid, P, dgamma, dbeta, dctx, scratch, ds, G, E);
     XMC_LAUNCH_CHECK();
     OuterArgs a;
     a.D = scratch; a.X = sent; a.W[0] = P.W1[0]; a.W[1] = P.W1[1]; a.dW[0] = G.W1[0]; a.dW[1] = G.W1[1]; a.dX = dsent;
-    a.B = B; a.R = 2 * HID; a.Rp = HID; a.C = E; a.ldw = E + SD;
+    a.B = B; a.R = 2 * HID; a.Rp = HID; a.C = E; a.ldw = E + SD; a.acc_dx = 0;
     hipLaunchKernelGGL(concept_outer_kernel, dim3(a.R / 2 + B), dim3(256), 0, ST(stream), a);
     XMC_LAUNCH_CHECK();
+    if (P.Ws) {                                       // dWs = ds^T sent;  dsent += ds Ws
+        a.D = ds; a.W[0] = P.Ws; a.W[1] = nullptr; a.dW[0] = grads[10]; a.dW[1] = nullptr;
+        a.R = SD; a.Rp = SD; a.ldw = E; a.acc_dx = 1;
+        hipLaunchKernelGGL(concept_outer_kernel, dim3(a.R / 2 + B), dim3(256), 0, ST(stream), a);
+        XMC_LAUNCH_CHECK();
+    }
     return 0;
 }

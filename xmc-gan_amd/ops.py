@@ -1540,19 +1540,53 @@ class ConceptQueryFn(torch.autograd.Function):
         return dsent, dw.view(ctx.wshape), dgw, dgb, None
 
 
+class ConceptGQueryFn(torch.autograd.Function):
+    """Query of the self-attention sampler (df_concept_gan.py:555-569): grouped 1x1 (8 -> 4 per concept) on the globally
+    averaged block input + GroupNorm over each concept's 4 values.  q0 f32 [B,128], wq [64,8,1,1] -> q f32 [B,16,4]."""
+
+    @staticmethod
+    def forward(ctx, q0, wq, gnw, gnb, eps):
+        q0 = q0.contiguous().float()
+        _need_cuda(q0, wq)
+        B = q0.shape[0]
+        assert q0.shape[1] == 128 and wq.numel() == 64 * 8
+        w = wq.detach().contiguous().float().view(64, 8)
+        q = torch.empty(B, 64, dtype=torch.float32, device=q0.device)
+        qraw = torch.empty_like(q)
+        L.call("xmc_concept_gquery_fwd", _p(q0), _p(w), _p(gnw), _p(gnb), _p(q), _p(qraw), B, float(eps), _st())
+        ctx.eps, ctx.wshape = float(eps), tuple(wq.shape)
+        ctx.save_for_backward(q0, w, gnw, qraw)
+        return q.view(B, 16, 4)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dq):
+        q0, w, gnw, qraw = ctx.saved_tensors
+        B = q0.shape[0]
+        dq = dq.contiguous().float()
+        dq0 = torch.empty_like(q0)
+        flat = torch.zeros(64 * 8 + 128, dtype=torch.float32, device=q0.device)
+        dw = flat[:512].view(64, 8)
+        dgw = flat[512:576] if gnw is not None else None
+        dgb = flat[576:] if gnw is not None else None
+        L.call("xmc_concept_gquery_bwd", _p(q0), _p(w), _p(gnw), _p(qraw), _p(dq), _p(dq0), _p(dw), _p(dgw), _p(dgb), B, ctx.eps, _st())
+        return dq0, dw.view(ctx.wshape), dgw, dgb, None
+
+
 class ConceptHeadFn(torch.autograd.Function):
-    """Everything between the region attention and the channel modulation of one sampler stage of InConceptBlock
-    (df_concept_gan.py:238-253, 291-326): value projection, ConceptReasoner, the gamma and beta grouped MLPs on
-    [sentence ; concept state].  pooled f32 [B,16,8], sent f32 [B,E], ten parameters -> (gamma, beta) f32 [B,128]."""
+    """Everything between the region attention and the channel modulation of one sampler stage of the attention-modulation
+    blocks (df_concept_gan.py:238-253, 291-326; 471-478 for the self-attention block): value projection, ConceptReasoner,
+    [sentence -> concept softmax re-weighting], the gamma and beta grouped MLPs on [sentence ; concept state].
+    pooled f32 [B,16,8], sent f32 [B,E], ten parameters (+ sent_linear.weight) -> (gamma, beta) f32 [B,128]."""
 
     @staticmethod
     def forward(ctx, pooled, sent, *params):
-        assert len(params) == 10
+        assert len(params) in (10, 11)
         pooled, sent = pooled.contiguous().float(), sent.contiguous().float()
         _need_cuda(pooled, sent)
         B, E = sent.shape
         ps = [p_.detach().contiguous().float() for p_ in params]
-        tab = (C.c_void_p * 10)(*[p_.data_ptr() for p_ in ps])
+        tab = (C.c_void_p * 11)(*[p_.data_ptr() for p_ in ps])          # tab[10] stays NULL without sent_linear
         gamma = torch.empty(B, 128, dtype=torch.float32, device=sent.device)
         beta = torch.empty_like(gamma)
         hid = torch.empty(B, 256, dtype=torch.float32, device=sent.device)
@@ -1574,9 +1608,9 @@ class ConceptHeadFn(torch.autograd.Function):
         for p_, n_ in zip(ps, sizes):
             grads.append(flat[off:off + p_.numel()].view(p_.shape))
             off += n_
-        tab = (C.c_void_p * 10)(*[p_.data_ptr() for p_ in ps])
-        gtab = (C.c_void_p * 10)(*[g_.data_ptr() for g_ in grads])
-        scratch = torch.empty(B, 256, dtype=torch.float32, device=sent.device)
+        tab = (C.c_void_p * 11)(*[p_.data_ptr() for p_ in ps])
+        gtab = (C.c_void_p * 11)(*[g_.data_ptr() for g_ in grads])
+        scratch = torch.empty(B, 260, dtype=torch.float32, device=sent.device)
         L.call("xmc_concept_head_bwd", _p(pooled), _p(sent), _p(hid), tab, _p(dgamma), _p(dbeta), _p(dpooled), _p(dsent), gtab,
                _p(scratch), B, E, _st())
         return (dpooled, dsent) + tuple(g_.view(sh) for g_, sh in zip(grads, ctx.shapes))
@@ -1584,6 +1618,10 @@ class ConceptHeadFn(torch.autograd.Function):
 
 def concept_query(sent, wq, gnw=None, gnb=None, eps=1e-5):
     return ConceptQueryFn.apply(sent, wq, gnw, gnb, eps)
+
+
+def concept_gquery(q0, wq, gnw=None, gnb=None, eps=1e-5):
+    return ConceptGQueryFn.apply(q0, wq, gnw, gnb, eps)
 
 
 def concept_head(pooled, sent, params):

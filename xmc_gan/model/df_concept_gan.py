@@ -5,8 +5,7 @@ self region attention + sentence->concept attention), plus the ``NetD`` stub tha
 Same class names, constructor/forward signatures and ``state_dict()`` keys.  Heavy per-pixel work runs in HIP kernels:
 1x1 / 3x3 / block-diagonal grouped convolutions on the MFMA implicit-GEMM kernels, GroupNorm(+LeakyReLU), the region
 attention (scores, softmax over H*W, weighted sum), the per-sample channel modulation and -- for the sentence-conditioned
-block -- the per-sample concept algebra on ``[B,16,<=260]`` numbers (csrc/concept.hip).  The self-attention variant
-(OutConceptBlock) still composes that algebra from ATen ops.
+and self-attention blocks -- the per-sample concept algebra on ``[B,16,<=260]`` numbers (csrc/concept.hip).
 """
 import torch
 import torch.nn as nn
@@ -202,14 +201,24 @@ class OutConceptBlock(_ConceptBlockBase):
     def forward(self, x, sent_embs):
         B = x.size(0)
         out = self._trunk(x)
-        gc = sent_embs.view(B, 1, -1).expand(B, self.cardinality, -1)
+        sent = sent_embs.float()
+        if not x.is_cuda:
+            raise RuntimeError("OutConceptBlock runs on the GPU only (no CPU fallback)")
         for samp, reas, sl, gm, bm in (
                 (self.concept_sampler1, self.concept_reasoner1, self.sent_linear1, self.gamma1_gconv, self.beta1_gconv),
                 (self.concept_sampler2, self.concept_reasoner2, self.sent_linear2, self.gamma2_gconv, self.beta2_gconv)):
-            st = reas(samp(out)).transpose(1, 2)                                  # [B,p',C]
-            s = F.linear(sent_embs, sl.weight).view(B, -1, 1)
-            ctx = self.get_context_embs(st, s).transpose(1, 2)                    # [B,C,p']
-            out = self._modulate(out, gc, ctx, gm, bm)
+            # the per-sample concept algebra in csrc/concept.hip, around the region attention:
+            #   query from the globally averaged map + GroupNorm                                               (555-569)
+            #   value projection, ConceptReasoner, sentence->concept softmax re-weighting, gamma / beta MLPs  (443-478, 570-581)
+            q0 = ops.global_avgpool(out).view(B, -1)
+            q = ops.concept_gquery(q0, samp.query_gconv.weight, samp.gn1.weight if samp.normalize else None,
+                                   samp.gn1.bias if samp.normalize else None)
+            pooled = samp.pool(out, q, samp._scale)                                    # [B,16,8]
+            gamma, beta = ops.concept_head(pooled, sent, (
+                samp.value_gconv.weight, reas.proj_edge.weight,
+                gm[0].weight, gm[0].bias, gm[2].weight, gm[2].bias, bm[0].weight, bm[0].bias, bm[2].weight, bm[2].bias,
+                sl.weight))
+            out = ops.affine_lrelu(out, gamma, beta)
         return out
 
 
