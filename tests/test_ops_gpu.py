@@ -721,7 +721,7 @@ def test_optimizer_step_repacks_cached_weights_in_bulk():
         return [y.detach().float() for y in ys]
 
     run()                                                    # creates the forward and data-gradient entries
-    ents = {k: e for k, e in ops._pack_cache.items() if k[0] in {id(w) for w in ws}}
+    ents = {k: e for k, e in ops._pack_cache.items() if any(e.ref() is w for w in ws)}
     assert len(ents) >= 6
     ptrs = {k: e.out.data_ptr() for k, e in ents.items()}
     before = [w.detach().clone() for w in ws]

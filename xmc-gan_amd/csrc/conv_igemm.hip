@@ -312,7 +312,7 @@ int dispatch(const XmcConvDesc& d, hipStream_t st) {
 
 }  // namespace
 
-int xmc_conv_tile_try(const XmcConvDesc* d, const float* const* pro, void* stream);   // conv_tile.hip
+int xmc_conv_tile_try(const XmcConvDesc* d, void* stream);                            // conv_tile.hip
 int xmc_conv_thin_try(const XmcConvDesc* d, void* stream);                            // conv_thin.hip
 int xmc_conv_pw1x1_try(const XmcConvDesc* d, void* stream);                           // conv_thin.hip
 int xmc_conv_wtile_try(const XmcConvDesc* d, void* stream);                           // conv_wtile.hip
@@ -351,7 +351,7 @@ extern "C" int xmc_conv_igemm(const XmcConvDesc* d, void* stream) {
         if (rc > 0) rc = xmc_conv_thin_try(&dd, stream);
         if (rc > 0) rc = xmc_conv_pw1x1_try(&dd, stream);
         if (rc > 0 && !no_wt2) rc = xmc_conv_wtile_try(&dd, stream);
-        if (rc > 0) rc = xmc_conv_tile_try(&dd, nullptr, stream);
+        if (rc > 0) rc = xmc_conv_tile_try(&dd, stream);
         if (rc < 0) return rc;
     }
     if (rc > 0) {

@@ -13,8 +13,9 @@
 // LDS rows are (slab bytes + 32 B) apart: with 16-byte chunks this stride makes the ds_read_b128
 // fragment pattern (16 consecutive pixels x 4 chunks) conflict-free for ANY patch alignment
 // (96 B and 160 B strides; checked exhaustively).
-// An optional prologue applies DF-GAN's conditional affine pair + LeakyReLU (df_gan.py:213-216)
-// to the patch while it is staged, so that tensor never makes a round trip through HBM.
+// (Round 1 carried an optional prologue here that applied DF-GAN's affine pair + LeakyReLU while the patch was staged.  No
+// caller ever used it: the weight gradient of the same layer needs the activated tensor as its operand, so the tensor has to
+// exist in HBM anyway and the fusion only moved a pass from the forward to the backward.  Removed in round 2.)
 #include "common.h"
 #include <stdlib.h>
 #include <type_traits>
@@ -28,7 +29,6 @@ struct TileCfg {
     int dh0[XMC_MAX_CLASSES], dw0[XMC_MAX_CLASSES];      // min tap offsets per class
     int PHu, PWu, dh0u, dw0u;    // union of the classes' patches (one staged patch serves all classes)
     int slab;                    // channels per slab (32 or 64)
-    const float* pro[4];         // optional prologue params g0,b0,g1,b1 : f32 [N][CS]; pro[0]==nullptr -> none
 };
 
 template <int BN, int WM, int WN>
@@ -111,14 +111,7 @@ __global__ __launch_bounds__(256) void tile_kernel(const XmcConvDesc d, const Ti
     int wcur = 0;
     for (int sl = 0; sl < nslab; ++sl) {
         __syncthreads();                          // previous slab's compute finished with patch + wbuf
-        // ---- stage the patch for this slab (optionally through the fused affine pair)
-        float P0[8], P1[8], P2[8], P3[8];
-        const bool has_pro = t.pro[0] != nullptr;
-        if (has_pro) {
-            const size_t pb = (size_t)img * d.CS + (size_t)sl * slab + pchunk * 8;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { P0[k] = t.pro[0][pb + k]; P1[k] = t.pro[1][pb + k]; P2[k] = t.pro[2][pb + k]; P3[k] = t.pro[3][pb + k]; }
-        }
+        // ---- stage the patch for this slab
         // all of this thread's patch loads are issued before the first one is consumed (latency overlap)
         constexpr int PIT = 12;                    // >= ceil(max patch pixels (10*34) / (256/8))
         u32x4 pv[PIT];
@@ -130,16 +123,6 @@ __global__ __launch_bounds__(256) void tile_kernel(const XmcConvDesc d, const Ti
             bool ok = pp < PH * PW && (unsigned)sy < (unsigned)d.SH && (unsigned)sx < (unsigned)d.SW;
             u32x4 z = {0, 0, 0, 0};
             pv[it] = ok ? src16[(((size_t)img * d.SH + sy) * d.SW + sx) * cs_units + sl * cps + pchunk] : z;
-            if (has_pro && ok) {
-                bf16x8 h = __builtin_bit_cast(bf16x8, pv[it]);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    float f = (float)h[k];
-                    f = lrelu_f(lrelu_f(f * P0[k] + P1[k]) * P2[k] + P3[k]);
-                    h[k] = (__bf16)f;
-                }
-                pv[it] = __builtin_bit_cast(u32x4, h);
-            }
         }
 #pragma unroll
         for (int it = 0; it < PIT; ++it) {
@@ -312,7 +295,6 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
             psrc[it] = in ? ((dh0 + py) * d.SW + (dw0 + px)) * cs_units + pchunk : 0;
             halo[it] = !in ? 0u : ((py < -dh0 ? 1u : 0u) | (py >= t.TH * SA - dh0 ? 2u : 0u) | (px < -dw0 ? 4u : 0u) | (px >= t.TW * SA - dw0 ? 8u : 0u));
         }
-        const bool has_pro = t.pro[0] != nullptr;
         u32x4 pv[PIT];
         unsigned okmask = 0;
         auto issue = [&](int tile) {
@@ -332,25 +314,6 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
             }
             okmask &= inpatch;
         };
-        auto transform = [&](int tile) {          // DF-GAN affine pair + LeakyReLU on the staged values (padding stays 0)
-            const int img = tile / tpi;
-            float P0[8], P1[8], P2[8], P3[8];
-            const size_t pb = (size_t)img * d.CS + pchunk * 8;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { P0[k] = t.pro[0][pb + k]; P1[k] = t.pro[1][pb + k]; P2[k] = t.pro[2][pb + k]; P3[k] = t.pro[3][pb + k]; }
-#pragma unroll
-            for (int it = 0; it < PIT; ++it) {
-                if (!((okmask >> it) & 1)) continue;
-                bf16x8 h = __builtin_bit_cast(bf16x8, pv[it]);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    float f = (float)h[k];
-                    f = lrelu_f(lrelu_f(f * P0[k] + P1[k]) * P2[k] + P3[k]);
-                    h[k] = (__bf16)f;
-                }
-                pv[it] = __builtin_bit_cast(u32x4, h);
-            }
-        };
         auto commit = [&]() {
             const bool all_ok = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_ballot_w64(okmask != inpatch) == 0);
 #pragma unroll
@@ -368,17 +331,13 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
         };
         if (tile0 < ntiles) {
             issue(tile0);
-            if (has_pro) transform(tile0);
             commit();
         }
         __syncthreads();                          // weights + first patch staged
         for (int tile = tile0; tile < ntiles; tile += tstep) {
             const int next = tile + tstep;
             __syncthreads();                      // B1
-            if (next < ntiles) {
-                issue(next);
-                if (has_pro) transform(next);
-            }
+            if (next < ntiles) issue(next);
             __syncthreads();                      // B2: the compute waves are done reading the patch
             if (next < ntiles) commit();
         }
@@ -933,7 +892,7 @@ int launch_ptile(const XmcConvDesc& d, const TileCfg& t, hipStream_t st) {
     if (gx > ntiles) gx = ntiles;
     dim3 grid((unsigned)gx, (unsigned)(d.CDw / BN), (unsigned)d.nclass);
     // all 4 output-parity classes from one staged patch when their 16 weight slices fit beside it
-    if (d.nclass == 4 && d.ntaps == 4 && !t.pro[0] && t.PHu * t.PWu <= 384) {
+    if (d.nclass == 4 && d.ntaps == 4 && t.PHu * t.PWu <= 384) {
         const size_t ldsm = (size_t)((t.PHu * t.PWu * pstride + 15) & ~15) + (size_t)16 * BN * pstride;
         static const bool no_merge = xmc_debug_off("no_class_merge");
         if (ldsm <= XMC_MAX_DYN_LDS && !no_merge) {
@@ -1047,7 +1006,6 @@ static int tile_plan(const XmcConvDesc* d, TileCfg* t) {
         }
         t->dh0u = hmin; t->dw0u = wmin; t->PHu = TH + (hmax - hmin); t->PWu = TW + (wmax - wmin);
     }
-    for (int k = 0; k < 4; ++k) t->pro[k] = nullptr;
     return 1;
 }
 
@@ -1062,15 +1020,13 @@ int xmc_conv_ptile_pool_try(const XmcConvDesc* d, void* stream) {
     return rc == XMC_ESHAPE ? 1 : rc;
 }
 
-// entry used by xmc_conv_igemm's dispatcher (conv_igemm.hip) and by the fused-prologue ABI call
-int xmc_conv_tile_try(const XmcConvDesc* d, const float* const* pro, void* stream) {
+// entry used by xmc_conv_igemm's dispatcher (conv_igemm.hip)
+int xmc_conv_tile_try(const XmcConvDesc* d, void* stream) {
     TileCfg t;
     if (!tile_plan(d, &t)) return 1;   // not eligible
-    if (pro) for (int k = 0; k < 4; ++k) t.pro[k] = pro[k];
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     int rc;
     if (d->CDw > 64 && d->CS > 64) {                  // wide: weights streamed through an LDS ring
-        if (pro) return 1;
         rc = launch_wtile(*d, t, st);
         return rc == XMC_ESHAPE ? 1 : rc;
     }

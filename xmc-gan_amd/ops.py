@@ -242,6 +242,10 @@ def repack_params(params):
     changed and whose ``_xmc_epoch`` it has bumped) into the buffers the entries already own, and mark them valid."""
     ids = {id(p): p for p in params}
     jobs, ents = [], []
+    for k in [k for k, e in _pack_cache.items() if e.ref() is None]:       # the parameter is gone: drop its packed copies
+        if _graphs_alive[0]:
+            _retired_packs.append(_pack_cache[k].out)
+        del _pack_cache[k]
     for (pid, _up, _tr, _dt), e in _pack_cache.items():
         w = ids.get(pid)
         if w is None or e.ref() is not w or e.wf is None or e.gepoch != _weights_epoch[0] or e.version != w._version:
