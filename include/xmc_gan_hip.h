@@ -281,6 +281,10 @@ int xmc_attn_pool_fwd(const void* key, const float* q, const void* x, float* sta
                       int ncon, int pk, int px, float scale, int dtype, void* stream);
 int xmc_attn_pool_bwd(const void* key, const float* q, const void* x, const float* stats, const float* ctx, const float* dctx,
                       float* dq, void* dkey, void* dx, int N, int HW, int ncon, int pk, int px, float scale, int dtype, void* stream);
+/* same, with another gradient of x (dx_in, dx layout; may alias dx) added on the way out */
+int xmc_attn_pool_bwd_acc(const void* key, const float* q, const void* x, const float* stats, const float* ctx, const float* dctx,
+                          float* dq, void* dkey, void* dx, const void* dx_in, int N, int HW, int ncon, int pk, int px, float scale,
+                          int dtype, void* stream);
 
 /*
  * Contrastive head (cosine_scores + sent_loss/img_loss, train_gan.py:85-139), fused:

@@ -275,11 +275,13 @@ __global__ void attn_pool_merge_kernel(const float* part, float* stats, float* c
     for (int k = 0; k < AP_PX; ++k) ctx[(size_t)i * AP_PX + k] = A[k] * inv;
 }
 
-// dq must be zero on entry (partial sums of the runs are added atomically); dkey, dx: every element written exactly once
+// dq must be zero on entry (partial sums of the runs are added atomically); dkey, dx: every element written exactly once.
+// dx_in (may alias dx): another gradient of x that is added on the way out -- the block's `affine` consumes x as well, and its
+// gradient would otherwise meet this one in a separate add pass
 template <int DT>
 __global__ __launch_bounds__(NT) void attn_pool_bwd_kernel(const void* key, const float* q, const void* x, const float* stats,
                                                            const float* ctx, const float* dctx, float* dq, void* dkey, void* dx,
-                                                           int HW, float scale, int ppc) {
+                                                           const void* dx_in, int HW, float scale, int ppc) {
     __shared__ float sm[AP_SLOTS][AP_CON][AP_PK + 1];
     const int n = blockIdx.y, chunk = blockIdx.x, c = threadIdx.x & (AP_CON - 1), slot = threadIdx.x / AP_CON;
     const size_t nc = (size_t)n * AP_CON + c;
@@ -303,6 +305,12 @@ __global__ __launch_bounds__(NT) void attn_pool_bwd_kernel(const void* key, cons
         const float a = __expf(sc - M) * invL;
 #pragma unroll
         for (int k = 0; k < AP_PX; ++k) { da += dc[k] * xv[k]; g[k] = a * dc[k]; }
+        if (dx_in) {
+            float o[8];
+            PVec<DT, AP_PX>::load(dx_in, ex, o);
+#pragma unroll
+            for (int k = 0; k < AP_PX; ++k) g[k] += o[k];
+        }
         PVec<DT, AP_PX>::store(dx, ex, g);
         const float ds = a * (da - dot);
 #pragma unroll
@@ -400,17 +408,22 @@ extern "C" int xmc_attn_pool_fwd(const void* key, const float* q, const void* x,
     XMC_LAUNCH_CHECK();
     return 0;
 }
-extern "C" int xmc_attn_pool_bwd(const void* key, const float* q, const void* x, const float* stats, const float* ctx,
-                                 const float* dctx, float* dq, void* dkey, void* dx, int N, int HW, int ncon, int pk, int px,
-                                 float scale, int dtype, void* s) {
+extern "C" int xmc_attn_pool_bwd_acc(const void* key, const float* q, const void* x, const float* stats, const float* ctx,
+                                     const float* dctx, float* dq, void* dkey, void* dx, const void* dx_in, int N, int HW, int ncon,
+                                     int pk, int px, float scale, int dtype, void* s) {
     if (!key || !q || !x || !stats || !ctx || !dctx || !dq || !dkey || !dx || N < 1 || HW < 1) return XMC_EINVAL;
     if (pk != AP_PK || px != AP_PX || ncon != AP_CON) return XMC_ESHAPE;
     if (hipMemsetAsync(dq, 0, sizeof(float) * (size_t)N * AP_CON * AP_PK, ST(s)) != hipSuccess) return XMC_EINVAL;
     const int ppc = ap_pixels_per_chunk(N, HW), chunks = (HW + ppc - 1) / ppc;
     dim3 grid(chunks, N);
-    if (dtype == XMC_BF16) hipLaunchKernelGGL((attn_pool_bwd_kernel<XMC_BF16>), grid, dim3(NT), 0, ST(s), key, q, x, stats, ctx, dctx, dq, dkey, dx, HW, scale, ppc);
-    else if (dtype == XMC_F32) hipLaunchKernelGGL((attn_pool_bwd_kernel<XMC_F32>), grid, dim3(NT), 0, ST(s), key, q, x, stats, ctx, dctx, dq, dkey, dx, HW, scale, ppc);
+    if (dtype == XMC_BF16) hipLaunchKernelGGL((attn_pool_bwd_kernel<XMC_BF16>), grid, dim3(NT), 0, ST(s), key, q, x, stats, ctx, dctx, dq, dkey, dx, dx_in, HW, scale, ppc);
+    else if (dtype == XMC_F32) hipLaunchKernelGGL((attn_pool_bwd_kernel<XMC_F32>), grid, dim3(NT), 0, ST(s), key, q, x, stats, ctx, dctx, dq, dkey, dx, dx_in, HW, scale, ppc);
     else return XMC_EINVAL;
     XMC_LAUNCH_CHECK();
     return 0;
+}
+extern "C" int xmc_attn_pool_bwd(const void* key, const float* q, const void* x, const float* stats, const float* ctx,
+                                 const float* dctx, float* dq, void* dkey, void* dx, int N, int HW, int ncon, int pk, int px,
+                                 float scale, int dtype, void* s) {
+    return xmc_attn_pool_bwd_acc(key, q, x, stats, ctx, dctx, dq, dkey, dx, nullptr, N, HW, ncon, pk, px, scale, dtype, s);
 }

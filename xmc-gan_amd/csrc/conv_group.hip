@@ -78,8 +78,14 @@ __global__ __launch_bounds__(512) void gconv_kernel(const XmcConvDesc d, int nun
             // D[row = output channel kb*4 + i][col = pixel]
             const int p = (chunk * TI + t) * 16 + col;
             if (p < total) {
+                const size_t e = (size_t)p * d.CD + cb * 16 + kb * 4;
+                if (d.res) {                                   // residual in the destination layout (another gradient of the same tensor)
+                    const bf16x4 r = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(d.res) + e);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[i] += (float)r[i];
+                }
                 bf16x4 o = {(__bf16)acc[0], (__bf16)acc[1], (__bf16)acc[2], (__bf16)acc[3]};
-                *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(d.dst) + (size_t)p * d.CD + cb * 16 + kb * 4) = o;
+                *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(d.dst) + e) = o;
             }
         }
     }
@@ -156,9 +162,14 @@ __global__ __launch_bounds__(NW * 64, 2) void gconv_patch_kernel(const XmcConvDe
                 const bf16x8 b = *reinterpret_cast<const bf16x8*>(smem + r * GP_W * pstr + loff[j]);
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[j], b, acc, 0, 0, 0);
             }
+            const size_t e = (((size_t)n * d.DH + y0 + r) * d.DW + x0 + col) * d.CD + cb * 16 + kb * 4;
+            if (d.res) {
+                const bf16x4 rr = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(d.res) + e);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] += (float)rr[i];
+            }
             bf16x4 o = {(__bf16)acc[0], (__bf16)acc[1], (__bf16)acc[2], (__bf16)acc[3]};
-            const size_t p = ((size_t)n * d.DH + y0 + r) * d.DW + x0 + col;
-            *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(d.dst) + p * d.CD + cb * 16 + kb * 4) = o;
+            *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(d.dst) + e) = o;
         }
     }
 }
@@ -172,7 +183,8 @@ int xmc_conv_group_try(const XmcConvDesc* d, void* stream) {
     if (off || G <= 1) return 1;
     if (d->dtype != XMC_BF16 || d->out_dtype != XMC_BF16) return 1;
     if (d->nclass != 1 || d->SA != 1 || d->DA != 1 || d->src_shift != 0 || d->dph[0] != 0 || d->dpw[0] != 0) return 1;
-    if (d->bias || d->res || d->alpha_dev || d->mask || d->dst2 || d->dst_pool || d->act != XMC_ACT_NONE) return 1;
+    if (d->bias || d->alpha_dev || d->mask || d->dst2 || d->dst_pool || d->act != XMC_ACT_NONE) return 1;
+    if (d->res && (d->res_mode != 0 || (d->res_scale != 0.f && d->res_scale != 1.f))) return 1;
     if (d->MH != d->DH || d->MW != d->DW || d->MH != d->SH || d->MW != d->SW) return 1;
     if (d->CS % G || d->CD % G || d->CD % 16 || d->CS % 8 || d->CD > 128) return 1;
     const int cig = d->CS / G, cog = d->CD / G;

@@ -1320,6 +1320,29 @@ class Nhwc8ToNchwFn(torch.autograd.Function):
         return NchwToNhwc8Fn.apply(dy, ctx.dtype), None
 
 
+def _affine_fwd_raw(x, ps, slope):
+    """ps: (g0, b0) or (g0, b0, g1, b1), contiguous f32 [N, C]"""
+    N, H, W, Cc = x.shape
+    for t in ps:
+        assert t.shape == (N, Cc), (t.shape, (N, Cc))
+    y = torch.empty_like(x)
+    ptrs = [_p(t) for t in ps] + ([] if len(ps) == 4 else [None, None])
+    L.call("xmc_affine2_act_fwd", _p(x), *ptrs, _p(y), N, H * W, Cc, float(slope), _code(x.dtype), _st())
+    return y
+
+
+def _affine_bwd_raw(x, dy, ps, slope):
+    """-> dx, red [len(ps), N, C] (the gradients of ps)"""
+    N, H, W, Cc = x.shape
+    dx = torch.empty_like(x)
+    nred = len(ps)
+    red = torch.zeros((nred, N, Cc), dtype=torch.float32, device=x.device)
+    ptrs = [_p(t) for t in ps] + ([] if nred == 4 else [None, None])
+    rptrs = [_p(red[i]) for i in range(nred)] + ([] if nred == 4 else [None, None])
+    L.call("xmc_affine2_act_bwd", _p(x), _p(dy), *ptrs, _p(dx), *rptrs, N, H * W, Cc, float(slope), _code(x.dtype), _st())
+    return dx, red
+
+
 class Affine2LreluFn(torch.autograd.Function):
     """lrelu(lrelu(x*g0+b0)*g1+b1) with per-sample, per-channel f32 g/b [N,C] -- two DF-GAN `affine` modules each
     followed by LeakyReLU(0.2) (df_gan.py:213-216 / 219-222, affine.forward 250-263).  With g1 = b1 = None it is the
@@ -1328,14 +1351,9 @@ class Affine2LreluFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, g0, b0, g1, b1, slope=0.2):
         x = x.contiguous()
-        N, H, W, Cc = x.shape
         two = g1 is not None
         ps = [t.contiguous().float() for t in ((g0, b0, g1, b1) if two else (g0, b0))]
-        for t in ps:
-            assert t.shape == (N, Cc), (t.shape, (N, Cc))
-        y = torch.empty_like(x)
-        ptrs = [_p(t) for t in ps] + ([] if two else [None, None])
-        L.call("xmc_affine2_act_fwd", _p(x), *ptrs, _p(y), N, H * W, Cc, float(slope), _code(x.dtype), _st())
+        y = _affine_fwd_raw(x, ps, slope)
         ctx.two, ctx.slope = two, float(slope)
         ctx.save_for_backward(x, *ps)
         return y
@@ -1344,17 +1362,30 @@ class Affine2LreluFn(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, dy):
         x, *ps = ctx.saved_tensors
-        dy = dy.contiguous()
-        N, H, W, Cc = x.shape
-        dx = torch.empty_like(x)
-        nred = 4 if ctx.two else 2
-        red = torch.zeros((nred, N, Cc), dtype=torch.float32, device=x.device)
-        ptrs = [_p(t) for t in ps] + ([] if ctx.two else [None, None])
-        rptrs = [_p(red[i]) for i in range(nred)] + ([] if ctx.two else [None, None])
-        L.call("xmc_affine2_act_bwd", _p(x), _p(dy), *ptrs, _p(dx), *rptrs, N, H * W, Cc, ctx.slope, _code(x.dtype), _st())
+        dx, red = _affine_bwd_raw(x, dy.contiguous(), ps, ctx.slope)
         if ctx.two:
             return dx, red[0], red[1], red[2], red[3], None
         return dx, red[0], red[1], None, None, None
+
+
+def _gn_fwd_raw(x, wf, bf, groups, slope, eps):
+    N, H, W, Cc = x.shape
+    y = torch.empty_like(x)
+    stats = torch.empty((N, groups, 2), dtype=torch.float32, device=x.device)
+    ws = torch.empty((N, Cc, 2), dtype=torch.float32, device=x.device)
+    L.call("xmc_groupnorm_fwd", _p(x), _p(wf), _p(bf), _p(y), _p(stats), _p(ws), N, H * W, Cc, groups, float(eps),
+           float(slope), _code(x.dtype), _st())
+    return y, stats
+
+
+def _gn_bwd_raw(x, dy, wf, bf, stats, groups, slope):
+    N, H, W, Cc = x.shape
+    dx = torch.empty_like(x)
+    dw, db = torch.empty_like(wf), torch.empty_like(bf)
+    ws = torch.empty(N * Cc * 2 + N * groups * 2, dtype=torch.float32, device=x.device)
+    L.call("xmc_groupnorm_bwd", _p(x), _p(dy), _p(wf), _p(bf), _p(stats), _p(dx), _p(dw), _p(db), _p(ws), N, H * W, Cc,
+           groups, float(slope), _code(x.dtype), _st())
+    return dx, dw, db
 
 
 class GroupNormFn(torch.autograd.Function):
@@ -1363,13 +1394,8 @@ class GroupNormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, groups, slope, eps):
         x = x.contiguous()
-        N, H, W, Cc = x.shape
         wf, bf = w.detach().float().contiguous(), b.detach().float().contiguous()
-        y = torch.empty_like(x)
-        stats = torch.empty((N, groups, 2), dtype=torch.float32, device=x.device)
-        ws = torch.empty((N, Cc, 2), dtype=torch.float32, device=x.device)
-        L.call("xmc_groupnorm_fwd", _p(x), _p(wf), _p(bf), _p(y), _p(stats), _p(ws), N, H * W, Cc, groups, float(eps),
-               float(slope), _code(x.dtype), _st())
+        y, stats = _gn_fwd_raw(x, wf, bf, groups, slope, eps)
         ctx.groups, ctx.slope = groups, slope
         ctx.save_for_backward(x, wf, bf, stats)
         return y
@@ -1378,13 +1404,7 @@ class GroupNormFn(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, dy):
         x, wf, bf, stats = ctx.saved_tensors
-        dy = dy.contiguous()
-        N, H, W, Cc = x.shape
-        dx = torch.empty_like(x)
-        dw, db = torch.empty_like(wf), torch.empty_like(bf)
-        ws = torch.empty(N * Cc * 2 + N * ctx.groups * 2, dtype=torch.float32, device=x.device)
-        L.call("xmc_groupnorm_bwd", _p(x), _p(dy), _p(wf), _p(bf), _p(stats), _p(dx), _p(dw), _p(db), _p(ws), N, H * W, Cc,
-               ctx.groups, float(ctx.slope), _code(x.dtype), _st())
+        dx, dw, db = _gn_bwd_raw(x, dy.contiguous(), wf, bf, stats, ctx.groups, ctx.slope)
         return dx, dw, db, None, None, None
 
 
@@ -1426,6 +1446,30 @@ def batchnorm_train(x, w, b, eps=1e-5):
     return BatchNormTrainFn.apply(x, w, b, eps)
 
 
+def _attn_fwd_raw(key, q, x, ncon, scale):
+    N, H, W, CK = key.shape
+    pk, px = CK // ncon, x.shape[3] // ncon
+    stats = torch.empty((N, ncon, 2), dtype=torch.float32, device=x.device)     # (max, sum of exp): the weights are recomputed
+    out = torch.empty((N, ncon, px), dtype=torch.float32, device=x.device)
+    ws = torch.empty(int(L.load().xmc_attn_pool_ws_floats(N, H * W)), dtype=torch.float32, device=x.device)
+    L.call("xmc_attn_pool_fwd", _p(key), _p(q), _p(x), _p(stats), _p(out), _p(ws), N, H * W, ncon, pk, px, float(scale),
+           _code(x.dtype), _st())
+    return out, stats
+
+
+def _attn_bwd_raw(key, q, x, stats, out, dctx, ncon, scale, dx_acc=None):
+    """``dx_acc``: another gradient of x; the kernel adds it on the way out and the sum is written IN PLACE into it."""
+    N, H, W, CK = key.shape
+    pk, px = CK // ncon, x.shape[3] // ncon
+    dq = torch.empty_like(q)
+    dkey = torch.empty_like(key)
+    dx = torch.empty_like(x) if dx_acc is None else dx_acc
+    assert dx.shape == x.shape and dx.dtype == x.dtype and dx.is_contiguous()
+    L.call("xmc_attn_pool_bwd_acc", _p(key), _p(q), _p(x), _p(stats), _p(out), _p(dctx), _p(dq), _p(dkey), _p(dx), _p(dx_acc),
+           N, H * W, ncon, pk, px, float(scale), _code(x.dtype), _st())
+    return dkey, dq, dx
+
+
 class AttnPoolFn(torch.autograd.Function):
     """Region attention of the concept samplers (df_concept_gan.py:293-299, 570-578): per (sample, concept) softmax over
     H*W of scale*<q, key>, then the attention-weighted sum of x.  key [N,H,W,ncon*pk], x [N,H,W,ncon*px], q f32 [N,ncon,pk]
@@ -1435,13 +1479,7 @@ class AttnPoolFn(torch.autograd.Function):
     def forward(ctx, key, q, x, ncon, scale):
         key, x = key.contiguous(), x.contiguous()
         q = q.contiguous().float()
-        N, H, W, CK = key.shape
-        pk, px = CK // ncon, x.shape[3] // ncon
-        stats = torch.empty((N, ncon, 2), dtype=torch.float32, device=x.device)     # (max, sum of exp): the weights are recomputed
-        out = torch.empty((N, ncon, px), dtype=torch.float32, device=x.device)
-        ws = torch.empty(int(L.load().xmc_attn_pool_ws_floats(N, H * W)), dtype=torch.float32, device=x.device)
-        L.call("xmc_attn_pool_fwd", _p(key), _p(q), _p(x), _p(stats), _p(out), _p(ws), N, H * W, ncon, pk, px, float(scale),
-               _code(x.dtype), _st())
+        out, stats = _attn_fwd_raw(key, q, x, ncon, scale)
         ctx.ncon, ctx.scale = ncon, scale
         ctx.save_for_backward(key, q, x, stats, out)
         return out
@@ -1450,12 +1488,7 @@ class AttnPoolFn(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, dctx):
         key, q, x, stats, out = ctx.saved_tensors
-        N, H, W, CK = key.shape
-        pk, px = CK // ctx.ncon, x.shape[3] // ctx.ncon
-        dq = torch.empty_like(q)
-        dkey, dx = torch.empty_like(key), torch.empty_like(x)
-        L.call("xmc_attn_pool_bwd", _p(key), _p(q), _p(x), _p(stats), _p(out), _p(dctx.contiguous().float()), _p(dq), _p(dkey),
-               _p(dx), N, H * W, ctx.ncon, pk, px, float(ctx.scale), _code(x.dtype), _st())
+        dkey, dq, dx = _attn_bwd_raw(key, q, x, stats, out, dctx.contiguous().float(), ctx.ncon, ctx.scale)
         return dkey, dq, dx, None, None
 
 
@@ -1577,6 +1610,33 @@ class ConceptGQueryFn(torch.autograd.Function):
         return dq0, dw.view(ctx.wshape), dgw, dgb, None
 
 
+def _head_fwd_raw(pooled, sent, ps):
+    B, E = sent.shape
+    tab = (C.c_void_p * 11)(*[p_.data_ptr() for p_ in ps])          # tab[10] stays NULL without sent_linear
+    gamma = torch.empty(B, 128, dtype=torch.float32, device=sent.device)
+    beta = torch.empty_like(gamma)
+    hid = torch.empty(B, 256, dtype=torch.float32, device=sent.device)
+    L.call("xmc_concept_head_fwd", _p(pooled), _p(sent), tab, _p(gamma), _p(beta), _p(hid), B, E, _st())
+    return gamma, beta, hid
+
+
+def _head_bwd_raw(pooled, sent, hid, ps, dgamma, dbeta):
+    B, E = sent.shape
+    dpooled, dsent = torch.empty_like(pooled), torch.empty_like(sent)
+    sizes = [(p_.numel() + 3) // 4 * 4 for p_ in ps]                      # 16-byte aligned slices of ONE zero-filled buffer
+    flat = torch.zeros(sum(sizes), dtype=torch.float32, device=sent.device)
+    grads, off = [], 0
+    for p_, n_ in zip(ps, sizes):
+        grads.append(flat[off:off + p_.numel()].view(p_.shape))
+        off += n_
+    tab = (C.c_void_p * 11)(*[p_.data_ptr() for p_ in ps])
+    gtab = (C.c_void_p * 11)(*[g_.data_ptr() for g_ in grads])
+    scratch = torch.empty(B, 260, dtype=torch.float32, device=sent.device)
+    L.call("xmc_concept_head_bwd", _p(pooled), _p(sent), _p(hid), tab, _p(dgamma), _p(dbeta), _p(dpooled), _p(dsent), gtab,
+           _p(scratch), B, E, _st())
+    return dpooled, dsent, grads
+
+
 class ConceptHeadFn(torch.autograd.Function):
     """Everything between the region attention and the channel modulation of one sampler stage of the attention-modulation
     blocks (df_concept_gan.py:238-253, 291-326; 471-478 for the self-attention block): value projection, ConceptReasoner,
@@ -1588,13 +1648,8 @@ class ConceptHeadFn(torch.autograd.Function):
         assert len(params) in (10, 11)
         pooled, sent = pooled.contiguous().float(), sent.contiguous().float()
         _need_cuda(pooled, sent)
-        B, E = sent.shape
         ps = [p_.detach().contiguous().float() for p_ in params]
-        tab = (C.c_void_p * 11)(*[p_.data_ptr() for p_ in ps])          # tab[10] stays NULL without sent_linear
-        gamma = torch.empty(B, 128, dtype=torch.float32, device=sent.device)
-        beta = torch.empty_like(gamma)
-        hid = torch.empty(B, 256, dtype=torch.float32, device=sent.device)
-        L.call("xmc_concept_head_fwd", _p(pooled), _p(sent), tab, _p(gamma), _p(beta), _p(hid), B, E, _st())
+        gamma, beta, hid = _head_fwd_raw(pooled, sent, ps)
         ctx.shapes = [tuple(p_.shape) for p_ in params]
         ctx.save_for_backward(pooled, sent, hid, *ps)
         return gamma, beta
@@ -1603,25 +1658,67 @@ class ConceptHeadFn(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, dgamma, dbeta):
         pooled, sent, hid, *ps = ctx.saved_tensors
-        B, E = sent.shape
-        dgamma, dbeta = dgamma.contiguous().float(), dbeta.contiguous().float()
-        dpooled, dsent = torch.empty_like(pooled), torch.empty_like(sent)
-        sizes = [(p_.numel() + 3) // 4 * 4 for p_ in ps]                      # 16-byte aligned slices of ONE zero-filled buffer
-        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=sent.device)
-        grads, off = [], 0
-        for p_, n_ in zip(ps, sizes):
-            grads.append(flat[off:off + p_.numel()].view(p_.shape))
-            off += n_
-        tab = (C.c_void_p * 11)(*[p_.data_ptr() for p_ in ps])
-        gtab = (C.c_void_p * 11)(*[g_.data_ptr() for g_ in grads])
-        scratch = torch.empty(B, 260, dtype=torch.float32, device=sent.device)
-        L.call("xmc_concept_head_bwd", _p(pooled), _p(sent), _p(hid), tab, _p(dgamma), _p(dbeta), _p(dpooled), _p(dsent), gtab,
-               _p(scratch), B, E, _st())
+        dpooled, dsent, grads = _head_bwd_raw(pooled, sent, hid, ps, dgamma.contiguous().float(), dbeta.contiguous().float())
         return (dpooled, dsent) + tuple(g_.view(sh) for g_, sh in zip(grads, ctx.shapes))
 
 
 def concept_query(sent, wq, gnw=None, gnb=None, eps=1e-5):
     return ConceptQueryFn.apply(sent, wq, gnw, gnb, eps)
+
+
+class ConceptStageFn(torch.autograd.Function):
+    """One sampler stage of an attention-modulation block as ONE autograd node (df_concept_gan.py:238-253 / 443-478 with the
+    sampler 287-302 / 570-581):  key = key_gconv(x) [-> GroupNorm];  pooled = region attention(key, q, x);
+    (gamma, beta) = concept head(pooled, sent);  y = lrelu(gamma * x + beta).
+    x has three consumers (key projection, attention values, modulation).  As separate nodes their three gradients met in two
+    framework add passes per stage; here the modulation's gradient is the buffer the attention backward accumulates into, and
+    the key projection's data gradient takes that buffer as its residual: no add pass, no framework kernel in the stage."""
+
+    @staticmethod
+    def forward(ctx, x, q, sent, wk, gnw, gnb, geom, ncon, scale, eps, *params):
+        x = x.contiguous()
+        q, sent = q.contiguous().float(), sent.contiguous().float()
+        _need_cuda(x, q, sent)
+        key = _conv_fwd_raw(x, wk, None, geom, L.ACT_NONE, x.dtype)
+        gn = gnw is not None
+        if gn:
+            gwf, gbf = gnw.detach().float().contiguous(), gnb.detach().float().contiguous()
+            keyn, gstats = _gn_fwd_raw(key, gwf, gbf, ncon, -1.0, eps)
+        else:
+            gwf = gbf = gstats = None
+            keyn = key
+        pooled, astats = _attn_fwd_raw(keyn, q, x, ncon, scale)
+        ps = [p_.detach().contiguous().float() for p_ in params]
+        gamma, beta, hid = _head_fwd_raw(pooled, sent, ps)
+        y = _affine_fwd_raw(x, [gamma, beta], 0.2)
+        ctx.geom, ctx.ncon, ctx.scale, ctx.gn = geom, ncon, scale, gn
+        ctx.shapes = [tuple(p_.shape) for p_ in params]
+        ctx.save_for_backward(x, q, sent, wk, key if gn else None, keyn, gwf, gbf, gstats, astats, pooled, hid, gamma, beta, *ps)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        x, q, sent, wk, key, keyn, gwf, gbf, gstats, astats, pooled, hid, gamma, beta, *ps = ctx.saved_tensors
+        geom = ctx.geom
+        dx, red = _affine_bwd_raw(x, dy.contiguous(), [gamma, beta], 0.2)
+        dpooled, dsent, grads = _head_bwd_raw(pooled, sent, hid, ps, red[0], red[1])
+        dkeyn, dq, dx = _attn_bwd_raw(keyn, q, x, astats, pooled, dpooled, ctx.ncon, ctx.scale, dx_acc=dx)
+        dgw = dgb = None
+        if ctx.gn:
+            dkey, dgw, dgb = _gn_bwd_raw(key, dkeyn, gwf, gbf, gstats, ctx.ncon, -1.0)
+        else:
+            dkey = dkeyn
+        dxt = _conv_dgrad_raw(dkey, wk, geom, (x.shape[1], x.shape[2]), x.dtype, res=dx)
+        dwk = None
+        if ctx.needs_input_grad[3] and not _skip_wgrad():
+            dwk = _conv_wgrad_raw(x, dkey, geom).view(wk.shape)
+        return (dxt, dq.view(q.shape), dsent, dwk, dgw, dgb, None, None, None, None) + \
+            tuple(g_.view(sh) for g_, sh in zip(grads, ctx.shapes))
+
+
+def concept_stage(x, q, sent, wk, gnw, gnb, geom, ncon, scale, head_params, eps=1e-5):
+    return ConceptStageFn.apply(x, q, sent, wk, gnw, gnb, geom, ncon, scale, eps, *head_params)
 
 
 def concept_gquery(q0, wq, gnw=None, gnb=None, eps=1e-5):

@@ -86,6 +86,13 @@ class _SamplerBase(nn.Module):
             key = ops.groupnorm(key, self.gn2.weight, self.gn2.bias, self.cardinality)
         return ops.attn_pool(key, q, x, self.cardinality, scale)
 
+    def stage(self, x, q, scale, sent, head_params):
+        """key projection [+ GroupNorm], region attention, concept head and the channel modulation lrelu(gamma * x + beta) as one
+        autograd node (ops.ConceptStageFn): x [B,H,W,128], q [B,16,4] f32 (already normalised) -> [B,H,W,128]."""
+        return ops.concept_stage(x, q, sent, self.key_gconv.weight, self.gn2.weight if self.normalize else None,
+                                 self.gn2.bias if self.normalize else None, self.key_gconv.geom, self.cardinality, scale,
+                                 head_params, eps=self.gn2.eps if self.normalize else 1e-5)
+
     def _attend(self, x, q, scale):
         """x [B,H,W,128], q [B,16,4] f32 -> value-projected context [B,16,4]."""
         B = x.size(0)
@@ -170,11 +177,9 @@ class InConceptBlock(_ConceptBlockBase):
             #   value projection, ConceptReasoner, gamma / beta grouped MLPs (238-253, 291-326)
             q = ops.concept_query(sent, samp.query_gconv.weight, samp.gn1.weight if samp.normalize else None,
                                   samp.gn1.bias if samp.normalize else None)
-            pooled = samp.pool(out, q, 1.0)                                            # [B,16,8]
-            gamma, beta = ops.concept_head(pooled, sent, (
+            out = samp.stage(out, q, 1.0, sent, (
                 samp.value_gconv.weight, reas.proj_edge.weight,
                 gm[0].weight, gm[0].bias, gm[2].weight, gm[2].bias, bm[0].weight, bm[0].bias, bm[2].weight, bm[2].bias))
-            out = ops.affine_lrelu(out, gamma, beta)
         return out
 
 
@@ -213,12 +218,10 @@ class OutConceptBlock(_ConceptBlockBase):
             q0 = ops.global_avgpool(out).view(B, -1)
             q = ops.concept_gquery(q0, samp.query_gconv.weight, samp.gn1.weight if samp.normalize else None,
                                    samp.gn1.bias if samp.normalize else None)
-            pooled = samp.pool(out, q, samp._scale)                                    # [B,16,8]
-            gamma, beta = ops.concept_head(pooled, sent, (
+            out = samp.stage(out, q, samp._scale, sent, (
                 samp.value_gconv.weight, reas.proj_edge.weight,
                 gm[0].weight, gm[0].bias, gm[2].weight, gm[2].bias, bm[0].weight, bm[0].bias, bm[2].weight, bm[2].bias,
                 sl.weight))
-            out = ops.affine_lrelu(out, gamma, beta)
         return out
 
 
