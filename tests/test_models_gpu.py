@@ -127,7 +127,10 @@ def test_train_iteration_parity(yml, over, batch, steps, mode):
         qf = mean_abs_err(p_outs[0]["fake"], q_outs[0]["fake"])
         assert qf <= QTOL["fwd"], qf
         qd = compare_grads(tapD.records[0], q_outs[0]["grads_D"], QTOL["grad"], "quant D ", 2e-2, QTOL["agg"])
-        qg = compare_grads(tapG.records[0], q_outs[0]["grads_G"], QTOL["grad"], "quant G ", 2e-2, QTOL["agg"]) if "grads_G" in q_outs[0] else 0.0
+        # with MA-GP the generator step runs against a discriminator that has just taken the penalty's Adam step, whose
+        # second-order rounding points the oracle only approximates (below): same x2 on the aggregate as for the penalty itself
+        qg = compare_grads(tapG.records[0], q_outs[0]["grads_G"], QTOL["grad"], "quant G ", 2e-2,
+                           (2 if h.magp else 1) * QTOL["agg"]) if "grads_G" in q_outs[0] else 0.0
         # second-order term: the rounding points of the double backward are only approximately those of the engine
         qgp = compare_grads(tapD.records[1], q_outs[0]["grads_GP"], QTOL["grad"], "quant GP ", 2e-2, 2 * QTOL["agg"]) if h.magp else 0.0
         print(f"\n[bf16 vs quantisation-aware oracle {yml} {over}] loss={ql:.2e} image={qf:.2e} D={qd:.2e} GP={qgp:.2e} G={qg:.2e}")

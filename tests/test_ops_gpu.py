@@ -457,6 +457,51 @@ def test_fused_discriminator_block_equals_composed_block(cin, cout, H, mode):
         torch.testing.assert_close(a, b, rtol=2e-2 if mode == "bf16" else 1e-4, atol=(2e-2 if mode == "bf16" else 1e-4) * sc, msg=lambda m: f"{n}: {m}")
 
 
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("cin,cout,H", [(32, 64, 32), (64, 64, 16), (8, 16, 64)])
+def test_fused_discriminator_block_double_backward_equals_composed_block(cin, cout, H, mode):
+    """The MA-GP pattern (train_gan.py:231-252) on one block: g = d<y, r>/dx with create_graph, then the gradient of a
+    non-linear function of g with respect to the block's parameters AND r.  Fused path: ops.ResDFn -> ops.ResDBwdFn (whose
+    backward is the linearised forward of the block); reference: the block composed from the fine-grained Functions."""
+    from xmc_gan.model.df_gan import resD
+    ops.set_precision(mode)
+    dt = ops.act_dtype()
+    torch.manual_seed(cin + H + 1)
+    blk = resD(cin, cout, downsample=True).to(DEV)
+    with torch.no_grad():
+        blk.gamma.fill_(0.41)
+    x0 = torch.randn(3, H, H, ops.chan_pad(cin, dt), device=DEV).to(dt)
+    r0 = torch.randn(3, H // 2, H // 2, ops.pad_to(cout, 8), device=DEV).to(dt)
+    t = torch.randn(3, H, H, ops.chan_pad(cin, dt), device=DEV)
+    got = {}
+    for name in ("fused", "composed"):
+        blk.zero_grad()
+        x = x0.clone().requires_grad_()
+        r = r0.clone().requires_grad_()
+        with (ops.composable() if name == "composed" else _null()):
+            y = blk(x)
+        with ops.no_wgrad():
+            g, = torch.autograd.grad(y, x, grad_outputs=r, create_graph=True)
+        loss = (g.float() * t).sum() + 0.5 * (g.float() ** 2).sum()
+        loss.backward()
+        got[name] = [g.detach().float(), r.grad.float()] + [p.grad.clone() if p.grad is not None else None for p in blk.parameters()]
+    names = ["g", "d/dr"] + [n for n, _ in blk.named_parameters()]
+    for n, a, b in zip(names, got["fused"], got["composed"]):
+        assert (a is None) == (b is None), n
+        if a is None:
+            continue
+        sc = b.abs().max().item() + 1e-12
+        torch.testing.assert_close(a, b, rtol=3e-2 if mode == "bf16" else 2e-4, atol=(3e-2 if mode == "bf16" else 2e-4) * sc, msg=lambda m: f"{n}: {m}")
+
+
+class _null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
 @pytest.mark.parametrize("R,C", [(32, 27), (1, 1024), (64, 6912), (512, 8192), (256, 4096), (37, 53), (128, 128)])
 @pytest.mark.parametrize("training", [True, False])
 def test_spectral_weight_matches_legacy_hook_arithmetic(R, C, training):

@@ -323,7 +323,7 @@ def _upconv_dgrad_raw(dy, w, geom, in_dtype):
 
 
 def _conv_fwd_raw(x, w, bias, geom, act, out_dtype, res=None, alpha=None, up=False, res_mode=0, want2=False, want_pool=False,
-                  round_act=False):
+                  round_act=False, mask=None):
     """y = act(conv(x, w) + bias) [*alpha] [+ res]; x [N,H,W,Cs]. ``up``: x is read through a fused nearest x2.
     ``res_mode`` 2: res is [N,OH/2,OW/2,C] and read through a nearest x2.  ``want2``: also return act(conv + bias) itself (the
     branch value before alpha / res);  ``want_pool``: also return avg_pool2d(y, 2).  Extras are appended: (y[, y2][, ypool])."""
@@ -354,6 +354,9 @@ def _conv_fwd_raw(x, w, bias, geom, act, out_dtype, res=None, alpha=None, up=Fal
     if res is not None:
         want = (N, OH // 2, OW // 2, cd_p) if res_mode == 2 else tuple(y.shape)
         assert tuple(res.shape) == want and res.dtype == out_dtype and res.is_contiguous(), (res.shape, want)
+    if mask is not None:      # y *= LeakyReLU'(mask) after alpha, before the residual (the linearised form of a LeakyReLU layer)
+        assert mask.shape == y.shape and mask.dtype == out_dtype and mask.is_contiguous()
+        d.mask = mask.data_ptr()
     outs = [y]
     if want2:
         y2 = torch.empty_like(y)
@@ -1108,14 +1111,14 @@ class ResDFn(torch.autograd.Function):
       * gamma*dout, the LeakyReLU mask of the residual output and d(gamma) = <dout, res> in one kernel (7 tensor passes -> 3),
       * the LeakyReLU mask of conv_r[0]'s output in the epilogue of conv_r[2]'s data gradient,
       * the shortcut's gradient (adjoint of the average pool: x0.25, nearest x2) as the row-indexed residual of conv_r[0]'s
-        data gradient, so neither the upsampled tensor nor the sum of the two branches is written separately.
-    Not differentiable a second time: MA-GP runs the composed block (ops.composable())."""
+        data gradient, so neither the upsampled tensor nor the sum of the two branches is written separately."""
 
     @staticmethod
     def forward(ctx, x, w0, w2, ws, bs, gamma, g0, g2, gs, xp_hint=None, want_pool=False):
         """``xp_hint``: avg_pool2d(x, 2) if the producer of x already wrote it (the previous block's third output);
         ``want_pool``: return (out, avg_pool2d(out, 2)) -- the pooled tensor is a by-product for the NEXT block's shortcut and
-        carries no gradient of its own (that block returns the full gradient of its input, pool path included)."""
+        carries no gradient of its own (that block returns the full gradient of its input, pool path included).
+        The backward is ResDBwdFn, itself a differentiable node (MA-GP)."""
         x = x.contiguous()
         dt = x.dtype
         N, H, W, _ = x.shape
@@ -1159,41 +1162,108 @@ class ResDFn(torch.autograd.Function):
         return out
 
     @staticmethod
-    @torch.autograd.function.once_differentiable
     def backward(ctx, dout, _doutp=None):
         x, xp, h1, res, w0, w2, ws, gamma = ctx.saved_tensors
-        g0, g2, gs = ctx.geoms
+        need = tuple(bool(v) for v in ctx.needs_input_grad[:6])
+        outs = ResDBwdFn.apply(dout, x, xp, h1, res, w0, w2, ws, gamma, ctx.geoms, ctx.learned, ctx.has_bs, need, _skip_wgrad())
+        return tuple(outs) + (None, None, None, None, None)
+
+
+class ResDBwdFn(torch.autograd.Function):
+    """First-order backward of ResDFn as a node of its own, so that it can be differentiated again (MA-GP, train_gan.py:231-252:
+    the penalty is a function of d(logit)/d(image), i.e. of this node's dx).  forward = the fused backward of the block:
+      * gamma*dout, the LeakyReLU mask of the residual output and d(gamma) = <dout, res> in one kernel (7 tensor passes -> 3),
+      * the LeakyReLU mask of conv_r[0]'s output in the epilogue of conv_r[2]'s data gradient,
+      * the shortcut's gradient (adjoint of the average pool: x0.25, nearest x2) as the row-indexed residual of conv_r[0]'s
+        data gradient, so neither the upsampled tensor nor the sum of the two branches is written separately.
+    With the masks m1 = LeakyReLU'(h1), m2 = LeakyReLU'(res) (piecewise constant: no gradient flows into the activations, as in
+    autograd's own leaky_relu double backward) the node is LINEAR in dout:
+        dx = Pool^T Ws^T dout + C0^T (m1 * C2^T (gamma m2 * dout))
+    so its backward for an incoming g = dL/d(dx) is the linearised FORWARD of the block applied to g -- the same fused launches
+    as the forward, masks in place of the activations -- plus three weight gradients:
+        d(dout)  = Ws Pool g + gamma m2 * C2 (m1 * C0 g)           d(gamma) = <m2 * dout, C2 (m1 * C0 g)>
+        d(w0) = wgrad(x = g, dy = gh)     d(w2) = wgrad(x = m1 * C0 g, dy = gr)     d(ws) = wgrad(x = Pool g, dy = dout)
+    (gh, gr: the data gradients this node computed on the way).  The composed block (ops.composable()) computes the same
+    quantities from ~25 fine-grained nodes; both forms are tested against each other."""
+
+    @staticmethod
+    def forward(ctx, dout, x, xp, h1, res, w0, w2, ws, gamma, geoms, learned, has_bs, need, skip_w):
+        g0, g2, gs = geoms
+        ctx.set_materialize_grads(False)       # gradients of outputs nothing depends on arrive as None, not as zeros
+        ctx.dout_dtype = dout.dtype
         dout = dout.contiguous()
         dt = x.dtype
         if dout.dtype != dt:
             dout = dout.to(dt)
-        skip_w = _skip_wgrad()
         # residual branch: g2 = gamma * dout * LeakyReLU'(res), d(gamma) = <dout, res>
         al = gamma.detach().reshape(-1).float()
         gr = torch.empty_like(res)
         dgam = torch.zeros(1, dtype=torch.float32, device=x.device)
         L.call("xmc_scale_mask_dot", _p(dout), _p(res), _p(al), _p(gr), _p(dgam), res.numel(), _code(dt), _st())
-        dw2 = _conv_wgrad_raw(h1, gr, g2).view(w2.shape) if (ctx.needs_input_grad[2] and not skip_w) else None
+        dw2 = _conv_wgrad_raw(h1, gr, g2).view(w2.shape) if (need[2] and not skip_w) else None
         gh = _conv_dgrad_raw(gr, w2, g2, (h1.shape[1], h1.shape[2]), dt, mask=h1)        # includes LeakyReLU'(h1)
-        dw0 = _conv_wgrad_raw(x, gh, g0).view(w0.shape) if (ctx.needs_input_grad[1] and not skip_w) else None
+        dw0 = _conv_wgrad_raw(x, gh, g0).view(w0.shape) if (need[1] and not skip_w) else None
         # shortcut branch
         dws = dbs = None
-        if ctx.learned:
-            if ctx.needs_input_grad[3] and not skip_w:
-                if ctx.has_bs and ctx.needs_input_grad[4]:
+        if learned:
+            if need[3] and not skip_w:
+                if has_bs and need[4]:
                     dws, dbs = _conv_wgrad_raw(xp, dout, gs, want_bias=True)
                     dbs = dbs[: gs.cout]
                 else:
                     dws = _conv_wgrad_raw(xp, dout, gs)
                 dws = dws.view(ws.shape)
-            dxp = _conv_dgrad_raw(dout, ws, gs, (xp.shape[1], xp.shape[2]), dt) if ctx.needs_input_grad[0] else None
+            dxp = _conv_dgrad_raw(dout, ws, gs, (xp.shape[1], xp.shape[2]), dt) if need[0] else None
         else:
             dxp = dout
         dx = None
-        if ctx.needs_input_grad[0]:
+        if need[0]:
             dx = _conv_dgrad_raw(gh, w0, g0, (x.shape[1], x.shape[2]), dt, res=dxp, res_rows=True, res_scale=0.25)
-        dgamma = dgam.reshape(gamma.shape).to(gamma.dtype) if ctx.needs_input_grad[5] else None
-        return dx, dw0, dw2, dws, dbs, dgamma, None, None, None, None, None
+        dgamma = dgam.reshape(gamma.shape).to(gamma.dtype) if need[5] else None
+        ctx.geoms, ctx.learned = geoms, learned
+        ctx.save_for_backward(dout, h1, res, w0, w2, ws, gamma, gr, gh)
+        return dx, dw0, dw2, dws, dbs, dgamma
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g, g_dw0=None, g_dw2=None, g_dws=None, g_dbs=None, g_dgamma=None):
+        if any(t is not None for t in (g_dw0, g_dw2, g_dws, g_dbs, g_dgamma)):
+            raise NotImplementedError("ResDBwdFn: only d(dx) is differentiated again (the MA-GP penalty); use ops.composable() "
+                                      "for second derivatives through the weight gradients")
+        nin = 14
+        if g is None:
+            return (None,) * nin
+        dout, h1, res, w0, w2, ws, gamma, gr, gh = ctx.saved_tensors
+        g0, g2, gs = ctx.geoms
+        dt = h1.dtype
+        g = g.contiguous()
+        if g.dtype != dt:
+            g = g.to(dt)
+        N, H, W, Cx = g.shape
+        skip_w = _skip_wgrad()
+        al = gamma.detach().reshape(-1).float()
+        gp = torch.empty((N, H // 2, W // 2, Cx), dtype=dt, device=g.device)           # Pool g
+        L.call("xmc_sumpool2", _p(g), _p(gp), N, H, W, Cx, 0.25, _code(dt), _st())
+        sc = _conv_fwd_raw(gp, ws, None, gs, L.ACT_NONE, dt) if ctx.learned else gp     # Ws Pool g (the bias does not enter dx)
+        v = _conv_fwd_raw(g, w0, None, g0, L.ACT_NONE, dt, mask=h1)                     # m1 * C0 g
+        ddout, c2 = _conv_fwd_raw(v, w2, None, g2, L.ACT_NONE, dt, res=sc, alpha=al, mask=res, want2=True)   # c2 = C2 v
+        dgamma = None
+        if ctx.needs_input_grad[8]:
+            u = torch.empty_like(c2)
+            L.call("xmc_lrelu_mask", _p(c2), _p(res), _p(u), c2.numel(), 0.2, _code(dt), _st())
+            dg = torch.zeros(1, dtype=torch.float32, device=g.device)
+            L.call("xmc_dot", _p(dout), _p(u), _p(dg), u.numel(), _code(dt), _st())
+            dgamma = dg.reshape(gamma.shape).to(gamma.dtype)
+        dw0 = dw2 = dws = None
+        if not skip_w:
+            if ctx.needs_input_grad[5]:
+                dw0 = _conv_wgrad_raw(g, gh, g0).view(w0.shape)
+            if ctx.needs_input_grad[6]:
+                dw2 = _conv_wgrad_raw(v, gr, g2).view(w2.shape)
+            if ctx.learned and ctx.needs_input_grad[7]:
+                dws = _conv_wgrad_raw(gp, dout, gs).view(ws.shape)
+        return (ddout.to(ctx.dout_dtype) if ctx.needs_input_grad[0] else None, None, None, None, None, dw0, dw2, dws, dgamma,
+                None, None, None, None, None)
 
 
 def res_pool_ok(h1, g2):

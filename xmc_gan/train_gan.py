@@ -13,6 +13,7 @@ against the f32 reference (tests/test_models_gpu.py states both).  Extras that t
 parallelism when launched under ``torch.distributed.run`` (gradient all-reduce + optional all-gathered
 contrastive negatives, ``--gather_negatives``).
 """
+import contextlib
 import os
 import sys
 
@@ -204,7 +205,9 @@ def gan_iteration(netG, netD, optimizerG, optimizerD, imgs, sent_embs, words_emb
     if T.MAGP:
         interpolated = imgs.detach().requires_grad_()
         sent_inter = psent_embs.detach().requires_grad_()
-        with ops.composable():         # this forward's backward is differentiated again: no fused first-order block nodes
+        # this forward's backward is differentiated again.  The fused discriminator blocks carry their own second-order node
+        # (ops.ResDBwdFn); with spectral norm the blocks are composed from the fine-grained Functions as before
+        with (ops.composable() if cfg.DISC.SPEC_NORM else contextlib.nullcontext()):
             features = netD(interpolated)
             o = netD.COND_DNET(features, sent_inter)
         with ops.no_wgrad():           # first-order pass only needs d(logit)/d(inputs)
