@@ -12,7 +12,7 @@
 
 namespace {
 
-constexpr int TH = 8, TW = 32;
+// tile: 8 x 32 pixels, or (T16) 16 x 16 for maps whose width is 16 (mod 32): a K step of 32 pixels is then two tile rows
 
 struct WTCfg {
     int tiles_y, tiles_x, ntiles;
@@ -34,8 +34,11 @@ template <int NCO, int NCI> struct WtOcc {
 // DIAG (grouped convolutions whose groups sit inside the diagonal 16x16 channel blocks, df_concept_gan.py:146): only the diagonal
 // 64-channel blocks are visited (blockIdx.y; Cin block == Cout block) and an item (ci block, tap) multiplies the ONE Cout block
 // with the same index: 1/8 of the dense MFMAs and half the staging.
-template <int NCO, int NCI, int NT, int SA = 1, int KT = 9, int CBW = 1, bool DIAG = false>     // 16-wide blocks of (padded) Cout and Cin; NT threads
+template <int NCO, int NCI, int NT, int SA = 1, int KT = 9, int CBW = 1, bool DIAG = false, bool T16 = false>     // 16-wide blocks of (padded) Cout and Cin; NT threads
 __global__ __launch_bounds__(NT, (SA == 1 ? WtOcc<NCO, NCI>::v : 1)) void wgrad_tile_kernel(const XmcConvDesc d, float* __restrict__ dwp, float* __restrict__ dbias, const WTCfg t) {
+    constexpr int TH = T16 ? 16 : 8, TW = T16 ? 16 : 32;
+    constexpr int KS = TH * TW / 32;                          // K steps of 32 pixels per tile
+    static_assert(!T16 || SA == 1, "16 x 16 tiles: unit stride only");
     constexpr int CDP = NCO * 16, CSP = NCI * 16;
     constexpr int YS = CDP * 2 + 32, XS = CSP * 2 + 32;      // LDS row strides (bytes)
     static_assert(NCO % CBW == 0, "co blocks per wave");
@@ -139,15 +142,16 @@ __global__ __launch_bounds__(NT, (SA == 1 ? WtOcc<NCO, NCI>::v : 1)) void wgrad_
         __syncthreads();
         if (tile + (int)gridDim.x < t.ntiles) prefetch(tile + gridDim.x);
 
-        // K loop: one tile row (32 pixels) per step
-        for (int r = 0; r < TH; ++r) {
+        // K loop: 32 pixels per step (one tile row; two rows of a 16 x 16 tile: the upper 16 pixels of a fragment are then one
+        // patch row further down instead of 16 columns to the right)
+        for (int r = 0; r < KS; ++r) {
             // A' fragment: dy^T [co = cb*16 + lane&15][pix = r*32 + 4*fg + j (+16)]: the 32 lanes one tr16 read serves together
             // address 8 consecutive pixel rows, which the 96/160-byte strides spread over distinct banks (rows 8*fg + j would
             // put lane groups 0 and 1 on the same banks)
             bf16x8 af[CBW];
 #pragma unroll
             for (int c = 0; c < (DIAG ? 0 : CBW); ++c) {
-                const unsigned char* ab = ydy + (size_t)(r * TW + 4 * fg + q) * YS + ((cg * CBW + c) * 16 + 4 * pp4) * 2;
+                const unsigned char* ab = ydy + (size_t)(r * 32 + 4 * fg + q) * YS + ((cg * CBW + c) * 16 + 4 * pp4) * 2;
                 bf16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(ab));
                 bf16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(ab + 16 * YS));
                 af[c] = bf16x8{alo[0], alo[1], alo[2], alo[3], ahi[0], ahi[1], ahi[2], ahi[3]};
@@ -156,12 +160,12 @@ __global__ __launch_bounds__(NT, (SA == 1 ? WtOcc<NCO, NCI>::v : 1)) void wgrad_
             for (int j = 0; j < MAXI; ++j) {
                 const int item = slice + j * NS;
                 if (item < nitems) {                          // wave-uniform
-                    const unsigned char* bb = xp + ((SA == 1 ? r * PW : r * 2 * PW) + 4 * fg + q) * XS + itoff[j] + (4 * pp4) * 2;
+                    const unsigned char* bb = xp + ((SA == 1 ? r * (32 / TW) * PW : r * 2 * PW) + 4 * fg + q) * XS + itoff[j] + (4 * pp4) * 2;
                     bf16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(bb));
-                    bf16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(bb + 16 * XS));
+                    bf16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(bb + (T16 ? PW : 16) * XS));
                     const bf16x8 bf = bf16x8{blo[0], blo[1], blo[2], blo[3], bhi[0], bhi[1], bhi[2], bhi[3]};
                     if (DIAG) {                               // the dy fragment of the Cout block with this item's index
-                        const unsigned char* ab = ydy + (size_t)(r * TW + 4 * fg + q) * YS + (itib[j] * 16 + 4 * pp4) * 2;
+                        const unsigned char* ab = ydy + (size_t)(r * 32 + 4 * fg + q) * YS + (itib[j] * 16 + 4 * pp4) * 2;
                         bf16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(ab));
                         bf16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(ab + 16 * YS));
                         const bf16x8 a1 = bf16x8{alo[0], alo[1], alo[2], alo[3], ahi[0], ahi[1], ahi[2], ahi[3]};
@@ -202,12 +206,12 @@ __global__ __launch_bounds__(NT, (SA == 1 ? WtOcc<NCO, NCI>::v : 1)) void wgrad_
     }
 }
 
-template <int NCO, int NCI, int NT = 256, int SA = 1, int KT = 9, int CBW = 1, bool DIAG = false>
+template <int NCO, int NCI, int NT = 256, int SA = 1, int KT = 9, int CBW = 1, bool DIAG = false, bool T16 = false>
 int launch_wt(const XmcConvDesc& d, float* dwp, float* dbias, const WTCfg& t, hipStream_t st) {
     constexpr int YS = NCO * 32 + 32, XS = NCI * 32 + 32;
-    size_t lds = (size_t)TH * TW * YS + (size_t)t.PH * t.PW * XS;
+    size_t lds = (size_t)256 * YS + (size_t)t.PH * t.PW * XS;
     if (lds > XMC_MAX_DYN_LDS) return 1;
-    XMC_ALLOW_BIG_LDS((wgrad_tile_kernel<NCO, NCI, NT, SA, KT, CBW, DIAG>));
+    XMC_ALLOW_BIG_LDS((wgrad_tile_kernel<NCO, NCI, NT, SA, KT, CBW, DIAG, T16>));
     int per_cu = (int)(160 * 1024 / lds);
     const int cap = WtOcc<NCO, NCI>::v >= 3 ? 3 : 2;
     if (per_cu > cap) per_cu = cap;
@@ -215,8 +219,8 @@ int launch_wt(const XmcConvDesc& d, float* dwp, float* dbias, const WTCfg& t, hi
     int gx = 256 * per_cu / (ny * nz);
     if (gx < 1) gx = 1;
     if (gx > t.ntiles) gx = t.ntiles;
-    hipLaunchKernelGGL((wgrad_tile_kernel<NCO, NCI, NT, SA, KT, CBW, DIAG>), dim3(gx, ny, nz), dim3(NT), lds, st, d, dwp, dbias, t);
-    xmc_note_kernel(DIAG ? "wgrad_tile_kernel<%d, %d, %d, %d, %d, %d, true>" : "wgrad_tile_kernel<%d, %d, %d, %d, %d, %d>", NCO, NCI, NT, SA, KT, CBW);
+    hipLaunchKernelGGL((wgrad_tile_kernel<NCO, NCI, NT, SA, KT, CBW, DIAG, T16>), dim3(gx, ny, nz), dim3(NT), lds, st, d, dwp, dbias, t);
+    xmc_note_kernel(T16 ? "wgrad_tile_kernel<%d, %d, %d, %d, %d, %d, false, true>" : DIAG ? "wgrad_tile_kernel<%d, %d, %d, %d, %d, %d, true>" : "wgrad_tile_kernel<%d, %d, %d, %d, %d, %d>", NCO, NCI, NT, SA, KT, CBW);
     XMC_LAUNCH_CHECK();
     return 0;
 }
@@ -234,6 +238,11 @@ int xmc_conv_wgrad_tile_try(const XmcConvDesc* d, float* dwp, float* dbias, void
     const bool wide = d->CD > 64 || d->CS > 64;              // 64-channel blocks over grid.y / grid.z
     if (wide && (no_wide || s2 || (d->CD > 64 && d->CD % 64) || (d->CS > 64 && d->CS % 64))) return 1;
     if (d->ntaps > (s2 ? 16 : 9) || d->ntaps < 1) return 1;
+    static const bool no_t16 = xmc_debug_off("no_wt_t16");
+    // 16 x 16 tiles for 3x3 layers on 16-pixel-wide maps (512 -> 512, batch 512: 1.00 ms on the row kernel, 0.60 ms = 1033 TF/s
+    // here; a 1x1 layer has no tap re-use to gain from and stays on the split-K kernel)
+    const bool t16 = d->MW % 32 != 0 && d->MW % 16 == 0 && d->MH % 16 == 0 && !s2 && d->ntaps >= 4 && !no_t16;
+    const int TH = t16 ? 16 : 8, TW = t16 ? 16 : 32;
     if (d->MW % TW != 0 || d->MH % TH != 0) return 1;
     if (d->CD % 8 != 0 || d->CS % 8 != 0) return 1;
     WTCfg t;
@@ -246,13 +255,17 @@ int xmc_conv_wgrad_tile_try(const XmcConvDesc* d, float* dwp, float* dbias, void
     }
     t.dh0 = hmin; t.dw0 = wmin;
     t.PH = d->SA * (TH - 1) + (hmax - hmin + 1); t.PW = d->SA * (TW - 1) + (wmax - wmin + 1);
-    if (s2 ? (t.PH > 18 || t.PW > 66 || (t.PW & 1)) : (t.PH > 10 || t.PW > 34)) return 1;
+    if (s2 ? (t.PH > 18 || t.PW > 66 || (t.PW & 1)) : t16 ? (t.PH > 18 || t.PW > 18) : (t.PH > 10 || t.PW > 34)) return 1;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int nco = d->CD <= 16 ? 1 : (d->CD <= 32 ? 2 : 4);
     const int nci = d->CS <= 16 ? 1 : (d->CS <= 32 ? 2 : 4);
     if (s2) {
         if (nco == 4 && nci == 2) return launch_wt<4, 2, 512, 2, 16, 4>(*d, dwp, dbias, t, st);
         if (nco == 2 && nci == 1) return launch_wt<2, 1, 256, 2, 16, 2>(*d, dwp, dbias, t, st);
+        return 1;
+    }
+    if (t16) {        // the wide layers on 16-pixel-wide maps (the row kernel otherwise: 540-600 TF/s)
+        if (nco == 4 && nci == 4) return launch_wt<4, 4, 512, 1, 9, 4, false, true>(*d, dwp, dbias, t, st);
         return 1;
     }
 #define WT_CASE(a, b) if (nco == a && nci == b) return launch_wt<a, b, 256, 1, 9, (a >= 2 ? 2 : 1)>(*d, dwp, dbias, t, st);
