@@ -223,7 +223,8 @@ int xmc_spectral_bwd(const float* g, const float* W, const float* u, const float
  * into a residual branch ending in LeakyReLU (ref = its output) together with d(gamma); dot is f32[1], zeroed by the caller */
 int xmc_scale_mask_dot(const void* dy, const void* ref, const float* alpha_dev, void* g, float* dot, int64_t n, int dtype, void* stream);
 /* Backward of y = a + alpha*b (up == 0; N,H,W,C = shape of dy) or y = up2(a) + alpha*b (up == 1; N,H,W,C = shape of a, dy and
- * b are [N,2H,2W,C]) in one pass: db = alpha*dy, da = 2x2 sum pool of dy (up only), dot += <dy,b>; dot is f32[1], zeroed by the caller */
+ * b are [N,2H,2W,C]) in one pass: db = alpha*dy (db == NULL: not written -- the convolution gradients that consume it take alpha as
+ * XmcConvDesc.alpha_dev / the unpack scale instead), da = 2x2 sum pool of dy (up only), dot += <dy,b>; dot is f32[1], zeroed by the caller */
 int xmc_axpby_bwd(const void* dy, const void* b, const float* alpha_dev, void* db, void* da, float* dot,
                   int N, int H, int W, int C, int up, const void* ymask /* NULL, or y of the LeakyReLU'd form: dy *= LeakyReLU'(y) first
                   (then da is also written in the plain form: the masked dy) */, int dtype, void* stream);

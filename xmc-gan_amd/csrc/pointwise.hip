@@ -573,7 +573,7 @@ __global__ void axpby_bwd_kernel(const void* dy, const void* b, const float* alp
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k) { s += u[k] * v[k]; o[k] = al * u[k]; }
-            Vec8<DT>::store(db, idx, o);
+            if (db) Vec8<DT>::store(db, idx, o);
             continue;
         }
         const int cc = (int)(idx % C8);
@@ -598,7 +598,7 @@ __global__ void axpby_bwd_kernel(const void* dy, const void* b, const float* alp
                 }
 #pragma unroll
                 for (int k = 0; k < 8; ++k) { s += u[k] * v[k]; o[k] = al * u[k]; sum[k] += u[k]; }
-                Vec8<DT>::store(db, hi, o);
+                if (db) Vec8<DT>::store(db, hi, o);       // db == NULL: the consumers of alpha*dy apply alpha themselves
             }
         Vec8<DT>::store(da, idx, sum);
     }
@@ -627,7 +627,7 @@ __global__ void unpack_wgrad_kernel(const float* dwp, float* gw, int Co, int Ci,
             float sacc = 0.f;
 #pragma unroll
             for (int r = 0; r < XMC_BIAS_REPLICAS; ++r) sacc += gb_rep[r * CDb + c];
-            gb[c] = sacc;
+            gb[c] = scale * sacc;
         }
     }
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -993,7 +993,7 @@ extern "C" int xmc_pack_weight_upconv(const float* w, void* wpk, int Co, int Ci,
 }
 extern "C" int xmc_axpby_bwd(const void* dy, const void* b, const float* alpha, void* db, void* da, float* dot,
                              int N, int H, int W, int C, int up, const void* ymask, int dtype, void* s) {
-    if (!dy || !b || !alpha || !db || !dot || C % 8 || ((up || ymask) && !da)) return XMC_EINVAL;
+    if (!dy || !b || !alpha || !dot || C % 8 || ((up || ymask) && !da)) return XMC_EINVAL;
     int64_t total = (int64_t)N * H * W * (C / 8);
     dim3 g(nblocks(total, NT, 2048)), blk(NT);
     if (dtype == XMC_BF16) hipLaunchKernelGGL((axpby_bwd_kernel<XMC_BF16>), g, blk, 0, ST(s), dy, b, alpha, db, da, dot, N, H, W, C / 8, up, ymask);

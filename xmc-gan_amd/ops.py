@@ -373,7 +373,7 @@ def _conv_fwd_raw(x, w, bias, geom, act, out_dtype, res=None, alpha=None, up=Fal
     return y if len(outs) == 1 else tuple(outs)
 
 
-def _conv_dgrad_raw(dy, w, geom, in_hw, in_dtype, mask=None, res=None, res_rows=False, res_scale=1.0):
+def _conv_dgrad_raw(dy, w, geom, in_hw, in_dtype, mask=None, res=None, res_rows=False, res_scale=1.0, alpha=None):
     """dx [N,H,W,cin_p] from dy [N,OH,OW,cout_p].  Epilogue options: ``mask`` (dx layout): dx *= LeakyReLU'(mask);
     ``res``: dx += res_scale * res, with ``res_rows`` the residual is [N,H/s,W/s,cin_p] and every pixel of it is added to its
     s x s block of dx (s == 2: the adjoint of avg_pool2d, df_gan.py:290)."""
@@ -408,6 +408,8 @@ def _conv_dgrad_raw(dy, w, geom, in_hw, in_dtype, mask=None, res=None, res_rows=
             _fill_taps(d, cls, taps)
             d.dph[cls], d.dpw[cls] = ph, pw
     d.ntaps = ntaps
+    if alpha is not None:         # dx = alpha * dgrad(dy) (f32 device scalar, applied to the accumulator)
+        d.alpha_dev = alpha.data_ptr()
     if mask is not None:
         assert mask.shape == dx.shape and mask.dtype == dx.dtype and mask.is_contiguous()
         d.mask = mask.data_ptr()
@@ -677,14 +679,15 @@ class UpConvFn(torch.autograd.Function):
         return dx, dw, db, None
 
 
-def _axpby_bwd_fused(dy, b, alpha, up, ymask=None):
+def _axpby_bwd_fused(dy, b, alpha, up, ymask=None, want_db=True):
     """(da, db, dalpha) of a + alpha*b / up2(a) + alpha*b from one pass over dy and b (not differentiable again).
-    ``ymask``: the forward applied LeakyReLU to the sum; dy is multiplied by LeakyReLU'(y) first."""
+    ``ymask``: the forward applied LeakyReLU to the sum; dy is multiplied by LeakyReLU'(y) first.  ``want_db`` False: alpha*dy
+    is not written (db is None); the caller hands alpha to the consumers of db instead."""
     dy = dy.contiguous()
     N, OH, OW, Cc = dy.shape
     H, W = (OH // 2, OW // 2) if up else (OH, OW)
     al = alpha.detach().reshape(-1).float()
-    db = torch.empty_like(dy)
+    db = torch.empty_like(dy) if want_db else None
     da = torch.empty((N, H, W, Cc), dtype=dy.dtype, device=dy.device) if (up or ymask is not None) else None
     dot = torch.zeros(1, dtype=torch.float32, device=dy.device)
     L.call("xmc_axpby_bwd", _p(dy), _p(b), _p(al), _p(db), _p(da), _p(dot), N, H, W, Cc, 1 if up else 0, _p(ymask), _code(dy.dtype), _st())
@@ -745,17 +748,21 @@ class ConvAxpbyUpFn(torch.autograd.Function):
     def backward(ctx, dy):
         h, w, res, gamma = ctx.saved_tensors
         geom = ctx.geom
-        dsc, dres, dgamma = _axpby_bwd_fused(dy, res, gamma, up=True)      # one pass over dy and res
-        dh = _conv_dgrad_raw(dres, w, geom, (h.shape[1], h.shape[2]), h.dtype) if ctx.needs_input_grad[0] else None
+        # one pass over dy and res; gamma*dy itself is never written: the data gradient applies gamma to its accumulator, the weight
+        # (and bias) gradient in its unpack
+        dy = dy.contiguous()
+        al = gamma.detach().reshape(-1).float()
+        dsc, _, dgamma = _axpby_bwd_fused(dy, res, gamma, up=True, want_db=False)
+        dh = _conv_dgrad_raw(dy, w, geom, (h.shape[1], h.shape[2]), h.dtype, alpha=al) if ctx.needs_input_grad[0] else None
         dw = db = None
         if not _skip_wgrad():
             want_b = ctx.has_b and ctx.needs_input_grad[2]
             if ctx.needs_input_grad[1]:
-                r = _conv_wgrad_raw(h, dres, geom, want_bias=want_b)
+                r = _conv_wgrad_raw(h, dy, geom, scale=al, want_bias=want_b)
                 dw, db = (r if want_b else (r, None))
                 dw = dw.view(w.shape)
             elif want_b:
-                db = ColSumFn.apply(dres)
+                db = ColSumFn.apply(dy) * al
             if db is not None:
                 db = db[: geom.cout]
         return dh, dw, db, None, (dsc if ctx.needs_input_grad[4] else None), (dgamma if ctx.needs_input_grad[5] else None)
