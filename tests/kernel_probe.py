@@ -1,6 +1,6 @@
 """Micro-driver: times convolution shapes in isolation through the C ABI (not a test).
 
-    python tests/kernel_probe.py "N,H,cin,cout,k,s,p,mode[,reps]" ...      mode: fwd | dgrad | wgrad | upfwd | updgrad
+    python tests/kernel_probe.py "N,H,cin,cout,k,s,p,mode[,reps]" ...      mode: fwd | dgrad | wgrad | upfwd | updgrad | upwgrad
     XMC_LIB_PATH=/path/to/variant.so python tests/kernel_probe.py ...     (A/B of kernel variants: one process per library)
 """
 import os
@@ -23,7 +23,7 @@ def run(spec):
     geom = ops.ConvGeom(cin, cout, k, s, p)
     x = torch.randn(N, H, H, ops.chan_pad(cin, bf), generator=g).to("cuda", bf)
     w = torch.nn.Parameter((torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).cuda())
-    if mode in ("upfwd", "updgrad"):
+    if mode in ("upfwd", "updgrad", "upwgrad"):
         OH = 2 * H
     else:
         OH = geom.out_hw(H, H)[0]
@@ -40,6 +40,9 @@ def run(spec):
         if mode == "wgrad":
             ops.new_iteration(x.device)
             return ops._conv_wgrad_raw(x, dy, geom)
+        if mode == "upwgrad":
+            ops.new_iteration(x.device)
+            return ops._conv_wgrad_raw(x, dy, geom, up=True)
         if mode == "upfwd":
             return ops._upconv_fwd_raw(x, w, None, geom, 0, bf)
         if mode == "updgrad":

@@ -22,7 +22,9 @@ struct WTCfg {
 // The small-channel variants are pure streaming (a tile is ~2 k cycles of MFMA work behind ~20 KB of loads): cap their
 // registers so three workgroups share a CU and one's load latency hides behind the others' tiles (3 -> 32 channels: 0.86 -> 0.4 ms).
 template <int NCO, int NCI> struct WtOcc {
-    static constexpr int v = (NCO == 2 && NCI == 1) ? 4 : ((NCO * NCI <= 2 || (NCO == 2 && NCI == 2)) ? 3 : 1);     // no spills at these caps
+    static constexpr int v = (NCO == 2 && NCI == 1) ? 4 : ((NCO * NCI <= 2 || (NCO == 2 && NCI == 2)) ? 3 : (NCO * NCI == 8 ? 2 : 1));     // no spills at these caps
+    // (2,4) / (4,2): 252 registers at two workgroups per CU, no spills; one wave per SIMD left the 64 -> 32 layer through the
+    // upsample (the largest single weight gradient of the step) at 1.33 ms = 464 TF/s, two reach 0.78 ms = 789
 };
 
 // SA == 2 (the 4x4 stride-2 layers, KT = 16 taps): the x patch covers (2*TH+2) x (2*TW+2) source pixels and is stored as two
