@@ -299,7 +299,10 @@ int dispatch(const XmcConvDesc& d, hipStream_t st) {
         // 256x256 tile, 8 waves of the same 128x64 patches: the A rows are shared by twice as many columns, 32 KB instead of
         // 48 KB through the vector-memory path per 2 x (256x128x32) MACs (that path bounds this kernel)
         static const bool no_big = xmc_debug_off("no_igemm256");
-        if (DT == XMC_BF16 && M >= 256 * 256 && d.CDw % 256 == 0 && !no_big) return launch<DT, 256, 256, 2, 4, 2>(d, st);
+        // ... whenever its tiles fill the chip once (512 -> 512 on the 8x8 maps at batch 512: 660 -> 840 TF/s; at batch 256, with
+        // 128 tiles, 605 -> 480: those stay on the smaller tiles)
+        const int64_t tiles256 = (M + 255) / 256 * (d.CDw / 256) * d.nclass;
+        if (DT == XMC_BF16 && (M >= 256 * 256 || tiles256 >= 256) && d.CDw % 256 == 0 && !no_big) return launch<DT, 256, 256, 2, 4, 2>(d, st);
         if (DT == XMC_BF16 && M >= 256 * 256) return launch<DT, 256, 128, 2, 2, 1>(d, st);
         // few output pixels (the 4x4 / 8x8 maps at the end of D, K = 4608-8192): 128-row tiles would leave half the CUs idle
         static const bool no_m64 = xmc_debug_off("no_igemm_m64");
