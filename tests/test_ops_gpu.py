@@ -85,6 +85,13 @@ CONV_CASES = [
     (128, 128, 4, 2, 1, 32, 3),    # 4x4 stride 2: output rows of 16 pixels, 4 segments per step
     (128, 256, 4, 2, 1, 64, 2),    # output rows of 32
     (128, 128, 4, 2, 1, 128, 1),   # output rows of 64: 130 source pixels per segment
+    (128, 128, 3, 1, 1, 8, 8),     # 8-pixel-wide map: 8 row segments per K step, pixel k+16 two segments on
+    (256, 128, 3, 1, 1, 4, 16),    # 4-pixel-wide map: 16 segments per step
+    (128, 256, 4, 2, 1, 16, 4),    # 4x4 stride 2 onto an 8x8 map (18 source pixels per segment)
+    (128, 128, 4, 2, 1, 8, 16),    # ... onto a 4x4 map
+    # all-taps weight gradient with 16x16 tiles (maps 16 pixels wide)
+    (128, 128, 3, 1, 1, 16, 3),
+    (256, 64, 3, 1, 1, 16, 2),     # 64-channel blocks over grid.y / grid.z
     # all-taps weight gradient of the 4x4 stride-2 layers with few channels (two column-parity planes in LDS)
     (32, 64, 4, 2, 1, 64, 2),      # resD block 0 shape: 64 co x 32 ci x 16 taps, 8 waves
     (16, 32, 4, 2, 1, 64, 3),      # 2 x 1 channel blocks, 4 waves

@@ -139,7 +139,8 @@ __global__ __launch_bounds__(WR_NT) void wgrad_row_kernel(const XmcConvDesc d, c
         dyoff[ks] = (k * LD + wm * 64 + 4 * pp) * 2;
         xoff[ks] = (((k / t.seg) * t.xseg + SA * (k % t.seg)) * LDX + wn * (WR_BCI / 4) + 4 * pp) * 2;
     }
-    const int xhi = (t.seg == 16 ? t.xseg : 16 * SA) * LDX * 2;     // pixel k+16: next segment when segments are 16 long
+    // pixel k+16: 16 columns on in a long segment; 16/seg segments on (same position) when segments are 16, 8 or 4 pixels long
+    const int xhi = (t.seg <= 16 ? (16 / t.seg) * t.xseg : 16 * SA) * LDX * 2;
 
     __syncthreads();                              // segment tables
     load_tiles(p_begin, 0);
@@ -245,7 +246,8 @@ int xmc_conv_wgrad_row_try(const XmcConvDesc* d, float* dwp, float* dbias, void*
     for (int t = 0; t < d->ntaps; ++t)
         if (d->dh[0][t] != t / kw - pad || d->dw[0][t] != t % kw - pad) return 1;
     const int W = d->MW;
-    if (W < 16 || (W & (W - 1)) != 0) return 1;
+    static const bool no_small = xmc_debug_off("no_wrow_small");
+    if (W < (no_small ? 16 : 4) || (W & (W - 1)) != 0) return 1;     // 8- and 4-pixel-wide maps: 8 / 16 row segments per K step
     const int64_t P = (int64_t)d->N * d->MH * d->MW;
     if (P % WR_KP != 0 || P < 4 * WR_KP) return 1;
     if ((int64_t)d->N * d->SH * d->SW >= (1ll << 31)) return 1;
