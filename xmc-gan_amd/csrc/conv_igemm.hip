@@ -321,6 +321,7 @@ int xmc_conv_pw1x1_try(const XmcConvDesc* d, void* stream);                     
 int xmc_conv_wtile_try(const XmcConvDesc* d, void* stream);                           // conv_wtile.hip
 int xmc_conv_ptile_pool_try(const XmcConvDesc* d, void* stream);                      // conv_tile.hip
 int xmc_conv_group_try(const XmcConvDesc* d, void* stream);                           // conv_group.hip
+int xmc_conv_thin_out_try(const XmcConvDesc* d, void* stream);                        // conv_thin.hip
 
 extern "C" int xmc_conv_igemm(const XmcConvDesc* d, void* stream) {
     if (!d || !d->src || !d->wpk || !d->dst) return XMC_EINVAL;
@@ -352,6 +353,7 @@ extern "C" int xmc_conv_igemm(const XmcConvDesc* d, void* stream) {
     if (!no_tile) {                       // streaming kernel for 8-channel sources, halo-tile kernels for unit-stride bf16 layers
         rc = xmc_conv_group_try(&dd, stream);
         if (rc > 0) rc = xmc_conv_thin_try(&dd, stream);
+        if (rc > 0) rc = xmc_conv_thin_out_try(&dd, stream);
         if (rc > 0) rc = xmc_conv_pw1x1_try(&dd, stream);
         if (rc > 0 && !no_wt2) rc = xmc_conv_wtile_try(&dd, stream);
         if (rc > 0) rc = xmc_conv_tile_try(&dd, stream);

@@ -232,7 +232,115 @@ int launch_pw(const XmcConvDesc& d, int ngroups, hipStream_t st) {
     return 0;
 }
 
+// ---- 8 stored output channels (conv_out of the generator: 32 -> 3, df_gan.py:85-87, + bias + tanh).  On the 32-wide tile
+// kernel this layer multiplies 32 output channels for the 8 it stores and is bound by that waste (0.66 ms where its 1.34 GB
+// of tensors take 0.27 ms).  Here the output channels are the 16 rows of the MFMA (8 used), the B operand is the lane's
+// 16-byte unit of the tap-shifted pixel read from a small LDS halo patch (pixel stride = channels + 16 bytes: conflict-free
+// ds_read_b128), the weights (9 taps x Cin/32 fragments) stay in registers; 4 waves x 2 rows of an 8 x 16-pixel tile,
+// 14-29 KB of LDS, persistent with the next patch prefetched into registers.
+constexpr int TO_H = 8, TO_W = 16, TO_PH = TO_H + 2, TO_PW = TO_W + 2;
+template <int KC>      // 32-channel K chunks per tap (Cin = 32 * KC)
+__global__ __launch_bounds__(256, 2) void thin_out_kernel(const XmcConvDesc d, int tiles_x, int tiles_y, int ntiles) {
+    constexpr int NKS = 9 * KC, CSU = 4 * KC, PSTR = CSU * 16 + 16;
+    constexpr int NUN = TO_PH * TO_PW * CSU, MAXU = (NUN + 255) / 256;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[TO_PH * TO_PW * PSTR];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 15, kb = lane >> 4;
+    const u32x4* __restrict__ src = reinterpret_cast<const u32x4*>(d.src);
+    const u32x4* __restrict__ wpk = reinterpret_cast<const u32x4*>(d.wpk);
+    bf16x8 wa[NKS];
+    int loff[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        loff[t] = ((d.dh[0][t] + 1) * TO_PW + d.dw[0][t] + 1 + col) * PSTR + kb * 16;
+#pragma unroll
+        for (int c = 0; c < KC; ++c)
+            wa[t * KC + c] = __builtin_bit_cast(bf16x8, wpk[((size_t)d.wi[0][t] * d.CDw + col) * CSU + c * 4 + kb]);
+    }
+    float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (d.bias && kb < 2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bias4[i] = d.bias[kb * 4 + i];
+    }
+    u32x4 pv[MAXU];
+    auto prefetch = [&](int tile) {
+        const int n = tile / (tiles_y * tiles_x), tr = tile - n * (tiles_y * tiles_x);
+        const int y0 = (tr / tiles_x) * TO_H - 1, x0 = (tr % tiles_x) * TO_W - 1;
+#pragma unroll
+        for (int it = 0; it < MAXU; ++it) {
+            const int id = tid + it * 256;
+            const int pp = id / CSU, ch = id - pp * CSU;
+            const int py = pp / TO_PW, px = pp - py * TO_PW;
+            const int sy = y0 + py, sx = x0 + px;
+            const bool ok = id < NUN && (unsigned)sy < (unsigned)d.SH && (unsigned)sx < (unsigned)d.SW;
+            const u32x4 z = {0, 0, 0, 0};
+            pv[it] = ok ? src[(((size_t)n * d.SH + sy) * d.SW + sx) * CSU + ch] : z;
+        }
+    };
+    int tile = blockIdx.x;
+    if (tile < ntiles) prefetch(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < MAXU; ++it) {
+            const int id = tid + it * 256;
+            const int pp = id / CSU, ch = id - pp * CSU;
+            if (id < NUN) *reinterpret_cast<u32x4*>(smem + pp * PSTR + ch * 16) = pv[it];
+        }
+        __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);
+        const int n = tile / (tiles_y * tiles_x), tr = tile - n * (tiles_y * tiles_x);
+        const int y0 = (tr / tiles_x) * TO_H, x0 = (tr % tiles_x) * TO_W;
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int r = wave * 2 + rr;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int c = 0; c < KC; ++c) {
+                    const bf16x8 b = *reinterpret_cast<const bf16x8*>(smem + r * TO_PW * PSTR + loff[t] + c * 64);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[t * KC + c], b, acc, 0, 0, 0);
+                }
+            if (kb < 2) {                                  // D[row = output channel kb*4 + i][col = pixel]; 8 channels stored
+                bf16x4 o;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float v = acc[i] + bias4[i];
+                    if (d.act == XMC_ACT_TANH) v = tanh_fast(v);
+                    else if (d.act == XMC_ACT_LRELU) v = lrelu_f(v);
+                    o[i] = (__bf16)v;
+                }
+                const size_t p = ((size_t)n * d.DH + y0 + r) * d.DW + x0 + col;
+                *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(d.dst) + p * 8 + kb * 4) = o;
+            }
+        }
+    }
+}
+
 }  // namespace
+
+// 0 = launched, 1 = not this kernel's case, < 0 = error
+int xmc_conv_thin_out_try(const XmcConvDesc* d, void* stream) {
+    static const bool off = xmc_debug_off("no_thin_out");
+    if (off) return 1;
+    if (d->dtype != XMC_BF16 || d->out_dtype != XMC_BF16 || d->CD != 8 || (d->CS != 32 && d->CS != 64) || d->CDw < 16) return 1;
+    if (d->SA != 1 || d->DA != 1 || d->src_shift != 0 || d->nclass != 1 || d->ntaps != 9 || d->groups > 1) return 1;
+    if (d->res || d->mask || d->alpha_dev || d->dst2 || d->dst_pool) return 1;
+    if (d->act != XMC_ACT_NONE && d->act != XMC_ACT_TANH && d->act != XMC_ACT_LRELU) return 1;
+    if (d->MH % TO_H != 0 || d->MW % TO_W != 0 || d->SH != d->MH || d->SW != d->MW || d->DH != d->MH || d->DW != d->MW) return 1;
+    if (d->dph[0] != 0 || d->dpw[0] != 0) return 1;
+    for (int k = 0; k < 9; ++k)
+        if (d->dh[0][k] < -1 || d->dh[0][k] > 1 || d->dw[0][k] < -1 || d->dw[0][k] > 1) return 1;
+    const int tx = d->MW / TO_W, ty = d->MH / TO_H, ntiles = d->N * tx * ty;
+    const int grid = ntiles < 256 * 8 ? ntiles : 256 * 8;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (d->CS == 32) hipLaunchKernelGGL((thin_out_kernel<1>), dim3(grid), dim3(256), 0, st, *d, tx, ty, ntiles);
+    else hipLaunchKernelGGL((thin_out_kernel<2>), dim3(grid), dim3(256), 0, st, *d, tx, ty, ntiles);
+    xmc_note_kernel("thin_out_kernel<%d>", d->CS / 32);
+    XMC_LAUNCH_CHECK();
+    return 0;
+}
 
 // 0 = launched, 1 = not this kernel's case, < 0 = error
 int xmc_conv_thin_try(const XmcConvDesc* d, void* stream) {
