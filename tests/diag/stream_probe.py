@@ -40,3 +40,15 @@ for (N, H, C) in ((512, 128, 64), (256, 256, 32), (256, 64, 128)):
     print(f"affine2_bwd    N{N} {H}x{H}x{C}: {ms*1e3:7.1f} us  {3*n*2/ms/1e9:5.2f} TB/s")
     ms = timeit(lambda: torch.add(dy, ref, out=g))
     print(f"torch add3     N{N} {H}x{H}x{C}: {ms*1e3:7.1f} us  {3*n*2/ms/1e9:5.2f} TB/s")
+
+# GroupNorm / modulation / region attention of the concept blocks on their largest maps
+for (N, H, C) in (((64, 128, 128),) if os.environ.get("XMC_PROBE_BIG") else ((64, 128, 128), (64, 64, 128), (64, 128, 64))):
+    n = N * H * H * C
+    x = torch.randn(N, H, H, C, device="cuda").to(bf)
+    dy = torch.randn(N, H, H, C, device="cuda").to(bf)
+    w = torch.ones(C, device="cuda"); b = torch.zeros(C, device="cuda")
+    y, stats = ops._gn_fwd_raw(x, w, b, 16, 0.2, 1e-5)
+    ms = timeit(lambda: ops._gn_fwd_raw(x, w, b, 16, 0.2, 1e-5))
+    print(f"groupnorm fwd  N{N} {H}x{H}x{C}: {ms*1e3:7.1f} us  {3*n*2/ms/1e9:5.2f} TB/s (3 passes)")
+    ms = timeit(lambda: ops._gn_bwd_raw(x, dy, w, b, stats, 16, 0.2))
+    print(f"groupnorm bwd  N{N} {H}x{H}x{C}: {ms*1e3:7.1f} us  {5*n*2/ms/1e9:5.2f} TB/s (5 passes)")
