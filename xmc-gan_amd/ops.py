@@ -528,11 +528,14 @@ class ConvFn(torch.autograd.Function):
         ctx.save_for_backward(x, w, y if act != L.ACT_NONE else None)
         if want_pool:
             ctx.mark_non_differentiable(yp)
+            ctx.set_materialize_grads(False)      # no zero-filled gradient tensor for the pooled by-product on every backward
             return y, yp
         return y
 
     @staticmethod
     def backward(ctx, dy, _dyp=None):
+        if dy is None:
+            return None, None, None, None, None, None, None
         x, w, y = ctx.saved_tensors
         geom = ctx.geom
         dy = dy.contiguous()
@@ -1165,11 +1168,14 @@ class ResDFn(torch.autograd.Function):
                 outp = torch.empty((N, out.shape[1] // 2, out.shape[2] // 2, out.shape[3]), dtype=dt, device=x.device)
                 L.call("xmc_sumpool2", _p(out), _p(outp), N, out.shape[1], out.shape[2], out.shape[3], 0.25, _code(dt), _st())
             ctx.mark_non_differentiable(outp)
+            ctx.set_materialize_grads(False)      # no zero-filled gradient tensor for the pooled by-product on every backward
             return out, outp
         return out
 
     @staticmethod
     def backward(ctx, dout, _doutp=None):
+        if dout is None:
+            return (None,) * 11
         x, xp, h1, res, w0, w2, ws, gamma = ctx.saved_tensors
         need = tuple(bool(v) for v in ctx.needs_input_grad[:6])
         outs = ResDBwdFn.apply(dout, x, xp, h1, res, w0, w2, ws, gamma, ctx.geoms, ctx.learned, ctx.has_bs, need, _skip_wgrad())
