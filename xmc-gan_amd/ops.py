@@ -323,7 +323,7 @@ def _upconv_dgrad_raw(dy, w, geom, in_dtype):
 
 
 def _conv_fwd_raw(x, w, bias, geom, act, out_dtype, res=None, alpha=None, up=False, res_mode=0, want2=False, want_pool=False,
-                  round_act=False, mask=None):
+                  round_act=False, mask=None, out=None):
     """y = act(conv(x, w) + bias) [*alpha] [+ res]; x [N,H,W,Cs]. ``up``: x is read through a fused nearest x2.
     ``res_mode`` 2: res is [N,OH/2,OW/2,C] and read through a nearest x2.  ``want2``: also return act(conv + bias) itself (the
     branch value before alpha / res);  ``want_pool``: also return avg_pool2d(y, 2).  Extras are appended: (y[, y2][, ypool])."""
@@ -335,7 +335,11 @@ def _conv_fwd_raw(x, w, bias, geom, act, out_dtype, res=None, alpha=None, up=Fal
     cd_p = pad_to(geom.cout, 8)
     assert CS == chan_pad(geom.cin, x.dtype), (CS, geom.cin)
     wpk = _packed_cached(w, geom, 0, x.dtype)
-    y = torch.empty((N, OH, OW, cd_p), dtype=out_dtype, device=x.device)
+    if out is None:
+        y = torch.empty((N, OH, OW, cd_p), dtype=out_dtype, device=x.device)
+    else:                          # caller-provided destination
+        assert tuple(out.shape) == (N, OH, OW, cd_p) and out.dtype == out_dtype and out.is_contiguous() and out.device == x.device
+        y = out
     d = L.ConvDesc()
     d.src, d.wpk, d.dst = x.data_ptr(), wpk.data_ptr(), y.data_ptr()
     d.bias = bias.data_ptr() if bias is not None else None
@@ -507,9 +511,9 @@ class ConvFn(torch.autograd.Function):
     197,233-240,273,276,280."""
 
     @staticmethod
-    def forward(ctx, x, w, b, geom, act, out_dtype, want_pool=False):
+    def forward(ctx, x, w, b, geom, act, out_dtype, want_pool=False, out=None):
         """``want_pool``: returns (y, avg_pool2d(y, 2)); the pooled tensor is a by-product for the consumer's shortcut branch
-        (written from the epilogue where the kernel can) and carries no gradient of its own."""
+        (written from the epilogue where the kernel can) and carries no gradient of its own.  ``out``: destination tensor."""
         x = x.contiguous()
         bp = None
         if b is not None:
@@ -520,7 +524,7 @@ class ConvFn(torch.autograd.Function):
             if bp.numel() < cd_p:
                 bp = torch.nn.functional.pad(bp, (0, cd_p - bp.numel()))
             bp = bp.contiguous()
-        y = _conv_fwd_raw(x, w, bp, geom, act, out_dtype, want_pool=want_pool)
+        y = _conv_fwd_raw(x, w, bp, geom, act, out_dtype, want_pool=want_pool, out=out)
         yp = None
         if want_pool:
             y, yp = y
@@ -535,7 +539,7 @@ class ConvFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, _dyp=None):
         if dy is None:
-            return None, None, None, None, None, None, None
+            return None, None, None, None, None, None, None, None
         x, w, y = ctx.saved_tensors
         geom = ctx.geom
         dy = dy.contiguous()
@@ -562,7 +566,7 @@ class ConvFn(torch.autograd.Function):
                 if geom.row_perm is not None:
                     db = torch.zeros_like(db).index_copy(0, geom.perm_dev(db.device).long(), db)
                 db = db[: geom.cout]
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None
 
 
 class ConvDgradFn(torch.autograd.Function):
@@ -775,8 +779,8 @@ def conv_axpby_up(h, w, b, geom, sc_lo, gamma):
     return ConvAxpbyUpFn.apply(h, w, b, geom, sc_lo, gamma)
 
 
-def conv2d(x, w, b, geom, act=L.ACT_NONE, out_dtype=None, want_pool=False):
-    return ConvFn.apply(x, w, b, geom, act, out_dtype or x.dtype, want_pool)
+def conv2d(x, w, b, geom, act=L.ACT_NONE, out_dtype=None, want_pool=False, out=None):
+    return ConvFn.apply(x, w, b, geom, act, out_dtype or x.dtype, want_pool, out)
 
 
 def linear(x, w, b, geom, act=L.ACT_NONE, out_dtype=None):
@@ -1372,18 +1376,22 @@ class NchwToNhwc8Fn(torch.autograd.Function):
     """[N,C<=8,H,W] f32 (module boundary, df_gan.py:127) -> [N,H,W,8] activation dtype, zero padded."""
 
     @staticmethod
-    def forward(ctx, x, dtype):
+    def forward(ctx, x, dtype, out=None):
         _need_cuda(x)
         x = x.contiguous().float()
         N, Cc, H, W = x.shape
-        y = torch.empty((N, H, W, 8), dtype=dtype, device=x.device)
+        if out is None:
+            y = torch.empty((N, H, W, 8), dtype=dtype, device=x.device)
+        else:                      # caller-provided destination (e.g. one half of the discriminator's 2B input)
+            assert tuple(out.shape) == (N, H, W, 8) and out.dtype == dtype and out.is_contiguous()
+            y = out
         L.call("xmc_nchw_to_nhwc8", _p(x), _p(y), N, Cc, H, W, _code(dtype), _st())
         ctx.c = Cc
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        return Nhwc8ToNchwFn.apply(dy, ctx.c), None
+        return Nhwc8ToNchwFn.apply(dy, ctx.c), None, None
 
 
 class Nhwc8ToNchwFn(torch.autograd.Function):
@@ -1892,8 +1900,8 @@ def global_avgpool(x, out_dtype=torch.float32):
     return GapFn.apply(x, out_dtype)
 
 
-def to_nhwc8(x_nchw):
-    return NchwToNhwc8Fn.apply(x_nchw, act_dtype())
+def to_nhwc8(x_nchw, out=None):
+    return NchwToNhwc8Fn.apply(x_nchw, act_dtype(), out)
 
 
 def to_nchw(x_nhwc8, c):

@@ -279,12 +279,12 @@ class _ConceptNetG(_DFNetG):
                          upsample=arch['upsample'][i], normalize=cfg.GEN.NORMALIZE) for i in range(arch['depth'])])
         self.conv_out = nn.Sequential(nn.LeakyReLU(0.2, inplace=True), HipConv2d(arch['out_channels'][-1], 3, 3, 1, 1), nn.Tanh())
 
-    def forward(self, noise, sent_embs, return_nhwc=False, **kwargs):
+    def forward(self, noise, sent_embs, return_nhwc=False, nhwc_dst=None, **kwargs):
         sent_embs = self.proj_sent(sent_embs.float())
         out = self.stem(noise)
         for gblock in self.upblocks:
             out = gblock(out, sent_embs)
-        return self.tail(out, False, return_nhwc)
+        return self.tail(out, False, return_nhwc, nhwc_dst)
 
 
 class InNetG(_ConceptNetG):

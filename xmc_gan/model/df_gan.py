@@ -79,17 +79,20 @@ class NetG(nn.Module):
         out = self.proj_noise(noise.float(), out_dtype=ops.act_dtype())
         return out.view(noise.size(0), 4, 4, 8 * self.ngf)
 
-    def tail(self, out, lrelu_done=False, return_nhwc=False):
+    nhwc_dst_ok = True       # forward(..., nhwc_dst=) writes the engine-layout image into a caller-provided tensor
+
+    def tail(self, out, lrelu_done=False, return_nhwc=False, nhwc_dst=None):
         """LeakyReLU -> Conv3x3(->3) -> Tanh (reference df_gan.py:84-88,101); tanh fused in the conv epilogue.
         ``return_nhwc``: also hand out the engine-layout image [B,S,S,8] the NCHW f32 result was converted from, so a
-        discriminator call on this image (``netD(fake, nhwc8=...)``) skips the NHWC->NCHW->NHWC round trip in both directions."""
+        discriminator call on this image (``netD(fake, nhwc8=...)``) skips the NHWC->NCHW->NHWC round trip in both directions.
+        ``nhwc_dst``: [B,S,S,8] tensor the engine-layout image is written into (one half of the discriminator's 2B input)."""
         if not lrelu_done:
             out = ops.lrelu(out)
-        out = self.conv_out[1](out, act=ACT_TANH)
+        out = self.conv_out[1](out, act=ACT_TANH, out=nhwc_dst)
         img = ops.to_nchw(out, 3)
         return (img, out) if return_nhwc else img
 
-    def forward(self, noise, sent_embs, return_nhwc=False, **kwargs):
+    def forward(self, noise, sent_embs, return_nhwc=False, nhwc_dst=None, **kwargs):
         out = self.stem(noise)
         sent_embs = self.proj_sent(sent_embs.float())
         # The 8 conditioning MLPs of every block depend only on the sentence embedding: all of them (40-56 two-layer MLPs)
@@ -108,7 +111,7 @@ class NetG(nn.Module):
             pending_up = gblock.upsample
         if pending_up:
             out = ops.upsample2(out)
-        return self.tail(out, lrelu_done, return_nhwc)
+        return self.tail(out, lrelu_done, return_nhwc, nhwc_dst)
 
 
 class NetD(nn.Module):

@@ -143,18 +143,26 @@ def gan_iteration(netG, netD, optimizerG, optimizerD, imgs, sent_embs, words_emb
     # ---- discriminator step (train_gan.py:187-229)
     psent_embs = sent_embs if cfg.DISC.SEPERATE else netG.proj_sent(sent_embs.float())
     nhwc_g = bool(getattr(netG, 'nhwc_out', False))             # generator can hand out its image in the engine layout
+    batched = nhwc_g and isinstance(netD, DF_DISC) and not cfg.DISC.SPEC_NORM and ops.fused_blocks()
+    # the discriminator's 2B-image input of the batched pass below: the real images are converted into its first half, the
+    # generator's last convolution writes its second half (no concatenation pass)
+    both_h = (torch.empty((2 * batch_size, imgs.shape[2], imgs.shape[3], 8), dtype=ops.act_dtype(), device=imgs.device)
+              if batched and getattr(netG, 'nhwc_dst_ok', False) else None)
     if nhwc_g:
-        fake, fake_h = netG(noise=noise, sent_embs=sent_embs, words_embs=words_embs, mask=mask, return_nhwc=True)
+        kw = dict(nhwc_dst=both_h[batch_size:]) if both_h is not None else {}
+        fake, fake_h = netG(noise=noise, sent_embs=sent_embs, words_embs=words_embs, mask=mask, return_nhwc=True, **kw)
+        assert both_h is None or fake_h.data_ptr() == both_h[batch_size:].data_ptr(), "generator ignored nhwc_dst"
     else:
         fake, fake_h = netG(noise=noise, sent_embs=sent_embs, words_embs=words_embs, mask=mask), None
-    imgs_h = ops.to_nhwc8(imgs) if isinstance(netD, DF_DISC) else None      # converted once, used by both steps
+    # converted once, used by both steps
+    imgs_h = ops.to_nhwc8(imgs, out=both_h[:batch_size] if both_h is not None else None) if isinstance(netD, DF_DISC) else None
     # The discriminator does not couple the samples of a batch, so its passes over the real and the generated images
     # (193, 202) run as ONE pass over 2B images and the three COND_DNET calls (194, 203, 208) as one over 3B-1 rows: same
     # values, half the launches, twice the work per launch on the small maps at the end of D.  Not with spectral norm: there
     # every forward CALL advances the power iteration (modules.py:16-17), so the call pattern is part of the result.
     if imgs_h is not None and fake_h is not None and not cfg.DISC.SPEC_NORM and ops.fused_blocks():
         B = batch_size
-        feats = netD(None, nhwc8=torch.cat((imgs_h, fake_h.detach())))
+        feats = netD(None, nhwc8=both_h if both_h is not None else torch.cat((imgs_h, fake_h.detach())))
         real_features, fake_features = feats[:B], feats[B:]
         ps_d = psent_embs.detach()
         rows = [feats, real_features[:B - 1]] if T.RMIS_LOSS else [feats]
