@@ -258,6 +258,11 @@ int xmc_affine2_act_fwd(const void* x, const float* g0, const float* b0, const f
 int xmc_affine2_act_bwd(const void* x, const void* dy, const float* g0, const float* b0, const float* g1,
                         const float* b1, void* dx, float* dg0, float* db0, float* dg1, float* db1,
                         int N, int HW, int C, float slope, int dtype, void* stream);
+/* ... with another gradient of x (dx_in, dx layout, may alias dx) added on the way out: x feeds the block's shortcut as well
+ * (df_gan.py:199-200), and its gradient would otherwise meet this one in a separate add pass */
+int xmc_affine2_act_bwd_acc(const void* x, const void* dy, const float* g0, const float* b0, const float* g1,
+                            const float* b1, void* dx, float* dg0, float* db0, float* dg1, float* db1, const void* dx_in,
+                            int N, int HW, int C, float slope, int dtype, void* stream);
 /* single-stage form of the same kernels: pass g1 = b1 = NULL (and dg1 = db1 = NULL) -> y = lrelu(x*g0 + b0), the
  * concept blocks' modulation `gamma * img_embs + beta` + LeakyReLU (df_concept_gan.py:238-239,250-251) */
 

@@ -362,7 +362,7 @@ __global__ void affine2_fwd_kernel(const void* x, const float* g0, const float* 
 template <int DT>
 __global__ void affine2_bwd_kernel(const void* x, const void* dy, const float* g0, const float* b0, const float* g1,
                                    const float* b1, void* dx, float* dg0, float* db0, float* dg1, float* db1,
-                                   int HW, int C8, int pix_per_block, float slope) {
+                                   int HW, int C8, int pix_per_block, float slope, const void* dx_in) {
     const int n = blockIdx.y, groups = NT / C8;
     const int cc = threadIdx.x % C8, g = threadIdx.x / C8;
     float G0[8], B0[8], G1[8], B1[8];
@@ -391,6 +391,12 @@ __global__ void affine2_bwd_kernel(const void* x, const void* dy, const float* g
                 float du = dvv * G1[k] * (u > 0.f ? 1.f : slope);
                 sg0[k] += du * xv[k]; sb0[k] += du;
                 xv[k] = du * G0[k];
+            }
+            if (dx_in) {                  // another gradient of x (the block's shortcut branch) joins here instead of in an add pass
+                float o[8];
+                Vec8<DT>::load(dx_in, idx, o);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) xv[k] += o[k];
             }
             Vec8<DT>::store(dx, idx, xv);
         }
@@ -912,19 +918,24 @@ extern "C" int xmc_affine2_act_fwd(const void* x, const float* g0, const float* 
     XMC_LAUNCH_CHECK();
     return 0;
 }
-extern "C" int xmc_affine2_act_bwd(const void* x, const void* dy, const float* g0, const float* b0, const float* g1,
-                                   const float* b1, void* dx, float* dg0, float* db0, float* dg1, float* db1,
-                                   int N, int HW, int C, float slope, int dtype, void* s) {
+extern "C" int xmc_affine2_act_bwd_acc(const void* x, const void* dy, const float* g0, const float* b0, const float* g1,
+                                       const float* b1, void* dx, float* dg0, float* db0, float* dg1, float* db1,
+                                       const void* dx_in, int N, int HW, int C, float slope, int dtype, void* s) {
     if (C % 8 || C / 8 > NT) return XMC_EALIGN;
     dim3 g; int ppb;
     affine_grid(HW, C / 8, N, g, ppb, 64);
     if (dtype == XMC_BF16)
-        hipLaunchKernelGGL((affine2_bwd_kernel<XMC_BF16>), g, dim3(NT), 0, ST(s), x, dy, g0, b0, g1, b1, dx, dg0, db0, dg1, db1, HW, C / 8, ppb, slope);
+        hipLaunchKernelGGL((affine2_bwd_kernel<XMC_BF16>), g, dim3(NT), 0, ST(s), x, dy, g0, b0, g1, b1, dx, dg0, db0, dg1, db1, HW, C / 8, ppb, slope, dx_in);
     else if (dtype == XMC_F32)
-        hipLaunchKernelGGL((affine2_bwd_kernel<XMC_F32>), g, dim3(NT), 0, ST(s), x, dy, g0, b0, g1, b1, dx, dg0, db0, dg1, db1, HW, C / 8, ppb, slope);
+        hipLaunchKernelGGL((affine2_bwd_kernel<XMC_F32>), g, dim3(NT), 0, ST(s), x, dy, g0, b0, g1, b1, dx, dg0, db0, dg1, db1, HW, C / 8, ppb, slope, dx_in);
     else return XMC_EINVAL;
     XMC_LAUNCH_CHECK();
     return 0;
+}
+extern "C" int xmc_affine2_act_bwd(const void* x, const void* dy, const float* g0, const float* b0, const float* g1,
+                                   const float* b1, void* dx, float* dg0, float* db0, float* dg1, float* db1,
+                                   int N, int HW, int C, float slope, int dtype, void* s) {
+    return xmc_affine2_act_bwd_acc(x, dy, g0, b0, g1, b1, dx, dg0, db0, dg1, db1, nullptr, N, HW, C, slope, dtype, s);
 }
 extern "C" int xmc_affine2_lrelu_fwd(const void* x, const float* g0, const float* b0, const float* g1, const float* b1,
                                      void* y, int N, int HW, int C, int dtype, void* s) {

@@ -84,6 +84,7 @@ _SIGS = {
     "xmc_global_avgpool_bwd": [vp, vp, i32, i32, i32, i32, i32, vp],
     "xmc_affine2_act_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp],
     "xmc_affine2_act_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp],
+    "xmc_affine2_act_bwd_acc": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp],
     "xmc_affine2_lrelu_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "xmc_affine2_lrelu_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "xmc_groupnorm_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, i32, vp],

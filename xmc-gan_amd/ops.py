@@ -1422,15 +1422,18 @@ def _affine_fwd_raw(x, ps, slope):
     return y
 
 
-def _affine_bwd_raw(x, dy, ps, slope):
-    """-> dx, red [len(ps), N, C] (the gradients of ps)"""
+def _affine_bwd_raw(x, dy, ps, slope, dx_acc=None):
+    """-> dx, red [len(ps), N, C] (the gradients of ps).  ``dx_acc``: another gradient of x, added on the way out."""
     N, H, W, Cc = x.shape
     dx = torch.empty_like(x)
+    if dx_acc is not None:
+        dx_acc = dx_acc.contiguous()
+        assert dx_acc.shape == x.shape and dx_acc.dtype == x.dtype
     nred = len(ps)
     red = torch.zeros((nred, N, Cc), dtype=torch.float32, device=x.device)
     ptrs = [_p(t) for t in ps] + ([] if nred == 4 else [None, None])
     rptrs = [_p(red[i]) for i in range(nred)] + ([] if nred == 4 else [None, None])
-    L.call("xmc_affine2_act_bwd", _p(x), _p(dy), *ptrs, _p(dx), *rptrs, N, H * W, Cc, float(slope), _code(x.dtype), _st())
+    L.call("xmc_affine2_act_bwd_acc", _p(x), _p(dy), *ptrs, _p(dx), *rptrs, _p(dx_acc), N, H * W, Cc, float(slope), _code(x.dtype), _st())
     return dx, red
 
 
@@ -1477,6 +1480,34 @@ def _gn_bwd_raw(x, dy, wf, bf, stats, groups, slope):
     L.call("xmc_groupnorm_bwd", _p(x), _p(dy), _p(wf), _p(bf), _p(stats), _p(dx), _p(dw), _p(db), _p(ws), N, H * W, Cc,
            groups, float(slope), _code(x.dtype), _st())
     return dx, dw, db
+
+
+class Affine2LreluSkipFn(torch.autograd.Function):
+    """Affine2LreluFn for an input that also feeds the block's shortcut (df_gan.py:199-200): returns (h, x) -- the second output
+    IS x, for the shortcut branch to consume -- so that both gradients of x arrive at this node and are summed inside the
+    affine backward kernel instead of in a framework add pass over the block input."""
+
+    @staticmethod
+    def forward(ctx, x, g0, b0, g1, b1):
+        x = x.contiguous()
+        ps = [t.contiguous().float() for t in (g0, b0, g1, b1)]
+        y = _affine_fwd_raw(x, ps, 0.2)
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(x, *ps)
+        return y, x.view_as(x)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy, dskip):
+        x, *ps = ctx.saved_tensors
+        if dy is None:
+            return dskip, None, None, None, None
+        dx, red = _affine_bwd_raw(x, dy.contiguous(), ps, 0.2, dx_acc=dskip)
+        return dx, red[0], red[1], red[2], red[3]
+
+
+def affine2_lrelu_skip(x, g0, b0, g1, b1):
+    return Affine2LreluSkipFn.apply(x, g0, b0, g1, b1)
 
 
 class GroupNormFn(torch.autograd.Function):

@@ -235,14 +235,16 @@ class G_Block(nn.Module):
         if not x_pending_up:
             out = ops.axpby(self.shortcut(x), self.residual(x, None, mod), self.gamma)
             return ops.lrelu(out) if out_lrelu else out
-        h = ops.affine2_lrelu(x, *mod[0:4])
+        # x feeds the residual branch AND the shortcut: the affine node hands x through as a second output, so that the two
+        # gradients of x are summed inside its backward kernel
+        h, xs = ops.affine2_lrelu_skip(x, *mod[0:4]) if x.is_cuda else (ops.affine2_lrelu(x, *mod[0:4]), x)
         h = ops.upconv3x3(h, self.c1.weight, self.c1.bias, self.c1.geom)
         h = ops.affine2_lrelu(h, *mod[4:8])
         if not out_lrelu and ops.fused_blocks() and h.shape[1] % 2 == 0:
             # c2, the block sum and the upsample of the shortcut in one pass (third epilogue form, res_mode 2)
-            return ops.conv_axpby_up(h, self.c2.weight, self.c2.bias, self.c2.geom, self.shortcut(x), self.gamma)
+            return ops.conv_axpby_up(h, self.c2.weight, self.c2.bias, self.c2.geom, self.shortcut(xs), self.gamma)
         # out_lrelu: the tail's LeakyReLU (df_gan.py:84-85) applied while the block sum is written
-        return ops.axpby_up(self.shortcut(x), self.c2(h), self.gamma, lrelu=out_lrelu)
+        return ops.axpby_up(self.shortcut(xs), self.c2(h), self.gamma, lrelu=out_lrelu)
 
     def shortcut(self, x):
         return self.c_sc(x) if self.learnable_sc else x
