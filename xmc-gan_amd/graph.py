@@ -56,7 +56,9 @@ class GraphedIteration:
         g = torch.cuda.CUDAGraph()
         if self.pool is None:
             self.pool = torch.cuda.graph_pool_handle()
-        g.capture_begin(pool=self.pool)
+        # thread_local: calls made by OTHER threads while this one captures (the process group's watchdog polling its events)
+        # must not invalidate the capture
+        g.capture_begin(pool=self.pool, capture_error_mode="thread_local")
         self._cur = g
 
     def _end(self):
