@@ -228,8 +228,13 @@ __global__ __launch_bounds__(256) void tile_kernel(const XmcConvDesc d, const Ti
 // SA == 2: stride-2 forward (the 4x4 stride-2 layer of a discriminator block with <= 64 channels): tiles of 8x16 output pixels
 // (two pixel blocks per compute wave), the (2*8+2) x (2*16+2) source patch stored as two column-parity planes per patch row so
 // that the pixels of consecutive output columns for a fixed tap are consecutive (and bank-conflict free) LDS rows.
-template <int BN, int SLAB, int NTAPS, int MC, int SA = 1>
+// M32: the compute waves use v_mfma_f32_32x32x16_bf16 (2 pixel blocks of 32 x BN/32 channel blocks of 32 per wave).  This kernel
+// runs ONE matrix wave per SIMD, and a single wave issues the 16x16x32 form at only ~63 % of the pipe's rate (tests/diag/
+// mfma_probe.hip: 1277 TF/s against 1948 for 32x32x16); same fragment bytes, half the MFMA instructions.  bf16 output, SA == 1,
+// unrolled tap loop only.
+template <int BN, int SLAB, int NTAPS, int MC, int SA = 1, bool M32 = false>
 __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const TileCfg t, int ntiles) {
+    static_assert(!M32 || (SA == 1 && NTAPS > 0), "32x32x16 form: unit stride, unrolled taps");
     constexpr int NS = 256;                      // threads per role
     constexpr int TM = SA == 1 ? 4 : 2, TN = BN / 16;
     constexpr int cps = SLAB / 8;
@@ -267,7 +272,10 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
     for (int id = tid; id < MC * d.ntaps * BN * cps; id += 512) {
         const int ch = id % cps, prow = (id / cps) % BN, tap = id / (cps * BN);          // tap = slice index c * ntaps + tap
         const int j = prow >> 4, q = prow & 15;
-        const int lrow = (j >> 1) * 32 + (q >> 2) * 8 + (j & 1) * 4 + (q & 3);
+        // M32: MFMA row rho = 8a + 4h + r of a 32-block lands in lane half h, accumulator 4a + r <- channel 16h + 4a + r
+        const int rho = prow & 31;
+        const int lrow = M32 ? (prow >> 5) * 32 + 16 * ((rho >> 2) & 1) + 4 * (rho >> 3) + (rho & 3)
+                             : (j >> 1) * 32 + (q >> 2) * 8 + (j & 1) * 4 + (q & 3);
         *reinterpret_cast<u32x4*>(wall + (tap * BN + prow) * pstride + ch * 16) =
             w16[((size_t)d.wi[MC > 1 ? tap / d.ntaps : cls][MC > 1 ? tap % d.ntaps : tap] * d.CDw + n0 + lrow) * cs_units + ch];
     }
@@ -340,6 +348,176 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
             if (next < ntiles) issue(next);
             __syncthreads();                      // B2: the compute waves are done reading the patch
             if (next < ntiles) commit();
+        }
+    } else if constexpr (M32) {
+        // ------------------------------------------------------------------------------------------------ compute role, 32x32x16
+        typedef __attribute__((ext_vector_type(16))) float f32x16;
+        constexpr int NB = BN / 32, S16 = SLAB / 16, NST = NTAPS * S16, G = 2 + NB, M = 2 * NB;
+        const int l32 = lane & 31, hh = lane >> 5;
+        const int cd8 = d.CD / 8;
+        int abyte[2], pty[2], ptx[2];
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb) {
+            const int ml = wm * 64 + pb * 32 + l32;
+            pty[pb] = ml >> t.log2TW; ptx[pb] = ml & (t.TW - 1);
+            abyte[pb] = (pty[pb] * PW + ptx[pb]) * pstride + hh * 16;
+        }
+        const int bbyte = l32 * pstride + hh * 16;
+        const float alpha = d.alpha_dev ? *d.alpha_dev : 1.f;
+        const float slope = d.act == XMC_ACT_LRELU ? XMC_LRELU : (d.act == XMC_ACT_RELU ? 0.f : 1.f);
+        const float rs = d.res_scale == 0.f ? 1.f : d.res_scale;
+        __syncthreads();                          // weights + first patch staged
+        int toffr[MC * NTAPS];
+#pragma unroll
+        for (int k = 0; k < MC * NTAPS; ++k) toffr[k] = __builtin_amdgcn_readfirstlane(s_toff[k]);
+        for (int tile = tile0; tile < ntiles; tile += tstep) {
+            const int img = tile / tpi, trem = tile - img * tpi;
+            const int a0 = (trem / t.tiles_x) * t.TH, b0 = (trem % t.tiles_x) * t.TW;
+            __syncthreads();                      // B1: patch of this tile is in LDS
+#pragma unroll
+            for (int mc = 0; mc < MC; ++mc) {
+                const int ccls = MC > 1 ? mc : cls;
+                const int dph = d.dph[ccls], dpw = d.dpw[ccls];
+                f32x16 acc[2][NB];
+#pragma unroll
+                for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+                    for (int c = 0; c < NB; ++c)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) acc[pb][c][e] = 0.f;
+                // K16 step st = (tap, 16-channel piece s): fragments [0, 2) pixels, [2, G) weights; the reads of step st+1 are dealt
+                // out between the MFMAs of step st and pinned there
+                u32x4 fr_[2][G];
+                auto rd = [&](int st, int g) -> u32x4 {
+                    const int tap = st / S16, sI = st % S16;
+                    if (g < 2) return *reinterpret_cast<const u32x4*>(patch + toffr[mc * NTAPS + tap] + sI * 32 + abyte[g]);
+                    return *reinterpret_cast<const u32x4*>(wall + (mc * NTAPS + tap) * BN * pstride + bbyte + sI * 32 + (g - 2) * 32 * pstride);
+                };
+#pragma unroll
+                for (int g = 0; g < G; ++g) fr_[0][g] = rd(0, g);
+#pragma unroll
+                for (int st = 0; st < NST; ++st) {
+                    const int cur = st & 1, nxt = cur ^ 1;
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {
+                        if (st + 1 < NST) fr_[nxt][g] = rd(st + 1, g);
+#pragma unroll
+                        for (int m = g * M / G; m < (g + 1) * M / G; ++m) {
+                            const int pb = m % 2, c = m / 2;
+                            acc[pb][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fr_[cur][2 + c]),
+                                                                                  __builtin_bit_cast(bf16x8, fr_[cur][pb]), acc[pb][c], 0, 0, 0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                if (mc == MC - 1) __syncthreads();    // B2: patch may be overwritten
+                // epilogue from registers: acc[pb][c][8v + r] = pixel wm*64 + pb*32 + l32, channel n0 + 32c + 16hh + 8v + r
+                const int dbase = (((img * d.DH + a0 * d.DA + dph) * d.DW) + b0 * d.DA + dpw) * cd8 + (n0 >> 3);
+                const int rbase = ((img * d.MH + a0) * d.MW + b0) * cd8 + (n0 >> 3);
+                bf16x8* __restrict__ dst8 = reinterpret_cast<bf16x8*>(d.dst);
+                int eo[2];
+#pragma unroll
+                for (int pb = 0; pb < 2; ++pb) eo[pb] = dbase + ((pty[pb] * d.DA) * d.DW + ptx[pb] * d.DA) * cd8;
+#pragma unroll
+                for (int c = 0; c < NB; ++c) {
+                    const int ub = c * 4 + hh * 2;        // first of this lane's two 8-channel units of the block
+                    if (n0 + ub * 8 >= d.CD) continue;
+                    float fin[2][2][8];
+                    bf16x8 mkv[2][2], rrv[2][2];
+#pragma unroll
+                    for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+                        for (int v2 = 0; v2 < 2; ++v2) {
+                            const size_t idx8 = (size_t)(eo[pb] + ub + v2);
+                            if (d.mask) mkv[pb][v2] = reinterpret_cast<const bf16x8*>(d.mask)[idx8];
+                            if (d.res) {
+                                size_t rix = idx8;
+                                if (d.res_mode == 1) rix = (size_t)(rbase + (pty[pb] * d.MW + ptx[pb]) * cd8 + ub + v2);
+                                else if (d.res_mode == 2)
+                                    rix = res_index8(d, idx8, img, (a0 + pty[pb]) * d.DA + dph, (b0 + ptx[pb]) * d.DA + dpw, 0, 0, (n0 >> 3) + ub + v2);
+                                rrv[pb][v2] = reinterpret_cast<const bf16x8*>(d.res)[rix];
+                            }
+                        }
+#pragma unroll
+                    for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+                        for (int v2 = 0; v2 < 2; ++v2) {
+                            const size_t idx8 = (size_t)(eo[pb] + ub + v2);
+                            float v[8];
+#pragma unroll
+                            for (int r = 0; r < 8; ++r) v[r] = acc[pb][c][8 * v2 + r];
+                            if (d.bias) {
+                                const float* bp = d.bias + n0 + (ub + v2) * 8;
+                                const f32x4 b0v = *reinterpret_cast<const f32x4*>(bp), b1v = *reinterpret_cast<const f32x4*>(bp + 4);
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) { v[r] += b0v[r]; v[4 + r] += b1v[r]; }
+                            }
+                            if (d.act == XMC_ACT_TANH) {
+#pragma unroll
+                                for (int r = 0; r < 8; ++r) v[r] = d.res || d.mask || d.dst2 ? tanhf(v[r]) : tanh_fast(v[r]);
+                            } else if (slope != 1.f) {
+#pragma unroll
+                                for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], v[r] * slope);
+                            }
+                            if (d.dst2 || d.round_act) {
+                                bf16x8 o2;
+#pragma unroll
+                                for (int r = 0; r < 8; ++r) { o2[r] = (__bf16)v[r]; v[r] = (float)o2[r]; }
+                                if (d.dst2) reinterpret_cast<bf16x8*>(d.dst2)[idx8] = o2;
+                            }
+                            if (d.alpha_dev) {
+#pragma unroll
+                                for (int r = 0; r < 8; ++r) v[r] *= alpha;
+                            }
+                            if (d.mask) {
+#pragma unroll
+                                for (int r = 0; r < 8; ++r) v[r] *= lrelu_slope((float)mkv[pb][v2][r]);
+                            }
+                            if (d.res) {
+#pragma unroll
+                                for (int r = 0; r < 8; ++r) v[r] += rs * (float)rrv[pb][v2][r];
+                            }
+                            bf16x8 o;
+#pragma unroll
+                            for (int r = 0; r < 8; ++r) { o[r] = (__bf16)v[r]; fin[pb][v2][r] = (float)o[r]; }
+                            dst8[idx8] = o;
+                        }
+                    if (MC == 1 && d.dst_pool) {
+                        // third output: 2x2 average of the rounded block output.  8x32 tiles: the wave's two 32-pixel blocks are tile rows
+                        // 2wm and 2wm+1 (vertical pair = the two blocks of a lane); 16x16 tiles: a block is two rows of 16 (vertical pair
+                        // = lane ^ 16).  Horizontal neighbour: lane ^ 1.
+                        bf16x8* __restrict__ pool8 = reinterpret_cast<bf16x8*>(d.dst_pool);
+#pragma unroll
+                        for (int v2 = 0; v2 < 2; ++v2) {
+                            if (t.log2TW == 5) {
+                                bf16x8 o;
+#pragma unroll
+                                for (int r = 0; r < 8; ++r) {
+                                    float sm = fin[0][v2][r] + fin[1][v2][r];
+                                    sm += __shfl_xor(sm, 1, 64);
+                                    o[r] = (__bf16)(0.25f * sm);
+                                }
+                                if ((l32 & 1) == 0)
+                                    pool8[((img * (d.DH >> 1) + ((a0 + pty[0]) >> 1)) * (d.DW >> 1) + ((b0 + ptx[0]) >> 1)) * cd8 + (n0 >> 3) + ub + v2] = o;
+                            } else {
+#pragma unroll
+                                for (int pb = 0; pb < 2; ++pb) {
+                                    bf16x8 o;
+#pragma unroll
+                                    for (int r = 0; r < 8; ++r) {
+                                        float sm = fin[pb][v2][r];
+                                        sm += __shfl_xor(sm, 16, 64);
+                                        sm += __shfl_xor(sm, 1, 64);
+                                        o[r] = (__bf16)(0.25f * sm);
+                                    }
+                                    if ((l32 & 17) == 0)
+                                        pool8[((img * (d.DH >> 1) + ((a0 + pty[pb]) >> 1)) * (d.DW >> 1) + ((b0 + ptx[pb]) >> 1)) * cd8 + (n0 >> 3) + ub + v2] = o;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
         }
     } else {
         // ------------------------------------------------------------------------------------------------ compute role
@@ -910,6 +1088,16 @@ int launch_ptile(const XmcConvDesc& d, const TileCfg& t, hipStream_t st) {
             XMC_LAUNCH_CHECK();
             return 0;
         }
+    }
+    static const bool no_m32 = xmc_debug_off("no_ptile_m32");
+    static const bool m32_all = xmc_debug_off("ptile_m32_all");
+    if (!no_m32 && d.ntaps == 9 && d.out_dtype == XMC_BF16 && t.slab == 64 &&
+        (m32_all || d.res || d.dst2 || d.dst_pool || d.mask)) {      // one matrix wave per SIMD: 32x32x16 form
+        XMC_ALLOW_BIG_LDS((ptile3_kernel<BN, 64, 9, 1, 1, true>));
+        hipLaunchKernelGGL((ptile3_kernel<BN, 64, 9, 1, 1, true>), grid, dim3(512), lds, st, d, t, ntiles);
+        xmc_note_kernel("ptile3_kernel<%d, 64, 9, 1, 1, true>", BN);
+        XMC_LAUNCH_CHECK();
+        return 0;
     }
 #define XMC_PT3(SL, NTP)                                                                                                      \
     do {                                                                                                                      \
