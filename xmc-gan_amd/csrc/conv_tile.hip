@@ -385,6 +385,33 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
                     for (int c = 0; c < NB; ++c)
 #pragma unroll
                         for (int e = 0; e < 16; ++e) acc[pb][c][e] = 0.f;
+                // The epilogue's mask / residual vectors are requested NOW, before the tile's MFMAs: their memory latency (one
+                // round trip per channel unit when they were requested in the epilogue, ~15 % of a tile) hides behind the K loop.
+                const int dbase = (((img * d.DH + a0 * d.DA + dph) * d.DW) + b0 * d.DA + dpw) * cd8 + (n0 >> 3);
+                const int rbase = ((img * d.MH + a0) * d.MW + b0) * cd8 + (n0 >> 3);
+                int eo[2];
+#pragma unroll
+                for (int pb = 0; pb < 2; ++pb) eo[pb] = dbase + ((pty[pb] * d.DA) * d.DW + ptx[pb] * d.DA) * cd8;
+                bf16x8 mkv[NB][2][2], rrv[NB][2][2];
+#pragma unroll
+                for (int c = 0; c < NB; ++c) {
+                    const int ub = c * 4 + hh * 2;
+                    if (n0 + ub * 8 >= d.CD) continue;
+#pragma unroll
+                    for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+                        for (int v2 = 0; v2 < 2; ++v2) {
+                            const size_t idx8 = (size_t)(eo[pb] + ub + v2);
+                            if (d.mask) mkv[c][pb][v2] = reinterpret_cast<const bf16x8*>(d.mask)[idx8];
+                            if (d.res) {
+                                size_t rix = idx8;
+                                if (d.res_mode == 1) rix = (size_t)(rbase + (pty[pb] * d.MW + ptx[pb]) * cd8 + ub + v2);
+                                else if (d.res_mode == 2)
+                                    rix = res_index8(d, idx8, img, (a0 + pty[pb]) * d.DA + dph, (b0 + ptx[pb]) * d.DA + dpw, 0, 0, (n0 >> 3) + ub + v2);
+                                rrv[c][pb][v2] = reinterpret_cast<const bf16x8*>(d.res)[rix];
+                            }
+                        }
+                }
                 // K16 step st = (tap, 16-channel piece s): fragments [0, 2) pixels, [2, G) weights; the reads of step st+1 are dealt
                 // out between the MFMAs of step st and pinned there
                 u32x4 fr_[2][G];
@@ -412,32 +439,12 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
                 }
                 if (mc == MC - 1) __syncthreads();    // B2: patch may be overwritten
                 // epilogue from registers: acc[pb][c][8v + r] = pixel wm*64 + pb*32 + l32, channel n0 + 32c + 16hh + 8v + r
-                const int dbase = (((img * d.DH + a0 * d.DA + dph) * d.DW) + b0 * d.DA + dpw) * cd8 + (n0 >> 3);
-                const int rbase = ((img * d.MH + a0) * d.MW + b0) * cd8 + (n0 >> 3);
                 bf16x8* __restrict__ dst8 = reinterpret_cast<bf16x8*>(d.dst);
-                int eo[2];
-#pragma unroll
-                for (int pb = 0; pb < 2; ++pb) eo[pb] = dbase + ((pty[pb] * d.DA) * d.DW + ptx[pb] * d.DA) * cd8;
 #pragma unroll
                 for (int c = 0; c < NB; ++c) {
                     const int ub = c * 4 + hh * 2;        // first of this lane's two 8-channel units of the block
                     if (n0 + ub * 8 >= d.CD) continue;
                     float fin[2][2][8];
-                    bf16x8 mkv[2][2], rrv[2][2];
-#pragma unroll
-                    for (int pb = 0; pb < 2; ++pb)
-#pragma unroll
-                        for (int v2 = 0; v2 < 2; ++v2) {
-                            const size_t idx8 = (size_t)(eo[pb] + ub + v2);
-                            if (d.mask) mkv[pb][v2] = reinterpret_cast<const bf16x8*>(d.mask)[idx8];
-                            if (d.res) {
-                                size_t rix = idx8;
-                                if (d.res_mode == 1) rix = (size_t)(rbase + (pty[pb] * d.MW + ptx[pb]) * cd8 + ub + v2);
-                                else if (d.res_mode == 2)
-                                    rix = res_index8(d, idx8, img, (a0 + pty[pb]) * d.DA + dph, (b0 + ptx[pb]) * d.DA + dpw, 0, 0, (n0 >> 3) + ub + v2);
-                                rrv[pb][v2] = reinterpret_cast<const bf16x8*>(d.res)[rix];
-                            }
-                        }
 #pragma unroll
                     for (int pb = 0; pb < 2; ++pb)
 #pragma unroll
@@ -471,11 +478,11 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
                             }
                             if (d.mask) {
 #pragma unroll
-                                for (int r = 0; r < 8; ++r) v[r] *= lrelu_slope((float)mkv[pb][v2][r]);
+                                for (int r = 0; r < 8; ++r) v[r] *= lrelu_slope((float)mkv[c][pb][v2][r]);
                             }
                             if (d.res) {
 #pragma unroll
-                                for (int r = 0; r < 8; ++r) v[r] += rs * (float)rrv[pb][v2][r];
+                                for (int r = 0; r < 8; ++r) v[r] += rs * (float)rrv[c][pb][v2][r];
                             }
                             bf16x8 o;
 #pragma unroll
