@@ -790,3 +790,73 @@ def test_optimizer_step_repacks_cached_weights_in_bulk():
     assert torch.equal(ys[0], y_ref)
     y_ref = ops.conv2d(xs[2].detach(), ws[2].detach().clone(), None, geoms[2]).float()
     assert torch.equal(ys[2], y_ref)
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_affine_skip_node_sums_both_gradients_of_its_input(mode):
+    """ops.affine2_lrelu_skip returns (h, x): the gradient arriving at the second output is added inside the affine backward
+    kernel.  Reference: the plain affine node plus autograd's own sum."""
+    ops.set_precision(mode)
+    dt = ops.act_dtype()
+    g = torch.Generator().manual_seed(11)
+    N, H, C = 3, 16, 64
+    x0 = torch.randn(N, H, H, C, generator=g).to(DEV, dt)
+    mods = [torch.randn(N, C, generator=g).to(DEV) * 0.5 + (1.0 if i % 2 == 0 else 0.0) for i in range(4)]
+    r1 = torch.randn(N, H, H, C, generator=g).to(DEV, dt)
+    r2 = torch.randn(N, H, H, C, generator=g).to(DEV, dt)
+    outs = []
+    for skip in (True, False):
+        x = x0.clone().requires_grad_()
+        ms = [m.clone().requires_grad_() for m in mods]
+        if skip:
+            h, xs = ops.affine2_lrelu_skip(x, *ms)
+        else:
+            h, xs = ops.affine2_lrelu(x, *ms), x
+        ((h.float() * r1.float()).sum() + (xs.float() * r2.float()).sum()).backward()
+        outs.append([h.detach().float(), x.grad.float()] + [m.grad for m in ms])
+    for a, b in zip(*outs):
+        sc = b.abs().max().item() + 1e-12
+        torch.testing.assert_close(a, b, rtol=2e-2 if mode == "bf16" else 1e-5, atol=(2e-2 if mode == "bf16" else 1e-5) * sc)
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("norm,with_sl", [(True, False), (False, False), (True, True)])
+def test_concept_stage_node_equals_composed_operators(mode, norm, with_sl):
+    """ops.concept_stage (key projection [+ GroupNorm], region attention, concept head, modulation as ONE autograd node with the
+    three gradients of its input summed inside the kernels) against the same stage composed from the separate operators."""
+    ops.set_precision(mode)
+    dt = ops.act_dtype()
+    g = torch.Generator().manual_seed(3 + int(norm) + 2 * int(with_sl))
+    B, H, E = 3, 16, 256
+    rnd = lambda *sh, sc=1.0: (torch.randn(*sh, generator=g) * sc).to(DEV)
+    x0 = rnd(B, H, H, 128).to(dt)
+    q0, sent0 = rnd(B, 16, 4), rnd(B, E)
+    wk0 = rnd(64, 8, 1, 1, sc=0.35)
+    gnw0, gnb0 = 1 + 0.1 * rnd(64), 0.1 * rnd(64)
+    P0 = [rnd(64, 8, 1, 1, sc=0.4), rnd(16, 4, sc=0.5)]
+    for _ in range(2):
+        P0 += [rnd(128, E + 4, 1, 1, sc=(E + 4) ** -0.5), 0.1 * rnd(128), rnd(128, 8, 1, 1, sc=0.35), 0.1 * rnd(128)]
+    if with_sl:
+        P0 += [rnd(4, E, sc=2.0 * E ** -0.5)]
+    r = rnd(B, H, H, 128).to(dt)
+    geom = ops.ConvGeom(128, 64, 1, 1, 0, groups=16)
+    res = []
+    for fused in (True, False):
+        leaf = lambda t: t.clone().requires_grad_()
+        x, q, sent, wk, gnw, gnb = leaf(x0), leaf(q0), leaf(sent0), torch.nn.Parameter(wk0.clone()), leaf(gnw0), leaf(gnb0)
+        P = [leaf(p) for p in P0]
+        if fused:
+            y = ops.concept_stage(x, q, sent, wk, gnw if norm else None, gnb if norm else None, geom, 16, 0.7, P)
+        else:
+            key = ops.conv2d(x, wk, None, geom)
+            if norm:
+                key = ops.groupnorm(key, gnw, gnb, 16)
+            pooled = ops.attn_pool(key, q, x, 16, 0.7)
+            gamma, beta = ops.concept_head(pooled, sent, P)
+            y = ops.affine_lrelu(x, gamma, beta)
+        (y.float() * r.float()).sum().backward()
+        res.append([y.detach().float(), x.grad.float(), q.grad, sent.grad, wk.grad] + ([gnw.grad, gnb.grad] if norm else []) + [p.grad for p in P])
+    for k, (a, b) in enumerate(zip(*res)):
+        sc = b.abs().max().item() + 1e-12
+        # bf16: the composed form rounds each of the three gradients of x to bf16 before adding them, the node adds in f32
+        torch.testing.assert_close(a, b, rtol=3e-2 if mode == "bf16" else 2e-4, atol=(3e-2 if mode == "bf16" else 2e-4) * sc, msg=lambda m: f"tensor {k}: {m}")
