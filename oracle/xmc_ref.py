@@ -39,26 +39,42 @@ CARD, PW, SD = 16, 8, 4  # cardinality, bottleneck width p, state dim p' (df_con
 # the engine is summation order, i.e. kernel error proper, which separates it from the error of the number format.
 # Covers DF_GEN + DF_DISC (the benched path); the mode is off unless a test turns it on, the goldens never see it.
 _QUANT = False
+_QSKIP = frozenset()      # storage sites that stay f32 although the mode is on (the per-site ladder, tests/diag/quant_ladder.py)
+_QGRAD = True             # round the gradient that flows back through a storage site as well
+
+# the storage sites of the engine's bf16 mode, by tag (`q(x, site)` / `qw(w, site)`):
+#   d.img  the image the discriminator reads          d.conv_img, d.r0, d.r2  its convolution outputs
+#   d.pool the pooled shortcut input                  d.sc  the 1x1 shortcut output        d.sum  the block sum
+#   d.w    packed discriminator weights               h.c / h.m / h.w  COND_DNET: condition, joint_conv.0 output, weights
+#   g.stem, g.aff (affine-affine-LeakyReLU passes), g.c1, g.c2, g.sc, g.sum, g.act (tail LeakyReLU), g.img, g.w
+QUANT_SITES = ("d.img", "d.conv_img", "d.r0", "d.r2", "d.pool", "d.sc", "d.sum", "d.w", "h.c", "h.m", "h.w",
+               "g.stem", "g.aff", "g.c1", "g.c2", "g.sc", "g.sum", "g.act", "g.img", "g.w")
 
 
 class quant:
-    """context manager / switch: `with X.quant(True): ...`"""
+    """context manager / switch: `with X.quant(True): ...`.  ``skip``: site tags (prefix match, e.g. "d." or "g.w") that keep
+    f32 storage; ``grad=False``: forward values are rounded, gradients pass through unrounded."""
 
-    def __init__(self, on=True):
-        self.on = bool(on)
+    def __init__(self, on=True, skip=(), grad=True, fmt=torch.bfloat16):
+        self.on, self.skip, self.grad, self.fmt = bool(on), tuple(skip), bool(grad), fmt
 
     def __enter__(self):
-        global _QUANT
-        self.prev, _QUANT = _QUANT, self.on
+        global _QUANT, _QSKIP, _QGRAD, _QFMT
+        self.prev = (_QUANT, _QSKIP, _QGRAD, _QFMT)
+        _QUANT, _QGRAD, _QFMT = self.on, self.grad, self.fmt
+        _QSKIP = frozenset(t for t in QUANT_SITES if any(t.startswith(p_) for p_ in self.skip))
         return self
 
     def __exit__(self, *a):
-        global _QUANT
-        _QUANT = self.prev
+        global _QUANT, _QSKIP, _QGRAD, _QFMT
+        _QUANT, _QSKIP, _QGRAD, _QFMT = self.prev
+
+
+_QFMT = torch.bfloat16     # the 16-bit storage format the mode rounds to (torch.float16: the what-if rung of the ladder)
 
 
 def _bf16(t):
-    return t.to(torch.bfloat16).to(torch.float32)
+    return t.to(_QFMT).to(torch.float32)
 
 
 class _QAct(torch.autograd.Function):
@@ -70,7 +86,7 @@ class _QAct(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        return _bf16(g)
+        return _bf16(g) if _QGRAD else g
 
 
 class _QWeight(torch.autograd.Function):
@@ -85,12 +101,12 @@ class _QWeight(torch.autograd.Function):
         return g
 
 
-def q(x):
-    return _QAct.apply(x) if _QUANT else x
+def q(x, site=None):
+    return _QAct.apply(x) if (_QUANT and site not in _QSKIP) else x
 
 
-def qw(w):
-    return _QWeight.apply(w) if _QUANT else w
+def qw(w, site=None):
+    return _QWeight.apply(w) if (_QUANT and site not in _QSKIP) else w
 
 
 # ----------------------------------------------------------------------------------------
@@ -406,6 +422,31 @@ def synth_params(shapes: dict, seed: int = 0) -> dict:
     return out
 
 
+def ref_init_params(shapes: dict, seed: int = 0, gamma: float = 0.0) -> dict:
+    """The reference's own parameterisation at the start of training: `weight_init` (train_gan.py:65-69) draws every Conv2d /
+    Linear weight Kaiming-normal (fan_in, relu gain) and zeroes every bias -- the conditioning MLPs' identity init
+    (df_gan.py:244-248) included, it runs after the constructors (477-478) -- and the block gammas start at `gamma` = 0
+    (df_gan.py:195,281).  bench.py times this parameterisation with gamma = 0.1 so that no branch is dead weight.
+    DF_GEN / DF_DISC keys only; per-key generators as in synth_params."""
+    out = {}
+    for key, shape in shapes.items():
+        g = torch.Generator().manual_seed((zlib.crc32(key.encode()) + 104729 * seed) & 0x7FFFFFFF)
+        leaf = key.rsplit(".", 1)[-1]
+        if leaf == "gamma":
+            t = torch.full(shape, float(gamma))
+        elif leaf == "bias":
+            t = torch.zeros(shape)
+        elif leaf == "weight":
+            fan_in = 1
+            for d in shape[1:]:
+                fan_in *= d
+            t = torch.randn(shape, generator=g) * math.sqrt(2.0 / fan_in)
+        else:
+            raise KeyError(f"ref_init_params: no rule for {key}")
+        out[key] = t.to(torch.float32)
+    return out
+
+
 def synth_batch(h: Hyper, batch: int, seed: int = 100, words_len: int = 20):
     """COCO-shaped synthetic batch (shapes per dataset.py:34-37, encoder.py:149)."""
     g = torch.Generator().manual_seed(seed)
@@ -462,7 +503,7 @@ def _upconv3x3_q(x_lo, w, b):
                 for tw in (0, 1):
                     (h0, h1), (w0, w1) = rows[i][th], rows[j][tw]
                     taps.append(w[:, :, h0:h1 + 1, w0:w1 + 1].sum(dim=(2, 3)))
-            wc = qw(torch.stack(taps, dim=2).view(w.size(0), C, 2, 2))
+            wc = qw(torch.stack(taps, dim=2).view(w.size(0), C, 2, 2), "g.w")
             xp = F.pad(x_lo, (1 - j, j, 1 - i, i))              # rows a-1..a (i=0) or a..a+1 (i=1), same for columns
             parts.append((i, j, F.conv2d(xp, wc)))
     out = torch.stack([torch.stack([parts[0][2], parts[1][2]], dim=-1), torch.stack([parts[2][2], parts[3][2]], dim=-1)], dim=-3)
@@ -476,15 +517,15 @@ def _g_block_q(P, p, x, c, upsample, x_is_lo=False):
     upsample (the engine never writes the upsampled tensor; affines and the 1x1 shortcut commute with it, c1 runs as the fused
     upsample convolution)."""
     hdn = F.leaky_relu(_affine(P, f"{p}.affine0", x, c), LRELU)
-    hdn = q(F.leaky_relu(_affine(P, f"{p}.affine1", hdn, c), LRELU))
+    hdn = q(F.leaky_relu(_affine(P, f"{p}.affine1", hdn, c), LRELU), "g.aff")
     if x_is_lo:
-        hdn = q(_upconv3x3_q(hdn, P[f"{p}.c1.weight"], P[f"{p}.c1.bias"]))
+        hdn = q(_upconv3x3_q(hdn, P[f"{p}.c1.weight"], P[f"{p}.c1.bias"]), "g.c1")
     else:
-        hdn = q(F.conv2d(hdn, qw(P[f"{p}.c1.weight"]), P[f"{p}.c1.bias"], 1, 1))
+        hdn = q(F.conv2d(hdn, qw(P[f"{p}.c1.weight"], "g.w"), P[f"{p}.c1.bias"], 1, 1), "g.c1")
     hdn = F.leaky_relu(_affine(P, f"{p}.affine2", hdn, c), LRELU)
-    hdn = q(F.leaky_relu(_affine(P, f"{p}.affine3", hdn, c), LRELU))
-    res = q(F.conv2d(hdn, qw(P[f"{p}.c2.weight"]), P[f"{p}.c2.bias"], 1, 1))
-    sc = q(F.conv2d(x, qw(P[f"{p}.c_sc.weight"]), P[f"{p}.c_sc.bias"])) if f"{p}.c_sc.weight" in P else x
+    hdn = q(F.leaky_relu(_affine(P, f"{p}.affine3", hdn, c), LRELU), "g.aff")
+    res = q(F.conv2d(hdn, qw(P[f"{p}.c2.weight"], "g.w"), P[f"{p}.c2.bias"], 1, 1), "g.c2")
+    sc = q(F.conv2d(x, qw(P[f"{p}.c_sc.weight"], "g.w"), P[f"{p}.c_sc.bias"]), "g.sc") if f"{p}.c_sc.weight" in P else x
     if x_is_lo:
         sc = F.interpolate(sc, scale_factor=2)
     return sc, res            # the caller forms sc + gamma * res (the last block fuses the tail's LeakyReLU into that pass)
@@ -498,15 +539,15 @@ def proj_sent(P, sent):
 
 
 def _stem(P, h: Hyper, noise):
-    out = q(F.linear(noise, P["proj_noise.weight"], P["proj_noise.bias"]))      # f32 GEMM in the engine, stored as activation
+    out = q(F.linear(noise, P["proj_noise.weight"], P["proj_noise.bias"]), "g.stem")      # f32 GEMM in the engine, stored as activation
     return out.view(out.size(0), 8 * h.nch, 4, 4)
 
 
 def _tail(P, x, lrelu_done=False):
     """conv_out = LeakyReLU -> Conv3x3(->3) -> Tanh (df_gan.py:84-88)."""
     if not lrelu_done:
-        x = q(F.leaky_relu(x, LRELU))
-    return q(torch.tanh(F.conv2d(x, qw(P["conv_out.1.weight"]), P["conv_out.1.bias"], 1, 1)))
+        x = q(F.leaky_relu(x, LRELU), "g.act")
+    return q(torch.tanh(F.conv2d(x, qw(P["conv_out.1.weight"], "g.w"), P["conv_out.1.bias"], 1, 1)), "g.img")
 
 
 def netg_forward(P, h: Hyper, noise, sent_embs, **_):
@@ -520,7 +561,7 @@ def netg_forward(P, h: Hyper, noise, sent_embs, **_):
             sc, res = _g_block_q(P, p, out, c, a["upsample"][i], x_is_lo=lo)
             out = sc + P[f"{p}.gamma"] * res
             last = i == a["depth"] - 1 and not a["upsample"][i]
-            out = q(F.leaky_relu(out, LRELU)) if last else q(out)
+            out = q(F.leaky_relu(out, LRELU), "g.sum") if last else q(out, "g.sum")
             lo = a["upsample"][i]
         if lo:
             out = F.interpolate(out, scale_factor=2)
@@ -790,15 +831,15 @@ def netd_forward(P, h: Hyper, x):
 def _netd_forward_q(P, h: Hyper, x, a):
     """DF_DISC with the engine's storage points (image, every convolution output, the pooled shortcut input, the block sum) and
     its order on the shortcut: average pool first, then the 1x1 convolution (they commute; df_gan.py:286-291)."""
-    out = q(F.conv2d(q(x), qw(sn_weight(P, "conv_img.weight")), P["conv_img.bias"], 1, 1))
+    out = q(F.conv2d(q(x, "d.img"), qw(sn_weight(P, "conv_img.weight"), "d.w"), P["conv_img.bias"], 1, 1), "d.conv_img")
     for i in range(1, a["depth"]):
         p = f"downblocks.{i - 1}"
-        r = q(F.leaky_relu(F.conv2d(out, qw(sn_weight(P, f"{p}.conv_r.0.weight")), None, 2, 1), LRELU))
-        r = q(F.leaky_relu(F.conv2d(r, qw(sn_weight(P, f"{p}.conv_r.2.weight")), None, 1, 1), LRELU))
-        s = q(F.avg_pool2d(out, 2))
+        r = q(F.leaky_relu(F.conv2d(out, qw(sn_weight(P, f"{p}.conv_r.0.weight"), "d.w"), None, 2, 1), LRELU), "d.r0")
+        r = q(F.leaky_relu(F.conv2d(r, qw(sn_weight(P, f"{p}.conv_r.2.weight"), "d.w"), None, 1, 1), LRELU), "d.r2")
+        s = q(F.avg_pool2d(out, 2), "d.pool")
         if a["cin"][i] != a["cout"][i]:
-            s = q(F.conv2d(s, qw(sn_weight(P, f"{p}.conv_s.weight")), P[f"{p}.conv_s.bias"]))
-        out = q(s + P[f"{p}.gamma"] * r)
+            s = q(F.conv2d(s, qw(sn_weight(P, f"{p}.conv_s.weight"), "d.w"), P[f"{p}.conv_s.bias"]), "d.sc")
+        out = q(s + P[f"{p}.gamma"] * r, "d.sum")
     return out
 
 
@@ -811,10 +852,10 @@ def cond_dnet(P, h: Hyper, feat, sent_embs):
         out = F.linear(out, sn_weight(P, "COND_DNET.proj_match.weight"), P["COND_DNET.proj_match.bias"])
     elif has_proj:
         sent_embs = F.linear(sent_embs, sn_weight(P, "COND_DNET.proj_match.weight"), P["COND_DNET.proj_match.bias"])
-    c = q(sent_embs).view(B, -1, 1, 1).repeat(1, 1, 4, 4)        # engine: the condition joins the bf16 feature map
+    c = q(sent_embs, "h.c").view(B, -1, 1, 1).repeat(1, 1, 4, 4)        # engine: the condition joins the bf16 feature map
     hc = torch.cat((feat, c), 1)
-    m = q(F.leaky_relu(F.conv2d(hc, qw(sn_weight(P, "COND_DNET.joint_conv.0.weight")), None, 1, 1), LRELU))
-    m = F.conv2d(m, qw(sn_weight(P, "COND_DNET.joint_conv.2.weight")))         # the logit itself leaves the engine in f32
+    m = q(F.leaky_relu(F.conv2d(hc, qw(sn_weight(P, "COND_DNET.joint_conv.0.weight"), "h.w"), None, 1, 1), LRELU), "h.m")
+    m = F.conv2d(m, qw(sn_weight(P, "COND_DNET.joint_conv.2.weight"), "h.w"))         # the logit itself leaves the engine in f32
     return [m, out, sent_embs]
 
 
