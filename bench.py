@@ -7,8 +7,17 @@
 A "step" is one full iteration of the reference loop body (train_gan.py:185-291: D step, optional MA-GP, G step,
 both Adam updates) on one synthetic COCO-shaped batch that is already resident in HBM.  One process per GPU;
 weak scaling (per-GPU batch fixed); value = images of all ranks / max-over-ranks time.  Rank 0 prints ONE JSON line
-carrying, besides the throughput, `roofline` (the dominant kernel family -- the MFMA implicit-GEMM convolution --
-timed per launch with HIP events on the launch stream) and `cpu_baseline` (the CPU oracle timed on this host).
+carrying, besides the throughput:
+  roofline      the dominant kernel (MFMA view), timed per launch with HIP events on the launch stream
+  roofline_hbm  the bandwidth-bound convolution kernels (algorithmic intensity below the chip's ridge): GB/s against 8 TB/s
+  cpu_baseline  the CPU oracle timed on this host's cores
+  parity        outside the timed region: one small iteration (64x64, batch 8, the real widths NCH=32, the reference's own
+                initialisation with block gammas 0.1 like the timed run) in the BENCHED precision mode against the f32 CPU oracle:
+                worst relative loss error and relative L2 error of the logits -- north_star's bar is 1e-3
+  alt_precision the same workload timed (and parity-checked) in the IEEE-half mode: the same kernels compiled for the 11-bit
+                format, same MFMA rate -- the mode whose losses stay inside 1e-3
+  dist          backend / world size / RCCL version the collectives ran on (`--force_dp`: the data-parallel path with its
+                graph seams and RCCL calls exercised at world size 1)
 """
 import argparse
 import json
@@ -28,6 +37,7 @@ STEP_GFLOP = {(64, False): 8.74, (128, False): 36.48, (256, False): 147.4,
               (64, True): 12.69, (128, True): 53.30, (256, True): 215.7}
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
 PEAK_F32_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0          # HBM3E spec (MI355X_MICROARCH.md; ~6300 measured with a float4 copy)
 
 
 def parse():
@@ -38,7 +48,12 @@ def parse():
     ap.add_argument("--imsize", type=int, default=256)
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (BASELINE configs 4/5: 256 per GPU)")
     ap.add_argument("--cfg", type=str, default="df_gan_damsm_nomagp.yml")
-    ap.add_argument("--precision", type=str, default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", type=str, default="bf16", choices=["bf16", "f16", "fp32"])
+    ap.add_argument("--force_dp", action="store_true",
+                    help="world size 1 only: create the RCCL process group anyway and run the data-parallel path (flat-bucket "
+                         "all-reduce, all-gather with --gather_negatives, graph seams) through it")
+    ap.add_argument("--no_parity", action="store_true")
+    ap.add_argument("--no_alt_precision", action="store_true")
     ap.add_argument("--gather_negatives", action="store_true", help="BASELINE config 5: all-gather contrastive negatives")
     ap.add_argument("--graph", type=int, default=-1, help="replay the iteration as a hipGraph (default: on for 1 GPU)")
     ap.add_argument("--gen", type=str, default="", help="variant: override GEN.ENCODER_NAME (e.g. CONCEPT_OUTATTN_GEN)")
@@ -104,6 +119,67 @@ def cpu_baseline(cfg, cfg_name, imsize, seconds_budget=15.0):
                 sample=f"{n} full G+D iterations of oracle/xmc_ref.py (PyTorch CPU fp32), {imsize}x{imsize}, batch {B}, {cfg_name}")
 
 
+def parity_leg(precision, cfg_name):
+    """One G+D iteration at 64x64, batch 8, NCH=32 in `precision` through the HIP kernels against the f32 CPU oracle on identical
+    inputs and parameters (the reference's initialisation, block gammas 0.1 as in the timed run).  The oracle is the checker
+    here, never the thing measured."""
+    import xmc_ref as X
+    from xmc_gan.config import gan
+    import xmc_gan.train_gan as tg
+    from xmc_gan_amd import ops
+    from xmc_gan_amd.optim import HipAdam
+    ops.set_precision(precision)
+    gan.reset_cfg()
+    gan.cfg_from_file(os.path.join(ROOT, "xmc_gan", "cfg", cfg_name))
+    cfg = gan.cfg
+    cfg.IMG.SIZE, cfg.TRAIN.BATCH_SIZE = 64, 8
+    h = X.Hyper.from_cfg(cfg)
+    PG, PD = X.ref_init_params(X.gen_shapes(h), 1, 0.1), X.ref_init_params(X.netd_shapes(h), 2, 0.1)
+    b = X.synth_batch(h, 8, seed=300, words_len=cfg.TEXT.MAX_LENGTH)
+    torch.set_num_threads(host_cores())
+    oG, oD = X.AdamState(h.g_lr, h.g_betas), X.AdamState(h.d_lr, h.d_betas)
+    ref = X.train_step({k: v.clone() for k, v in PG.items()}, {k: v.clone() for k, v in PD.items()}, oG, oD, h, b)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    netG = tg._GEN_ARCH[h.gen](cfg).to(dev)
+    netD = tg._DISC_ARCH["DF_DISC"](cfg, is_disc=True).to(dev)
+    netG.load_state_dict(PG, strict=True)
+    netD.load_state_dict(PD, strict=True)
+    with torch.no_grad():
+        ps = netG.proj_sent(b["sent_embs"].to(dev))
+        lr = netD.COND_DNET(netD(b["imgs"].to(dev)), sent_embs=ps)[0].float().cpu()
+        lf = netD.COND_DNET(netD(ref["fake"].to(dev)), sent_embs=ps)[0].float().cpu()
+    optG, optD = HipAdam(netG.parameters(), lr=h.g_lr, betas=h.g_betas), HipAdam(netD.parameters(), lr=h.d_lr, betas=h.d_betas)
+    o = tg.gan_iteration(netG, netD, optG, optD, *(b[k].to(dev) for k in ("imgs", "sent_embs", "words_embs", "mask", "noise")), {})
+    torch.cuda.synchronize()
+    losses = {k: abs(float(o[k]) - float(ref[k])) / max(abs(float(ref[k])), 1e-12) for k in o
+              if k != "fake" and k in ref and not torch.is_tensor(ref[k])}
+    rel = lambda x, y: float((x - y).norm() / y.norm())
+    worst = max(losses, key=losses.get)
+    return dict(mode={"bf16": "bf16", "f16": "f16", "fp32": "f32"}[precision], against="f32 CPU oracle (oracle/xmc_ref.py), same inputs and parameters",
+                workload=f"one G+D iteration, 64x64, batch 8, NCH=32, {cfg_name}, reference initialisation with block gammas 0.1",
+                loss_rel_vs_f32_oracle=round(losses[worst], 6), worst_loss=worst,
+                losses={k: round(v, 6) for k, v in losses.items()},
+                logit_rel={"real": round(rel(lr, ref["logit_real"]), 6), "fake_on_oracle_image": round(rel(lf, ref["logit_fake"]), 6)},
+                bar=1e-3, within_bar=bool(losses[worst] <= 1e-3))
+
+
+def alt_precision_leg(a):
+    """The timed workload once more in the IEEE-half mode (a child process: a fresh allocator, graph pool and library state)."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(a.steps), "--warmup", str(a.warmup),
+           "--imsize", str(a.imsize), "--batch", str(a.batch), "--cfg", a.cfg, "--precision", "f16", "--no_cpu_baseline",
+           "--no_parity", "--no_alt_precision", "--no_roofline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    if r.returncode != 0 or not line:
+        return dict(dtype="f16", error=(r.stderr or r.stdout)[-400:])
+    j = json.loads(line[-1])
+    return dict(dtype="f16", value=j["value"], unit=j["unit"], ms_per_step=j["ms_per_step"],
+                step_frac_of_bf16_peak=j["step_frac_of_bf16_peak"], losses_finite=j["config"]["losses_finite"],
+                note="same kernels compiled for IEEE half (libxmc_gan_hip_f16.so), loss scale 4096 on the backward passes")
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD `torch.distributed.run` (this process has
     not initialised the GPU and never does), relay the ranks' output, pass rank 0's JSON line through, and fail unless the
@@ -154,11 +230,23 @@ def main():
         local_rank %= max(ndev, 1)                       # gloo rehearsal: several ranks on one card
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or a.force_dp:
+        if world == 1:                                   # single-card rehearsal of the RCCL path: a one-rank group of our own
+            import socket
+            with socket.socket() as s_:
+                s_.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(s_.getsockname()[1]))
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
-            torch.distributed.init_process_group("nccl", device_id=dev)
+            torch.distributed.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
         else:
-            torch.distributed.init_process_group(backend)
+            torch.distributed.init_process_group(backend, rank=rank, world_size=world)
+        if a.force_dp:
+            from xmc_gan_amd import parallel
+            parallel.force_collectives(True)
+    dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
 
     from xmc_gan.config import gan
     import xmc_gan.train_gan as tg
@@ -212,17 +300,18 @@ def main():
             for i in range(3):                   # 2 eager warm-ups + the capture itself, outside the timed region
                 graphed(d0["imgs"], d0["sent"], d0["words"], d0["mask"], d0["noise"])
             torch.cuda.synchronize()
-        except Exception as e:                   # noqa: BLE001 -- any capture problem: every rank falls back together
+        except Exception as e:                   # noqa: BLE001
             import traceback
-            print(f"[bench rank {rank}] graph capture failed ({type(e).__name__}: {e}); running eager\n"
+            print(f"[bench rank {rank}] graph capture failed ({type(e).__name__}: {e})\n"
                   + "".join(traceback.format_exc().splitlines(True)[-12:]), file=sys.stderr)
+            if dist_on:
+                # A rank that threw mid-capture has issued fewer seam collectives than its peers; anything it sends now (a
+                # "did it work" flag included) would be matched against a peer's pending gradient all-reduce of another size and
+                # dtype -- undefined behaviour or a hang.  There is no safe in-band way to agree on a fallback: fail the job.
+                os._exit(3)
             ok = 0
-        if world > 1:
-            flag = torch.tensor([ok], device=dev, dtype=torch.int32)
-            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
-            ok = int(flag.item())
         if not ok:
-            graphed, use_graph = None, False
+            graphed, use_graph = None, False             # single process: packed-weight caches were invalidated by graph._capture
 
     def step(i, force_eager=False):
         d = data[i % nb]
@@ -249,15 +338,16 @@ def main():
         dt = t.item()
     finite = all(torch.isfinite(v).all().item() for k, v in last.items() if k != "fake")
 
-    roof = None
+    roof = roof_hbm = None
     if not a.no_roofline:
         # one more iteration (on EVERY rank: it contains the collectives) with each conv launch bracketed by HIP
         # events on the launch stream; rank 0 reports
         prof.enable()
         step(a.warmup + a.steps, force_eager=True)
         torch.cuda.synchronize()
-        roof = prof.summary(PEAK_BF16_TFLOPS if a.precision == "bf16" else PEAK_F32_TFLOPS,
-                            pmc_traffic_lookup(S, B, a.cfg, a.precision))
+        peak = PEAK_F32_TFLOPS if a.precision == "fp32" else PEAK_BF16_TFLOPS      # f16 MFMA = the bf16 rate
+        roof = prof.summary(peak, pmc_traffic_lookup(S, B, a.cfg, a.precision))
+        roof_hbm = prof.summary_hbm(PEAK_HBM_GBS, 1e3 * peak / PEAK_HBM_GBS)
         if os.environ.get("XMC_PROF_SHAPES") and rank == 0:
             for fam, tag, n, ms, tf in prof.by_shape()[:max(60, int(os.environ["XMC_PROF_SHAPES"]))]:
                 print(f"{fam:52s} {tag:58s} n={n:3d} {ms:8.3f} ms {tf:8.1f} TF/s", file=sys.stderr)
@@ -271,7 +361,7 @@ def main():
         gf = STEP_GFLOP.get((S, magp))
         out = dict(metric="images/sec per G+D step", value=round(imgs_s, 2), unit="images/s", n_gpus=world, steps=a.steps,
                    warmup=a.warmup, ms_per_step=round(1e3 * dt / a.steps, 3), higher_is_better=True, scaling="weak",
-                   vs_baseline=None, dtype=a.precision if a.precision == "bf16" else "f32", data="synthetic",
+                   vs_baseline=None, dtype={"bf16": "bf16", "f16": "f16", "fp32": "f32"}[a.precision], data="synthetic",
                    config=dict(workload=f"{S}x{S} COCO-shaped synthetic batch, {B} images per GPU, one full G+D iteration "
                                         f"(D step{' + MA-GP' if magp else ''} + G step + Adam x{3 if magp else 2}), {a.cfg}"
                                         + (" with DISC.SPEC_NORM=True" if a.spec_norm else "")
@@ -283,10 +373,28 @@ def main():
                    step_frac_of_bf16_peak=None if gf is None else round(imgs_s * gf / 1e3 / (PEAK_BF16_TFLOPS * world), 4))
         if roof is not None:
             out["roofline"] = roof
+            out["roofline_hbm"] = roof_hbm
+        out["dist"] = dict(backend=(torch.distributed.get_backend() if dist_on else None), world_size=world,
+                           process_group=bool(dist_on), forced_at_world_1=bool(a.force_dp),
+                           rccl_version=(".".join(map(str, torch.cuda.nccl.version())) if dist_on and backend == "nccl" else None),
+                           collectives_per_iteration=(graphed.seams_per_iteration() if graphed is not None else None))
         if not a.no_cpu_baseline and world == 1:       # the CPU leg is timed on rank 0 of the single-GPU run only
             out["cpu_baseline"] = cpu_baseline(cfg, a.cfg, S)
+    # free the timed run's networks, graphs and pools before the side legs
+    del graphed, netG, netD, optG, optD, data, last
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    if rank == 0 and world == 1 and not a.force_dp:
+        if not a.no_alt_precision and a.precision == "bf16" and not a.gen and not a.spec_norm:
+            out["alt_precision"] = alt_precision_leg(a)
+        if not a.no_parity and not a.gen and not a.spec_norm:
+            out["parity"] = parity_leg(a.precision, a.cfg)
+            if "alt_precision" in out:
+                out["alt_precision"]["parity"] = parity_leg("f16", a.cfg)
+    if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on:
         torch.distributed.destroy_process_group()
 
 

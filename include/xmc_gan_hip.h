@@ -24,9 +24,14 @@
 extern "C" {
 #endif
 
-#define XMC_ABI_VERSION 1
+/* 2: XmcConvDesc gained dst2 / dst_pool / round_act / groups, alpha applies only with alpha_dev, return codes are
+ *    0 / XMC_E* / -(1000 + hipError_t); xmc_half_format() added.  lib.py refuses a library of another version. */
+#define XMC_ABI_VERSION 2
 
+/* XMC_BF16 names the 16-bit storage / MFMA-operand format THIS BUILD of the library was compiled for: bf16 in
+ * libxmc_gan_hip.so, IEEE half in libxmc_gan_hip_f16.so (same sources, same entry points; xmc_half_format()). */
 enum { XMC_BF16 = 0, XMC_F32 = 1 };
+enum { XMC_HALF_IS_BF16 = 0, XMC_HALF_IS_F16 = 1 };
 enum { XMC_ACT_NONE = 0, XMC_ACT_LRELU = 1, XMC_ACT_TANH = 2, XMC_ACT_RELU = 3 };
 enum { XMC_EINVAL = -1, XMC_EALIGN = -2, XMC_ESHAPE = -3 };
 
@@ -97,6 +102,8 @@ typedef struct XmcConvDesc {
 } XmcConvDesc;
 
 int xmc_abi_version(void);
+/* XMC_HALF_IS_BF16 or XMC_HALF_IS_F16: what a tensor of dtype code XMC_BF16 holds in this build */
+int xmc_half_format(void);
 /* Name (template instantiation, as rocprof prints it) of the convolution kernel the calling thread dispatched last;
  * "" before the first one.  Measurement aid for bench.py's roofline; not part of the reference's surface. */
 const char* xmc_last_kernel(void);
@@ -324,6 +331,8 @@ int xmc_cast(const void* x, void* y, int64_t n, int src_dtype, int dst_dtype, vo
  * nchunks (tensor index, chunk index) int32 pairs, one per block, chunk = xmc_adam_chunk_elems() elements.
  * `step` is a device counter per tensor holding the number of updates already applied; the launch uses
  * step+1 for the bias corrections and then increments it, so the whole call is hipGraph-replayable.
+ * `grad_scale` multiplies every gradient element as it is read (1 = torch.optim.Adam exactly; the IEEE-half mode
+ * differentiates LOSS_SCALE * loss and passes 1 / LOSS_SCALE here).
  */
 typedef struct XmcAdamEntry {
     float* param;
@@ -335,7 +344,7 @@ typedef struct XmcAdamEntry {
 } XmcAdamEntry;
 int xmc_adam_chunk_elems(void);
 int xmc_adam_step(const XmcAdamEntry* table_dev, int ntensors, const int32_t* chunks_dev, int nchunks,
-                  float lr, float beta1, float beta2, float eps, void* stream);
+                  float lr, float beta1, float beta2, float eps, float grad_scale, void* stream);
 
 /* ---- matching-aware gradient penalty, train_gan.py:241-247:  2 * mean_b ||[d logit / d img_b, d logit / d sent_b]||_2^6 ---------
  * ss[b] += sum_k x[b][k]^2 over an f32 block [B, cols] (cols % 4 == 0; ss zeroed by the caller, blocks accumulate);

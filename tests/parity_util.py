@@ -55,7 +55,8 @@ class GradTap:
         orig = opt.step
 
         def step(*a, **k):
-            self.records.append({n: (None if p.grad is None else p.grad.detach().float().cpu().clone()) for n, p in self.named})
+            gs = float(k.get("grad_scale", 1.0))      # IEEE-half mode: the backward ran on loss_scale * loss
+            self.records.append({n: (None if p.grad is None else p.grad.detach().float().cpu().clone() * gs) for n, p in self.named})
             return orig(*a, **k)
 
         opt.step = step
@@ -75,9 +76,10 @@ def run_product_steps(h, PG, PD, batches, eps=1e-8):
     return netG, netD, outs, tapG, tapD
 
 
-def run_oracle_steps(h, PG, PD, batches, eps=1e-8, quant=False):
-    """`quant`: the oracle's quantisation-aware mode (bf16 rounding at the engine's storage points, f32 arithmetic)."""
-    with X.quant(quant):
+def run_oracle_steps(h, PG, PD, batches, eps=1e-8, quant=False, fmt=None):
+    """`quant`: the oracle's quantisation-aware mode (rounding to the 16-bit format `fmt`, default bf16, at the engine's
+    storage points; f32 arithmetic)."""
+    with X.quant(quant, fmt=fmt or torch.bfloat16):
         return _run_oracle_steps(h, PG, PD, batches, eps)
 
 

@@ -15,16 +15,19 @@ import xmc_ref as X
 from golden_util import CFG_DIR, ROOT
 
 
-def test_library_loads_and_exports_every_declared_symbol():
+@pytest.mark.parametrize("variant", ["bf16", "f16"])
+def test_library_loads_and_exports_every_declared_symbol(variant):
+    """both builds of the kernels (bf16 and IEEE-half storage: the same sources, common.h) export the whole C ABI"""
     import xmc_gan_amd.lib as L
-    lib = L.load()
+    lib = L.load(variant)
+    assert lib.xmc_half_format() == (0 if variant == "bf16" else 1)
     hdr = open(os.path.join(ROOT, "include", "xmc_gan_hip.h")).read()
     declared = set(re.findall(r"\b(xmc_[a-z0-9_]+)\s*\(", hdr))
     assert declared, "no declarations parsed"
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/xmc_gan_hip.h but not exported"
     assert set(L.EXPORTS) == declared
-    assert lib.xmc_abi_version() == 1
+    assert lib.xmc_abi_version() == L.ABI_VERSION == 2
     # argument validation happens before any launch, so it is safe without a GPU
     d = L.ConvDesc()
     assert lib.xmc_conv_igemm(ctypes.byref(d), None) == -1
@@ -47,7 +50,7 @@ def test_library_loads_and_exports_every_declared_symbol():
 
 def test_missing_library_fails_loudly(monkeypatch):
     import xmc_gan_amd.lib as L
-    monkeypatch.setattr(L, "_lib", None)
+    monkeypatch.setattr(L, "_libs", {})
     monkeypatch.setattr(L, "LIB_PATH", "/nonexistent/libxmc_gan_hip.so")
     with pytest.raises(RuntimeError, match="no CPU/PyTorch fallback"):
         L.load()

@@ -23,10 +23,12 @@ MODES = ["fp32", "bf16"]
 
 def rt(t, mode):
     """round-trip through the activation dtype (so CPU reference and kernel see identical operands)."""
-    return t.to(torch.bfloat16).float() if mode == "bf16" else t
+    return t.to(torch.bfloat16).float() if mode == "bf16" else t.to(torch.float16).float() if mode == "f16" else t
 
 
 def tol(mode, scale=1.0):
+    if mode == "f16":        # the IEEE-half build of the same kernels: 2^-11 relative to the output scale
+        return dict(rtol=3e-3, atol=3e-3 * scale)
     return dict(rtol=2e-2, atol=2e-2 * scale) if mode == "bf16" else dict(rtol=2e-4, atol=2e-4 * scale)
 
 
@@ -101,7 +103,7 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("mode", MODES + ["f16"])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_fwd_dgrad_wgrad(case, mode):
     cin, cout, k, s, p, H, N = case

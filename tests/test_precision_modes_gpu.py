@@ -1,0 +1,93 @@
+"""The three precision modes of the engine against north_star's bar -- "logits/loss within 1e-3 rel of the CPU reference".
+
+  fp32  exact-f32 MFMA, f32 storage            meets it (tests/test_models_gpu.py, measured ~1e-6); 1/16 of the bf16 MFMA rate
+  bf16  bf16 storage + MFMA operands           cannot: the ladder (tests/diag/quant_ladder.py) shows the error is
+                                               the 8-bit significand of EVERY convolution operand, not a few stored tensors
+  f16   IEEE-half storage + MFMA operands      the same kernels compiled for the 11-bit format (libxmc_gan_hip_f16.so), same
+                                               MFMA rate: THIS is the mode that is both fast and inside 1e-3 on the losses
+
+Checked here at the real widths (NCH=32, 64x64, batch 8: BASELINE configuration 1/2's network) on two parameterisations:
+the parity tests' synthetic one (block gammas 0.25-0.75: worst case) and the reference's own start of training (Kaiming weights,
+zero biases, block gammas 0.1 as bench.py sets them)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    import xmc_ref as X
+    from xmc_gan_amd import ops
+    from parity_util import (DEV, build_product, compare_grads, compare_losses, rel_err, run_oracle_steps, run_product_steps,
+                             setup_cfg)
+
+
+def _params(h, kind, seed):
+    if kind == "synth":
+        return X.synth_params(X.gen_shapes(h), 5 + seed), X.synth_params(X.netd_shapes(h), 6 + seed)
+    return X.ref_init_params(X.gen_shapes(h), 5 + seed, 0.1), X.ref_init_params(X.netd_shapes(h), 6 + seed, 0.1)
+
+
+def _logits(h, PG, PD, b):
+    netG, netD, _, _ = build_product(h, PG, PD)
+    with torch.no_grad():
+        ps = netG.proj_sent(b["sent_embs"].to(DEV))
+        return netD.COND_DNET(netD(b["imgs"].to(DEV)), sent_embs=ps)[0].float().cpu()
+
+
+@pytest.fixture(autouse=True)
+def _restore_precision():
+    yield
+    ops.set_precision("bf16")
+
+
+@pytest.mark.parametrize("kind", ["synth", "ref"])
+@pytest.mark.parametrize("yml", ["df_gan_damsm_nomagp.yml", "df_gan_damsm.yml"])
+def test_f16_mode_losses_within_1e_3_of_f32_reference(yml, kind):
+    """first G+D iteration in the IEEE-half mode vs the plain f32 oracle: every loss scalar within 1e-3 relative (north_star),
+    the real-pair logit vector within 2e-3 relative L2; against the oracle rounding to half where the engine stores a tensor
+    (kernel error proper) 5e-4."""
+    ops.set_precision("f16")
+    cfg, h = setup_cfg(yml)
+    PG, PD = _params(h, kind, 0)
+    batches = [X.synth_batch(h, 8, seed=200, words_len=cfg.TEXT.MAX_LENGTH)]
+    _, _, o = run_oracle_steps(h, PG, PD, batches, eps=1e-3)
+    _, _, oq = run_oracle_steps(h, PG, PD, batches, eps=1e-3, quant=True, fmt=torch.float16)
+    _, _, p, tapG, tapD = run_product_steps(h, PG, PD, batches, eps=1e-3)
+    wl = compare_losses(p[0], o[0], 1e-3, 1e-4)
+    wq = compare_losses(p[0], oq[0], 5e-4, 1e-4)
+    lg = rel_err(_logits(h, PG, PD, batches[0]), o[0]["logit_real"])
+    assert lg <= 2e-3, lg
+    # gradients: against the half-rounding oracle (same storage points), all tensors of a backward as one vector
+    gd = compare_grads(tapD.records[0], oq[0]["grads_D"], 0.05, "f16 D ", 2e-2, 1e-2)
+    gg = compare_grads(tapG.records[0], oq[0]["grads_G"], 0.05, "f16 G ", 2e-2, 2e-2 if h.magp else 1e-2)
+    print(f"\n[f16 {yml} {kind}] losses vs f32 oracle {wl:.2e}, vs half-rounding oracle {wq:.2e}; logits vs f32 {lg:.2e}; "
+          f"grads vs half-rounding oracle D {gd:.2e} G {gg:.2e}")
+
+
+@pytest.mark.parametrize("kind", ["synth", "ref"])
+def test_bf16_mode_loss_error_is_the_format_not_the_kernels(kind):
+    """the benched bf16 mode on the same inputs: inside 1e-2 of the bf16-rounding oracle (kernels right), NOT inside 1e-3 of the
+    f32 oracle (the format's floor; recorded, with the ladder) -- the figure bench.py prints as `parity`."""
+    ops.set_precision("bf16")
+    cfg, h = setup_cfg("df_gan_damsm_nomagp.yml")
+    PG, PD = _params(h, kind, 0)
+    batches = [X.synth_batch(h, 8, seed=200, words_len=cfg.TEXT.MAX_LENGTH)]
+    _, _, o = run_oracle_steps(h, PG, PD, batches, eps=1e-3)
+    _, _, oq = run_oracle_steps(h, PG, PD, batches, eps=1e-3, quant=True)
+    _, _, p, _, _ = run_product_steps(h, PG, PD, batches, eps=1e-3)
+    wq = compare_losses(p[0], oq[0], 1e-2, 2e-3)
+    wl = compare_losses(p[0], o[0], 5e-2, 1e-2)
+    print(f"\n[bf16 {kind}] losses vs f32 oracle {wl:.2e} (format floor), vs bf16-rounding oracle {wq:.2e} (kernels)")
+
+
+def test_f16_build_is_a_separate_library_with_the_same_abi():
+    from xmc_gan_amd import lib as L
+    a, b = L.load("bf16"), L.load("f16")
+    assert a is not b and a.xmc_half_format() == 0 and b.xmc_half_format() == 1
+    assert a.xmc_abi_version() == b.xmc_abi_version() == L.ABI_VERSION
+    ops.set_precision("f16")
+    assert ops.act_dtype() == torch.float16 and ops.loss_scale() > 1 and ops.loss_scale("gp") == 1.0
+    with pytest.raises(TypeError):
+        ops._code(torch.bfloat16)
+    ops.set_precision("bf16")
+    assert ops.act_dtype() == torch.bfloat16 and ops.loss_scale() == 1.0

@@ -223,17 +223,17 @@ __global__ void gn_bwd_apply_kernel(const void* x, const void* dy, const float* 
 // (pk key channels, px value channels: 8 or 16 bytes) with one vector access per pixel
 template <int DT, int P> struct PVec;            // P consecutive channels of one pixel <-> floats
 template <int P> struct PVec<XMC_BF16, P> {
-    typedef __attribute__((ext_vector_type(P))) __bf16 vt;
+    typedef __attribute__((ext_vector_type(P))) xmc_h16 vt;
     __device__ static __forceinline__ void load(const void* base, size_t elem, float (&v)[8]) {
-        vt t = *reinterpret_cast<const vt*>(reinterpret_cast<const __bf16*>(base) + elem);
+        vt t = *reinterpret_cast<const vt*>(reinterpret_cast<const xmc_h16*>(base) + elem);
 #pragma unroll
         for (int k = 0; k < P; ++k) v[k] = (float)t[k];
     }
     __device__ static __forceinline__ void store(void* base, size_t elem, const float (&v)[8]) {
         vt t;
 #pragma unroll
-        for (int k = 0; k < P; ++k) t[k] = (__bf16)v[k];
-        *reinterpret_cast<vt*>(reinterpret_cast<__bf16*>(base) + elem) = t;
+        for (int k = 0; k < P; ++k) t[k] = (xmc_h16)v[k];
+        *reinterpret_cast<vt*>(reinterpret_cast<xmc_h16*>(base) + elem) = t;
     }
 };
 template <int P> struct PVec<XMC_F32, P> {

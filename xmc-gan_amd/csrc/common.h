@@ -5,9 +5,27 @@
 
 #include "xmc_gan_hip.h"
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+// The 16-bit storage / MFMA-operand format is a build parameter of the library (one code path, two builds of these sources):
+//   libxmc_gan_hip.so      bf16    (8 significant bits; the format BASELINE.json's configurations name)
+//   libxmc_gan_hip_f16.so  IEEE half (11 significant bits, same MFMA rate; `-DXMC_H16_IS_F16`): the precision mode whose
+//                          losses stay within 1e-3 of the f32 reference end to end
+// XMC_BF16 in the C ABI means "the 16-bit format of this build" (xmc_half_format() reports which).  The typedef names below
+// keep their historical bf16 spelling.
+#ifdef XMC_H16_IS_F16
+typedef _Float16 xmc_h16;
+#define XMC_MFMA_16x16x32 __builtin_amdgcn_mfma_f32_16x16x32_f16
+#define XMC_MFMA_32x32x16 __builtin_amdgcn_mfma_f32_32x32x16_f16
+#define XMC_HALF_FORMAT 1
+#else
+typedef __bf16 xmc_h16;
+#define XMC_MFMA_16x16x32 __builtin_amdgcn_mfma_f32_16x16x32_bf16
+#define XMC_MFMA_32x32x16 __builtin_amdgcn_mfma_f32_32x32x16_bf16
+#define XMC_HALF_FORMAT 0
+#endif
+typedef __attribute__((ext_vector_type(8))) xmc_h16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) xmc_h16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((__vector_size__(4 * sizeof(short)))) short xmc_s16x4;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
@@ -43,6 +61,11 @@ bool xmc_debug_off(const char* token);
         }                                                                                                                      \
     } while (0)
 
+// ds_read_b64_tr_b16 (transposing LDS read of four 16-bit elements), format-agnostic through the i16 form of the builtin
+__device__ __forceinline__ bf16x4 xmc_ds_read_tr16(const void* p) {
+    return __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) xmc_s16x4*)(p)));
+}
+
 __device__ __forceinline__ float lrelu_f(float v) { return v > 0.f ? v : XMC_LRELU * v; }
 // tanh for results that are stored as bf16: 1 - 2 / (exp(2x) + 1) on the hardware exp2 / rcp (absolute error ~1e-7, far below
 // half a bf16 ulp of the result; libm's tanhf costs ~0.7 ms on the generator's 256x256 output layer).  The f32 parity mode
@@ -65,7 +88,7 @@ template <> struct Vec8<XMC_BF16> {
     __device__ static __forceinline__ void store(void* p, size_t idx8, const float (&v)[8]) {
         bf16x8 t;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) t[i] = (__bf16)v[i];
+        for (int i = 0; i < 8; ++i) t[i] = (xmc_h16)v[i];
         reinterpret_cast<bf16x8*>(p)[idx8] = t;
     }
 };
@@ -104,7 +127,7 @@ __device__ __forceinline__ void epilogue_tail(const XmcConvDesc& d, size_t idx8,
     if (d.dst2) Vec8<ODT>::store(d.dst2, idx8, v);
     if (ODT == XMC_BF16 && (d.dst2 || d.round_act)) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = (float)(__bf16)v[k];
+        for (int k = 0; k < 8; ++k) v[k] = (float)(xmc_h16)v[k];
     }
     if (d.alpha_dev) {
 #pragma unroll

@@ -73,19 +73,19 @@ __global__ __launch_bounds__(512) void gconv_kernel(const XmcConvDesc d, int nun
             for (int j = 0; j < NMF; ++j) {
                 const u32x4 z = {0, 0, 0, 0};
                 const u32x4 v = ok[t][j] ? xb[t][j] : z;
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[j], __builtin_bit_cast(bf16x8, v), acc, 0, 0, 0);
+                acc = XMC_MFMA_16x16x32(wa[j], __builtin_bit_cast(bf16x8, v), acc, 0, 0, 0);
             }
             // D[row = output channel kb*4 + i][col = pixel]
             const int p = (chunk * TI + t) * 16 + col;
             if (p < total) {
                 const size_t e = (size_t)p * d.CD + cb * 16 + kb * 4;
                 if (d.res) {                                   // residual in the destination layout (another gradient of the same tensor)
-                    const bf16x4 r = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(d.res) + e);
+                    const bf16x4 r = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const xmc_h16*>(d.res) + e);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) acc[i] += (float)r[i];
                 }
-                bf16x4 o = {(__bf16)acc[0], (__bf16)acc[1], (__bf16)acc[2], (__bf16)acc[3]};
-                *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(d.dst) + e) = o;
+                bf16x4 o = {(xmc_h16)acc[0], (xmc_h16)acc[1], (xmc_h16)acc[2], (xmc_h16)acc[3]};
+                *reinterpret_cast<bf16x4*>(reinterpret_cast<xmc_h16*>(d.dst) + e) = o;
             }
         }
     }
@@ -160,16 +160,16 @@ __global__ __launch_bounds__(NW * 64, 2) void gconv_patch_kernel(const XmcConvDe
 #pragma unroll
             for (int j = 0; j < NMF; ++j) {
                 const bf16x8 b = *reinterpret_cast<const bf16x8*>(smem + r * GP_W * pstr + loff[j]);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[j], b, acc, 0, 0, 0);
+                acc = XMC_MFMA_16x16x32(wa[j], b, acc, 0, 0, 0);
             }
             const size_t e = (((size_t)n * d.DH + y0 + r) * d.DW + x0 + col) * d.CD + cb * 16 + kb * 4;
             if (d.res) {
-                const bf16x4 rr = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(d.res) + e);
+                const bf16x4 rr = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const xmc_h16*>(d.res) + e);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) acc[i] += (float)rr[i];
             }
-            bf16x4 o = {(__bf16)acc[0], (__bf16)acc[1], (__bf16)acc[2], (__bf16)acc[3]};
-            *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(d.dst) + e) = o;
+            bf16x4 o = {(xmc_h16)acc[0], (xmc_h16)acc[1], (xmc_h16)acc[2], (xmc_h16)acc[3]};
+            *reinterpret_cast<bf16x4*>(reinterpret_cast<xmc_h16*>(d.dst) + e) = o;
         }
     }
 }

@@ -30,7 +30,7 @@ namespace {
 template <int DT> struct Mma;
 template <> struct Mma<XMC_BF16> {
     __device__ static __forceinline__ f32x4 run(u32x4 a, u32x4 b, f32x4 c) {
-        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+        return XMC_MFMA_16x16x32(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
     }
 };
 template <> struct Mma<XMC_F32> {

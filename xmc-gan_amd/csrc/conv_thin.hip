@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void thin_in_kernel(const XmcConvDesc d, const
                     const u32x4 pf = *reinterpret_cast<const u32x4*>(patch + pbase[i] + toff[ks]);
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[ks][j]), __builtin_bit_cast(bf16x8, pf), acc[j], 0, 0, 0);
+                        acc[j] = XMC_MFMA_16x16x32(__builtin_bit_cast(bf16x8, wf[ks][j]), __builtin_bit_cast(bf16x8, pf), acc[j], 0, 0, 0);
                 }
 #pragma unroll
                 for (int u = 0; u < UPL; ++u) {
@@ -131,8 +131,8 @@ __global__ __launch_bounds__(256) void thin_in_kernel(const XmcConvDesc d, const
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const float x0 = acc[2 * u][q] + bias8[u][q], x1 = acc[2 * u + 1][q] + bias8[u][4 + q];
-                        o[q] = (__bf16)fmaxf(x0, x0 * slope);
-                        o[4 + q] = (__bf16)fmaxf(x1, x1 * slope);
+                        o[q] = (xmc_h16)fmaxf(x0, x0 * slope);
+                        o[4 + q] = (xmc_h16)fmaxf(x1, x1 * slope);
                     }
                     dst8[dbase + eoff[i] + u] = o;
 #pragma unroll
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void thin_in_kernel(const XmcConvDesc d, const
                     for (int q = 0; q < 8; ++q) {
                         float sm = fin[0][u][q] + fin[1][u][q];
                         sm += __shfl_xor(sm, 1, 64);
-                        o[q] = (__bf16)(0.25f * sm);
+                        o[q] = (xmc_h16)(0.25f * sm);
                     }
                     if ((fr & 1) == 0) pool8[((img * (d.DH >> 1) + prow) * (d.DW >> 1) + pcol) * cd8 + fc * UPL + u] = o;
                 }
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void pw1x1_kernel(const XmcConvDesc d, int ngr
             for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[ks][j]), __builtin_bit_cast(bf16x8, pf[r][ks]), acc[j], 0, 0, 0);
+                    acc[j] = XMC_MFMA_16x16x32(__builtin_bit_cast(bf16x8, wf[ks][j]), __builtin_bit_cast(bf16x8, pf[r][ks]), acc[j], 0, 0, 0);
             const size_t pix = (size_t)(g0 + r) * 16 + fr;
 #pragma unroll
             for (int u = 0; u < TN / 2; ++u) {
@@ -213,8 +213,8 @@ __global__ __launch_bounds__(256) void pw1x1_kernel(const XmcConvDesc d, int ngr
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float x0 = acc[2 * u][q] + bias8[u][q], x1 = acc[2 * u + 1][q] + bias8[u][4 + q];
-                    o[q] = (__bf16)fmaxf(x0, x0 * slope);
-                    o[4 + q] = (__bf16)fmaxf(x1, x1 * slope);
+                    o[q] = (xmc_h16)fmaxf(x0, x0 * slope);
+                    o[4 + q] = (xmc_h16)fmaxf(x1, x1 * slope);
                 }
                 dst8[pix * cd8 + u * 4 + fc] = o;
             }
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256, 2) void thin_out_kernel(const XmcConvDesc d, i
 #pragma unroll
                 for (int c = 0; c < KC; ++c) {
                     const bf16x8 b = *reinterpret_cast<const bf16x8*>(smem + r * TO_PW * PSTR + loff[t] + c * 64);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[t * KC + c], b, acc, 0, 0, 0);
+                    acc = XMC_MFMA_16x16x32(wa[t * KC + c], b, acc, 0, 0, 0);
                 }
             if (kb < 2) {                                  // D[row = output channel kb*4 + i][col = pixel]; 8 channels stored
                 bf16x4 o;
@@ -309,10 +309,10 @@ __global__ __launch_bounds__(256, 2) void thin_out_kernel(const XmcConvDesc d, i
                     float v = acc[i] + bias4[i];
                     if (d.act == XMC_ACT_TANH) v = tanh_fast(v);
                     else if (d.act == XMC_ACT_LRELU) v = lrelu_f(v);
-                    o[i] = (__bf16)v;
+                    o[i] = (xmc_h16)v;
                 }
                 const size_t p = ((size_t)n * d.DH + y0 + r) * d.DW + x0 + col;
-                *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(d.dst) + p * 8 + kb * 4) = o;
+                *reinterpret_cast<bf16x4*>(reinterpret_cast<xmc_h16*>(d.dst) + p * 8 + kb * 4) = o;
             }
         }
     }

@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void tile_kernel(const XmcConvDesc d, const Ti
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[i]),
+                        acc[i][j] = XMC_MFMA_16x16x32(__builtin_bit_cast(bf16x8, af[i]),
                                                                              __builtin_bit_cast(bf16x8, bf[j]), acc[i][j], 0, 0, 0);
             }
             if (more) {
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
 #pragma unroll
                         for (int m = g * M / G; m < (g + 1) * M / G; ++m) {
                             const int pb = m % 2, c = m / 2;
-                            acc[pb][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fr_[cur][2 + c]),
+                            acc[pb][c] = XMC_MFMA_32x32x16(__builtin_bit_cast(bf16x8, fr_[cur][2 + c]),
                                                                                   __builtin_bit_cast(bf16x8, fr_[cur][pb]), acc[pb][c], 0, 0, 0);
                         }
                         __builtin_amdgcn_sched_barrier(0);
@@ -469,7 +469,7 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
                             if (d.dst2 || d.round_act) {
                                 bf16x8 o2;
 #pragma unroll
-                                for (int r = 0; r < 8; ++r) { o2[r] = (__bf16)v[r]; v[r] = (float)o2[r]; }
+                                for (int r = 0; r < 8; ++r) { o2[r] = (xmc_h16)v[r]; v[r] = (float)o2[r]; }
                                 if (d.dst2) reinterpret_cast<bf16x8*>(d.dst2)[idx8] = o2;
                             }
                             if (d.alpha_dev) {
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
                             }
                             bf16x8 o;
 #pragma unroll
-                            for (int r = 0; r < 8; ++r) { o[r] = (__bf16)v[r]; fin[pb][v2][r] = (float)o[r]; }
+                            for (int r = 0; r < 8; ++r) { o[r] = (xmc_h16)v[r]; fin[pb][v2][r] = (float)o[r]; }
                             dst8[idx8] = o;
                         }
                     if (MC == 1 && d.dst_pool) {
@@ -502,7 +502,7 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
                                 for (int r = 0; r < 8; ++r) {
                                     float sm = fin[0][v2][r] + fin[1][v2][r];
                                     sm += __shfl_xor(sm, 1, 64);
-                                    o[r] = (__bf16)(0.25f * sm);
+                                    o[r] = (xmc_h16)(0.25f * sm);
                                 }
                                 if ((l32 & 1) == 0)
                                     pool8[((img * (d.DH >> 1) + ((a0 + pty[0]) >> 1)) * (d.DW >> 1) + ((b0 + ptx[0]) >> 1)) * cd8 + (n0 >> 3) + ub + v2] = o;
@@ -515,7 +515,7 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
                                         float sm = fin[pb][v2][r];
                                         sm += __shfl_xor(sm, 16, 64);
                                         sm += __shfl_xor(sm, 1, 64);
-                                        o[r] = (__bf16)(0.25f * sm);
+                                        o[r] = (xmc_h16)(0.25f * sm);
                                     }
                                     if ((l32 & 17) == 0)
                                         pool8[((img * (d.DH >> 1) + ((a0 + pty[pb]) >> 1)) * (d.DW >> 1) + ((b0 + ptx[pb]) >> 1)) * cd8 + (n0 >> 3) + ub + v2] = o;
@@ -584,7 +584,7 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[j]),
+                        acc[i][j] = XMC_MFMA_16x16x32(__builtin_bit_cast(bf16x8, w[j]),
                                                                              __builtin_bit_cast(bf16x8, p[i]), acc[i][j], 0, 0, 0);
             };
             if constexpr (NTAPS > 0) {
@@ -612,7 +612,7 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
 #pragma unroll
                         for (int m = g * M / G; m < (g + 1) * M / G; ++m) {
                             const int mi = m % TM, mj = m / TM;
-                            acc[mi][mj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fr_[cur][TM + mj]),
+                            acc[mi][mj] = XMC_MFMA_16x16x32(__builtin_bit_cast(bf16x8, fr_[cur][TM + mj]),
                                                                                    __builtin_bit_cast(bf16x8, fr_[cur][mi]), acc[mi][mj], 0, 0, 0);
                         }
                         __builtin_amdgcn_sched_barrier(0);
@@ -645,20 +645,20 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
                                 const float x0 = acc[i][2 * u][q] + bias8[u][q], x1 = acc[i][2 * u + 1][q] + bias8[u][4 + q];
-                                o[q] = (__bf16)fmaxf(x0, x0 * slope);
-                                o[4 + q] = (__bf16)fmaxf(x1, x1 * slope);
+                                o[q] = (xmc_h16)fmaxf(x0, x0 * slope);
+                                o[4 + q] = (xmc_h16)fmaxf(x1, x1 * slope);
                             }
                         } else if (do_tanh) {     // generator output layer (df_gan.py:88-90)
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
-                                o[q] = (__bf16)tanh_fast(acc[i][2 * u][q] + bias8[u][q]);
-                                o[4 + q] = (__bf16)tanh_fast(acc[i][2 * u + 1][q] + bias8[u][4 + q]);
+                                o[q] = (xmc_h16)tanh_fast(acc[i][2 * u][q] + bias8[u][q]);
+                                o[4 + q] = (xmc_h16)tanh_fast(acc[i][2 * u + 1][q] + bias8[u][4 + q]);
                             }
                         } else {
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
-                                o[q] = (__bf16)(acc[i][2 * u][q] + bias8[u][q]);
-                                o[4 + q] = (__bf16)(acc[i][2 * u + 1][q] + bias8[u][4 + q]);
+                                o[q] = (xmc_h16)(acc[i][2 * u][q] + bias8[u][q]);
+                                o[4 + q] = (xmc_h16)(acc[i][2 * u + 1][q] + bias8[u][4 + q]);
                             }
                         }
                         dst8[eoff[i] + u * 4] = o;
@@ -707,7 +707,7 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
                             if (d.dst2 || d.round_act) {
                                 bf16x8 o2;
 #pragma unroll
-                                for (int q = 0; q < 8; ++q) { o2[q] = (__bf16)v[q]; v[q] = (float)o2[q]; }
+                                for (int q = 0; q < 8; ++q) { o2[q] = (xmc_h16)v[q]; v[q] = (float)o2[q]; }
                                 if (d.dst2) reinterpret_cast<bf16x8*>(d.dst2)[idx8] = o2;
                             }
                             if (d.alpha_dev) {
@@ -725,7 +725,7 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
                             }
                             bf16x8 o;
 #pragma unroll
-                            for (int q = 0; q < 8; ++q) { o[q] = (__bf16)v[q]; fin[i][q] = (float)o[q]; }
+                            for (int q = 0; q < 8; ++q) { o[q] = (xmc_h16)v[q]; fin[i][q] = (float)o[q]; }
                             dst8[idx8] = o;
                         } else {
                             epilogue_tail<XMC_F32>(d, idx8, rix[i], v, alpha);
@@ -747,7 +747,7 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
                             for (int q = 0; q < 8; ++q) {
                                 float sm = t.log2TW == 5 ? fin[pr][q] + fin[(pr + 2) % TM][q] : fin[(2 * pr) % TM][q] + fin[(2 * pr + 1) % TM][q];
                                 sm += __shfl_xor(sm, 1, 64);
-                                o[q] = (__bf16)(0.25f * sm);
+                                o[q] = (xmc_h16)(0.25f * sm);
                             }
                             if ((fr & 1) == 0)
                                 pool8[((img * (d.DH >> 1) + ((a0 + ty_) >> 1)) * (d.DW >> 1) + ((b0 + tx_) >> 1)) * cd8 + (n0 >> 3) + fc + u * 4] = o;
@@ -1018,7 +1018,7 @@ __global__ __launch_bounds__(512) void wtile_kernel(const XmcConvDesc d, const T
                     if (rd_on && mj < TM) P[sub ^ 1][mj] = rdp(rpa, rsub, mj);
 #pragma unroll
                     for (int mi = 0; mi < TM; ++mi)
-                        acc[mi][mj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, Wf[mj]),
+                        acc[mi][mj] = XMC_MFMA_16x16x32(__builtin_bit_cast(bf16x8, Wf[mj]),
                                                                                __builtin_bit_cast(bf16x8, P[sub][mi]), acc[mi][mj], 0, 0, 0);
                     if (rd_on) Wf[mj] = rdw(rwb, rsub, mj);
                     __builtin_amdgcn_sched_barrier(0);

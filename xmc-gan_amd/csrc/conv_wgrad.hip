@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const XmcConvDesc d, float* 
     constexpr int WTM = BCO / WM, WTN = BCI / WN;
     constexpr int TM = WTM / 16, TN = WTN / 16;
     constexpr int CHO = BCO / EPC, CHI = BCI / EPC;  // 16-byte chunks per tile row
-    using elem_t = typename std::conditional<DT == XMC_BF16, __bf16, float>::type;
+    using elem_t = typename std::conditional<DT == XMC_BF16, xmc_h16, float>::type;
     __shared__ __attribute__((aligned(16))) elem_t s_dy[KP * LDO];
     __shared__ __attribute__((aligned(16))) elem_t s_x[KP * LDI];
 
@@ -134,23 +134,23 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const XmcConvDesc d, float* 
             bf16x8 af[TM], bfr[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                const __bf16* base = &s_dy[(ks * 32 + 4 * fg + q) * LDO + wm * WTM + i * 16 + 4 * pp];
-                bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(base));
-                bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(base + 16 * LDO));
+                const xmc_h16* base = &s_dy[(ks * 32 + 4 * fg + q) * LDO + wm * WTM + i * 16 + 4 * pp];
+                bf16x4 lo = xmc_ds_read_tr16((base));
+                bf16x4 hi = xmc_ds_read_tr16((base + 16 * LDO));
                 af[i] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const __bf16* base = &s_x[(ks * 32 + 4 * fg + q) * LDI + wn * WTN + j * 16 + 4 * pp];
-                bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(base));
-                bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(base + 16 * LDI));
+                const xmc_h16* base = &s_x[(ks * 32 + 4 * fg + q) * LDI + wn * WTN + j * 16 + 4 * pp];
+                bf16x4 lo = xmc_ds_read_tr16((base));
+                bf16x4 hi = xmc_ds_read_tr16((base + 16 * LDI));
                 bfr[j] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = XMC_MFMA_16x16x32(af[i], bfr[j], acc[i][j], 0, 0, 0);
           }
         } else {
 #pragma unroll

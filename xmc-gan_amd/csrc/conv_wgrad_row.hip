@@ -159,8 +159,8 @@ __global__ __launch_bounds__(WR_NT) void wgrad_row_kernel(const XmcConvDesc d, c
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const unsigned char* base = sdy + dyoff[ks] + i * 32;
-                bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(base));
-                bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(base + 16 * LD * 2));
+                bf16x4 lo = xmc_ds_read_tr16((base));
+                bf16x4 hi = xmc_ds_read_tr16((base + 16 * LD * 2));
                 af[i] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             }
 #pragma unroll
@@ -169,15 +169,15 @@ __global__ __launch_bounds__(WR_NT) void wgrad_row_kernel(const XmcConvDesc d, c
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     const unsigned char* base = sx + xoff[ks] + (w * LDX + j * 16) * 2;
-                    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(base));
-                    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(base + xhi));
+                    bf16x4 lo = xmc_ds_read_tr16((base));
+                    bf16x4 hi = xmc_ds_read_tr16((base + xhi));
                     bfr[j] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 }
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[w][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[w][i][j], 0, 0, 0);
+                        acc[w][i][j] = XMC_MFMA_16x16x32(af[i], bfr[j], acc[w][i][j], 0, 0, 0);
             }
         }
         if (step + 1 < nstep) store_tiles(buf ^ 1);

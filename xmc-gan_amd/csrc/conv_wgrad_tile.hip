@@ -154,8 +154,8 @@ __global__ __launch_bounds__(NT, (SA == 1 ? WtOcc<NCO, NCI>::v : 1)) void wgrad_
 #pragma unroll
             for (int c = 0; c < (DIAG ? 0 : CBW); ++c) {
                 const unsigned char* ab = ydy + (size_t)(r * 32 + 4 * fg + q) * YS + ((cg * CBW + c) * 16 + 4 * pp4) * 2;
-                bf16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(ab));
-                bf16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(ab + 16 * YS));
+                bf16x4 alo = xmc_ds_read_tr16((ab));
+                bf16x4 ahi = xmc_ds_read_tr16((ab + 16 * YS));
                 af[c] = bf16x8{alo[0], alo[1], alo[2], alo[3], ahi[0], ahi[1], ahi[2], ahi[3]};
             }
 #pragma unroll
@@ -163,18 +163,18 @@ __global__ __launch_bounds__(NT, (SA == 1 ? WtOcc<NCO, NCI>::v : 1)) void wgrad_
                 const int item = slice + j * NS;
                 if (item < nitems) {                          // wave-uniform
                     const unsigned char* bb = xp + ((SA == 1 ? r * (32 / TW) * PW : r * 2 * PW) + 4 * fg + q) * XS + itoff[j] + (4 * pp4) * 2;
-                    bf16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(bb));
-                    bf16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(bb + (T16 ? PW : 16) * XS));
+                    bf16x4 blo = xmc_ds_read_tr16((bb));
+                    bf16x4 bhi = xmc_ds_read_tr16((bb + (T16 ? PW : 16) * XS));
                     const bf16x8 bf = bf16x8{blo[0], blo[1], blo[2], blo[3], bhi[0], bhi[1], bhi[2], bhi[3]};
                     if (DIAG) {                               // the dy fragment of the Cout block with this item's index
                         const unsigned char* ab = ydy + (size_t)(r * 32 + 4 * fg + q) * YS + (itib[j] * 16 + 4 * pp4) * 2;
-                        bf16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(ab));
-                        bf16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(ab + 16 * YS));
+                        bf16x4 alo = xmc_ds_read_tr16((ab));
+                        bf16x4 ahi = xmc_ds_read_tr16((ab + 16 * YS));
                         const bf16x8 a1 = bf16x8{alo[0], alo[1], alo[2], alo[3], ahi[0], ahi[1], ahi[2], ahi[3]};
-                        acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bf, acc[j][0], 0, 0, 0);
+                        acc[j][0] = XMC_MFMA_16x16x32(a1, bf, acc[j][0], 0, 0, 0);
                     } else {
 #pragma unroll
-                        for (int c = 0; c < CBW; ++c) acc[j][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[c], bf, acc[j][c], 0, 0, 0);
+                        for (int c = 0; c < CBW; ++c) acc[j][c] = XMC_MFMA_16x16x32(af[c], bf, acc[j][c], 0, 0, 0);
                     }
                 }
             }

@@ -345,7 +345,7 @@ __global__ __launch_bounds__(64 * CW + 256) void wtile2_kernel(const XmcConvDesc
                     if (dst2_8 || d.round_act) {
                         bf16x8 o2;
 #pragma unroll
-                        for (int r = 0; r < 8; ++r) { o2[r] = (__bf16)v[r]; v[r] = (float)o2[r]; }
+                        for (int r = 0; r < 8; ++r) { o2[r] = (xmc_h16)v[r]; v[r] = (float)o2[r]; }
                         if (dst2_8) dst2_8[eo[i] + u * 4] = o2;
                     }
                     if (d.alpha_dev) {
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(64 * CW + 256) void wtile2_kernel(const XmcConvDesc
                     }
                     bf16x8 o;
 #pragma unroll
-                    for (int r = 0; r < 8; ++r) { o[r] = (__bf16)v[r]; fin[i][r] = (float)o[r]; }
+                    for (int r = 0; r < 8; ++r) { o[r] = (xmc_h16)v[r]; fin[i][r] = (float)o[r]; }
                     if (!(WT_ABL & 16)) dst8[eo[i] + u * 4] = o;
                     else asm volatile("" :: "v"(o));
                 }
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(64 * CW + 256) void wtile2_kernel(const XmcConvDesc
                         for (int r = 0; r < 8; ++r) {
                             float sm = (t.log2TW == 5 ? fin[pr][r] + fin[pr + 2][r] : fin[2 * pr][r] + fin[2 * pr + 1][r]);
                             sm += __shfl_xor(sm, 1, 64);
-                            o[r] = (__bf16)(0.25f * sm);
+                            o[r] = (xmc_h16)(0.25f * sm);
                         }
                         (void)i1;
                         if ((lane_op & 1) == 0)
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(64 * CW + 256) void wtile2_kernel(const XmcConvDesc
                         if (!(WT_ABL & 4)) P[sub ^ 1][k] = rdp(rpa, rsub, k);
 #pragma unroll
                     for (int mi = 0; mi < TM; ++mi)
-                        acc[mi][mj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, Wf[mj]),
+                        acc[mi][mj] = XMC_MFMA_16x16x32(__builtin_bit_cast(bf16x8, Wf[mj]),
                                                                                __builtin_bit_cast(bf16x8, P[sub][mi]), acc[mi][mj], 0, 0, 0);
                     if (!(WT_ABL & 4)) Wf[mj] = rdw(rwb, rsub, mj);
                     __builtin_amdgcn_sched_barrier(0);

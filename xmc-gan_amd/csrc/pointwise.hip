@@ -427,7 +427,7 @@ template <int DT>
 __global__ void hinge_fwd_kernel(const void* x, int stride, float sign, float* out, int64_t n) {
     float s = 0.f;
     for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
-        float v = DT == XMC_BF16 ? (float)reinterpret_cast<const __bf16*>(x)[i * stride] : reinterpret_cast<const float*>(x)[i * stride];
+        float v = DT == XMC_BF16 ? (float)reinterpret_cast<const xmc_h16*>(x)[i * stride] : reinterpret_cast<const float*>(x)[i * stride];
         s += fmaxf(1.f + sign * v, 0.f);
     }
     s = wave_sum(s);
@@ -444,9 +444,9 @@ template <int DT>
 __global__ void hinge_bwd_kernel(const void* x, int stride, float sign, const float* dloss, void* dx, int64_t n) {
     const float gscale = (*dloss) * sign / (float)n;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        float v = DT == XMC_BF16 ? (float)reinterpret_cast<const __bf16*>(x)[i * stride] : reinterpret_cast<const float*>(x)[i * stride];
+        float v = DT == XMC_BF16 ? (float)reinterpret_cast<const xmc_h16*>(x)[i * stride] : reinterpret_cast<const float*>(x)[i * stride];
         float gval = (1.f + sign * v) > 0.f ? gscale : 0.f;
-        if (DT == XMC_BF16) reinterpret_cast<__bf16*>(dx)[i * stride] = (__bf16)gval;
+        if (DT == XMC_BF16) reinterpret_cast<xmc_h16*>(dx)[i * stride] = (xmc_h16)gval;
         else reinterpret_cast<float*>(dx)[i * stride] = gval;
     }
 }
@@ -499,7 +499,7 @@ __global__ void pack_weight_kernel(const float* w, void* wpk, int Co, int Ci, in
     const int64_t total = (int64_t)KHW * rows_pad * cols_pad;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const float v = pack_value(w, Co, Ci, KHW, rows_pad, cols_pad, transpose, row_perm, groups, i);
-        if (DT == XMC_BF16) reinterpret_cast<__bf16*>(wpk)[i] = (__bf16)v;
+        if (DT == XMC_BF16) reinterpret_cast<xmc_h16*>(wpk)[i] = (xmc_h16)v;
         else reinterpret_cast<float*>(wpk)[i] = v;
     }
 }
@@ -508,7 +508,7 @@ __global__ void pack_upconv_kernel(const float* w, void* wpk, int Co, int Ci, in
     const int64_t total = (int64_t)16 * rows_pad * cols_pad;
     for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
         const float v = pack_upconv_value(w, Co, Ci, rows_pad, cols_pad, transpose, idx);
-        if (DT == XMC_BF16) reinterpret_cast<__bf16*>(wpk)[idx] = (__bf16)v;
+        if (DT == XMC_BF16) reinterpret_cast<xmc_h16*>(wpk)[idx] = (xmc_h16)v;
         else reinterpret_cast<float*>(wpk)[idx] = v;
     }
 }
@@ -521,7 +521,7 @@ constexpr int PM_CHUNK = 2048;
 struct PackJobs { XmcPackJob j[XMC_PACK_MULTI_MAX]; int32_t first[XMC_PACK_MULTI_MAX + 1]; int32_t njobs; };
 template <int DT>
 __device__ __forceinline__ void pack_store(void* p, int64_t i, float v) {
-    if (DT == XMC_BF16) reinterpret_cast<__bf16*>(p)[i] = (__bf16)v;
+    if (DT == XMC_BF16) reinterpret_cast<xmc_h16*>(p)[i] = (xmc_h16)v;
     else reinterpret_cast<float*>(p)[i] = v;
 }
 template <int DT>
@@ -740,6 +740,7 @@ __global__ void rows_scale_kernel(const float* __restrict__ x, const float* __re
 #define ST(s) reinterpret_cast<hipStream_t>(s)
 
 extern "C" int xmc_abi_version(void) { return XMC_ABI_VERSION; }
+extern "C" int xmc_half_format(void) { return XMC_HALF_FORMAT; }
 
 static thread_local char g_last_kernel[96] = "";
 void xmc_note_kernel(const char* fmt, ...) {

@@ -47,6 +47,26 @@ class GraphedIteration:
         self._graphs = []       # keep the CUDAGraph objects alive
         self._cur = None
         self._seq = None
+        self._pack_serial = None    # ops' pack-entry counter when the last capture ended
+        self._counted = 0           # captures ops counts as alive on our behalf
+
+    def close(self):
+        """drop the graphs; lets ops release the packed-weight buffers it kept alive for their replays"""
+        self.seqs, self.static_out, self._graphs = {}, {}, []
+        while self._counted > 0:
+            self._counted -= 1
+            ops.graph_released()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # interpreter shutdown
+            pass
+
+    def seams_per_iteration(self):
+        """collective calls a replay makes, per captured phase (0 without data parallelism)"""
+        return {("g_step" if ph else "d_only"): sum(1 for it in seq if getattr(it, "__name__", "") == "eager")
+                for ph, seq in self.seqs.items()}
 
     def _phase(self):
         return (self.it_state.get('i', 0) + 1) % self.n_critic == 0
@@ -87,12 +107,14 @@ class GraphedIteration:
         self.stream.wait_stream(torch.cuda.current_stream())
         state = dict(self.it_state)
         self._seq = []
+        ok = False
         with torch.cuda.stream(self.stream):
             _active = self
             try:
                 self._begin()
                 out = self.step_fn(*self.static_in, state)
                 self._end()
+                ok = True
             finally:
                 _active = None
                 if self._cur is not None:           # an exception inside the step: leave capture mode before it propagates
@@ -101,11 +123,18 @@ class GraphedIteration:
                     except Exception:
                         pass
                     self._cur = None
+                if not ok:
+                    # nothing recorded by the aborted capture ever ran: packed weights it created are uninitialised memory and
+                    # its re-pack marked others valid without re-packing them.  Invalidate all of it before anyone runs eagerly.
+                    self._seq = None
+                    ops.end_of_capture(failed=True)
         torch.cuda.current_stream().wait_stream(self.stream)
         self.seqs[phase] = self._seq
         self.static_out[phase] = out
         self._seq = None
-        ops.end_of_capture()            # packed-weight entries created inside the capture live in graph-private memory
+        # packed-weight entries created inside the capture live in graph-private memory
+        self._pack_serial = ops.end_of_capture()
+        self._counted += 1
 
     def __call__(self, *inputs):
         for s, t in zip(self.static_in, inputs):
@@ -119,6 +148,9 @@ class GraphedIteration:
             self._capture(phase)
         for item in self.seqs[phase]:
             item()
+        # the replay changed the weights without the host-side bookkeeping of an eager optimizer step: packed copies made since
+        # the capture were not refreshed by it
+        self._pack_serial = ops.drop_packs_newer_than(self._pack_serial)
         i = self.it_state.get('i', 0) + 1
         self.it_state['i'] = 0 if i % self.n_critic == 0 else i
         return self.static_out[phase]

@@ -8,8 +8,13 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("XMC_LIB_PATH", os.path.join(HERE, "libxmc_gan_hip.so"))   # override: kernel experiments
+LIB_PATH_F16 = os.environ.get("XMC_LIB_PATH_F16", os.path.join(HERE, "libxmc_gan_hip_f16.so"))
+ABI_VERSION = 2          # include/xmc_gan_hip.h XMC_ABI_VERSION; the ctypes structures below mirror that version
 
+# BF16 is the dtype code of "the 16-bit storage format of the loaded build": bf16 in libxmc_gan_hip.so, IEEE half in
+# libxmc_gan_hip_f16.so (the same sources compiled with -DXMC_H16_IS_F16; `use_variant`)
 BF16, F32 = 0, 1
+H16 = BF16
 ACT_NONE, ACT_LRELU, ACT_TANH, ACT_RELU = 0, 1, 2, 3
 MAX_TAPS, MAX_CLASSES = 16, 4
 
@@ -47,6 +52,7 @@ class AdamEntry(C.Structure):
 # name -> argtypes  (restype is int unless listed in _RESTYPE)
 _SIGS = {
     "xmc_abi_version": [],
+    "xmc_half_format": [],
     "xmc_last_kernel": [],
     "xmc_conv_igemm": [C.POINTER(ConvDesc), vp],
     "xmc_conv_wgrad": [C.POINTER(ConvDesc), vp, vp],
@@ -110,35 +116,51 @@ _SIGS = {
     "xmc_gp_finish": [vp, i32, vp, vp, vp],
     "xmc_rows_scale": [vp, vp, vp, vp, i32, i64, vp],
     "xmc_adam_chunk_elems": [],
-    "xmc_adam_step": [vp, i32, vp, i32, f32, f32, f32, f32, vp],
+    "xmc_adam_step": [vp, i32, vp, i32, f32, f32, f32, f32, f32, vp],
 }
 _RESTYPE = {"xmc_contrastive_ws_bytes": i64, "xmc_attn_pool_ws_floats": i64, "xmc_last_kernel": C.c_char_p}
 EXPORTS = tuple(_SIGS)
 
-_lib = None
+_libs = {}               # variant -> loaded library
+_variant = "bf16"
 
 
 class XmcHipError(RuntimeError):
     pass
 
 
-def load():
-    """Load the shared library (once) and set prototypes."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def use_variant(v):
+    """Select the build every following call goes to: "bf16" (libxmc_gan_hip.so) or "f16" (libxmc_gan_hip_f16.so)."""
+    global _variant
+    assert v in ("bf16", "f16")
+    _variant = v
+
+
+def variant():
+    return _variant
+
+
+def load(v=None):
+    """Load the shared library of the selected variant (once each) and set prototypes."""
+    v = v or _variant
+    lib = _libs.get(v)
+    if lib is not None:
+        return lib
+    path = LIB_PATH if v == "bf16" else LIB_PATH_F16
+    if not os.path.exists(path):
         raise RuntimeError(
-            f"{LIB_PATH} is missing: build it with `make -C xmc-gan_amd/csrc` (or __graft_entry__.build()). "
+            f"{path} is missing: build it with `make -C xmc-gan_amd/csrc` (or __graft_entry__.build()). "
             "The XMC-GAN step has no CPU/PyTorch fallback.")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, args in _SIGS.items():
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = _RESTYPE.get(name, C.c_int)
-    if lib.xmc_abi_version() != 1:
-        raise RuntimeError("libxmc_gan_hip.so ABI version mismatch")
-    _lib = lib
+    if lib.xmc_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"{path}: ABI version {lib.xmc_abi_version()}, this binding needs {ABI_VERSION} (stale build?)")
+    if lib.xmc_half_format() != (0 if v == "bf16" else 1):
+        raise RuntimeError(f"{path} was not built for the {v} storage format")
+    _libs[v] = lib
     return lib
 
 

@@ -25,10 +25,14 @@ _PRECISION = os.environ.get("XMC_PRECISION", "bf16")
 
 
 def set_precision(p):
-    """'bf16' (default: bf16 activations/MFMA operands, f32 accumulate, f32 parameters) or 'fp32'."""
+    """'bf16' (default: bf16 activations / MFMA operands, f32 accumulate, f32 parameters), 'f16' (IEEE half in the same places,
+    through the f16 build of the library: same MFMA rate, 11 significant bits instead of 8 -- the mode whose losses stay within
+    1e-3 of the f32 reference -- with the backward passes run on LOSS_SCALE x the loss, see `loss_scale`) or 'fp32'."""
     global _PRECISION
-    assert p in ("bf16", "fp32")
+    assert p in ("bf16", "f16", "fp32")
     _PRECISION = p
+    L.use_variant("f16" if p == "f16" else "bf16")
+    bump_weights_epoch()           # packed weights of the other format / library are not ours
 
 
 def precision():
@@ -36,7 +40,21 @@ def precision():
 
 
 def act_dtype():
-    return torch.bfloat16 if _PRECISION == "bf16" else torch.float32
+    return {"bf16": torch.bfloat16, "f16": torch.float16, "fp32": torch.float32}[_PRECISION]
+
+
+# f16 activations gradients: a hinge / InfoNCE gradient of 1/B spread over a 256x256x32 map is ~1e-6 per element, far into
+# the subnormal range of IEEE half (spacing 6e-8).  The iteration therefore differentiates LOSS_SCALE * loss and the optimizer
+# kernel divides the (f32) parameter gradients by it again (train_gan.gan_iteration, optim.HipAdam.step(grad_scale=)); a power
+# of two, so bf16 / fp32 results would not change either -- they run unscaled.
+LOSS_SCALE_F16 = float(os.environ.get("XMC_LOSS_SCALE", 4096.0))
+
+
+def loss_scale(phase="step"):
+    """factor the D / G backward passes run on.  The MA-GP backward (`phase="gp"`) runs unscaled: its seeds are 6 ||g||^4 g / B
+    on a gradient norm that is O(1)..O(30) for an untrained discriminator -- a fixed power of two would overflow IEEE half
+    (65504) at the upper end; its first-order pass starts from ones, not from 1/B, and sits in the normal range."""
+    return LOSS_SCALE_F16 if (_PRECISION == "f16" and phase == "step") else 1.0
 
 
 class composable:
@@ -73,15 +91,15 @@ def _skip_wgrad():
 
 # ------------------------------------------------------------------------------------------ helpers
 def _code(dtype):
-    if dtype == torch.bfloat16:
-        return L.BF16
     if dtype == torch.float32:
         return L.F32
-    raise TypeError(f"unsupported dtype {dtype}")
+    if dtype == (torch.float16 if L.variant() == "f16" else torch.bfloat16):
+        return L.H16           # "the 16-bit format of the loaded build"
+    raise TypeError(f"unsupported dtype {dtype} for the {L.variant()} build of the library")
 
 
 def _esz(dtype):
-    return 2 if dtype == torch.bfloat16 else 4
+    return 4 if dtype == torch.float32 else 2
 
 
 def _p(t):
@@ -100,6 +118,11 @@ def _need_cuda(*ts):
 
 def pad_to(n, m):
     return (n + m - 1) // m * m
+
+
+def _nbytes(*ts):
+    """bytes of the given tensors (None skipped): the algorithmic HBM traffic of a launch that touches each of them once"""
+    return sum(t.numel() * t.element_size() for t in ts if t is not None)
 
 
 def chan_pad(c, dtype):
@@ -161,7 +184,7 @@ class _PackEntry:
     re-pack every entry of the parameters they changed in ONE launch (``repack_params``) -- so after the first iteration the
     forward / backward passes find every pack valid and launch no pack kernel of their own (~100-200 launches of ~6 us per
     iteration before).  ``gepoch``: bumped when entries may point into graph-private memory (graph._capture)."""
-    __slots__ = ("ref", "version", "pepoch", "gepoch", "geom", "out", "up", "transpose", "wf", "private")
+    __slots__ = ("ref", "version", "pepoch", "gepoch", "geom", "out", "up", "transpose", "wf", "private", "born")
 
     def valid(self, w, geom):
         return (self.ref() is w and self.version == w._version and self.pepoch == getattr(w, "_xmc_epoch", 0) and
@@ -214,6 +237,8 @@ def _packed_cached(w, geom, transpose, dtype, up=False):
     e.wf = wd if (wd.dtype == torch.float32 and wd.is_contiguous()) else None      # None: re-packed lazily, never in bulk
     e.out = _pack(w, geom, transpose, dtype, up)
     e.private = w.is_cuda and torch.cuda.is_current_stream_capturing()       # buffer lives in that graph's memory pool
+    _pack_serial[0] += 1
+    e.born = _pack_serial[0]
     if hit is not None and _graphs_alive[0]:
         _retired_packs.append(hit.out)        # a captured graph may still write / read the buffer it saw
     _pack_cache[k] = e
@@ -226,15 +251,45 @@ def _packed_upconv_cached(w, geom, transpose, dtype):
 
 _graphs_alive = [0]       # set by graph.GraphedIteration: pack buffers a capture has seen must outlive it
 _retired_packs = []
+_pack_serial = [0]        # counts pack entries ever created (graph.GraphedIteration: "which entries are newer than my capture?")
 
 
-def end_of_capture():
+def end_of_capture(failed=False):
     """graph.GraphedIteration: a capture has ended.  Entries it created point into its private pool and are dropped (eager
     code must not use them); every other entry stays valid -- the captured re-pack launches keep writing the same buffers, in
-    the same place of the iteration, as the eager ones."""
+    the same place of the iteration, as the eager ones.
+    ``failed``: the capture raised.  Its launches were only recorded, never executed: the entries it created hold uninitialised
+    memory, and a `repack_params` recorded inside it has marked OTHER entries valid for weights that were never re-packed --
+    every cached copy is invalidated, and no live graph is counted."""
+    if failed:
+        for k in [k for k, e in _pack_cache.items() if e.private]:
+            del _pack_cache[k]
+        bump_weights_epoch()
+        return _pack_serial[0]
     _graphs_alive[0] += 1
     for k in [k for k, e in _pack_cache.items() if e.private]:
         del _pack_cache[k]
+    return _pack_serial[0]
+
+
+def drop_packs_newer_than(serial):
+    """graph.GraphedIteration, after a replay: the captured re-pack refreshed the copies that existed when it was captured;
+    copies created since (eagerly, e.g. an evaluation pass or another dtype between two replays) were not and would pass
+    `valid()` with stale contents -- drop them (their next eager use packs afresh)."""
+    if _pack_serial[0] == serial:
+        return serial
+    for k in [k for k, e in _pack_cache.items() if e.born > serial]:
+        if _graphs_alive[0]:
+            _retired_packs.append(_pack_cache[k].out)
+        del _pack_cache[k]
+    return _pack_serial[0]
+
+
+def graph_released():
+    """a GraphedIteration was destroyed: buffers kept alive for its replays can go once no graph is left"""
+    _graphs_alive[0] = max(0, _graphs_alive[0] - 1)
+    if _graphs_alive[0] == 0:
+        _retired_packs.clear()
 
 
 def repack_params(params):
@@ -286,7 +341,7 @@ def _upconv_fwd_raw(x, w, bias, geom, act, out_dtype):
             _fill_taps(d, cls, [(i - 1 + th, j - 1 + tw, cls * 4 + th * 2 + tw) for th in range(2) for tw in range(2)])
             d.dph[cls], d.dpw[cls] = i, j
     with prof.launch("igemm_kernel (conv fwd+dgrad, MFMA implicit GEMM)", 2.0 * N * 4 * H * W * geom.cout * geom.cin * 9,
-                     f"upconv-fwd {x.dtype} N{N} {2 * H}x{2 * W} {geom.cin}->{geom.cout} k3s1"):
+                     f"upconv-fwd {x.dtype} N{N} {2 * H}x{2 * W} {geom.cin}->{geom.cout} k3s1", _nbytes(x, wpk, y)):
         L.check(L.load().xmc_conv_igemm(C.byref(d), _st()), "xmc_conv_igemm(upconv fwd)")
     return y
 
@@ -317,7 +372,7 @@ def _upconv_dgrad_raw(dy, w, geom, in_dtype):
                     taps.append((ro, co, (i * 2 + j) * 4 + th * 2 + tw))
     _fill_taps(d, 0, taps)
     with prof.launch("igemm_kernel (conv fwd+dgrad, MFMA implicit GEMM)", 2.0 * N * OH * OW * geom.cout * geom.cin * 9,
-                     f"upconv-dgrad {dy.dtype} N{N} {OH}x{OW} {geom.cin}->{geom.cout} k3s1"):
+                     f"upconv-dgrad {dy.dtype} N{N} {OH}x{OW} {geom.cin}->{geom.cout} k3s1", _nbytes(dy, wpk, dx)):
         L.check(L.load().xmc_conv_igemm(C.byref(d), _st()), "xmc_conv_igemm(upconv dgrad)")
     return dx
 
@@ -372,7 +427,7 @@ def _conv_fwd_raw(x, w, bias, geom, act, out_dtype, res=None, alpha=None, up=Fal
         d.dst_pool = yp.data_ptr()
         outs.append(yp)
     with prof.launch("igemm_kernel (conv fwd+dgrad, MFMA implicit GEMM)", 2.0 * N * OH * OW * geom.cout * geom.cin * geom.k * geom.k,
-                     f"fwd {x.dtype} N{N} {H}x{W} {geom.cin}->{geom.cout} k{geom.k}s{geom.s}"):
+                     f"fwd {x.dtype} N{N} {H}x{W} {geom.cin}->{geom.cout} k{geom.k}s{geom.s}", _nbytes(x, wpk, res, mask, *outs)):
         L.check(L.load().xmc_conv_igemm(C.byref(d), _st()), "xmc_conv_igemm(fwd)")
     return y if len(outs) == 1 else tuple(outs)
 
@@ -423,7 +478,7 @@ def _conv_dgrad_raw(dy, w, geom, in_hw, in_dtype, mask=None, res=None, res_rows=
         assert not res_rows or s == 2
         d.res, d.res_mode, d.res_scale = res.data_ptr(), 1 if res_rows else 0, float(res_scale)
     with prof.launch("igemm_kernel (conv fwd+dgrad, MFMA implicit GEMM)", 2.0 * N * OH * OW * geom.cout * geom.cin * geom.k * geom.k,
-                     f"dgrad {dy.dtype} N{N} {H}x{W} {geom.cin}->{geom.cout} k{geom.k}s{geom.s}"):
+                     f"dgrad {dy.dtype} N{N} {H}x{W} {geom.cin}->{geom.cout} k{geom.k}s{geom.s}", _nbytes(dy, wpk, dx, mask, res)):
         L.check(L.load().xmc_conv_igemm(C.byref(d), _st()), "xmc_conv_igemm(dgrad)")
     return dx
 
@@ -491,7 +546,7 @@ def _conv_wgrad_raw(x, dy, geom, scale=None, up=False, want_bias=False):
     d.groups = geom.groups
     _fill_taps(d, 0, [(kh - geom.p, kw - geom.p, kh * geom.k + kw) for kh in range(geom.k) for kw in range(geom.k)])
     with prof.launch("wgrad_kernel (conv weight gradient, MFMA + split-K atomics)", 2.0 * N * OH * OW * geom.cout * geom.cin * geom.k * geom.k,
-                     f"wgrad {x.dtype} N{N} {H}x{W} {geom.cin}->{geom.cout} k{geom.k}s{geom.s}"):
+                     f"wgrad {x.dtype} N{N} {H}x{W} {geom.cin}->{geom.cout} k{geom.k}s{geom.s}", _nbytes(x, dy, dwp)):
         L.check(L.load().xmc_conv_wgrad_bias(C.byref(d), _p(dwp), _p(gb), _st()), "xmc_conv_wgrad")
     gw = torch.empty((geom.cout, geom.cin // geom.groups, geom.k, geom.k), dtype=torch.float32, device=x.device)
     if want_bias:
@@ -515,6 +570,8 @@ class ConvFn(torch.autograd.Function):
         """``want_pool``: returns (y, avg_pool2d(y, 2)); the pooled tensor is a by-product for the consumer's shortcut branch
         (written from the epilogue where the kernel can) and carries no gradient of its own.  ``out``: destination tensor."""
         x = x.contiguous()
+        # `out` is written behind autograd's back (no version bump): it must be a tensor no earlier node has saved
+        assert out is None or out._version == 0, "ConvFn(out=): the destination must be a fresh tensor"
         bp = None
         if b is not None:
             cd_p = pad_to(geom.cout, 8)
@@ -1382,8 +1439,9 @@ class NchwToNhwc8Fn(torch.autograd.Function):
         N, Cc, H, W = x.shape
         if out is None:
             y = torch.empty((N, H, W, 8), dtype=dtype, device=x.device)
-        else:                      # caller-provided destination (e.g. one half of the discriminator's 2B input)
-            assert tuple(out.shape) == (N, H, W, 8) and out.dtype == dtype and out.is_contiguous()
+        else:                      # caller-provided destination (e.g. one half of the discriminator's 2B input); written
+            # behind autograd's back (no version bump), so it must be a tensor no earlier node has saved
+            assert tuple(out.shape) == (N, H, W, 8) and out.dtype == dtype and out.is_contiguous() and out._version == 0
             y = out
         L.call("xmc_nchw_to_nhwc8", _p(x), _p(y), N, Cc, H, W, _code(dtype), _st())
         ctx.c = Cc
@@ -1978,3 +2036,7 @@ def contrastive(a, b, labels=None, inv_num_pos=None):
 
 def cast(x, dtype):
     return CastFn.apply(x, dtype)
+
+
+if _PRECISION != "bf16":          # XMC_PRECISION in the environment: select the matching build of the library
+    set_precision(_PRECISION)

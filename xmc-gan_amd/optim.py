@@ -114,7 +114,9 @@ class HipAdam(torch.optim.Optimizer):
         return self._tables[key][:4]
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, grad_scale=1.0):
+        """``grad_scale``: factor applied to every gradient element as the kernel reads it (the IEEE-half mode passes
+        1 / loss scale; 1.0 is torch.optim.Adam exactly)."""
         assert closure is None
         for group in self.param_groups:
             ps = [p for p in group["params"] if p.grad is not None]
@@ -125,7 +127,7 @@ class HipAdam(torch.optim.Optimizer):
             tab, ch, nt, nc = self._table(ps, ps[0].device)
             b1, b2 = group["betas"]
             L.call("xmc_adam_step", C.c_void_p(tab.data_ptr()), nt, C.c_void_p(ch.data_ptr()), nc,
-                   float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                   float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(grad_scale),
                    C.c_void_p(torch.cuda.current_stream().cuda_stream))
         # the kernels wrote the parameters behind autograd's back: invalidate their packed copies and re-pack, in one launch,
         # the ones that exist (ops._PackEntry)

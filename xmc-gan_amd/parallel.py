@@ -12,6 +12,22 @@ import torch
 import torch.distributed as dist
 
 
+_FORCE = [False]
+
+
+def force_collectives(on=True):
+    """Run the data-parallel path (flat-bucket gradient all-reduce, embedding all-gather, graph seams) even at world size 1,
+    provided a process group exists: the single-card rehearsal of the RCCL calls (bench.py --force_dp)."""
+    _FORCE[0] = bool(on)
+
+
+def active():
+    """does the iteration issue collectives?"""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or _FORCE[0]
+
+
 def world():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
@@ -29,7 +45,7 @@ def allreduce_mean_grads(params, bucket_elems=64 * 1024 * 1024):
     The pack / unpack copies are multi-tensor kernels on the caller's stream (capturable); only the collective itself is an
     eager seam of a captured iteration (graph.seam)."""
     W = world()
-    if W == 1:
+    if not active():
         return
     from . import graph
     grads = [p.grad for p in params if p.grad is not None]
@@ -74,4 +90,4 @@ class _GatherRows(torch.autograd.Function):
 
 def gather_rows(x):
     """[n, ...] -> [world*n, ...] (rank-major), differentiable; identity when not distributed."""
-    return x if world() == 1 else _GatherRows.apply(x)
+    return _GatherRows.apply(x) if active() else x

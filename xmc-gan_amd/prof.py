@@ -24,8 +24,9 @@ def active():
 class launch:
     """with prof.launch(family, flops): <enqueue one kernel>"""
 
-    def __init__(self, family, flops, tag=None):
-        self.family, self.flops, self.tag = family, flops, tag
+    def __init__(self, family, flops, tag=None, nbytes=0):
+        """``nbytes``: algorithmic HBM bytes of the launch = every operand and result tensor once (the `roofline_hbm` view)"""
+        self.family, self.flops, self.tag, self.nbytes = family, flops, tag, nbytes
 
     def __enter__(self):
         if _on:
@@ -39,18 +40,22 @@ class launch:
             self.e1.record()
             from . import lib
             kern = lib.load().xmc_last_kernel().decode()       # the instantiation the C dispatcher picked
-            _recs.append((self.family, self.flops, self.e0, self.e1, self.tag, kern))
+            _recs.append((self.family, self.flops, self.e0, self.e1, self.tag, kern, self.nbytes))
 
 
 def _aggregate(key):
     agg = {}
     for rec in _recs:
-        f = agg.setdefault(key(rec), dict(launches=0, gflop=0.0, ms=0.0))
+        f = agg.setdefault(key(rec), dict(launches=0, gflop=0.0, ms=0.0, gbyte=0.0))
         f["launches"] += 1
         f["gflop"] += rec[1] / 1e9
+        f["gbyte"] += rec[6] / 1e9
         f["ms"] += rec[2].elapsed_time(rec[3])
     for f in agg.values():
         f["tflops"] = round(f["gflop"] / max(f["ms"], 1e-9), 2)
+        f["gbytes_per_s"] = round(f["gbyte"] / max(f["ms"], 1e-9) * 1e3, 1)
+        f["flop_per_byte"] = round(f["gflop"] / max(f["gbyte"], 1e-12), 1)
+        f["gbyte"] = round(f["gbyte"], 3)
         f["avg_launch_us"] = round(1e3 * f["ms"] / f["launches"], 2)
         f["gflop_per_launch"] = round(f["gflop"] / f["launches"], 3)
         f["gflop"], f["ms"] = round(f["gflop"], 1), round(f["ms"], 3)
@@ -74,11 +79,25 @@ def summary(peak_tflops, traffic_lookup=None):
                 kernels=kern, families=fam)
 
 
+def summary_hbm(peak_gbs, ridge_flop_per_byte, top=8):
+    """The HBM view ("layers with Cout <= 64 ... report their GB/s, not MFMA %"): the convolution instantiations
+    whose algorithmic intensity (FLOPs / bytes of their operand and result tensors, each once) lies below the ridge of the chip
+    are bandwidth-bound; for the `top` of them by time: algorithmic bytes / HIP-event duration against the HBM peak."""
+    torch.cuda.synchronize()
+    kern = _aggregate(lambda r: r[5])
+    rows = [(k, v) for k, v in kern.items() if v["gbyte"] > 0 and v["flop_per_byte"] < ridge_flop_per_byte]
+    rows.sort(key=lambda kv: -kv[1]["ms"])
+    out = [dict(kernel=k, bound="hbm", achieved=v["gbytes_per_s"], peak=peak_gbs, unit="GB/s", frac=round(v["gbytes_per_s"] / peak_gbs, 4),
+                launches=v["launches"], ms=v["ms"], algorithmic_mbyte_per_launch=round(1e3 * v["gbyte"] / v["launches"], 1),
+                flop_per_byte=v["flop_per_byte"]) for k, v in rows[:top]]
+    return dict(ridge_flop_per_byte=ridge_flop_per_byte, total_ms=round(sum(v["ms"] for _, v in rows), 3), kernels=out)
+
+
 def by_shape():
     """[(family, tag, launches, total_ms, tflops)] sorted by time (debug aid)."""
     torch.cuda.synchronize()
     agg = {}
-    for family, flops, e0, e1, tag, kern in _recs:
+    for family, flops, e0, e1, tag, kern, _nb in _recs:
         a = agg.setdefault((kern or family.split(" ")[0], tag), [0, 0.0, 0.0])
         a[0] += 1; a[1] += e0.elapsed_time(e1); a[2] += flops
     rows = [(k[0], k[1], v[0], v[1], v[2] / 1e9 / max(v[1], 1e-9)) for k, v in agg.items()]

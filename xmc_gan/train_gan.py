@@ -61,7 +61,7 @@ def parse_args(argv=None):
     parser.add_argument('--max_epoch', type=int, default=-1)
     parser.add_argument('--data_dir', type=str, default='', help='dataset root (default: <repo>/data/<DATASET_NAME>)')
     parser.add_argument('--output_dir', type=str, default='', help='run directory (default: <repo>/output/<name>)')
-    parser.add_argument('--precision', type=str, default=None, choices=['bf16', 'fp32'])
+    parser.add_argument('--precision', type=str, default=None, choices=['bf16', 'f16', 'fp32'])
     parser.add_argument('--gather_negatives', action='store_true',
                         help='data parallel: all-gather embeddings so the contrastive losses see world*batch negatives')
     return parser.parse_args(argv)
@@ -204,9 +204,11 @@ def gan_iteration(netG, netD, optimizerG, optimizerD, imgs, sent_embs, words_emb
     errD = errD_real + (mis_loss * T.SMOOTH.MISMATCH) + enc_loss
     netG.zero_grad()
     netD.zero_grad()
-    errD.backward()
+    ls = ops.loss_scale()            # 1 unless the IEEE-half mode is on (ops.set_precision): keeps 1/B-sized gradients normal
+    unscale = dict(grad_scale=1.0 / ls) if ls != 1.0 else {}       # HipAdam divides the f32 parameter gradients by it again
+    (errD * ls if ls != 1.0 else errD).backward()
     parallel.allreduce_mean_grads(netD.parameters())
-    optimizerD.step()
+    optimizerD.step(**unscale)
     out.update(errD=errD.detach(), errD_real=errD_real.detach(), errD_fake=errD_fake.detach())
 
     # ---- matching-aware gradient penalty on real pairs (train_gan.py:231-252)
@@ -266,11 +268,11 @@ def gan_iteration(netG, netD, optimizerG, optimizerD, imgs, sent_embs, words_emb
             errG = errG_fake + enc_loss
             netG.zero_grad()
             netD.zero_grad()
-            errG.backward()
+            (errG * ls if ls != 1.0 else errG).backward()
         finally:
             _set_requires_grad(netD, True)
         parallel.allreduce_mean_grads(netG.parameters())
-        optimizerG.step()
+        optimizerG.step(**unscale)
         it_state['i'] = 0
         out.update(errG=errG.detach(), errG_fake=errG_fake.detach())
     out['fake'] = fake.detach()
