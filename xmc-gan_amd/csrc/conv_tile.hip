@@ -760,295 +760,6 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
     }
 }
 
-// Wide layers (Cin % 64 == 0, Cout % 128 == 0, 3x3-like tap sets, one class): the same halo-patch idea with the weights
-// STREAMED.  The gather kernel (conv_igemm.hip) pulls 48 KB through the CU's vector-memory path per 128 MFMAs of a wave
-// pair; measured with s_memtime, a CU accepts ~22 B/clk from L2, less than half of what that needs at the MFMA rate, so it
-// tops out near 700 TFLOP/s whatever its schedule (with loads AND LDS stores compiled out it reaches 970).  Here a workgroup
-// owns 256 pixels x 128 output channels; per 64-channel slab the patch is staged ONCE for all taps and only the weights
-// of each (slab, tap) stage -- 16 KB -- are streamed: ~21 KB per 128 MFMAs.
-//   waves 4-7 ("stage"):   weights of stage g+3 global -> registers, stage g+2 registers -> LDS ring (3 deep); the next slab's
-//                          patch is loaded into registers during a slab and written at the slab boundary;
-//   waves 0-3 ("compute"): 64 pixels x 128 channels each: 12 fragment reads + 32 MFMAs per K sub-step, the reads of the next
-//                          sub-step dealt out between the MFMAs (pinned), first fragments of the next stage prefetched
-//                          across the barrier;  epilogue from registers (lane = 32 consecutive channels of 4 pixels).
-// One barrier per stage, one more at a slab boundary.
-template <int NTAPS>
-__global__ __launch_bounds__(512) void wtile_kernel(const XmcConvDesc d, const TileCfg t, int ntiles) {
-    constexpr int BN = 128, TM = 4, TN = 8, NS = 256;
-    constexpr int cps = 8, pstride = 160, PIT = 12;
-    constexpr int WSTG = BN * pstride;           // bytes of one weight stage
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ int s_toff[XMC_MAX_TAPS], s_twi[XMC_MAX_TAPS];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n0 = blockIdx.y * BN;
-    const int tpi = t.tiles_y * t.tiles_x;
-    const int cls = blockIdx.z;                  // output-parity class (stride-2 data gradient, fused upsample conv): own patch
-    const int PH = t.PH[cls], PW = t.PW[cls], dh0 = t.dh0[cls], dw0 = t.dw0[cls];
-    if (tid < XMC_MAX_TAPS) {
-        const int tt = tid < d.ntaps ? tid : 0;
-        s_toff[tid] = ((d.dh[cls][tt] - dh0) * PW + (d.dw[cls][tt] - dw0)) * pstride;
-        s_twi[tid] = d.wi[cls][tt];
-    }
-    const int cs_units = d.CS / 8;
-    const int nslab = d.CS / 64;
-    // Persistent: this workgroup's tiles are blockIdx.x, + gridDim.x, ...  The K stages of all of them form ONE stream
-    // (patch sequence q = (tile, slab), NTAPS stages each): the weight ring never drains, a tile change is a patch change plus
-    // the epilogue, the next tile's first patch is loaded while the current tile is still being multiplied, and the stores
-    // of the epilogue drain during the next tile (measured before: 12 k cycles of prologue + 16 k of epilogue per 57 k of K loop).
-    const int mytiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int Q = mytiles * nslab;
-    const int G = Q * NTAPS;
-    unsigned char* patch = smem;
-    const int patch_bytes = (PH * PW * pstride + 15) & ~15;
-    unsigned char* wring = smem + patch_bytes;   // [3][BN][pstride]
-    __syncthreads();
-    if (mytiles <= 0) return;
-
-    if (wave >= 4) {
-        // ================================================================================================ staging role
-        const int rt = tid - NS;
-        const int unit = rt & 7, r32 = rt >> 3;   // weights: 8 units per row, rows r32 + 32*i; patch: pixels r32 + 32*it
-        const u32x4* __restrict__ src16 = reinterpret_cast<const u32x4*>(d.src);
-        const u32x4* __restrict__ w16 = reinterpret_cast<const u32x4*>(d.wpk);
-        int psrc[PIT];
-        unsigned halo[PIT], inpatch = 0;
-        int py = r32 / PW, px = r32 - (r32 / PW) * PW;       // pixel r32 + 32*it, stepped without a division per unit
-#pragma unroll
-        for (int it = 0; it < PIT; ++it) {
-            const int pp = r32 + it * 32;
-            const bool in = pp < PH * PW;
-            inpatch |= in ? (1u << it) : 0u;
-            psrc[it] = in ? ((dh0 + py) * d.SW + (dw0 + px)) * cs_units + unit : 0;
-            halo[it] = !in ? 0u : ((py < -dh0 ? 1u : 0u) | (py >= t.TH - dh0 ? 2u : 0u) | (px < -dw0 ? 4u : 0u) | (px >= t.TW - dw0 ? 8u : 0u));
-            px += 32;
-            if (px >= PW) { px -= PW; ++py; }     // PW >= 32: at most one wrap
-            if (px >= PW) { px -= PW; ++py; }
-        }
-        unsigned okmask = 0;                      // of the patch held in pv
-        int wrow[4], wdst[4];                     // weight rows of this thread: source row offset (units), LDS byte offset
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            // physical LDS row (n-block j, row q) <- logical channel (j/2)*32 + (q/4)*8 + (j%2)*4 + q%4: lane group fc = q/4 then
-            // holds, for unit u = j/2, channels u*32 + fc*8 .. +7, so the four lane groups of a pixel store 64 contiguous bytes
-            const int prow = r32 + 32 * i;
-            const int j = prow >> 4, q = prow & 15;
-            const int lrow = (j >> 1) * 32 + (q >> 2) * 8 + (j & 1) * 4 + (q & 3);
-            wrow[i] = (n0 + lrow) * cs_units + unit;
-            wdst[i] = prow * pstride + unit * 16;
-        }
-        u32x4 pv[PIT], wv[4];
-        auto issue_patch = [&](int q) {
-            const int tk = q / nslab, sl = q - tk * nslab;
-            const int tile = (int)blockIdx.x + tk * (int)gridDim.x;
-            const int img = tile / tpi, trem = tile - img * tpi;
-            const int a0 = (trem / t.tiles_x) * t.TH, b0 = (trem % t.tiles_x) * t.TW;
-            const int base = ((img * d.SH + a0) * d.SW + b0) * cs_units + sl * 8;
-            const unsigned border = (a0 + dh0 < 0 ? 1u : 0u) | (a0 + PH + dh0 > d.SH ? 2u : 0u) | (b0 + dw0 < 0 ? 4u : 0u) | (b0 + PW + dw0 > d.SW ? 8u : 0u);
-            okmask = 0;
-#pragma unroll
-            for (int it = 0; it < PIT; ++it) {
-                const bool ok = (halo[it] & border) == 0 && ((inpatch >> it) & 1);
-                okmask |= ok ? (1u << it) : 0u;
-                pv[it] = src16[(unsigned)(base + (ok ? psrc[it] : 0))];
-            }
-        };
-        auto commit_patch = [&]() {
-#pragma unroll
-            for (int it = 0; it < PIT; ++it) {
-                u32x4 v = pv[it];
-                if (!((okmask >> it) & 1)) v = u32x4{0, 0, 0, 0};
-                if ((inpatch >> it) & 1) *reinterpret_cast<u32x4*>(patch + (r32 + it * 32) * pstride + unit * 16) = v;
-            }
-        };
-        auto issue_w = [&](int g) {
-            const int qq = g / NTAPS, tap = g - qq * NTAPS;          // stage g: slab (g / NTAPS) % nslab -- the same for every tile
-            const int sl = qq % nslab;
-            const int wb = s_twi[tap] * d.CDw * cs_units + sl * 8;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) wv[i] = w16[(unsigned)(wb + wrow[i])];
-        };
-        auto commit_w = [&](int g) {
-            unsigned char* wb = wring + (g % 3) * WSTG;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(wb + wdst[i]) = wv[i];
-        };
-        {   // all loads of the prologue in flight together (one memory latency instead of three in a row)
-            u32x4 w0[4], w1[4];
-            issue_patch(0);
-            issue_w(0);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) w0[i] = wv[i];
-            if (G > 1) issue_w(1);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) w1[i] = wv[i];
-            commit_patch();
-#pragma unroll
-            for (int i = 0; i < 4; ++i) wv[i] = w0[i];
-            commit_w(0);
-            if (G > 1) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) wv[i] = w1[i];
-                commit_w(1);
-            }
-        }
-        if (G > 2) issue_w(2);
-        if (Q > 1) issue_patch(1);
-        __syncthreads();                          // patch of slab 0 and weight stages 0, 1 are in LDS
-        for (int q = 0, g = 0; q < Q; ++q) {
-#pragma unroll
-            for (int tap = 0; tap < NTAPS; ++tap, ++g) {
-                if (g + 2 < G) commit_w(g + 2);   // loaded during stage g-1
-                const bool boundary = tap == NTAPS - 1 && q + 1 < Q;
-                if (!boundary && g + 3 < G) issue_w(g + 3);
-                __syncthreads();                  // end of stage g
-                if (boundary) {
-                    commit_patch();               // the compute waves are done with slab sl; nothing younger than these loads is
-                    __syncthreads();              // in flight, so the wait in front of the LDS stores is for them alone
-                    if (g + 3 < G) issue_w(g + 3);
-                    if (q + 2 < Q) issue_patch(q + 2);
-                }
-            }
-        }
-    } else {
-        // ================================================================================================ compute role
-        const int wm = wave;
-        const int fr = lane & 15, fc = lane >> 4;
-        const int cd8 = d.CD / 8;
-        int abyte[TM];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int ml = wm * 64 + i * 16 + fr;
-            const int ty = ml >> t.log2TW, tx = ml & (t.TW - 1);
-            abyte[i] = (ty * PW + tx) * pstride + fc * 16;
-        }
-        const int bbyte = fr * pstride + fc * 16;
-        f32x4 acc[TM][TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // Fragment registers: pixel fragments double buffered (every MFMA column of a sub-step uses all four), weight fragments
-        // in ONE set of eight: the MFMAs run column by column (all four pixel blocks against weight fragment mj), and as soon as
-        // the four MFMAs of column mj have issued, slot mj is re-loaded with the NEXT sub-step's fragment -- 28 MFMAs ahead of
-        // its first use.  (64 instead of 96 fragment registers.)
-        u32x4 P[2][TM], Wf[TN];
-        auto rdp = [&](const unsigned char* pa, int sub, int mi) -> u32x4 {
-            return *reinterpret_cast<const u32x4*>(pa + sub * 64 + abyte[mi]);
-        };
-        auto rdw = [&](const unsigned char* wb, int sub, int mj) -> u32x4 {
-            return *reinterpret_cast<const u32x4*>(wb + bbyte + sub * 64 + mj * 16 * pstride);
-        };
-        auto load_all = [&](const unsigned char* pa, const unsigned char* wb) {      // sub-step 0 of a stage, nothing in flight
-#pragma unroll
-            for (int k = 0; k < TM; ++k) { P[0][k] = rdp(pa, 0, k); Wf[k] = rdw(wb, 0, k); }
-#pragma unroll
-            for (int k = TM; k < TN; ++k) Wf[k] = rdw(wb, 0, k);
-        };
-        // epilogue from registers: acc[i][j][q] = pixel (m-block i, fr), channel n0 + (j/2)*32 + fc*8 + (j%2)*4 + q; clears acc
-        const int ch0 = n0 + fc * 8;
-        const float alpha = d.alpha_dev ? *d.alpha_dev : 1.f;
-        auto epilogue = [&](int tile) {
-            // Everything the epilogue needs besides the accumulators is recomputed here from an opaque lane index: hoisted out
-            // of the tile loop as "invariant", the 16 store addresses and 32 bias values spill (scratch reloads in front of
-            // every store: measured 30 k cycles per epilogue instead of 8 k).
-            int lane_op = fr;
-            asm volatile("" : "+v"(lane_op) :: "memory");
-            const int img = tile / tpi, trem = tile - img * tpi;
-            const int a0 = (trem / t.tiles_x) * t.TH, b0 = (trem % t.tiles_x) * t.TW;
-            const int dbase = (((img * d.DH + a0 * d.DA + d.dph[cls]) * d.DW) + b0 * d.DA + d.dpw[cls]) * cd8 + (n0 >> 3);
-            const int rbase = ((img * d.MH + a0) * d.MW + b0) * cd8 + (n0 >> 3);
-            // pixel block outermost, one address at a time (4 x 64-bit bases kept across the unit loop were being spilled)
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int ml = wm * 64 + i * 16 + lane_op;
-                const int ty = ml >> t.log2TW, tx = ml & (t.TW - 1);
-                const int eo = ((ty * d.DA) * d.DW + tx * d.DA) * cd8 + fc;
-                const int ro = (ty * d.MW + tx) * cd8 + fc;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (ch0 + u * 32 >= d.CD) continue;
-                    const size_t idx8 = (size_t)(dbase + eo + u * 4);
-                    float v[8];
-                    if (d.bias) {
-                        const f32x4 b0v = *reinterpret_cast<const f32x4*>(d.bias + ch0 + u * 32), b1v = *reinterpret_cast<const f32x4*>(d.bias + ch0 + u * 32 + 4);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) { v[q] = acc[i][2 * u][q] + b0v[q]; v[4 + q] = acc[i][2 * u + 1][q] + b1v[q]; }
-                    } else {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) { v[q] = acc[i][2 * u][q]; v[4 + q] = acc[i][2 * u + 1][q]; }
-                    }
-                    if (d.act == XMC_ACT_LRELU) {
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) v[q] = lrelu_f(v[q]);
-                    } else if (d.act == XMC_ACT_RELU) {
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
-                    } else if (d.act == XMC_ACT_TANH) {
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) v[q] = tanhf(v[q]);
-                    }
-                    size_t ridx8 = d.res_mode == 1 ? (size_t)(rbase + ro + u * 4) : idx8;
-                    if (d.res_mode == 2) ridx8 = res_index8(d, idx8, img, (a0 + ty) * d.DA + d.dph[cls], (b0 + tx) * d.DA + d.dpw[cls], 0, 0, (n0 >> 3) + fc + u * 4);
-                    if (d.out_dtype == XMC_BF16) epilogue_tail<XMC_BF16>(d, idx8, ridx8, v, alpha);
-                    else epilogue_tail<XMC_F32>(d, idx8, ridx8, v, alpha);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        };
-        __syncthreads();                          // patch 0 and weight stages 0, 1 are in LDS
-        load_all(patch + s_toff[0], wring);
-        int toffr[NTAPS];                         // tap -> patch byte offset, in scalar registers
-#pragma unroll
-        for (int k = 0; k < NTAPS; ++k) toffr[k] = __builtin_amdgcn_readfirstlane(s_toff[k]);
-        // one stage: MFMAs of both K sub-steps; PF: prefetch the next stage's first fragments during the second sub-step
-        auto stage = [&](const unsigned char* pa, const unsigned char* wb, const unsigned char* npa, const unsigned char* nwb, auto pf) {
-            constexpr bool PF = decltype(pf)::value;
-#pragma unroll
-            for (int sub = 0; sub < 2; ++sub) {
-                const bool rd_on = sub == 0 || PF;
-                const unsigned char* rpa = sub == 0 ? pa : npa;
-                const unsigned char* rwb = sub == 0 ? wb : nwb;
-                const int rsub = sub == 0 ? 1 : 0;
-#pragma unroll
-                for (int mj = 0; mj < TN; ++mj) {
-                    if (rd_on && mj < TM) P[sub ^ 1][mj] = rdp(rpa, rsub, mj);
-#pragma unroll
-                    for (int mi = 0; mi < TM; ++mi)
-                        acc[mi][mj] = XMC_MFMA_16x16x32(__builtin_bit_cast(bf16x8, Wf[mj]),
-                                                                               __builtin_bit_cast(bf16x8, P[sub][mi]), acc[mi][mj], 0, 0, 0);
-                    if (rd_on) Wf[mj] = rdw(rwb, rsub, mj);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        };
-        for (int q = 0, g = 0, sl = 0, tk = 0; q < Q; ++q) {
-#pragma unroll
-            for (int tap = 0; tap < NTAPS; ++tap, ++g) {
-                const unsigned char* pa = patch + toffr[tap];
-                const unsigned char* wb = wring + (g % 3) * WSTG;
-                const unsigned char* npa = patch + toffr[tap + 1 < NTAPS ? tap + 1 : 0];
-                const unsigned char* nwb = wring + ((g + 1) % 3) * WSTG;
-                if (tap + 1 < NTAPS) stage(pa, wb, npa, nwb, std::true_type{});
-                else stage(pa, wb, npa, nwb, std::false_type{});      // next stage: new slab (patch not there yet) or none
-                __syncthreads();                  // end of stage g
-                if (tap == NTAPS - 1) {
-                    if (sl == nslab - 1) epilogue((int)blockIdx.x + tk * (int)gridDim.x);     // while the staging waves write the next patch
-                    if (q + 1 < Q) {
-                        __syncthreads();          // the staging waves have written the next patch
-                        load_all(npa, nwb);
-                    }
-                }
-            }
-            if (++sl == nslab) { sl = 0; ++tk; }
-        }
-    }
-}
-
-
 template <int BN>
 int launch_ptile(const XmcConvDesc& d, const TileCfg& t, hipStream_t st) {
     int maxpatch = 0;
@@ -1139,29 +850,6 @@ int launch_tile(const XmcConvDesc& d, const TileCfg& t, hipStream_t st) {
     return 0;
 }
 
-int launch_wtile(const XmcConvDesc& d, const TileCfg& t, hipStream_t st) {
-    int maxpatch = 0;
-    for (int z = 0; z < d.nclass; ++z) maxpatch = t.PH[z] * t.PW[z] > maxpatch ? t.PH[z] * t.PW[z] : maxpatch;
-    if (maxpatch > 384) return XMC_ESHAPE;
-    const size_t lds = (size_t)((maxpatch * 160 + 15) & ~15) + (size_t)3 * 128 * 160;
-    if (lds > XMC_MAX_DYN_LDS) return XMC_ESHAPE;
-    const int ntiles = d.N * t.tiles_y * t.tiles_x, ny = d.CDw / 128;
-    int gx = 256 / (ny * d.nclass);               // one 8-wave workgroup per CU, persistent over its tiles
-    if (gx < 1) gx = 1;
-    if (gx > ntiles) gx = ntiles;
-    dim3 grid((unsigned)gx, (unsigned)ny, (unsigned)d.nclass);
-    if (d.ntaps == 9) {
-        XMC_ALLOW_BIG_LDS(wtile_kernel<9>);
-        hipLaunchKernelGGL(wtile_kernel<9>, grid, dim3(512), lds, st, d, t, ntiles);
-    } else {
-        XMC_ALLOW_BIG_LDS(wtile_kernel<4>);
-        hipLaunchKernelGGL(wtile_kernel<4>, grid, dim3(512), lds, st, d, t, ntiles);
-    }
-    xmc_note_kernel("wtile_kernel<%d>", d.ntaps);
-    XMC_LAUNCH_CHECK();
-    return 0;
-}
-
 }  // namespace
 
 // Returns 1 if the descriptor is eligible for the halo-tile kernel (and fills cfg), 0 otherwise.
@@ -1172,9 +860,7 @@ static int tile_plan(const XmcConvDesc* d, TileCfg* t) {
     if (d->SA != 1 && !(s2 && !no_s2 && d->nclass == 1 && d->ntaps == 16 && d->CS == 32 && d->CDw <= 64 && d->DA == 1)) return 0;
     if (d->CS % 32 != 0 || d->MW % 16 != 0) return 0;
     if (d->ntaps < 2) return 0;                       // 1x1: nothing to reuse, the gather kernel streams it
-    static const bool no_wt = xmc_debug_off("no_wtile2");
-    const bool wide = d->CDw > 64 && d->CS > 64;
-    if (wide && (no_wt || d->CDw % 128 != 0 || d->CS % 64 != 0 || d->nclass != 1 || d->ntaps != 9)) return 0;   // gather kernel (the 4-class 2x2-tap form measured no faster: one patch per class)
+    if (d->CDw > 64 && d->CS > 64) return 0;          // wide layers: the streamed-weights kernel (conv_wtile.hip) or the gather kernel
     int TW = (d->MW >= 32 && !s2) ? 32 : 16;
     int TH = s2 ? 8 : 256 / TW;
     if (d->MH % TH != 0 || d->MW % TW != 0) return 0;
@@ -1221,10 +907,6 @@ int xmc_conv_tile_try(const XmcConvDesc* d, void* stream) {
     if (!tile_plan(d, &t)) return 1;   // not eligible
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     int rc;
-    if (d->CDw > 64 && d->CS > 64) {                  // wide: weights streamed through an LDS ring
-        rc = launch_wtile(*d, t, st);
-        return rc == XMC_ESHAPE ? 1 : rc;
-    }
     static const bool no_pt = xmc_debug_off("no_ptile");
     if (!no_pt && d->CS <= 64 && t.slab == d->CS && d->CDw <= 64) {          // persistent, weights resident
         rc = d->CDw == 64 ? launch_ptile<64>(*d, t, st) : launch_ptile<32>(*d, t, st);

@@ -21,6 +21,9 @@ from . import prof
 
 # ------------------------------------------------------------------------------------------ config
 _state = threading.local()
+# kernel / operator A/B switches (comma-separated tokens; unset in production).  The C dispatchers read the same variable
+# (common.h: xmc_debug_off); the one host-side token is "no_fused_blocks" (blocks composed from the fine-grained Functions).
+_DEBUG_DISPATCH = frozenset(t for t in os.environ.get("XMC_DEBUG_DISPATCH", "").split(",") if t)
 _PRECISION = os.environ.get("XMC_PRECISION", "bf16")
 
 
@@ -70,7 +73,7 @@ class composable:
 
 
 def fused_blocks():
-    return not getattr(_state, "composable", False) and not os.environ.get("XMC_NO_FUSED_BLOCKS")
+    return not getattr(_state, "composable", False) and "no_fused_blocks" not in _DEBUG_DISPATCH
 
 
 class no_wgrad:

@@ -52,9 +52,8 @@ class _ModMLP(nn.Sequential):
             nn.LeakyReLU(0.2, inplace=True),
             nn.Conv2d(2 * CARD * SD, CARD * PW, 1, 1, 0, groups=CARD))
 
-    def forward(self, cond):                      # cond [B,16,nef+4] -> [B,128]
-        h = F.leaky_relu(_grouped_vec(cond, self[0]), 0.2)
-        return _grouped_vec(h, self[2]).reshape(cond.size(0), -1)
+    def forward(self, cond):
+        raise RuntimeError("_ModMLP holds the parameters of a gamma / beta head; it is evaluated inside ops.concept_stage")
 
 
 class ConceptReasoner(nn.Module):
@@ -64,9 +63,8 @@ class ConceptReasoner(nn.Module):
         self.normalize = False                    # forced off upstream (308)
         self.proj_edge = nn.Linear(state_dim, cardinality, bias=False)
 
-    def forward(self, x, **kwargs):               # x [B,16,4]
-        adj = torch.tanh(F.linear(x, self.proj_edge.weight))
-        return F.relu(x + torch.matmul(adj, x))
+    def forward(self, x, **kwargs):
+        raise RuntimeError("ConceptReasoner holds proj_edge; the reasoning step runs inside ops.concept_stage (csrc/concept.hip)")
 
 
 class _SamplerBase(nn.Module):
@@ -79,6 +77,8 @@ class _SamplerBase(nn.Module):
             self.gn1 = nn.GroupNorm(cardinality, sw)
             self.gn2 = nn.GroupNorm(cardinality, sw)
 
+    # pool / _attend / ConceptSampler.forward: the un-fused form, used by the word-attention generator (concept_gan.py), whose
+    # per-concept algebra is not in csrc/concept.hip
     def pool(self, x, q, scale):
         """region attention with an already normalised query: x [B,H,W,128], q [B,16,4] f32 -> pooled x [B,16,8]."""
         key = self.key_gconv(x)
@@ -110,9 +110,7 @@ class CondConceptSampler(_SamplerBase):
         self._init_common(cardinality, bottleneck_width, state_dim, normalize)
 
     def forward(self, x, sent_embs):
-        B = x.size(0)
-        q = _grouped_vec(sent_embs.view(B, 1, -1).expand(B, self.cardinality, -1), self.query_gconv)
-        return self._attend(x, q, 1.0)
+        raise RuntimeError("CondConceptSampler is evaluated by InConceptBlock.forward (ops.concept_query + ops.concept_stage)")
 
 
 class ConceptSampler(_SamplerBase):
@@ -147,9 +145,6 @@ class _ConceptBlockBase(nn.Module):
             return ops.groupnorm(e, self.gn.weight, self.gn.bias, self.cardinality, slope=0.2)
         return ops.lrelu(e)
 
-    def _modulate(self, out, gc, ctx, gmlp, bmlp):
-        cond = torch.cat([gc, ctx], dim=2)
-        return ops.affine_lrelu(out, gmlp(cond), bmlp(cond))
 
 
 class InConceptBlock(_ConceptBlockBase):
@@ -196,12 +191,6 @@ class OutConceptBlock(_ConceptBlockBase):
         self.sent_linear2 = nn.Linear(cond_dim, state_dim, bias=False)
         self.gamma1_gconv, self.beta1_gconv = _ModMLP(cgw), _ModMLP(cgw)
         self.gamma2_gconv, self.beta2_gconv = _ModMLP(cgw), _ModMLP(cgw)
-
-    @staticmethod
-    def get_context_embs(state_embs, sent_embs):
-        """state [B,p',C], sentence [B,p',1] -> softmax over concepts of <sent, state>, re-weighted states (471-478)."""
-        attn = F.softmax(torch.matmul(sent_embs.transpose(1, 2), state_embs), dim=2)
-        return state_embs * attn
 
     def forward(self, x, sent_embs):
         B = x.size(0)
