@@ -68,3 +68,84 @@ def test_full_size_iteration_runs_and_is_reproducible():
         assert v == v and abs(v) < 1e6, key
         g_step = key in ("errG", "errG_fake", "gs_loss", "disc_loss")
         assert abs(v - outs[1][key]) <= (1e-3 if g_step else 1e-6) * abs(v) + 1e-6, (key, v, outs[1][key])
+
+
+def _d_backward(netD, netG, imgs, sent, r_feat):
+    """D forward + backward under a loss LINEAR in the feature map (sum(feat * r) + sum(logit)): returns (d loss / d image,
+    {name: weight gradient}) -- linear so that gradients of batch slices add up exactly."""
+    x = imgs.clone().requires_grad_()
+    feat = netD(x)
+    logit = netD.COND_DNET(feat, sent_embs=sent)[0]
+    loss = (feat.float() * r_feat).sum() + logit.float().sum()
+    netD.zero_grad()
+    loss.backward()
+    return x.grad.detach().clone(), {n: p.grad.detach().clone() for n, p in netD.named_parameters() if p.grad is not None}
+
+
+@pytest.mark.parametrize("size,batch,mode", [(256, 256, "bf16"), (64, 64, "bf16"), (64, 64, "fp32")])
+def test_full_size_backward_equals_sum_of_batch_slices(size, batch, mode):
+    """BASELINE config 4 (256 px, 256 images) and config 2 (64 px, 64 images) at their REAL batch through the discriminator's
+    backward pass, by a size-independent property: the network does not couple samples, so under a loss linear in its outputs
+      * d loss / d image of a sample slice of the full-batch backward == the backward of just that slice, and
+      * every weight gradient of the full batch == the sum of the weight gradients of its two halves.
+    The full batch takes the large-launch kernels (>= 65 536-pixel tile thresholds, streaming 1x1 kernels, persistent tile
+    loops over all 256 CUs); the slices are the sizes the oracle-pinned iteration tests run at."""
+    ops.set_precision(mode)
+    cfg, h = setup_cfg("df_gan_damsm_nomagp.yml", **{"IMG.SIZE": size})
+    assert h.nch == 32
+    PG, PD = X.synth_params(X.gen_shapes(h), 3), X.synth_params(X.netd_shapes(h), 4)
+    b = X.synth_batch(h, batch, seed=31, words_len=cfg.TEXT.MAX_LENGTH)
+    netG, netD, _, _ = build_product(h, PG, PD)
+    imgs = b["imgs"].to(DEV)
+    with torch.no_grad():
+        sent = netG.proj_sent(b["sent_embs"].to(DEV))
+    g = torch.Generator().manual_seed(5)
+    r = torch.randn(batch, 16 * 32, 4, 4, generator=g).to(DEV)
+    dx, dw = _d_backward(netD, netG, imgs, sent, r)
+    hb = batch // 2
+    dx0, dw0 = _d_backward(netD, netG, imgs[:hb], sent[:hb], r[:hb])
+    dx1, dw1 = _d_backward(netD, netG, imgs[hb:], sent[hb:], r[hb:])
+    k = 8 if size == 64 else 2
+    dxe, _ = _d_backward(netD, netG, imgs[batch - k:], sent[batch - k:], r[batch - k:])
+    # data gradients: different batch sizes may take different kernels (summation order; in bf16 a rounding boundary now and then)
+    t = 1e-5 if mode == "fp32" else 1e-2
+    assert rel_err(dx[:hb], dx0) < t and rel_err(dx[hb:], dx1) < t, (rel_err(dx[:hb], dx0), rel_err(dx[hb:], dx1))
+    assert rel_err(dx[batch - k:], dxe) < t, rel_err(dx[batch - k:], dxe)
+    assert set(dw) == set(dw0) == set(dw1)
+    worst = 0.0
+    for n in dw:
+        e = rel_err(dw[n], dw0[n] + dw1[n])
+        worst = max(worst, e)
+        # f32 accumulation of identical bf16 / f32 products in another order (atomics): 1e-4; bf16 mode re-rounds the
+        # intermediate gradient tensors when the batch changes kernels: 1e-2
+        assert e < (1e-4 if mode == "fp32" else 1e-2), (n, e)
+    print(f"\n[{size}px b{batch} {mode}] dgrad slices {rel_err(dx[:hb], dx0):.1e}, wgrad full vs sum of halves worst {worst:.1e}")
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_config2_generator_full_batch_equals_slices(mode):
+    """config 2's generator at batch 64: forward and weight gradients of the full batch == those of its batch-8 slices (the
+    batch size the oracle-pinned NCH=32 iteration test runs at)."""
+    ops.set_precision(mode)
+    cfg, h = setup_cfg("df_gan_damsm_nomagp.yml")
+    PG, PD = X.synth_params(X.gen_shapes(h), 3), X.synth_params(X.netd_shapes(h), 4)
+    b = {k_: v.to(DEV) for k_, v in X.synth_batch(h, 64, seed=32, words_len=cfg.TEXT.MAX_LENGTH).items()}
+    netG, _, _, _ = build_product(h, PG, PD)
+    r = torch.randn(64, 3, 64, 64, generator=torch.Generator().manual_seed(6)).to(DEV)
+
+    def run(sl):
+        netG.zero_grad()
+        img = netG(noise=b["noise"][sl], sent_embs=b["sent_embs"][sl], words_embs=b["words_embs"][sl], mask=b["mask"][sl])
+        (img * r[sl]).sum().backward()
+        return img.detach().clone(), {n: p.grad.detach().clone() for n, p in netG.named_parameters() if p.grad is not None}
+
+    img, gw = run(slice(0, 64))
+    acc = None
+    t = 1e-5 if mode == "fp32" else 2e-2
+    for i in range(8):
+        im_i, gw_i = run(slice(8 * i, 8 * i + 8))
+        assert mean_abs_err(img[8 * i:8 * i + 8], im_i) < t
+        acc = gw_i if acc is None else {n: acc[n] + gw_i[n] for n in acc}
+    worst = max(rel_err(gw[n], acc[n]) for n in gw)
+    assert worst < (2e-4 if mode == "fp32" else 3e-2), worst
+    print(f"\n[G 64px b64 {mode}] weight gradients full vs sum of 8 slices: worst {worst:.1e}")

@@ -94,6 +94,9 @@ STEP_CASES = [
     ("df_gan_damsm_nomagp.yml", {"IMG.SIZE": 128, "TRAIN.NCH": 8}, 2, 1),
     ("df_gan_damsm.yml", {"TRAIN.NCH": 8, "TRAIN.ENCODER_LOSS.B_GLOBAL": True}, 6, 1),   # global positives
     ("concept_in_df_gan_damsm_nomagp.yml", {"TRAIN.NCH": 8}, 3, 1),                      # sentence->region attention G
+    # BASELINE config 3's resolution: the softmax over 16 384 regions and its backward, the LDS-patch grouped 3x3 and the
+    # diagonal-block weight gradient at 128x128 under a whole-iteration gradient comparison
+    ("concept_in_df_gan_damsm_nomagp.yml", {"TRAIN.NCH": 8, "IMG.SIZE": 128}, 2, 1),
     ("concept_out_df_gan_sbert_damsm_nomagp.yml", {"TRAIN.NCH": 8}, 3, 1),               # self-attention G, E=768
     ("concept_in_df_gan_sbert_n2_damsm.yml", {"TRAIN.NCH": 8}, 3, 2),                    # N_CRITIC=2 + MA-GP
     ("df_gan_damsm_nomagp.yml", {"TRAIN.NCH": 8, "GEN.ENCODER_NAME": "CONCEPT_OUTATTN_GEN"}, 4, 2),   # word-attention G (BatchNorm)
