@@ -319,6 +319,7 @@ int xmc_conv_tile_try(const XmcConvDesc* d, void* stream);                      
 int xmc_conv_thin_try(const XmcConvDesc* d, void* stream);                            // conv_thin.hip
 int xmc_conv_pw1x1_try(const XmcConvDesc* d, void* stream);                           // conv_thin.hip
 int xmc_conv_wtile_try(const XmcConvDesc* d, void* stream);                           // conv_wtile.hip
+int xmc_conv_wtile3_try(const XmcConvDesc* d, void* stream);                          // conv_wtile3.hip
 int xmc_conv_ptile_pool_try(const XmcConvDesc* d, void* stream);                      // conv_tile.hip
 int xmc_conv_group_try(const XmcConvDesc* d, void* stream);                           // conv_group.hip
 int xmc_conv_thin_out_try(const XmcConvDesc* d, void* stream);                        // conv_thin.hip
@@ -341,9 +342,11 @@ extern "C" int xmc_conv_igemm(const XmcConvDesc* d, void* stream) {
     if (d->res_mode < 0 || d->res_mode > 2 || (d->res_mode == 2 && (d->DA != 1 || (d->DH & 1) || (d->DW & 1)))) return XMC_ESHAPE;
     static const bool no_tile = xmc_debug_off("no_tile");
     static const bool no_wt2 = xmc_debug_off("no_wtile_v2");
+    static const bool no_wt3 = xmc_debug_off("no_wtile3");
     int rc = 1;
     if (!no_tile && d->dst_pool) {        // kernels that write the pooled third output from their epilogue
         rc = xmc_conv_thin_try(d, stream);
+        if (rc > 0 && !no_wt3) rc = xmc_conv_wtile3_try(d, stream);
         if (rc > 0 && !no_wt2) rc = xmc_conv_wtile_try(d, stream);
         if (rc > 0) rc = xmc_conv_ptile_pool_try(d, stream);
         if (rc <= 0) return rc;
@@ -355,6 +358,7 @@ extern "C" int xmc_conv_igemm(const XmcConvDesc* d, void* stream) {
         if (rc > 0) rc = xmc_conv_thin_try(&dd, stream);
         if (rc > 0) rc = xmc_conv_thin_out_try(&dd, stream);
         if (rc > 0) rc = xmc_conv_pw1x1_try(&dd, stream);
+        if (rc > 0 && !no_wt3) rc = xmc_conv_wtile3_try(&dd, stream);
         if (rc > 0 && !no_wt2) rc = xmc_conv_wtile_try(&dd, stream);
         if (rc > 0) rc = xmc_conv_tile_try(&dd, stream);
         if (rc < 0) return rc;

@@ -1,0 +1,525 @@
+// Streamed-weights halo-patch convolution, third form (round 3): two MFMA waves per SIMD in ping-pong, LDS-DMA staging, no staging
+// waves.  Forward / data gradient of the wide layers of D and G (Cin % 64 == 0, Cout % 128 == 0), 16-bit storage.
+//
+// What it keeps from conv_wtile.hip: a persistent workgroup per CU owns 256 output pixels (TH x TW of one image) x BN output
+// channels; K is cut into slabs of 64 source channels; per slab the input patch (tile + halo) is staged in LDS ONCE and every tap
+// reads its pixel fragments from it at a shifted offset, so only the weights of each (slab, tap) STAGE are streamed.
+// What changes (the role-split kernel sat at 41 % MfmaUtil with LDS ~2/3 busy and staging waves that cannot
+// issue faster than the vector-memory path accepts):
+//   * ALL eight waves are MFMA waves.  Wave tile 128 pixels x 64 channels (BN = 256: 2 x 4 waves) -- 24 fragment reads per 64
+//     MFMAs = 37 % of the LDS read bandwidth at the MFMA rate instead of 50-67 % -- or 64 x 64 (BN = 128: 4 x 2 waves).
+//   * The two waves of a SIMD (w and w + 4) run the SAME program one barrier apart: while one is in a LOAD phase (fragment
+//     ds_reads for its next 16 MFMAs + its share of the staging) the other is in its MFMA phase (16 back-to-back MFMAs, nothing
+//     else), then they swap.  The matrix pipe of every SIMD always has one wave feeding it; LDS latency, address arithmetic and
+//     the staging issue are all in the partner's shadow.  Two barriers per 16 MFMAs per wave, raw s_barrier (no vmcnt drain).
+//   * Staging is LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write -- the 79 B/clk store path and the staging
+//     registers are out of the loop).  LDS images are lane-linear; the bank-conflict swizzle (16-byte chunk index XOR (row & 7),
+//     conflict-free ds_read_b128 for the row = lane & 15 fragment pattern at ANY row alignment, checked by enumeration) is
+//     applied to the per-lane SOURCE address and again on the read.  Halo pixels outside the image read a 16-byte zero page.
+//   * Weight ring: 2 slots of BN x 128 B at BN = 256 (stage g+1 is fetched during stage g, issued in phase 1, awaited in phase 3),
+//     3 slots at BN = 128 (two phases per stage: stage g+2 issued in phase 1 of stage g, awaited in phase 1 of stage g+1).
+//     Two patch buffers (slab q+1 is fetched during slab q, one or two 1 KB pieces per wave and stage).
+//     2 x 32 + 2 x 42.5 KB = 149 KB.
+// Hazard bookkeeping (cdna_hip_programming.md, "Read a staged buffer one phase AFTER the wait that retires it"): interval i is the
+// time between barriers i-1 and i; the first-half waves (0-3) run LOAD(k) in interval 2k and MFMA(k) in 2k+1, the second half
+// LOAD(k) in 2k+1 and MFMA(k) in 2k+2.  RAW: a DMA is awaited (counted vmcnt) before the barrier that ends the awaiting phase, and
+// the first read of that data is at least one barrier later for either half.  WAR: a slot is re-filled no earlier than two
+// intervals after the last ds_read of it was ISSUED, and those reads were retired (lgkmcnt(0) in front of the MFMAs) one interval
+// earlier.
+//
+// MODE 0: unit source stride, 3x3 or 2x2 tap sets (the parity classes of a stride-2 data gradient / fused upsample conv: one
+//         class per blockIdx.z).  MODE 1: the 4x4 stride-2 forward as a dense 2x2-tap convolution over the space-to-depth view,
+//         gathered from NHWC while it is staged (see conv_wtile.hip).
+// Takes over: F.conv2d at df_gan.py:187-188 (G_Block c1/c2), 273,276 (resD conv_r) for the wide layers and the matching halves of
+// errD.backward() / errG.backward() (train_gan.py:228,288).
+#include "common.h"
+#include <stdlib.h>
+#include <type_traits>
+
+namespace {
+
+struct W3Cfg {
+    int TH, TW, log2TW;
+    int tiles_y, tiles_x;
+    int PH[XMC_MAX_CLASSES], PW[XMC_MAX_CLASSES];        // patch size per class
+    int dh0[XMC_MAX_CLASSES], dw0[XMC_MAX_CLASSES];      // min tap offsets per class (MODE 0)
+    int nslab;                                           // K slabs per tile: CS/64 (MODE 0), 4*CS/64 (MODE 1)
+    int patch_bytes;                                     // one patch buffer: 384 pixel slots x 128 B
+    int8_t tsel[4][4];                                   // MODE 1: tap index of (dy*2+dx, ta*2+tb)
+};
+
+constexpr int kPI = 6;              // 1 KB patch pieces (8 pixels x 128 B) per wave and slab, at most
+constexpr int kPieces = 44;         // pieces of a patch buffer: 352 pixel slots (the largest patch, 10 x 34, has 340 pixels)
+constexpr int kPatchSlots = kPieces * 8;
+
+__device__ __attribute__((aligned(16))) unsigned char g_zero16[16];     // what a halo pixel outside the image reads
+
+typedef __attribute__((address_space(3))) unsigned char lds_u8;
+typedef const __attribute__((address_space(1))) void* gptr_t;
+
+// one LDS-DMA: 64 lanes x 16 bytes from per-lane global addresses to the wave-uniform LDS address `dst` + lane * 16
+__device__ __forceinline__ void glds16(const void* src, lds_u8* dst) {
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+}
+
+// WM = wave rows (pixel direction): 2 -> BN = 256, wave tile 128 x 64, four phases per stage, ring of 2
+//                                   4 -> BN = 128, wave tile  64 x 64, two phases per stage, ring of 4
+template <int NTAPS, int MODE, int WM>
+__global__ __launch_bounds__(512) void wtile3_kernel(const XmcConvDesc d, const W3Cfg t, int ntiles) {
+    constexpr int WN = 8 / WM, BN = 64 * WN;
+    constexpr int TMW = 16 / WM;                 // 16-pixel blocks per wave (8 or 4)
+    constexpr int TNW = 4;                       // 16-channel blocks per wave
+    constexpr int NPH = TMW / 2;                 // phases (clusters of 16 MFMAs) per stage: 4 or 2
+    constexpr int RING = WM == 2 ? 2 : 4;
+    constexpr int WSTG = BN * 128;               // bytes of one weight stage
+    constexpr int NI = BN / 64;                  // 1 KB weight pieces per wave and stage (4 or 2)
+    constexpr int PPS = (kPI + NTAPS - 1) / NTAPS;   // patch pieces per wave and stage (1 for 3x3, 2 for 2x2 tap sets)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // everything lives in ONE LDS array (a second __shared__ object beside an LDS-DMA target can make hipcc drain vmcnt in front
+    // of every ds_read): [ring][2 patches][tables]
+    unsigned char* const wring = smem;
+    unsigned char* const patch0 = smem + RING * WSTG;
+    const int pbytes = t.patch_bytes;
+    int* const s_toff = reinterpret_cast<int*>(smem + RING * WSTG + 2 * pbytes);      // [16] tap -> patch PIXEL offset
+    int* const s_wbase = s_toff + XMC_MAX_TAPS;                                       // [16] (slab group, tap) -> first unit of the weight slice
+    int* const s_slab = s_wbase + XMC_MAX_TAPS;                                       // [64] MODE 1: slab -> (group << 8) | channel block
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = wave >> 2;                  // SIMD partner: waves w and w + 4 share a SIMD
+    const int wr = WM == 2 ? (wave >> 2) : (wave & 3);      // pixel slice of the tile
+    const int wc = WM == 2 ? (wave & 3) : (wave >> 2);      // 64-channel slice of BN
+    const int n0 = blockIdx.y * BN;
+    const int cls = blockIdx.z;
+    const int tpi = t.tiles_y * t.tiles_x;
+    const int PW = t.PW[cls], PH = t.PH[cls];
+    const int dh0 = MODE == 0 ? t.dh0[cls] : 0, dw0 = MODE == 0 ? t.dw0[cls] : 0;
+    const int cs_units = d.CS / 8;
+    const int nslab = t.nslab;
+    const int cb = d.CS / 64;
+    if (tid < XMC_MAX_TAPS) {
+        if (MODE == 0) {
+            const int tt = tid < NTAPS ? tid : 0;
+            s_toff[tid] = (d.dh[cls][tt] - dh0) * PW + (d.dw[cls][tt] - dw0);
+            s_wbase[tid] = d.wi[cls][tt] * d.CDw * cs_units;
+        } else {
+            const int g4 = tid >> 2, tp = tid & 3;                     // tid = (dy*2+dx)*4 + (ta*2+tb)
+            s_toff[tid] = (tp >> 1) * PW + (tp & 1);
+            s_wbase[tid] = d.wi[0][t.tsel[g4][tp]] * d.CDw * cs_units;
+        }
+    }
+    if (tid >= 64 && tid < 128) {
+        const int sl = tid - 64;
+        s_slab[sl] = MODE == 0 ? sl : (((sl / cb) << 8) | (sl % cb));
+    }
+    const int mytiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int Q = mytiles * nslab;               // patches (tile, slab) of this workgroup, one stream
+    __syncthreads();
+    if (mytiles <= 0) return;
+
+    const u32x4* __restrict__ src16 = reinterpret_cast<const u32x4*>(d.src);
+    const u32x4* __restrict__ w16 = reinterpret_cast<const u32x4*>(d.wpk);
+    const u32x4* const zero16 = reinterpret_cast<const u32x4*>(g_zero16);
+
+    // ------------------------------------------------------------------------------------------------ staging addresses
+    // weights: piece i of this wave covers physical ring rows (wave * NI + i) * 8 + (lane >> 3), LDS chunk slot lane & 7, which
+    // holds logical chunk (lane & 7) ^ (row & 7) of logical channel lrow(row):
+    //   physical row (n-block j, r) <- logical channel (j/2)*32 + (r/4)*8 + (j%2)*4 + r%4, so that lane group fc = r/4 ends with
+    //   channels u*32 + fc*8 .. +7 of unit u = j/2 in its two accumulator blocks (16-byte stores in the epilogue)
+    // (one per-lane register + wave-uniform piece terms: the row of piece gi = wave * NI + i is gi * 8 + (lane >> 3))
+    const int wlane = (n0 + (lane >> 5) * 8 + ((lane >> 3) & 3)) * cs_units + ((lane & 7) ^ (lane >> 3));
+    auto wpiece_off = [&](int i) {               // uniform: (j/2)*32 + (j%2)*4 + (r/8)*16 channels, j = gi / 2, r/8 = gi % 2
+        const int gi = wave * NI + i, j = gi >> 1;
+        return ((j >> 1) * 32 + (j & 1) * 4 + (gi & 1) * 16) * cs_units;
+    };
+    // patch: piece i covers pixel slots (wave * kPI + i) * 8 + (lane >> 3), chunk slot lane & 7 <- logical chunk ^ (pixel & 7)
+    int psrc[kPI];
+    unsigned hpack = 0;                          // 5 bits per piece: halo nibble (which tile borders the pixel lies beyond) | 16 = not a patch pixel
+#pragma unroll
+    for (int i = 0; i < kPI; ++i) {
+        const int pp = (wave * kPI + i) * 8 + (lane >> 3);
+        const bool in = pp < PH * PW;
+        const int py = pp / PW, px = pp - py * PW;
+        const int ch = (lane & 7) ^ (pp & 7);
+        unsigned hb;
+        if (MODE == 0) {
+            psrc[i] = in ? ((dh0 + py) * d.SW + (dw0 + px)) * cs_units + ch : 0;
+            hb = (py < -dh0 ? 1u : 0u) | (py >= t.TH - dh0 ? 2u : 0u) | (px < -dw0 ? 4u : 0u) | (px >= t.TW - dw0 ? 8u : 0u);
+        } else {
+            psrc[i] = in ? ((2 * py - 1) * d.SW + (2 * px - 1)) * cs_units + ch : 0;
+            hb = (py == 0 ? 1u : 0u) | (py == t.TH ? 2u : 0u) | (px == 0 ? 4u : 0u) | (px == t.TW ? 8u : 0u);
+        }
+        hpack |= (in ? hb : 16u) << (5 * i);
+    }
+    lds_u8* const lds0 = (lds_u8*)smem;
+    const int wpiece0 = wave * NI * 1024;
+
+    // patch q = (tile, slab): base unit of its pixel (0,0) / channel block, and which tile borders lie on the image border
+    int pbase = 0;
+    unsigned pborder = 0;
+    auto patch_setup = [&](int q) {
+        const int tk = q / nslab, sl = q - tk * nslab;
+        const int tile = (int)blockIdx.x + tk * (int)gridDim.x;
+        const int img = tile / tpi, trem = tile - img * tpi;
+        const int a0 = (trem / t.tiles_x) * t.TH, b0 = (trem % t.tiles_x) * t.TW;
+        if (MODE == 0) {
+            pbase = ((img * d.SH + a0) * d.SW + b0) * cs_units + sl * 8;
+            pborder = (a0 + dh0 < 0 ? 1u : 0u) | (a0 + PH + dh0 > d.SH ? 2u : 0u) | (b0 + dw0 < 0 ? 4u : 0u) | (b0 + PW + dw0 > d.SW ? 8u : 0u);
+        } else {
+            const int si = s_slab[sl];
+            const int grp = si >> 8, cbi = si & 0xff, dy = grp >> 1, dx = grp & 1;
+            pbase = ((img * d.SH + 2 * a0 + dy) * d.SW + 2 * b0 + dx) * cs_units + cbi * 8;
+            pborder = ((a0 == 0 && dy == 0) ? 1u : 0u) | ((a0 + t.TH == d.MH && dy == 1) ? 2u : 0u) |
+                      ((b0 == 0 && dx == 0) ? 4u : 0u) | ((b0 + t.TW == d.MW && dx == 1) ? 8u : 0u);
+        }
+    };
+    // Every lane of every piece issues (halo pixels outside the image and slots past the end of the patch copy the zero page).  The
+    // eight waves cover 48 pieces, the buffer has 44: pieces 44-47 are re-directed onto piece 43, which -- like them -- lies wholly
+    // past the largest patch (340 pixels < 43 x 8) and only ever receives zeros.  No branch, the same count on every wave.
+    auto patch_piece = [&](int i, int buf, int z) {     // i: compile-time piece index; z: opaque zero (keeps the 64-bit address
+        // arithmetic at the point of use instead of in hoisted, spilled registers)
+        const bool ok = (((hpack + (unsigned)z) >> (5 * i)) & (pborder | 16u)) == 0;
+        const u32x4* s = ok ? src16 + (unsigned)(pbase + psrc[i] + z) : zero16;
+        const int g = wave * kPI + i;
+        glds16(s, lds0 + RING * WSTG + buf * pbytes + (g < kPieces ? g : kPieces - 1) * 1024);
+    };
+    // weights of stage (slab sl, tap): the same for every tile
+    auto weights = [&](int sl, int tap, int slot, int z) {
+        int wb;
+        if (MODE == 0) {
+            wb = s_wbase[tap] + sl * 8;
+        } else {
+            const int si = s_slab[sl];
+            wb = s_wbase[(si >> 8) * 4 + tap] + (si & 0xff) * 8;
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) glds16(w16 + (unsigned)(wb + wpiece_off(i) + wlane + z), lds0 + slot * WSTG + wpiece0 + i * 1024);
+    };
+
+    // ------------------------------------------------------------------------------------------------ fragment addresses
+    const int fr = lane & 15, fc = lane >> 4;
+    // patch PIXEL index of (pixel block i, lane fr) at tap offset 0: ppl0 + (i / 2) * ps2 + (i % 2) * ps1 (8 x 32 tiles: block i is
+    // half a tile row; 16 x 16 tiles: a whole row) -- one per-lane register, the block terms are wave-uniform
+    int ppl0;
+    {
+        const int ml = wr * (256 / WM) + fr;
+        ppl0 = (ml >> t.log2TW) * PW + (ml & (t.TW - 1));
+    }
+    const int ps1 = t.log2TW == 5 ? 16 : PW, ps2 = t.log2TW == 5 ? PW : 2 * PW;
+    // weight fragment (n-block j of this wave, row fr, chunk ksub*4 + fc): chunk slot = chunk ^ (row & 7), row & 7 == fr & 7
+    const int wf0 = (wc * TNW * 16 + fr) * 128 + ((fc ^ (fr & 7)) << 4), wf1 = wf0 ^ 64;      // K sub-step 0 / 1
+
+    f32x4 acc[TMW][TNW];
+#pragma unroll
+    for (int i = 0; i < TMW; ++i)
+#pragma unroll
+        for (int j = 0; j < TNW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int cd8 = d.CD / 8;
+    const int ch0 = n0 + wc * 64 + fc * 8;       // first channel of this lane's unit 0
+    const int nw8 = (n0 + wc * 64) >> 3;
+    // epilogue from registers: acc[i][j][r] = pixel (block i, fr), channel n0 + wc*64 + (j/2)*32 + fc*8 + (j%2)*4 + r; clears acc.
+    // order: bias, activation, [second output], alpha, LeakyReLU' mask, (row-indexed / half-resolution, scaled) residual, pool.
+    auto epilogue = [&](int tile) {
+        int lane_op = fr;                        // opaque: keeps the store addresses from being hoisted out of the tile loop (spills)
+        asm volatile("" : "+v"(lane_op) :: "memory");
+        const int img = tile / tpi, trem = tile - img * tpi;
+        const int a0 = (trem / t.tiles_x) * t.TH, b0 = (trem % t.tiles_x) * t.TW;
+        const int dbase = (((img * d.DH + a0 * d.DA + d.dph[cls]) * d.DW) + b0 * d.DA + d.dpw[cls]) * cd8 + nw8;
+        const int rbase = d.res_mode ? ((img * d.MH + a0) * d.MW + b0) * cd8 + nw8 : dbase;
+        const int rsy = d.res_mode ? d.MW : d.DA * d.DW, rsx = d.res_mode ? 1 : d.DA;
+        const float slope = d.act == XMC_ACT_LRELU ? XMC_LRELU : (d.act == XMC_ACT_RELU ? 0.f : 1.f);
+        const float alpha = d.alpha_dev ? *d.alpha_dev : 1.f;
+        const float rs = d.res_scale == 0.f ? 1.f : d.res_scale;
+        bf16x8* __restrict__ dst8 = reinterpret_cast<bf16x8*>(d.dst);
+        const bf16x8* __restrict__ mask8 = reinterpret_cast<const bf16x8*>(d.mask);
+        const bf16x8* __restrict__ res8 = reinterpret_cast<const bf16x8*>(d.res);
+        bf16x8* __restrict__ dst2_8 = reinterpret_cast<bf16x8*>(d.dst2);
+        bf16x8* __restrict__ pool8 = reinterpret_cast<bf16x8*>(d.dst_pool);
+        // four pixel blocks at a time (register pressure: the accumulators of the whole wave tile are live here)
+#pragma unroll
+        for (int g = 0; g < TMW / 4; ++g) {
+            int eo[4], ro[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ml = wr * (256 / WM) + (g * 4 + i) * 16 + lane_op;
+                const int ty = ml >> t.log2TW, tx = ml & (t.TW - 1);
+                eo[i] = dbase + ((ty * d.DA) * d.DW + tx * d.DA) * cd8 + fc;
+                if (d.res_mode == 2)
+                    ro[i] = ((img * (d.DH >> 1) + ((a0 + ty) >> 1)) * (d.DW >> 1) + ((b0 + tx) >> 1)) * cd8 + nw8 + fc;
+                else
+                    ro[i] = rbase + (ty * rsy + tx * rsx) * cd8 + fc;
+            }
+#pragma unroll
+            for (int u = 0; u < TNW / 2; ++u) {
+                if (ch0 + u * 32 >= d.CD) continue;
+                float fin[4][8];
+                bf16x8 mkv[4], rrv[4];
+                if (mask8) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) mkv[i] = mask8[eo[i] + u * 4];
+                }
+                if (res8) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) rrv[i] = res8[ro[i] + u * 4];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float v[8];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { v[r] = acc[g * 4 + i][2 * u][r]; v[4 + r] = acc[g * 4 + i][2 * u + 1][r]; }
+                    if (d.bias) {
+                        const f32x4 b0v = *reinterpret_cast<const f32x4*>(d.bias + ch0 + u * 32), b1v = *reinterpret_cast<const f32x4*>(d.bias + ch0 + u * 32 + 4);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { v[r] += b0v[r]; v[4 + r] += b1v[r]; }
+                    }
+                    if (d.act == XMC_ACT_TANH) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) v[r] = tanhf(v[r]);
+                    } else if (slope != 1.f) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], v[r] * slope);
+                    }
+                    if (dst2_8 || d.round_act) {
+                        bf16x8 o2;
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) { o2[r] = (xmc_h16)v[r]; v[r] = (float)o2[r]; }
+                        if (dst2_8) dst2_8[eo[i] + u * 4] = o2;
+                    }
+                    if (d.alpha_dev) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) v[r] *= alpha;
+                    }
+                    if (mask8) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) v[r] *= lrelu_slope((float)mkv[i][r]);
+                    }
+                    if (res8) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) v[r] += rs * (float)rrv[i][r];
+                    }
+                    bf16x8 o;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) { o[r] = (xmc_h16)v[r]; fin[i][r] = (float)o[r]; }
+                    dst8[eo[i] + u * 4] = o;
+                }
+                if (pool8) {
+                    // 2x2 average of the ROUNDED output (== F.avg_pool2d of dst): the vertical neighbour is pixel block i+2 (8x32
+                    // tiles) or i+1 (16x16 tiles) of the same lane -- both inside this group of four -- the horizontal one lane ^ 1
+#pragma unroll
+                    for (int pr = 0; pr < 2; ++pr) {
+                        const int i0 = t.log2TW == 5 ? pr : 2 * pr;
+                        const int ml = wr * (256 / WM) + (g * 4 + i0) * 16 + lane_op;
+                        const int ty = ml >> t.log2TW, tx = ml & (t.TW - 1);
+                        bf16x8 o;
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) {
+                            float sm = (t.log2TW == 5 ? fin[pr][r] + fin[pr + 2][r] : fin[2 * pr][r] + fin[2 * pr + 1][r]);
+                            sm += __shfl_xor(sm, 1, 64);
+                            o[r] = (xmc_h16)(0.25f * sm);
+                        }
+                        if ((lane_op & 1) == 0)
+                            pool8[((img * (d.DH >> 1) + ((a0 + ty) >> 1)) * (d.DW >> 1) + ((b0 + tx) >> 1)) * cd8 + nw8 + fc + u * 4] = o;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TMW; ++i)
+#pragma unroll
+            for (int j = 0; j < TNW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+
+    int toffr[NTAPS];                            // tap -> patch pixel offset, in scalar registers
+#pragma unroll
+    for (int k = 0; k < NTAPS; ++k) toffr[k] = __builtin_amdgcn_readfirstlane(s_toff[k]);
+
+    // ------------------------------------------------------------------------------------------------ prologue
+    patch_setup(0);
+#pragma unroll
+    for (int i = 0; i < kPI; ++i) patch_piece(i, 0, 0);
+#pragma unroll
+    for (int s0 = 0; s0 < RING - 1; ++s0) weights(0, s0, s0, 0);      // the loop fetches RING - 1 stages ahead (RING - 1 <= 3 < NTAPS)
+    patch_setup(Q > 1 ? 1 : 0);                  // the loop fetches patch q+1 during slab q
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (half == 1) __builtin_amdgcn_s_barrier();     // the second wave of every SIMD runs one interval behind the first
+
+    // ------------------------------------------------------------------------------------------------ the stream
+    u32x4 Wf[TNW], Pf[4];
+    int slot = 0;                                // ring slot of the running stage
+    int sl = 0, tk = 0;
+    for (int q = 0; q < Q; ++q) {
+        const int pcur = (q & 1) * pbytes, pnxt = ((q + 1) & 1) * pbytes;
+        // The fragment addresses of a tap do not depend on q: left alone, loop-invariant code motion hoists all NTAPS x TMW of them
+        // out of the slab loop and spills them (and every scratch re-load drains the LDS-DMA queue with vmcnt(0)).  An opaque zero
+        // per slab keeps them where they are used: three VALU instructions per fragment read, in the partner's MFMA shadow.
+        int zq = 0;
+        asm volatile("" : "+v"(zq));
+        const int sl1 = sl + 1 == nslab ? 0 : sl + 1;
+#pragma unroll
+        for (int tap = 0; tap < NTAPS; ++tap) {
+            const unsigned char* const wb = wring + slot * WSTG;
+            const unsigned char* const pb = patch0 + pcur;
+            // stage to fetch: RING - 1 stages ahead (past the end of the stream it re-fetches valid addresses into a slot nobody reads)
+            constexpr int D = RING - 1;
+            const int ft = tap + D >= NTAPS ? tap + D - NTAPS : tap + D;
+            const int fs = tap + D >= NTAPS ? sl1 : sl;
+            const int fslot = slot + D >= RING ? slot + D - RING : slot + D;
+#pragma unroll
+            for (int p = 0; p < NPH; ++p) {
+                const int ksub = NPH == 4 ? (p >> 1) : p;
+                const int mb = NPH == 4 ? (p & 1) * 4 : 0;          // first pixel block of this cluster
+                // ---------------- LOAD phase of cluster (stage, p)
+                if (NPH == 4 ? (p & 1) == 0 : true) {
+#pragma unroll
+                    for (int j = 0; j < TNW; ++j)
+                        Wf[j] = *reinterpret_cast<const u32x4*>(wb + (ksub ? wf1 : wf0) + zq + j * 2048);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int pp = ppl0 + (((mb + i) >> 1) * ps2 + ((mb + i) & 1) * ps1 + toffr[tap]) + zq;
+                    const int chunk = ((fc + 4 * ksub) ^ pp) & 7;
+                    Pf[i] = *reinterpret_cast<const u32x4*>(pb + pp * 128 + chunk * 16);
+                }
+                // Staging.  Every wait is a full vmcnt(0) on operations issued at least two intervals earlier by this wave, and the
+                // first ds_read of what it retires is at least two barriers later for either half.
+                if (NPH == 4) {
+                    if (p == 1) weights(fs, ft, fslot, zq);              // slot of stage g-1: last read three intervals ago
+                    if (p == 2) {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the weights of phase 1 and the patch pieces of the last stage
+#pragma unroll
+                        for (int e = 0; e < PPS; ++e)
+                            if (tap * PPS + e < kPI) patch_piece(tap * PPS + e, (q + 1) & 1, zq);
+                    }
+                } else {
+                    if (p == 1) {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // everything this wave issued one stage ago
+                        weights(fs, ft, fslot, zq);
+#pragma unroll
+                        for (int e = 0; e < PPS; ++e)
+                            if (tap * PPS + e < kPI) patch_piece(tap * PPS + e, (q + 1) & 1, zq);
+                    }
+                }
+                (void)pnxt;
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                // ---------------- MFMA phase: 16 back-to-back MFMAs, nothing else
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < TNW; ++j)
+                        acc[mb + i][j] = XMC_MFMA_16x16x32(__builtin_bit_cast(bf16x8, Wf[j]), __builtin_bit_cast(bf16x8, Pf[i]), acc[mb + i][j], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+            }
+            slot = slot + 1 == RING ? 0 : slot + 1;
+        }
+        // end of a tile: the epilogue takes the place of (the start of) this wave's next LOAD phase, i.e. it runs beside the SIMD
+        // partner's MFMA phase
+        if (sl == nslab - 1) {
+            epilogue((int)blockIdx.x + tk * (int)gridDim.x);
+            ++tk;
+        }
+        sl = sl1;
+        patch_setup(q + 2 < Q ? q + 2 : Q - 1);
+    }
+    if (half == 0) __builtin_amdgcn_s_barrier();     // same barrier count for every wave
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup's LDS allocation
+}
+
+// Fills the plan; returns 1 when the descriptor is this kernel's case.
+int plan3(const XmcConvDesc* d, W3Cfg* t, int* mode, int* wm) {
+    if (d->dtype != XMC_BF16 || d->out_dtype != XMC_BF16 || d->src_shift != 0) return 0;
+    if (d->CS % 64 != 0 || d->CS > 64 * 64 / 4) return 0;
+    if (d->CDw % 256 == 0) *wm = 2;
+    else if (d->CDw % 128 == 0) *wm = 4;
+    else return 0;
+    if (d->MW % 16 != 0) return 0;
+    const int TW = d->MW >= 32 ? 32 : 16, TH = 256 / TW;
+    if (d->MH % TH != 0 || d->MW % TW != 0) return 0;
+    t->TH = TH; t->TW = TW; t->log2TW = TW == 32 ? 5 : 4;
+    t->tiles_y = d->MH / TH; t->tiles_x = d->MW / TW;
+    int maxpix = 0;
+    if (d->SA == 1) {
+        if (d->ntaps != 9 && d->ntaps != 4) return 0;
+        *mode = 0;
+        t->nslab = d->CS / 64;
+        for (int z = 0; z < d->nclass; ++z) {
+            int hmin = 127, hmax = -128, wmin = 127, wmax = -128;
+            for (int k = 0; k < d->ntaps; ++k) {
+                const int h = d->dh[z][k], w = d->dw[z][k];
+                hmin = h < hmin ? h : hmin; hmax = h > hmax ? h : hmax;
+                wmin = w < wmin ? w : wmin; wmax = w > wmax ? w : wmax;
+            }
+            if (hmin < -TH || hmax > TH || wmin < -TW || wmax > TW) return 0;
+            t->dh0[z] = hmin; t->dw0[z] = wmin;
+            t->PH[z] = TH + (hmax - hmin); t->PW[z] = TW + (wmax - wmin);
+            if (d->SH != d->MH || d->SW != d->MW) return 0;
+            maxpix = t->PH[z] * t->PW[z] > maxpix ? t->PH[z] * t->PW[z] : maxpix;
+        }
+    } else if (d->SA == 2) {
+        if (d->ntaps != 16 || d->nclass != 1 || d->DA != 1 || d->SH != 2 * d->MH || d->SW != 2 * d->MW) return 0;
+        *mode = 1;
+        t->nslab = 4 * (d->CS / 64);
+        if (t->nslab > 64) return 0;
+        for (int g = 0; g < 4; ++g)
+            for (int tp = 0; tp < 4; ++tp) {
+                const int wh = 2 * (tp >> 1) + (g >> 1) - 1, ww = 2 * (tp & 1) + (g & 1) - 1;
+                int found = -1;
+                for (int k = 0; k < 16; ++k)
+                    if (d->dh[0][k] == wh && d->dw[0][k] == ww) found = found < 0 ? k : 99;
+                if (found < 0 || found > 15) return 0;
+                t->tsel[g][tp] = (int8_t)found;
+            }
+        t->PH[0] = TH + 1; t->PW[0] = TW + 1; t->dh0[0] = t->dw0[0] = 0;
+        maxpix = t->PH[0] * t->PW[0];
+    } else {
+        return 0;
+    }
+    if (maxpix > (kPieces - 1) * 8) return 0;      // piece 43 must stay past the end of every patch (patch_piece)
+    if (d->dst_pool && (d->DA != 1 || d->nclass != 1 || (d->DH & 1) || (d->DW & 1))) return 0;
+    if (d->res_mode == 2 && d->DA != 1) return 0;
+    t->patch_bytes = kPatchSlots * 128;
+    if ((int64_t)d->N * d->SH * d->SW * (d->CS / 8) >= (1ll << 31) || (int64_t)d->N * d->DH * d->DW * (d->CD / 8) >= (1ll << 31)) return 0;
+    return 1;
+}
+
+template <int NTAPS, int MODE, int WM>
+int launch3(const XmcConvDesc& d, const W3Cfg& t, hipStream_t st) {
+    constexpr int BN = 64 * (8 / WM), RING = WM == 2 ? 2 : 4;
+    const size_t lds = (size_t)RING * BN * 128 + 2 * (size_t)t.patch_bytes + (size_t)(2 * XMC_MAX_TAPS + 64) * sizeof(int);
+    if (lds > XMC_MAX_DYN_LDS) return XMC_ESHAPE;
+    const int ntiles = d.N * t.tiles_y * t.tiles_x, ny = d.CDw / BN;
+    int gx = 256 / (ny * d.nclass);               // one 8-wave workgroup per CU, persistent over its tiles
+    if (gx < 1) gx = 1;
+    if (gx > ntiles) gx = ntiles;
+    XMC_ALLOW_BIG_LDS((wtile3_kernel<NTAPS, MODE, WM>));
+    hipLaunchKernelGGL((wtile3_kernel<NTAPS, MODE, WM>), dim3((unsigned)gx, (unsigned)ny, (unsigned)d.nclass), dim3(512), lds, st, d, t, ntiles);
+    xmc_note_kernel("wtile3_kernel<%d, %d, %d>", NTAPS, MODE, WM);
+    XMC_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+// entry used by xmc_conv_igemm's dispatcher: 0 = launched, 1 = not this kernel's case, < 0 = error
+int xmc_conv_wtile3_try(const XmcConvDesc* d, void* stream) {
+    W3Cfg t;
+    int mode = 0, wm = 2;
+    if (!plan3(d, &t, &mode, &wm)) return 1;
+    static const bool no128 = xmc_debug_off("no_wtile3_bn128");
+    if (wm == 4 && no128) return 1;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    int rc;
+#define W3_GO(NT_, MD_) (wm == 2 ? launch3<NT_, MD_, 2>(*d, t, st) : launch3<NT_, MD_, 4>(*d, t, st))
+    if (mode == 1) rc = W3_GO(4, 1);
+    else if (d->ntaps == 9) rc = W3_GO(9, 0);
+    else rc = W3_GO(4, 0);
+#undef W3_GO
+    return rc == XMC_ESHAPE ? 1 : rc;
+}
