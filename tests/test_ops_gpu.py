@@ -117,7 +117,7 @@ def test_conv_fwd_dgrad_wgrad(case, mode):
     # Large cases run without the activation: among millions of pre-activations a few land within rounding of LeakyReLU's
     # kink, the GPU and CPU masks then differ in one element and that moves k*k*Cin entries of dx and Cin*k*k of dW by
     # 0.8*|r|*|x| -- the reference's kink, not a kernel error.  The fused activation is covered by the small cases.
-    big = N * cout * H * H > (1 << 20)
+    big = N * cout * H * H > ((1 << 14) if mode == "f16" else (1 << 20))      # f16: its tolerance is 8x tighter, the kink is not
     yr = F.conv2d(xr, wr, br, s, p) if big else F.leaky_relu(F.conv2d(xr, wr, br, s, p), 0.2)
     r = rt(torch.randn(yr.shape, generator=g), mode)
     (yr * r).sum().backward()

@@ -100,11 +100,11 @@ __global__ __launch_bounds__(512) void wtile3_kernel(const XmcConvDesc d, const 
     if (tid < XMC_MAX_TAPS) {
         if (MODE == 0) {
             const int tt = tid < NTAPS ? tid : 0;
-            s_toff[tid] = (d.dh[cls][tt] - dh0) * PW + (d.dw[cls][tt] - dw0);
+            s_toff[tid] = ((d.dh[cls][tt] - dh0) * PW + (d.dw[cls][tt] - dw0)) | ((d.dw[cls][tt] - dw0) << 16);
             s_wbase[tid] = d.wi[cls][tt] * d.CDw * cs_units;
         } else {
             const int g4 = tid >> 2, tp = tid & 3;                     // tid = (dy*2+dx)*4 + (ta*2+tb)
-            s_toff[tid] = (tp >> 1) * PW + (tp & 1);
+            s_toff[tid] = ((tp >> 1) * PW + (tp & 1)) | ((tp & 1) << 16);
             s_wbase[tid] = d.wi[0][t.tsel[g4][tp]] * d.CDw * cs_units;
         }
     }
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(512) void wtile3_kernel(const XmcConvDesc d, const 
         const int pp = (wave * kPI + i) * 8 + (lane >> 3);
         const bool in = pp < PH * PW;
         const int py = pp / PW, px = pp - py * PW;
-        const int ch = (lane & 7) ^ (pp & 7);
+        const int ch = (lane & 7) ^ (px & 7);      // keyed by the patch COLUMN: the reader's XOR term then depends on lane and tap only
         unsigned hb;
         if (MODE == 0) {
             psrc[i] = in ? ((dh0 + py) * d.SW + (dw0 + px)) * cs_units + ch : 0;
@@ -184,16 +184,22 @@ __global__ __launch_bounds__(512) void wtile3_kernel(const XmcConvDesc d, const 
         glds16(s, lds0 + RING * WSTG + buf * pbytes + (g < kPieces ? g : kPieces - 1) * 1024);
     };
     // weights of stage (slab sl, tap): the same for every tile
-    auto weights = [&](int sl, int tap, int slot, int z) {
-        int wb;
-        if (MODE == 0) {
-            wb = s_wbase[tap] + sl * 8;
-        } else {
-            const int si = s_slab[sl];
-            wb = s_wbase[(si >> 8) * 4 + tap] + (si & 0xff) * 8;
-        }
+    int wbr[NTAPS];                              // MODE 0: first unit of each tap's weight slice, in scalar registers (an LDS table read
+#pragma unroll                                   // inside a LOAD phase would wait for the fragment reads issued before it)
+    for (int k = 0; k < NTAPS; ++k) wbr[k] = __builtin_amdgcn_readfirstlane(s_wbase[k]);
+    // MODE 1: the weight slice of (slab, tap) depends on the slab's group; looked up once per slab for this slab and the next (the
+    // stages fetched ahead wrap into it), not inside the phases
+    int wbm[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    auto wbm_setup = [&](int which, int sl) {
+        const int si = __builtin_amdgcn_readfirstlane(s_slab[sl]);
 #pragma unroll
-        for (int i = 0; i < NI; ++i) glds16(w16 + (unsigned)(wb + wpiece_off(i) + wlane + z), lds0 + slot * WSTG + wpiece0 + i * 1024);
+        for (int k = 0; k < 4; ++k) wbm[which][k] = __builtin_amdgcn_readfirstlane(s_wbase[(si >> 8) * 4 + k]) + (si & 0xff) * 8;
+    };
+    auto weights = [&](int sl, int tap, int slot, int z, int i0 = 0, int i1 = 16, int nxt = 0) {     // pieces [i0, i1) of the stage
+        const int wb = MODE == 0 ? wbr[tap < NTAPS ? tap : 0] + sl * 8 : wbm[nxt][tap & 3];
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            if (i >= i0 && i < i1) glds16(w16 + (unsigned)(wb + wpiece_off(i) + wlane + z), lds0 + slot * WSTG + wpiece0 + i * 1024);
     };
 
     // ------------------------------------------------------------------------------------------------ fragment addresses
@@ -336,6 +342,7 @@ __global__ __launch_bounds__(512) void wtile3_kernel(const XmcConvDesc d, const 
 
     // ------------------------------------------------------------------------------------------------ prologue
     patch_setup(0);
+    if (MODE == 1) wbm_setup(0, 0);
 #pragma unroll
     for (int i = 0; i < kPI; ++i) patch_piece(i, 0, 0);
 #pragma unroll
@@ -357,6 +364,7 @@ __global__ __launch_bounds__(512) void wtile3_kernel(const XmcConvDesc d, const 
         int zq = 0;
         asm volatile("" : "+v"(zq));
         const int sl1 = sl + 1 == nslab ? 0 : sl + 1;
+        if (MODE == 1) { wbm_setup(0, sl); wbm_setup(1, sl1); }
 #pragma unroll
         for (int tap = 0; tap < NTAPS; ++tap) {
             const unsigned char* const wb = wring + slot * WSTG;
@@ -374,28 +382,45 @@ __global__ __launch_bounds__(512) void wtile3_kernel(const XmcConvDesc d, const 
                 if (NPH == 4 ? (p & 1) == 0 : true) {
 #pragma unroll
                     for (int j = 0; j < TNW; ++j)
-                        Wf[j] = *reinterpret_cast<const u32x4*>(wb + (ksub ? wf1 : wf0) + zq + j * 2048);
+                    {   // inline asm + hand-placed counted waits: with LDS-DMA in the kernel hipcc answers every fragment use with
+                        // lgkmcnt(0), i.e. the first MFMA of a cluster would wait for the LAST of its eight reads
+                        const unsigned wa = (unsigned)(size_t)(wb + (ksub ? wf1 : wf0) + zq - smem);
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(Wf[j]) : "v"(wa), "n"(j * 2048));
+                    }
                 }
+                {
+                    // chunk fc + 4 ksub of a pixel sits at slot (fc + 4 ksub) ^ (patch column & 7), and the column of (block i, lane
+                    // fr) at this tap is fr + tdx (mod 8) for every block: two VALU instructions per (tap, sub-step), one per read
+                    const int slot16 = (((fc + 4 * ksub) ^ (fr + zq + (toffr[tap] >> 16))) & 7) << 4;
+                    const unsigned char* const pl = pb + ((ppl0 + (toffr[tap] & 0xffff)) * 128 + slot16);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int pp = ppl0 + (((mb + i) >> 1) * ps2 + ((mb + i) & 1) * ps1 + toffr[tap]) + zq;
-                    const int chunk = ((fc + 4 * ksub) ^ pp) & 7;
-                    Pf[i] = *reinterpret_cast<const u32x4*>(pb + pp * 128 + chunk * 16);
+                    for (int i = 0; i < 4; ++i)
+                    {
+                        const unsigned pa = (unsigned)(size_t)(pl + (((mb + i) >> 1) * ps2 + ((mb + i) & 1) * ps1) * 128 - smem);
+                        asm volatile("ds_read_b128 %0, %1" : "=v"(Pf[i]) : "v"(pa));
+                    }
                 }
                 // Staging.  Every wait is a full vmcnt(0) on operations issued at least two intervals earlier by this wave, and the
                 // first ds_read of what it retires is at least two barriers later for either half.
                 if (NPH == 4) {
-                    if (p == 1) weights(fs, ft, fslot, zq);              // slot of stage g-1: last read three intervals ago
-                    if (p == 2) {
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the weights of phase 1 and the patch pieces of the last stage
+                    // at most two LDS-DMA per phase (their issue costs the wave 60-185 cycles each).  The slot of stage g-1 was last
+                    // read in phase 2 of g-1, three intervals before the first piece; the next patch's buffer in the last phase of
+                    // the previous slab, three intervals before phase 1.
+                    if (p == 0) weights(fs, ft, fslot, zq, 0, 1, tap + D >= NTAPS);
+                    if (p == 1) {
+                        weights(fs, ft, fslot, zq, 1, 2, tap + D >= NTAPS);
 #pragma unroll
                         for (int e = 0; e < PPS; ++e)
                             if (tap * PPS + e < kPI) patch_piece(tap * PPS + e, (q + 1) & 1, zq);
                     }
+                    if (p == 2) weights(fs, ft, fslot, zq, 2, 4, tap + D >= NTAPS);
+                    if (p == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stage g+1 (first read: after this phase's barrier)
                 } else {
+                    // ring of 4: stage g+3 goes into the slot of stage g-1 (last read in phase 1 of g-1: three intervals before phase 0)
+                    if (p == 0) weights(fs, ft, fslot, zq, 0, 1, tap + D >= NTAPS);
                     if (p == 1) {
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // everything this wave issued one stage ago
-                        weights(fs, ft, fslot, zq);
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // everything this wave issued up to phase 0 (first read: two stages on)
+                        weights(fs, ft, fslot, zq, 1, 2, tap + D >= NTAPS);
 #pragma unroll
                         for (int e = 0; e < PPS; ++e)
                             if (tap * PPS + e < kPI) patch_piece(tap * PPS + e, (q + 1) & 1, zq);
@@ -405,14 +430,24 @@ __global__ __launch_bounds__(512) void wtile3_kernel(const XmcConvDesc d, const 
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
                 // ---------------- MFMA phase: 16 back-to-back MFMAs, nothing else
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                // (no explicit wait: the compiler counts -- lgkmcnt(3) before the first MFMA, then one fewer per pixel fragment --
+                // so the cluster starts as soon as its first two operands are there)
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i) {
+                    // LDS returns in order (weights first, then the four pixel fragments): pixel block i is usable once all but the
+                    // 3 - i youngest reads have returned
+                    if (i == 0) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+                    if (i == 1) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+                    if (i == 2) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
+                    if (i == 3) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int j = 0; j < TNW; ++j)
                         acc[mb + i][j] = XMC_MFMA_16x16x32(__builtin_bit_cast(bf16x8, Wf[j]), __builtin_bit_cast(bf16x8, Pf[i]), acc[mb + i][j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
@@ -512,8 +547,10 @@ int xmc_conv_wtile3_try(const XmcConvDesc* d, void* stream) {
     W3Cfg t;
     int mode = 0, wm = 2;
     if (!plan3(d, &t, &mode, &wm)) return 1;
-    static const bool no128 = xmc_debug_off("no_wtile3_bn128");
-    if (wm == 4 && no128) return 1;
+    // BN = 128 (64 x 64 wave tiles: the same fragment-read load as the role-split kernel, without its dedicated staging waves) measures
+    // 3-6 % behind conv_wtile.hip on the 128-channel layers: kept for A/B runs only
+    static const bool bn128 = xmc_debug_off("wtile3_bn128");
+    if (wm == 4 && !bn128) return 1;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     int rc;
 #define W3_GO(NT_, MD_) (wm == 2 ? launch3<NT_, MD_, 2>(*d, t, st) : launch3<NT_, MD_, 4>(*d, t, st))
