@@ -238,7 +238,11 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
     constexpr int NS = 256;                      // threads per role
     constexpr int TM = SA == 1 ? 4 : 2, TN = BN / 16;
     constexpr int cps = SLAB / 8;
-    constexpr int pstride = SLAB * 2 + 32;
+    // bytes between patch pixels / weight rows.  The 16-row fragment pattern of v_mfma_f32_16x16x32 is bank-conflict free at
+    // 128 + 32 bytes; the 32-row pattern of the 32x32x16 form is NOT (rows r and r + 8 land on one 16-byte slot: 2-way on every
+    // read, SQ_LDS_BANK_CONFLICT 0.44 per active cycle in round 2) but is at 128 + 16 (slot = 9 r mod 16: a permutation of any
+    // 16 of 32 consecutive rows; checked by enumeration over every patch alignment)
+    constexpr int pstride = SLAB * 2 + (M32 ? 16 : 32);
     constexpr int PIT = ((SA == 1 ? 384 : 18 * 34) * cps + NS - 1) / NS;     // patch units per staging thread (patches of <= 384 / 612 pixels)
     constexpr int UPL = BN / 32;
     constexpr int S = SLAB / 32;

@@ -525,6 +525,15 @@ class _ZeroArena:
 _arena = _ZeroArena()
 
 
+def _zeros_f32(shape, device):
+    """zero-filled f32 scratch for an accumulator the kernels add into (dot products, per-channel sums, small parameter gradients):
+    a slice of the per-iteration arena (one memset per iteration) instead of one fill launch each -- ~100 launches per iteration in
+    the headline configuration, ~420 with the attention-modulation generators.  Valid until the next `new_iteration()`."""
+    if isinstance(shape, int):
+        shape = (shape,)
+    return _arena.zeros(tuple(shape), torch.device(device))
+
+
 def new_iteration(device):
     """Call once at the start of a training iteration (before any backward): re-zeroes the weight-gradient scratch arena."""
     _arena.new_iteration(torch.device(device))
@@ -756,7 +765,7 @@ def _axpby_bwd_fused(dy, b, alpha, up, ymask=None, want_db=True):
     al = alpha.detach().reshape(-1).float()
     db = torch.empty_like(dy) if want_db else None
     da = torch.empty((N, H, W, Cc), dtype=dy.dtype, device=dy.device) if (up or ymask is not None) else None
-    dot = torch.zeros(1, dtype=torch.float32, device=dy.device)
+    dot = _zeros_f32(1, dy.device)
     L.call("xmc_axpby_bwd", _p(dy), _p(b), _p(al), _p(db), _p(da), _p(dot), N, H, W, Cc, 1 if up else 0, _p(ymask), _code(dy.dtype), _st())
     return da, db, dot.reshape(alpha.shape).to(alpha.dtype)
 
@@ -947,7 +956,7 @@ class CondMLPBankFn(torch.autograd.Function):
         _gemm_group(t)
         dc = None
         if ctx.needs_input_grad[0]:                      # dc = sum_g dh_g W1_g
-            dc = torch.zeros(B, K, dtype=torch.float32, device=dev)
+            dc = _zeros_f32((B, K), dev)
             t = np.zeros(G, dtype=L.GEMM_PROBLEM)
             t["A"], t["B"], t["C"] = pdh, pw1, dc.data_ptr()
             t["M"], t["N"], t["K"] = B, K, Hd
@@ -1142,7 +1151,7 @@ class DotFn(torch.autograd.Function):
         a, b = a.contiguous(), b.contiguous()
         if a.dtype != b.dtype:
             b = b.to(a.dtype)
-        out = torch.zeros(1, dtype=torch.float32, device=a.device)
+        out = _zeros_f32(1, a.device)
         L.call("xmc_dot", _p(a), _p(b), _p(out), a.numel(), _code(a.dtype), _st())
         ctx.save_for_backward(a, b)
         return out
@@ -1275,7 +1284,7 @@ class ResDBwdFn(torch.autograd.Function):
         # residual branch: g2 = gamma * dout * LeakyReLU'(res), d(gamma) = <dout, res>
         al = gamma.detach().reshape(-1).float()
         gr = torch.empty_like(res)
-        dgam = torch.zeros(1, dtype=torch.float32, device=x.device)
+        dgam = _zeros_f32(1, x.device)
         L.call("xmc_scale_mask_dot", _p(dout), _p(res), _p(al), _p(gr), _p(dgam), res.numel(), _code(dt), _st())
         dw2 = _conv_wgrad_raw(h1, gr, g2).view(w2.shape) if (need[2] and not skip_w) else None
         gh = _conv_dgrad_raw(gr, w2, g2, (h1.shape[1], h1.shape[2]), dt, mask=h1)        # includes LeakyReLU'(h1)
@@ -1328,7 +1337,7 @@ class ResDBwdFn(torch.autograd.Function):
         if ctx.needs_input_grad[8]:
             u = torch.empty_like(c2)
             L.call("xmc_lrelu_mask", _p(c2), _p(res), _p(u), c2.numel(), 0.2, _code(dt), _st())
-            dg = torch.zeros(1, dtype=torch.float32, device=g.device)
+            dg = _zeros_f32(1, g.device)
             L.call("xmc_dot", _p(dout), _p(u), _p(dg), u.numel(), _code(dt), _st())
             dgamma = dg.reshape(gamma.shape).to(gamma.dtype)
         dw0 = dw2 = dws = None
@@ -1356,7 +1365,7 @@ class ColSumFn(torch.autograd.Function):
     def forward(ctx, x):
         x = x.contiguous()
         Cc = x.shape[-1]
-        out = torch.zeros(Cc, dtype=torch.float32, device=x.device)
+        out = _zeros_f32(Cc, x.device)
         L.call("xmc_colsum", _p(x), _p(out), x.numel() // Cc, Cc, _code(x.dtype), _st())
         ctx.shape, ctx.dtype = x.shape, x.dtype
         return out
@@ -1491,7 +1500,7 @@ def _affine_bwd_raw(x, dy, ps, slope, dx_acc=None):
         dx_acc = dx_acc.contiguous()
         assert dx_acc.shape == x.shape and dx_acc.dtype == x.dtype
     nred = len(ps)
-    red = torch.zeros((nred, N, Cc), dtype=torch.float32, device=x.device)
+    red = _zeros_f32((nred, N, Cc), x.device)
     ptrs = [_p(t) for t in ps] + ([] if nred == 4 else [None, None])
     rptrs = [_p(red[i]) for i in range(nred)] + ([] if nred == 4 else [None, None])
     L.call("xmc_affine2_act_bwd_acc", _p(x), _p(dy), *ptrs, _p(dx), *rptrs, _p(dx_acc), N, H * W, Cc, float(slope), _code(x.dtype), _st())
@@ -1750,7 +1759,7 @@ class ConceptQueryFn(torch.autograd.Function):
         B, E = sent.shape
         dq = dq.contiguous().float()
         dsent = torch.empty_like(sent)
-        flat = torch.zeros(64 * E + 128, dtype=torch.float32, device=sent.device)      # one fill for all accumulators
+        flat = _zeros_f32(64 * E + 128, sent.device)      # one slice for all accumulators
         dw = flat[:64 * E].view(64, E)
         dgw = flat[64 * E:64 * E + 64] if gnw is not None else None
         dgb = flat[64 * E + 64:] if gnw is not None else None
@@ -1785,7 +1794,7 @@ class ConceptGQueryFn(torch.autograd.Function):
         B = q0.shape[0]
         dq = dq.contiguous().float()
         dq0 = torch.empty_like(q0)
-        flat = torch.zeros(64 * 8 + 128, dtype=torch.float32, device=q0.device)
+        flat = _zeros_f32(64 * 8 + 128, q0.device)
         dw = flat[:512].view(64, 8)
         dgw = flat[512:576] if gnw is not None else None
         dgb = flat[576:] if gnw is not None else None
@@ -1807,7 +1816,7 @@ def _head_bwd_raw(pooled, sent, hid, ps, dgamma, dbeta):
     B, E = sent.shape
     dpooled, dsent = torch.empty_like(pooled), torch.empty_like(sent)
     sizes = [(p_.numel() + 3) // 4 * 4 for p_ in ps]                      # 16-byte aligned slices of ONE zero-filled buffer
-    flat = torch.zeros(sum(sizes), dtype=torch.float32, device=sent.device)
+    flat = _zeros_f32(sum(sizes), sent.device)
     grads, off = [], 0
     for p_, n_ in zip(ps, sizes):
         grads.append(flat[off:off + p_.numel()].view(p_.shape))
@@ -1928,7 +1937,7 @@ class GradPenaltyFn(torch.autograd.Function):
                 g = torch.nn.functional.pad(g, (0, 4 - g.shape[1] % 4))
             flat.append(g)
         _need_cuda(*flat)
-        ss = torch.zeros(B, dtype=torch.float32, device=flat[0].device)
+        ss = _zeros_f32(B, flat[0].device)
         for g in flat:
             L.call("xmc_rows_sumsq", _p(g), _p(ss), B, g.shape[1], _st())
         gp = torch.empty(1, dtype=torch.float32, device=ss.device)
