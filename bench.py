@@ -65,11 +65,11 @@ def parse():
 
 def pmc_traffic_lookup(imsize, batch, cfg_name, precision):
     """HBM bytes per launch of a kernel from the committed rocprofv3 PMC summary of THIS workload
-    (profiles/r02_pmc_hbm_traffic_<S>px_b<B>.csv: separate --pmc FETCH_SIZE / WRITE_SIZE passes of this script, FETCH_SIZE
+    (profiles/r03_pmc_hbm_traffic_<S>px_b<B>.csv: separate --pmc FETCH_SIZE / WRITE_SIZE passes of this script, FETCH_SIZE
     doubled as MI355X_MICROARCH.md prescribes for gfx950; made by profiles/summarize.py).  Counters cannot be read from
     inside the process, so the figure is None for workloads without a committed summary."""
     import csv
-    path = os.path.join(ROOT, "profiles", f"r02_pmc_hbm_traffic_{imsize}px_b{batch}.csv")
+    path = os.path.join(ROOT, "profiles", f"r03_pmc_hbm_traffic_{imsize}px_b{batch}.csv")
     if cfg_name != "df_gan_damsm_nomagp.yml" or precision != "bf16" or not os.path.exists(path):
         return None
     rows = list(csv.DictReader(open(path)))

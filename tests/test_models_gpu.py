@@ -145,7 +145,8 @@ def test_train_iteration_parity(yml, over, batch, steps, mode):
     if mode == "fp32" and h.gen != "DF_GEN" and h.img_size >= 128:
         # the same cancelling sums (below) in f32: at 16 384 regions the order of the f32 atomics alone moves these tensors between
         # 1.4e-3 and 5.2e-3 from run to run (two driver-box runs of this case); x4 on their per-tensor bar, aggregate unchanged
-        loose = (lambda n: "concept_sampler" in n and n.split(".")[-2] in ("query_gconv", "key_gconv", "gn1", "gn2"), 4.0)
+        # (and what hangs off the pooled context: reasoner, value projection, modulation heads)
+        loose = (lambda n: ".concept" in n, 4.0)
     if mode == "bf16" and h.gen != "DF_GEN":
         # Parameters upstream of the region-attention LOGITS (query / key projections and their GroupNorms).  Their gradient is
         # sum_p a_p (<dctx, x_p> - <dctx, ctx>) k_p over up to 16 384 regions: with the synthetic weights the attention is close

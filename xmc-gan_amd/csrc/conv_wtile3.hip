@@ -551,6 +551,9 @@ int xmc_conv_wtile3_try(const XmcConvDesc* d, void* stream) {
     // 3-6 % behind conv_wtile.hip on the 128-channel layers: kept for A/B runs only
     static const bool bn128 = xmc_debug_off("wtile3_bn128");
     if (wm == 4 && !bn128) return 1;
+    // 256-channel tiles halve the number of workgroups: below one tile per CU the role-split kernel (128-channel tiles, twice the
+    // workgroups) wins -- 128x128 / batch 64: 10.8 vs 10.4 ms per iteration
+    if (wm == 2 && (long long)d->N * t.tiles_y * t.tiles_x * (d->CDw / 256) * d->nclass < 256) return 1;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     int rc;
 #define W3_GO(NT_, MD_) (wm == 2 ? launch3<NT_, MD_, 2>(*d, t, st) : launch3<NT_, MD_, 4>(*d, t, st))
