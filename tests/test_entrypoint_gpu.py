@@ -17,7 +17,7 @@ from golden_util import CFG_DIR
 def _mini_yml(tmp_path, **subst):
     """df_gan_damsm.yml shrunk for a test run (thin network, tiny vocabulary, no pretrained encoder file)."""
     txt = open(os.path.join(CFG_DIR, "df_gan_damsm.yml")).read()
-    rep = {"NCH: 32": "NCH: 8", "VOCA_SIZE: 27297": "VOCA_SIZE: 40", "BATCH_SIZE: 88": "BATCH_SIZE: 4",
+    rep = {"NCH: 32": "NCH: 8", "VOCA_SIZE: 27297": "VOCA_SIZE: 40", "BATCH_SIZE: 88": "BATCH_SIZE: 4", "LOG_INTERVAL: 200": "LOG_INTERVAL: 2",
            "NUM_WORKERS: 8": "NUM_WORKERS: 0", "ENCODER_DIR: data/DAMSMencoders/coco/text_encoder100.pth": "ENCODER_DIR: ''",
            "MAX_LENGTH: 20": "MAX_LENGTH: 8", "MAGP: true": "MAGP: false"}
     rep.update(subst)
@@ -79,3 +79,16 @@ def test_real_data_path_and_resume(tmp_path):
     sd2 = torch.load(os.path.join(run, "model", "optimizerD.pth"), map_location="cpu")
     assert all(float(st["step"]) == 53 * 2 for st in sd2["state"].values())
     assert "netG_053.pth" in os.listdir(os.path.join(run, "model"))
+    # the logging / evaluation tail (reference train_gan.py:146-160, 297-326, 338-395)
+    img = os.path.join(run, "img")
+    files = set(os.listdir(img))
+    assert {"sents.txt", "imgs.png", "fake_samples_epoch_001.png", "fake_samples_epoch_053.png", "test", "org"} <= files, files
+    assert any(f.startswith("fake_samples_") and "epoch" not in f for f in files)          # every LOG_INTERVAL steps
+    assert len(open(os.path.join(img, "sents.txt")).read().splitlines()) == 4             # one caption per sample of the first batch
+    assert len(os.listdir(os.path.join(img, "test"))) == len(os.listdir(os.path.join(img, "org"))) == 8    # the 8 test images
+    from PIL import Image
+    assert Image.open(os.path.join(img, "test", "k000.png")).size == (64, 64)
+    rows = [__import__("json").loads(line) for line in open(os.path.join(run, "log", "scalars.jsonl"))]
+    tags = {r["tag"] for r in rows}
+    assert {"epoch", "Loss_D", "Loss_G", "errD_real", "errD_fake", "errD_mismatch", "ds_loss", "gs_loss", "disc_loss"} <= tags, tags
+    assert max(r["step"] for r in rows) == 53

@@ -7,6 +7,8 @@ import os
 import re
 import sys
 
+import json
+
 import numpy as np
 import pytest
 import torch
@@ -332,3 +334,31 @@ def test_bench_gpus_n_without_launcher_starts_n_ranks():
     r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], env=env2, capture_output=True, text=True,
                         timeout=300)
     assert r2.returncode != 0 and "WORLD_SIZE=1" in (r2.stderr + r2.stdout)
+
+
+def test_image_grid_and_scalar_log(tmp_path):
+    """the logging tail's host helpers (reference train_gan.py:160,299-326 via torchvision.utils.save_image / tensorboard): grid
+    geometry, per-image min-max scaling, PNG round trip, JSON-lines scalars"""
+    from PIL import Image
+    from xmc_gan.utils.visual import ScalarLog, make_grid, save_image, to_uint8_hwc
+    rng = np.random.RandomState(0)
+    x = rng.randn(10, 3, 6, 5).astype(np.float32) * 3
+    g = make_grid(x)                                    # 8 per row -> 2 rows; padding 2
+    assert g.shape == (3, 2 * (6 + 2) + 2, 8 * (5 + 2) + 2)
+    tile = g[:, 2:8, 2:7]                               # first image, scaled to [0, 1] on its own
+    assert abs(tile.min()) < 1e-6 and abs(tile.max() - 1.0) < 1e-6
+    np.testing.assert_allclose(tile, (x[0] - x[0].min()) / (x[0].max() - x[0].min()), atol=1e-6)
+    assert np.all(g[:, :2, :] == 0)                      # padding stays at pad_value
+    np.testing.assert_allclose(g[:, 10:16, 9:14], (x[9] - x[9].min()) / (x[9].max() - x[9].min()), atol=1e-6)   # image 9: row 1, cell 1
+    assert np.all(g[:, 10:16, 16:] == 0)                 # empty cells of the last row
+    save_image(torch.from_numpy(x), tmp_path / "g.png")
+    im = np.asarray(Image.open(tmp_path / "g.png"))
+    assert im.shape == (g.shape[1], g.shape[2], 3) and im.dtype == np.uint8
+    np.testing.assert_allclose(im.transpose(2, 0, 1) / 255.0, g, atol=1 / 255.0 + 1e-6)
+    assert to_uint8_hwc(np.zeros((3, 4, 4), np.float32)).tolist() == np.full((4, 4, 3), 127, np.uint8).tolist()   # truncation, as upstream
+    log = ScalarLog(str(tmp_path), "tb")
+    log.add_scalar("Loss_D", 1.5, 3)
+    log.add_scalar("FID", 42.0, 3)
+    log.close()
+    rows = [json.loads(line) for line in open(tmp_path / "scalars.jsonl")]
+    assert rows == [{"tag": "Loss_D", "value": 1.5, "step": 3}, {"tag": "FID", "value": 42.0, "step": 3}]

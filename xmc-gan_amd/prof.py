@@ -43,9 +43,13 @@ class launch:
             _recs.append((self.family, self.flops, self.e0, self.e1, self.tag, kern, self.nbytes))
 
 
-def _aggregate(key):
+def _aggregate_where(pred):
+    return _aggregate(lambda r: r[5], [r for r in _recs if pred(r)])
+
+
+def _aggregate(key, recs=None):
     agg = {}
-    for rec in _recs:
+    for rec in (_recs if recs is None else recs):
         f = agg.setdefault(key(rec), dict(launches=0, gflop=0.0, ms=0.0, gbyte=0.0))
         f["launches"] += 1
         f["gflop"] += rec[1] / 1e9
@@ -73,10 +77,20 @@ def summary(peak_tflops, traffic_lookup=None):
     dom = max(kern, key=lambda k: kern[k]["ms"])
     d = kern[dom]
     traffic = traffic_lookup(dom) if traffic_lookup else None
+    # the dominant instantiation of each operator family as well (forward + data gradient / weight gradient): the overall dominant
+    # kernel changes family from round to round, these two keep a comparable series
+    per_family = {}
+    for fname in {r[0] for r in _recs}:
+        ks = _aggregate_where(lambda r, f=fname: r[0] == f)
+        if ks:
+            k = max(ks, key=lambda n: ks[n]["ms"])
+            per_family[fname.split(" ")[0]] = dict(kernel=k, achieved=ks[k]["tflops"], frac=round(ks[k]["tflops"] / peak_tflops, 4),
+                                                   launches=ks[k]["launches"], ms=ks[k]["ms"], avg_launch_us=ks[k]["avg_launch_us"],
+                                                   traffic=traffic_lookup(k) if traffic_lookup else None)
     return dict(bound="mfma", kernel=dom, achieved=d["tflops"], peak=peak_tflops, unit="TFLOP/s",
                 frac=round(d["tflops"] / peak_tflops, 4), traffic=traffic, launches=d["launches"],
                 avg_launch_us=d["avg_launch_us"], algorithmic_gflop_per_launch=d["gflop_per_launch"],
-                kernels=kern, families=fam)
+                dominant_per_family=per_family, kernels=kern, families=fam)
 
 
 def summary_hbm(peak_gbs, ridge_flop_per_byte, top=8):

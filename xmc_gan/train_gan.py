@@ -35,6 +35,7 @@ from xmc_gan.model.concept_gan import InNetG as CONCEPT_INATTN_GEN, OutNetG as C
 from xmc_gan.model.encoder import RNN_ENCODER, SBERT_ENCODER
 from xmc_gan.utils.logger import setup_logger
 from xmc_gan.utils.miscc import count_params
+from xmc_gan.utils.visual import ScalarLog, fid_between, save_image, to_uint8_hwc
 from xmc_gan_amd import ops, parallel
 from xmc_gan_amd.optim import HipAdam
 
@@ -329,11 +330,29 @@ class SyntheticTextEncoder(torch.nn.Module):
 
 
 # --------------------------------------------------------------------------------------- epoch loop
+def _log_epoch_scalars(writer, last, epoch):
+    """the per-epoch scalars of the reference (train_gan.py:300-320): the losses of the epoch's last iteration"""
+    if writer is None or 'errD' not in last:
+        return
+    writer.add_scalar('epoch', epoch, epoch)
+    for tag, key in (('Loss_D', 'errD'), ('Loss_G', 'errG'), ('errD_real', 'errD_real'), ('errD_fake', 'errD_fake'),
+                     ('errD_mismatch', 'errD_mismatch'), ('ds_loss', 'ds_loss'), ('gs_loss', 'gs_loss'), ('disc_loss', 'disc_loss')):
+        if key in last:
+            writer.add_scalar(tag, last[key].item(), epoch)
+    writer.flush()
+
+
 def train(train_loader, test_loader, state_epoch, text_encoder, netG, netD, optimizerG, optimizerD, logger, model_dir,
-          opts=None, img_dir=None, max_steps=None):
-    """Epoch loop with the reference's signature (train_gan.py:142); returns the last iteration's losses."""
+          opts=None, img_dir=None, max_steps=None, writer=None):
+    """Epoch loop with the reference's signature (train_gan.py:142); returns the last iteration's losses.
+
+    With ``img_dir`` (rank 0) it keeps the reference's visual log: ``sents.txt`` and ``imgs.png`` of the first batch (146-160),
+    ``fake_samples_<step>.png`` every LOG_INTERVAL steps (298-299), ``fake_samples_epoch_<epoch>.png`` from a fixed noise /
+    caption batch in eval mode after every epoch (322-326); with ``writer`` the per-epoch scalars (300-320)."""
     device = next(netG.parameters()).device
     it_state, last, nsteps = {}, {}, 0
+    fixed = None
+    visual = img_dir is not None and parallel.rank() == 0
     for epoch in range(state_epoch + 1, cfg.TRAIN.MAX_EPOCH + 1):
         netG.train()
         netD.train()
@@ -346,6 +365,18 @@ def train(train_loader, test_loader, state_epoch, text_encoder, netG, netD, opti
             with torch.no_grad():
                 words_embs, sent_embs, mask = text_encoder(caps, cap_lens)
             words_embs, sent_embs = words_embs.detach(), sent_embs.detach()
+            if visual and fixed is None:         # the reference takes these from the loader's first batch before the loop
+                i2w = getattr(getattr(train_loader, 'dataset', None), 'i2w', None)
+                with open(f'{img_dir}/sents.txt', 'w') as f:
+                    if torch.is_tensor(caps):            # WORD captions: token ids (index_to_sent, dataset.py) or the ids themselves
+                        for row, n in zip(caps.tolist(), torch.as_tensor(cap_lens).tolist()):
+                            f.write((' '.join(i2w[t] for t in row[:n]) if i2w else ' '.join(str(t) for t in row[:n])) + ' \n')
+                    else:                                # SENT captions: the sentences
+                        for sent in caps:
+                            f.write(f'{sent} \n')
+                fixed = dict(noise=torch.randn(mask.size(0), cfg.TRAIN.NOISE_DIM).to(device), sent=sent_embs.clone(),
+                             words=words_embs.clone(), mask=mask.clone())
+                save_image(imgs, f'{img_dir}/imgs.png', normalize=True, scale_each=True)
             imgs = imgs.to(device, non_blocking=True)
             noise = torch.randn(mask.size(0), cfg.TRAIN.NOISE_DIM).to(device)        # CPU generator, as upstream (197-198)
             last = gan_iteration(netG, netD, optimizerG, optimizerD, imgs, sent_embs, words_embs, mask, noise,
@@ -354,9 +385,18 @@ def train(train_loader, test_loader, state_epoch, text_encoder, netG, netD, opti
                 logger.info(f'[{epoch}/{cfg.TRAIN.MAX_EPOCH}][{step + 1}/{len(train_loader)}] '
                             f'Loss_D: {last["errD"].item():.3f} Loss_G: {last["errG"].item():.3f} '
                             f'errD_real: {last["errD_real"].item():.3f} errD_fake: {last["errD_fake"].item():.3f} ')
+            if visual and (step + 1) % cfg.TRAIN.LOG_INTERVAL == 0:
+                save_image(last['fake'], f'{img_dir}/fake_samples_{step + 1:03d}.png', normalize=True, scale_each=True)
             nsteps += 1
             if max_steps is not None and nsteps >= max_steps:
                 return last
+        if parallel.rank() == 0:
+            _log_epoch_scalars(writer, last, epoch)
+        if visual and fixed is not None:
+            with torch.no_grad():
+                netG.eval()
+                fake = netG(noise=fixed['noise'], sent_embs=fixed['sent'], words_embs=fixed['words'], mask=fixed['mask'])
+                save_image(fake, f'{img_dir}/fake_samples_epoch_{epoch:03d}.png', normalize=True, scale_each=True)
         if epoch > 50 and parallel.rank() == 0:
             torch.save(netG.state_dict(), f'{model_dir}/netG_{epoch:03d}.pth')
             torch.save(netD.state_dict(), f'{model_dir}/netD_{epoch:03d}.pth')
@@ -364,16 +404,26 @@ def train(train_loader, test_loader, state_epoch, text_encoder, netG, netD, opti
             torch.save(optimizerD.state_dict(), f'{model_dir}/optimizerD.pth')
             logger.info('Save models')
             if test_loader is not None:
-                eval(loader=test_loader, state_epoch=epoch, text_encoder=text_encoder, netG=netG, logger=logger, num_samples=6000)
+                eval(loader=test_loader, state_epoch=epoch, text_encoder=text_encoder, netG=netG, logger=logger, num_samples=6000,
+                     save_dir=f'{img_dir}/test' if img_dir else None, org_dir=f'{img_dir}/org' if img_dir else None, writer=writer)
     return last
 
 
 @torch.no_grad()
-def eval(loader, state_epoch, text_encoder, netG, logger, num_samples=6000, save_dir=None):
-    """Generate images for a loader (G forward only, train_gan.py:338-387).  FID (389-390) needs the optional
-    ``pytorch_fid`` package and image files on disk; without it only the tensors are produced."""
+def eval(loader, state_epoch, text_encoder, netG, logger, num_samples=6000, save_dir=None, org_dir=None, writer=None):
+    """Generate images for the test loader and score them (train_gan.py:338-395): every generated image goes to
+    ``save_dir/<key>.png`` and, unless ``org_dir`` already holds ``num_samples`` files, every real one to ``org_dir/<key>.png``,
+    as 8-bit PNGs of (x + 1) * 127.5; FID between the two directories when ``pytorch_fid`` is importable (logged and written to
+    the scalar log as 'FID').  Returns (uint8 tensor of the generated images, FID or None)."""
+    from PIL import Image
     netG.eval()
     device = next(netG.parameters()).device
+    if save_dir:
+        os.makedirs(save_dir, exist_ok=True)
+    save_org = False
+    if org_dir:
+        os.makedirs(org_dir, exist_ok=True)
+        save_org = len(os.listdir(org_dir)) != num_samples
     cnt, outs = 0, []
     for imgs, texts_lst, keys in loader:
         caps, cap_lens = texts_lst[0]
@@ -381,11 +431,22 @@ def eval(loader, state_epoch, text_encoder, netG, logger, num_samples=6000, save
         noise = torch.randn(sent_embs.size(0), cfg.TRAIN.NOISE_DIM).to(device)
         fake = netG(noise=noise, sent_embs=sent_embs, words_embs=words_embs, mask=mask)
         outs.append(((fake + 1.0) * 127.5).clamp(0, 255).to(torch.uint8).cpu())
+        for j in range(fake.size(0)):
+            if save_dir:
+                Image.fromarray(to_uint8_hwc(fake[j])).save(f'{save_dir}/{keys[j]}.png')
+            if save_org:
+                Image.fromarray(to_uint8_hwc(imgs[j])).save(f'{org_dir}/{keys[j]}.png')
         cnt += fake.size(0)
         if cnt >= num_samples:
             break
-    logger.info(f' epoch {state_epoch}, generated {cnt} images')
-    return torch.cat(outs) if outs else None
+    fid = fid_between(org_dir, save_dir, device) if (save_dir and org_dir and cnt) else None
+    if fid is None:
+        logger.info(f' epoch {state_epoch}, generated {cnt} images (FID not computed: pytorch_fid is not installed)')
+    else:
+        logger.info(f' epoch {state_epoch}, FID : {fid}')
+        if writer is not None:
+            writer.add_scalar('FID', fid, state_epoch)
+    return (torch.cat(outs) if outs else None), fid
 
 
 def build_models(device):
@@ -486,9 +547,12 @@ def main(argv=None):
     elif cfg.DISC.ENCODER_DIR:
         netD.load_state_dict(torch.load(f'{PROJ_DIR}/{cfg.DISC.ENCODER_DIR}', map_location=device), strict=False)
 
+    writer = ScalarLog(log_dir, args.log_type, run_name=cfg.CONFIG_NAME) if rank == 0 else None
     last = train(train_loader=train_loader, test_loader=test_loader, state_epoch=state_epoch, text_encoder=text_encoder,
                  netG=netG, netD=netD, optimizerG=optimizerG, optimizerD=optimizerD, logger=logger, model_dir=model_dir,
-                 opts=StepOptions(gather_negatives=args.gather_negatives), img_dir=img_dir)
+                 opts=StepOptions(gather_negatives=args.gather_negatives), img_dir=img_dir if rank == 0 else None, writer=writer)
+    if writer is not None:
+        writer.close()
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.destroy_process_group()
