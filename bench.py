@@ -76,7 +76,8 @@ def pmc_traffic_lookup(imsize, batch, cfg_name, precision):
 
     def lookup(kernel):
         for r in rows:
-            if kernel + "(" in r["kernel"]:
+            # names as the library reports them leave out trailing default template arguments
+            if any(kernel[:-1] + tail + "(" in r["kernel"] for tail in (">", ", false>", ", false, false>")):
                 return round((float(r["fetch_MB_per_dispatch_corrected_x2"]) + float(r["write_MB_per_dispatch"])) * 2**20)
         return None
     return lookup

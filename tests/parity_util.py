@@ -140,7 +140,7 @@ def compare_grads(tap_rec, oracle_grads, rtol, name="", floor=1e-5, agg_rtol=Non
         worst = max(worst, err)
         num2 += (gp - go).double().pow(2).sum().item()
         den2 += go.double().pow(2).sum().item()
-        tol = rtol * (loose[1] if loose is not None and loose[0](n) else 1.0)
+        tol = rtol * ((loose[1](n) if callable(loose[1]) else loose[1]) if loose is not None and loose[0](n) else 1.0)
         assert err <= tol, f"{name}{n}: rel error {err:.3e} > {tol}"
     if agg_rtol is not None:      # all gradient tensors of this backward taken as one vector
         agg = (num2 / max(den2, 1e-300)) ** 0.5

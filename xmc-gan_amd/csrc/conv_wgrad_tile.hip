@@ -9,6 +9,7 @@
 // MFMA operands are pixel-major in LDS, fragments come from ds_read_b64_tr_b16 (see conv_wgrad.hip).
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -66,34 +67,97 @@ __global__ __launch_bounds__(NT, (SA == 1 ? WtOcc<NCO, NCI>::v : 1)) void wgrad_
     const u32x4* __restrict__ y16 = reinterpret_cast<const u32x4*>(d.dst);
 
     constexpr int ACB = DIAG ? 1 : CBW;                      // accumulator blocks per item
+    constexpr bool AF2 = false;                               // dy fragments of the next K step in a second register set
+    // staging tables (below) where their ~XIT + 6 registers fit; the 4-wave variants that already sit at their register cap
+    // (two workgroups per CU: the other one's MFMAs cover this one's address arithmetic) keep computing addresses per tile
+    constexpr bool TAB = !(NT == 256 && SA == 1 && NCO >= 2 && NCO * NCI >= 4);
     f32x4 acc[MAXI][ACB];
 #pragma unroll
     for (int j = 0; j < MAXI; ++j)
 #pragma unroll
         for (int c = 0; c < ACB; ++c) acc[j][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    u32x4 yv[YIT], xv[XIT];
-    auto prefetch = [&](int tile) {
-        const int img = tile / tpi, trem = tile - img * tpi;
-        const int a0 = (trem / t.tiles_x) * TH, b0 = (trem % t.tiles_x) * TW;
+    // Staging tables, computed ONCE: everything about a staged 16-byte unit that does not depend on the tile -- its source offset
+    // from the tile's patch origin, the image borders it would cross (4 bits), whether this thread stages it at all.  Per tile
+    // the loads are then unconditional (a unit outside the image reads the tile's own first pixel and is zeroed when it goes to
+    // LDS): one add per load instead of two runtime divisions, four compares and a branch, which all eight waves ran in front
+    // of the MFMA loop of every tile with the matrix pipe idle.
+    const int ych = tid % YCH, xch = tid % XCH;               // NT % YCH == 0: a thread always holds the same channel chunk
+    const bool yok = cou0 + ych < cd_units;
+    const int sh = d.src_shift;
+    unsigned xoff[TAB ? XIT : 1];
+    unsigned xhalo = 0, xin = 0;                              // 4 halo bits per unit (XIT <= 8) / "stages this unit"
+    static_assert(XIT <= 16, "halo bits");
+    unsigned xhalo2 = 0;
+    int xl[SA == 2 ? XIT : 1];
+    // dy: unit `it` of a thread is (NT / YCH) / TW tile rows below unit 0
+    static_assert((NT / YCH) % TW == 0, "dy units of a thread differ by whole tile rows");
+    const unsigned yoff0 = yok ? (unsigned)((((tid / YCH) / TW) * d.MW + ((tid / YCH) % TW)) * cd_units + cou0 + ych) : 0u;
+    const unsigned ystep = yok ? (unsigned)(((NT / YCH) / TW) * d.MW * cd_units) : 0u;
+    const int shs = d.SH << sh, sws = d.SW << sh;
+    const int row0 = t.dh0 >> sh, col0 = t.dw0 >> sh;         // patch origin at the stored resolution (floor)
+    const unsigned xsafe = (unsigned)(((0 - row0) * d.SW + (0 - col0)) * cs_units);       // the tile's own first pixel, chunk 0
+    if constexpr (TAB)
 #pragma unroll
-        for (int it = 0; it < YIT; ++it) {
-            int id = tid + it * NT;
-            int pix = id / YCH, ch = id - pix * YCH;
-            int py = pix / TW, px = pix - py * TW;
-            u32x4 z = {0, 0, 0, 0};
-            yv[it] = cou0 + ch < cd_units ? y16[(((size_t)img * d.MH + a0 + py) * d.MW + b0 + px) * cd_units + cou0 + ch] : z;
+    for (int it = 0; it < XIT; ++it) {
+        const int pp = (tid + it * NT) / XCH;
+        const int py = pp / PW, px = pp - py * PW;
+        const bool in = pp < PH * PW && ciu0 + xch < cs_units;
+        xin |= in ? (1u << it) : 0u;
+        xoff[it] = in ? (unsigned)(((((t.dh0 + py) >> sh) - row0) * d.SW + (((t.dw0 + px) >> sh) - col0)) * cs_units + ciu0 + xch) : xsafe;
+        // outside the image: above (first tile row only), below (last tile row only), left, right
+        const unsigned hb = !in ? 0u : ((t.dh0 + py < 0 ? 1u : 0u) | (t.dh0 + py >= shs - (t.tiles_y - 1) * TH * SA ? 2u : 0u) |
+                                        (t.dw0 + px < 0 ? 4u : 0u) | (t.dw0 + px >= sws - (t.tiles_x - 1) * TW * SA ? 8u : 0u));
+        if (it < 8) xhalo |= hb << (4 * it); else xhalo2 |= hb << (4 * (it - 8));
+        if constexpr (SA == 2) xl[it] = ((py * 2 + (px & 1)) * (PW >> 1) + (px >> 1)) * XS + xch * 16;
+    }
+
+    u32x4 yv[YIT], xv[XIT];
+    unsigned xzero = 0;                                       // units of the prefetched tile that lie outside the image
+    auto prefetch = [&](int tile) {
+        if constexpr (!TAB) {
+            const int img = tile / tpi, trem = tile - img * tpi;
+            const int a0 = (trem / t.tiles_x) * TH, b0 = (trem % t.tiles_x) * TW;
+#pragma unroll
+            for (int it = 0; it < YIT; ++it) {
+                int id = tid + it * NT;
+                int pix = id / YCH, ch = id - pix * YCH;
+                int py = pix / TW, px = pix - py * TW;
+                u32x4 z = {0, 0, 0, 0};
+                yv[it] = cou0 + ch < cd_units ? y16[(((size_t)img * d.MH + a0 + py) * d.MW + b0 + px) * cd_units + cou0 + ch] : z;
+            }
+#pragma unroll
+            for (int it = 0; it < XIT; ++it) {
+                int id = tid + it * NT;
+                int pp = id / XCH, ch = id - pp * XCH;
+                int py = pp / PW, px = pp - py * PW;
+                int sy = a0 * SA + t.dh0 + py, sx = b0 * SA + t.dw0 + px;          // coordinates at the (possibly x2-upsampled) resolution
+                bool ok = pp < PH * PW && ciu0 + ch < cs_units && (unsigned)sy < (unsigned)(d.SH << d.src_shift) &&
+                          (unsigned)sx < (unsigned)(d.SW << d.src_shift);
+                u32x4 z = {0, 0, 0, 0};
+                xv[it] = ok ? x16[(((size_t)img * d.SH + (sy >> d.src_shift)) * d.SW + (sx >> d.src_shift)) * cs_units + ciu0 + ch] : z;
+            }
+            return;
         }
+        // (uniform, but an integer division leaves its result in a VGPR: without the readfirstlane every address below is built
+        // per lane in 64 bits instead of SGPR base + 32-bit lane offset)
+        const int img = __builtin_amdgcn_readfirstlane(tile / tpi), trem = tile - img * tpi;
+        const int ty = __builtin_amdgcn_readfirstlane(trem / t.tiles_x), tx = trem - ty * t.tiles_x;
+        const int a0 = ty * TH, b0 = tx * TW;
+        const u32x4* __restrict__ yb = y16 + (((size_t)img * d.MH + a0) * d.MW + b0) * cd_units;
+#pragma unroll
+        for (int it = 0; it < YIT; ++it) yv[it] = yb[yoff0 + it * ystep];
+        // halo depth <= tile size: a row / column of the patch is outside the image only for tiles on that border
+        const unsigned border = (ty == 0 ? 1u : 0u) | (ty == t.tiles_y - 1 ? 2u : 0u) | (tx == 0 ? 4u : 0u) | (tx == t.tiles_x - 1 ? 8u : 0u);
+        const long long xbase = (((long long)img * d.SH + (((a0 * SA) >> sh) + row0)) * d.SW + (((b0 * SA) >> sh) + col0)) * cs_units;
+        const u32x4* __restrict__ xb = x16 + xbase;
+        xzero = 0;
 #pragma unroll
         for (int it = 0; it < XIT; ++it) {
-            int id = tid + it * NT;
-            int pp = id / XCH, ch = id - pp * XCH;
-            int py = pp / PW, px = pp - py * PW;
-            int sy = a0 * SA + t.dh0 + py, sx = b0 * SA + t.dw0 + px;          // coordinates at the (possibly x2-upsampled) resolution
-            bool ok = pp < PH * PW && ciu0 + ch < cs_units && (unsigned)sy < (unsigned)(d.SH << d.src_shift) &&
-                      (unsigned)sx < (unsigned)(d.SW << d.src_shift);
-            u32x4 z = {0, 0, 0, 0};
-            xv[it] = ok ? x16[(((size_t)img * d.SH + (sy >> d.src_shift)) * d.SW + (sx >> d.src_shift)) * cs_units + ciu0 + ch] : z;
+            const unsigned hb = it < 8 ? (xhalo >> (4 * it)) & 15u : (xhalo2 >> (4 * (it - 8))) & 15u;
+            const bool out = (hb & border) != 0;
+            xv[it] = xb[out ? xsafe : xoff[it]];
+            xzero |= out ? (1u << it) : 0u;
         }
     };
 
@@ -116,36 +180,100 @@ __global__ __launch_bounds__(NT, (SA == 1 ? WtOcc<NCO, NCI>::v : 1)) void wgrad_
         const int th = d.dh[0][tap] - t.dh0, tw = d.dw[0][tap] - t.dw0;
         itoff[j] = (SA == 1 ? th * PW + tw : (th * 2 + (tw & 1)) * (PW >> 1) + (tw >> 1)) * XS + (ib * 16) * 2;
     }
+    // this wave's share of the (ci block, tap) items: j < nv (wave-uniform, fixed for the launch)
+    int nv = (nitems - slice + NS - 1) / NS;
+    nv = nv < 0 ? 0 : (nv > MAXI ? MAXI : nv);
+    nv = __builtin_amdgcn_readfirstlane(nv);
+    const unsigned char* afrag = ydy + (size_t)(4 * fg + q) * YS + (cg * CBW * 16 + 4 * pp4) * 2;
+    const unsigned char* bfrag = xp + (size_t)(4 * fg + q) * XS + (4 * pp4) * 2;
+    // the fragment bases the K loop uses, re-derived per tile through an opaque zero: left loop-invariant, all KS x items read
+    // addresses are hoisted out of the tile loop and live across it (78 spilled registers)
+    const unsigned char *afr = afrag, *bfr = bfrag;
 
+    // K loop of one tile for a wave with NV items, branch-free and software-pipelined: the two transposing reads of item s+1 (and,
+    // once per K step, the dy fragments of step r+1) are issued in front of the MFMAs of item s and pinned there.  (The loop this
+    // replaces tested `item < nitems` per item: every item became a basic block of its own -- 2 reads, lgkmcnt(0), 4 MFMAs --
+    // so a wave alternated between waiting on the LDS and feeding the matrix pipe.)
+    auto kloop = [&](auto nvc) {
+        constexpr int NV = decltype(nvc)::value;
+        constexpr int NSTEP = KS * NV;
+        bf16x8 af[AF2 ? 2 : 1][CBW], bq[2];
+        auto rd_a = [&](int r, bf16x8* a) {
+#pragma unroll
+            for (int c = 0; c < CBW; ++c) {
+                const unsigned char* ab = afr + (size_t)(r * 32) * YS + c * 32;
+                bf16x4 alo = xmc_ds_read_tr16((ab));
+                bf16x4 ahi = xmc_ds_read_tr16((ab + 16 * YS));
+                a[c] = bf16x8{alo[0], alo[1], alo[2], alo[3], ahi[0], ahi[1], ahi[2], ahi[3]};
+            }
+        };
+        auto rd_b = [&](int r, int j) -> bf16x8 {
+            const unsigned char* bb = bfr + (SA == 1 ? r * (32 / TW) * PW : r * 2 * PW) * XS + itoff[j];
+            bf16x4 blo = xmc_ds_read_tr16((bb));
+            bf16x4 bhi = xmc_ds_read_tr16((bb + (T16 ? PW : 16) * XS));
+            return bf16x8{blo[0], blo[1], blo[2], blo[3], bhi[0], bhi[1], bhi[2], bhi[3]};
+        };
+        rd_a(0, af[0]);
+        bq[0] = rd_b(0, 0);
+#pragma unroll
+        for (int r = 0; r < KS; ++r) {
+            const int ab = AF2 ? (r & 1) : 0;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const int s = r * NV + j;
+                if (s + 1 < NSTEP) bq[(s + 1) & 1] = rd_b((s + 1) / NV, (s + 1) % NV);
+                if (AF2 && j == 0 && r + 1 < KS) rd_a(r + 1, af[AF2 ? (r + 1) & 1 : 0]);
+#pragma unroll
+                for (int c = 0; c < CBW; ++c) acc[j][c] = XMC_MFMA_16x16x32(af[ab][c], bq[s & 1], acc[j][c], 0, 0, 0);
+                if (!AF2 && j == NV - 1 && r + 1 < KS) rd_a(r + 1, af[0]);     // single buffer: behind the step's last MFMAs
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+
+    // One copy of the whole tile loop per K-loop variant, chosen once: with the variants as branches INSIDE the loop the
+    // accumulators of the three paths meet in phi nodes the register allocator did not coalesce (68 extra registers, spills).
+    auto tiles = [&](auto variant) {
+    constexpr int VNV = decltype(variant)::value;            // items per wave known at compile time; 0 = generic loop
     for (; tile < t.ntiles; tile += gridDim.x) {
         __syncthreads();                                      // previous tile's reads are done
 #pragma unroll
         for (int it = 0; it < YIT; ++it) {
-            int id = tid + it * NT;
-            int pix = id / YCH, ch = id - pix * YCH;
-            *reinterpret_cast<u32x4*>(ydy + pix * YS + ch * 16) = yv[it];
+            const int id = tid + it * NT;
+            u32x4 v = yv[it];
+            if (!yok) v = u32x4{0, 0, 0, 0};
+            *reinterpret_cast<u32x4*>(ydy + (id / YCH) * YS + ych * 16) = v;
             if (dbias != nullptr && blockIdx.y == 0) {        // bias gradient: this thread always holds chunk tid % YCH
-                bf16x8 h = __builtin_bit_cast(bf16x8, yv[it]);
+                bf16x8 h = __builtin_bit_cast(bf16x8, v);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) bsum[k] += (float)h[k];
             }
         }
 #pragma unroll
         for (int it = 0; it < XIT; ++it) {
-            int id = tid + it * NT;
-            int pp = id / XCH, ch = id - pp * XCH;
-            int lp = pp;
-            if (SA == 2) {                                    // patch pixel (py, px) -> row py, plane px & 1, column px >> 1
-                const int py = pp / PW, px = pp - py * PW;
-                lp = (py * 2 + (px & 1)) * (PW >> 1) + (px >> 1);
+            if constexpr (!TAB) {
+                const int pp = (tid + it * NT) / XCH;
+                if (pp < PH * PW) *reinterpret_cast<u32x4*>(xp + pp * XS + xch * 16) = xv[it];
+            } else {
+                u32x4 v = xv[it];
+                if ((xzero >> it) & 1) v = u32x4{0, 0, 0, 0};
+                const int lo = SA == 2 ? xl[SA == 2 ? it : 0] : ((tid + it * NT) / XCH) * XS + xch * 16;
+                if ((xin >> it) & 1) *reinterpret_cast<u32x4*>(xp + lo) = v;
             }
-            if (pp < PH * PW) *reinterpret_cast<u32x4*>(xp + lp * XS + ch * 16) = xv[it];
         }
         __syncthreads();
         if (tile + (int)gridDim.x < t.ntiles) prefetch(tile + gridDim.x);
 
         // K loop: 32 pixels per step (one tile row; two rows of a 16 x 16 tile: the upper 16 pixels of a fragment are then one
         // patch row further down instead of 16 columns to the right)
+        {
+            int zq = 0;
+            asm volatile("" : "+v"(zq));
+            afr = afrag + zq; bfr = bfrag + zq;
+        }
+        if constexpr (VNV > 0) {
+            kloop(std::integral_constant<int, VNV>{});
+        } else
         for (int r = 0; r < KS; ++r) {
             // A' fragment: dy^T [co = cb*16 + lane&15][pix = r*32 + 4*fg + j (+16)]: the 32 lanes one tr16 read serves together
             // address 8 consecutive pixel rows, which the 96/160-byte strides spread over distinct banks (rows 8*fg + j would
@@ -160,8 +288,7 @@ __global__ __launch_bounds__(NT, (SA == 1 ? WtOcc<NCO, NCI>::v : 1)) void wgrad_
             }
 #pragma unroll
             for (int j = 0; j < MAXI; ++j) {
-                const int item = slice + j * NS;
-                if (item < nitems) {                          // wave-uniform
+                if (slice + j * NS < nitems) {                                 // wave-uniform
                     const unsigned char* bb = xp + ((SA == 1 ? r * (32 / TW) * PW : r * 2 * PW) + 4 * fg + q) * XS + itoff[j] + (4 * pp4) * 2;
                     bf16x4 blo = xmc_ds_read_tr16((bb));
                     bf16x4 bhi = xmc_ds_read_tr16((bb + (T16 ? PW : 16) * XS));
@@ -180,6 +307,13 @@ __global__ __launch_bounds__(NT, (SA == 1 ? WtOcc<NCO, NCI>::v : 1)) void wgrad_
             }
         }
     }
+    };
+    // the pipelined K loop where its registers fit: the 8-wave 64 x 64 variants (one workgroup per CU, 256 registers per lane);
+    // the occupancy-capped small-channel variants keep the generic loop and hide LDS latency behind their other workgroups
+    constexpr bool PIPE = !DIAG && NT == 512 && SA == 1;
+    if (PIPE && nv == MAXI) tiles(std::integral_constant<int, PIPE ? MAXI : 0>{});
+    else if (PIPE && MAXI > 1 && nv == MAXI - 1) tiles(std::integral_constant<int, (PIPE && MAXI > 1) ? MAXI - 1 : 0>{});
+    else tiles(std::integral_constant<int, 0>{});
 
     if (dbias != nullptr && blockIdx.y == 0) {
 #pragma unroll
