@@ -67,7 +67,11 @@ __global__ __launch_bounds__(NT, (SA == 1 ? WtOcc<NCO, NCI>::v : 1)) void wgrad_
     const u32x4* __restrict__ y16 = reinterpret_cast<const u32x4*>(d.dst);
 
     constexpr int ACB = DIAG ? 1 : CBW;                      // accumulator blocks per item
-    constexpr bool AF2 = false;                               // dy fragments of the next K step in a second register set
+    // (same-box ablation, 64 x 64 blocks at batch 512: BD 1 / 2 / 3 with AF2 = 1030 / 1086 / 1014 TF/s, BD 1 without AF2 1040: the K loop
+    // is no longer what a tile waits for.  Of a tile's 4.3 us, 2.4 us are the global loads' latency when nothing else runs (they
+    // hide behind the K loop except ~0.5 us) and 3.75 us are K loop + LDS stores + the two barriers with the loads taken out.)
+    constexpr int BD = 2;                                     // x fragments in flight ahead of the MFMAs that use them
+    constexpr bool AF2 = NT == 512 && SA == 1 && !DIAG;                              // dy fragments of the next K step in a second register set
     // staging tables (below) where their ~XIT + 6 registers fit; the 4-wave variants that already sit at their register cap
     // (two workgroups per CU: the other one's MFMAs cover this one's address arithmetic) keep computing addresses per tile
     constexpr bool TAB = !(NT == 256 && SA == 1 && NCO >= 2 && NCO * NCI >= 4);
@@ -197,7 +201,7 @@ __global__ __launch_bounds__(NT, (SA == 1 ? WtOcc<NCO, NCI>::v : 1)) void wgrad_
     auto kloop = [&](auto nvc) {
         constexpr int NV = decltype(nvc)::value;
         constexpr int NSTEP = KS * NV;
-        bf16x8 af[AF2 ? 2 : 1][CBW], bq[2];
+        bf16x8 af[AF2 ? 2 : 1][CBW], bq[BD + 1];
         auto rd_a = [&](int r, bf16x8* a) {
 #pragma unroll
             for (int c = 0; c < CBW; ++c) {
@@ -214,17 +218,20 @@ __global__ __launch_bounds__(NT, (SA == 1 ? WtOcc<NCO, NCI>::v : 1)) void wgrad_
             return bf16x8{blo[0], blo[1], blo[2], blo[3], bhi[0], bhi[1], bhi[2], bhi[3]};
         };
         rd_a(0, af[0]);
-        bq[0] = rd_b(0, 0);
+#pragma unroll
+        for (int k = 0; k < BD; ++k)
+            if (k < NSTEP) bq[k] = rd_b(k / NV, k % NV);
 #pragma unroll
         for (int r = 0; r < KS; ++r) {
             const int ab = AF2 ? (r & 1) : 0;
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
                 const int s = r * NV + j;
-                if (s + 1 < NSTEP) bq[(s + 1) & 1] = rd_b((s + 1) / NV, (s + 1) % NV);
+                // the x fragment of item s + BD goes into the ring slot item s - 1 has just released
+                if (s + BD < NSTEP) bq[(s + BD) % (BD + 1)] = rd_b((s + BD) / NV, (s + BD) % NV);
                 if (AF2 && j == 0 && r + 1 < KS) rd_a(r + 1, af[AF2 ? (r + 1) & 1 : 0]);
 #pragma unroll
-                for (int c = 0; c < CBW; ++c) acc[j][c] = XMC_MFMA_16x16x32(af[ab][c], bq[s & 1], acc[j][c], 0, 0, 0);
+                for (int c = 0; c < CBW; ++c) acc[j][c] = XMC_MFMA_16x16x32(af[ab][c], bq[s % (BD + 1)], acc[j][c], 0, 0, 0);
                 if (!AF2 && j == NV - 1 && r + 1 < KS) rd_a(r + 1, af[0]);     // single buffer: behind the step's last MFMAs
                 __builtin_amdgcn_sched_barrier(0);
             }
