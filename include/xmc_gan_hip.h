@@ -26,7 +26,7 @@ extern "C" {
 
 /* 2: XmcConvDesc gained dst2 / dst_pool / round_act / groups, alpha applies only with alpha_dev, return codes are
  *    0 / XMC_E* / -(1000 + hipError_t); xmc_half_format() added.  lib.py refuses a library of another version. */
-#define XMC_ABI_VERSION 2
+#define XMC_ABI_VERSION 3
 
 /* XMC_BF16 names the 16-bit storage / MFMA-operand format THIS BUILD of the library was compiled for: bf16 in
  * libxmc_gan_hip.so, IEEE half in libxmc_gan_hip_f16.so (same sources, same entry points; xmc_half_format()). */
@@ -99,6 +99,12 @@ typedef struct XmcConvDesc {
     /* groups > 1: wpk is the block-diagonal expansion of an nn.Conv2d(groups=g) weight (xmc_pack_weight_grouped); kernels that
      * know the structure skip the zero blocks (conv_group.hip), the others multiply them.  0 is read as 1. */
     int32_t groups;
+    /* post_act (XMC_ACT_NONE / XMC_ACT_LRELU): an activation applied LAST, after alpha / mask / residual -- the LeakyReLU in front
+     * of the generator's output convolution (df_gan.py:84-85) applied to the block sum while it is written, so that the sum itself is
+     * never stored.  pool_scale: factor of the 2x2 sum written to dst_pool; 0 is read as 0.25 (average pool); 1 gives the adjoint
+     * of a nearest x2 upsample (sum pool), the gradient of the half-resolution shortcut of a generator block. */
+    int32_t post_act;
+    float pool_scale;
 } XmcConvDesc;
 
 int xmc_abi_version(void);
@@ -157,6 +163,11 @@ int xmc_unpack_wgrad(const float* dwp, float* gw, int Co, int Ci, int KH, int KW
 int xmc_unpack_wgrad_bias(const float* dwp, float* gw, int Co, int Ci, int KH, int KW, int rows_pad, int cols_pad,
                           const float* scale_dev, const int32_t* row_perm, int accumulate,
                           const float* gb_replicas, float* gb, int CD, void* stream);
+/* same, and *dot += sum_c bias_dot[c] * (the UNSCALED bias gradient c), c < Co: the bias term of d(alpha) of a layer
+ * y = alpha * (conv(x) + bias) whose output is not kept (xmc_affine2_act_bwd_dot); bias_dot and dot both NULL = the call above */
+int xmc_unpack_wgrad_bias_dot(const float* dwp, float* gw, int Co, int Ci, int KH, int KW, int rows_pad, int cols_pad,
+                              const float* scale_dev, const int32_t* row_perm, int accumulate,
+                              const float* gb_replicas, float* gb, int CD, const float* bias_dot, float* dot, void* stream);
 
 /* ---- layout conversion at the module boundary (NetD.forward input df_gan.py:127, NetG output df_gan.py:101) -- */
 int xmc_nchw_to_nhwc8(const float* src /*[N,C,H,W] f32*/, void* dst /*[N,H,W,8]*/, int N, int C, int H, int W,
@@ -270,6 +281,19 @@ int xmc_affine2_act_bwd(const void* x, const void* dy, const float* g0, const fl
 int xmc_affine2_act_bwd_acc(const void* x, const void* dy, const float* g0, const float* b0, const float* g1,
                             const float* b1, void* dx, float* dg0, float* db0, float* dg1, float* db1, const void* dx_in,
                             int N, int HW, int C, float slope, int dtype, void* stream);
+/* ... for a consumer y -> sum + alpha * f(y) whose backward hands over dy = d loss / d f's input UNSCALED (df_gan.py:200-202:
+ * `shortcut + gamma * c2(y)`): *dot += <dy, y> (y = this node's forward output, recomputed; d(alpha) up to f's bias term) and
+ * dy is multiplied by *alpha_dev before use.  alpha_dev and dot both NULL = the call above. */
+int xmc_affine2_act_bwd_dot(const void* x, const void* dy, const float* g0, const float* b0, const float* g1,
+                            const float* b1, void* dx, float* dg0, float* db0, float* dg1, float* db1, const void* dx_in,
+                            const float* alpha_dev, float* dot, int N, int HW, int C, float slope, int dtype, void* stream);
+/* ... and dx_pool [N, H/2, W/2, C] (optional) = the 2x2 sum pool of the dx this call writes (each dx rounded as stored): the
+ * gradient of the half-resolution shortcut of the generator block that produced x (the adjoint of F.interpolate(scale_factor=2),
+ * df_gan.py:200-202), written in the same pass */
+int xmc_affine2_act_bwd_dot_pool(const void* x, const void* dy, const float* g0, const float* b0, const float* g1,
+                                 const float* b1, void* dx, float* dg0, float* db0, float* dg1, float* db1, const void* dx_in,
+                                 const float* alpha_dev, float* dot, void* dx_pool, int N, int H, int W, int C, float slope,
+                                 int dtype, void* stream);
 /* single-stage form of the same kernels: pass g1 = b1 = NULL (and dg1 = db1 = NULL) -> y = lrelu(x*g0 + b0), the
  * concept blocks' modulation `gamma * img_embs + beta` + LeakyReLU (df_concept_gan.py:238-239,250-251) */
 

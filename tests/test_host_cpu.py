@@ -29,12 +29,12 @@ def test_library_loads_and_exports_every_declared_symbol(variant):
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/xmc_gan_hip.h but not exported"
     assert set(L.EXPORTS) == declared
-    assert lib.xmc_abi_version() == L.ABI_VERSION == 2
+    assert lib.xmc_abi_version() == L.ABI_VERSION == 3
     # argument validation happens before any launch, so it is safe without a GPU
     d = L.ConvDesc()
     assert lib.xmc_conv_igemm(ctypes.byref(d), None) == -1
     assert lib.xmc_conv_wgrad(ctypes.byref(d), None, None) == -1
-    assert ctypes.sizeof(L.ConvDesc) == 360 and ctypes.sizeof(L.AdamEntry) == 48 and ctypes.sizeof(L.PackJob) == 64   # = the C structs
+    assert ctypes.sizeof(L.ConvDesc) == 368 and ctypes.sizeof(L.AdamEntry) == 48 and ctypes.sizeof(L.PackJob) == 64   # = the C structs
     # the entry points added for the callers either side of the step reject bad arguments the same way (nothing launched)
     import numpy as np
     assert np.dtype(L.GEMM_PROBLEM).itemsize == 88                    # sizeof(XmcGemmProblem)

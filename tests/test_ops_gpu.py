@@ -862,3 +862,70 @@ def test_concept_stage_node_equals_composed_operators(mode, norm, with_sl):
         sc = b.abs().max().item() + 1e-12
         # bf16: the composed form rounds each of the three gradients of x to bf16 before adding them, the node adds in f32
         torch.testing.assert_close(a, b, rtol=3e-2 if mode == "bf16" else 2e-4, atol=(3e-2 if mode == "bf16" else 2e-4) * sc, msg=lambda m: f"tensor {k}: {m}")
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("C,H,tail,gamma", [(32, 32, True, 0.3), (32, 32, True, 0.0), (64, 16, False, 0.3), (128, 16, False, 0.0),
+                                            (256, 8, False, -0.5)])
+def test_generator_block_end_node_equals_composed_operators(mode, C, H, tail, gamma):
+    """ops.g_block_end (affine pair, c2, block sum with the upsampled shortcut [, LeakyReLU, conv_out, tanh] as ONE node whose
+    backward takes d(gamma) from <c2^T dout, h2> + <b2, colsum(dout)> instead of a stored c2 output, and the LeakyReLU' mask of
+    the tail inside conv_out's data gradient) against the same operators composed.  gamma = 0 is the reference's initial value
+    (df_gan.py:196): d(gamma) must survive it.  Followed by an affine-skip node of a next block, whose backward hands the 2x2 sum
+    pool of its dx to this node's backward (ops._pooled_grads) -- both ways must agree with the pooling pass."""
+    ops.set_precision(mode)
+    dt = ops.act_dtype()
+    g = torch.Generator().manual_seed(7 + C + H)
+    N = 3
+    rnd = lambda *sh, sc=1.0: (torch.randn(*sh, generator=g) * sc).to(DEV)
+    h10 = rnd(N, H, H, C).to(dt)
+    sc0 = rnd(N, H // 2, H // 2, C).to(dt)
+    mods0 = [rnd(N, C, sc=0.5) + (1.0 if i % 2 == 0 else 0.0) for i in range(4)]
+    mods_next0 = [rnd(N, C, sc=0.5) + (1.0 if i % 2 == 0 else 0.0) for i in range(4)]
+    w20, b20 = rnd(C, C, 3, 3, sc=(9 * C) ** -0.5), rnd(C, sc=0.1)
+    wo0, bo0 = rnd(3, C, 3, 3, sc=(9 * C) ** -0.5), rnd(3, sc=0.1)
+    geom2, geomo = ops.ConvGeom(C, C, 3, 1, 1), ops.ConvGeom(C, 3, 3, 1, 1)
+    r_img = rnd(N, H, H, 8).to(dt)
+    r_h, r_x = rnd(N, H, H, C).to(dt), rnd(N, H, H, C).to(dt)
+    res = []
+    # fp32: fused against composed.  Half formats: both against the composed operators in fp32 -- the fused node rounds FEWER
+    # intermediates (gamma * dout and the masked gradient are never stored), so the bar is "no further from the f32 result than
+    # the composed half-precision operators are" (x2 + a floor), not agreement between two differently rounded half results.
+    variants = [(True, mode), (False, mode)] + ([(False, "fp32")] if mode != "fp32" else [])
+    for fused, vmode in variants:
+        ops.set_precision(vmode)
+        vdt = ops.act_dtype()
+        leaf = lambda t: t.float().to(vdt).clone().requires_grad_() if t.dtype != torch.float32 else t.clone().requires_grad_()
+        h1, sc = leaf(h10), leaf(sc0)
+        ms, msn = [leaf(m) for m in mods0], [leaf(m) for m in mods_next0]
+        w2, b2, wo, bo = (torch.nn.Parameter(t.clone()) for t in (w20, b20, wo0, bo0))
+        gam = torch.nn.Parameter(torch.full((1,), gamma, device=DEV))
+        if fused:
+            y = ops.g_block_end(h1, ms, w2, b2, geom2, sc, gam, tail=(wo, bo, geomo) if tail else None)
+        else:
+            h2 = ops.affine2_lrelu(h1, *ms)
+            y = ops.axpby_up(sc, ops.conv2d(h2, w2, b2, geom2), gam, lrelu=tail)
+            if tail:
+                y = ops.conv2d(y, wo, bo, geomo, act=L.ACT_TANH)
+        if tail:
+            loss = (y.float() * r_img.float()).sum()
+        else:       # the next block's first node: its dx is this node's dout, its pooled dx this node's shortcut gradient
+            hn, xs = ops.affine2_lrelu_skip(y, *msn, pool_grad=fused)
+            loss = (hn.float() * r_h.float()).sum() + (xs.float() * r_x.float()).sum()
+        ops.new_iteration(DEV)
+        loss.backward()
+        assert not ops._pooled_grads, "the pooled by-product was not consumed"
+        res.append([y.detach().float(), h1.grad.float(), sc.grad.float(), gam.grad, w2.grad, b2.grad] + [m.grad for m in ms] +
+                   ([wo.grad, bo.grad] if tail else [m.grad for m in msn]))
+    ops.set_precision(mode)
+    names = ["y", "dh1", "dsc", "dgamma", "dw2", "db2", "dg0", "db0", "dg1", "db1"] + (["dwo", "dbo"] if tail else ["n0", "n1", "n2", "n3"])
+    for k, nm in enumerate(names):
+        fz, cp = res[0][k], res[1][k]
+        truth = res[2][k] if mode != "fp32" else cp
+        scl = truth.abs().max().item() + 1e-12
+        ef = (fz - truth).abs().max().item() / scl
+        if mode == "fp32":
+            assert ef < 2e-4, (nm, ef)
+        else:
+            ec = (cp - truth).abs().max().item() / scl
+            assert ef <= 2 * ec + 1e-2, (nm, ef, ec)

@@ -146,6 +146,10 @@ __device__ __forceinline__ void epilogue_tail(const XmcConvDesc& d, size_t idx8,
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] += rs * rr[k];
     }
+    if (d.post_act == XMC_ACT_LRELU) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = lrelu_f(v[k]);
+    }
     Vec8<ODT>::store(d.dst, idx8, v);
 }
 

@@ -339,6 +339,7 @@ extern "C" int xmc_conv_igemm(const XmcConvDesc* d, void* stream) {
             return XMC_ESHAPE;
     if ((int64_t)d->N * d->MH * d->MW >= (1ll << 31)) return XMC_ESHAPE;
     if (d->dst_pool && (d->DA != 1 || d->nclass != 1 || (d->DH & 1) || (d->DW & 1) || d->out_dtype != d->dtype)) return XMC_ESHAPE;
+    if (d->post_act != XMC_ACT_NONE && d->post_act != XMC_ACT_LRELU) return XMC_EINVAL;
     if (d->res_mode < 0 || d->res_mode > 2 || (d->res_mode == 2 && (d->DA != 1 || (d->DH & 1) || (d->DW & 1)))) return XMC_ESHAPE;
     static const bool no_tile = xmc_debug_off("no_tile");
     static const bool no_wt2 = xmc_debug_off("no_wtile_v2");
@@ -368,6 +369,6 @@ extern "C" int xmc_conv_igemm(const XmcConvDesc* d, void* stream) {
         rc = dd.dtype == XMC_BF16 ? dispatch<XMC_BF16>(dd, st) : dispatch<XMC_F32>(dd, st);
         if (rc != 0) return rc;
     }
-    if (d->dst_pool) return xmc_sumpool2(d->dst, d->dst_pool, d->N, d->DH, d->DW, d->CD, 0.25f, d->out_dtype, stream);
+    if (d->dst_pool) return xmc_sumpool2(d->dst, d->dst_pool, d->N, d->DH, d->DW, d->CD, d->pool_scale == 0.f ? 0.25f : d->pool_scale, d->out_dtype, stream);
     return 0;
 }

@@ -73,6 +73,8 @@ __global__ __launch_bounds__(256) void thin_in_kernel(const XmcConvDesc d, const
     const float slope = d.act == XMC_ACT_LRELU ? XMC_LRELU : 1.f;
     const int tpi = t.tiles_y * t.tiles_x;
     bf16x8* __restrict__ dst8 = reinterpret_cast<bf16x8*>(d.dst);
+    const bf16x8* __restrict__ mask8 = reinterpret_cast<const bf16x8*>(d.mask);
+    const float pscale = d.pool_scale == 0.f ? 0.25f : d.pool_scale;
 
     u32x4 pv[2];
     unsigned okbits = 0;
@@ -128,11 +130,21 @@ __global__ __launch_bounds__(256) void thin_in_kernel(const XmcConvDesc d, const
                 for (int u = 0; u < UPL; ++u) {
                     if (ch0 + u * 8 >= d.CD) continue;
                     bf16x8 o;
+                    if (mask8 == nullptr) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float x0 = acc[2 * u][q] + bias8[u][q], x1 = acc[2 * u + 1][q] + bias8[u][4 + q];
-                        o[q] = (xmc_h16)fmaxf(x0, x0 * slope);
-                        o[4 + q] = (xmc_h16)fmaxf(x1, x1 * slope);
+                        for (int q = 0; q < 4; ++q) {
+                            const float x0 = acc[2 * u][q] + bias8[u][q], x1 = acc[2 * u + 1][q] + bias8[u][4 + q];
+                            o[q] = (xmc_h16)fmaxf(x0, x0 * slope);
+                            o[4 + q] = (xmc_h16)fmaxf(x1, x1 * slope);
+                        }
+                    } else {              // data gradient of the layer above a LeakyReLU: times LeakyReLU'(mask), mask in the dst layout
+                        const bf16x8 mk = mask8[dbase + eoff[i] + u];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float x0 = acc[2 * u][q] + bias8[u][q], x1 = acc[2 * u + 1][q] + bias8[u][4 + q];
+                            o[q] = (xmc_h16)(fmaxf(x0, x0 * slope) * lrelu_slope((float)mk[q]));
+                            o[4 + q] = (xmc_h16)(fmaxf(x1, x1 * slope) * lrelu_slope((float)mk[4 + q]));
+                        }
                     }
                     dst8[dbase + eoff[i] + u] = o;
 #pragma unroll
@@ -150,7 +162,7 @@ __global__ __launch_bounds__(256) void thin_in_kernel(const XmcConvDesc d, const
                     for (int q = 0; q < 8; ++q) {
                         float sm = fin[0][u][q] + fin[1][u][q];
                         sm += __shfl_xor(sm, 1, 64);
-                        o[q] = (xmc_h16)(0.25f * sm);
+                        o[q] = (xmc_h16)(pscale * sm);
                     }
                     if ((fr & 1) == 0) pool8[((img * (d.DH >> 1) + prow) * (d.DW >> 1) + pcol) * cd8 + fc * UPL + u] = o;
                 }
@@ -326,7 +338,7 @@ int xmc_conv_thin_out_try(const XmcConvDesc* d, void* stream) {
     if (off) return 1;
     if (d->dtype != XMC_BF16 || d->out_dtype != XMC_BF16 || d->CD != 8 || (d->CS != 32 && d->CS != 64) || d->CDw < 16) return 1;
     if (d->SA != 1 || d->DA != 1 || d->src_shift != 0 || d->nclass != 1 || d->ntaps != 9 || d->groups > 1) return 1;
-    if (d->res || d->mask || d->alpha_dev || d->dst2 || d->dst_pool) return 1;
+    if (d->res || d->mask || d->alpha_dev || d->dst2 || d->dst_pool || d->post_act) return 1;
     if (d->act != XMC_ACT_NONE && d->act != XMC_ACT_TANH && d->act != XMC_ACT_LRELU) return 1;
     if (d->MH % TO_H != 0 || d->MW % TO_W != 0 || d->SH != d->MH || d->SW != d->MW || d->DH != d->MH || d->DW != d->MW) return 1;
     if (d->dph[0] != 0 || d->dpw[0] != 0) return 1;
@@ -349,7 +361,7 @@ int xmc_conv_thin_try(const XmcConvDesc* d, void* stream) {
     if (d->dtype != XMC_BF16 || d->out_dtype != XMC_BF16 || d->CS != 8) return 1;
     if (d->SA != 1 || d->DA != 1 || d->src_shift != 0 || d->nclass != 1 || d->ntaps > 12) return 1;
     if (d->CDw != 32 && d->CDw != 64) return 1;
-    if (d->res || d->mask || d->alpha_dev || d->dst2 || (d->act != XMC_ACT_NONE && d->act != XMC_ACT_LRELU)) return 1;
+    if (d->res || d->alpha_dev || d->dst2 || d->post_act || (d->act != XMC_ACT_NONE && d->act != XMC_ACT_LRELU)) return 1;
     if (d->MH % 8 != 0 || d->MW % 32 != 0 || d->SH != d->MH || d->SW != d->MW || d->DH != d->MH || d->DW != d->MW) return 1;
     if (d->dph[0] != 0 || d->dpw[0] != 0) return 1;
     int hmin = 127, hmax = -128, wmin = 127, wmax = -128;
@@ -386,6 +398,7 @@ int xmc_conv_pw1x1_try(const XmcConvDesc* d, void* stream) {
     if (d->ntaps != 1 || d->nclass != 1 || d->SA != 1 || d->DA != 1 || d->src_shift != 0) return 1;
     if (d->dh[0][0] != 0 || d->dw[0][0] != 0 || d->dph[0] != 0 || d->dpw[0] != 0) return 1;
     if (d->SH != d->MH || d->SW != d->MW || d->DH != d->MH || d->DW != d->MW) return 1;
+    if (d->post_act) return 1;
     if (d->res || d->mask || d->alpha_dev || d->dst2 || (d->act != XMC_ACT_NONE && d->act != XMC_ACT_LRELU)) return 1;
     if (d->CS % 32 != 0 || d->CS > 128 || d->CDw % 32 != 0 || d->CDw > 128 || d->CD % 8 != 0) return 1;
     const int ks = d->CS / 32, tn = d->CDw / 16;

@@ -368,6 +368,7 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
         }
         const int bbyte = l32 * pstride + hh * 16;
         const float alpha = d.alpha_dev ? *d.alpha_dev : 1.f;
+        const float pscale = d.pool_scale == 0.f ? 0.25f : d.pool_scale;
         const float slope = d.act == XMC_ACT_LRELU ? XMC_LRELU : (d.act == XMC_ACT_RELU ? 0.f : 1.f);
         const float rs = d.res_scale == 0.f ? 1.f : d.res_scale;
         __syncthreads();                          // weights + first patch staged
@@ -488,6 +489,10 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
 #pragma unroll
                                 for (int r = 0; r < 8; ++r) v[r] += rs * (float)rrv[c][pb][v2][r];
                             }
+                            if (d.post_act == XMC_ACT_LRELU) {
+#pragma unroll
+                                for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], v[r] * XMC_LRELU);
+                            }
                             bf16x8 o;
 #pragma unroll
                             for (int r = 0; r < 8; ++r) { o[r] = (xmc_h16)v[r]; fin[pb][v2][r] = (float)o[r]; }
@@ -506,7 +511,7 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
                                 for (int r = 0; r < 8; ++r) {
                                     float sm = fin[0][v2][r] + fin[1][v2][r];
                                     sm += __shfl_xor(sm, 1, 64);
-                                    o[r] = (xmc_h16)(0.25f * sm);
+                                    o[r] = (xmc_h16)(pscale * sm);
                                 }
                                 if ((l32 & 1) == 0)
                                     pool8[((img * (d.DH >> 1) + ((a0 + pty[0]) >> 1)) * (d.DW >> 1) + ((b0 + ptx[0]) >> 1)) * cd8 + (n0 >> 3) + ub + v2] = o;
@@ -519,7 +524,7 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
                                         float sm = fin[pb][v2][r];
                                         sm += __shfl_xor(sm, 16, 64);
                                         sm += __shfl_xor(sm, 1, 64);
-                                        o[r] = (xmc_h16)(0.25f * sm);
+                                        o[r] = (xmc_h16)(pscale * sm);
                                     }
                                     if ((l32 & 17) == 0)
                                         pool8[((img * (d.DH >> 1) + ((a0 + pty[pb]) >> 1)) * (d.DW >> 1) + ((b0 + ptx[pb]) >> 1)) * cd8 + (n0 >> 3) + ub + v2] = o;
@@ -546,13 +551,14 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
         const int bbyte = fr * pstride + fc * 16;
         const int ch0 = n0 + fc * 8;                          // unit u of this lane: channels ch0 + 32*u .. +7
         const float alpha = d.alpha_dev ? *d.alpha_dev : 1.f;
+        const float pscale = d.pool_scale == 0.f ? 0.25f : d.pool_scale;
         float bias8[UPL][8];
 #pragma unroll
         for (int u = 0; u < UPL; ++u)
 #pragma unroll
             for (int c = 0; c < 8; ++c) bias8[u][c] = (d.bias && ch0 + u * 32 < d.CD) ? d.bias[ch0 + u * 32 + c] : 0.f;
         // one uniform decision instead of a chain of branches per stored unit
-        const bool fast = d.out_dtype == XMC_BF16 && d.res == nullptr && d.mask == nullptr && d.alpha_dev == nullptr && d.dst2 == nullptr && d.dst_pool == nullptr &&
+        const bool fast = d.out_dtype == XMC_BF16 && d.res == nullptr && d.mask == nullptr && d.alpha_dev == nullptr && d.dst2 == nullptr && d.dst_pool == nullptr && d.post_act == XMC_ACT_NONE &&
                           (d.act == XMC_ACT_NONE || d.act == XMC_ACT_LRELU || d.act == XMC_ACT_TANH);
         const bool do_tanh = d.act == XMC_ACT_TANH;
         const float slope = d.act == XMC_ACT_LRELU ? XMC_LRELU : 1.f;
@@ -575,6 +581,34 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // bf16 epilogue operands (LeakyReLU' mask, residual) are requested NOW, before the tile's MFMAs, as in the 32x32x16 role:
+            // requested in the epilogue, one memory round trip per tile stood between the last MFMA and the first store -- at 32
+            // channels as long as the tile's whole K loop (32 -> 32 @ 256^2 with the block sum: 1.01 ms against 0.55 without).
+            const bool pre = d.out_dtype == XMC_BF16;
+            const int dbase = (((img * d.DH + a0 * d.DA + dph) * d.DW) + b0 * d.DA + dpw) * cd8 + (n0 >> 3);
+            const int rbase = ((img * d.MH + a0) * d.MW + b0) * cd8 + (n0 >> 3);
+            // (one 32-channel unit per lane only: with two, the 64 extra live registers spill; the 64-channel layers with such an
+            // epilogue run in the 32x32x16 role anyway)
+            constexpr bool HOIST = UPL == 1;
+            bf16x8 mkv[HOIST ? TM : 1], rrv[HOIST ? TM : 1];
+            if (HOIST && pre && (d.mask || d.res)) {
+#pragma unroll
+                for (int u = 0; u < UPL; ++u) {
+                    if (ch0 + u * 32 >= d.CD) continue;
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        const size_t idx8 = (size_t)(dbase + eoff[i] + u * 4);
+                        size_t rix = d.res_mode == 1 ? (size_t)(rbase + roff[i] + u * 4) : idx8;
+                        if (d.res_mode == 2) {
+                            const int ml_ = wm * (16 * TM) + i * 16 + fr;
+                            const int y_ = (a0 + (ml_ >> t.log2TW)) * d.DA + dph, x_ = (b0 + (ml_ & (t.TW - 1))) * d.DA + dpw;
+                            rix = res_index8(d, idx8, img, y_, x_, 0, 0, (n0 >> 3) + fc + u * 4);
+                        }
+                        if (d.mask) mkv[HOIST ? i : 0] = reinterpret_cast<const bf16x8*>(d.mask)[idx8];
+                        if (d.res) rrv[HOIST ? i : 0] = reinterpret_cast<const bf16x8*>(d.res)[rix];
+                    }
+                }
+            }
             auto ldfrag = [&](int toff, int tap, int s, u32x4* p, u32x4* w) {
                 const unsigned char* pa = patch + toff + s * 64;
                 const unsigned char* wb = wall + tap * BN * pstride + bbyte + s * 64;
@@ -635,8 +669,6 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
             }
             if (mc == MC - 1) __syncthreads();    // B2: patch may be overwritten
             // epilogue from registers: acc[i][j][r] = pixel (m-block i, fr), channel ch0 + j*4 + r
-            const int dbase = (((img * d.DH + a0 * d.DA + dph) * d.DW) + b0 * d.DA + dpw) * cd8 + (n0 >> 3);
-            const int rbase = ((img * d.MH + a0) * d.MW + b0) * cd8 + (n0 >> 3);
             if (fast) {
                 bf16x8* __restrict__ dst8 = reinterpret_cast<bf16x8*>(d.dst) + dbase;
 #pragma unroll
@@ -673,22 +705,21 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
                 for (int u = 0; u < UPL; ++u) {
                     if (ch0 + u * 32 >= d.CD) continue;
                     float fin[TM][8];
-                    // bf16: mask / residual vectors of the whole unit are requested before the first is used (one memory latency
-                    // per unit instead of one per vector)
-                    const bool pre = d.out_dtype == XMC_BF16;
-                    bf16x8 mkv[TM], rrv[TM];
-                    size_t rix[TM];
+                    size_t rix[TM];           // f32 destination: epilogue_tail loads its own operands; two units: one round trip per unit
+                    bf16x8 mkl[HOIST ? 1 : TM], rrl[HOIST ? 1 : TM];
+                    if (!pre || !HOIST) {
 #pragma unroll
-                    for (int i = 0; i < TM; ++i) {
-                        const size_t idx8 = (size_t)(dbase + eoff[i] + u * 4);
-                        rix[i] = d.res_mode == 1 ? (size_t)(rbase + roff[i] + u * 4) : idx8;
-                        if (d.res_mode == 2) {
-                            const int ml_ = wm * (16 * TM) + i * 16 + fr;
-                            const int y_ = (a0 + (ml_ >> t.log2TW)) * d.DA + dph, x_ = (b0 + (ml_ & (t.TW - 1))) * d.DA + dpw;
-                            rix[i] = res_index8(d, idx8, img, y_, x_, 0, 0, (n0 >> 3) + fc + u * 4);
+                        for (int i = 0; i < TM; ++i) {
+                            const size_t idx8 = (size_t)(dbase + eoff[i] + u * 4);
+                            rix[i] = d.res_mode == 1 ? (size_t)(rbase + roff[i] + u * 4) : idx8;
+                            if (d.res_mode == 2) {
+                                const int ml_ = wm * (16 * TM) + i * 16 + fr;
+                                const int y_ = (a0 + (ml_ >> t.log2TW)) * d.DA + dph, x_ = (b0 + (ml_ & (t.TW - 1))) * d.DA + dpw;
+                                rix[i] = res_index8(d, idx8, img, y_, x_, 0, 0, (n0 >> 3) + fc + u * 4);
+                            }
+                            if (pre && d.mask) mkl[HOIST ? 0 : i] = reinterpret_cast<const bf16x8*>(d.mask)[idx8];
+                            if (pre && d.res) rrl[HOIST ? 0 : i] = reinterpret_cast<const bf16x8*>(d.res)[rix[i]];
                         }
-                        if (pre && d.mask) mkv[i] = reinterpret_cast<const bf16x8*>(d.mask)[idx8];
-                        if (pre && d.res) rrv[i] = reinterpret_cast<const bf16x8*>(d.res)[rix[i]];
                     }
 #pragma unroll
                     for (int i = 0; i < TM; ++i) {
@@ -720,12 +751,16 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
                             }
                             if (d.mask) {
 #pragma unroll
-                                for (int q = 0; q < 8; ++q) v[q] *= lrelu_slope((float)mkv[i][q]);
+                                for (int q = 0; q < 8; ++q) v[q] *= lrelu_slope((float)(HOIST ? mkv[HOIST ? i : 0] : mkl[HOIST ? 0 : i])[q]);
                             }
                             if (d.res) {
                                 const float rs = d.res_scale == 0.f ? 1.f : d.res_scale;
 #pragma unroll
-                                for (int q = 0; q < 8; ++q) v[q] += rs * (float)rrv[i][q];
+                                for (int q = 0; q < 8; ++q) v[q] += rs * (float)(HOIST ? rrv[HOIST ? i : 0] : rrl[HOIST ? 0 : i])[q];
+                            }
+                            if (d.post_act == XMC_ACT_LRELU) {
+#pragma unroll
+                                for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], v[q] * XMC_LRELU);
                             }
                             bf16x8 o;
 #pragma unroll
@@ -751,7 +786,7 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
                             for (int q = 0; q < 8; ++q) {
                                 float sm = t.log2TW == 5 ? fin[pr][q] + fin[(pr + 2) % TM][q] : fin[(2 * pr) % TM][q] + fin[(2 * pr + 1) % TM][q];
                                 sm += __shfl_xor(sm, 1, 64);
-                                o[q] = (xmc_h16)(0.25f * sm);
+                                o[q] = (xmc_h16)(pscale * sm);
                             }
                             if ((fr & 1) == 0)
                                 pool8[((img * (d.DH >> 1) + ((a0 + ty_) >> 1)) * (d.DW >> 1) + ((b0 + tx_) >> 1)) * cd8 + (n0 >> 3) + fc + u * 4] = o;

@@ -304,6 +304,10 @@ __global__ __launch_bounds__(512) void wtile3_kernel(const XmcConvDesc d, const 
 #pragma unroll
                         for (int r = 0; r < 8; ++r) v[r] += rs * (float)rrv[i][r];
                     }
+                    if (d.post_act == XMC_ACT_LRELU) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], v[r] * XMC_LRELU);
+                    }
                     bf16x8 o;
 #pragma unroll
                     for (int r = 0; r < 8; ++r) { o[r] = (xmc_h16)v[r]; fin[i][r] = (float)o[r]; }
@@ -322,7 +326,7 @@ __global__ __launch_bounds__(512) void wtile3_kernel(const XmcConvDesc d, const 
                         for (int r = 0; r < 8; ++r) {
                             float sm = (t.log2TW == 5 ? fin[pr][r] + fin[pr + 2][r] : fin[2 * pr][r] + fin[2 * pr + 1][r]);
                             sm += __shfl_xor(sm, 1, 64);
-                            o[r] = (xmc_h16)(0.25f * sm);
+                            o[r] = (xmc_h16)((d.pool_scale == 0.f ? 0.25f : d.pool_scale) * sm);
                         }
                         if ((lane_op & 1) == 0)
                             pool8[((img * (d.DH >> 1) + ((a0 + ty) >> 1)) * (d.DW >> 1) + ((b0 + tx) >> 1)) * cd8 + nw8 + fc + u * 4] = o;

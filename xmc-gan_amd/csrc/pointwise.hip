@@ -359,10 +359,20 @@ __global__ void affine2_fwd_kernel(const void* x, const float* g0, const float* 
         Vec8<DT>::store(y, idx, v);
     }
 }
-template <int DT>
+// POOL: the loop runs over 2x2 pixel quads instead of pixels (HW = number of quads, Wq = quads per row) and the sum of the four
+// ROUNDED dx of a quad goes to dx_pool [N, HW, C]: the 2x2 sum pool of dx, i.e. the gradient of the producing generator block's
+// half-resolution shortcut (df_gan.py:200-202), without another pass over dx.
+template <int DT, bool POOL>
 __global__ void affine2_bwd_kernel(const void* x, const void* dy, const float* g0, const float* b0, const float* g1,
                                    const float* b1, void* dx, float* dg0, float* db0, float* dg1, float* db1,
-                                   int HW, int C8, int pix_per_block, float slope, const void* dx_in) {
+                                   int HW, int C8, int pix_per_block, float slope, const void* dx_in,
+                                   const float* alpha_dev, float* dot, void* dx_pool, int Wq) {
+    // alpha_dev / dot (both optional): dy arrives UNSCALED from a consumer y -> alpha * f(y) (the block sum `shortcut + gamma *
+    // c2(y)`, df_gan.py:200-202): dot += <dy, y> with y this node's forward output recomputed here, which is d(alpha) up to the
+    // consumer's bias term, and dy is multiplied by alpha before it is used -- so the consumer's output never has to be stored
+    // for d(gamma), and gamma = 0 (the reference's initial value) loses nothing.
+    const float al = alpha_dev ? *alpha_dev : 1.f;
+    float dacc = 0.f;
     const int n = blockIdx.y, groups = NT / C8;
     const int cc = threadIdx.x % C8, g = threadIdx.x / C8;
     float G0[8], B0[8], G1[8], B1[8];
@@ -374,32 +384,57 @@ __global__ void affine2_bwd_kernel(const void* x, const void* dy, const float* g
         G0[k] = g0[pb + k]; B0[k] = b0[pb + k]; G1[k] = two ? g1[pb + k] : 1.f; B1[k] = two ? b1[pb + k] : 0.f;
         sg0[k] = sb0[k] = sg1[k] = sb1[k] = 0.f;
     }
+    // one pixel: its dx is stored and (POOL) added, rounded as stored, to acc8
+    auto pixel = [&](size_t pix, float* acc8) {
+        float xv[8], dv[8];
+        const size_t idx = pix * C8 + cc;
+        Vec8<DT>::load(x, idx, xv);
+        Vec8<DT>::load(dy, idx, dv);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float u = xv[k] * G0[k] + B0[k];
+            float a1 = u > 0.f ? u : slope * u;
+            float v = a1 * G1[k] + B1[k];
+            if (dot) {
+                const float y2 = two ? (v > 0.f ? v : slope * v) : a1;
+                dacc += dv[k] * (DT == XMC_BF16 ? (float)(xmc_h16)y2 : y2);       // the consumer read the stored (rounded) y
+            }
+            const float dvk = dv[k] * al;
+            float dvv = two ? dvk * (v > 0.f ? 1.f : slope) : dvk;
+            sg1[k] += dvv * a1; sb1[k] += dvv;
+            float du = dvv * G1[k] * (u > 0.f ? 1.f : slope);
+            sg0[k] += du * xv[k]; sb0[k] += du;
+            xv[k] = du * G0[k];
+        }
+        if (dx_in) {                  // another gradient of x (the block's shortcut branch) joins here instead of in an add pass
+            float o[8];
+            Vec8<DT>::load(dx_in, idx, o);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) xv[k] += o[k];
+        }
+        Vec8<DT>::store(dx, idx, xv);
+        if (POOL) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc8[k] += DT == XMC_BF16 ? (float)(xmc_h16)xv[k] : xv[k];
+        }
+    };
     const int p_end = min(HW, (int)(blockIdx.x + 1) * pix_per_block);
     if (g < groups)
         for (int p = blockIdx.x * pix_per_block + g; p < p_end; p += groups) {
-            float xv[8], dv[8];
-            const size_t idx = ((size_t)n * HW + p) * C8 + cc;
-            Vec8<DT>::load(x, idx, xv);
-            Vec8<DT>::load(dy, idx, dv);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                float u = xv[k] * G0[k] + B0[k];
-                float a1 = u > 0.f ? u : slope * u;
-                float v = a1 * G1[k] + B1[k];
-                float dvv = two ? dv[k] * (v > 0.f ? 1.f : slope) : dv[k];
-                sg1[k] += dvv * a1; sb1[k] += dvv;
-                float du = dvv * G1[k] * (u > 0.f ? 1.f : slope);
-                sg0[k] += du * xv[k]; sb0[k] += du;
-                xv[k] = du * G0[k];
+            if (!POOL) {
+                pixel((size_t)n * HW + p, nullptr);
+            } else {
+                const int qy = p / Wq, qx = p - qy * Wq;
+                const size_t p00 = (size_t)n * HW * 4 + (size_t)(2 * qy) * (2 * Wq) + 2 * qx;
+                float acc8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                pixel(p00, acc8); pixel(p00 + 1, acc8); pixel(p00 + 2 * Wq, acc8); pixel(p00 + 2 * Wq + 1, acc8);
+                Vec8<DT>::store(dx_pool, ((size_t)n * HW + p) * C8 + cc, acc8);
             }
-            if (dx_in) {                  // another gradient of x (the block's shortcut branch) joins here instead of in an add pass
-                float o[8];
-                Vec8<DT>::load(dx_in, idx, o);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) xv[k] += o[k];
-            }
-            Vec8<DT>::store(dx, idx, xv);
         }
+    if (dot) {
+        dacc = wave_sum(dacc);
+        if ((threadIdx.x & 63) == 0) atomicAdd(dot, dacc);
+    }
     // block reduction over the `groups` pixel lanes that share a channel chunk
     __shared__ float red[NT * 8];
     float* outs[4] = {dg0, db0, dg1, db1};
@@ -658,7 +693,8 @@ __global__ void axpby_bwd_kernel(const void* dy, const void* b, const float* alp
 
 __global__ void unpack_wgrad_kernel(const float* dwp, float* gw, int Co, int Ci, int KHW, int rows_pad, int cols_pad,
                                     const float* scale_dev, const int32_t* row_perm, int accumulate,
-                                    const float* gb_rep, float* gb, int CDb, int groups) {
+                                    const float* gb_rep, float* gb, int CDb, int groups,
+                                    const float* bias_dot, float* dot) {
     // groups > 1: gw is a grouped-convolution weight gradient [Co][Ci/groups][KHW] = the diagonal blocks of the dense one
     const float scale = scale_dev ? *scale_dev : 1.f;
     const int cog = Co / groups, cig = Ci / groups;
@@ -671,6 +707,8 @@ __global__ void unpack_wgrad_kernel(const float* dwp, float* gw, int Co, int Ci,
 #pragma unroll
             for (int r = 0; r < XMC_BIAS_REPLICAS; ++r) sacc += gb_rep[r * CDb + c];
             gb[c] = scale * sacc;
+            // <bias, UNSCALED bias gradient>: the bias term of d(alpha) for y = alpha * (conv(x) + bias) (see affine2_bwd_kernel)
+            if (bias_dot && c < Co) atomicAdd(dot, bias_dot[c] * sacc);
         }
     }
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -919,19 +957,35 @@ extern "C" int xmc_affine2_act_fwd(const void* x, const float* g0, const float* 
     XMC_LAUNCH_CHECK();
     return 0;
 }
+extern "C" int xmc_affine2_act_bwd_dot_pool(const void* x, const void* dy, const float* g0, const float* b0, const float* g1,
+                                            const float* b1, void* dx, float* dg0, float* db0, float* dg1, float* db1,
+                                            const void* dx_in, const float* alpha_dev, float* dot, void* dx_pool, int N, int H, int W,
+                                            int C, float slope, int dtype, void* s) {
+    if (C % 8 || C / 8 > NT) return XMC_EALIGN;
+    if ((alpha_dev == nullptr) != (dot == nullptr)) return XMC_EINVAL;
+    if (dx_pool && ((H & 1) || (W & 1))) return XMC_ESHAPE;
+    const int HW = dx_pool ? (H / 2) * (W / 2) : H * W;          // loop units: quads or pixels
+    dim3 g; int ppb;
+    affine_grid(HW, C / 8, N, g, ppb, dx_pool ? 16 : 64);
+#define XMC_AFF_BWD(DTC, PL) hipLaunchKernelGGL((affine2_bwd_kernel<DTC, PL>), g, dim3(NT), 0, ST(s), x, dy, g0, b0, g1, b1, dx, dg0, db0, dg1, db1, \
+                                                HW, C / 8, ppb, slope, dx_in, alpha_dev, dot, dx_pool, W / 2)
+    if (dtype == XMC_BF16) { if (dx_pool) XMC_AFF_BWD(XMC_BF16, true); else XMC_AFF_BWD(XMC_BF16, false); }
+    else if (dtype == XMC_F32) { if (dx_pool) XMC_AFF_BWD(XMC_F32, true); else XMC_AFF_BWD(XMC_F32, false); }
+    else return XMC_EINVAL;
+#undef XMC_AFF_BWD
+    XMC_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int xmc_affine2_act_bwd_dot(const void* x, const void* dy, const float* g0, const float* b0, const float* g1,
+                                       const float* b1, void* dx, float* dg0, float* db0, float* dg1, float* db1,
+                                       const void* dx_in, const float* alpha_dev, float* dot, int N, int HW, int C, float slope,
+                                       int dtype, void* s) {
+    return xmc_affine2_act_bwd_dot_pool(x, dy, g0, b0, g1, b1, dx, dg0, db0, dg1, db1, dx_in, alpha_dev, dot, nullptr, N, 1, HW, C, slope, dtype, s);
+}
 extern "C" int xmc_affine2_act_bwd_acc(const void* x, const void* dy, const float* g0, const float* b0, const float* g1,
                                        const float* b1, void* dx, float* dg0, float* db0, float* dg1, float* db1,
                                        const void* dx_in, int N, int HW, int C, float slope, int dtype, void* s) {
-    if (C % 8 || C / 8 > NT) return XMC_EALIGN;
-    dim3 g; int ppb;
-    affine_grid(HW, C / 8, N, g, ppb, 64);
-    if (dtype == XMC_BF16)
-        hipLaunchKernelGGL((affine2_bwd_kernel<XMC_BF16>), g, dim3(NT), 0, ST(s), x, dy, g0, b0, g1, b1, dx, dg0, db0, dg1, db1, HW, C / 8, ppb, slope, dx_in);
-    else if (dtype == XMC_F32)
-        hipLaunchKernelGGL((affine2_bwd_kernel<XMC_F32>), g, dim3(NT), 0, ST(s), x, dy, g0, b0, g1, b1, dx, dg0, db0, dg1, db1, HW, C / 8, ppb, slope, dx_in);
-    else return XMC_EINVAL;
-    XMC_LAUNCH_CHECK();
-    return 0;
+    return xmc_affine2_act_bwd_dot(x, dy, g0, b0, g1, b1, dx, dg0, db0, dg1, db1, dx_in, nullptr, nullptr, N, HW, C, slope, dtype, s);
 }
 extern "C" int xmc_affine2_act_bwd(const void* x, const void* dy, const float* g0, const float* b0, const float* g1,
                                    const float* b1, void* dx, float* dg0, float* db0, float* dg1, float* db1,
@@ -1011,7 +1065,7 @@ extern "C" int xmc_unpack_wgrad_grouped(const float* dwp, float* gw, int Co, int
     if (!dwp || !gw || rows_pad < Co || cols_pad < Ci || groups < 1 || Co % groups || Ci % groups) return XMC_EINVAL;
     int64_t total = (int64_t)Co * (Ci / groups) * KH * KW;
     hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(nblocks(total)), dim3(NT), 0, ST(s), dwp, gw, Co, Ci, KH * KW, rows_pad, cols_pad,
-                       scale_dev, row_perm, accumulate, (const float*)nullptr, (float*)nullptr, 0, groups);
+                       scale_dev, row_perm, accumulate, (const float*)nullptr, (float*)nullptr, 0, groups, (const float*)nullptr, (float*)nullptr);
     XMC_LAUNCH_CHECK();
     return 0;
 }
@@ -1019,15 +1073,22 @@ extern "C" int xmc_unpack_wgrad(const float* dwp, float* gw, int Co, int Ci, int
                                 const float* scale_dev, const int32_t* row_perm, int accumulate, void* s) {
     return xmc_unpack_wgrad_grouped(dwp, gw, Co, Ci, KH, KW, rows_pad, cols_pad, scale_dev, row_perm, accumulate, 1, s);
 }
+extern "C" int xmc_unpack_wgrad_bias_dot(const float* dwp, float* gw, int Co, int Ci, int KH, int KW, int rows_pad, int cols_pad,
+                                         const float* scale_dev, const int32_t* row_perm, int accumulate,
+                                         const float* gb_replicas, float* gb, int CD, const float* bias_dot, float* dot, void* s) {
+    if (!dwp || !gw || rows_pad < Co || cols_pad < Ci || !gb_replicas || !gb || CD < 1) return XMC_EINVAL;
+    if ((bias_dot == nullptr) != (dot == nullptr) || (bias_dot && row_perm)) return XMC_EINVAL;
+    int64_t total = (int64_t)Co * Ci * KH * KW;
+    hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(nblocks(total)), dim3(NT), 0, ST(s), dwp, gw, Co, Ci, KH * KW, rows_pad, cols_pad,
+                       scale_dev, row_perm, accumulate, gb_replicas, gb, CD, 1, bias_dot, dot);
+    XMC_LAUNCH_CHECK();
+    return 0;
+}
 extern "C" int xmc_unpack_wgrad_bias(const float* dwp, float* gw, int Co, int Ci, int KH, int KW, int rows_pad, int cols_pad,
                                      const float* scale_dev, const int32_t* row_perm, int accumulate,
                                      const float* gb_replicas, float* gb, int CD, void* s) {
-    if (!dwp || !gw || rows_pad < Co || cols_pad < Ci || !gb_replicas || !gb || CD < 1) return XMC_EINVAL;
-    int64_t total = (int64_t)Co * Ci * KH * KW;
-    hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(nblocks(total)), dim3(NT), 0, ST(s), dwp, gw, Co, Ci, KH * KW, rows_pad, cols_pad,
-                       scale_dev, row_perm, accumulate, gb_replicas, gb, CD, 1);
-    XMC_LAUNCH_CHECK();
-    return 0;
+    return xmc_unpack_wgrad_bias_dot(dwp, gw, Co, Ci, KH, KW, rows_pad, cols_pad, scale_dev, row_perm, accumulate, gb_replicas, gb, CD,
+                                     nullptr, nullptr, s);
 }
 
 extern "C" int xmc_pack_weight_upconv(const float* w, void* wpk, int Co, int Ci, int rows_pad, int cols_pad, int transpose,

@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("XMC_LIB_PATH", os.path.join(HERE, "libxmc_gan_hip.so"))   # override: kernel experiments
 LIB_PATH_F16 = os.environ.get("XMC_LIB_PATH_F16", os.path.join(HERE, "libxmc_gan_hip_f16.so"))
-ABI_VERSION = 2          # include/xmc_gan_hip.h XMC_ABI_VERSION; the ctypes structures below mirror that version
+ABI_VERSION = 3          # include/xmc_gan_hip.h XMC_ABI_VERSION; the ctypes structures below mirror that version
 
 # BF16 is the dtype code of "the 16-bit storage format of the loaded build": bf16 in libxmc_gan_hip.so, IEEE half in
 # libxmc_gan_hip_f16.so (the same sources compiled with -DXMC_H16_IS_F16; `use_variant`)
@@ -30,7 +30,8 @@ class ConvDesc(C.Structure):
                 ("dh", (C.c_int8 * MAX_TAPS) * MAX_CLASSES), ("dw", (C.c_int8 * MAX_TAPS) * MAX_CLASSES),
                 ("wi", (C.c_int8 * MAX_TAPS) * MAX_CLASSES),
                 ("dph", C.c_int8 * MAX_CLASSES), ("dpw", C.c_int8 * MAX_CLASSES),
-                ("mask", vp), ("res_scale", f32), ("res_mode", i32), ("dst2", vp), ("dst_pool", vp), ("round_act", i32), ("groups", i32)]
+                ("mask", vp), ("res_scale", f32), ("res_mode", i32), ("dst2", vp), ("dst_pool", vp), ("round_act", i32), ("groups", i32),
+                ("post_act", i32), ("pool_scale", f32)]
 
 
 # XmcGemmProblem as a numpy record (filled vectorised on the host, handed to xmc_gemm_group by pointer)
@@ -65,6 +66,7 @@ _SIGS = {
     "xmc_unpack_wgrad": [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp],
     "xmc_unpack_wgrad_grouped": [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, i32, vp],
     "xmc_unpack_wgrad_bias": [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, i32, vp],
+    "xmc_unpack_wgrad_bias_dot": [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, i32, vp, vp, vp],
     "xmc_nchw_to_nhwc8": [vp, vp, i32, i32, i32, i32, i32, vp],
     "xmc_nhwc8_to_nchw": [vp, vp, i32, i32, i32, i32, i32, vp],
     "xmc_lrelu": [vp, vp, i64, f32, i32, vp],
@@ -91,6 +93,8 @@ _SIGS = {
     "xmc_affine2_act_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp],
     "xmc_affine2_act_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp],
     "xmc_affine2_act_bwd_acc": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp],
+    "xmc_affine2_act_bwd_dot": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp],
+    "xmc_affine2_act_bwd_dot_pool": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp],
     "xmc_affine2_lrelu_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "xmc_affine2_lrelu_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "xmc_groupnorm_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, i32, vp],

@@ -381,7 +381,7 @@ def _upconv_dgrad_raw(dy, w, geom, in_dtype):
 
 
 def _conv_fwd_raw(x, w, bias, geom, act, out_dtype, res=None, alpha=None, up=False, res_mode=0, want2=False, want_pool=False,
-                  round_act=False, mask=None, out=None):
+                  round_act=False, mask=None, out=None, post_act=L.ACT_NONE):
     """y = act(conv(x, w) + bias) [*alpha] [+ res]; x [N,H,W,Cs]. ``up``: x is read through a fused nearest x2.
     ``res_mode`` 2: res is [N,OH/2,OW/2,C] and read through a nearest x2.  ``want2``: also return act(conv + bias) itself (the
     branch value before alpha / res);  ``want_pool``: also return avg_pool2d(y, 2).  Extras are appended: (y[, y2][, ypool])."""
@@ -410,6 +410,7 @@ def _conv_fwd_raw(x, w, bias, geom, act, out_dtype, res=None, alpha=None, up=Fal
     d.act, d.dtype, d.out_dtype = act, _code(x.dtype), _code(out_dtype)
     d.res_mode, d.round_act = res_mode, int(bool(round_act))
     d.groups = geom.groups
+    d.post_act = post_act           # applied last, to the sum with the residual (XmcConvDesc.post_act)
     _fill_taps(d, 0, [(kh - geom.p, kw - geom.p, kh * geom.k + kw) for kh in range(geom.k) for kw in range(geom.k)])
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.numel() >= cd_p, "bias must be f32 and padded to the stored channels"
@@ -435,10 +436,11 @@ def _conv_fwd_raw(x, w, bias, geom, act, out_dtype, res=None, alpha=None, up=Fal
     return y if len(outs) == 1 else tuple(outs)
 
 
-def _conv_dgrad_raw(dy, w, geom, in_hw, in_dtype, mask=None, res=None, res_rows=False, res_scale=1.0, alpha=None):
+def _conv_dgrad_raw(dy, w, geom, in_hw, in_dtype, mask=None, res=None, res_rows=False, res_scale=1.0, alpha=None, want_sumpool=False):
     """dx [N,H,W,cin_p] from dy [N,OH,OW,cout_p].  Epilogue options: ``mask`` (dx layout): dx *= LeakyReLU'(mask);
     ``res``: dx += res_scale * res, with ``res_rows`` the residual is [N,H/s,W/s,cin_p] and every pixel of it is added to its
-    s x s block of dx (s == 2: the adjoint of avg_pool2d, df_gan.py:290)."""
+    s x s block of dx (s == 2: the adjoint of avg_pool2d, df_gan.py:290).  ``want_sumpool`` (stride 1): returns (dx, 2x2 sum pool
+    of dx) -- the adjoint of a nearest x2 upsample, the gradient of a generator block's half-resolution shortcut."""
     _need_cuda(dy, w)
     N, OH, OW, CDy = dy.shape
     H, W = in_hw
@@ -480,10 +482,15 @@ def _conv_dgrad_raw(dy, w, geom, in_hw, in_dtype, mask=None, res=None, res_rows=
         assert tuple(res.shape) == want and res.dtype == dx.dtype and res.is_contiguous(), (res.shape, want)
         assert not res_rows or s == 2
         d.res, d.res_mode, d.res_scale = res.data_ptr(), 1 if res_rows else 0, float(res_scale)
+    dxp = None
+    if want_sumpool:
+        assert s == 1 and H % 2 == 0 and W % 2 == 0 and in_dtype == dy.dtype
+        dxp = torch.empty((N, H // 2, W // 2, cs_p), dtype=in_dtype, device=dy.device)
+        d.dst_pool, d.pool_scale = dxp.data_ptr(), 1.0
     with prof.launch("igemm_kernel (conv fwd+dgrad, MFMA implicit GEMM)", 2.0 * N * OH * OW * geom.cout * geom.cin * geom.k * geom.k,
-                     f"dgrad {dy.dtype} N{N} {H}x{W} {geom.cin}->{geom.cout} k{geom.k}s{geom.s}", _nbytes(dy, wpk, dx, mask, res)):
+                     f"dgrad {dy.dtype} N{N} {H}x{W} {geom.cin}->{geom.cout} k{geom.k}s{geom.s}", _nbytes(dy, wpk, dx, mask, res, dxp)):
         L.check(L.load().xmc_conv_igemm(C.byref(d), _st()), "xmc_conv_igemm(dgrad)")
-    return dx
+    return (dx, dxp) if want_sumpool else dx
 
 
 class _ZeroArena:
@@ -540,10 +547,25 @@ def _zeros_f32(shape, device):
 def new_iteration(device):
     """Call once at the start of a training iteration (before any backward): re-zeroes the weight-gradient scratch arena."""
     _arena.new_iteration(torch.device(device))
+    _pooled_grads.clear()
 
 
-def _conv_wgrad_raw(x, dy, geom, scale=None, up=False, want_bias=False):
-    """gw [Co,Ci,k,k] f32 from x [N,H,W,cs_p], dy [N,OH,OW,cd_p] (and the bias gradient [cd_p] f32 from the same launch)."""
+# By-products handed from one backward node to the next: {(data_ptr, shape, dtype) of a gradient tensor: its 2x2 sum pool}.  The
+# node that WRITES the gradient of a generator block's output (the next block's affine backward) can pool it in the same pass;
+# the node that CONSUMES it (GBlockEndFn.backward, which needs the pooled tensor as the gradient of the half-resolution shortcut)
+# pops the entry instead of launching a pooling pass.  Autograd hands a single-consumer gradient over as the same tensor, and the
+# producer's tensor is alive until then, so the key is unique while it is in the table; entries nobody popped die with the
+# iteration (new_iteration) -- and a missing entry only means the pooling pass runs.
+_pooled_grads = {}
+
+
+def _pool_key(t):
+    return (t.data_ptr(), tuple(t.shape), t.dtype)
+
+
+def _conv_wgrad_raw(x, dy, geom, scale=None, up=False, want_bias=False, bias_dot=None, dot=None):
+    """gw [Co,Ci,k,k] f32 from x [N,H,W,cs_p], dy [N,OH,OW,cd_p] (and the bias gradient [cd_p] f32 from the same launch).
+    ``bias_dot`` (f32 [>= cout]) / ``dot`` (f32 [1]): dot += <bias_dot, unscaled bias gradient> (xmc_unpack_wgrad_bias_dot)."""
     _need_cuda(x, dy)
     N, H, W, CS = x.shape
     _, OH, OW, CDy = dy.shape
@@ -567,9 +589,11 @@ def _conv_wgrad_raw(x, dy, geom, scale=None, up=False, want_bias=False):
     if want_bias:
         assert geom.groups == 1
         gbs = torch.empty(CDy, dtype=torch.float32, device=x.device)
-        L.call("xmc_unpack_wgrad_bias", _p(dwp), _p(gw), geom.cout, geom.cin, geom.k, geom.k, rows, CS, _p(scale),
-               _p(geom.perm_dev(x.device)), 0, _p(gb), _p(gbs), CDy, _st())
+        assert (bias_dot is None) == (dot is None)
+        L.call("xmc_unpack_wgrad_bias_dot", _p(dwp), _p(gw), geom.cout, geom.cin, geom.k, geom.k, rows, CS, _p(scale),
+               _p(geom.perm_dev(x.device)), 0, _p(gb), _p(gbs), CDy, _p(bias_dot), _p(dot), _st())
         return gw, gbs
+    assert bias_dot is None
     L.call("xmc_unpack_wgrad_grouped", _p(dwp), _p(gw), geom.cout, geom.cin, geom.k, geom.k, rows, CS, _p(scale),
            _p(geom.perm_dev(x.device)), 0, geom.groups, _st())
     return gw
@@ -849,6 +873,105 @@ class ConvAxpbyUpFn(torch.autograd.Function):
 
 def conv_axpby_up(h, w, b, geom, sc_lo, gamma):
     return ConvAxpbyUpFn.apply(h, w, b, geom, sc_lo, gamma)
+
+
+def _bias_padded(b, geom):
+    if b is None:
+        return None
+    bp = b.detach().float()
+    cd_p = pad_to(geom.cout, 8)
+    if bp.numel() < cd_p:
+        bp = torch.nn.functional.pad(bp, (0, cd_p - bp.numel()))
+    return bp.contiguous()
+
+
+class GBlockEndFn(torch.autograd.Function):
+    """The second half of a generator block as ONE first-order node (df_gan.py:199-202,219-224):
+        h1 -> affine2, LeakyReLU, affine3, LeakyReLU -> c2 -> up2(shortcut) + gamma * (.)
+    and, for the last block, the network's tail as well (df_gan.py:84-88): -> LeakyReLU -> conv_out -> tanh.
+    What the node buys over its parts (Affine2LreluFn, ConvAxpbyUpFn / AxpbyUpFn, ConvFn):
+      * c2's own output is never stored.  d(gamma) = <dout, c2(h2) + b2> = <c2^T dout, h2> + <b2, colsum(dout)>: the first term
+        is accumulated by the affine backward kernel, which recomputes h2 anyway and receives c2^T dout UNSCALED (it applies
+        gamma itself, so gamma = 0 -- the reference's initial value -- loses nothing); the second rides on the unpack of c2's
+        bias gradient.  One hi-res write in the forward and one hi-res read in the backward less per block.
+      * last block: the block sum is written once, already through the tail's LeakyReLU (XmcConvDesc.post_act), and its
+        LeakyReLU' mask is applied in the epilogue of conv_out's data gradient: the sum, gamma * dout and the masked gradient
+        are not separate passes over the largest tensor of the generator (256 x 256 x 32 per image)."""
+
+    @staticmethod
+    def forward(ctx, h1, g0, b0, g1, b1, w2, b2, geom2, sc_lo, gamma, w_out=None, b_out=None, geom_out=None, nhwc_dst=None):
+        h1, sc_lo = h1.contiguous(), sc_lo.contiguous()
+        ps = [t.contiguous().float() for t in (g0, b0, g1, b1)]
+        h2 = _affine_fwd_raw(h1, ps, 0.2)
+        al = gamma.detach().reshape(-1).float()
+        tail = w_out is not None
+        # round_act: c2's output is rounded to the storage format before it enters the sum, as when it was stored (same rounding
+        # points as the unfused sequence and as the quantisation-aware oracle)
+        y = _conv_fwd_raw(h2, w2, _bias_padded(b2, geom2), geom2, L.ACT_NONE, h2.dtype, res=sc_lo, alpha=al, res_mode=2,
+                          round_act=True, post_act=L.ACT_LRELU if tail else L.ACT_NONE)
+        img = None
+        if tail:
+            assert nhwc_dst is None or nhwc_dst._version == 0, "GBlockEndFn(nhwc_dst=): the destination must be a fresh tensor"
+            img = _conv_fwd_raw(y, w_out, _bias_padded(b_out, geom_out), geom_out, L.ACT_TANH, y.dtype, out=nhwc_dst)
+        ctx.geom2, ctx.geom_out, ctx.tail = geom2, geom_out, tail
+        ctx.has_b2, ctx.has_bo = b2 is not None, b_out is not None
+        ctx.save_for_backward(h1, *ps, h2, w2, b2, gamma, y if tail else None, w_out, img)
+        return img if tail else y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        h1, g0, b0, g1, b1, h2, w2, b2, gamma, y, w_out, img = ctx.saved_tensors
+        geom2, geom_out = ctx.geom2, ctx.geom_out
+        dt = h1.dtype
+        N, H, W, _ = h2.shape
+        dy = dy.contiguous()
+        if dy.dtype != dt:
+            dy = dy.to(dt)
+        skip_w = _skip_wgrad()
+        dw_out = db_out = None
+        if ctx.tail:
+            dpre = torch.empty_like(dy)
+            L.call("xmc_tanh_bwd", _p(dy), _p(img), _p(dpre), dy.numel(), _code(dt), _st())
+            if not skip_w:
+                r = _conv_wgrad_raw(y, dpre, geom_out, want_bias=ctx.has_bo)
+                dw_out, db_out = r if ctx.has_bo else (r, None)
+                dw_out = dw_out.view(w_out.shape)
+                if db_out is not None:
+                    db_out = db_out[: geom_out.cout]
+            # gradient of the block SUM: conv_out's data gradient times LeakyReLU'(y) (sign(y) = sign(sum)), in its epilogue
+            # ... and its 2x2 sums, the gradient of the half-resolution shortcut, as the epilogue's pooled output
+            dz, dsc = _conv_dgrad_raw(dpre, w_out, geom_out, (H, W), dt, mask=y, want_sumpool=True)
+        else:
+            dz = dy
+            dsc = _pooled_grads.pop(_pool_key(dz), None)          # written by the producer of dy in the pass that wrote dy
+            if dsc is None:
+                dsc = torch.empty((N, H // 2, W // 2, dz.shape[3]), dtype=dt, device=dz.device)
+                L.call("xmc_sumpool2", _p(dz), _p(dsc), N, H, W, dz.shape[3], 1.0, _code(dt), _st())
+        al = gamma.detach().reshape(-1).float()
+        dot = _zeros_f32(1, dz.device)
+        dw2 = db2 = None
+        if ctx.has_b2:
+            # (the bias term of d(gamma) rides on the unpack of the bias gradient, so that launch runs even when the weight gradients are
+            # skipped)
+            bdot = _bias_padded(b2, geom2)
+            dw2, db2 = _conv_wgrad_raw(h2, dz, geom2, scale=al, want_bias=True, bias_dot=bdot, dot=dot)
+            dw2, db2 = dw2.view(w2.shape), db2[: geom2.cout]
+        elif not skip_w:
+            dw2 = _conv_wgrad_raw(h2, dz, geom2, scale=al).view(w2.shape)
+        dh2u = _conv_dgrad_raw(dz, w2, geom2, (H, W), dt)                         # c2^T dz, NOT yet times gamma
+        dh1, red = _affine_bwd_raw(h1, dh2u, (g0, b0, g1, b1), 0.2, alpha=al, dot=dot)
+        dgamma = dot.reshape(gamma.shape).to(gamma.dtype)
+        if skip_w:
+            dw2 = db2 = None
+        return (dh1, red[0], red[1], red[2], red[3], dw2, db2, None, dsc, dgamma, dw_out, db_out, None, None)
+
+
+def g_block_end(h1, mod4, c2w, c2b, geom2, sc_lo, gamma, tail=None, nhwc_dst=None):
+    """``tail``: (conv_out weight, bias, geometry) for the last block -> the tanh image in the engine layout."""
+    if tail is None:
+        return GBlockEndFn.apply(h1, *mod4, c2w, c2b, geom2, sc_lo, gamma)
+    return GBlockEndFn.apply(h1, *mod4, c2w, c2b, geom2, sc_lo, gamma, tail[0], tail[1], tail[2], nhwc_dst)
 
 
 def conv2d(x, w, b, geom, act=L.ACT_NONE, out_dtype=None, want_pool=False, out=None):
@@ -1495,8 +1618,10 @@ def _affine_fwd_raw(x, ps, slope):
     return y
 
 
-def _affine_bwd_raw(x, dy, ps, slope, dx_acc=None):
-    """-> dx, red [len(ps), N, C] (the gradients of ps).  ``dx_acc``: another gradient of x, added on the way out."""
+def _affine_bwd_raw(x, dy, ps, slope, dx_acc=None, alpha=None, dot=None, want_sumpool=False):
+    """-> dx, red [len(ps), N, C] (the gradients of ps).  ``dx_acc``: another gradient of x, added on the way out.
+    ``alpha`` / ``dot`` (f32 [1] each): dy is the UNSCALED gradient from a consumer `sum + alpha * f(y)`: dot += <dy, y>, dy *= alpha
+    (xmc_affine2_act_bwd_dot).  ``want_sumpool``: -> dx, red, 2x2 sum pool of dx (same pass)."""
     N, H, W, Cc = x.shape
     dx = torch.empty_like(x)
     if dx_acc is not None:
@@ -1506,8 +1631,11 @@ def _affine_bwd_raw(x, dy, ps, slope, dx_acc=None):
     red = _zeros_f32((nred, N, Cc), x.device)
     ptrs = [_p(t) for t in ps] + ([] if nred == 4 else [None, None])
     rptrs = [_p(red[i]) for i in range(nred)] + ([] if nred == 4 else [None, None])
-    L.call("xmc_affine2_act_bwd_acc", _p(x), _p(dy), *ptrs, _p(dx), *rptrs, _p(dx_acc), N, H * W, Cc, float(slope), _code(x.dtype), _st())
-    return dx, red
+    assert (alpha is None) == (dot is None)
+    dxp = torch.empty((N, H // 2, W // 2, Cc), dtype=x.dtype, device=x.device) if want_sumpool else None
+    L.call("xmc_affine2_act_bwd_dot_pool", _p(x), _p(dy), *ptrs, _p(dx), *rptrs, _p(dx_acc), _p(alpha), _p(dot), _p(dxp), N, H, W, Cc,
+           float(slope), _code(x.dtype), _st())
+    return (dx, red, dxp) if want_sumpool else (dx, red)
 
 
 class Affine2LreluFn(torch.autograd.Function):
@@ -1561,11 +1689,13 @@ class Affine2LreluSkipFn(torch.autograd.Function):
     affine backward kernel instead of in a framework add pass over the block input."""
 
     @staticmethod
-    def forward(ctx, x, g0, b0, g1, b1):
+    def forward(ctx, x, g0, b0, g1, b1, pool_grad=False):
+        """``pool_grad``: x came out of a GBlockEndFn -- the backward pools its dx for that node (ops._pooled_grads)"""
         x = x.contiguous()
         ps = [t.contiguous().float() for t in (g0, b0, g1, b1)]
         y = _affine_fwd_raw(x, ps, 0.2)
         ctx.set_materialize_grads(False)
+        ctx.pool = bool(pool_grad)
         ctx.save_for_backward(x, *ps)
         return y, x.view_as(x)
 
@@ -1574,13 +1704,18 @@ class Affine2LreluSkipFn(torch.autograd.Function):
     def backward(ctx, dy, dskip):
         x, *ps = ctx.saved_tensors
         if dy is None:
-            return dskip, None, None, None, None
-        dx, red = _affine_bwd_raw(x, dy.contiguous(), ps, 0.2, dx_acc=dskip)
-        return dx, red[0], red[1], red[2], red[3]
+            return dskip, None, None, None, None, None
+        if ctx.pool and x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0:
+            # x is the output of the previous generator block, whose backward needs the 2x2 sum pool of this gradient
+            dx, red, dxp = _affine_bwd_raw(x, dy.contiguous(), ps, 0.2, dx_acc=dskip, want_sumpool=True)
+            _pooled_grads[_pool_key(dx)] = dxp
+        else:
+            dx, red = _affine_bwd_raw(x, dy.contiguous(), ps, 0.2, dx_acc=dskip)
+        return dx, red[0], red[1], red[2], red[3], None
 
 
-def affine2_lrelu_skip(x, g0, b0, g1, b1):
-    return Affine2LreluSkipFn.apply(x, g0, b0, g1, b1)
+def affine2_lrelu_skip(x, g0, b0, g1, b1, pool_grad=False):
+    return Affine2LreluSkipFn.apply(x, g0, b0, g1, b1, pool_grad)
 
 
 class GroupNormFn(torch.autograd.Function):

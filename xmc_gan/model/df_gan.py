@@ -104,9 +104,19 @@ class NetG(nn.Module):
         # through operators that commute with / absorb the upsample, so the 4x larger tensor is never written.
         pending_up = False
         lrelu_done = False
+        from_end = False            # `out` was written by an ops.GBlockEndFn (whose backward wants the 2x2 sum pool of its gradient)
         for bi, (gblock, m) in enumerate(zip(self.upblocks, mods)):
             last = bi == nblk - 1 and not gblock.upsample      # its output goes straight into the tail's LeakyReLU
-            out = gblock.forward_fused(out, m, pending_up, out_lrelu=last)
+            fuse = gblock.fuses_end(out, pending_up)
+            if last and fuse:
+                # the block's second half and the tail (LeakyReLU -> conv_out -> tanh) as one node: ops.GBlockEndFn
+                co = self.conv_out[1]
+                out8 = gblock.forward_fused(out, m, pending_up, out_lrelu=True, tail=(co.weight, co.bias, co.geom), nhwc_dst=nhwc_dst,
+                                            x_from_end=from_end)
+                img = ops.to_nchw(out8, 3)
+                return (img, out8) if return_nhwc else img
+            out = gblock.forward_fused(out, m, pending_up, out_lrelu=last, x_from_end=from_end)
+            from_end = fuse and not last
             lrelu_done = last
             pending_up = gblock.upsample
         if pending_up:
@@ -227,7 +237,11 @@ class G_Block(nn.Module):
             out = ops.upsample2(out)
         return out
 
-    def forward_fused(self, x, mod, x_pending_up, out_lrelu=False):
+    def fuses_end(self, x, x_pending_up):
+        """whether forward_fused runs the block's second half (and, for the last block, the network's tail) as ops.GBlockEndFn"""
+        return bool(x_pending_up) and ops.fused_blocks() and x.is_cuda
+
+    def forward_fused(self, x, mod, x_pending_up, out_lrelu=False, tail=None, nhwc_dst=None, x_from_end=False):
         """Same function as ``forward`` on the logical input ``up2(x)`` when ``x_pending_up`` (else ``x``), returning the
         block output WITHOUT its trailing upsample.  With a pending upsample: the conditional affines and the 1x1 shortcut
         commute with nearest upsampling and run at low resolution, ``c1`` runs as the fused upsample+3x3 operator
@@ -237,8 +251,14 @@ class G_Block(nn.Module):
             return ops.lrelu(out) if out_lrelu else out
         # x feeds the residual branch AND the shortcut: the affine node hands x through as a second output, so that the two
         # gradients of x are summed inside its backward kernel
-        h, xs = ops.affine2_lrelu_skip(x, *mod[0:4]) if x.is_cuda else (ops.affine2_lrelu(x, *mod[0:4]), x)
+        h, xs = ops.affine2_lrelu_skip(x, *mod[0:4], pool_grad=x_from_end) if x.is_cuda else (ops.affine2_lrelu(x, *mod[0:4]), x)
         h = ops.upconv3x3(h, self.c1.weight, self.c1.bias, self.c1.geom)
+        if self.fuses_end(x, x_pending_up) and (tail is not None or not out_lrelu):
+            # affine2/3 + LeakyReLUs, c2, the block sum with the upsampled shortcut [, the tail] in one node whose backward
+            # needs neither c2's output nor a separate pass for gamma * dout (ops.GBlockEndFn)
+            return ops.g_block_end(h, mod[4:8], self.c2.weight, self.c2.bias, self.c2.geom, self.shortcut(xs), self.gamma,
+                                   tail=tail, nhwc_dst=nhwc_dst)
+        assert tail is None
         h = ops.affine2_lrelu(h, *mod[4:8])
         if not out_lrelu and ops.fused_blocks() and h.shape[1] % 2 == 0:
             # c2, the block sum and the upsample of the shortcut in one pass (third epilogue form, res_mode 2)
