@@ -359,11 +359,16 @@ __global__ void affine2_fwd_kernel(const void* x, const float* g0, const float* 
         Vec8<DT>::store(y, idx, v);
     }
 }
-// POOL: the loop runs over 2x2 pixel quads instead of pixels (HW = number of quads, Wq = quads per row) and the sum of the four
-// ROUNDED dx of a quad goes to dx_pool [N, HW, C]: the 2x2 sum pool of dx, i.e. the gradient of the producing generator block's
-// half-resolution shortcut (df_gan.py:200-202), without another pass over dx.
+// POOL: the loop runs over vertical pixel PAIRS (HW = (H/2) * W pairs, pair p = (row pair p / W, column p % W)): consecutive
+// lanes still walk consecutive pixels of a row (as without POOL), both pixels of a pair are loaded before either is used, and the
+// 2x2 sum of the ROUNDED dx -- own pair + the pair of the neighbouring column, one lane exchange -- goes to dx_pool
+// [N, H/2, W/2, C]: the 2x2 sum pool of dx, i.e. the gradient of the producing generator block's half-resolution shortcut
+// (df_gan.py:200-202), without another pass over dx.  (A first version gave each thread a whole 2x2 quad, one pixel after the
+// other: four dependent round trips per step and half-line accesses -- 3.9 ms per iteration for what the pooling pass did in 0.5.)
+// Needs C8 a power of two <= 32 (the column neighbour is lane ^ C8), even W, H.
 template <int DT, bool POOL>
-__global__ void affine2_bwd_kernel(const void* x, const void* dy, const float* g0, const float* b0, const float* g1,
+__global__ __launch_bounds__(NT, POOL ? 2 : 4) void affine2_bwd_kernel(        // POOL: two pixels' operands live at once, 128 registers spill
+                                   const void* x, const void* dy, const float* g0, const float* b0, const float* g1,
                                    const float* b1, void* dx, float* dg0, float* db0, float* dg1, float* db1,
                                    int HW, int C8, int pix_per_block, float slope, const void* dx_in,
                                    const float* alpha_dev, float* dot, void* dx_pool, int Wq) {
@@ -384,12 +389,8 @@ __global__ void affine2_bwd_kernel(const void* x, const void* dy, const float* g
         G0[k] = g0[pb + k]; B0[k] = b0[pb + k]; G1[k] = two ? g1[pb + k] : 1.f; B1[k] = two ? b1[pb + k] : 0.f;
         sg0[k] = sb0[k] = sg1[k] = sb1[k] = 0.f;
     }
-    // one pixel: its dx is stored and (POOL) added, rounded as stored, to acc8
-    auto pixel = [&](size_t pix, float* acc8) {
-        float xv[8], dv[8];
-        const size_t idx = pix * C8 + cc;
-        Vec8<DT>::load(x, idx, xv);
-        Vec8<DT>::load(dy, idx, dv);
+    // one pixel from its loaded operands: dx is stored and (POOL) added, rounded as stored, to acc8
+    auto pixel = [&](size_t idx, float (&xv)[8], const float (&dv)[8], const float (&o)[8], float* acc8) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             float u = xv[k] * G0[k] + B0[k];
@@ -407,8 +408,6 @@ __global__ void affine2_bwd_kernel(const void* x, const void* dy, const float* g
             xv[k] = du * G0[k];
         }
         if (dx_in) {                  // another gradient of x (the block's shortcut branch) joins here instead of in an add pass
-            float o[8];
-            Vec8<DT>::load(dx_in, idx, o);
 #pragma unroll
             for (int k = 0; k < 8; ++k) xv[k] += o[k];
         }
@@ -422,13 +421,26 @@ __global__ void affine2_bwd_kernel(const void* x, const void* dy, const float* g
     if (g < groups)
         for (int p = blockIdx.x * pix_per_block + g; p < p_end; p += groups) {
             if (!POOL) {
-                pixel((size_t)n * HW + p, nullptr);
+                float xv[8], dv[8], o[8];
+                const size_t idx = ((size_t)n * HW + p) * C8 + cc;
+                Vec8<DT>::load(x, idx, xv);
+                Vec8<DT>::load(dy, idx, dv);
+                if (dx_in) Vec8<DT>::load(dx_in, idx, o);
+                pixel(idx, xv, dv, o, nullptr);
             } else {
-                const int qy = p / Wq, qx = p - qy * Wq;
-                const size_t p00 = (size_t)n * HW * 4 + (size_t)(2 * qy) * (2 * Wq) + 2 * qx;
+                const int W = 2 * Wq;
+                const int qy = p / W, col = p - qy * W;
+                const size_t i0 = (((size_t)n * (HW / W) * 2 + 2 * qy) * W + col) * C8 + cc, i1 = i0 + (size_t)W * C8;
+                float x0[8], d0[8], o0[8], x1[8], d1[8], o1[8];
+                Vec8<DT>::load(x, i0, x0); Vec8<DT>::load(x, i1, x1);
+                Vec8<DT>::load(dy, i0, d0); Vec8<DT>::load(dy, i1, d1);
+                if (dx_in) { Vec8<DT>::load(dx_in, i0, o0); Vec8<DT>::load(dx_in, i1, o1); }
                 float acc8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                pixel(p00, acc8); pixel(p00 + 1, acc8); pixel(p00 + 2 * Wq, acc8); pixel(p00 + 2 * Wq + 1, acc8);
-                Vec8<DT>::store(dx_pool, ((size_t)n * HW + p) * C8 + cc, acc8);
+                pixel(i0, x0, d0, o0, acc8);
+                pixel(i1, x1, d1, o1, acc8);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc8[k] += __shfl_xor(acc8[k], C8, 64);       // the pair of column col ^ 1: lane ^ C8
+                if ((col & 1) == 0) Vec8<DT>::store(dx_pool, (((size_t)n * (HW / W) + qy) * Wq + (col >> 1)) * C8 + cc, acc8);
             }
         }
     if (dot) {
@@ -963,10 +975,15 @@ extern "C" int xmc_affine2_act_bwd_dot_pool(const void* x, const void* dy, const
                                             int C, float slope, int dtype, void* s) {
     if (C % 8 || C / 8 > NT) return XMC_EALIGN;
     if ((alpha_dev == nullptr) != (dot == nullptr)) return XMC_EINVAL;
-    if (dx_pool && ((H & 1) || (W & 1))) return XMC_ESHAPE;
-    const int HW = dx_pool ? (H / 2) * (W / 2) : H * W;          // loop units: quads or pixels
+    const int C8 = C / 8;
+    if (dx_pool && ((H & 1) || (W & 1) || (C8 & (C8 - 1)) || C8 > 32)) return XMC_ESHAPE;
+    const int HW = dx_pool ? (H / 2) * W : H * W;               // loop units: vertical pixel pairs or pixels
     dim3 g; int ppb;
-    affine_grid(HW, C / 8, N, g, ppb, dx_pool ? 16 : 64);
+    affine_grid(HW, C / 8, N, g, ppb, dx_pool ? 32 : 64);
+    if (dx_pool && (ppb & 1)) {                                  // column neighbours (p, p ^ 1) must meet in one workgroup step
+        ppb += 1;
+        g.x = (HW + ppb - 1) / ppb;
+    }
 #define XMC_AFF_BWD(DTC, PL) hipLaunchKernelGGL((affine2_bwd_kernel<DTC, PL>), g, dim3(NT), 0, ST(s), x, dy, g0, b0, g1, b1, dx, dg0, db0, dg1, db1, \
                                                 HW, C / 8, ppb, slope, dx_in, alpha_dev, dot, dx_pool, W / 2)
     if (dtype == XMC_BF16) { if (dx_pool) XMC_AFF_BWD(XMC_BF16, true); else XMC_AFF_BWD(XMC_BF16, false); }

@@ -1705,7 +1705,7 @@ class Affine2LreluSkipFn(torch.autograd.Function):
         x, *ps = ctx.saved_tensors
         if dy is None:
             return dskip, None, None, None, None, None
-        if ctx.pool and x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0:
+        if ctx.pool and x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0 and x.shape[3] // 8 in (1, 2, 4, 8, 16, 32):
             # x is the output of the previous generator block, whose backward needs the 2x2 sum pool of this gradient
             dx, red, dxp = _affine_bwd_raw(x, dy.contiguous(), ps, 0.2, dx_acc=dskip, want_sumpool=True)
             _pooled_grads[_pool_key(dx)] = dxp
