@@ -572,6 +572,11 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
             const int img = tile / tpi, trem = tile - img * tpi;
             const int a0 = (trem / t.tiles_x) * t.TH, b0 = (trem % t.tiles_x) * t.TW;
             __syncthreads();                      // B1: patch of this tile is in LDS
+            constexpr bool HOIST = UPL == 1;
+            // epilogue operands requested ahead of the MFMAs (below).  They live across the class loop: a ROW-indexed residual
+            // (res_mode 1: the shortcut gradient of a discriminator block, one vector per 2x2 block of dst) is the same for all MC
+            // classes of a tile and is requested once, with the first class -- not once per class in front of a 16-MFMA K loop
+            bf16x8 mkv[HOIST ? TM : 1], rrv[HOIST ? TM : 1];
 #pragma unroll
           for (int mc = 0; mc < MC; ++mc) {
             const int ccls = MC > 1 ? mc : cls;
@@ -589,8 +594,7 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
             const int rbase = ((img * d.MH + a0) * d.MW + b0) * cd8 + (n0 >> 3);
             // (one 32-channel unit per lane only: with two, the 64 extra live registers spill; the 64-channel layers with such an
             // epilogue run in the 32x32x16 role anyway)
-            constexpr bool HOIST = UPL == 1;
-            bf16x8 mkv[HOIST ? TM : 1], rrv[HOIST ? TM : 1];
+            const bool res_once = MC > 1 && d.res_mode == 1;
             if (HOIST && pre && (d.mask || d.res)) {
 #pragma unroll
                 for (int u = 0; u < UPL; ++u) {
@@ -605,7 +609,7 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
                             rix = res_index8(d, idx8, img, y_, x_, 0, 0, (n0 >> 3) + fc + u * 4);
                         }
                         if (d.mask) mkv[HOIST ? i : 0] = reinterpret_cast<const bf16x8*>(d.mask)[idx8];
-                        if (d.res) rrv[HOIST ? i : 0] = reinterpret_cast<const bf16x8*>(d.res)[rix];
+                        if (d.res && (mc == 0 || !res_once)) rrv[HOIST ? i : 0] = reinterpret_cast<const bf16x8*>(d.res)[rix];
                     }
                 }
             }
