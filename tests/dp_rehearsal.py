@@ -53,6 +53,9 @@ def worst_rel(a, b):
 
 
 def main():
+    if os.environ.get("XMC_DUMP_AFTER"):        # where is a rank stuck?  (seconds; dumps every thread's stack and exits)
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["XMC_DUMP_AFTER"]), exit=True)
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default="")
     ap.add_argument("--nch", type=int, default=8)

@@ -21,15 +21,16 @@ def force_collectives(on=True):
     _FORCE[0] = bool(on)
 
 
-def active():
-    """does the iteration issue collectives?"""
-    if not (dist.is_available() and dist.is_initialized()):
-        return False
-    return dist.get_world_size() > 1 or _FORCE[0]
-
-
 def world():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def active():
+    """does the iteration issue collectives?  (through world(), so that a caller which narrows the step to one rank by
+    replacing world / rank -- tests/dp_rehearsal.py's single-process references inside a 2-rank job -- also switches them off)"""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return world() > 1 or _FORCE[0]
 
 
 def rank():
