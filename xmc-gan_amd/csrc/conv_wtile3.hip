@@ -553,8 +553,9 @@ int xmc_conv_wtile3_try(const XmcConvDesc* d, void* stream) {
     if (!plan3(d, &t, &mode, &wm)) return 1;
     // BN = 128 (64 x 64 wave tiles: the same fragment-read load as the role-split kernel, without its dedicated staging waves) measures
     // 3-6 % behind conv_wtile.hip on the 128-channel layers: kept for A/B runs only
-    static const bool bn128 = xmc_debug_off("wtile3_bn128");
-    if (wm == 4 && !bn128) return 1;
+    static const bool bn128 = xmc_debug_off("wtile3_bn128"), bn128_epi = xmc_debug_off("wtile3_bn128_epi"), bn128_plain = xmc_debug_off("wtile3_bn128_plain");
+    const bool heavy = d->res || d->dst2 || d->dst_pool || d->mask;
+    if (wm == 4 && !(bn128 || (bn128_epi && heavy) || (bn128_plain && !heavy))) return 1;
     // 256-channel tiles halve the number of workgroups: below one tile per CU the role-split kernel (128-channel tiles, twice the
     // workgroups) wins -- 128x128 / batch 64: 10.8 vs 10.4 ms per iteration
     if (wm == 2 && (long long)d->N * t.tiles_y * t.tiles_x * (d->CDw / 256) * d->nclass < 256) return 1;
