@@ -153,6 +153,23 @@ __device__ __forceinline__ void epilogue_tail(const XmcConvDesc& d, size_t idx8,
     Vec8<ODT>::store(d.dst, idx8, v);
 }
 
+// Epilogue option sets as compile-time bit masks (kernels with a template parameter EPI; -1 = read the descriptor at run time).
+// A convolution epilogue is several hundred VALU instructions per wave and tile; with every option a run-time branch per 8-channel
+// unit the weights-resident kernel measured 0.535 ms where the same launch with its options folded takes 0.450 (conv_tile.hip), so
+// the option sets that occur in the training step get an instantiation each and everything else goes through the generic one.
+constexpr int kEpiBias = 1, kEpiLrelu = 2, kEpiRound = 4, kEpiDst2 = 8, kEpiAlpha = 16, kEpiMask = 32, kEpiRes = 64, kEpiPost = 128, kEpiPool = 256;
+constexpr int kEpiGSum = kEpiBias | kEpiRound | kEpiAlpha | kEpiRes;                      // generator c2 + block sum (ops.GBlockEndFn)
+constexpr int kEpiDKeep = kEpiLrelu | kEpiDst2 | kEpiAlpha | kEpiRes | kEpiPool;          // discriminator conv_r[2] + block end, kept for a backward
+constexpr int kEpiDFwd = kEpiLrelu | kEpiRound | kEpiAlpha | kEpiRes | kEpiPool;          // ... forward only
+constexpr int kEpiDLast = kEpiLrelu | kEpiDst2 | kEpiAlpha | kEpiRes;                     // ... last block of a pass (no pooled output)
+// the mask of a descriptor, or -1 if it uses an option the masks do not describe (tanh / relu, f32 destination)
+static inline int xmc_epi_mask(const XmcConvDesc& d) {
+    if ((d.act != XMC_ACT_NONE && d.act != XMC_ACT_LRELU) || d.out_dtype != XMC_BF16) return -1;
+    return (d.bias ? kEpiBias : 0) | (d.act == XMC_ACT_LRELU ? kEpiLrelu : 0) | ((d.round_act && !d.dst2) ? kEpiRound : 0) | (d.dst2 ? kEpiDst2 : 0) |
+           (d.alpha_dev ? kEpiAlpha : 0) | (d.mask ? kEpiMask : 0) | (d.res ? kEpiRes : 0) | (d.post_act == XMC_ACT_LRELU ? kEpiPost : 0) |
+           (d.dst_pool ? kEpiPool : 0);
+}
+
 // residual index (in 8-channel units) of destination pixel (n, y, x) for the three residual layouts; (a, b) is the pixel's
 // position in the [MH, MW] GEMM grid
 __device__ __forceinline__ size_t res_index8(const XmcConvDesc& d, size_t idx8, int n, int y, int x, int a, int b, int ch8) {

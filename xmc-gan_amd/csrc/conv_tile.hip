@@ -232,7 +232,11 @@ __global__ __launch_bounds__(256) void tile_kernel(const XmcConvDesc d, const Ti
 // runs ONE matrix wave per SIMD, and a single wave issues the 16x16x32 form at only ~63 % of the pipe's rate (tests/diag/
 // mfma_probe.hip: 1277 TF/s against 1948 for 32x32x16); same fragment bytes, half the MFMA instructions.  bf16 output, SA == 1,
 // unrolled tap loop only.
-template <int BN, int SLAB, int NTAPS, int MC, int SA = 1, bool M32 = false>
+// EPI (32x32x16 role): the epilogue's option set as a compile-time bit mask (kEpi*), or -1 = read the descriptor at run time.  The
+// epilogue of this role is ~500 VALU instructions per wave and tile -- more issue time than the tile's 144 MFMAs -- and with every
+// option a run-time branch per 8-channel unit it measured 0.535 ms where the same launch with its options folded takes 0.450
+// (64 -> 64 @128^2, batch 256, block sum): the option sets that occur in the training step get an instantiation each.
+template <int BN, int SLAB, int NTAPS, int MC, int SA = 1, bool M32 = false, int EPI = -1>
 __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const TileCfg t, int ntiles) {
     static_assert(!M32 || (SA == 1 && NTAPS > 0), "32x32x16 form: unit stride, unrolled taps");
     constexpr int NS = 256;                      // threads per role
@@ -369,7 +373,17 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
         const int bbyte = l32 * pstride + hh * 16;
         const float alpha = d.alpha_dev ? *d.alpha_dev : 1.f;
         const float pscale = d.pool_scale == 0.f ? 0.25f : d.pool_scale;
-        const float slope = d.act == XMC_ACT_LRELU ? XMC_LRELU : (d.act == XMC_ACT_RELU ? 0.f : 1.f);
+        constexpr bool RT = EPI < 0;                       // options read from the descriptor
+        const bool e_bias = RT ? d.bias != nullptr : (EPI & kEpiBias) != 0;
+        const bool e_tanh = RT ? d.act == XMC_ACT_TANH : false;
+        const bool e_round = RT ? (d.dst2 != nullptr || d.round_act != 0) : (EPI & (kEpiRound | kEpiDst2)) != 0;
+        const bool e_dst2 = RT ? d.dst2 != nullptr : (EPI & kEpiDst2) != 0;
+        const bool e_alpha = RT ? d.alpha_dev != nullptr : (EPI & kEpiAlpha) != 0;
+        const bool e_mask = RT ? d.mask != nullptr : (EPI & kEpiMask) != 0;
+        const bool e_res = RT ? d.res != nullptr : (EPI & kEpiRes) != 0;
+        const bool e_post = RT ? d.post_act == XMC_ACT_LRELU : (EPI & kEpiPost) != 0;
+        const bool e_pool = RT ? d.dst_pool != nullptr : (EPI & kEpiPool) != 0;
+        const float slope = RT ? (d.act == XMC_ACT_LRELU ? XMC_LRELU : (d.act == XMC_ACT_RELU ? 0.f : 1.f)) : ((EPI & kEpiLrelu) ? XMC_LRELU : 1.f);
         const float rs = d.res_scale == 0.f ? 1.f : d.res_scale;
         __syncthreads();                          // weights + first patch staged
         int toffr[MC * NTAPS];
@@ -407,8 +421,8 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
 #pragma unroll
                         for (int v2 = 0; v2 < 2; ++v2) {
                             const size_t idx8 = (size_t)(eo[pb] + ub + v2);
-                            if (d.mask) mkv[c][pb][v2] = reinterpret_cast<const bf16x8*>(d.mask)[idx8];
-                            if (d.res) {
+                            if (e_mask) mkv[c][pb][v2] = reinterpret_cast<const bf16x8*>(d.mask)[idx8];
+                            if (e_res) {
                                 size_t rix = idx8;
                                 if (d.res_mode == 1) rix = (size_t)(rbase + (pty[pb] * d.MW + ptx[pb]) * cd8 + ub + v2);
                                 else if (d.res_mode == 2)
@@ -458,38 +472,38 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
                             float v[8];
 #pragma unroll
                             for (int r = 0; r < 8; ++r) v[r] = acc[pb][c][8 * v2 + r];
-                            if (d.bias) {
+                            if (e_bias) {
                                 const float* bp = d.bias + n0 + (ub + v2) * 8;
                                 const f32x4 b0v = *reinterpret_cast<const f32x4*>(bp), b1v = *reinterpret_cast<const f32x4*>(bp + 4);
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) { v[r] += b0v[r]; v[4 + r] += b1v[r]; }
                             }
-                            if (d.act == XMC_ACT_TANH) {
+                            if (e_tanh) {
 #pragma unroll
                                 for (int r = 0; r < 8; ++r) v[r] = d.res || d.mask || d.dst2 ? tanhf(v[r]) : tanh_fast(v[r]);
                             } else if (slope != 1.f) {
 #pragma unroll
                                 for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], v[r] * slope);
                             }
-                            if (d.dst2 || d.round_act) {
+                            if (e_round) {
                                 bf16x8 o2;
 #pragma unroll
                                 for (int r = 0; r < 8; ++r) { o2[r] = (xmc_h16)v[r]; v[r] = (float)o2[r]; }
-                                if (d.dst2) reinterpret_cast<bf16x8*>(d.dst2)[idx8] = o2;
+                                if (e_dst2) reinterpret_cast<bf16x8*>(d.dst2)[idx8] = o2;
                             }
-                            if (d.alpha_dev) {
+                            if (e_alpha) {
 #pragma unroll
                                 for (int r = 0; r < 8; ++r) v[r] *= alpha;
                             }
-                            if (d.mask) {
+                            if (e_mask) {
 #pragma unroll
                                 for (int r = 0; r < 8; ++r) v[r] *= lrelu_slope((float)mkv[c][pb][v2][r]);
                             }
-                            if (d.res) {
+                            if (e_res) {
 #pragma unroll
                                 for (int r = 0; r < 8; ++r) v[r] += rs * (float)rrv[c][pb][v2][r];
                             }
-                            if (d.post_act == XMC_ACT_LRELU) {
+                            if (e_post) {
 #pragma unroll
                                 for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], v[r] * XMC_LRELU);
                             }
@@ -498,7 +512,7 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
                             for (int r = 0; r < 8; ++r) { o[r] = (xmc_h16)v[r]; fin[pb][v2][r] = (float)o[r]; }
                             dst8[idx8] = o;
                         }
-                    if (MC == 1 && d.dst_pool) {
+                    if (MC == 1 && e_pool) {
                         // third output: 2x2 average of the rounded block output.  8x32 tiles: the wave's two 32-pixel blocks are tile rows
                         // 2wm and 2wm+1 (vertical pair = the two blocks of a lane); 16x16 tiles: a block is two rows of 16 (vertical pair
                         // = lane ^ 16).  Horizontal neighbour: lane ^ 1.
@@ -854,6 +868,22 @@ int launch_ptile(const XmcConvDesc& d, const TileCfg& t, hipStream_t st) {
     static const bool m32_all = xmc_debug_off("ptile_m32_all");
     if (!no_m32 && d.ntaps == 9 && d.out_dtype == XMC_BF16 && t.slab == 64 &&
         (m32_all || d.res || d.dst2 || d.dst_pool || d.mask)) {      // one matrix wave per SIMD: 32x32x16 form
+        // the epilogue option sets of the training step as compile-time instantiations (kEpi*), anything else through the
+        // descriptor-reading one
+        int epi = xmc_epi_mask(d);
+        static const bool no_epi = xmc_debug_off("no_ptile_epi");
+        if (no_epi) epi = -1;
+#define XMC_PT3_EPI(E)                                                                                                   \
+        if (epi == (E)) {                                                                                                \
+            XMC_ALLOW_BIG_LDS((ptile3_kernel<BN, 64, 9, 1, 1, true, (E)>));                                              \
+            hipLaunchKernelGGL((ptile3_kernel<BN, 64, 9, 1, 1, true, (E)>), grid, dim3(512), lds, st, d, t, ntiles);     \
+            xmc_note_kernel("ptile3_kernel<%d, 64, 9, 1, 1, true>", BN);                                                 \
+            XMC_LAUNCH_CHECK();                                                                                          \
+            return 0;                                                                                                    \
+        }
+        XMC_PT3_EPI(kEpiGSum) XMC_PT3_EPI(kEpiDKeep) XMC_PT3_EPI(kEpiDFwd) XMC_PT3_EPI(kEpiDLast)
+        XMC_PT3_EPI(kEpiMask)                                                                // data gradient through a LeakyReLU
+#undef XMC_PT3_EPI
         XMC_ALLOW_BIG_LDS((ptile3_kernel<BN, 64, 9, 1, 1, true>));
         hipLaunchKernelGGL((ptile3_kernel<BN, 64, 9, 1, 1, true>), grid, dim3(512), lds, st, d, t, ntiles);
         xmc_note_kernel("ptile3_kernel<%d, 64, 9, 1, 1, true>", BN);

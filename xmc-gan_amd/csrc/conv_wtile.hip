@@ -57,7 +57,7 @@ constexpr int kPIT = 12;            // patch pixels per staging thread (32 pixel
 
 // CW = number of compute waves: 4 (one per SIMD, 64 pixels x BN channels each) or 8 (two per SIMD, 64 pixels x BN/2 channels each:
 // the two waves of a SIMD interleave their MFMAs, so one's LDS latency and barrier skew are covered by the other's matrix work)
-template <int NTAPS, int MODE, int TN, int CW>
+template <int NTAPS, int MODE, int TN, int CW, int EPI = -1>
 __global__ __launch_bounds__(64 * CW + 256) void wtile2_kernel(const XmcConvDesc d, const WtCfg t, int ntiles) {
     constexpr int BN = 16 * TN, TM = 4, NS = 64 * CW;
     constexpr int TNW = TN * 4 / CW;             // 16-channel blocks per compute wave
@@ -291,7 +291,17 @@ __global__ __launch_bounds__(64 * CW + 256) void wtile2_kernel(const XmcConvDesc
             const int dbase = (((img * d.DH + a0 * d.DA + d.dph[cls]) * d.DW) + b0 * d.DA + d.dpw[cls]) * cd8 + nw8;
             const int rbase = d.res_mode ? ((img * d.MH + a0) * d.MW + b0) * cd8 + nw8 : dbase;
             const int rsy = d.res_mode ? d.MW : d.DA * d.DW, rsx = d.res_mode ? 1 : d.DA;
-            const float slope = d.act == XMC_ACT_LRELU ? XMC_LRELU : (d.act == XMC_ACT_RELU ? 0.f : 1.f);
+            constexpr bool RT = EPI < 0;               // epilogue options read from the descriptor (common.h: kEpi*)
+            const bool e_bias = RT ? d.bias != nullptr : (EPI & kEpiBias) != 0;
+            const bool e_tanh = RT ? d.act == XMC_ACT_TANH : false;
+            const bool e_round = RT ? (d.dst2 != nullptr || d.round_act != 0) : (EPI & (kEpiRound | kEpiDst2)) != 0;
+            const bool e_dst2 = RT ? d.dst2 != nullptr : (EPI & kEpiDst2) != 0;
+            const bool e_alpha = RT ? d.alpha_dev != nullptr : (EPI & kEpiAlpha) != 0;
+            const bool e_mask = RT ? d.mask != nullptr : (EPI & kEpiMask) != 0;
+            const bool e_res = RT ? d.res != nullptr : (EPI & kEpiRes) != 0;
+            const bool e_post = RT ? d.post_act == XMC_ACT_LRELU : (EPI & kEpiPost) != 0;
+            const bool e_pool = RT ? d.dst_pool != nullptr : (EPI & kEpiPool) != 0;
+            const float slope = RT ? (d.act == XMC_ACT_LRELU ? XMC_LRELU : (d.act == XMC_ACT_RELU ? 0.f : 1.f)) : ((EPI & kEpiLrelu) ? XMC_LRELU : 1.f);
             const float alpha = d.alpha_dev ? *d.alpha_dev : 1.f;
             const float rs = d.res_scale == 0.f ? 1.f : d.res_scale;
             bf16x8* __restrict__ dst8 = reinterpret_cast<bf16x8*>(d.dst);
@@ -317,11 +327,11 @@ __global__ __launch_bounds__(64 * CW + 256) void wtile2_kernel(const XmcConvDesc
                 // every mask / residual vector of this channel unit is requested before the first one is used: one memory latency
                 // per unit instead of one per vector (they were 2 x 16 dependent round trips per tile, longer than its MFMAs)
                 bf16x8 mkv[TM], rrv[TM];
-                if (mask8) {
+                if (e_mask) {
 #pragma unroll
                     for (int i = 0; i < TM; ++i) mkv[i] = mask8[eo[i] + u * 4];
                 }
-                if (res8) {
+                if (e_res) {
 #pragma unroll
                     for (int i = 0; i < TM; ++i) rrv[i] = res8[ro[i] + u * 4];
                 }
@@ -330,37 +340,37 @@ __global__ __launch_bounds__(64 * CW + 256) void wtile2_kernel(const XmcConvDesc
                     float v[8];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { v[r] = acc[i][2 * u][r]; v[4 + r] = acc[i][2 * u + 1][r]; }
-                    if (d.bias && !(WT_ABL & 32)) {
+                    if (e_bias && !(WT_ABL & 32)) {
                         const f32x4 b0v = *reinterpret_cast<const f32x4*>(d.bias + ch0 + u * 32), b1v = *reinterpret_cast<const f32x4*>(d.bias + ch0 + u * 32 + 4);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) { v[r] += b0v[r]; v[4 + r] += b1v[r]; }
                     }
-                    if (d.act == XMC_ACT_TANH) {
+                    if (e_tanh) {
 #pragma unroll
                         for (int r = 0; r < 8; ++r) v[r] = tanhf(v[r]);
                     } else if (slope != 1.f) {
 #pragma unroll
                         for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], v[r] * slope);
                     }
-                    if (dst2_8 || d.round_act) {
+                    if (e_round) {
                         bf16x8 o2;
 #pragma unroll
                         for (int r = 0; r < 8; ++r) { o2[r] = (xmc_h16)v[r]; v[r] = (float)o2[r]; }
-                        if (dst2_8) dst2_8[eo[i] + u * 4] = o2;
+                        if (e_dst2) dst2_8[eo[i] + u * 4] = o2;
                     }
-                    if (d.alpha_dev) {
+                    if (e_alpha) {
 #pragma unroll
                         for (int r = 0; r < 8; ++r) v[r] *= alpha;
                     }
-                    if (mask8) {
+                    if (e_mask) {
 #pragma unroll
                         for (int r = 0; r < 8; ++r) v[r] *= lrelu_slope((float)mkv[i][r]);
                     }
-                    if (res8) {
+                    if (e_res) {
 #pragma unroll
                         for (int r = 0; r < 8; ++r) v[r] += rs * (float)rrv[i][r];
                     }
-                    if (d.post_act == XMC_ACT_LRELU) {
+                    if (e_post) {
 #pragma unroll
                         for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], v[r] * XMC_LRELU);
                     }
@@ -370,7 +380,7 @@ __global__ __launch_bounds__(64 * CW + 256) void wtile2_kernel(const XmcConvDesc
                     if (!(WT_ABL & 16)) dst8[eo[i] + u * 4] = o;
                     else asm volatile("" :: "v"(o));
                 }
-                if (pool8) {
+                if (e_pool) {
                     // 2x2 average of the ROUNDED block output (== F.avg_pool2d of dst): the vertical neighbour is pixel block
                     // i+2 (8x32 tiles) or i+1 (16x16 tiles) of the same lane, the horizontal one the same block of lane ^ 1
 #pragma unroll
@@ -524,6 +534,26 @@ int launch(const XmcConvDesc& d, const WtCfg& t, hipStream_t st) {
     int gx = 256 / (ny * d.nclass);               // one 8-wave workgroup per CU, persistent over its tiles
     if (gx < 1) gx = 1;
     if (gx > ntiles) gx = ntiles;
+    // epilogue option sets of the training step as compile-time instantiations (common.h: kEpi*), eight compute waves only
+    static const bool no_epi = xmc_debug_off("no_wtile_epi");
+    const int epi = (no_epi || CW != 8) ? -1 : xmc_epi_mask(d);
+#define XMC_W2_EPI(E)                                                                                                                          \
+    if (epi == (E)) {                                                                                                                          \
+        XMC_ALLOW_BIG_LDS((wtile2_kernel<NTAPS, MODE, TN, CW, (E)>));                                                                          \
+        hipLaunchKernelGGL((wtile2_kernel<NTAPS, MODE, TN, CW, (E)>), dim3((unsigned)gx, (unsigned)ny, (unsigned)d.nclass), dim3(64 * CW + 256), lds, st, \
+                           d, t, ntiles);                                                                                                      \
+        xmc_note_kernel("wtile2_kernel<%d, %d, %d, %d>", NTAPS, MODE, TN, CW);                                                                 \
+        XMC_LAUNCH_CHECK();                                                                                                                    \
+        return 0;                                                                                                                              \
+    }
+    if constexpr (CW == 8 && NTAPS == 9 && TN == 8) {
+        XMC_W2_EPI(kEpiGSum) XMC_W2_EPI(kEpiDKeep) XMC_W2_EPI(kEpiDFwd) XMC_W2_EPI(kEpiDLast) XMC_W2_EPI(kEpiMask) XMC_W2_EPI(0)
+    } else if constexpr (CW == 8 && MODE == 1 && TN == 8) {
+        XMC_W2_EPI(kEpiLrelu)
+    } else if constexpr (CW == 8 && NTAPS == 4 && MODE == 0) {
+        XMC_W2_EPI(kEpiRes) XMC_W2_EPI(kEpiBias) XMC_W2_EPI(0)
+    }
+#undef XMC_W2_EPI
     XMC_ALLOW_BIG_LDS((wtile2_kernel<NTAPS, MODE, TN, CW>));
     hipLaunchKernelGGL((wtile2_kernel<NTAPS, MODE, TN, CW>), dim3((unsigned)gx, (unsigned)ny, (unsigned)d.nclass), dim3(64 * CW + 256), lds, st, d, t,
                        ntiles);

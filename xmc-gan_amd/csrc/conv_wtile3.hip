@@ -64,7 +64,7 @@ __device__ __forceinline__ void glds16(const void* src, lds_u8* dst) {
 
 // WM = wave rows (pixel direction): 2 -> BN = 256, wave tile 128 x 64, four phases per stage, ring of 2
 //                                   4 -> BN = 128, wave tile  64 x 64, two phases per stage, ring of 4
-template <int NTAPS, int MODE, int WM>
+template <int NTAPS, int MODE, int WM, int EPI = -1>
 __global__ __launch_bounds__(512) void wtile3_kernel(const XmcConvDesc d, const W3Cfg t, int ntiles) {
     constexpr int WN = 8 / WM, BN = 64 * WN;
     constexpr int TMW = 16 / WM;                 // 16-pixel blocks per wave (8 or 4)
@@ -234,7 +234,17 @@ __global__ __launch_bounds__(512) void wtile3_kernel(const XmcConvDesc d, const 
         const int dbase = (((img * d.DH + a0 * d.DA + d.dph[cls]) * d.DW) + b0 * d.DA + d.dpw[cls]) * cd8 + nw8;
         const int rbase = d.res_mode ? ((img * d.MH + a0) * d.MW + b0) * cd8 + nw8 : dbase;
         const int rsy = d.res_mode ? d.MW : d.DA * d.DW, rsx = d.res_mode ? 1 : d.DA;
-        const float slope = d.act == XMC_ACT_LRELU ? XMC_LRELU : (d.act == XMC_ACT_RELU ? 0.f : 1.f);
+        constexpr bool RT = EPI < 0;                   // epilogue options read from the descriptor (common.h: kEpi*)
+        const bool e_bias = RT ? d.bias != nullptr : (EPI & kEpiBias) != 0;
+        const bool e_tanh = RT ? d.act == XMC_ACT_TANH : false;
+        const bool e_round = RT ? (d.dst2 != nullptr || d.round_act != 0) : (EPI & (kEpiRound | kEpiDst2)) != 0;
+        const bool e_dst2 = RT ? d.dst2 != nullptr : (EPI & kEpiDst2) != 0;
+        const bool e_alpha = RT ? d.alpha_dev != nullptr : (EPI & kEpiAlpha) != 0;
+        const bool e_mask = RT ? d.mask != nullptr : (EPI & kEpiMask) != 0;
+        const bool e_res = RT ? d.res != nullptr : (EPI & kEpiRes) != 0;
+        const bool e_post = RT ? d.post_act == XMC_ACT_LRELU : (EPI & kEpiPost) != 0;
+        const bool e_pool = RT ? d.dst_pool != nullptr : (EPI & kEpiPool) != 0;
+        const float slope = RT ? (d.act == XMC_ACT_LRELU ? XMC_LRELU : (d.act == XMC_ACT_RELU ? 0.f : 1.f)) : ((EPI & kEpiLrelu) ? XMC_LRELU : 1.f);
         const float alpha = d.alpha_dev ? *d.alpha_dev : 1.f;
         const float rs = d.res_scale == 0.f ? 1.f : d.res_scale;
         bf16x8* __restrict__ dst8 = reinterpret_cast<bf16x8*>(d.dst);
@@ -261,11 +271,11 @@ __global__ __launch_bounds__(512) void wtile3_kernel(const XmcConvDesc d, const 
                 if (ch0 + u * 32 >= d.CD) continue;
                 float fin[4][8];
                 bf16x8 mkv[4], rrv[4];
-                if (mask8) {
+                if (e_mask) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) mkv[i] = mask8[eo[i] + u * 4];
                 }
-                if (res8) {
+                if (e_res) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) rrv[i] = res8[ro[i] + u * 4];
                 }
@@ -274,37 +284,37 @@ __global__ __launch_bounds__(512) void wtile3_kernel(const XmcConvDesc d, const 
                     float v[8];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { v[r] = acc[g * 4 + i][2 * u][r]; v[4 + r] = acc[g * 4 + i][2 * u + 1][r]; }
-                    if (d.bias) {
+                    if (e_bias) {
                         const f32x4 b0v = *reinterpret_cast<const f32x4*>(d.bias + ch0 + u * 32), b1v = *reinterpret_cast<const f32x4*>(d.bias + ch0 + u * 32 + 4);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) { v[r] += b0v[r]; v[4 + r] += b1v[r]; }
                     }
-                    if (d.act == XMC_ACT_TANH) {
+                    if (e_tanh) {
 #pragma unroll
                         for (int r = 0; r < 8; ++r) v[r] = tanhf(v[r]);
                     } else if (slope != 1.f) {
 #pragma unroll
                         for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], v[r] * slope);
                     }
-                    if (dst2_8 || d.round_act) {
+                    if (e_round) {
                         bf16x8 o2;
 #pragma unroll
                         for (int r = 0; r < 8; ++r) { o2[r] = (xmc_h16)v[r]; v[r] = (float)o2[r]; }
-                        if (dst2_8) dst2_8[eo[i] + u * 4] = o2;
+                        if (e_dst2) dst2_8[eo[i] + u * 4] = o2;
                     }
-                    if (d.alpha_dev) {
+                    if (e_alpha) {
 #pragma unroll
                         for (int r = 0; r < 8; ++r) v[r] *= alpha;
                     }
-                    if (mask8) {
+                    if (e_mask) {
 #pragma unroll
                         for (int r = 0; r < 8; ++r) v[r] *= lrelu_slope((float)mkv[i][r]);
                     }
-                    if (res8) {
+                    if (e_res) {
 #pragma unroll
                         for (int r = 0; r < 8; ++r) v[r] += rs * (float)rrv[i][r];
                     }
-                    if (d.post_act == XMC_ACT_LRELU) {
+                    if (e_post) {
 #pragma unroll
                         for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], v[r] * XMC_LRELU);
                     }
@@ -313,7 +323,7 @@ __global__ __launch_bounds__(512) void wtile3_kernel(const XmcConvDesc d, const 
                     for (int r = 0; r < 8; ++r) { o[r] = (xmc_h16)v[r]; fin[i][r] = (float)o[r]; }
                     dst8[eo[i] + u * 4] = o;
                 }
-                if (pool8) {
+                if (e_pool) {
                     // 2x2 average of the ROUNDED output (== F.avg_pool2d of dst): the vertical neighbour is pixel block i+2 (8x32
                     // tiles) or i+1 (16x16 tiles) of the same lane -- both inside this group of four -- the horizontal one lane ^ 1
 #pragma unroll
@@ -537,6 +547,25 @@ int launch3(const XmcConvDesc& d, const W3Cfg& t, hipStream_t st) {
     int gx = 256 / (ny * d.nclass);               // one 8-wave workgroup per CU, persistent over its tiles
     if (gx < 1) gx = 1;
     if (gx > ntiles) gx = ntiles;
+    // epilogue option sets of the training step as compile-time instantiations (common.h: kEpi*), 256-channel tiles only
+    static const bool no_epi = xmc_debug_off("no_wtile_epi");
+    const int epi = (no_epi || WM != 2) ? -1 : xmc_epi_mask(d);
+#define XMC_W3_EPI(E)                                                                                                                        \
+    if (epi == (E)) {                                                                                                                        \
+        XMC_ALLOW_BIG_LDS((wtile3_kernel<NTAPS, MODE, WM, (E)>));                                                                            \
+        hipLaunchKernelGGL((wtile3_kernel<NTAPS, MODE, WM, (E)>), dim3((unsigned)gx, (unsigned)ny, (unsigned)d.nclass), dim3(512), lds, st, d, t, ntiles); \
+        xmc_note_kernel("wtile3_kernel<%d, %d, %d>", NTAPS, MODE, WM);                                                                       \
+        XMC_LAUNCH_CHECK();                                                                                                                  \
+        return 0;                                                                                                                            \
+    }
+    if constexpr (WM == 2 && NTAPS == 9) {
+        XMC_W3_EPI(kEpiGSum) XMC_W3_EPI(kEpiDKeep) XMC_W3_EPI(kEpiDFwd) XMC_W3_EPI(kEpiDLast) XMC_W3_EPI(kEpiMask) XMC_W3_EPI(0)
+    } else if constexpr (WM == 2 && MODE == 1) {
+        XMC_W3_EPI(kEpiLrelu)
+    } else if constexpr (WM == 2) {
+        XMC_W3_EPI(kEpiRes) XMC_W3_EPI(kEpiBias) XMC_W3_EPI(0)
+    }
+#undef XMC_W3_EPI
     XMC_ALLOW_BIG_LDS((wtile3_kernel<NTAPS, MODE, WM>));
     hipLaunchKernelGGL((wtile3_kernel<NTAPS, MODE, WM>), dim3((unsigned)gx, (unsigned)ny, (unsigned)d.nclass), dim3(512), lds, st, d, t, ntiles);
     xmc_note_kernel("wtile3_kernel<%d, %d, %d>", NTAPS, MODE, WM);
