@@ -572,10 +572,23 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
 #pragma unroll
             for (int c = 0; c < 8; ++c) bias8[u][c] = (d.bias && ch0 + u * 32 < d.CD) ? d.bias[ch0 + u * 32 + c] : 0.f;
         // one uniform decision instead of a chain of branches per stored unit
-        const bool fast = d.out_dtype == XMC_BF16 && d.res == nullptr && d.mask == nullptr && d.alpha_dev == nullptr && d.dst2 == nullptr && d.dst_pool == nullptr && d.post_act == XMC_ACT_NONE &&
-                          (d.act == XMC_ACT_NONE || d.act == XMC_ACT_LRELU || d.act == XMC_ACT_TANH);
-        const bool do_tanh = d.act == XMC_ACT_TANH;
-        const float slope = d.act == XMC_ACT_LRELU ? XMC_LRELU : 1.f;
+        constexpr bool RT = EPI < 0;                       // epilogue options read from the descriptor (common.h: kEpi*)
+        constexpr int EB = RT ? 0 : (EPI & ~kEpiBias);     // (the bias vector is always added: zeros when there is none)
+        const bool fast = RT ? (d.out_dtype == XMC_BF16 && d.res == nullptr && d.mask == nullptr && d.alpha_dev == nullptr && d.dst2 == nullptr &&
+                                d.dst_pool == nullptr && d.post_act == XMC_ACT_NONE &&
+                                (d.act == XMC_ACT_NONE || d.act == XMC_ACT_LRELU || d.act == XMC_ACT_TANH))
+                             : (EB == 0 || EB == kEpiLrelu);
+        const bool do_tanh = RT ? d.act == XMC_ACT_TANH : false;
+        const float slope = RT ? (d.act == XMC_ACT_LRELU ? XMC_LRELU : 1.f) : ((EPI & kEpiLrelu) ? XMC_LRELU : 1.f);
+        const bool e_lrelu = RT ? d.act == XMC_ACT_LRELU : (EPI & kEpiLrelu) != 0;
+        const bool e_relu = RT ? d.act == XMC_ACT_RELU : false;
+        const bool e_round = RT ? (d.dst2 != nullptr || d.round_act != 0) : (EPI & (kEpiRound | kEpiDst2)) != 0;
+        const bool e_dst2 = RT ? d.dst2 != nullptr : (EPI & kEpiDst2) != 0;
+        const bool e_alpha = RT ? d.alpha_dev != nullptr : (EPI & kEpiAlpha) != 0;
+        const bool e_mask = RT ? d.mask != nullptr : (EPI & kEpiMask) != 0;
+        const bool e_res = RT ? d.res != nullptr : (EPI & kEpiRes) != 0;
+        const bool e_post = RT ? d.post_act == XMC_ACT_LRELU : (EPI & kEpiPost) != 0;
+        const bool e_pool = RT ? d.dst_pool != nullptr : (EPI & kEpiPool) != 0;
         __syncthreads();                          // weights + first patch staged
         int toffr[NTAPS > 0 ? MC * NTAPS : 1];
         if constexpr (NTAPS > 0) {
@@ -603,13 +616,13 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
             // bf16 epilogue operands (LeakyReLU' mask, residual) are requested NOW, before the tile's MFMAs, as in the 32x32x16 role:
             // requested in the epilogue, one memory round trip per tile stood between the last MFMA and the first store -- at 32
             // channels as long as the tile's whole K loop (32 -> 32 @ 256^2 with the block sum: 1.01 ms against 0.55 without).
-            const bool pre = d.out_dtype == XMC_BF16;
+            const bool pre = RT ? d.out_dtype == XMC_BF16 : true;
             const int dbase = (((img * d.DH + a0 * d.DA + dph) * d.DW) + b0 * d.DA + dpw) * cd8 + (n0 >> 3);
             const int rbase = ((img * d.MH + a0) * d.MW + b0) * cd8 + (n0 >> 3);
             // (one 32-channel unit per lane only: with two, the 64 extra live registers spill; the 64-channel layers with such an
             // epilogue run in the 32x32x16 role anyway)
             const bool res_once = MC > 1 && d.res_mode == 1;
-            if (HOIST && pre && (d.mask || d.res)) {
+            if (HOIST && pre && (e_mask || e_res)) {
 #pragma unroll
                 for (int u = 0; u < UPL; ++u) {
                     if (ch0 + u * 32 >= d.CD) continue;
@@ -622,8 +635,8 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
                             const int y_ = (a0 + (ml_ >> t.log2TW)) * d.DA + dph, x_ = (b0 + (ml_ & (t.TW - 1))) * d.DA + dpw;
                             rix = res_index8(d, idx8, img, y_, x_, 0, 0, (n0 >> 3) + fc + u * 4);
                         }
-                        if (d.mask) mkv[HOIST ? i : 0] = reinterpret_cast<const bf16x8*>(d.mask)[idx8];
-                        if (d.res && (mc == 0 || !res_once)) rrv[HOIST ? i : 0] = reinterpret_cast<const bf16x8*>(d.res)[rix];
+                        if (e_mask) mkv[HOIST ? i : 0] = reinterpret_cast<const bf16x8*>(d.mask)[idx8];
+                        if (e_res && (mc == 0 || !res_once)) rrv[HOIST ? i : 0] = reinterpret_cast<const bf16x8*>(d.res)[rix];
                     }
                 }
             }
@@ -735,8 +748,8 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
                                 const int y_ = (a0 + (ml_ >> t.log2TW)) * d.DA + dph, x_ = (b0 + (ml_ & (t.TW - 1))) * d.DA + dpw;
                                 rix[i] = res_index8(d, idx8, img, y_, x_, 0, 0, (n0 >> 3) + fc + u * 4);
                             }
-                            if (pre && d.mask) mkl[HOIST ? 0 : i] = reinterpret_cast<const bf16x8*>(d.mask)[idx8];
-                            if (pre && d.res) rrl[HOIST ? 0 : i] = reinterpret_cast<const bf16x8*>(d.res)[rix[i]];
+                            if (pre && e_mask) mkl[HOIST ? 0 : i] = reinterpret_cast<const bf16x8*>(d.mask)[idx8];
+                            if (pre && e_res) rrl[HOIST ? 0 : i] = reinterpret_cast<const bf16x8*>(d.res)[rix[i]];
                         }
                     }
 #pragma unroll
@@ -745,38 +758,38 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
                         float v[8];
 #pragma unroll
                         for (int q = 0; q < 4; ++q) { v[q] = acc[i][2 * u][q] + bias8[u][q]; v[4 + q] = acc[i][2 * u + 1][q] + bias8[u][4 + q]; }
-                        if (d.act == XMC_ACT_LRELU) {
+                        if (e_lrelu) {
 #pragma unroll
                             for (int q = 0; q < 8; ++q) v[q] = lrelu_f(v[q]);
-                        } else if (d.act == XMC_ACT_RELU) {
+                        } else if (e_relu) {
 #pragma unroll
                             for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
-                        } else if (d.act == XMC_ACT_TANH) {
+                        } else if (do_tanh) {
 #pragma unroll
                             for (int q = 0; q < 8; ++q) v[q] = tanhf(v[q]);
                         }
                         if (pre) {      // epilogue_tail<XMC_BF16> with the loads hoisted
                             bf16x8* __restrict__ dst8 = reinterpret_cast<bf16x8*>(d.dst);
-                            if (d.dst2 || d.round_act) {
+                            if (e_round) {
                                 bf16x8 o2;
 #pragma unroll
                                 for (int q = 0; q < 8; ++q) { o2[q] = (xmc_h16)v[q]; v[q] = (float)o2[q]; }
-                                if (d.dst2) reinterpret_cast<bf16x8*>(d.dst2)[idx8] = o2;
+                                if (e_dst2) reinterpret_cast<bf16x8*>(d.dst2)[idx8] = o2;
                             }
-                            if (d.alpha_dev) {
+                            if (e_alpha) {
 #pragma unroll
                                 for (int q = 0; q < 8; ++q) v[q] *= alpha;
                             }
-                            if (d.mask) {
+                            if (e_mask) {
 #pragma unroll
                                 for (int q = 0; q < 8; ++q) v[q] *= lrelu_slope((float)(HOIST ? mkv[HOIST ? i : 0] : mkl[HOIST ? 0 : i])[q]);
                             }
-                            if (d.res) {
+                            if (e_res) {
                                 const float rs = d.res_scale == 0.f ? 1.f : d.res_scale;
 #pragma unroll
                                 for (int q = 0; q < 8; ++q) v[q] += rs * (float)(HOIST ? rrv[HOIST ? i : 0] : rrl[HOIST ? 0 : i])[q];
                             }
-                            if (d.post_act == XMC_ACT_LRELU) {
+                            if (e_post) {
 #pragma unroll
                                 for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], v[q] * XMC_LRELU);
                             }
@@ -790,7 +803,7 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
                             for (int q = 0; q < 8; ++q) fin[i][q] = v[q];
                         }
                     }
-                    if (SA == 1 && MC == 1 && TM == 4 && d.dst_pool) {
+                    if (SA == 1 && MC == 1 && TM == 4 && e_pool) {
                         // third output: 2x2 average of the rounded block output (the launcher admits it for bf16, DA == 1 only).
                         // Vertical neighbour = pixel block i+2 (8x32 tiles) / i+1 (16x16 tiles) of this lane, horizontal = lane ^ 1.
                         bf16x8* __restrict__ pool8 = reinterpret_cast<bf16x8*>(d.dst_pool);
@@ -827,6 +840,18 @@ int launch_ptile(const XmcConvDesc& d, const TileCfg& t, hipStream_t st) {
         const int nt2 = d.N * t.tiles_y * t.tiles_x;
         int g2 = 256 / (int)(d.CDw / BN);
         if (g2 > nt2) g2 = nt2;
+        static const bool no_epi2 = xmc_debug_off("no_ptile_epi");
+        const int epi2 = no_epi2 ? -1 : (xmc_epi_mask(d) & ~kEpiBias);          // (< 0 stays < 0: bit 0 of -1 cleared is -2)
+#define XMC_PT3S2(E)                                                                                                        \
+        if (epi2 == (E)) {                                                                                                  \
+            XMC_ALLOW_BIG_LDS((ptile3_kernel<BN, 32, 16, 1, 2, false, (E)>));                                               \
+            hipLaunchKernelGGL((ptile3_kernel<BN, 32, 16, 1, 2, false, (E)>), dim3(g2, d.CDw / BN, 1), dim3(512), lds2, st, d, t, nt2); \
+            xmc_note_kernel("ptile3_kernel<%d, 32, 16, 1, 2>", BN);                                                         \
+            XMC_LAUNCH_CHECK();                                                                                             \
+            return 0;                                                                                                       \
+        }
+        XMC_PT3S2(kEpiLrelu) XMC_PT3S2(0)
+#undef XMC_PT3S2
         XMC_ALLOW_BIG_LDS((ptile3_kernel<BN, 32, 16, 1, 2>));
         hipLaunchKernelGGL((ptile3_kernel<BN, 32, 16, 1, 2>), dim3(g2, d.CDw / BN, 1), dim3(512), lds2, st, d, t, nt2);
         xmc_note_kernel("ptile3_kernel<%d, 32, 16, 1, 2>", BN);
@@ -852,6 +877,15 @@ int launch_ptile(const XmcConvDesc& d, const TileCfg& t, hipStream_t st) {
             int gm = 256 / (int)(d.CDw / BN);
             if (gm > ntiles) gm = ntiles;
             dim3 gridm((unsigned)gm, (unsigned)(d.CDw / BN), 1);
+            static const bool no_epim = xmc_debug_off("no_ptile_epi");
+            const int epim = no_epim ? -1 : (xmc_epi_mask(d) & ~kEpiBias);
+#define XMC_PT3M(SL, E)                                                                                                     \
+            if (t.slab == (SL) && epim == (E)) {                                                                            \
+                XMC_ALLOW_BIG_LDS((ptile3_kernel<BN, SL, 4, 4, 1, false, (E)>));                                            \
+                hipLaunchKernelGGL((ptile3_kernel<BN, SL, 4, 4, 1, false, (E)>), gridm, dim3(512), ldsm, st, d, t, ntiles); \
+            } else
+            XMC_PT3M(64, kEpiRes) XMC_PT3M(64, 0) XMC_PT3M(32, kEpiRes) XMC_PT3M(32, 0)
+#undef XMC_PT3M
             if (t.slab == 64) {
                 XMC_ALLOW_BIG_LDS((ptile3_kernel<BN, 64, 4, 4>));
                 hipLaunchKernelGGL((ptile3_kernel<BN, 64, 4, 4>), gridm, dim3(512), ldsm, st, d, t, ntiles);
@@ -896,6 +930,20 @@ int launch_ptile(const XmcConvDesc& d, const TileCfg& t, hipStream_t st) {
         hipLaunchKernelGGL((ptile3_kernel<BN, SL, NTP, 1>), grid, dim3(512), lds, st, d, t, ntiles);                          \
         xmc_note_kernel("ptile3_kernel<%d, %d, %d, 1>", BN, SL, NTP);                                                         \
     } while (0)
+    static const bool no_epi9 = xmc_debug_off("no_ptile_epi");
+    const int epi9 = (no_epi9 || d.ntaps != 9) ? -1 : (xmc_epi_mask(d) & ~kEpiBias);
+#define XMC_PT3E(SL, E)                                                                                                       \
+    if (t.slab == (SL) && epi9 == (E)) {                                                                                      \
+        XMC_ALLOW_BIG_LDS((ptile3_kernel<BN, SL, 9, 1, 1, false, (E)>));                                                      \
+        hipLaunchKernelGGL((ptile3_kernel<BN, SL, 9, 1, 1, false, (E)>), grid, dim3(512), lds, st, d, t, ntiles);             \
+        xmc_note_kernel("ptile3_kernel<%d, %d, %d, 1>", BN, SL, 9);                                                           \
+        XMC_LAUNCH_CHECK();                                                                                                   \
+        return 0;                                                                                                             \
+    }
+    // plain / bias only (the data gradients, the 64 -> 64 forward without a block end) and the generator's last block: c2 + block sum
+    // + the tail's LeakyReLU
+    XMC_PT3E(64, 0) XMC_PT3E(32, 0) XMC_PT3E(32, (kEpiGSum | kEpiPost) & ~kEpiBias) XMC_PT3E(64, (kEpiGSum | kEpiPost) & ~kEpiBias)
+#undef XMC_PT3E
     if (t.slab == 64) {
         if (d.ntaps == 9) XMC_PT3(64, 9); else if (d.ntaps == 4) XMC_PT3(64, 4); else XMC_PT3(64, 0);
     } else {
