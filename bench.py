@@ -75,11 +75,20 @@ def pmc_traffic_lookup(imsize, batch, cfg_name, precision):
     rows = list(csv.DictReader(open(path)))
 
     def lookup(kernel):
-        for r in rows:
-            # names as the library reports them leave out trailing default template arguments
-            if any(kernel[:-1] + tail + "(" in r["kernel"] for tail in (">", ", false>", ", false, false>")):
-                return round((float(r["fetch_MB_per_dispatch_corrected_x2"]) + float(r["write_MB_per_dispatch"])) * 2**20)
-        return None
+        # the library reports a kernel without trailing default template arguments; instantiations that differ only in the
+        # epilogue-variant argument (EPI, common.h) share the reported name: those are averaged, weighted by their dispatches
+        def avg(pred):
+            tot, n = 0.0, 0
+            for r in rows:
+                if pred(r["kernel"]):
+                    k = int(r["dispatches"])
+                    tot += k * (float(r["fetch_MB_per_dispatch_corrected_x2"]) + float(r["write_MB_per_dispatch"]))
+                    n += k
+            return round(tot / n * 2**20) if n else None
+        exact = avg(lambda nm: any(kernel[:-1] + tail + "(" in nm for tail in (">", ", false>", ", false, false>")))
+        if exact is not None:
+            return exact
+        return avg(lambda nm: kernel[:-1] + ", " in nm)
     return lookup
 
 
