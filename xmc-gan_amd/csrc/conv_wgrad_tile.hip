@@ -38,7 +38,7 @@ template <int NCO, int NCI> struct WtOcc {
 // 64-channel blocks are visited (blockIdx.y; Cin block == Cout block) and an item (ci block, tap) multiplies the ONE Cout block
 // with the same index: 1/8 of the dense MFMAs and half the staging.
 template <int NCO, int NCI, int NT, int SA = 1, int KT = 9, int CBW = 1, bool DIAG = false, bool T16 = false>     // 16-wide blocks of (padded) Cout and Cin; NT threads
-__global__ __launch_bounds__(NT, (SA == 1 ? WtOcc<NCO, NCI>::v : 1)) void wgrad_tile_kernel(const XmcConvDesc d, float* __restrict__ dwp, float* __restrict__ dbias, const WTCfg t) {
+__global__ __launch_bounds__(NT, ((SA == 1 && NT == 256) ? WtOcc<NCO, NCI>::v : 1)) void wgrad_tile_kernel(const XmcConvDesc d, float* __restrict__ dwp, float* __restrict__ dbias, const WTCfg t) {
     constexpr int TH = T16 ? 16 : 8, TW = T16 ? 16 : 32;
     constexpr int KS = TH * TW / 32;                          // K steps of 32 pixels per tile
     static_assert(!T16 || SA == 1, "16 x 16 tiles: unit stride only");
@@ -358,6 +358,7 @@ int launch_wt(const XmcConvDesc& d, float* dwp, float* dbias, const WTCfg& t, hi
     int per_cu = (int)(160 * 1024 / lds);
     const int cap = WtOcc<NCO, NCI>::v >= 3 ? 3 : 2;
     if (per_cu > cap) per_cu = cap;
+    if (NT == 512) per_cu = 1;                                // 8 waves at ~200 registers: one workgroup per CU
     const int ny = (d.CS + 63) / 64, nz = DIAG ? 1 : (d.CD + 63) / 64;
     int gx = 256 * per_cu / (ny * nz);
     if (gx < 1) gx = 1;
@@ -414,6 +415,10 @@ int xmc_conv_wgrad_tile_try(const XmcConvDesc* d, float* dwp, float* dbias, void
 #define WT_CASE(a, b) if (nco == a && nci == b) return launch_wt<a, b, 256, 1, 9, (a >= 2 ? 2 : 1)>(*d, dwp, dbias, t, st);
     // (4,4) = 64x64 channels with 4 waves needs 144 accumulator + 76 staging registers per lane and measured slower than
     // the split-K kernel (166 vs 230 TF/s); it runs with 8 waves instead (below)
+    // 64 -> 32 / 32 -> 64 channels as 8 waves with the pipelined K loop (A/B: XMC_DEBUG_DISPATCH=no_wt24_8w keeps the 4-wave forms)
+    static const bool no_8w = xmc_debug_off("no_wt24_8w");
+    if (!no_8w && nco == 2 && nci == 4) return launch_wt<2, 4, 512, 1, 9, 2>(*d, dwp, dbias, t, st);
+    if (!no_8w && nco == 4 && nci == 2) return launch_wt<4, 2, 512, 1, 9, 4>(*d, dwp, dbias, t, st);
     WT_CASE(1, 2) WT_CASE(1, 4) WT_CASE(2, 1) WT_CASE(2, 2) WT_CASE(2, 4) WT_CASE(4, 1) WT_CASE(4, 2)
     // grouped layer with its groups inside the diagonal 16x16 blocks (8 -> 8 channels per group): diagonal blocks only
     static const bool no_diag = xmc_debug_off("no_wt_diag");
