@@ -547,9 +547,9 @@ int launch3(const XmcConvDesc& d, const W3Cfg& t, hipStream_t st) {
     int gx = 256 / (ny * d.nclass);               // one 8-wave workgroup per CU, persistent over its tiles
     if (gx < 1) gx = 1;
     if (gx > ntiles) gx = ntiles;
-    // epilogue option sets of the training step as compile-time instantiations (common.h: kEpi*), 256-channel tiles only
+    // epilogue option sets of the training step as compile-time instantiations (common.h: kEpi*)
     static const bool no_epi = xmc_debug_off("no_wtile_epi");
-    const int epi = (no_epi || WM != 2) ? -1 : xmc_epi_mask(d);
+    const int epi = no_epi ? -1 : xmc_epi_mask(d);
 #define XMC_W3_EPI(E)                                                                                                                        \
     if (epi == (E)) {                                                                                                                        \
         XMC_ALLOW_BIG_LDS((wtile3_kernel<NTAPS, MODE, WM, (E)>));                                                                            \
@@ -558,11 +558,11 @@ int launch3(const XmcConvDesc& d, const W3Cfg& t, hipStream_t st) {
         XMC_LAUNCH_CHECK();                                                                                                                  \
         return 0;                                                                                                                            \
     }
-    if constexpr (WM == 2 && NTAPS == 9) {
+    if constexpr (NTAPS == 9) {
         XMC_W3_EPI(kEpiGSum) XMC_W3_EPI(kEpiDKeep) XMC_W3_EPI(kEpiDFwd) XMC_W3_EPI(kEpiDLast) XMC_W3_EPI(kEpiMask) XMC_W3_EPI(0)
-    } else if constexpr (WM == 2 && MODE == 1) {
+    } else if constexpr (MODE == 1) {
         XMC_W3_EPI(kEpiLrelu)
-    } else if constexpr (WM == 2) {
+    } else {
         XMC_W3_EPI(kEpiRes) XMC_W3_EPI(kEpiBias) XMC_W3_EPI(0)
     }
 #undef XMC_W3_EPI
