@@ -36,6 +36,7 @@ static inline int xmc_esz(int dtype) { return dtype == XMC_BF16 ? 2 : 4; }
 // name of the kernel the calling thread dispatched last (xmc_last_kernel(), used by bench.py's roofline to attribute
 // its per-launch HIP-event timings to the instantiation rocprof reports)
 void xmc_note_kernel(const char* fmt, ...);
+void xmc_note_generic_epi(const char* kernel, int mask);
 // true when `token` is listed in the XMC_DEBUG_DISPATCH environment variable (kernel A/B experiments; unset in production)
 bool xmc_debug_off(const char* token);
 
@@ -162,6 +163,7 @@ constexpr int kEpiGSum = kEpiBias | kEpiRound | kEpiAlpha | kEpiRes;            
 constexpr int kEpiDKeep = kEpiLrelu | kEpiDst2 | kEpiAlpha | kEpiRes | kEpiPool;          // discriminator conv_r[2] + block end, kept for a backward
 constexpr int kEpiDFwd = kEpiLrelu | kEpiRound | kEpiAlpha | kEpiRes | kEpiPool;          // ... forward only
 constexpr int kEpiDLast = kEpiLrelu | kEpiDst2 | kEpiAlpha | kEpiRes;                     // ... last block of a pass (no pooled output)
+constexpr int kEpiDLin = kEpiDst2 | kEpiAlpha | kEpiMask | kEpiRes;                      // the block end linearised (MA-GP: ResDBwdFn.backward)
 // the mask of a descriptor, or -1 if it uses an option the masks do not describe (tanh / relu, f32 destination)
 static inline int xmc_epi_mask(const XmcConvDesc& d) {
     if ((d.act != XMC_ACT_NONE && d.act != XMC_ACT_LRELU) || d.out_dtype != XMC_BF16) return -1;

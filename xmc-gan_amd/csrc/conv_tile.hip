@@ -850,8 +850,9 @@ int launch_ptile(const XmcConvDesc& d, const TileCfg& t, hipStream_t st) {
             XMC_LAUNCH_CHECK();                                                                                             \
             return 0;                                                                                                       \
         }
-        XMC_PT3S2(kEpiLrelu) XMC_PT3S2(0)
+        XMC_PT3S2(kEpiLrelu) XMC_PT3S2(0) XMC_PT3S2(kEpiMask)
 #undef XMC_PT3S2
+        xmc_note_generic_epi("ptile3<s2>", epi2);
         XMC_ALLOW_BIG_LDS((ptile3_kernel<BN, 32, 16, 1, 2>));
         hipLaunchKernelGGL((ptile3_kernel<BN, 32, 16, 1, 2>), dim3(g2, d.CDw / BN, 1), dim3(512), lds2, st, d, t, nt2);
         xmc_note_kernel("ptile3_kernel<%d, 32, 16, 1, 2>", BN);
@@ -887,6 +888,7 @@ int launch_ptile(const XmcConvDesc& d, const TileCfg& t, hipStream_t st) {
             XMC_PT3M(64, kEpiRes) XMC_PT3M(64, 0) XMC_PT3M(32, kEpiRes) XMC_PT3M(32, 0)
 #undef XMC_PT3M
             if (t.slab == 64) {
+                xmc_note_generic_epi("ptile3<4,4>", epim);
                 XMC_ALLOW_BIG_LDS((ptile3_kernel<BN, 64, 4, 4>));
                 hipLaunchKernelGGL((ptile3_kernel<BN, 64, 4, 4>), gridm, dim3(512), ldsm, st, d, t, ntiles);
             } else {
@@ -915,9 +917,10 @@ int launch_ptile(const XmcConvDesc& d, const TileCfg& t, hipStream_t st) {
             XMC_LAUNCH_CHECK();                                                                                          \
             return 0;                                                                                                    \
         }
-        XMC_PT3_EPI(kEpiGSum) XMC_PT3_EPI(kEpiDKeep) XMC_PT3_EPI(kEpiDFwd) XMC_PT3_EPI(kEpiDLast)
+        XMC_PT3_EPI(kEpiGSum) XMC_PT3_EPI(kEpiDKeep) XMC_PT3_EPI(kEpiDFwd) XMC_PT3_EPI(kEpiDLast) XMC_PT3_EPI(kEpiDLin)
         XMC_PT3_EPI(kEpiMask)                                                                // data gradient through a LeakyReLU
 #undef XMC_PT3_EPI
+        xmc_note_generic_epi("ptile3<M32>", epi);
         XMC_ALLOW_BIG_LDS((ptile3_kernel<BN, 64, 9, 1, 1, true>));
         hipLaunchKernelGGL((ptile3_kernel<BN, 64, 9, 1, 1, true>), grid, dim3(512), lds, st, d, t, ntiles);
         xmc_note_kernel("ptile3_kernel<%d, 64, 9, 1, 1, true>", BN);
@@ -944,6 +947,7 @@ int launch_ptile(const XmcConvDesc& d, const TileCfg& t, hipStream_t st) {
     // + the tail's LeakyReLU
     XMC_PT3E(64, 0) XMC_PT3E(32, 0) XMC_PT3E(32, (kEpiGSum | kEpiPost) & ~kEpiBias) XMC_PT3E(64, (kEpiGSum | kEpiPost) & ~kEpiBias)
 #undef XMC_PT3E
+    xmc_note_generic_epi("ptile3<16x16>", epi9);
     if (t.slab == 64) {
         if (d.ntaps == 9) XMC_PT3(64, 9); else if (d.ntaps == 4) XMC_PT3(64, 4); else XMC_PT3(64, 0);
     } else {

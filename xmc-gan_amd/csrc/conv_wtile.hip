@@ -547,13 +547,17 @@ int launch(const XmcConvDesc& d, const WtCfg& t, hipStream_t st) {
         return 0;                                                                                                                              \
     }
     if constexpr (CW == 8 && NTAPS == 9 && TN == 8) {
-        XMC_W2_EPI(kEpiGSum) XMC_W2_EPI(kEpiDKeep) XMC_W2_EPI(kEpiDFwd) XMC_W2_EPI(kEpiDLast) XMC_W2_EPI(kEpiMask) XMC_W2_EPI(0)
+        XMC_W2_EPI(kEpiGSum) XMC_W2_EPI(kEpiDKeep) XMC_W2_EPI(kEpiDFwd) XMC_W2_EPI(kEpiDLast) XMC_W2_EPI(kEpiMask) XMC_W2_EPI(0) XMC_W2_EPI(kEpiDLin)
+        XMC_W2_EPI(kEpiBias) XMC_W2_EPI(kEpiBias | kEpiLrelu)            // the attention-modulation blocks' convolutions
+    } else if constexpr (CW == 8 && NTAPS == 9) {
+        XMC_W2_EPI(kEpiBias) XMC_W2_EPI(kEpiBias | kEpiLrelu) XMC_W2_EPI(0)
     } else if constexpr (CW == 8 && MODE == 1 && TN == 8) {
-        XMC_W2_EPI(kEpiLrelu)
+        XMC_W2_EPI(kEpiLrelu) XMC_W2_EPI(0) XMC_W2_EPI(kEpiMask)
     } else if constexpr (CW == 8 && NTAPS == 4 && MODE == 0) {
         XMC_W2_EPI(kEpiRes) XMC_W2_EPI(kEpiBias) XMC_W2_EPI(0)
     }
 #undef XMC_W2_EPI
+    xmc_note_generic_epi(NTAPS == 9 ? (TN == 8 ? "wtile2<9,0,8>" : "wtile2<9,0,4>") : MODE == 1 ? (TN == 8 ? "wtile2<4,1,8>" : "wtile2<4,1,4>") : "wtile2<4,0>", CW == 8 ? xmc_epi_mask(d) : -1);
     XMC_ALLOW_BIG_LDS((wtile2_kernel<NTAPS, MODE, TN, CW>));
     hipLaunchKernelGGL((wtile2_kernel<NTAPS, MODE, TN, CW>), dim3((unsigned)gx, (unsigned)ny, (unsigned)d.nclass), dim3(64 * CW + 256), lds, st, d, t,
                        ntiles);

@@ -559,13 +559,14 @@ int launch3(const XmcConvDesc& d, const W3Cfg& t, hipStream_t st) {
         return 0;                                                                                                                            \
     }
     if constexpr (NTAPS == 9) {
-        XMC_W3_EPI(kEpiGSum) XMC_W3_EPI(kEpiDKeep) XMC_W3_EPI(kEpiDFwd) XMC_W3_EPI(kEpiDLast) XMC_W3_EPI(kEpiMask) XMC_W3_EPI(0)
+        XMC_W3_EPI(kEpiGSum) XMC_W3_EPI(kEpiDKeep) XMC_W3_EPI(kEpiDFwd) XMC_W3_EPI(kEpiDLast) XMC_W3_EPI(kEpiMask) XMC_W3_EPI(0) XMC_W3_EPI(kEpiDLin)
     } else if constexpr (MODE == 1) {
-        XMC_W3_EPI(kEpiLrelu)
+        XMC_W3_EPI(kEpiLrelu) XMC_W3_EPI(0) XMC_W3_EPI(kEpiMask)       // forward; data gradient of the fused upsample conv; MA-GP's linearised forward
     } else {
         XMC_W3_EPI(kEpiRes) XMC_W3_EPI(kEpiBias) XMC_W3_EPI(0)
     }
 #undef XMC_W3_EPI
+    xmc_note_generic_epi(NTAPS == 9 ? "wtile3<9,0>" : MODE == 1 ? "wtile3<4,1>" : "wtile3<4,0>", epi);
     XMC_ALLOW_BIG_LDS((wtile3_kernel<NTAPS, MODE, WM>));
     hipLaunchKernelGGL((wtile3_kernel<NTAPS, MODE, WM>), dim3((unsigned)gx, (unsigned)ny, (unsigned)d.nclass), dim3(512), lds, st, d, t, ntiles);
     xmc_note_kernel("wtile3_kernel<%d, %d, %d>", NTAPS, MODE, WM);

@@ -801,6 +801,22 @@ void xmc_note_kernel(const char* fmt, ...) {
 }
 extern "C" const char* xmc_last_kernel(void) { return g_last_kernel; }
 
+// XMC_DEBUG_DISPATCH=log_generic_epi: one line on stderr per (kernel, epilogue option mask) that ran through a descriptor-reading
+// epilogue although its options are expressible as a mask -- the list of instantiations still worth adding (common.h: kEpi*)
+void xmc_note_generic_epi(const char* kernel, int mask) {
+    static const bool on = xmc_debug_off("log_generic_epi");
+    if (!on || mask < 0) return;
+    static char seen[64][96];
+    static int nseen = 0;
+    char key[96];
+    snprintf(key, sizeof key, "%s epi=%d", kernel, mask);
+    for (int i = 0; i < nseen; ++i)
+        if (!strcmp(seen[i], key)) return;
+    if (nseen < 64) strcpy(seen[nseen++], key);
+    fprintf(stderr, "[xmc] generic epilogue: %s (bias %d lrelu %d round %d dst2 %d alpha %d mask %d res %d post %d pool %d)\n", key, mask & 1, (mask >> 1) & 1,
+            (mask >> 2) & 1, (mask >> 3) & 1, (mask >> 4) & 1, (mask >> 5) & 1, (mask >> 6) & 1, (mask >> 7) & 1, (mask >> 8) & 1);
+}
+
 // One debugging switch for the kernel dispatchers: XMC_DEBUG_DISPATCH="tok1,tok2,..." disables the named specialised kernels
 // (the dispatcher then falls through to the next, more general one).  Unset in production: every call returns false.
 bool xmc_debug_off(const char* token) {
