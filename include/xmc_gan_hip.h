@@ -223,6 +223,10 @@ int xmc_gemm_group(const XmcGemmProblem* problems, int nproblems, void* stream);
  *   (gate rows i,f,g,o); w_hh [2,4H,H]; words [B,2H,T] (encoder.py:140: outputs transposed; zero at t >= len);
  *   sent [B,2H] = [h_fwd(len-1), h_rev(0)] (encoder.py:142-147).  H must be 128. */
 int xmc_embedding_gather(const int64_t* ids, const float* table, float* out, int64_t n_tokens, int dim, int64_t vocab, void* stream);
+/* xmc_gru_bidir: the same for nn.GRU (encoder.py:99-102, TEXT.RNN_TYPE 'GRU'): xproj [B,T,2,3H] = W_i* x + b_i* (+ b_h* for the r and z
+ * rows), w_hh [2,3H,H] (rows r, z, n), b_hn [2,H] (the candidate gate's hidden bias, which sits inside the product with r) */
+int xmc_gru_bidir(const float* xproj, const float* w_hh, const float* b_hn, const int32_t* lens, float* words, float* sent, int B, int T,
+                  int H, void* stream);
 int xmc_lstm_bidir(const float* xproj, const float* w_hh, const int32_t* lens, float* words, float* sent, int B, int T, int H,
                    void* stream);
 /* Spectral normalisation of a layer weight: the legacy torch.nn.utils.spectral_norm hook the reference's layer factories apply

@@ -230,7 +230,7 @@ def golden_rnn_encoder(name, yml, batch, seed, out_dir, **over):
     cfg = RH.load_cfg(yml, **over)
     M = RH.modules()
     enc = M.encoder.RNN_ENCODER(cfg)
-    shapes = X.rnn_encoder_shapes(cfg.TEXT.VOCA_SIZE, cfg.TEXT.EMBEDDING_DIM)
+    shapes = X.rnn_encoder_shapes(cfg.TEXT.VOCA_SIZE, cfg.TEXT.EMBEDDING_DIM, rnn_type=cfg.TEXT.RNN_TYPE)
     enc.load_state_dict(X.synth_rnn_params(shapes, seed), strict=True)
     enc.eval()
     caps, lens = X.synth_captions(batch, cfg.TEXT.MAX_LENGTH, cfg.TEXT.VOCA_SIZE, seed + 1)
@@ -289,6 +289,8 @@ def main():
     # frozen text front end: embedding + bidirectional LSTM over packed captions
     golden_rnn_encoder("enc_damsm", "df_gan_damsm.yml", 6, 41, a.out)
     golden_rnn_encoder("enc_len12", "df_gan_damsm.yml", 5, 42, a.out, **{"TEXT.MAX_LENGTH": 12, "TEXT.VOCA_SIZE": 500})
+    # the GRU branch of the same encoder (encoder.py:99-102; no shipped preset selects it)
+    golden_rnn_encoder("enc_gru", "df_gan_damsm.yml", 5, 43, a.out, **{"TEXT.RNN_TYPE": "GRU", "TEXT.VOCA_SIZE": 400})
 
 
 if __name__ == "__main__":

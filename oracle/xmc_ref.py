@@ -863,16 +863,17 @@ def cond_dnet(P, h: Hyper, feat, sent_embs):
 # contrastive head (train_gan.py:72-139)
 # ----------------------------------------------------------------------------------------
 # ------------------------------------------------------------------ frozen text front end (encoder.py:73-153)
-def rnn_encoder_shapes(voca_size: int, emb_dim: int = 256, ninput: int = 300) -> dict:
-    """state_dict of RNN_ENCODER: nn.Embedding(V, 300) + one-layer bidirectional nn.LSTM(300, emb_dim/2)
-    (encoder.py:75-104).  Gate rows are ordered i, f, g, o (torch.nn.LSTM)."""
+def rnn_encoder_shapes(voca_size: int, emb_dim: int = 256, ninput: int = 300, rnn_type: str = "LSTM") -> dict:
+    """state_dict of RNN_ENCODER: nn.Embedding(V, 300) + one-layer bidirectional nn.LSTM(300, emb_dim/2) or nn.GRU
+    (encoder.py:75-104).  Gate rows are ordered i, f, g, o (torch.nn.LSTM) / r, z, n (torch.nn.GRU)."""
     H = emb_dim // 2
+    G = {"LSTM": 4, "GRU": 3}[rnn_type]
     out = {"encoder.weight": (voca_size, ninput)}
     for sfx in ("", "_reverse"):
-        out[f"rnn.weight_ih_l0{sfx}"] = (4 * H, ninput)
-        out[f"rnn.weight_hh_l0{sfx}"] = (4 * H, H)
-        out[f"rnn.bias_ih_l0{sfx}"] = (4 * H,)
-        out[f"rnn.bias_hh_l0{sfx}"] = (4 * H,)
+        out[f"rnn.weight_ih_l0{sfx}"] = (G * H, ninput)
+        out[f"rnn.weight_hh_l0{sfx}"] = (G * H, H)
+        out[f"rnn.bias_ih_l0{sfx}"] = (G * H,)
+        out[f"rnn.bias_hh_l0{sfx}"] = (G * H,)
     return out
 
 
@@ -902,7 +903,8 @@ def synth_captions(batch: int, max_len: int, voca_size: int, seed: int = 0):
 
 
 def rnn_encoder(P, caps, cap_lens, n_steps: int):
-    """RNN_ENCODER.forward in eval mode (encoder.py:118-153; dropout is the identity, train_gan.py:468), LSTM only.
+    """RNN_ENCODER.forward in eval mode (encoder.py:118-153; dropout is the identity, train_gan.py:468); the cell type
+    (encoder.py:95-102) follows from the parameter shapes: 4H gate rows = nn.LSTM, 3H = nn.GRU.
 
     The reference sorts by length, packs, runs nn.LSTM and un-sorts; per sample that is: the forward direction runs
     t = 0..len-1, the reverse direction t = len-1..0, both from zero state; outputs at t >= len are zero
@@ -913,6 +915,25 @@ def rnn_encoder(P, caps, cap_lens, n_steps: int):
     emb = P["encoder.weight"][caps]                                     # [B, T, 300]
     words = torch.zeros(B, 2 * H, n_steps, dtype=emb.dtype)
     sent = torch.zeros(B, 2 * H, dtype=emb.dtype)
+    if P["rnn.weight_hh_l0"].shape[0] == 3 * H:
+        # nn.GRU (sentence embedding = the final hidden state, encoder.py:146-147):
+        #   r = s(W_ir x + b_ir + W_hr h + b_hr)   z = s(W_iz x + b_iz + W_hz h + b_hz)
+        #   n = tanh(W_in x + b_in + r * (W_hn h + b_hn))   h' = (1 - z) * n + z * h
+        for d, sfx in enumerate(("", "_reverse")):
+            w_ih, w_hh = P[f"rnn.weight_ih_l0{sfx}"], P[f"rnn.weight_hh_l0{sfx}"]
+            b_ih, b_hh = P[f"rnn.bias_ih_l0{sfx}"], P[f"rnn.bias_hh_l0{sfx}"]
+            for b in range(B):
+                n = int(cap_lens[b])
+                hcur = torch.zeros(H, dtype=emb.dtype)
+                for t in (range(n) if d == 0 else range(n - 1, -1, -1)):
+                    gi, gh = w_ih @ emb[b, t] + b_ih, w_hh @ hcur + b_hh
+                    r = torch.sigmoid(gi[:H] + gh[:H])
+                    z = torch.sigmoid(gi[H:2 * H] + gh[H:2 * H])
+                    cand = torch.tanh(gi[2 * H:] + r * gh[2 * H:])
+                    hcur = (1 - z) * cand + z * hcur
+                    words[b, d * H:(d + 1) * H, t] = hcur
+                sent[b, d * H:(d + 1) * H] = hcur
+        return words, sent, caps == 0
     for d, sfx in enumerate(("", "_reverse")):
         w_ih, w_hh = P[f"rnn.weight_ih_l0{sfx}"], P[f"rnn.weight_hh_l0{sfx}"]
         bias = P[f"rnn.bias_ih_l0{sfx}"] + P[f"rnn.bias_hh_l0{sfx}"]

@@ -45,6 +45,7 @@ def test_library_loads_and_exports_every_declared_symbol(variant):
     assert lib.xmc_embedding_gather(one, one, one, 4, 302, 10, None) == -2        # width not a multiple of 4 floats
     assert lib.xmc_embedding_gather(None, one, one, 4, 300, 10, None) == -1
     assert lib.xmc_lstm_bidir(one, one, one, one, one, 4, 20, 64, None) == -1     # only H = 128 is built
+    assert lib.xmc_gru_bidir(one, one, one, one, one, one, 4, 20, 64, None) == -1
     assert lib.xmc_spectral_sigma(None, one, one, one, one, None, 8, 8, 1, 1e-12, None) == -1
     assert lib.xmc_spectral_bwd(one, one, one, one, one, one, None, 8, 8, None) == -1
     assert lib.xmc_affine2_act_fwd(one, one, one, None, None, one, 1, 16, 12, 0.0, 0, None) == -2   # channels % 8
@@ -195,8 +196,13 @@ def test_text_encoder_classes_mirror_reference_state():
     enc.load_state_dict(ref.state_dict(), strict=True)
     with pytest.raises(RuntimeError):                    # no CPU fallback
         enc.eval()(torch.ones(2, cfg.TEXT.MAX_LENGTH, dtype=torch.int64), torch.tensor([3, 4]))
-    cfg.TEXT.RNN_TYPE = "GRU"
-    with pytest.raises(NotImplementedError):
+    cfg.TEXT.RNN_TYPE = "GRU"                            # encoder.py:99-102: the same container with an nn.GRU
+    gru = RNN_ENCODER(cfg)
+    ref_g = torch.nn.ModuleDict(dict(encoder=torch.nn.Embedding(cfg.TEXT.VOCA_SIZE, 300),
+                                     rnn=torch.nn.GRU(300, 128, 1, batch_first=True, bidirectional=True)))
+    gru.load_state_dict(ref_g.state_dict(), strict=True)
+    cfg.TEXT.RNN_TYPE = "RNN_TANH"
+    with pytest.raises(NotImplementedError):             # encoder.py:103
         RNN_ENCODER(cfg)
     with pytest.raises(ImportError):
         SBERT_ENCODER(cfg)

@@ -329,7 +329,7 @@ def test_checkpoint_resume_matches_uninterrupted_run(tmp_path):
         assert rel_err(q, p) < 1e-4, n
 
 
-@pytest.mark.parametrize("name", ["rnn_enc_damsm.npz", "rnn_enc_len12.npz"])
+@pytest.mark.parametrize("name", ["rnn_enc_damsm.npz", "rnn_enc_len12.npz", "rnn_enc_gru.npz"])
 def test_rnn_encoder_matches_reference_golden(name):
     """RNN_ENCODER on the HIP kernels vs the reference's own outputs (tests/golden/rnn_*.npz, made by
     oracle/make_golden.py from encoder.py:73-153 on CPU).  f32 throughout: 1e-4 relative / 2e-5 absolute; the mask is exact."""
@@ -337,10 +337,10 @@ def test_rnn_encoder_matches_reference_golden(name):
     from golden_util import load
     from xmc_gan.model.encoder import RNN_ENCODER
     fx = load(name)
-    over = {k: int(v) for k, v in (kv.split("=") for kv in map(str, fx["over"]))}
+    over = {k: (int(v) if v.lstrip("-").isdigit() else v) for k, v in (kv.split("=") for kv in map(str, fx["over"]))}
     cfg, _ = setup_cfg(str(fx["yml"]), **over)
     enc = RNN_ENCODER(cfg)
-    shapes = X.rnn_encoder_shapes(cfg.TEXT.VOCA_SIZE, cfg.TEXT.EMBEDDING_DIM)
+    shapes = X.rnn_encoder_shapes(cfg.TEXT.VOCA_SIZE, cfg.TEXT.EMBEDDING_DIM, rnn_type=cfg.TEXT.RNN_TYPE)
     assert {k: tuple(v.shape) for k, v in enc.state_dict().items()} == shapes
     enc.load_state_dict(X.synth_rnn_params(shapes, int(fx["seed"])), strict=True)
     enc = enc.to(DEV).eval()
@@ -378,6 +378,38 @@ def test_rnn_encoder_matches_oracle_at_batch(batch):
     bad[0, 0] = V
     with pytest.raises(IndexError):
         enc(bad, lens)
+
+
+@pytest.mark.parametrize("batch", [5, 256])
+def test_gru_encoder_matches_oracle_and_torch(batch):
+    """TEXT.RNN_TYPE 'GRU' (encoder.py:99-102): the HIP recurrence against the CPU oracle, and the oracle itself against the
+    module the reference calls -- torch.nn.GRU over pack_padded_sequence / pad_packed_sequence, sorted and un-sorted as in
+    encoder.py:121-151."""
+    from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
+    from xmc_gan.model.encoder import RNN_ENCODER
+    cfg, _ = setup_cfg("df_gan_damsm.yml", **{"TEXT.VOCA_SIZE": 500, "TEXT.RNN_TYPE": "GRU"})
+    T, V = cfg.TEXT.MAX_LENGTH, cfg.TEXT.VOCA_SIZE
+    shapes = X.rnn_encoder_shapes(V, cfg.TEXT.EMBEDDING_DIM, rnn_type="GRU")
+    P = X.synth_rnn_params(shapes, 4)
+    caps, lens = X.synth_captions(batch, T, V, seed=batch + 1)
+    w_o, s_o, m_o = X.rnn_encoder(P, caps, lens, T)
+    enc = RNN_ENCODER(cfg)
+    assert {k: tuple(v.shape) for k, v in enc.state_dict().items()} == shapes
+    enc.load_state_dict(P, strict=True)
+    # the reference's own sequence of calls on CPU
+    with torch.no_grad():
+        ref = enc.rnn
+        sl, si = lens.sort(descending=True)
+        emb = torch.nn.functional.embedding(caps[si], P["encoder.weight"])
+        out, hid = ref(pack_padded_sequence(emb, sl.tolist(), batch_first=True))
+        out = pad_packed_sequence(out, batch_first=True, total_length=T)[0].transpose(1, 2)[si.argsort()]
+        hid = hid.transpose(0, 1).contiguous().view(-1, cfg.TEXT.EMBEDDING_DIM)[si.argsort()]
+    assert rel_err(w_o, out) < 1e-5 and rel_err(s_o, hid) < 1e-5
+    enc = enc.to(DEV).eval()
+    w, s, m = enc(caps, lens)
+    assert torch.equal(m.cpu(), m_o)
+    assert rel_err(w, w_o) < 1e-5 and rel_err(s, s_o) < 1e-5
+    assert (w.cpu() - w_o).abs().max().item() < 2e-5
 
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])

@@ -56,7 +56,7 @@ def test_rnn_encoder_matches_reference(name):
     over = dict(kv.split("=") for kv in map(str, fx["over"]))
     T = int(over.get("TEXT.MAX_LENGTH", 20))
     V = int(over.get("TEXT.VOCA_SIZE", 27297))
-    shapes = X.rnn_encoder_shapes(V, 256)
+    shapes = X.rnn_encoder_shapes(V, 256, rnn_type=over.get("TEXT.RNN_TYPE", "LSTM"))
     tab = lambda s: sorted(f"{k}:{','.join(map(str, v))}" for k, v in s.items())
     assert tab(shapes) == sorted(map(str, fx["keys"]))
     P = X.synth_rnn_params(shapes, int(fx["seed"]))

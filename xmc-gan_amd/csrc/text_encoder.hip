@@ -112,6 +112,96 @@ __global__ __launch_bounds__(LG) void lstm_bidir_kernel(const float* __restrict_
     }
 }
 
+// nn.GRU (encoder.py:99-102: TEXT.RNN_TYPE 'GRU'), same launch geometry and data layout as the LSTM kernel with three gate rows
+// (r, z, n in torch.nn.GRU's order):   r = s(x_r + W_hr h)   z = s(x_z + W_hz h)   n = tanh(x_n + r * (W_hn h + b_hn))
+//                                      h' = (1 - z) * n + z * h
+// xproj holds W_i* x + b_i* (+ b_h* for r and z, which commute with the sum); b_hn sits INSIDE the product with r and is a
+// separate argument.
+constexpr int GG = 3 * LH;
+
+template <int NB>
+__global__ __launch_bounds__(GG) void gru_bidir_kernel(const float* __restrict__ xproj, const float* __restrict__ w_hh,
+                                                       const float* __restrict__ b_hn, const int32_t* __restrict__ lens,
+                                                       float* __restrict__ words, float* __restrict__ sent, int B, int T) {
+    extern __shared__ float hist[];                     // [NB][T][LH] outputs of this direction
+    __shared__ __attribute__((aligned(16))) float h_s[NB][LH];
+    __shared__ float gh_s[NB][GG];                      // r, z: x + W h (pre-activation); n: W_hn h + b_hn
+    __shared__ float gx_s[NB][LH];                      // x part of the candidate gate
+    const int j = threadIdx.x, dir = blockIdx.y, b0 = blockIdx.x * NB;
+
+    float w[LH];
+    {
+        const f32x4* wr = reinterpret_cast<const f32x4*>(w_hh + ((size_t)dir * GG + j) * LH);
+#pragma unroll
+        for (int k = 0; k < LH / 4; ++k) {
+            const f32x4 v = wr[k];
+            w[4 * k] = v[0], w[4 * k + 1] = v[1], w[4 * k + 2] = v[2], w[4 * k + 3] = v[3];
+        }
+    }
+    const float bn = j >= 2 * LH ? b_hn[dir * LH + (j - 2 * LH)] : 0.f;
+    int len[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int b = b0 + nb;
+        len[nb] = b < B ? min(max(lens[b], 0), T) : 0;
+    }
+    for (int i = j; i < NB * LH; i += GG) (&h_s[0][0])[i] = 0.f;
+    for (int i = j; i < NB * T * LH; i += GG) hist[i] = 0.f;
+    __syncthreads();
+
+    auto xin = [&](int nb, int step) -> float {
+        const int t = dir == 0 ? step : len[nb] - 1 - step;
+        return step < len[nb] ? xproj[(((size_t)(b0 + nb) * T + t) * 2 + dir) * GG + j] : 0.f;
+    };
+    float xnext[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) xnext[nb] = xin(nb, 0);
+
+    for (int step = 0; step < T; ++step) {
+        float acc[NB], xcur[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            xcur[nb] = xnext[nb];
+            acc[nb] = 0.f;
+            xnext[nb] = xin(nb, step + 1);
+        }
+#pragma unroll
+        for (int k = 0; k < LH; k += 4) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const f32x4 hv = *reinterpret_cast<const f32x4*>(&h_s[nb][k]);
+                acc[nb] += w[k] * hv[0] + w[k + 1] * hv[1] + w[k + 2] * hv[2] + w[k + 3] * hv[3];
+            }
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            if (j < 2 * LH) gh_s[nb][j] = acc[nb] + xcur[nb];
+            else { gh_s[nb][j] = acc[nb] + bn; gx_s[nb][j - 2 * LH] = xcur[nb]; }
+        }
+        __syncthreads();
+        if (j < NB * LH) {
+            const int nb = j / LH, u = j % LH;
+            if (step < len[nb]) {
+                const int t = dir == 0 ? step : len[nb] - 1 - step;
+                const float rg = sigmoid_f(gh_s[nb][u]), zg = sigmoid_f(gh_s[nb][LH + u]);
+                const float ng = tanhf(gx_s[nb][u] + rg * gh_s[nb][2 * LH + u]);
+                const float h = (1.f - zg) * ng + zg * h_s[nb][u];
+                h_s[nb][u] = h;
+                hist[((size_t)nb * T + t) * LH + u] = h;
+            }
+        }
+        __syncthreads();
+    }
+    if (j < NB * LH) {
+        const int nb = j / LH, u = j % LH, b = b0 + nb;
+        if (b < B) {
+            sent[(size_t)b * 2 * LH + dir * LH + u] = h_s[nb][u];
+            float* row = words + ((size_t)b * 2 * LH + dir * LH + u) * T;
+            for (int t = 0; t < T; ++t) row[t] = hist[((size_t)nb * T + t) * LH + u];
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int xmc_embedding_gather(const int64_t* ids, const float* table, float* out, int64_t n_tokens, int dim, int64_t vocab,
@@ -142,6 +232,25 @@ extern "C" int xmc_lstm_bidir(const float* xproj, const float* w_hh, const int32
     } else {
         XMC_ALLOW_BIG_LDS(lstm_bidir_kernel<1>);
         hipLaunchKernelGGL(lstm_bidir_kernel<1>, grid, blk, lds, (hipStream_t)stream, xproj, w_hh, lens, words, sent, B, T);
+    }
+    XMC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int xmc_gru_bidir(const float* xproj, const float* w_hh, const float* b_hn, const int32_t* lens, float* words, float* sent,
+                             int B, int T, int H, void* stream) {
+    if (!xproj || !w_hh || !b_hn || !lens || !words || !sent || B <= 0 || T <= 0) return XMC_EINVAL;
+    if (H != LH) return XMC_EINVAL;                     // TEXT.EMBEDDING_DIM 256, as for the LSTM
+    const int NB = B >= 256 ? 2 : 1;
+    const size_t lds = (size_t)NB * T * LH * sizeof(float);
+    if (lds > 96 * 1024) return XMC_EINVAL;
+    dim3 grid((B + NB - 1) / NB, 2), blk(GG);
+    if (NB == 2) {
+        XMC_ALLOW_BIG_LDS(gru_bidir_kernel<2>);
+        hipLaunchKernelGGL(gru_bidir_kernel<2>, grid, blk, lds, (hipStream_t)stream, xproj, w_hh, b_hn, lens, words, sent, B, T);
+    } else {
+        XMC_ALLOW_BIG_LDS(gru_bidir_kernel<1>);
+        hipLaunchKernelGGL(gru_bidir_kernel<1>, grid, blk, lds, (hipStream_t)stream, xproj, w_hh, b_hn, lens, words, sent, B, T);
     }
     XMC_LAUNCH_CHECK();
     return 0;

@@ -82,6 +82,7 @@ _SIGS = {
     "xmc_gemm_group": [vp, i32, vp],
     "xmc_embedding_gather": [vp, vp, vp, i64, i32, i64, vp],
     "xmc_lstm_bidir": [vp, vp, vp, vp, vp, i32, i32, i32, vp],
+    "xmc_gru_bidir": [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "xmc_spectral_sigma": [vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp],
     "xmc_spectral_bwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
     "xmc_colsum": [vp, vp, i64, i32, i32, vp],

@@ -1134,6 +1134,23 @@ def lstm_bidir(xproj, w_hh, lens, T):
     return words, sent
 
 
+def gru_bidir(xproj, w_hh, b_hn, lens, T):
+    """One-layer bidirectional GRU recurrence over length-packed sequences (encoder.py:99-102,134-147 with RNN_TYPE 'GRU'),
+    forward only.  xproj f32 [B,T,2,3H] (W_i* x + b_i*, plus b_h* for the r and z rows), w_hh f32 [2,3H,H], b_hn f32 [2,H],
+    lens int32 [B].  Returns words [B,2H,T] (zero at t >= len) and sent [B,2H] = [h_fwd(len-1), h_rev(0)]."""
+    if not xproj.is_cuda:
+        raise RuntimeError("xmc_gan_amd.ops.gru_bidir: CPU tensors are not supported (no CPU fallback)")
+    B, H = xproj.shape[0], w_hh.shape[2]
+    assert xproj.dtype == torch.float32 and xproj.is_contiguous() and xproj.shape == (B, T, 2, 3 * H)
+    assert w_hh.dtype == torch.float32 and w_hh.is_contiguous() and w_hh.shape == (2, 3 * H, H)
+    assert b_hn.dtype == torch.float32 and b_hn.is_contiguous() and b_hn.shape == (2, H)
+    assert lens.dtype == torch.int32 and lens.is_contiguous() and lens.numel() == B
+    words = torch.empty(B, 2 * H, T, dtype=torch.float32, device=xproj.device)
+    sent = torch.empty(B, 2 * H, dtype=torch.float32, device=xproj.device)
+    L.call("xmc_gru_bidir", _p(xproj), _p(w_hh), _p(b_hn), _p(lens), _p(words), _p(sent), B, T, H, _st())
+    return words, sent
+
+
 class SpectralNormFn(torch.autograd.Function):
     """W / sigma(W) as the legacy ``torch.nn.utils.spectral_norm`` hook computes it (reference model/modules.py:3,16-17,
     31-32): in training mode ONE power iteration updates ``u`` [R] / ``v`` [C] in place (v <- normalize(W^T u),

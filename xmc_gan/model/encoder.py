@@ -27,20 +27,23 @@ class RNN_ENCODER(nn.Module):
         self.rnn_type = cfg.TEXT.RNN_TYPE
         self.num_directions = 2
         self.nhidden = cfg.TEXT.EMBEDDING_DIM // self.num_directions
-        if self.rnn_type != 'LSTM':
-            # upstream also offers nn.GRU (encoder.py:99-102); every shipped RNN preset sets RNN_TYPE: 'LSTM'
-            raise NotImplementedError(f"TEXT.RNN_TYPE={self.rnn_type!r}: only the LSTM encoder is built")
+        if self.rnn_type not in ('LSTM', 'GRU'):
+            raise NotImplementedError(f"TEXT.RNN_TYPE={self.rnn_type!r} (encoder.py:103)")
+        self.ngates = 4 if self.rnn_type == 'LSTM' else 3
         self.encoder = nn.Embedding(self.ntoken, self.ninput)
         self.drop = nn.Dropout(self.drop_prob)
         # dropout= is a no-op for a single layer; left out to spare the construction-time warning (same parameters)
-        self.rnn = nn.LSTM(self.ninput, self.nhidden, self.nlayers, batch_first=True, bidirectional=True)
+        rnn = nn.LSTM if self.rnn_type == 'LSTM' else nn.GRU               # encoder.py:95-102
+        self.rnn = rnn(self.ninput, self.nhidden, self.nlayers, batch_first=True, bidirectional=True)
         self.encoder.weight.data.uniform_(-0.1, 0.1)                       # _init_weights (encoder.py:106-108)
-        self.geom = ops.ConvGeom(self.ninput, 2 * 4 * self.nhidden, 1, 1, 0)
+        self.geom = ops.ConvGeom(self.ninput, 2 * self.ngates * self.nhidden, 1, 1, 0)
         self._packed = None
 
     def _weights(self):
-        """[W_ih_fwd; W_ih_rev] (2*4H, 300), summed biases (2*4H), [W_hh_fwd, W_hh_rev] (2, 4H, H); rebuilt when a
-        parameter changes (load_state_dict, .to())."""
+        """[W_ih_fwd; W_ih_rev] (2*G*H, 300), input-side biases (2*G*H), [W_hh_fwd, W_hh_rev] (2, G*H, H) [, GRU: b_hn (2, H)];
+        G = 4 gate rows (LSTM) or 3 (GRU); rebuilt when a parameter changes (load_state_dict, .to()).
+        LSTM: the two bias vectors add up front.  GRU: b_hh of the r and z rows likewise, but the candidate gate is
+        tanh(W_in x + b_in + r * (W_hn h + b_hn)), so its hidden bias stays with the recurrence."""
         r = self.rnn
         ps = (r.weight_ih_l0, r.weight_ih_l0_reverse, r.weight_hh_l0, r.weight_hh_l0_reverse,
               r.bias_ih_l0, r.bias_ih_l0_reverse, r.bias_hh_l0, r.bias_hh_l0_reverse)
@@ -48,9 +51,16 @@ class RNN_ENCODER(nn.Module):
         if self._packed is None or self._packed[0] != key:
             with torch.no_grad():
                 w_ih = torch.cat((ps[0], ps[1]), 0).float().contiguous()
-                bias = torch.cat((ps[4] + ps[6], ps[5] + ps[7]), 0).float().contiguous()
                 w_hh = torch.stack((ps[2], ps[3]), 0).float().contiguous()
-            self._packed = (key, w_ih, bias, w_hh)
+                if self.rnn_type == 'LSTM':
+                    bias = torch.cat((ps[4] + ps[6], ps[5] + ps[7]), 0).float().contiguous()
+                    extra = ()
+                else:
+                    H = self.nhidden
+                    keep = torch.cat((torch.ones(2 * H), torch.zeros(H))).to(ps[6])            # b_hr, b_hz join; b_hn does not
+                    bias = torch.cat((ps[4] + ps[6] * keep, ps[5] + ps[7] * keep), 0).float().contiguous()
+                    extra = (torch.stack((ps[6][2 * H:], ps[7][2 * H:]), 0).float().contiguous(),)
+            self._packed = (key, w_ih, bias, w_hh) + extra
         return self._packed[1:]
 
     def forward(self, caps, cap_lens, **kwargs):
@@ -70,11 +80,15 @@ class RNN_ENCODER(nn.Module):
                 raise IndexError("token id outside [0, TEXT.VOCA_SIZE)")
         caps = caps.to(dev, torch.int64, non_blocking=True)
         lens = cap_lens.to(dev, torch.int32, non_blocking=True).contiguous()
-        w_ih, bias, w_hh = self._weights()
+        w_ih, bias, w_hh, *extra = self._weights()
         B, T = caps.shape
         emb = ops.embedding(caps, self.encoder.weight)                                     # [B, T, 300]
         xproj = ops.linear(emb.view(B * T, self.ninput), w_ih, bias, self.geom, out_dtype=torch.float32)
-        words_embs, sent_embs = ops.lstm_bidir(xproj.view(B, T, 2, 4 * self.nhidden), w_hh, lens, T)
+        xproj = xproj.view(B, T, 2, self.ngates * self.nhidden)
+        if self.rnn_type == 'LSTM':
+            words_embs, sent_embs = ops.lstm_bidir(xproj, w_hh, lens, T)
+        else:
+            words_embs, sent_embs = ops.gru_bidir(xproj, w_hh, extra[0], lens, T)
         mask = (caps == 0)
         return words_embs, sent_embs, mask
 
