@@ -26,7 +26,7 @@ extern "C" {
 
 /* 2: XmcConvDesc gained dst2 / dst_pool / round_act / groups, alpha applies only with alpha_dev, return codes are
  *    0 / XMC_E* / -(1000 + hipError_t); xmc_half_format() added.  lib.py refuses a library of another version. */
-#define XMC_ABI_VERSION 3
+#define XMC_ABI_VERSION 4
 
 /* XMC_BF16 names the 16-bit storage / MFMA-operand format THIS BUILD of the library was compiled for: bf16 in
  * libxmc_gan_hip.so, IEEE half in libxmc_gan_hip_f16.so (same sources, same entry points; xmc_half_format()). */
@@ -105,6 +105,13 @@ typedef struct XmcConvDesc {
      * of a nearest x2 upsample (sum pool), the gradient of the half-resolution shortcut of a generator block. */
     int32_t post_act;
     float pool_scale;
+    /* sign_bits (uint8 [N, DH, DW, CD/8], dst pixel order): bit r of byte u of a pixel = (act(acc + bias) > 0) for channel 8u + r -- all a
+     *             backward pass needs of a LeakyReLU'd residual branch (its mask); replaces dst2 there at 1/16 of the bytes.
+     * dot       : f32 device scalar; *dot += sum over the launch of (acc + bias)[e] * mask[e] (the value BEFORE alpha / mask, times the mask
+     *             tensor's VALUE): with mask = the input h1 of the layer whose data gradient this is and src = dout * LeakyReLU'(branch),
+     *             that is <dout, branch> = d(gamma) of `shortcut + gamma * branch` (df_gan.py:284) without the branch tensor. */
+    void* sign_bits;
+    float* dot;
 } XmcConvDesc;
 
 int xmc_abi_version(void);
@@ -182,6 +189,8 @@ int xmc_lrelu(const void* x, void* y, int64_t n, float slope, int dtype, void* s
 int xmc_lrelu_mask(const void* dy, const void* ref, void* dx, int64_t n, float slope, int dtype, void* stream);
 /* y = tanh(x) ; dx = dy * (1 - y^2)         (nn.Tanh df_gan.py:87) */
 int xmc_tanh(const void* x, void* y, int64_t n, int dtype, void* stream);
+/* dx = dy * LeakyReLU'(branch), the branch given as sign bits (XmcConvDesc.sign_bits layout: byte i = the 8 elements 8i .. 8i+7) */
+int xmc_signmask_apply(const void* dy, const void* bits, void* dx, int64_t n, float slope, int dtype, void* stream);
 int xmc_tanh_bwd(const void* dy, const void* y, void* dx, int64_t n, int dtype, void* stream);
 /* y = a + (*alpha_dev) * b                  (shortcut + gamma*residual, df_gan.py:200,284) */
 int xmc_axpby(const void* a, const void* b, const float* alpha_dev, void* y, int64_t n, int dtype, void* stream);

@@ -29,12 +29,12 @@ def test_library_loads_and_exports_every_declared_symbol(variant):
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/xmc_gan_hip.h but not exported"
     assert set(L.EXPORTS) == declared
-    assert lib.xmc_abi_version() == L.ABI_VERSION == 3
+    assert lib.xmc_abi_version() == L.ABI_VERSION == 4
     # argument validation happens before any launch, so it is safe without a GPU
     d = L.ConvDesc()
     assert lib.xmc_conv_igemm(ctypes.byref(d), None) == -1
     assert lib.xmc_conv_wgrad(ctypes.byref(d), None, None) == -1
-    assert ctypes.sizeof(L.ConvDesc) == 368 and ctypes.sizeof(L.AdamEntry) == 48 and ctypes.sizeof(L.PackJob) == 64   # = the C structs
+    assert ctypes.sizeof(L.ConvDesc) == 384 and ctypes.sizeof(L.AdamEntry) == 48 and ctypes.sizeof(L.PackJob) == 64   # = the C structs
     # the entry points added for the callers either side of the step reject bad arguments the same way (nothing launched)
     import numpy as np
     assert np.dtype(L.GEMM_PROBLEM).itemsize == 88                    # sizeof(XmcGemmProblem)
@@ -46,6 +46,7 @@ def test_library_loads_and_exports_every_declared_symbol(variant):
     assert lib.xmc_embedding_gather(None, one, one, 4, 300, 10, None) == -1
     assert lib.xmc_lstm_bidir(one, one, one, one, one, 4, 20, 64, None) == -1     # only H = 128 is built
     assert lib.xmc_gru_bidir(one, one, one, one, one, one, 4, 20, 64, None) == -1
+    assert lib.xmc_signmask_apply(one, None, one, 64, 0.2, 0, None) == -1 and lib.xmc_signmask_apply(one, one, one, 12, 0.2, 0, None) == -2
     assert lib.xmc_spectral_sigma(None, one, one, one, one, None, 8, 8, 1, 1e-12, None) == -1
     assert lib.xmc_spectral_bwd(one, one, one, one, one, one, None, 8, 8, None) == -1
     assert lib.xmc_affine2_act_fwd(one, one, one, None, None, one, 1, 16, 12, 0.0, 0, None) == -2   # channels % 8

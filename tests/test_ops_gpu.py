@@ -446,22 +446,22 @@ def test_fused_discriminator_block_equals_composed_block(cin, cout, H, mode):
     x0 = torch.randn(3, H, H, ops.chan_pad(cin, dt), device=DEV).to(dt)
     r = torch.randn(3, H // 2, H // 2, ops.pad_to(cout, 8), device=DEV).to(dt)
     got = {}
-    for name in ("fused", "composed"):
+    # "fused": the block keeps the SIGN BITS of its residual branch (XmcConvDesc.sign_bits) and gets d(gamma) from the dot in the
+    # data-gradient epilogue; "fused_values": the branch tensor itself (what ops.second_order() selects for MA-GP)
+    for name in ("fused", "fused_values", "composed"):
         blk.zero_grad()
         x = x0.clone().requires_grad_()
-        if name == "fused":
+        with (ops.composable() if name == "composed" else ops.second_order(name == "fused_values")):
             y = blk(x)
-        else:
-            with ops.composable():
-                y = blk(x)
         (y.float() * r.float()).sum().backward()
         got[name] = [y.detach().float(), x.grad.float()] + [p.grad.clone() if p.grad is not None else None for p in blk.parameters()]
     names = ["y", "dx"] + [n for n, _ in blk.named_parameters()]
-    for n, a, b in zip(names, got["fused"], got["composed"]):
-        assert (a is None) == (b is None), n
+    for n, a, b, c in zip(names, got["fused"], got["composed"], got["fused_values"]):
+        assert (a is None) == (b is None) == (c is None), n
         if a is None:
             continue
         sc = b.abs().max().item() + 1e-12
+        torch.testing.assert_close(c, b, rtol=2e-2 if mode == "bf16" else 1e-4, atol=(2e-2 if mode == "bf16" else 1e-4) * sc, msg=lambda m: f"{n} (values): {m}")
         # bf16: the composed path rounds dx of each branch to bf16 before adding them, the fused path adds in f32
         torch.testing.assert_close(a, b, rtol=2e-2 if mode == "bf16" else 1e-4, atol=(2e-2 if mode == "bf16" else 1e-4) * sc, msg=lambda m: f"{n}: {m}")
 
@@ -487,7 +487,7 @@ def test_fused_discriminator_block_double_backward_equals_composed_block(cin, co
         blk.zero_grad()
         x = x0.clone().requires_grad_()
         r = r0.clone().requires_grad_()
-        with (ops.composable() if name == "composed" else _null()):
+        with (ops.composable() if name == "composed" else ops.second_order()):
             y = blk(x)
         with ops.no_wgrad():
             g, = torch.autograd.grad(y, x, grad_outputs=r, create_graph=True)
@@ -501,6 +501,63 @@ def test_fused_discriminator_block_double_backward_equals_composed_block(cin, co
             continue
         sc = b.abs().max().item() + 1e-12
         torch.testing.assert_close(a, b, rtol=3e-2 if mode == "bf16" else 2e-4, atol=(3e-2 if mode == "bf16" else 2e-4) * sc, msg=lambda m: f"{n}: {m}")
+
+
+@pytest.mark.parametrize("N,H,C", [(2, 16, 64), (8, 32, 256), (4, 64, 128), (16, 16, 512), (2, 128, 64), (3, 24, 40), (64, 32, 256), (32, 32, 512)])
+def test_conv_sign_bits_and_gradient_dot_against_the_stored_branch(N, H, C):
+    """XmcConvDesc.sign_bits / .dot (include/xmc_gan_hip.h), the two epilogue options a discriminator block's first-order backward
+    runs on: the bits must be exactly `branch > 0` of the branch the kernel would otherwise store, the block output must not change
+    by a bit, and the dot must equal <C2^T g, h1> of the unmasked data gradient.  Shapes pick different kernels (thin / weights-
+    resident / streamed-weights tiles); the names are printed with -s."""
+    ops.set_precision("bf16")
+    dt = ops.act_dtype()
+    g = torch.Generator(device="cpu").manual_seed(N * 1000 + H + C)
+    Cp = ops.pad_to(C, 8)
+    h1 = torch.nn.functional.leaky_relu(torch.randn(N, H, H, Cp, generator=g), 0.2).to(DEV).to(dt)
+    sc = torch.randn(N, H, H, Cp, generator=g).to(DEV).to(dt)
+    w2 = (torch.randn(C, C, 3, 3, generator=g) * (2.0 / (9 * C)) ** 0.5).to(DEV)
+    if Cp != C:
+        h1[..., C:] = 0
+        sc[..., C:] = 0
+    al = torch.tensor([0.63], device=DEV)
+    g2 = ops.ConvGeom(C, C, 3, 1, 1)
+    pool = H % 2 == 0
+    out_v, branch, *pv = ops._conv_fwd_raw(h1, w2, None, g2, L.ACT_LRELU, dt, res=sc, alpha=al, want2=True, want_pool=pool, round_act=True)
+    k_v = L.load().xmc_last_kernel().decode()
+    out_s, bits, *ps = ops._conv_fwd_raw(h1, w2, None, g2, L.ACT_LRELU, dt, res=sc, alpha=al, want_sign=True, want_pool=pool, round_act=True)
+    k_s = L.load().xmc_last_kernel().decode()
+    print(f"forward: {k_v} / {k_s}")
+    assert torch.equal(out_v, out_s) and (not pool or torch.equal(pv[0], ps[0]))
+    assert bits.dtype == torch.uint8 and tuple(bits.shape) == (N, H, H, Cp // 8)
+    want = ((branch.float() > 0).view(N, H, H, Cp // 8, 8).to(torch.int32) << torch.arange(8, device=DEV, dtype=torch.int32)).sum(-1)
+    assert torch.equal(bits.to(torch.int32), want)
+    # the mask pass from the bits == the mask pass from the branch values
+    dout = torch.randn(N, H, H, Cp, generator=g).to(DEV).to(dt)
+    gr_s = torch.empty_like(dout)
+    L.call("xmc_signmask_apply", dout.data_ptr(), bits.data_ptr(), gr_s.data_ptr(), dout.numel(), 0.2, ops._code(dt), ops._st())
+    gr_v = torch.where(branch.float() > 0, dout.float(), 0.2 * dout.float()).to(dt)
+    assert torch.equal(gr_s, gr_v)
+    # data gradient with gamma and the dot in its epilogue
+    u = ops._conv_dgrad_raw(gr_s, w2, g2, (H, H), dt)                                  # C2^T g, unmasked, rounded to bf16
+    ref = ops._conv_dgrad_raw(gr_s, w2, g2, (H, H), dt, mask=h1, alpha=al)
+    dgam = torch.zeros(1, device=DEV)
+    got = ops._conv_dgrad_raw(gr_s, w2, g2, (H, H), dt, mask=h1, alpha=al, dot=dgam)
+    print(f"data gradient: {L.load().xmc_last_kernel().decode()}")
+    assert torch.equal(got, ref)
+    want_dot = (u.double() * h1.double()).sum().item()
+    scale = (u.double() * h1.double()).abs().sum().item()
+    assert abs(dgam.item() - want_dot) <= 2e-3 * scale / (u.numel() ** 0.5) * 30 + 1e-6 * scale, (dgam.item(), want_dot, scale)
+
+
+def test_fused_discriminator_block_refuses_second_derivative_without_the_branch():
+    """A block that kept only sign bits cannot be differentiated twice: it says so instead of returning a wrong penalty."""
+    from xmc_gan.model.df_gan import resD
+    ops.set_precision("bf16")
+    blk = resD(32, 64, downsample=True).to(DEV)
+    x = torch.randn(2, 16, 16, 32, device=DEV).to(ops.act_dtype()).requires_grad_()
+    y = blk(x)
+    with pytest.raises(RuntimeError, match="second_order"):
+        torch.autograd.grad(y.float().sum(), x, create_graph=True)
 
 
 class _null:

@@ -123,20 +123,33 @@ __device__ __forceinline__ float wave_max(float v) {
 
 // Shared tail of the convolution epilogues: second output, alpha, LeakyReLU' mask, (scaled, possibly re-indexed) residual, store.
 // v holds act(acc + bias).
+// (sign_bits / dot: see XmcConvDesc; `dacc` is the caller's running sum for dot, reduced and added once per workgroup)
 template <int ODT>
-__device__ __forceinline__ void epilogue_tail(const XmcConvDesc& d, size_t idx8, size_t ridx8, float (&v)[8], float alpha) {
+__device__ __forceinline__ void epilogue_tail(const XmcConvDesc& d, size_t idx8, size_t ridx8, float (&v)[8], float alpha, float* dacc = nullptr) {
+    if (d.sign_bits) {
+        unsigned b = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) b |= (v[k] > 0.f ? 1u : 0u) << k;
+        reinterpret_cast<unsigned char*>(d.sign_bits)[idx8] = (unsigned char)b;
+    }
     if (d.dst2) Vec8<ODT>::store(d.dst2, idx8, v);
     if (ODT == XMC_BF16 && (d.dst2 || d.round_act)) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] = (float)(xmc_h16)v[k];
+    }
+    float mk[8];
+    if (d.mask) {
+        Vec8<ODT>::load(d.mask, idx8, mk);
+        if (d.dot && dacc) {                       // before alpha: gamma = 0 must not lose d(gamma)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) *dacc += v[k] * mk[k];
+        }
     }
     if (d.alpha_dev) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] *= alpha;
     }
     if (d.mask) {
-        float mk[8];
-        Vec8<ODT>::load(d.mask, idx8, mk);
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] *= lrelu_slope(mk[k]);
     }
@@ -158,18 +171,22 @@ __device__ __forceinline__ void epilogue_tail(const XmcConvDesc& d, size_t idx8,
 // A convolution epilogue is several hundred VALU instructions per wave and tile; with every option a run-time branch per 8-channel
 // unit the weights-resident kernel measured 0.535 ms where the same launch with its options folded takes 0.450 (conv_tile.hip), so
 // the option sets that occur in the training step get an instantiation each and everything else goes through the generic one.
-constexpr int kEpiBias = 1, kEpiLrelu = 2, kEpiRound = 4, kEpiDst2 = 8, kEpiAlpha = 16, kEpiMask = 32, kEpiRes = 64, kEpiPost = 128, kEpiPool = 256;
+constexpr int kEpiBias = 1, kEpiLrelu = 2, kEpiRound = 4, kEpiDst2 = 8, kEpiAlpha = 16, kEpiMask = 32, kEpiRes = 64, kEpiPost = 128, kEpiPool = 256,
+              kEpiSign = 512, kEpiDot = 1024;
 constexpr int kEpiGSum = kEpiBias | kEpiRound | kEpiAlpha | kEpiRes;                      // generator c2 + block sum (ops.GBlockEndFn)
 constexpr int kEpiDKeep = kEpiLrelu | kEpiDst2 | kEpiAlpha | kEpiRes | kEpiPool;          // discriminator conv_r[2] + block end, kept for a backward
 constexpr int kEpiDFwd = kEpiLrelu | kEpiRound | kEpiAlpha | kEpiRes | kEpiPool;          // ... forward only
 constexpr int kEpiDLast = kEpiLrelu | kEpiDst2 | kEpiAlpha | kEpiRes;                     // ... last block of a pass (no pooled output)
 constexpr int kEpiDLin = kEpiDst2 | kEpiAlpha | kEpiMask | kEpiRes;                      // the block end linearised (MA-GP: ResDBwdFn.backward)
+constexpr int kEpiDKeepS = kEpiLrelu | kEpiRound | kEpiSign | kEpiAlpha | kEpiRes | kEpiPool;   // block end kept for a first-order backward: sign bits instead of the branch
+constexpr int kEpiDLastS = kEpiLrelu | kEpiRound | kEpiSign | kEpiAlpha | kEpiRes;
+constexpr int kEpiDgDot = kEpiMask | kEpiAlpha | kEpiDot;                                 // conv_r[2]'s data gradient with d(gamma) in its epilogue
 // the mask of a descriptor, or -1 if it uses an option the masks do not describe (tanh / relu, f32 destination)
 static inline int xmc_epi_mask(const XmcConvDesc& d) {
     if ((d.act != XMC_ACT_NONE && d.act != XMC_ACT_LRELU) || d.out_dtype != XMC_BF16) return -1;
     return (d.bias ? kEpiBias : 0) | (d.act == XMC_ACT_LRELU ? kEpiLrelu : 0) | ((d.round_act && !d.dst2) ? kEpiRound : 0) | (d.dst2 ? kEpiDst2 : 0) |
            (d.alpha_dev ? kEpiAlpha : 0) | (d.mask ? kEpiMask : 0) | (d.res ? kEpiRes : 0) | (d.post_act == XMC_ACT_LRELU ? kEpiPost : 0) |
-           (d.dst_pool ? kEpiPool : 0);
+           (d.dst_pool ? kEpiPool : 0) | (d.sign_bits ? kEpiSign : 0) | (d.dot ? kEpiDot : 0);
 }
 
 // residual index (in 8-channel units) of destination pixel (n, y, x) for the three residual layouts; (a, b) is the pixel's

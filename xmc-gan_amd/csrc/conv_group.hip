@@ -183,7 +183,7 @@ int xmc_conv_group_try(const XmcConvDesc* d, void* stream) {
     if (off || G <= 1) return 1;
     if (d->dtype != XMC_BF16 || d->out_dtype != XMC_BF16) return 1;
     if (d->nclass != 1 || d->SA != 1 || d->DA != 1 || d->src_shift != 0 || d->dph[0] != 0 || d->dpw[0] != 0) return 1;
-    if (d->bias || d->alpha_dev || d->mask || d->dst2 || d->dst_pool || d->post_act || d->act != XMC_ACT_NONE) return 1;
+    if (d->bias || d->alpha_dev || d->mask || d->dst2 || d->dst_pool || d->post_act || d->sign_bits || d->dot || d->act != XMC_ACT_NONE) return 1;
     if (d->res && (d->res_mode != 0 || (d->res_scale != 0.f && d->res_scale != 1.f))) return 1;
     if (d->MH != d->DH || d->MW != d->DW || d->MH != d->SH || d->MW != d->SW) return 1;
     if (d->CS % G || d->CD % G || d->CD % 16 || d->CS % 8 || d->CD > 128) return 1;

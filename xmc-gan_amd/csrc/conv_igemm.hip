@@ -218,6 +218,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const XmcConvDesc d
     // ---- epilogue: acc -> LDS (f32 [EP_ROWS][BN+4]) -> coalesced channel-vector stores, EP_ROWS rows at a time
     float* ep = reinterpret_cast<float*>(smem);
     const float alpha = d.alpha_dev ? *d.alpha_dev : 1.f;
+    float dacc = 0.f;
     constexpr int CPR = BN / 8;                      // 8-channel chunks per tile row
     const int dph = d.dph[cls], dpw = d.dpw[cls];
     for (int half = 0; half < BM / EP_ROWS; ++half) {
@@ -262,9 +263,13 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const XmcConvDesc d
                 for (int k = 0; k < 8; ++k) v[k] = tanhf(v[k]);
             }
             const size_t ridx8 = res_index8(d, idx8, n, a * d.DA + dph, b * d.DA + dpw, a, b, ch >> 3);
-            if (d.out_dtype == XMC_BF16) epilogue_tail<XMC_BF16>(d, idx8, ridx8, v, alpha);
-            else epilogue_tail<XMC_F32>(d, idx8, ridx8, v, alpha);
+            if (d.out_dtype == XMC_BF16) epilogue_tail<XMC_BF16>(d, idx8, ridx8, v, alpha, &dacc);
+            else epilogue_tail<XMC_F32>(d, idx8, ridx8, v, alpha, &dacc);
         }
+    }
+    if (d.dot) {                                     // one atomic per wave: the d(gamma) dot product of XmcConvDesc.dot
+        dacc = wave_sum(dacc);
+        if (lane == 0) atomicAdd(d.dot, dacc);
     }
 }
 
@@ -340,6 +345,7 @@ extern "C" int xmc_conv_igemm(const XmcConvDesc* d, void* stream) {
     if ((int64_t)d->N * d->MH * d->MW >= (1ll << 31)) return XMC_ESHAPE;
     if (d->dst_pool && (d->DA != 1 || d->nclass != 1 || (d->DH & 1) || (d->DW & 1) || d->out_dtype != d->dtype)) return XMC_ESHAPE;
     if (d->post_act != XMC_ACT_NONE && d->post_act != XMC_ACT_LRELU) return XMC_EINVAL;
+    if (d->dot && !d->mask) return XMC_EINVAL;                  // the dot is <value before alpha, mask tensor>
     if (d->res_mode < 0 || d->res_mode > 2 || (d->res_mode == 2 && (d->DA != 1 || (d->DH & 1) || (d->DW & 1)))) return XMC_ESHAPE;
     static const bool no_tile = xmc_debug_off("no_tile");
     static const bool no_wt2 = xmc_debug_off("no_wtile_v2");

@@ -338,7 +338,7 @@ int xmc_conv_thin_out_try(const XmcConvDesc* d, void* stream) {
     if (off) return 1;
     if (d->dtype != XMC_BF16 || d->out_dtype != XMC_BF16 || d->CD != 8 || (d->CS != 32 && d->CS != 64) || d->CDw < 16) return 1;
     if (d->SA != 1 || d->DA != 1 || d->src_shift != 0 || d->nclass != 1 || d->ntaps != 9 || d->groups > 1) return 1;
-    if (d->res || d->mask || d->alpha_dev || d->dst2 || d->dst_pool || d->post_act) return 1;
+    if (d->res || d->mask || d->alpha_dev || d->dst2 || d->dst_pool || d->post_act || d->sign_bits || d->dot) return 1;
     if (d->act != XMC_ACT_NONE && d->act != XMC_ACT_TANH && d->act != XMC_ACT_LRELU) return 1;
     if (d->MH % TO_H != 0 || d->MW % TO_W != 0 || d->SH != d->MH || d->SW != d->MW || d->DH != d->MH || d->DW != d->MW) return 1;
     if (d->dph[0] != 0 || d->dpw[0] != 0) return 1;
@@ -361,7 +361,7 @@ int xmc_conv_thin_try(const XmcConvDesc* d, void* stream) {
     if (d->dtype != XMC_BF16 || d->out_dtype != XMC_BF16 || d->CS != 8) return 1;
     if (d->SA != 1 || d->DA != 1 || d->src_shift != 0 || d->nclass != 1 || d->ntaps > 12) return 1;
     if (d->CDw != 32 && d->CDw != 64) return 1;
-    if (d->res || d->alpha_dev || d->dst2 || d->post_act || (d->act != XMC_ACT_NONE && d->act != XMC_ACT_LRELU)) return 1;
+    if (d->res || d->alpha_dev || d->dst2 || d->post_act || d->sign_bits || d->dot || (d->act != XMC_ACT_NONE && d->act != XMC_ACT_LRELU)) return 1;
     if (d->MH % 8 != 0 || d->MW % 32 != 0 || d->SH != d->MH || d->SW != d->MW || d->DH != d->MH || d->DW != d->MW) return 1;
     if (d->dph[0] != 0 || d->dpw[0] != 0) return 1;
     int hmin = 127, hmax = -128, wmin = 127, wmax = -128;
@@ -398,7 +398,7 @@ int xmc_conv_pw1x1_try(const XmcConvDesc* d, void* stream) {
     if (d->ntaps != 1 || d->nclass != 1 || d->SA != 1 || d->DA != 1 || d->src_shift != 0) return 1;
     if (d->dh[0][0] != 0 || d->dw[0][0] != 0 || d->dph[0] != 0 || d->dpw[0] != 0) return 1;
     if (d->SH != d->MH || d->SW != d->MW || d->DH != d->MH || d->DW != d->MW) return 1;
-    if (d->post_act) return 1;
+    if (d->post_act || d->sign_bits || d->dot) return 1;
     if (d->res || d->mask || d->alpha_dev || d->dst2 || (d->act != XMC_ACT_NONE && d->act != XMC_ACT_LRELU)) return 1;
     if (d->CS % 32 != 0 || d->CS > 128 || d->CDw % 32 != 0 || d->CDw > 128 || d->CD % 8 != 0) return 1;
     const int ks = d->CS / 32, tn = d->CDw / 16;

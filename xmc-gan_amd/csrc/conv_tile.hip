@@ -163,6 +163,7 @@ __global__ __launch_bounds__(256) void tile_kernel(const XmcConvDesc d, const Ti
     // ---- epilogue in two halves of 128 rows through LDS (f32), coalesced 8-channel stores
     float* ep = reinterpret_cast<float*>(smem);
     const float alpha = d.alpha_dev ? *d.alpha_dev : 1.f;
+    float dacc = 0.f;
     constexpr int CPR = BN / 8;
     const int dph = d.dph[cls], dpw = d.dpw[cls];
     for (int half = 0; half < BM / EP_ROWS; ++half) {
@@ -206,9 +207,13 @@ __global__ __launch_bounds__(256) void tile_kernel(const XmcConvDesc d, const Ti
                 for (int k = 0; k < 8; ++k) v[k] = tanhf(v[k]);
             }
             const size_t ridx8 = res_index8(d, idx8, img, (a0 + ty) * d.DA + dph, (b0 + tx) * d.DA + dpw, a0 + ty, b0 + tx, (n0 >> 3) + cc);
-            if (d.out_dtype == XMC_BF16) epilogue_tail<XMC_BF16>(d, idx8, ridx8, v, alpha);
-            else epilogue_tail<XMC_F32>(d, idx8, ridx8, v, alpha);
+            if (d.out_dtype == XMC_BF16) epilogue_tail<XMC_BF16>(d, idx8, ridx8, v, alpha, &dacc);
+            else epilogue_tail<XMC_F32>(d, idx8, ridx8, v, alpha, &dacc);
         }
+    }
+    if (d.dot) {
+        dacc = wave_sum(dacc);
+        if (lane == 0) atomicAdd(d.dot, dacc);
     }
 }
 
@@ -383,6 +388,9 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
         const bool e_res = RT ? d.res != nullptr : (EPI & kEpiRes) != 0;
         const bool e_post = RT ? d.post_act == XMC_ACT_LRELU : (EPI & kEpiPost) != 0;
         const bool e_pool = RT ? d.dst_pool != nullptr : (EPI & kEpiPool) != 0;
+        constexpr bool e_sign = !RT && (EPI & kEpiSign) != 0;       // sign bits / dot: compile-time sets only (the launcher declines otherwise)
+        constexpr bool e_dot = !RT && (EPI & kEpiDot) != 0;
+        float dacc = 0.f;                                  // running sum for XmcConvDesc.dot over this workgroup's tiles
         const float slope = RT ? (d.act == XMC_ACT_LRELU ? XMC_LRELU : (d.act == XMC_ACT_RELU ? 0.f : 1.f)) : ((EPI & kEpiLrelu) ? XMC_LRELU : 1.f);
         const float rs = d.res_scale == 0.f ? 1.f : d.res_scale;
         __syncthreads();                          // weights + first patch staged
@@ -485,11 +493,21 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
 #pragma unroll
                                 for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], v[r] * slope);
                             }
+                            if (e_sign) {
+                                unsigned sb = 0;
+#pragma unroll
+                                for (int r = 0; r < 8; ++r) sb |= (v[r] > 0.f ? 1u : 0u) << r;
+                                reinterpret_cast<unsigned char*>(d.sign_bits)[idx8] = (unsigned char)sb;
+                            }
                             if (e_round) {
                                 bf16x8 o2;
 #pragma unroll
                                 for (int r = 0; r < 8; ++r) { o2[r] = (xmc_h16)v[r]; v[r] = (float)o2[r]; }
                                 if (e_dst2) reinterpret_cast<bf16x8*>(d.dst2)[idx8] = o2;
+                            }
+                            if (e_dot && e_mask) {
+#pragma unroll
+                                for (int r = 0; r < 8; ++r) dacc += v[r] * (float)mkv[c][pb][v2][r];
                             }
                             if (e_alpha) {
 #pragma unroll
@@ -549,6 +567,10 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
                 }
             }
         }
+        if (e_dot) {                              // one atomic per wave for the whole launch
+            dacc = wave_sum(dacc);
+            if (lane == 0) atomicAdd(d.dot, dacc);
+        }
     } else {
         // ------------------------------------------------------------------------------------------------ compute role
         const int fr = lane & 15, fc = lane >> 4;
@@ -575,7 +597,7 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
         constexpr bool RT = EPI < 0;                       // epilogue options read from the descriptor (common.h: kEpi*)
         constexpr int EB = RT ? 0 : (EPI & ~kEpiBias);     // (the bias vector is always added: zeros when there is none)
         const bool fast = RT ? (d.out_dtype == XMC_BF16 && d.res == nullptr && d.mask == nullptr && d.alpha_dev == nullptr && d.dst2 == nullptr &&
-                                d.dst_pool == nullptr && d.post_act == XMC_ACT_NONE &&
+                                d.dst_pool == nullptr && d.post_act == XMC_ACT_NONE && d.sign_bits == nullptr && d.dot == nullptr &&
                                 (d.act == XMC_ACT_NONE || d.act == XMC_ACT_LRELU || d.act == XMC_ACT_TANH))
                              : (EB == 0 || EB == kEpiLrelu);
         const bool do_tanh = RT ? d.act == XMC_ACT_TANH : false;
@@ -589,6 +611,9 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
         const bool e_res = RT ? d.res != nullptr : (EPI & kEpiRes) != 0;
         const bool e_post = RT ? d.post_act == XMC_ACT_LRELU : (EPI & kEpiPost) != 0;
         const bool e_pool = RT ? d.dst_pool != nullptr : (EPI & kEpiPool) != 0;
+        constexpr bool e_sign = !RT && (EPI & kEpiSign) != 0;       // sign bits / dot: compile-time sets only (the launcher declines otherwise)
+        constexpr bool e_dot = !RT && (EPI & kEpiDot) != 0;
+        float dacc = 0.f;
         __syncthreads();                          // weights + first patch staged
         int toffr[NTAPS > 0 ? MC * NTAPS : 1];
         if constexpr (NTAPS > 0) {
@@ -770,11 +795,21 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
                         }
                         if (pre) {      // epilogue_tail<XMC_BF16> with the loads hoisted
                             bf16x8* __restrict__ dst8 = reinterpret_cast<bf16x8*>(d.dst);
+                            if (e_sign) {
+                                unsigned sb = 0;
+#pragma unroll
+                                for (int q = 0; q < 8; ++q) sb |= (v[q] > 0.f ? 1u : 0u) << q;
+                                reinterpret_cast<unsigned char*>(d.sign_bits)[idx8] = (unsigned char)sb;
+                            }
                             if (e_round) {
                                 bf16x8 o2;
 #pragma unroll
                                 for (int q = 0; q < 8; ++q) { o2[q] = (xmc_h16)v[q]; v[q] = (float)o2[q]; }
                                 if (e_dst2) reinterpret_cast<bf16x8*>(d.dst2)[idx8] = o2;
+                            }
+                            if (e_dot && e_mask) {
+#pragma unroll
+                                for (int q = 0; q < 8; ++q) dacc += v[q] * (float)(HOIST ? mkv[HOIST ? i : 0] : mkl[HOIST ? 0 : i])[q];
                             }
                             if (e_alpha) {
 #pragma unroll
@@ -798,7 +833,7 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
                             for (int q = 0; q < 8; ++q) { o[q] = (xmc_h16)v[q]; fin[i][q] = (float)o[q]; }
                             dst8[idx8] = o;
                         } else {
-                            epilogue_tail<XMC_F32>(d, idx8, rix[i], v, alpha);
+                            epilogue_tail<XMC_F32>(d, idx8, rix[i], v, alpha, &dacc);
 #pragma unroll
                             for (int q = 0; q < 8; ++q) fin[i][q] = v[q];
                         }
@@ -827,6 +862,10 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
             }
           }
         }
+        if (e_dot) {
+            dacc = wave_sum(dacc);
+            if (lane == 0) atomicAdd(d.dot, dacc);
+        }
     }
 }
 
@@ -852,6 +891,7 @@ int launch_ptile(const XmcConvDesc& d, const TileCfg& t, hipStream_t st) {
         }
         XMC_PT3S2(kEpiLrelu) XMC_PT3S2(0) XMC_PT3S2(kEpiMask)
 #undef XMC_PT3S2
+        if (d.sign_bits || d.dot) return XMC_ESHAPE;     // only compile-time option sets carry these two
         xmc_note_generic_epi("ptile3<s2>", epi2);
         XMC_ALLOW_BIG_LDS((ptile3_kernel<BN, 32, 16, 1, 2>));
         hipLaunchKernelGGL((ptile3_kernel<BN, 32, 16, 1, 2>), dim3(g2, d.CDw / BN, 1), dim3(512), lds2, st, d, t, nt2);
@@ -878,6 +918,7 @@ int launch_ptile(const XmcConvDesc& d, const TileCfg& t, hipStream_t st) {
             int gm = 256 / (int)(d.CDw / BN);
             if (gm > ntiles) gm = ntiles;
             dim3 gridm((unsigned)gm, (unsigned)(d.CDw / BN), 1);
+            if (d.sign_bits || d.dot) return XMC_ESHAPE;
             static const bool no_epim = xmc_debug_off("no_ptile_epi");
             const int epim = no_epim ? -1 : (xmc_epi_mask(d) & ~kEpiBias);
 #define XMC_PT3M(SL, E)                                                                                                     \
@@ -903,7 +944,7 @@ int launch_ptile(const XmcConvDesc& d, const TileCfg& t, hipStream_t st) {
     static const bool no_m32 = xmc_debug_off("no_ptile_m32");
     static const bool m32_all = xmc_debug_off("ptile_m32_all");
     if (!no_m32 && d.ntaps == 9 && d.out_dtype == XMC_BF16 && t.slab == 64 &&
-        (m32_all || d.res || d.dst2 || d.dst_pool || d.mask)) {      // one matrix wave per SIMD: 32x32x16 form
+        (m32_all || d.res || d.dst2 || d.dst_pool || d.mask || d.sign_bits)) {      // one matrix wave per SIMD: 32x32x16 form
         // the epilogue option sets of the training step as compile-time instantiations (kEpi*), anything else through the
         // descriptor-reading one
         int epi = xmc_epi_mask(d);
@@ -918,8 +959,10 @@ int launch_ptile(const XmcConvDesc& d, const TileCfg& t, hipStream_t st) {
             return 0;                                                                                                    \
         }
         XMC_PT3_EPI(kEpiGSum) XMC_PT3_EPI(kEpiDKeep) XMC_PT3_EPI(kEpiDFwd) XMC_PT3_EPI(kEpiDLast) XMC_PT3_EPI(kEpiDLin)
+        XMC_PT3_EPI(kEpiDKeepS) XMC_PT3_EPI(kEpiDLastS) XMC_PT3_EPI(kEpiDgDot)
         XMC_PT3_EPI(kEpiMask)                                                                // data gradient through a LeakyReLU
 #undef XMC_PT3_EPI
+        if (d.sign_bits || d.dot) return XMC_ESHAPE;
         xmc_note_generic_epi("ptile3<M32>", epi);
         XMC_ALLOW_BIG_LDS((ptile3_kernel<BN, 64, 9, 1, 1, true>));
         hipLaunchKernelGGL((ptile3_kernel<BN, 64, 9, 1, 1, true>), grid, dim3(512), lds, st, d, t, ntiles);
@@ -947,6 +990,7 @@ int launch_ptile(const XmcConvDesc& d, const TileCfg& t, hipStream_t st) {
     // + the tail's LeakyReLU
     XMC_PT3E(64, 0) XMC_PT3E(32, 0) XMC_PT3E(32, (kEpiGSum | kEpiPost) & ~kEpiBias) XMC_PT3E(64, (kEpiGSum | kEpiPost) & ~kEpiBias)
 #undef XMC_PT3E
+    if (d.sign_bits || d.dot) return XMC_ESHAPE;
     xmc_note_generic_epi("ptile3<16x16>", epi9);
     if (t.slab == 64) {
         if (d.ntaps == 9) XMC_PT3(64, 9); else if (d.ntaps == 4) XMC_PT3(64, 4); else XMC_PT3(64, 0);

@@ -263,6 +263,7 @@ __global__ __launch_bounds__(64 * CW + 256) void wtile2_kernel(const XmcConvDesc
         // weight fragment (n-block mj, row fr, chunk sub*4+fc) of a ring slot: chunk index XOR (row & 7)
         const int bb0 = fr * 128 + ((fc ^ (fr & 7)) << 4) + wn * TNW * 2048, bb1 = bb0 ^ 64;
         f32x4 acc[TM][TNW];
+        float dacc = 0.f;                        // running sum for XmcConvDesc.dot over this workgroup's tiles
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -301,6 +302,8 @@ __global__ __launch_bounds__(64 * CW + 256) void wtile2_kernel(const XmcConvDesc
             const bool e_res = RT ? d.res != nullptr : (EPI & kEpiRes) != 0;
             const bool e_post = RT ? d.post_act == XMC_ACT_LRELU : (EPI & kEpiPost) != 0;
             const bool e_pool = RT ? d.dst_pool != nullptr : (EPI & kEpiPool) != 0;
+            constexpr bool e_sign = !RT && (EPI & kEpiSign) != 0;       // sign bits / dot: compile-time sets only (the launcher declines otherwise)
+            constexpr bool e_dot = !RT && (EPI & kEpiDot) != 0;
             const float slope = RT ? (d.act == XMC_ACT_LRELU ? XMC_LRELU : (d.act == XMC_ACT_RELU ? 0.f : 1.f)) : ((EPI & kEpiLrelu) ? XMC_LRELU : 1.f);
             const float alpha = d.alpha_dev ? *d.alpha_dev : 1.f;
             const float rs = d.res_scale == 0.f ? 1.f : d.res_scale;
@@ -352,11 +355,21 @@ __global__ __launch_bounds__(64 * CW + 256) void wtile2_kernel(const XmcConvDesc
 #pragma unroll
                         for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], v[r] * slope);
                     }
+                    if (e_sign) {
+                        unsigned sb = 0;
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) sb |= (v[r] > 0.f ? 1u : 0u) << r;
+                        reinterpret_cast<unsigned char*>(d.sign_bits)[eo[i] + u * 4] = (unsigned char)sb;
+                    }
                     if (e_round) {
                         bf16x8 o2;
 #pragma unroll
                         for (int r = 0; r < 8; ++r) { o2[r] = (xmc_h16)v[r]; v[r] = (float)o2[r]; }
                         if (e_dst2) dst2_8[eo[i] + u * 4] = o2;
+                    }
+                    if (e_dot && e_mask) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) dacc += v[r] * (float)mkv[i][r];
                     }
                     if (e_alpha) {
 #pragma unroll
@@ -462,6 +475,10 @@ __global__ __launch_bounds__(64 * CW + 256) void wtile2_kernel(const XmcConvDesc
                 sl = 0; ++tk;
             }
         }
+        if ((EPI < 0 ? d.dot != nullptr : (EPI & kEpiDot) != 0)) {
+            dacc = wave_sum(dacc);
+            if (lane == 0) atomicAdd(d.dot, dacc);
+        }
     }
 }
 
@@ -548,6 +565,7 @@ int launch(const XmcConvDesc& d, const WtCfg& t, hipStream_t st) {
     }
     if constexpr (CW == 8 && NTAPS == 9 && TN == 8) {
         XMC_W2_EPI(kEpiGSum) XMC_W2_EPI(kEpiDKeep) XMC_W2_EPI(kEpiDFwd) XMC_W2_EPI(kEpiDLast) XMC_W2_EPI(kEpiMask) XMC_W2_EPI(0) XMC_W2_EPI(kEpiDLin)
+        XMC_W2_EPI(kEpiDKeepS) XMC_W2_EPI(kEpiDLastS) XMC_W2_EPI(kEpiDgDot)
         XMC_W2_EPI(kEpiBias) XMC_W2_EPI(kEpiBias | kEpiLrelu)            // the attention-modulation blocks' convolutions
     } else if constexpr (CW == 8 && NTAPS == 9) {
         XMC_W2_EPI(kEpiBias) XMC_W2_EPI(kEpiBias | kEpiLrelu) XMC_W2_EPI(0)
@@ -557,6 +575,7 @@ int launch(const XmcConvDesc& d, const WtCfg& t, hipStream_t st) {
         XMC_W2_EPI(kEpiRes) XMC_W2_EPI(kEpiBias) XMC_W2_EPI(0)
     }
 #undef XMC_W2_EPI
+    if (d.sign_bits || d.dot) return 1;          // only the compile-time sets above carry these two; the next kernel in line takes it
     xmc_note_generic_epi(NTAPS == 9 ? (TN == 8 ? "wtile2<9,0,8>" : "wtile2<9,0,4>") : MODE == 1 ? (TN == 8 ? "wtile2<4,1,8>" : "wtile2<4,1,4>") : "wtile2<4,0>", CW == 8 ? xmc_epi_mask(d) : -1);
     XMC_ALLOW_BIG_LDS((wtile2_kernel<NTAPS, MODE, TN, CW>));
     hipLaunchKernelGGL((wtile2_kernel<NTAPS, MODE, TN, CW>), dim3((unsigned)gx, (unsigned)ny, (unsigned)d.nclass), dim3(64 * CW + 256), lds, st, d, t,

@@ -216,6 +216,7 @@ __global__ __launch_bounds__(512) void wtile3_kernel(const XmcConvDesc d, const 
     const int wf0 = (wc * TNW * 16 + fr) * 128 + ((fc ^ (fr & 7)) << 4), wf1 = wf0 ^ 64;      // K sub-step 0 / 1
 
     f32x4 acc[TMW][TNW];
+    float dacc = 0.f;                            // running sum for XmcConvDesc.dot over this workgroup's tiles
 #pragma unroll
     for (int i = 0; i < TMW; ++i)
 #pragma unroll
@@ -244,6 +245,8 @@ __global__ __launch_bounds__(512) void wtile3_kernel(const XmcConvDesc d, const 
         const bool e_res = RT ? d.res != nullptr : (EPI & kEpiRes) != 0;
         const bool e_post = RT ? d.post_act == XMC_ACT_LRELU : (EPI & kEpiPost) != 0;
         const bool e_pool = RT ? d.dst_pool != nullptr : (EPI & kEpiPool) != 0;
+        constexpr bool e_sign = !RT && (EPI & kEpiSign) != 0;       // sign bits / dot: compile-time sets only (the launcher declines otherwise)
+        constexpr bool e_dot = !RT && (EPI & kEpiDot) != 0;
         const float slope = RT ? (d.act == XMC_ACT_LRELU ? XMC_LRELU : (d.act == XMC_ACT_RELU ? 0.f : 1.f)) : ((EPI & kEpiLrelu) ? XMC_LRELU : 1.f);
         const float alpha = d.alpha_dev ? *d.alpha_dev : 1.f;
         const float rs = d.res_scale == 0.f ? 1.f : d.res_scale;
@@ -296,11 +299,21 @@ __global__ __launch_bounds__(512) void wtile3_kernel(const XmcConvDesc d, const 
 #pragma unroll
                         for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], v[r] * slope);
                     }
+                    if (e_sign) {
+                        unsigned sb = 0;
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) sb |= (v[r] > 0.f ? 1u : 0u) << r;
+                        reinterpret_cast<unsigned char*>(d.sign_bits)[eo[i] + u * 4] = (unsigned char)sb;
+                    }
                     if (e_round) {
                         bf16x8 o2;
 #pragma unroll
                         for (int r = 0; r < 8; ++r) { o2[r] = (xmc_h16)v[r]; v[r] = (float)o2[r]; }
                         if (e_dst2) dst2_8[eo[i] + u * 4] = o2;
+                    }
+                    if (e_dot && e_mask) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) dacc += v[r] * (float)mkv[i][r];
                     }
                     if (e_alpha) {
 #pragma unroll
@@ -479,6 +492,10 @@ __global__ __launch_bounds__(512) void wtile3_kernel(const XmcConvDesc d, const 
     }
     if (half == 0) __builtin_amdgcn_s_barrier();     // same barrier count for every wave
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup's LDS allocation
+    if ((EPI < 0 ? d.dot != nullptr : (EPI & kEpiDot) != 0)) {
+        dacc = wave_sum(dacc);
+        if (lane == 0) atomicAdd(d.dot, dacc);
+    }
 }
 
 // Fills the plan; returns 1 when the descriptor is this kernel's case.
@@ -560,12 +577,14 @@ int launch3(const XmcConvDesc& d, const W3Cfg& t, hipStream_t st) {
     }
     if constexpr (NTAPS == 9) {
         XMC_W3_EPI(kEpiGSum) XMC_W3_EPI(kEpiDKeep) XMC_W3_EPI(kEpiDFwd) XMC_W3_EPI(kEpiDLast) XMC_W3_EPI(kEpiMask) XMC_W3_EPI(0) XMC_W3_EPI(kEpiDLin)
+        XMC_W3_EPI(kEpiDKeepS) XMC_W3_EPI(kEpiDLastS) XMC_W3_EPI(kEpiDgDot)
     } else if constexpr (MODE == 1) {
         XMC_W3_EPI(kEpiLrelu) XMC_W3_EPI(0) XMC_W3_EPI(kEpiMask)       // forward; data gradient of the fused upsample conv; MA-GP's linearised forward
     } else {
         XMC_W3_EPI(kEpiRes) XMC_W3_EPI(kEpiBias) XMC_W3_EPI(0)
     }
 #undef XMC_W3_EPI
+    if (d.sign_bits || d.dot) return 1;          // only the compile-time sets above carry these two; the next kernel in line takes it
     xmc_note_generic_epi(NTAPS == 9 ? "wtile3<9,0>" : MODE == 1 ? "wtile3<4,1>" : "wtile3<4,0>", epi);
     XMC_ALLOW_BIG_LDS((wtile3_kernel<NTAPS, MODE, WM>));
     hipLaunchKernelGGL((wtile3_kernel<NTAPS, MODE, WM>), dim3((unsigned)gx, (unsigned)ny, (unsigned)d.nclass), dim3(512), lds, st, d, t, ntiles);
@@ -584,7 +603,7 @@ int xmc_conv_wtile3_try(const XmcConvDesc* d, void* stream) {
     // BN = 128 (64 x 64 wave tiles: the same fragment-read load as the role-split kernel, without its dedicated staging waves) measures
     // 3-6 % behind conv_wtile.hip on the 128-channel layers: kept for A/B runs only
     static const bool bn128 = xmc_debug_off("wtile3_bn128"), bn128_epi = xmc_debug_off("wtile3_bn128_epi"), bn128_plain = xmc_debug_off("wtile3_bn128_plain");
-    const bool heavy = d->res || d->dst2 || d->dst_pool || d->mask;
+    const bool heavy = d->res || d->dst2 || d->dst_pool || d->mask || d->sign_bits;
     if (wm == 4 && !(bn128 || (bn128_epi && heavy) || (bn128_plain && !heavy))) return 1;
     // 256-channel tiles halve the number of workgroups: below one tile per CU the role-split kernel (128-channel tiles, twice the
     // workgroups) wins -- 128x128 / batch 64: 10.8 vs 10.4 ms per iteration

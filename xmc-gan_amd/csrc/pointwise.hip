@@ -83,6 +83,29 @@ int run_map1(const void* x, void* y, int64_t n, int dtype, hipStream_t st, F f) 
     XMC_LAUNCH_CHECK();
     return 0;
 }
+// y = dy * LeakyReLU'(branch) with the branch given as its sign bits (XmcConvDesc.sign_bits: one byte per 8-channel unit, bit r =
+// element r > 0): the mask pass of a discriminator block's backward without the branch tensor (17/16 of a tensor read, one written)
+template <int DT>
+__global__ void signmask_kernel(const void* dy, const unsigned char* __restrict__ bits, void* y, int64_t n8, float slope) {
+    for (int64_t base = (int64_t)blockIdx.x * (NT * UN); base < n8; base += (int64_t)gridDim.x * (NT * UN)) {
+        float u[UN][8];
+        unsigned b[UN];
+#pragma unroll
+        for (int j = 0; j < UN; ++j) {
+            const int64_t i = base + j * NT + threadIdx.x;
+            if (i < n8) { Vec8<DT>::load(dy, i, u[j]); b[j] = bits[i]; }
+        }
+#pragma unroll
+        for (int j = 0; j < UN; ++j) {
+            const int64_t i = base + j * NT + threadIdx.x;
+            if (i < n8) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) u[j][k] = ((b[j] >> k) & 1u) ? u[j][k] : slope * u[j][k];
+                Vec8<DT>::store(y, i, u[j]);
+            }
+        }
+    }
+}
 template <class F>
 int run_map2(const void* a, const void* b, void* y, int64_t n, int dtype, hipStream_t st, F f) {
     if (n % 8) return XMC_EALIGN;
@@ -832,6 +855,17 @@ extern "C" int xmc_lrelu(const void* x, void* y, int64_t n, float slope, int dty
 extern "C" int xmc_tanh(const void* x, void* y, int64_t n, int dtype, void* s) { return run_map1(x, y, n, dtype, ST(s), FTanh{}); }
 extern "C" int xmc_lrelu_mask(const void* dy, const void* ref, void* dx, int64_t n, float slope, int dtype, void* s) {
     return run_map2(dy, ref, dx, n, dtype, ST(s), FLreluMask{slope});
+}
+extern "C" int xmc_signmask_apply(const void* dy, const void* bits, void* dx, int64_t n, float slope, int dtype, void* s) {
+    if (!dy || !bits || !dx) return XMC_EINVAL;
+    if (n % 8) return XMC_EALIGN;
+    if (n == 0) return 0;
+    const int64_t n8 = n / 8;
+    if (dtype == XMC_BF16) hipLaunchKernelGGL((signmask_kernel<XMC_BF16>), dim3(sblocks(n8)), dim3(NT), 0, ST(s), dy, (const unsigned char*)bits, dx, n8, slope);
+    else if (dtype == XMC_F32) hipLaunchKernelGGL((signmask_kernel<XMC_F32>), dim3(sblocks(n8)), dim3(NT), 0, ST(s), dy, (const unsigned char*)bits, dx, n8, slope);
+    else return XMC_EINVAL;
+    XMC_LAUNCH_CHECK();
+    return 0;
 }
 extern "C" int xmc_tanh_bwd(const void* dy, const void* y, void* dx, int64_t n, int dtype, void* s) {
     return run_map2(dy, y, dx, n, dtype, ST(s), FTanhBwd{});

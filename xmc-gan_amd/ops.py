@@ -92,6 +92,27 @@ def _skip_wgrad():
     return getattr(_state, "skip_wgrad", False)
 
 
+def _second_order():
+    return getattr(_state, "second_order", False)
+
+
+class second_order:
+    """Context: forwards inside it keep what a DIFFERENTIATED backward needs (the discriminator blocks store their residual
+    branch instead of its sign bits).  The MA-GP term wraps its discriminator forward in this (train_gan.py:231-247)."""
+
+    def __init__(self, on=True):
+        self.on = on
+
+    def __enter__(self):
+        self.prev = getattr(_state, "second_order", False)
+        _state.second_order = bool(self.on)
+        return self
+
+    def __exit__(self, *a):
+        _state.second_order = self.prev
+        return False
+
+
 # ------------------------------------------------------------------------------------------ helpers
 def _code(dtype):
     if dtype == torch.float32:
@@ -381,7 +402,7 @@ def _upconv_dgrad_raw(dy, w, geom, in_dtype):
 
 
 def _conv_fwd_raw(x, w, bias, geom, act, out_dtype, res=None, alpha=None, up=False, res_mode=0, want2=False, want_pool=False,
-                  round_act=False, mask=None, out=None, post_act=L.ACT_NONE):
+                  round_act=False, mask=None, out=None, post_act=L.ACT_NONE, want_sign=False):
     """y = act(conv(x, w) + bias) [*alpha] [+ res]; x [N,H,W,Cs]. ``up``: x is read through a fused nearest x2.
     ``res_mode`` 2: res is [N,OH/2,OW/2,C] and read through a nearest x2.  ``want2``: also return act(conv + bias) itself (the
     branch value before alpha / res);  ``want_pool``: also return avg_pool2d(y, 2).  Extras are appended: (y[, y2][, ypool])."""
@@ -425,6 +446,11 @@ def _conv_fwd_raw(x, w, bias, geom, act, out_dtype, res=None, alpha=None, up=Fal
         y2 = torch.empty_like(y)
         d.dst2 = y2.data_ptr()
         outs.append(y2)
+    if want_sign:                 # sign bits of act(conv + bias), one byte per 8-channel unit (XmcConvDesc.sign_bits)
+        assert not want2
+        bits = torch.empty((N, OH, OW, cd_p // 8), dtype=torch.uint8, device=x.device)
+        d.sign_bits = bits.data_ptr()
+        outs.append(bits)
     if want_pool:
         assert OH % 2 == 0 and OW % 2 == 0 and out_dtype == x.dtype
         yp = torch.empty((N, OH // 2, OW // 2, cd_p), dtype=out_dtype, device=x.device)
@@ -436,7 +462,8 @@ def _conv_fwd_raw(x, w, bias, geom, act, out_dtype, res=None, alpha=None, up=Fal
     return y if len(outs) == 1 else tuple(outs)
 
 
-def _conv_dgrad_raw(dy, w, geom, in_hw, in_dtype, mask=None, res=None, res_rows=False, res_scale=1.0, alpha=None, want_sumpool=False):
+def _conv_dgrad_raw(dy, w, geom, in_hw, in_dtype, mask=None, res=None, res_rows=False, res_scale=1.0, alpha=None, want_sumpool=False,
+                    dot=None):
     """dx [N,H,W,cin_p] from dy [N,OH,OW,cout_p].  Epilogue options: ``mask`` (dx layout): dx *= LeakyReLU'(mask);
     ``res``: dx += res_scale * res, with ``res_rows`` the residual is [N,H/s,W/s,cin_p] and every pixel of it is added to its
     s x s block of dx (s == 2: the adjoint of avg_pool2d, df_gan.py:290).  ``want_sumpool`` (stride 1): returns (dx, 2x2 sum pool
@@ -477,6 +504,9 @@ def _conv_dgrad_raw(dy, w, geom, in_hw, in_dtype, mask=None, res=None, res_rows=
     if mask is not None:
         assert mask.shape == dx.shape and mask.dtype == dx.dtype and mask.is_contiguous()
         d.mask = mask.data_ptr()
+    if dot is not None:           # dot += <dgrad(dy) before alpha, mask values> (XmcConvDesc.dot), f32 [1], accumulated
+        assert mask is not None and dot.dtype == torch.float32 and dot.numel() == 1
+        d.dot = dot.data_ptr()
     if res is not None:
         want = (N, H // s, W // s, cs_p) if res_rows else tuple(dx.shape)
         assert tuple(res.shape) == want and res.dtype == dx.dtype and res.is_contiguous(), (res.shape, want)
@@ -1370,10 +1400,14 @@ class ResDFn(torch.autograd.Function):
         # residual branch itself is kept (second output) only when a backward pass will ask for it
         keep = any(ctx.needs_input_grad[:6])
         pool_ok = want_pool and res_pool_ok(h1, g2)
-        r = _conv_fwd_raw(h1, w2, None, g2, L.ACT_LRELU, dt, res=sc, alpha=al, want2=keep, want_pool=pool_ok, round_act=True)
+        # what the backward needs of the residual branch: its LeakyReLU' mask -- the SIGN bits, 1/16 of the tensor -- unless the
+        # backward itself will be differentiated (MA-GP: ops.second_order()), whose linearised forward needs the values
+        bits_mode = keep and not _second_order() and "no_sign_bits" not in _DEBUG_DISPATCH
+        r = _conv_fwd_raw(h1, w2, None, g2, L.ACT_LRELU, dt, res=sc, alpha=al, want2=keep and not bits_mode, want_sign=bits_mode,
+                          want_pool=pool_ok, round_act=True)
         r = r if isinstance(r, tuple) else (r,)
         out = r[0]
-        res = r[1] if keep else None
+        res = r[1] if keep else None              # the branch (bf16 tensor) or its sign bits (uint8 [N,H,W,C/8])
         outp = r[-1] if pool_ok else None
         ctx.geoms = (g0, g2, gs)
         ctx.learned = ws is not None
@@ -1394,6 +1428,9 @@ class ResDFn(torch.autograd.Function):
             return (None,) * 11
         x, xp, h1, res, w0, w2, ws, gamma = ctx.saved_tensors
         need = tuple(bool(v) for v in ctx.needs_input_grad[:6])
+        if res is not None and res.dtype == torch.uint8 and torch.is_grad_enabled():      # create_graph=True
+            raise RuntimeError("ResDFn: this block kept only the sign bits of its residual branch; wrap the forward in "
+                               "ops.second_order() to differentiate its backward (the MA-GP pattern)")
         outs = ResDBwdFn.apply(dout, x, xp, h1, res, w0, w2, ws, gamma, ctx.geoms, ctx.learned, ctx.has_bs, need, _skip_wgrad())
         return tuple(outs) + (None, None, None, None, None)
 
@@ -1426,11 +1463,21 @@ class ResDBwdFn(torch.autograd.Function):
             dout = dout.to(dt)
         # residual branch: g2 = gamma * dout * LeakyReLU'(res), d(gamma) = <dout, res>
         al = gamma.detach().reshape(-1).float()
-        gr = torch.empty_like(res)
         dgam = _zeros_f32(1, x.device)
-        L.call("xmc_scale_mask_dot", _p(dout), _p(res), _p(al), _p(gr), _p(dgam), res.numel(), _code(dt), _st())
-        dw2 = _conv_wgrad_raw(h1, gr, g2).view(w2.shape) if (need[2] and not skip_w) else None
-        gh = _conv_dgrad_raw(gr, w2, g2, (h1.shape[1], h1.shape[2]), dt, mask=h1)        # includes LeakyReLU'(h1)
+        if res.dtype == torch.uint8:
+            # `res` holds only the branch's sign bits.  With s = LeakyReLU'(branch) and branch = s * C2 h1:
+            #   <dout, branch> = <s * dout, C2 h1> = <C2^T (s * dout), h1>
+            # so the data gradient of conv_r[2] runs on the UNSCALED s * dout, accumulates the dot with h1 -- the tensor it reads as
+            # its LeakyReLU' mask anyway -- before it applies gamma, and the weight gradient takes gamma as its scale.
+            gr = torch.empty_like(dout)
+            L.call("xmc_signmask_apply", _p(dout), _p(res), _p(gr), dout.numel(), 0.2, _code(dt), _st())
+            dw2 = _conv_wgrad_raw(h1, gr, g2, scale=al).view(w2.shape) if (need[2] and not skip_w) else None
+            gh = _conv_dgrad_raw(gr, w2, g2, (h1.shape[1], h1.shape[2]), dt, mask=h1, alpha=al, dot=dgam)
+        else:
+            gr = torch.empty_like(res)
+            L.call("xmc_scale_mask_dot", _p(dout), _p(res), _p(al), _p(gr), _p(dgam), res.numel(), _code(dt), _st())
+            dw2 = _conv_wgrad_raw(h1, gr, g2).view(w2.shape) if (need[2] and not skip_w) else None
+            gh = _conv_dgrad_raw(gr, w2, g2, (h1.shape[1], h1.shape[2]), dt, mask=h1)        # includes LeakyReLU'(h1)
         dw0 = _conv_wgrad_raw(x, gh, g0).view(w0.shape) if (need[1] and not skip_w) else None
         # shortcut branch
         dws = dbs = None

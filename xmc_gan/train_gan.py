@@ -218,7 +218,8 @@ def gan_iteration(netG, netD, optimizerG, optimizerD, imgs, sent_embs, words_emb
         sent_inter = psent_embs.detach().requires_grad_()
         # this forward's backward is differentiated again.  The fused discriminator blocks carry their own second-order node
         # (ops.ResDBwdFn); with spectral norm the blocks are composed from the fine-grained Functions as before
-        with (ops.composable() if cfg.DISC.SPEC_NORM else contextlib.nullcontext()):
+        # ops.second_order(): the blocks keep their residual branch (not just its sign bits) for the linearised forward
+        with (ops.composable() if cfg.DISC.SPEC_NORM else contextlib.nullcontext()), ops.second_order():
             features = netD(interpolated)
             o = netD.COND_DNET(features, sent_inter)
         with ops.no_wgrad():           # first-order pass only needs d(logit)/d(inputs)
