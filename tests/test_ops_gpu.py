@@ -100,6 +100,10 @@ CONV_CASES = [
     # streaming 1x1 kernel (conv_thin.hip pw1x1): >= 16 k pixels, Cin <= 128, Cout <= 128
     (32, 64, 1, 1, 0, 64, 4),      # shortcut conv of resD block 0 (on the pooled input): one K step
     (64, 128, 1, 1, 0, 32, 16),    # two K steps, 8 row blocks; its dgrad: four K steps, 4 row blocks
+    # streamed-weights kernel on 8x8 maps (conv_wtile3.hip, tiles of four whole images); batch sizes at which it is chosen
+    (256, 256, 3, 1, 1, 8, 512),   # 128-channel tiles (64x64 wave tiles), forward and data gradient
+    (128, 512, 3, 1, 1, 8, 512),   # 256-channel tiles forward; the 128-channel data gradient stays on the gather kernel
+    (256, 512, 4, 2, 1, 16, 512),  # 4x4 stride 2 onto 8x8 (space-to-depth patches of four images); dgrad = 4 classes of 2x2 taps on 8x8 grids
 ]
 
 
@@ -170,7 +174,8 @@ def test_grouped_conv_fwd_dgrad_wgrad(cin, cout, k, H, W, N, mode):
 
 @pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("cin,cout,H,N", [(64, 32, 16, 2), (32, 32, 32, 1), (128, 64, 8, 3), (256, 128, 4, 2), (8, 8, 16, 2),
-                                           (128, 128, 16, 2), (256, 128, 8, 4)])   # wide: weight gradient by kernel rows through the upsample
+                                           (128, 128, 16, 2), (256, 128, 8, 4),    # wide: weight gradient by kernel rows through the upsample
+                                           (256, 256, 8, 512)])                    # 8x8 -> 16x16 at a batch that takes the multi-image tiles
 def test_upsample_conv_fusion(cin, cout, H, N, mode):
     """conv3x3(interpolate(x, 2), w) + b computed on the low-resolution tensor with pre-summed 2x2 weights
     (df_gan.py:202 + 187): forward, dgrad (4x4-tap stride-2 gather), wgrad (through the fused upsample), bias grad;
@@ -503,7 +508,8 @@ def test_fused_discriminator_block_double_backward_equals_composed_block(cin, co
         torch.testing.assert_close(a, b, rtol=3e-2 if mode == "bf16" else 2e-4, atol=(3e-2 if mode == "bf16" else 2e-4) * sc, msg=lambda m: f"{n}: {m}")
 
 
-@pytest.mark.parametrize("N,H,C", [(2, 16, 64), (8, 32, 256), (4, 64, 128), (16, 16, 512), (2, 128, 64), (3, 24, 40), (64, 32, 256), (32, 32, 512)])
+@pytest.mark.parametrize("N,H,C", [(2, 16, 64), (8, 32, 256), (4, 64, 128), (16, 16, 512), (2, 128, 64), (3, 24, 40), (64, 32, 256), (32, 32, 512),
+                                   (512, 8, 256), (512, 8, 512)])          # 8x8 maps: multi-image tiles, 128- and 256-channel
 def test_conv_sign_bits_and_gradient_dot_against_the_stored_branch(N, H, C):
     """XmcConvDesc.sign_bits / .dot (include/xmc_gan_hip.h), the two epilogue options a discriminator block's first-order backward
     runs on: the bits must be exactly `branch > 0` of the branch the kernel would otherwise store, the block output must not change
@@ -547,6 +553,65 @@ def test_conv_sign_bits_and_gradient_dot_against_the_stored_branch(N, H, C):
     want_dot = (u.double() * h1.double()).sum().item()
     scale = (u.double() * h1.double()).abs().sum().item()
     assert abs(dgam.item() - want_dot) <= 2e-3 * scale / (u.numel() ** 0.5) * 30 + 1e-6 * scale, (dgam.item(), want_dot, scale)
+
+
+@pytest.mark.parametrize("N", [512, 256])
+def test_multi_image_tiles_equal_the_small_batch_kernels(N):
+    """conv_wtile3.hip's tiles of four whole 8x8 images (chosen from batch 256 up) against the SAME operator on 8-sample slices,
+    which the dispatcher sends to the gather kernel: same bf16 operands, f32 accumulation in another order -> relative L2 <= 5e-4
+    (measured 1e-5 .. 1e-4; a wrong halo or image offset would be O(1)).  Covers 3x3, the 4x4 stride-2 forward (space-to-depth
+    patches) and its four-class data gradient, the fused upsample conv and a whole discriminator block with its fused epilogues."""
+    from xmc_gan.model.df_gan import resD
+    ops.set_precision("bf16")
+    dt = ops.act_dtype()
+    g = torch.Generator().manual_seed(N)
+    S = 8
+    slices = (slice(0, N), slice(0, S), slice(N - S, N))
+    rel = lambda a, b: ((a.float() - b.float()).norm() / (b.float().norm() + 1e-30)).item()
+    last = lambda: L.load().xmc_last_kernel().decode()
+
+    def check(name, run, x, r, want_kernel=True, tol=5e-4):
+        outs = []
+        for sl in slices:
+            xd = x[sl].clone().requires_grad_()
+            y, kf = run(xd)
+            (y.float() * r[sl].float()).sum().backward()
+            outs.append((y.detach(), xd.grad.detach(), kf))
+        if want_kernel:
+            assert outs[0][2].startswith("wtile3_kernel") and not outs[1][2].startswith("wtile3_kernel"), (name, outs[0][2], outs[1][2])
+        for which, a, b in (("y", 0, 0), ("dx", 1, 1)):
+            e0, e1 = rel(outs[0][a][:S], outs[1][b]), rel(outs[0][a][N - S:], outs[2][b])
+            assert e0 < tol and e1 < tol, (name, which, e0, e1)
+
+    for (cin, cout, k, s, p, H) in [(512, 512, 3, 1, 1, 8), (128, 512, 3, 1, 1, 8), (256, 512, 4, 2, 1, 16)]:
+        x = torch.randn(N, H, H, cin, generator=g).to(DEV).to(dt)
+        w = torch.nn.Parameter((torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)).to(DEV))
+        b = torch.nn.Parameter((torch.randn(cout, generator=g) * 0.1).to(DEV))
+        geom = ops.ConvGeom(cin, cout, k, s, p)
+        Ho = (H + 2 * p - k) // s + 1
+        r = torch.randn(N, Ho, Ho, cout, generator=g).to(DEV).to(dt)
+
+        def run(xd, w=w, b=b, geom=geom):
+            y = ops.conv2d(xd, w, b, geom, act=L.ACT_LRELU)
+            return y, last()
+        check(f"conv {cin}->{cout} k{k} s{s}", run, x, r)
+    x = torch.randn(N, 8, 8, 256, generator=g).to(DEV).to(dt)
+    w = torch.nn.Parameter((torch.randn(256, 256, 3, 3, generator=g) / math.sqrt(256 * 9)).to(DEV))
+    b = torch.nn.Parameter((torch.randn(256, generator=g) * 0.1).to(DEV))
+    r = torch.randn(N, 16, 16, 256, generator=g).to(DEV).to(dt)
+
+    def run_up(xd):
+        y = ops.upconv3x3(xd, w, b, ops.ConvGeom(256, 256, 3, 1, 1))
+        return y, last()
+    check("upconv 256->256 8x8 -> 16x16", run_up, x, r)
+    torch.manual_seed(3)
+    blk = resD(256, 512, downsample=True).to(DEV)
+    with torch.no_grad():
+        blk.gamma.fill_(0.37)
+    x = torch.randn(N, 16, 16, 256, generator=g).to(DEV).to(dt)
+    r = torch.randn(N, 8, 8, 512, generator=g).to(DEV).to(dt)
+    # a whole block: its inner LeakyReLU mask flips where a pre-activation sits within that 1e-4 of zero (0.8 |g| per element)
+    check("resD 256->512 16 -> 8", lambda xd: (blk(xd), ""), x, r, want_kernel=False, tol=5e-3)
 
 
 def test_fused_discriminator_block_refuses_second_derivative_without_the_branch():

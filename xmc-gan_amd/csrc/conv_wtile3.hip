@@ -46,10 +46,11 @@ struct W3Cfg {
     int nslab;                                           // K slabs per tile: CS/64 (MODE 0), 4*CS/64 (MODE 1)
     int patch_bytes;                                     // one patch buffer: 384 pixel slots x 128 B
     int8_t tsel[4][4];                                   // MODE 1: tap index of (dy*2+dx, ta*2+tb)
+    int ipt;                                             // images per tile: 1, or 4 (8 x 8 maps: a tile is four whole images side by side)
 };
 
 constexpr int kPI = 6;              // 1 KB patch pieces (8 pixels x 128 B) per wave and slab, at most
-constexpr int kPieces = 44;         // pieces of a patch buffer: 352 pixel slots (the largest patch, 10 x 34, has 340 pixels)
+constexpr int kPieces = 47;         // pieces of a patch buffer: 376 pixel slots (10 x 34 = 340 pixels; four 8 x 8 images with their halos, 10 x 37 = 370)
 constexpr int kPatchSlots = kPieces * 8;
 
 __device__ __attribute__((aligned(16))) unsigned char g_zero16[16];     // what a halo pixel outside the image reads
@@ -97,6 +98,7 @@ __global__ __launch_bounds__(512) void wtile3_kernel(const XmcConvDesc d, const 
     const int cs_units = d.CS / 8;
     const int nslab = t.nslab;
     const int cb = d.CS / 64;
+    const bool mi = t.ipt > 1;                   // multi-image tiles (8 x 8 maps)
     if (tid < XMC_MAX_TAPS) {
         if (MODE == 0) {
             const int tt = tid < NTAPS ? tid : 0;
@@ -140,14 +142,32 @@ __global__ __launch_bounds__(512) void wtile3_kernel(const XmcConvDesc d, const 
         const int pp = (wave * kPI + i) * 8 + (lane >> 3);
         const bool in = pp < PH * PW;
         const int py = pp / PW, px = pp - py * PW;
-        const int ch = (lane & 7) ^ (px & 7);      // keyed by the patch COLUMN: the reader's XOR term then depends on lane and tap only
+        // swizzle key = the pixel's column in ITS image's patch (mod 8): the reader's XOR term then depends on lane and tap only
         unsigned hb;
-        if (MODE == 0) {
-            psrc[i] = in ? ((dh0 + py) * d.SW + (dw0 + px)) * cs_units + ch : 0;
-            hb = (py < -dh0 ? 1u : 0u) | (py >= t.TH - dh0 ? 2u : 0u) | (px < -dw0 ? 4u : 0u) | (px >= t.TW - dw0 ? 8u : 0u);
+        if (!mi) {
+            const int ch = (lane & 7) ^ (px & 7);
+            if (MODE == 0) {
+                psrc[i] = in ? ((dh0 + py) * d.SW + (dw0 + px)) * cs_units + ch : 0;
+                hb = (py < -dh0 ? 1u : 0u) | (py >= t.TH - dh0 ? 2u : 0u) | (px < -dw0 ? 4u : 0u) | (px >= t.TW - dw0 ? 8u : 0u);
+            } else {
+                psrc[i] = in ? ((2 * py - 1) * d.SW + (2 * px - 1)) * cs_units + ch : 0;
+                hb = (py == 0 ? 1u : 0u) | (py == t.TH ? 2u : 0u) | (px == 0 ? 4u : 0u) | (px == t.TW ? 8u : 0u);
+            }
+        } else if (MODE == 0) {
+            // four 8 x 8 images side by side, 9 patch columns apart: [z] img0 [z] img1 [z] img2 [z] img3 [z] -- a zero column between
+            // neighbours serves as the right halo of one and the left halo of the next; every tile border is an image border, so a
+            // pixel is either data (bits 0) or always zero (bits 15 against pborder = 15)
+            const int q = px + dw0, kq = q >= 0 ? q / 9 : 0, x = q - 9 * kq, row = dh0 + py;
+            const bool data = in && q >= 0 && x < 8 && kq < 4 && row >= 0 && row < d.SH;
+            const int ch = (lane & 7) ^ ((x - dw0) & 7);
+            psrc[i] = data ? ((kq * d.SH + row) * d.SW + x) * cs_units + ch : 0;
+            hb = data ? 0u : 15u;
         } else {
-            psrc[i] = in ? ((2 * py - 1) * d.SW + (2 * px - 1)) * cs_units + ch : 0;
-            hb = (py == 0 ? 1u : 0u) | (py == t.TH ? 2u : 0u) | (px == 0 ? 4u : 0u) | (px == t.TW ? 8u : 0u);
+            // space-to-depth patches of four 16 x 16 images: 9 columns each (both outer columns carry data for one of the groups)
+            const int kq = px / 9, x9 = px - 9 * kq;
+            const int ch = (lane & 7) ^ (x9 & 7);
+            psrc[i] = in ? ((kq * d.SH + 2 * py - 1) * d.SW + (2 * x9 - 1)) * cs_units + ch : 0;
+            hb = (py == 0 ? 1u : 0u) | (py == t.TH ? 2u : 0u) | (x9 == 0 ? 4u : 0u) | (x9 == 8 ? 8u : 0u);
         }
         hpack |= (in ? hb : 16u) << (5 * i);
     }
@@ -160,17 +180,18 @@ __global__ __launch_bounds__(512) void wtile3_kernel(const XmcConvDesc d, const 
     auto patch_setup = [&](int q) {
         const int tk = q / nslab, sl = q - tk * nslab;
         const int tile = (int)blockIdx.x + tk * (int)gridDim.x;
-        const int img = tile / tpi, trem = tile - img * tpi;
+        const int timg = tile / tpi, trem = tile - timg * tpi, img = timg * t.ipt;
         const int a0 = (trem / t.tiles_x) * t.TH, b0 = (trem % t.tiles_x) * t.TW;
         if (MODE == 0) {
             pbase = ((img * d.SH + a0) * d.SW + b0) * cs_units + sl * 8;
             pborder = (a0 + dh0 < 0 ? 1u : 0u) | (a0 + PH + dh0 > d.SH ? 2u : 0u) | (b0 + dw0 < 0 ? 4u : 0u) | (b0 + PW + dw0 > d.SW ? 8u : 0u);
+            if (mi) pborder = 15u;
         } else {
             const int si = s_slab[sl];
             const int grp = si >> 8, cbi = si & 0xff, dy = grp >> 1, dx = grp & 1;
             pbase = ((img * d.SH + 2 * a0 + dy) * d.SW + 2 * b0 + dx) * cs_units + cbi * 8;
             pborder = ((a0 == 0 && dy == 0) ? 1u : 0u) | ((a0 + t.TH == d.MH && dy == 1) ? 2u : 0u) |
-                      ((b0 == 0 && dx == 0) ? 4u : 0u) | ((b0 + t.TW == d.MW && dx == 1) ? 8u : 0u);
+                      ((b0 == 0 && dx == 0) ? 4u : 0u) | (((mi || b0 + t.TW == d.MW) && dx == 1) ? 8u : 0u);
         }
     };
     // Every lane of every piece issues (halo pixels outside the image and slots past the end of the patch copy the zero page).  The
@@ -209,9 +230,10 @@ __global__ __launch_bounds__(512) void wtile3_kernel(const XmcConvDesc d, const 
     int ppl0;
     {
         const int ml = wr * (256 / WM) + fr;
-        ppl0 = (ml >> t.log2TW) * PW + (ml & (t.TW - 1));
+        const int col = ml & (t.TW - 1);
+        ppl0 = (ml >> t.log2TW) * PW + (mi ? col + (col >> 3) : col);       // multi-image: image k's columns start 9 k patch columns in
     }
-    const int ps1 = t.log2TW == 5 ? 16 : PW, ps2 = t.log2TW == 5 ? PW : 2 * PW;
+    const int ps1 = t.log2TW == 5 ? (mi ? 18 : 16) : PW, ps2 = t.log2TW == 5 ? PW : 2 * PW;
     // weight fragment (n-block j of this wave, row fr, chunk ksub*4 + fc): chunk slot = chunk ^ (row & 7), row & 7 == fr & 7
     const int wf0 = (wc * TNW * 16 + fr) * 128 + ((fc ^ (fr & 7)) << 4), wf1 = wf0 ^ 64;      // K sub-step 0 / 1
 
@@ -230,9 +252,11 @@ __global__ __launch_bounds__(512) void wtile3_kernel(const XmcConvDesc d, const 
     auto epilogue = [&](int tile) {
         int lane_op = fr;                        // opaque: keeps the store addresses from being hoisted out of the tile loop (spills)
         asm volatile("" : "+v"(lane_op) :: "memory");
-        const int img = tile / tpi, trem = tile - img * tpi;
+        const int timg = tile / tpi, trem = tile - timg * tpi, img = timg * t.ipt;
         const int a0 = (trem / t.tiles_x) * t.TH, b0 = (trem % t.tiles_x) * t.TW;
         const int dbase = (((img * d.DH + a0 * d.DA + d.dph[cls]) * d.DW) + b0 * d.DA + d.dpw[cls]) * cd8 + nw8;
+        // multi-image tiles: tile column tx is column tx % 8 of image img + tx / 8
+        const int dimg = d.DH * d.DW * cd8, rimg = d.res_mode ? d.MH * d.MW * cd8 : dimg;
         const int rbase = d.res_mode ? ((img * d.MH + a0) * d.MW + b0) * cd8 + nw8 : dbase;
         const int rsy = d.res_mode ? d.MW : d.DA * d.DW, rsx = d.res_mode ? 1 : d.DA;
         constexpr bool RT = EPI < 0;                   // epilogue options read from the descriptor (common.h: kEpi*)
@@ -262,12 +286,13 @@ __global__ __launch_bounds__(512) void wtile3_kernel(const XmcConvDesc d, const 
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int ml = wr * (256 / WM) + (g * 4 + i) * 16 + lane_op;
-                const int ty = ml >> t.log2TW, tx = ml & (t.TW - 1);
-                eo[i] = dbase + ((ty * d.DA) * d.DW + tx * d.DA) * cd8 + fc;
+                const int ty = ml >> t.log2TW, txt = ml & (t.TW - 1);
+                const int tx = mi ? (txt & 7) : txt, ki = mi ? (txt >> 3) : 0;
+                eo[i] = dbase + ((ty * d.DA) * d.DW + tx * d.DA) * cd8 + ki * dimg + fc;
                 if (d.res_mode == 2)
-                    ro[i] = ((img * (d.DH >> 1) + ((a0 + ty) >> 1)) * (d.DW >> 1) + ((b0 + tx) >> 1)) * cd8 + nw8 + fc;
+                    ro[i] = (((img + ki) * (d.DH >> 1) + ((a0 + ty) >> 1)) * (d.DW >> 1) + ((b0 + tx) >> 1)) * cd8 + nw8 + fc;
                 else
-                    ro[i] = rbase + (ty * rsy + tx * rsx) * cd8 + fc;
+                    ro[i] = rbase + (ty * rsy + tx * rsx) * cd8 + ki * rimg + fc;
             }
 #pragma unroll
             for (int u = 0; u < TNW / 2; ++u) {
@@ -343,7 +368,8 @@ __global__ __launch_bounds__(512) void wtile3_kernel(const XmcConvDesc d, const 
                     for (int pr = 0; pr < 2; ++pr) {
                         const int i0 = t.log2TW == 5 ? pr : 2 * pr;
                         const int ml = wr * (256 / WM) + (g * 4 + i0) * 16 + lane_op;
-                        const int ty = ml >> t.log2TW, tx = ml & (t.TW - 1);
+                        const int ty = ml >> t.log2TW, txt = ml & (t.TW - 1);
+                        const int tx = mi ? (txt & 7) : txt, ki = mi ? (txt >> 3) : 0;
                         bf16x8 o;
 #pragma unroll
                         for (int r = 0; r < 8; ++r) {
@@ -352,7 +378,7 @@ __global__ __launch_bounds__(512) void wtile3_kernel(const XmcConvDesc d, const 
                             o[r] = (xmc_h16)((d.pool_scale == 0.f ? 0.25f : d.pool_scale) * sm);
                         }
                         if ((lane_op & 1) == 0)
-                            pool8[((img * (d.DH >> 1) + ((a0 + ty) >> 1)) * (d.DW >> 1) + ((b0 + tx) >> 1)) * cd8 + nw8 + fc + u * 4] = o;
+                            pool8[(((img + ki) * (d.DH >> 1) + ((a0 + ty) >> 1)) * (d.DW >> 1) + ((b0 + tx) >> 1)) * cd8 + nw8 + fc + u * 4] = o;
                     }
                 }
             }
@@ -505,11 +531,15 @@ int plan3(const XmcConvDesc* d, W3Cfg* t, int* mode, int* wm) {
     if (d->CDw % 256 == 0) *wm = 2;
     else if (d->CDw % 128 == 0) *wm = 4;
     else return 0;
-    if (d->MW % 16 != 0) return 0;
-    const int TW = d->MW >= 32 ? 32 : 16, TH = 256 / TW;
-    if (d->MH % TH != 0 || d->MW % TW != 0) return 0;
+    // 8 x 8 maps (the last discriminator blocks, the generator's second block): a tile is four whole images side by side
+    static const bool no_mi = xmc_debug_off("no_wtile3_multi_image");
+    const bool mi = !no_mi && d->MW == 8 && d->MH == 8 && d->N % 4 == 0;
+    if (!mi && d->MW % 16 != 0) return 0;
+    const int TW = (mi || d->MW >= 32) ? 32 : 16, TH = 256 / TW;
+    if (!mi && (d->MH % TH != 0 || d->MW % TW != 0)) return 0;
     t->TH = TH; t->TW = TW; t->log2TW = TW == 32 ? 5 : 4;
-    t->tiles_y = d->MH / TH; t->tiles_x = d->MW / TW;
+    t->tiles_y = mi ? 1 : d->MH / TH; t->tiles_x = mi ? 1 : d->MW / TW;
+    t->ipt = mi ? 4 : 1;
     int maxpix = 0;
     if (d->SA == 1) {
         if (d->ntaps != 9 && d->ntaps != 4) return 0;
@@ -525,8 +555,16 @@ int plan3(const XmcConvDesc* d, W3Cfg* t, int* mode, int* wm) {
             if (hmin < -TH || hmax > TH || wmin < -TW || wmax > TW) return 0;
             t->dh0[z] = hmin; t->dw0[z] = wmin;
             t->PH[z] = TH + (hmax - hmin); t->PW[z] = TW + (wmax - wmin);
+            if (mi) {
+                // image k's columns start at patch column 9 k - dw0; one shared zero column between neighbours
+                if (wmax - wmin < 1 || wmax - wmin > 2 || wmin > 0 || wmax < 0 || hmin > 0 || hmax < 0) return 0;
+                t->PW[z] = 36 + (wmax - wmin == 2 ? 1 : 0);
+                // rows below the declared patch are only ever read as zeros: every slot past the patch is zero-filled on each fill, so
+                // the bottom halo row may (and, for 3x3, does: 10 x 37 = 370 > 368) reach into the last piece
+                if (t->PH[z] * t->PW[z] > kPieces * 8 || (hmax > 0 ? (t->PH[z] - 1) * t->PW[z] : t->PH[z] * t->PW[z]) > (kPieces - 1) * 8) return 0;
+            }
             if (d->SH != d->MH || d->SW != d->MW) return 0;
-            maxpix = t->PH[z] * t->PW[z] > maxpix ? t->PH[z] * t->PW[z] : maxpix;
+            if (!mi) maxpix = t->PH[z] * t->PW[z] > maxpix ? t->PH[z] * t->PW[z] : maxpix;
         }
     } else if (d->SA == 2) {
         if (d->ntaps != 16 || d->nclass != 1 || d->DA != 1 || d->SH != 2 * d->MH || d->SW != 2 * d->MW) return 0;
@@ -542,12 +580,12 @@ int plan3(const XmcConvDesc* d, W3Cfg* t, int* mode, int* wm) {
                 if (found < 0 || found > 15) return 0;
                 t->tsel[g][tp] = (int8_t)found;
             }
-        t->PH[0] = TH + 1; t->PW[0] = TW + 1; t->dh0[0] = t->dw0[0] = 0;
+        t->PH[0] = TH + 1; t->PW[0] = mi ? 36 : TW + 1; t->dh0[0] = t->dw0[0] = 0;
         maxpix = t->PH[0] * t->PW[0];
     } else {
         return 0;
     }
-    if (maxpix > (kPieces - 1) * 8) return 0;      // piece 43 must stay past the end of every patch (patch_piece)
+    if (maxpix > (kPieces - 1) * 8) return 0;      // the last piece must stay past the end of every patch (patch_piece)
     if (d->dst_pool && (d->DA != 1 || d->nclass != 1 || (d->DH & 1) || (d->DW & 1))) return 0;
     if (d->res_mode == 2 && d->DA != 1) return 0;
     t->patch_bytes = kPatchSlots * 128;
@@ -560,7 +598,7 @@ int launch3(const XmcConvDesc& d, const W3Cfg& t, hipStream_t st) {
     constexpr int BN = 64 * (8 / WM), RING = WM == 2 ? 2 : 4;
     const size_t lds = (size_t)RING * BN * 128 + 2 * (size_t)t.patch_bytes + (size_t)(2 * XMC_MAX_TAPS + 64) * sizeof(int);
     if (lds > XMC_MAX_DYN_LDS) return XMC_ESHAPE;
-    const int ntiles = d.N * t.tiles_y * t.tiles_x, ny = d.CDw / BN;
+    const int ntiles = d.N / t.ipt * t.tiles_y * t.tiles_x, ny = d.CDw / BN;
     int gx = 256 / (ny * d.nclass);               // one 8-wave workgroup per CU, persistent over its tiles
     if (gx < 1) gx = 1;
     if (gx > ntiles) gx = ntiles;
@@ -604,10 +642,19 @@ int xmc_conv_wtile3_try(const XmcConvDesc* d, void* stream) {
     // 3-6 % behind conv_wtile.hip on the 128-channel layers: kept for A/B runs only
     static const bool bn128 = xmc_debug_off("wtile3_bn128"), bn128_epi = xmc_debug_off("wtile3_bn128_epi"), bn128_plain = xmc_debug_off("wtile3_bn128_plain");
     const bool heavy = d->res || d->dst2 || d->dst_pool || d->mask || d->sign_bits;
-    if (wm == 4 && !(bn128 || (bn128_epi && heavy) || (bn128_plain && !heavy))) return 1;
-    // 256-channel tiles halve the number of workgroups: below one tile per CU the role-split kernel (128-channel tiles, twice the
-    // workgroups) wins -- 128x128 / batch 64: 10.8 vs 10.4 ms per iteration
-    if (wm == 2 && (long long)d->N * t.tiles_y * t.tiles_x * (d->CDw / 256) * d->nclass < 256) return 1;
+    static const bool any_count = xmc_debug_off("wtile3_any_tile_count");      // tests: small batches through this kernel
+    const long long tiles = (long long)d->N / t.ipt * t.tiles_y * t.tiles_x * d->nclass;
+    if (t.ipt > 1) {
+        // 8 x 8 maps: nothing but the generic kernel (~550 TF/s) behind this one.  256-channel tiles when they give one workgroup per
+        // CU, else 128-channel tiles (twice the workgroups), else not worth it
+        if (wm == 2 && tiles * (d->CDw / 256) < 256 && !any_count) wm = 4;
+        if (wm == 4 && tiles * (d->CDw / 128) < 256 && !any_count) return 1;
+    } else {
+        if (wm == 4 && !(bn128 || (bn128_epi && heavy) || (bn128_plain && !heavy))) return 1;
+        // 256-channel tiles halve the number of workgroups: below one tile per CU the role-split kernel (128-channel tiles, twice the
+        // workgroups) wins -- 128x128 / batch 64: 10.8 vs 10.4 ms per iteration
+        if (wm == 2 && tiles * (d->CDw / 256) < 256 && !any_count) return 1;
+    }
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     int rc;
 #define W3_GO(NT_, MD_) (wm == 2 ? launch3<NT_, MD_, 2>(*d, t, st) : launch3<NT_, MD_, 4>(*d, t, st))
