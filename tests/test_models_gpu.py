@@ -205,6 +205,40 @@ def test_train_iteration_parity(yml, over, batch, steps, mode):
 
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_gradient_penalty_pattern_needs_no_context_on_a_leaf_input(mode):
+    """The reference's own MA-GP lines (train_gan.py:231-247) run unchanged on the product modules: NetD.forward sees a leaf input
+    that requires grad and keeps the blocks' residual branches; the result equals the explicit ops.second_order() form (same launches),
+    while a non-leaf input without the context (blocks keep sign bits only) is refused by the create_graph backward."""
+    ops.set_precision(mode)
+    cfg, h = setup_cfg("df_gan_damsm.yml", **{"IMG.SIZE": 64, "TRAIN.NCH": 8})
+    PG, PD = X.synth_params(X.gen_shapes(h), 3), X.synth_params(X.netd_shapes(h), 4)
+    netG, netD, _, _ = build_product(h, PG, PD)
+    b = X.synth_batch(h, 4, seed=2, words_len=cfg.TEXT.MAX_LENGTH)
+    imgs, sent = b["imgs"].to(DEV), netG.proj_sent(b["sent_embs"].to(DEV)).detach()
+
+    def penalty(x_in, ctx):
+        s_in = sent.clone().requires_grad_()
+        with ctx:
+            o = netD.COND_DNET(netD(x_in), s_in)
+        g = torch.autograd.grad(outputs=o[0], inputs=(x_in, s_in), grad_outputs=torch.ones_like(o[0]), retain_graph=True,
+                                create_graph=True, only_inputs=True)
+        gp = ops.grad_penalty(g[0], g[1])
+        netD.zero_grad()
+        gp.backward()
+        return gp.detach(), [p.grad.clone() for p in netD.parameters() if p.grad is not None]
+
+    import contextlib
+    gp0, gr0 = penalty(imgs.detach().requires_grad_(), contextlib.nullcontext())
+    gp1, gr1 = penalty(imgs.detach().requires_grad_(), ops.second_order())
+    assert torch.equal(gp0, gp1) and len(gr0) == len(gr1)
+    for a, c in zip(gr0, gr1):                     # the same launches; f32 atomics of the weight gradients land in another order
+        assert rel_err(a, c) < 1e-5
+    x_nl = imgs.detach().requires_grad_() * 1.0                           # not a leaf
+    with pytest.raises(RuntimeError, match="second_order"):
+        penalty(x_nl, contextlib.nullcontext())
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
 def test_spectral_norm_forward_and_power_iteration(mode):
     """DISC.SPEC_NORM=True: state_dict layout, one power iteration per forward call in training mode (u/v buffers
     equal to the oracle's afterwards -- the matrix-vector products run in f32 in both precision modes), none in eval."""

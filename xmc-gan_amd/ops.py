@@ -96,6 +96,10 @@ def _second_order():
     return getattr(_state, "second_order", False)
 
 
+def second_order_active():
+    return _second_order()
+
+
 class second_order:
     """Context: forwards inside it keep what a DIFFERENTIATED backward needs (the discriminator blocks store their residual
     branch instead of its sign bits).  The MA-GP term wraps its discriminator forward in this (train_gan.py:231-247)."""

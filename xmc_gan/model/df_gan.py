@@ -142,13 +142,19 @@ class NetD(nn.Module):
         the engine layout [B,S,S,8] (``ops.to_nhwc8(x)`` or NetG's ``return_nhwc`` output); ``x`` is then not read."""
         pooled = None               # avg_pool2d of `out`, written by the layer that produced it (third output of its epilogue)
         xin = ops.to_nhwc8(x) if nhwc8 is None else nhwc8
-        if ops.fused_blocks() and xin.is_cuda and xin.shape[1] % 2 == 0:
-            out, pooled = self.conv_img(xin, want_pool=True)
-        else:
-            out = self.conv_img(xin)
-        nblk = len(self.downblocks)
-        for i, block in enumerate(self.downblocks):
-            out, pooled = block(out, xp_hint=pooled, want_pool=i + 1 < nblk)
+        # A LEAF input that requires grad is the gradient-penalty pattern (train_gan.py:231-237: `imgs.detach().requires_grad_()`,
+        # then autograd.grad(..., create_graph=True)): the blocks then keep what a differentiated backward needs, as inside
+        # ops.second_order().  The training passes feed images without grad (D step) or the generator's output (G step, not a leaf).
+        src = x if nhwc8 is None else nhwc8
+        leaf_in = torch.is_tensor(src) and src.requires_grad and src.is_leaf
+        with ops.second_order(leaf_in or ops.second_order_active()):
+            if ops.fused_blocks() and xin.is_cuda and xin.shape[1] % 2 == 0:
+                out, pooled = self.conv_img(xin, want_pool=True)
+            else:
+                out = self.conv_img(xin)
+            nblk = len(self.downblocks)
+            for i, block in enumerate(self.downblocks):
+                out, pooled = block(out, xp_hint=pooled, want_pool=i + 1 < nblk)
         return as_nchw_view(out)
 
 
