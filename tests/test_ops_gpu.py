@@ -100,6 +100,10 @@ CONV_CASES = [
     # streaming 1x1 kernel (conv_thin.hip pw1x1): >= 16 k pixels, Cin <= 128, Cout <= 128
     (32, 64, 1, 1, 0, 64, 4),      # shortcut conv of resD block 0 (on the pooled input): one K step
     (64, 128, 1, 1, 0, 32, 16),    # two K steps, 8 row blocks; its dgrad: four K steps, 4 row blocks
+    # streaming 1x1 kernel with its weights in LDS (conv_thin.hip pw1x1w): Cin 128 / 256, >= 32 k pixels
+    (128, 256, 1, 1, 0, 32, 40),   # shortcut of the 128 -> 256 block: one column slice; its dgrad (256 -> 128) the KS = 8 form
+    (256, 512, 1, 1, 0, 16, 130),  # two column slices of 256; M = 33280 (last wave iteration partial); dgrad (Cin 512) on the gather kernel
+    (256, 120, 1, 1, 0, 32, 33),   # Cout padded 120 -> 128
     # streamed-weights kernel on 8x8 maps (conv_wtile3.hip, tiles of four whole images); batch sizes at which it is chosen
     (256, 256, 3, 1, 1, 8, 512),   # 128-channel tiles (64x64 wave tiles), forward and data gradient
     (128, 512, 3, 1, 1, 8, 512),   # 256-channel tiles forward; the 128-channel data gradient stays on the gather kernel

@@ -244,6 +244,99 @@ int launch_pw(const XmcConvDesc& d, int ngroups, hipStream_t st) {
     return 0;
 }
 
+// 1x1 convolution with MANY channels (the learned shortcuts of the deeper discriminator blocks, 128 -> 256 and 256 -> 512, and their
+// data gradients): the weights no longer fit in registers, so they sit in LDS -- the workgroup's column slice, staged once, rows
+// padded by 16 bytes (16 consecutive rows then cover every bank exactly once per ds_read_b128 of a lane group) -- and everything
+// else is pw1x1_kernel: the source goes from global memory straight into the MFMA B operand, four 16-pixel groups in flight per
+// wave, each weight fragment read once per 64 pixels, 64-byte-per-pixel stores.  8 waves per workgroup (2 per SIMD) share the
+// slice.  85-170 FLOP/byte: an HBM stream (the gather kernel ran these at 1.7-2.6 TB/s: two K steps of prologue and an LDS
+// transposition of the result per 256x256 tile).
+template <int KS>                             // KS = Cin / 32 K-steps (4 or 8)
+__global__ __launch_bounds__(512) void pw1x1w_kernel(const XmcConvDesc d, int ngroups, int ncols) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char wlds[];
+    constexpr int RSTR = KS * 64 + 16;         // bytes per weight row
+    const int tid = threadIdx.x, lane = tid & 63, fr = lane & 15, fc = lane >> 4;
+    const int cs_units = d.CS >> 3, cd8 = d.CD >> 3;
+    const int c0 = blockIdx.y * ncols;         // first output channel of this workgroup's slice
+    const u32x4* __restrict__ src16 = reinterpret_cast<const u32x4*>(d.src);
+    const u32x4* __restrict__ w16 = reinterpret_cast<const u32x4*>(d.wpk);
+    bf16x8* __restrict__ dst8 = reinterpret_cast<bf16x8*>(d.dst);
+    // physical row (block j, r) <- logical channel (j/2)*32 + (r/4)*8 + (j%2)*4 + r%4 (conv_tile.hip: lane group fc ends with 8
+    // consecutive channels in its two accumulator blocks -> 16-byte stores, 64 bytes per pixel per 32 channels)
+    for (int id = tid; id < ncols * KS * 4; id += 512) {
+        const int row = id / (KS * 4), ch = id - row * (KS * 4);
+        const int j = row >> 4, r = row & 15;
+        const int lrow = (j >> 1) * 32 + (r >> 2) * 8 + (j & 1) * 4 + (r & 3);
+        *reinterpret_cast<u32x4*>(wlds + row * RSTR + ch * 16) = w16[((size_t)d.wi[0][0] * d.CDw + c0 + lrow) * cs_units + ch];
+    }
+    __syncthreads();
+    const float slope = d.act == XMC_ACT_LRELU ? XMC_LRELU : 1.f;
+    const int wave_g = blockIdx.x * 8 + (tid >> 6), nwaves = gridDim.x * 8;
+    constexpr int UNR = 4;
+    const int nu = ncols >> 5;                 // 32-channel units of the slice
+    for (int g0 = wave_g * UNR; g0 < ngroups; g0 += nwaves * UNR) {
+        u32x4 pf[UNR][KS];
+#pragma unroll
+        for (int r = 0; r < UNR; ++r) {
+            const int g = g0 + r < ngroups ? g0 + r : ngroups - 1;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) pf[r][ks] = src16[(size_t)(g * 16 + fr) * cs_units + ks * 4 + fc];
+        }
+        for (int u = 0; u < nu; ++u) {
+            f32x4 acc[UNR][2];
+#pragma unroll
+            for (int r = 0; r < UNR; ++r) acc[r][0] = acc[r][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const unsigned char* const wr = wlds + (u * 32 + fr) * RSTR + fc * 16;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 wa = *reinterpret_cast<const bf16x8*>(wr + ks * 64), wb = *reinterpret_cast<const bf16x8*>(wr + 16 * RSTR + ks * 64);
+#pragma unroll
+                for (int r = 0; r < UNR; ++r) {
+                    acc[r][0] = XMC_MFMA_16x16x32(wa, __builtin_bit_cast(bf16x8, pf[r][ks]), acc[r][0], 0, 0, 0);
+                    acc[r][1] = XMC_MFMA_16x16x32(wb, __builtin_bit_cast(bf16x8, pf[r][ks]), acc[r][1], 0, 0, 0);
+                }
+            }
+            const int ch = c0 + u * 32 + fc * 8;
+            if (ch >= d.CD) continue;
+            float b8[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) b8[c] = d.bias ? d.bias[ch + c] : 0.f;
+#pragma unroll
+            for (int r = 0; r < UNR; ++r) {
+                if (g0 + r >= ngroups) break;
+                bf16x8 o;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float x0 = acc[r][0][q] + b8[q], x1 = acc[r][1][q] + b8[4 + q];
+                    o[q] = (xmc_h16)fmaxf(x0, x0 * slope);
+                    o[4 + q] = (xmc_h16)fmaxf(x1, x1 * slope);
+                }
+                dst8[((size_t)(g0 + r) * 16 + fr) * cd8 + (ch >> 3)] = o;
+            }
+        }
+    }
+}
+
+template <int KS>
+int launch_pww(const XmcConvDesc& d, int ngroups, hipStream_t st) {
+    // the column slice of a workgroup: as many 32-channel units as fit in LDS, dividing CDw evenly (256 x 512: two slices of 135 KB)
+    constexpr int RSTR = KS * 64 + 16;
+    int ny = 1;
+    while ((size_t)(d.CDw / ny) * RSTR > XMC_MAX_DYN_LDS || d.CDw % ny != 0 || (d.CDw / ny) % 32 != 0) {
+        if (++ny > d.CDw / 32) return 1;
+    }
+    const int ncols = d.CDw / ny;
+    const size_t lds = (size_t)ncols * RSTR;
+    int nb = (ngroups + 8 * 4 - 1) / (8 * 4);           // 8 waves per block, 4 groups per wave and iteration
+    if (nb > 256 / ny) nb = 256 / ny;                   // one workgroup per CU (the slice is staged once per workgroup)
+    if (nb < 1) nb = 1;
+    XMC_ALLOW_BIG_LDS((pw1x1w_kernel<KS>));
+    hipLaunchKernelGGL((pw1x1w_kernel<KS>), dim3(nb, ny), dim3(512), lds, st, d, ngroups, ncols);
+    xmc_note_kernel("pw1x1w_kernel<%d>", KS);
+    XMC_LAUNCH_CHECK();
+    return 0;
+}
+
 // ---- 8 stored output channels (conv_out of the generator: 32 -> 3, df_gan.py:85-87, + bias + tanh).  On the 32-wide tile
 // kernel this layer multiplies 32 output channels for the 8 it stores and is bound by that waste (0.66 ms where its 1.34 GB
 // of tensors take 0.27 ms).  Here the output channels are the 16 rows of the MFMA (8 used), the B operand is the lane's
@@ -400,13 +493,18 @@ int xmc_conv_pw1x1_try(const XmcConvDesc* d, void* stream) {
     if (d->SH != d->MH || d->SW != d->MW || d->DH != d->MH || d->DW != d->MW) return 1;
     if (d->post_act || d->sign_bits || d->dot) return 1;
     if (d->res || d->mask || d->alpha_dev || d->dst2 || (d->act != XMC_ACT_NONE && d->act != XMC_ACT_LRELU)) return 1;
-    if (d->CS % 32 != 0 || d->CS > 128 || d->CDw % 32 != 0 || d->CDw > 128 || d->CD % 8 != 0) return 1;
-    const int ks = d->CS / 32, tn = d->CDw / 16;
-    if (ks * tn > 16 || ks == 3) return 1;
+    if (d->CS % 32 != 0 || d->CDw % 32 != 0 || d->CD % 8 != 0) return 1;
     const int64_t M = (int64_t)d->N * d->MH * d->MW;
     if (M % 16 != 0 || M / 16 >= (1ll << 31) || M < 16 * 1024) return 1;
     const int ngroups = (int)(M / 16);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int ks = d->CS / 32, tn = d->CDw / 16;
+    // more weight fragments than a wave's registers hold: weights in LDS (Cin 128 or 256, any Cout)
+    static const bool no_w = xmc_debug_off("no_pw1x1_lds");
+    if (!no_w && (ks == 4 || ks == 8) && ks * tn > 16 && d->CDw >= 128 && M >= 32 * 1024)
+        return ks == 4 ? launch_pww<4>(*d, ngroups, st) : launch_pww<8>(*d, ngroups, st);
+    if (d->CS > 128 || d->CDw > 128) return 1;
+    if (ks * tn > 16 || ks == 3) return 1;
 #define PW_CASE(K, T) if (ks == K && tn == T) return launch_pw<K, T>(*d, ngroups, st);
     PW_CASE(1, 2) PW_CASE(1, 4) PW_CASE(1, 8) PW_CASE(2, 2) PW_CASE(2, 4) PW_CASE(2, 8) PW_CASE(4, 2) PW_CASE(4, 4)
 #undef PW_CASE
