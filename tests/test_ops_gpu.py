@@ -100,6 +100,11 @@ CONV_CASES = [
     # streaming 1x1 kernel (conv_thin.hip pw1x1): >= 16 k pixels, Cin <= 128, Cout <= 128
     (32, 64, 1, 1, 0, 64, 4),      # shortcut conv of resD block 0 (on the pooled input): one K step
     (64, 128, 1, 1, 0, 32, 16),    # two K steps, 8 row blocks; its dgrad: four K steps, 4 row blocks
+    # deep-K steps of the gather kernel (KSUB 4) on the 4x4 maps: K >= 2048 with at most one workgroup per CU
+    (256, 256, 3, 1, 1, 4, 128),   # 64x128 tiles, K = 2304 (9 taps x 256: the last step is partial)
+    (512, 512, 3, 1, 1, 4, 512),   # 128x128 tiles, exactly 256 of them
+    (512, 512, 4, 2, 1, 8, 256),   # 4x4 stride 2 onto 4x4, K = 8192; its dgrad: four 2x2-tap classes on 4x4 grids
+    (768, 64, 3, 1, 1, 4, 95),     # the logit head's joint convolution at 3B-1 rows: 128x64 tiles, K = 6912
     # streaming 1x1 kernel with its weights in LDS (conv_thin.hip pw1x1w): Cin 128 / 256, >= 32 k pixels
     (128, 256, 1, 1, 0, 32, 40),   # shortcut of the 128 -> 256 block: one column slice; its dgrad (256 -> 128) the KS = 8 form
     (256, 512, 1, 1, 0, 16, 130),  # two column slices of 256; M = 33280 (last wave iteration partial); dgrad (Cin 512) on the gather kernel

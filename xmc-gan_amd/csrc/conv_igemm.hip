@@ -311,10 +311,27 @@ int dispatch(const XmcConvDesc& d, hipStream_t st) {
         if (DT == XMC_BF16 && M >= 256 * 256) return launch<DT, 256, 128, 2, 2, 1>(d, st);
         // few output pixels (the 4x4 / 8x8 maps at the end of D, K = 4608-8192): 128-row tiles would leave half the CUs idle
         static const bool no_m64 = xmc_debug_off("no_igemm_m64");
-        if (DT == XMC_BF16 && !no_m64 && (M + 127) / 128 * (d.CDw / 128) * d.nclass < 256) return launch<DT, 64, 128, 2, 2, 2>(d, st);
+        // deep K on a grid of at most one workgroup per CU (the 4x4 / 8x8 maps: K = 2304-8192, 128-256 tiles): every K step is one
+        // exposed memory round trip (~1.1 us measured per 64-deep step, MFMAs 0.1 us of it) and nothing else runs on the CU, so the
+        // steps are made twice as deep (KSUB 4: 98 / 131 KB of LDS, which only matters when a second workgroup would have fitted)
+        static const bool no_k4 = xmc_debug_off("no_igemm_ksub4");
+        const bool deepk = DT == XMC_BF16 && !no_k4 && (int64_t)d.ntaps * d.CS >= 2048;
+        const int64_t t128 = (M + 127) / 128 * (d.CDw / 128) * d.nclass;
+        if (DT == XMC_BF16 && !no_m64 && t128 < 256) {
+            if (deepk && (M + 63) / 64 * (d.CDw / 128) * d.nclass <= 256) return launch<DT, 64, 128, 2, 2, 4>(d, st);
+            return launch<DT, 64, 128, 2, 2, 2>(d, st);
+        }
+        if (deepk && t128 <= 256) return launch<DT, 128, 128, 2, 2, 4>(d, st);
         return launch<DT, 128, 128, 2, 2, 2>(d, st);
     }
-    if (d.CDw % 64 == 0) return launch<DT, 128, 64, 4, 1, 2>(d, st);
+    if (d.CDw % 64 == 0) {
+        // the joint convolution of the logit head (768 -> 64 on 4x4 maps, K = 6912, 32-96 workgroups): deep steps as above
+        static const bool no_k4b = xmc_debug_off("no_igemm_ksub4");
+        const int64_t Mb = (int64_t)d.N * d.MH * d.MW;
+        if (DT == XMC_BF16 && !no_k4b && (int64_t)d.ntaps * d.CS >= 2048 && (Mb + 127) / 128 * (d.CDw / 64) * d.nclass <= 256)
+            return launch<DT, 128, 64, 4, 1, 4>(d, st);
+        return launch<DT, 128, 64, 4, 1, 2>(d, st);
+    }
     return launch<DT, 128, 32, 4, 1, 2>(d, st);
 }
 
