@@ -55,26 +55,36 @@ class quant:
     """context manager / switch: `with X.quant(True): ...`.  ``skip``: site tags (prefix match, e.g. "d." or "g.w") that keep
     f32 storage; ``grad=False``: forward values are rounded, gradients pass through unrounded."""
 
-    def __init__(self, on=True, skip=(), grad=True, fmt=torch.bfloat16):
+    def __init__(self, on=True, skip=(), grad=True, fmt=torch.bfloat16, grad_scale=None):
+        """``grad_scale``: the factor the engine's backward passes run at in this format (ops.loss_scale(): 4096 for IEEE half, whose
+        5 exponent bits would otherwise put 1/B-sized gradients among the denormals; 1 for bf16) -- a gradient tensor is rounded as
+        round(g * scale) / scale, which is what the engine stores and later divides out."""
         self.on, self.skip, self.grad, self.fmt = bool(on), tuple(skip), bool(grad), fmt
+        self.gscale = float(grad_scale) if grad_scale is not None else (4096.0 if fmt == torch.float16 else 1.0)
 
     def __enter__(self):
-        global _QUANT, _QSKIP, _QGRAD, _QFMT
-        self.prev = (_QUANT, _QSKIP, _QGRAD, _QFMT)
-        _QUANT, _QGRAD, _QFMT = self.on, self.grad, self.fmt
+        global _QUANT, _QSKIP, _QGRAD, _QFMT, _QGSCALE
+        self.prev = (_QUANT, _QSKIP, _QGRAD, _QFMT, _QGSCALE)
+        _QUANT, _QGRAD, _QFMT, _QGSCALE = self.on, self.grad, self.fmt, self.gscale
         _QSKIP = frozenset(t for t in QUANT_SITES if any(t.startswith(p_) for p_ in self.skip))
         return self
 
     def __exit__(self, *a):
-        global _QUANT, _QSKIP, _QGRAD, _QFMT
-        _QUANT, _QSKIP, _QGRAD, _QFMT = self.prev
+        global _QUANT, _QSKIP, _QGRAD, _QFMT, _QGSCALE
+        _QUANT, _QSKIP, _QGRAD, _QFMT, _QGSCALE = self.prev
 
 
 _QFMT = torch.bfloat16     # the 16-bit storage format the mode rounds to (torch.float16: the what-if rung of the ladder)
+_QGSCALE = 1.0             # loss scale of the backward passes (see quant.__init__)
 
 
 def _bf16(t):
     return t.to(_QFMT).to(torch.float32)
+
+
+def _bf16g(g):
+    """a stored GRADIENT tensor: rounded at the engine's loss scale"""
+    return _bf16(g * _QGSCALE) / _QGSCALE if _QGSCALE != 1.0 else _bf16(g)
 
 
 class _QAct(torch.autograd.Function):
@@ -86,7 +96,7 @@ class _QAct(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        return _bf16(g) if _QGRAD else g
+        return _bf16g(g) if _QGRAD else g
 
 
 class _QWeight(torch.autograd.Function):
@@ -99,6 +109,27 @@ class _QWeight(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         return g
+
+
+class _QBranchTimesGamma(torch.autograd.Function):
+    """gamma * LeakyReLU(z) of a discriminator block as the engine's first-order path stores it (xmc_gan_amd/ops.py ResDFn /
+    ResDBwdFn): forward, the branch is rounded where it enters the block sum; backward, the engine keeps only the
+    branch's SIGN, rounds s * dout (`xmc_signmask_apply`) and applies gamma in f32 in the epilogue of the data gradient that
+    follows -- so the gradient handed to the convolution is gamma * round(s * dout), not round(gamma * dout) * s."""
+
+    @staticmethod
+    def forward(ctx, z, gamma):
+        r = _bf16(F.leaky_relu(z, LRELU))
+        ctx.save_for_backward(z, gamma, r)
+        return gamma * r
+
+    @staticmethod
+    def backward(ctx, g):
+        z, gamma, r = ctx.saved_tensors
+        sg = torch.where(z > 0, g, LRELU * g)
+        if _QGRAD:
+            sg = _bf16g(sg)
+        return gamma * sg, (g * r).sum().reshape(gamma.shape)
 
 
 def q(x, site=None):
@@ -811,10 +842,10 @@ def sn_weight(P, name, train=True, eps=1e-12):
     return W / sigma
 
 
-def netd_forward(P, h: Hyper, x):
+def netd_forward(P, h: Hyper, x, second_order=False):
     a = disc_arch(h.img_size, h.nch)
     if _QUANT:
-        return _netd_forward_q(P, h, x, a)
+        return _netd_forward_q(P, h, x, a, second_order)
     out = F.conv2d(x, sn_weight(P, "conv_img.weight"), P["conv_img.bias"], 1, 1)
     for i in range(1, a["depth"]):
         p = f"downblocks.{i - 1}"
@@ -828,18 +859,23 @@ def netd_forward(P, h: Hyper, x):
     return out
 
 
-def _netd_forward_q(P, h: Hyper, x, a):
+def _netd_forward_q(P, h: Hyper, x, a, second_order=False):
     """DF_DISC with the engine's storage points (image, every convolution output, the pooled shortcut input, the block sum) and
-    its order on the shortcut: average pool first, then the 1x1 convolution (they commute; df_gan.py:286-291)."""
+    its order on the shortcut: average pool first, then the 1x1 convolution (they commute; df_gan.py:286-291).
+    ``second_order``: the pass whose backward is differentiated again (MA-GP) -- there the engine stores the residual branch and
+    rounds gamma * s * dout in one pointwise pass; everywhere else it stores the branch's sign bits (_QBranchTimesGamma)."""
     out = q(F.conv2d(q(x, "d.img"), qw(sn_weight(P, "conv_img.weight"), "d.w"), P["conv_img.bias"], 1, 1), "d.conv_img")
     for i in range(1, a["depth"]):
         p = f"downblocks.{i - 1}"
         r = q(F.leaky_relu(F.conv2d(out, qw(sn_weight(P, f"{p}.conv_r.0.weight"), "d.w"), None, 2, 1), LRELU), "d.r0")
-        r = q(F.leaky_relu(F.conv2d(r, qw(sn_weight(P, f"{p}.conv_r.2.weight"), "d.w"), None, 1, 1), LRELU), "d.r2")
+        z = F.conv2d(r, qw(sn_weight(P, f"{p}.conv_r.2.weight"), "d.w"), None, 1, 1)
         s = q(F.avg_pool2d(out, 2), "d.pool")
         if a["cin"][i] != a["cout"][i]:
             s = q(F.conv2d(s, qw(sn_weight(P, f"{p}.conv_s.weight"), "d.w"), P[f"{p}.conv_s.bias"]), "d.sc")
-        out = q(s + P[f"{p}.gamma"] * r, "d.sum")
+        if second_order or "d.r2" in _QSKIP:
+            out = q(s + P[f"{p}.gamma"] * q(F.leaky_relu(z, LRELU), "d.r2"), "d.sum")
+        else:
+            out = q(s + _QBranchTimesGamma.apply(z, P[f"{p}.gamma"]), "d.sum")
     return out
 
 
@@ -1072,7 +1108,7 @@ def train_step(PG, PD, optG: AdamState, optD: AdamState, h: Hyper, batch, it_cou
         D = _leaves(PD)
         xi = imgs.detach().clone().requires_grad_()
         si = psent.detach().clone().requires_grad_()
-        o = cond_dnet(D, h, netd_forward(D, h, xi), si)
+        o = cond_dnet(D, h, netd_forward(D, h, xi, second_order=True), si)
         g0, g1 = torch.autograd.grad(o[0], (xi, si), torch.ones_like(o[0]), create_graph=True)
         gcat = torch.cat((g0.reshape(B, -1), g1.reshape(B, -1)), dim=1)
         gp = (gcat.pow(2).sum(1).sqrt() ** 6).mean()

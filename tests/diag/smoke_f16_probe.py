@@ -1,0 +1,37 @@
+"""smoke()'s IEEE-half leg without the assertion on the gradient tolerance: prints the worst generator-gradient tensors."""
+import os, sys
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import torch
+import xmc_ref as X
+from xmc_gan_amd import ops
+from parity_util import compare_grads, run_oracle_steps, run_product_steps, setup_cfg, rel_err
+mode = sys.argv[1] if len(sys.argv) > 1 else "f16"
+ops.set_precision(mode)
+cfg, h = setup_cfg("df_gan_damsm.yml", **{"TRAIN.NCH": 8})
+PG, PD = X.synth_params(X.gen_shapes(h), 5), X.synth_params(X.netd_shapes(h), 6)
+batches = [X.synth_batch(h, 4, seed=200, words_len=cfg.TEXT.MAX_LENGTH)]
+fmt = torch.float16 if mode == "f16" else torch.bfloat16
+_, _, o = run_oracle_steps(h, PG, PD, batches, eps=1e-3, quant=True, fmt=fmt)
+_, _, o32 = run_oracle_steps(h, PG, PD, batches, eps=1e-3)
+# argv[2]: which phases keep the residual branch VALUES (the pre-sign-bits form): "" none, "d" the D step, "g" the G step, "dg" both
+phases = sys.argv[2] if len(sys.argv) > 2 else ""
+import xmc_gan_amd.optim as _optim
+_calls = [0]
+_orig_step = _optim.HipAdam.step
+def _step(self, *a, **k):
+    _calls[0] += 1
+    return _orig_step(self, *a, **k)
+_optim.HipAdam.step = _step
+_orig_so = ops._second_order
+def _so():
+    ph = "d" if _calls[0] == 0 else ("m" if _calls[0] == 1 else "g")
+    return _orig_so() or (ph in phases)
+ops._second_order = _so
+_, _, p, tapG, tapD = run_product_steps(h, PG, PD, batches, eps=1e-3)
+for name, rec, ref, ref32 in (("D", tapD.records[0], o[0]["grads_D"], o32[0]["grads_D"]), ("G", tapG.records[0], o[0]["grads_G"], o32[0]["grads_G"])):
+    rows = sorted(((rel_err(rec[n], ref[n]), rel_err(rec[n], ref32[n]), rel_err(ref[n], ref32[n]), n) for n in ref if n in rec), reverse=True)
+    print(f"{name}: worst vs rounding oracle / engine vs f32 oracle / rounding oracle vs f32 oracle")
+    for e, e32, eo, n in rows[:5]:
+        print(f"   {e:.3e} {e32:.3e} {eo:.3e} {n}")
