@@ -110,6 +110,14 @@ template <> struct Vec8<XMC_F32> {
     }
 };
 
+// lane ^ 1 / lane ^ 2 exchange inside a quad as a DPP modifier of a VALU instruction: hipcc lowers __shfl_xor to ds_bpermute_b32, an
+// LDS-pipe instruction with its round trip (32 of them per tile in a pooled epilogue, beside the staging traffic)
+__device__ __forceinline__ float xmc_xor1(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));     // quad_perm:[1,0,3,2]
+}
+__device__ __forceinline__ float xmc_xor2(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));     // quad_perm:[2,3,0,1]
+}
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -114,9 +114,9 @@ __global__ __launch_bounds__(64) void concept_query_fwd_kernel(const float* __re
     float x = rows_dot64(Wq, E, s_sent, E, c);
     qraw[(size_t)b * 64 + c] = x;
     if (gnw) {                                        // GroupNorm over the SD values of a concept
-        float m = x + __shfl_xor(x, 1, 64); m += __shfl_xor(m, 2, 64); m *= 0.25f;
+        float m = x + xmc_xor1(x); m += xmc_xor2(m); m *= 0.25f;
         const float dx = x - m;
-        float v = dx * dx; v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v *= 0.25f;
+        float v = dx * dx; v += xmc_xor1(v); v += xmc_xor2(v); v *= 0.25f;
         x = dx * rsqrtf(v + eps) * gnw[c] + gnb[c];
     }
     q[(size_t)b * 64 + c] = x;
@@ -130,15 +130,15 @@ __global__ __launch_bounds__(64) void concept_query_bwd_kernel(const float* __re
     const float x = qraw[(size_t)b * 64 + c];
     float g = dq[(size_t)b * 64 + c];
     if (gnw) {
-        float m = x + __shfl_xor(x, 1, 64); m += __shfl_xor(m, 2, 64); m *= 0.25f;
+        float m = x + xmc_xor1(x); m += xmc_xor2(m); m *= 0.25f;
         const float dxm = x - m;
-        float v = dxm * dxm; v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v *= 0.25f;
+        float v = dxm * dxm; v += xmc_xor1(v); v += xmc_xor2(v); v *= 0.25f;
         const float rstd = rsqrtf(v + eps), xh = dxm * rstd;
         atomicAdd(&dgnw[c], g * xh);
         atomicAdd(&dgnb[c], g);
         const float gh = g * gnw[c];
-        float s1 = gh + __shfl_xor(gh, 1, 64); s1 += __shfl_xor(s1, 2, 64); s1 *= 0.25f;
-        float s2 = gh * xh; s2 += __shfl_xor(s2, 1, 64); s2 += __shfl_xor(s2, 2, 64); s2 *= 0.25f;
+        float s1 = gh + xmc_xor1(gh); s1 += xmc_xor2(s1); s1 *= 0.25f;
+        float s2 = gh * xh; s2 += xmc_xor1(s2); s2 += xmc_xor2(s2); s2 *= 0.25f;
         g = rstd * (gh - s1 - xh * s2);
     }
     dx[(size_t)b * 64 + c] = g;
@@ -154,9 +154,9 @@ __global__ __launch_bounds__(64) void concept_gquery_fwd_kernel(const float* __r
     for (int i = 0; i < PWD; ++i) x += Wq[c * PWD + i] * q0[(size_t)b * CARD * PWD + g * PWD + i];
     qraw[(size_t)b * 64 + c] = x;
     if (gnw) {
-        float m = x + __shfl_xor(x, 1, 64); m += __shfl_xor(m, 2, 64); m *= 0.25f;
+        float m = x + xmc_xor1(x); m += xmc_xor2(m); m *= 0.25f;
         const float dx = x - m;
-        float v = dx * dx; v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v *= 0.25f;
+        float v = dx * dx; v += xmc_xor1(v); v += xmc_xor2(v); v *= 0.25f;
         x = dx * rsqrtf(v + eps) * gnw[c] + gnb[c];
     }
     q[(size_t)b * 64 + c] = x;
@@ -172,15 +172,15 @@ __global__ __launch_bounds__(64) void concept_gquery_bwd_kernel(const float* __r
     const float x = qraw[(size_t)b * 64 + c];
     float gr = dq[(size_t)b * 64 + c];
     if (gnw) {
-        float m = x + __shfl_xor(x, 1, 64); m += __shfl_xor(m, 2, 64); m *= 0.25f;
+        float m = x + xmc_xor1(x); m += xmc_xor2(m); m *= 0.25f;
         const float dxm = x - m;
-        float v = dxm * dxm; v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v *= 0.25f;
+        float v = dxm * dxm; v += xmc_xor1(v); v += xmc_xor2(v); v *= 0.25f;
         const float rstd = rsqrtf(v + eps), xh = dxm * rstd;
         atomicAdd(&dgnw[c], gr * xh);
         atomicAdd(&dgnb[c], gr);
         const float gh = gr * gnw[c];
-        float s1 = gh + __shfl_xor(gh, 1, 64); s1 += __shfl_xor(s1, 2, 64); s1 *= 0.25f;
-        float s2 = gh * xh; s2 += __shfl_xor(s2, 1, 64); s2 += __shfl_xor(s2, 2, 64); s2 *= 0.25f;
+        float s1 = gh + xmc_xor1(gh); s1 += xmc_xor2(s1); s1 *= 0.25f;
+        float s2 = gh * xh; s2 += xmc_xor1(s2); s2 += xmc_xor2(s2); s2 *= 0.25f;
         gr = rstd * (gh - s1 - xh * s2);
     }
     s_dx[c] = gr;
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(64) void concept_head_bwd_kernel(const float* __res
         if (P.Ws) {                       // c[g][d] = att[g] r[g][d], att = softmax_g(l), l[g] = <s, r[g]>, s = Ws sent
             const float dc = dr;
             float da_g = dc * S.r[g][d];                          // d att[g] = <dc[g], r[g]>
-            da_g += __shfl_xor(da_g, 1, 64); da_g += __shfl_xor(da_g, 2, 64);
+            da_g += xmc_xor1(da_g); da_g += xmc_xor2(da_g);
             float dot = (d == 0) ? S.att[g] * da_g : 0.f;         // sum_g att[g] d att[g]
 #pragma unroll
             for (int o = 32; o >= 1; o >>= 1) dot += __shfl_xor(dot, o, 64);

@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void thin_in_kernel(const XmcConvDesc d, const
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
                         float sm = fin[0][u][q] + fin[1][u][q];
-                        sm += __shfl_xor(sm, 1, 64);
+                        sm += xmc_xor1(sm);
                         o[q] = (xmc_h16)(pscale * sm);
                     }
                     if ((fr & 1) == 0) pool8[((img * (d.DH >> 1) + prow) * (d.DW >> 1) + pcol) * cd8 + fc * UPL + u] = o;

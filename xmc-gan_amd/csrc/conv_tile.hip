@@ -542,7 +542,7 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
 #pragma unroll
                                 for (int r = 0; r < 8; ++r) {
                                     float sm = fin[0][v2][r] + fin[1][v2][r];
-                                    sm += __shfl_xor(sm, 1, 64);
+                                    sm += xmc_xor1(sm);
                                     o[r] = (xmc_h16)(pscale * sm);
                                 }
                                 if ((l32 & 1) == 0)
@@ -555,7 +555,7 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
                                     for (int r = 0; r < 8; ++r) {
                                         float sm = fin[pb][v2][r];
                                         sm += __shfl_xor(sm, 16, 64);
-                                        sm += __shfl_xor(sm, 1, 64);
+                                        sm += xmc_xor1(sm);
                                         o[r] = (xmc_h16)(pscale * sm);
                                     }
                                     if ((l32 & 17) == 0)
@@ -851,7 +851,7 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
 #pragma unroll
                             for (int q = 0; q < 8; ++q) {
                                 float sm = t.log2TW == 5 ? fin[pr][q] + fin[(pr + 2) % TM][q] : fin[(2 * pr) % TM][q] + fin[(2 * pr + 1) % TM][q];
-                                sm += __shfl_xor(sm, 1, 64);
+                                sm += xmc_xor1(sm);
                                 o[q] = (xmc_h16)(pscale * sm);
                             }
                             if ((fr & 1) == 0)

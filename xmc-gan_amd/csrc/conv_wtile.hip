@@ -405,7 +405,7 @@ __global__ __launch_bounds__(64 * CW + 256) void wtile2_kernel(const XmcConvDesc
 #pragma unroll
                         for (int r = 0; r < 8; ++r) {
                             float sm = (t.log2TW == 5 ? fin[pr][r] + fin[pr + 2][r] : fin[2 * pr][r] + fin[2 * pr + 1][r]);
-                            sm += __shfl_xor(sm, 1, 64);
+                            sm += xmc_xor1(sm);
                             o[r] = (xmc_h16)((d.pool_scale == 0.f ? 0.25f : d.pool_scale) * sm);
                         }
                         (void)i1;
