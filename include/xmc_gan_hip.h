@@ -26,7 +26,7 @@ extern "C" {
 
 /* 2: XmcConvDesc gained dst2 / dst_pool / round_act / groups, alpha applies only with alpha_dev, return codes are
  *    0 / XMC_E* / -(1000 + hipError_t); xmc_half_format() added.  lib.py refuses a library of another version. */
-#define XMC_ABI_VERSION 4
+#define XMC_ABI_VERSION 5
 
 /* XMC_BF16 names the 16-bit storage / MFMA-operand format THIS BUILD of the library was compiled for: bf16 in
  * libxmc_gan_hip.so, IEEE half in libxmc_gan_hip_f16.so (same sources, same entry points; xmc_half_format()). */
@@ -191,6 +191,11 @@ int xmc_lrelu_mask(const void* dy, const void* ref, void* dx, int64_t n, float s
 int xmc_tanh(const void* x, void* y, int64_t n, int dtype, void* stream);
 /* dx = dy * LeakyReLU'(branch), the branch given as sign bits (XmcConvDesc.sign_bits layout: byte i = the 8 elements 8i .. 8i+7) */
 int xmc_signmask_apply(const void* dy, const void* bits, void* dx, int64_t n, float slope, int dtype, void* stream);
+/* A 1x1 convolution (ntaps == 1, unit stride: the discriminator's learned shortcut, df_gan.py:280,286-291, or its data gradient) on the
+ * streaming kernels ONLY, writing as a by-product the masked copy of its SOURCE: src_masked = src * LeakyReLU'(src_bits), bits in the
+ * XmcConvDesc.sign_bits layout of the source tensor -- the backward of a block reads `dout` once for both.  Returns 1 (nothing
+ * launched) when the shape is not one the streaming kernels take; the caller then uses xmc_conv_igemm + xmc_signmask_apply.  (ABI 5) */
+int xmc_conv_pw1x1_masked_src(const XmcConvDesc* d, const void* src_bits, void* src_masked, float slope, void* stream);
 int xmc_tanh_bwd(const void* dy, const void* y, void* dx, int64_t n, int dtype, void* stream);
 /* y = a + (*alpha_dev) * b                  (shortcut + gamma*residual, df_gan.py:200,284) */
 int xmc_axpby(const void* a, const void* b, const float* alpha_dev, void* y, int64_t n, int dtype, void* stream);

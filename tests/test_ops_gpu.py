@@ -623,6 +623,28 @@ def test_multi_image_tiles_equal_the_small_batch_kernels(N):
     check("resD 256->512 16 -> 8", lambda xd: (blk(xd), ""), x, r, want_kernel=False, tol=5e-3)
 
 
+@pytest.mark.parametrize("N,H,cin,cout", [(16, 32, 32, 64), (64, 32, 64, 128), (40, 32, 128, 256), (130, 16, 256, 512), (2, 8, 32, 64)])
+def test_shortcut_data_gradient_writes_the_masked_gradient_as_a_by_product(N, H, cin, cout):
+    """xmc_conv_pw1x1_masked_src (include/xmc_gan_hip.h): the streaming 1x1 kernels, reading `dout` as the source of the learned
+    shortcut's data gradient, also write dout x LeakyReLU'(sign bits) -- both outputs bit-equal to the two separate launches
+    (xmc_conv_igemm, xmc_signmask_apply).  Shapes: registers-resident weights (Cin of the data gradient 64 / 128), weights in LDS
+    (256 / 512: the 512-channel source is declined by the streaming kernels and takes the fallback), and a map too small for them."""
+    ops.set_precision("bf16")
+    dt = ops.act_dtype()
+    g = torch.Generator().manual_seed(N + cin)
+    dout = torch.randn(N, H, H, cout, generator=g).to(DEV).to(dt)
+    bits = torch.randint(0, 256, (N, H, H, cout // 8), generator=g, dtype=torch.int64).to(torch.uint8).to(DEV)
+    ws = (torch.randn(cout, cin, 1, 1, generator=g) / math.sqrt(cin)).to(DEV)
+    gs = ops.ConvGeom(cin, cout, 1, 1, 0)
+    dx_ref = ops._conv_dgrad_raw(dout, ws, gs, (H, H), dt)
+    gr_ref = torch.empty_like(dout)
+    L.call("xmc_signmask_apply", dout.data_ptr(), bits.data_ptr(), gr_ref.data_ptr(), dout.numel(), 0.2, ops._code(dt), ops._st())
+    dx, gr = ops._conv_dgrad_raw(dout, ws, gs, (H, H), dt, src_bits=bits)
+    print(L.load().xmc_last_kernel().decode())
+    assert torch.equal(gr, gr_ref)
+    assert torch.equal(dx, dx_ref)
+
+
 def test_fused_discriminator_block_refuses_second_derivative_without_the_branch():
     """A block that kept only sign bits cannot be differentiated twice: it says so instead of returning a wrong penalty."""
     from xmc_gan.model.df_gan import resD

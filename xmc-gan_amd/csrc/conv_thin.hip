@@ -176,8 +176,22 @@ __global__ __launch_bounds__(256) void thin_in_kernel(const XmcConvDesc d, const
 // their data gradients): nothing to stage -- a lane's 16-byte unit of a pixel IS its K-fragment, so the source goes straight
 // from global memory into the MFMA B operand (16 pixels x 64 bytes per wave load, fully coalesced), the weights (<= 16
 // fragments) live in registers, and the result leaves in 64-byte-per-pixel contiguous stores.  Pure stream: HBM bound.
-template <int KS, int TN>                     // KS = Cin / 32 K-steps, TN = Cout(padded) / 16 row blocks
-__global__ __launch_bounds__(256) void pw1x1_kernel(const XmcConvDesc d, int ngroups) {
+// By-product for the backward pass of a discriminator block (ops.ResDBwdFn): the kernel that streams `dout` as the SOURCE
+// of the shortcut's data gradient also writes `dout x LeakyReLU'(branch)` from the block's sign bits (MASKED: src_masked[unit] =
+// src[unit] with the lanes of cleared bits times `slope`, rounded like xmc_signmask_apply) -- the separate mask pass read dout again.
+__device__ __forceinline__ u32x4 mask_unit(u32x4 v, unsigned bits, float slope) {
+    bf16x8 h = __builtin_bit_cast(bf16x8, v);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float f = (float)h[k];
+        h[k] = (xmc_h16)(((bits >> k) & 1u) ? f : slope * f);
+    }
+    return __builtin_bit_cast(u32x4, h);
+}
+
+template <int KS, int TN, bool MASKED = false>                     // KS = Cin / 32 K-steps, TN = Cout(padded) / 16 row blocks
+__global__ __launch_bounds__(256) void pw1x1_kernel(const XmcConvDesc d, int ngroups, const unsigned char* __restrict__ sbits, u32x4* __restrict__ smasked,
+                                                    float mslope) {
     const int lane = threadIdx.x & 63, fr = lane & 15, fc = lane >> 4;
     const int cs_units = d.CS >> 3, cd8 = d.CD >> 3;
     const u32x4* __restrict__ src16 = reinterpret_cast<const u32x4*>(d.src);
@@ -205,6 +219,17 @@ __global__ __launch_bounds__(256) void pw1x1_kernel(const XmcConvDesc d, int ngr
             const int g = g0 + r < ngroups ? g0 + r : ngroups - 1;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) pf[r][ks] = src16[(size_t)(g * 16 + fr) * cs_units + ks * 4 + fc];
+        }
+        if (MASKED) {
+#pragma unroll
+            for (int r = 0; r < UNR; ++r) {
+                if (g0 + r >= ngroups) break;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const size_t idx = (size_t)((g0 + r) * 16 + fr) * cs_units + ks * 4 + fc;
+                    smasked[idx] = mask_unit(pf[r][ks], sbits[idx], mslope);
+                }
+            }
         }
 #pragma unroll
         for (int r = 0; r < UNR; ++r) {
@@ -235,11 +260,12 @@ __global__ __launch_bounds__(256) void pw1x1_kernel(const XmcConvDesc d, int ngr
 }
 
 template <int KS, int TN>
-int launch_pw(const XmcConvDesc& d, int ngroups, hipStream_t st) {
+int launch_pw(const XmcConvDesc& d, int ngroups, hipStream_t st, const unsigned char* sbits, void* smasked, float mslope) {
     int nb = (ngroups + 4 * 4 - 1) / (4 * 4);           // 4 waves per block, 4 groups per wave and iteration
     if (nb > 256 * 8) nb = 256 * 8;
-    hipLaunchKernelGGL((pw1x1_kernel<KS, TN>), dim3(nb), dim3(256), 0, st, d, ngroups);
-    xmc_note_kernel("pw1x1_kernel<%d, %d>", KS, TN);
+    if (smasked) hipLaunchKernelGGL((pw1x1_kernel<KS, TN, true>), dim3(nb), dim3(256), 0, st, d, ngroups, sbits, (u32x4*)smasked, mslope);
+    else hipLaunchKernelGGL((pw1x1_kernel<KS, TN, false>), dim3(nb), dim3(256), 0, st, d, ngroups, nullptr, nullptr, 0.f);
+    xmc_note_kernel(smasked ? "pw1x1_kernel<%d, %d, true>" : "pw1x1_kernel<%d, %d>", KS, TN);
     XMC_LAUNCH_CHECK();
     return 0;
 }
@@ -251,8 +277,9 @@ int launch_pw(const XmcConvDesc& d, int ngroups, hipStream_t st) {
 // wave, each weight fragment read once per 64 pixels, 64-byte-per-pixel stores.  8 waves per workgroup (2 per SIMD) share the
 // slice.  85-170 FLOP/byte: an HBM stream (the gather kernel ran these at 1.7-2.6 TB/s: two K steps of prologue and an LDS
 // transposition of the result per 256x256 tile).
-template <int KS>                             // KS = Cin / 32 K-steps (4 or 8)
-__global__ __launch_bounds__(512) void pw1x1w_kernel(const XmcConvDesc d, int ngroups, int ncols) {
+template <int KS, bool MASKED = false>        // KS = Cin / 32 K-steps (4 or 8); MASKED: see pw1x1_kernel (the first column slice writes it)
+__global__ __launch_bounds__(512) void pw1x1w_kernel(const XmcConvDesc d, int ngroups, int ncols, const unsigned char* __restrict__ sbits,
+                                                     u32x4* __restrict__ smasked, float mslope) {
     extern __shared__ __attribute__((aligned(16))) unsigned char wlds[];
     constexpr int RSTR = KS * 64 + 16;         // bytes per weight row
     const int tid = threadIdx.x, lane = tid & 63, fr = lane & 15, fc = lane >> 4;
@@ -281,6 +308,17 @@ __global__ __launch_bounds__(512) void pw1x1w_kernel(const XmcConvDesc d, int ng
             const int g = g0 + r < ngroups ? g0 + r : ngroups - 1;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) pf[r][ks] = src16[(size_t)(g * 16 + fr) * cs_units + ks * 4 + fc];
+        }
+        if (MASKED && blockIdx.y == 0) {
+#pragma unroll
+            for (int r = 0; r < UNR; ++r) {
+                if (g0 + r >= ngroups) break;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const size_t idx = (size_t)((g0 + r) * 16 + fr) * cs_units + ks * 4 + fc;
+                    smasked[idx] = mask_unit(pf[r][ks], sbits[idx], mslope);
+                }
+            }
         }
         for (int u = 0; u < nu; ++u) {
             f32x4 acc[UNR][2];
@@ -318,7 +356,7 @@ __global__ __launch_bounds__(512) void pw1x1w_kernel(const XmcConvDesc d, int ng
 }
 
 template <int KS>
-int launch_pww(const XmcConvDesc& d, int ngroups, hipStream_t st) {
+int launch_pww(const XmcConvDesc& d, int ngroups, hipStream_t st, const unsigned char* sbits, void* smasked, float mslope) {
     // the column slice of a workgroup: as many 32-channel units as fit in LDS, dividing CDw evenly (256 x 512: two slices of 135 KB)
     constexpr int RSTR = KS * 64 + 16;
     int ny = 1;
@@ -330,9 +368,14 @@ int launch_pww(const XmcConvDesc& d, int ngroups, hipStream_t st) {
     int nb = (ngroups + 8 * 4 - 1) / (8 * 4);           // 8 waves per block, 4 groups per wave and iteration
     if (nb > 256 / ny) nb = 256 / ny;                   // one workgroup per CU (the slice is staged once per workgroup)
     if (nb < 1) nb = 1;
-    XMC_ALLOW_BIG_LDS((pw1x1w_kernel<KS>));
-    hipLaunchKernelGGL((pw1x1w_kernel<KS>), dim3(nb, ny), dim3(512), lds, st, d, ngroups, ncols);
-    xmc_note_kernel("pw1x1w_kernel<%d>", KS);
+    if (smasked) {
+        XMC_ALLOW_BIG_LDS((pw1x1w_kernel<KS, true>));
+        hipLaunchKernelGGL((pw1x1w_kernel<KS, true>), dim3(nb, ny), dim3(512), lds, st, d, ngroups, ncols, sbits, (u32x4*)smasked, mslope);
+    } else {
+        XMC_ALLOW_BIG_LDS((pw1x1w_kernel<KS, false>));
+        hipLaunchKernelGGL((pw1x1w_kernel<KS, false>), dim3(nb, ny), dim3(512), lds, st, d, ngroups, ncols, nullptr, nullptr, 0.f);
+    }
+    xmc_note_kernel(smasked ? "pw1x1w_kernel<%d, true>" : "pw1x1w_kernel<%d>", KS);
     XMC_LAUNCH_CHECK();
     return 0;
 }
@@ -484,7 +527,7 @@ int xmc_conv_thin_try(const XmcConvDesc* d, void* stream) {
 }
 
 // 0 = launched, 1 = not this kernel's case, < 0 = error
-int xmc_conv_pw1x1_try(const XmcConvDesc* d, void* stream) {
+static int pw1x1_go(const XmcConvDesc* d, void* stream, const unsigned char* sbits, void* smasked, float mslope) {
     static const bool off = xmc_debug_off("no_pw1x1");
     if (off) return 1;
     if (d->dtype != XMC_BF16 || d->out_dtype != XMC_BF16) return 1;
@@ -502,11 +545,25 @@ int xmc_conv_pw1x1_try(const XmcConvDesc* d, void* stream) {
     // more weight fragments than a wave's registers hold: weights in LDS (Cin 128 or 256, any Cout)
     static const bool no_w = xmc_debug_off("no_pw1x1_lds");
     if (!no_w && (ks == 4 || ks == 8) && ks * tn > 16 && d->CDw >= 128 && M >= 32 * 1024)
-        return ks == 4 ? launch_pww<4>(*d, ngroups, st) : launch_pww<8>(*d, ngroups, st);
+        return ks == 4 ? launch_pww<4>(*d, ngroups, st, sbits, smasked, mslope) : launch_pww<8>(*d, ngroups, st, sbits, smasked, mslope);
     if (d->CS > 128 || d->CDw > 128) return 1;
     if (ks * tn > 16 || ks == 3) return 1;
-#define PW_CASE(K, T) if (ks == K && tn == T) return launch_pw<K, T>(*d, ngroups, st);
+#define PW_CASE(K, T) if (ks == K && tn == T) return launch_pw<K, T>(*d, ngroups, st, sbits, smasked, mslope);
     PW_CASE(1, 2) PW_CASE(1, 4) PW_CASE(1, 8) PW_CASE(2, 2) PW_CASE(2, 4) PW_CASE(2, 8) PW_CASE(4, 2) PW_CASE(4, 4)
 #undef PW_CASE
     return 1;
+}
+
+int xmc_conv_pw1x1_try(const XmcConvDesc* d, void* stream) { return pw1x1_go(d, stream, nullptr, nullptr, 0.f); }
+
+// The 1x1 convolution of `d` on the streaming kernels only, with the masked copy of its SOURCE as a by-product (see mask_unit):
+// src_masked[unit] = src[unit] x LeakyReLU'(bit) from one sign byte per 8-channel unit (XmcConvDesc.sign_bits layout of the source
+// tensor).  Returns 1 and launches nothing when the shape is not one of theirs -- the caller then runs xmc_conv_igemm and
+// xmc_signmask_apply separately.
+extern "C" int xmc_conv_pw1x1_masked_src(const XmcConvDesc* d, const void* src_bits, void* src_masked, float slope, void* stream) {
+    if (!d || !d->src || !d->wpk || !d->dst || !src_bits || !src_masked) return XMC_EINVAL;
+    if (d->ntaps != 1 || d->CS % 8 != 0 || d->CD % 8 != 0 || d->CDw % 32 != 0 || d->CDw < d->CD || d->N < 1 || d->MH < 1 || d->MW < 1) return XMC_ESHAPE;
+    static const bool off = xmc_debug_off("no_pw1x1_masked_src");
+    if (off) return 1;
+    return pw1x1_go(d, stream, static_cast<const unsigned char*>(src_bits), src_masked, slope);
 }

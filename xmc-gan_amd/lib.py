@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("XMC_LIB_PATH", os.path.join(HERE, "libxmc_gan_hip.so"))   # override: kernel experiments
 LIB_PATH_F16 = os.environ.get("XMC_LIB_PATH_F16", os.path.join(HERE, "libxmc_gan_hip_f16.so"))
-ABI_VERSION = 4          # include/xmc_gan_hip.h XMC_ABI_VERSION; the ctypes structures below mirror that version
+ABI_VERSION = 5          # include/xmc_gan_hip.h XMC_ABI_VERSION; the ctypes structures below mirror that version
 
 # BF16 is the dtype code of "the 16-bit storage format of the loaded build": bf16 in libxmc_gan_hip.so, IEEE half in
 # libxmc_gan_hip_f16.so (the same sources compiled with -DXMC_H16_IS_F16; `use_variant`)
@@ -73,6 +73,7 @@ _SIGS = {
     "xmc_lrelu_mask": [vp, vp, vp, i64, f32, i32, vp],
     "xmc_tanh": [vp, vp, i64, i32, vp],
     "xmc_signmask_apply": [vp, vp, vp, i64, f32, i32, vp],
+    "xmc_conv_pw1x1_masked_src": [C.POINTER(ConvDesc), vp, vp, f32, vp],
     "xmc_tanh_bwd": [vp, vp, vp, i64, i32, vp],
     "xmc_axpby": [vp, vp, vp, vp, i64, i32, vp],
     "xmc_scale_mask_dot": [vp, vp, vp, vp, vp, i64, i32, vp],

@@ -467,7 +467,7 @@ def _conv_fwd_raw(x, w, bias, geom, act, out_dtype, res=None, alpha=None, up=Fal
 
 
 def _conv_dgrad_raw(dy, w, geom, in_hw, in_dtype, mask=None, res=None, res_rows=False, res_scale=1.0, alpha=None, want_sumpool=False,
-                    dot=None):
+                    dot=None, src_bits=None):
     """dx [N,H,W,cin_p] from dy [N,OH,OW,cout_p].  Epilogue options: ``mask`` (dx layout): dx *= LeakyReLU'(mask);
     ``res``: dx += res_scale * res, with ``res_rows`` the residual is [N,H/s,W/s,cin_p] and every pixel of it is added to its
     s x s block of dx (s == 2: the adjoint of avg_pool2d, df_gan.py:290).  ``want_sumpool`` (stride 1): returns (dx, 2x2 sum pool
@@ -521,6 +521,20 @@ def _conv_dgrad_raw(dy, w, geom, in_hw, in_dtype, mask=None, res=None, res_rows=
         assert s == 1 and H % 2 == 0 and W % 2 == 0 and in_dtype == dy.dtype
         dxp = torch.empty((N, H // 2, W // 2, cs_p), dtype=in_dtype, device=dy.device)
         d.dst_pool, d.pool_scale = dxp.data_ptr(), 1.0
+    if src_bits is not None:
+        # ``src_bits`` (sign bytes in dy's layout): also return dy x LeakyReLU'(bits).  The streaming 1x1 kernels write it while they
+        # read dy (xmc_conv_pw1x1_masked_src); any other shape runs the data gradient and the mask pass separately.
+        assert k == 1 and s == 1 and not want_sumpool and src_bits.dtype == torch.uint8 and src_bits.numel() * 8 == dy.numel()
+        dym = torch.empty_like(dy)
+        with prof.launch("igemm_kernel (conv fwd+dgrad, MFMA implicit GEMM)", 2.0 * N * OH * OW * geom.cout * geom.cin,
+                         f"dgrad+srcmask {dy.dtype} N{N} {H}x{W} {geom.cin}->{geom.cout} k1s1", _nbytes(dy, wpk, dx, dym)):
+            rc = L.load().xmc_conv_pw1x1_masked_src(C.byref(d), _p(src_bits), _p(dym), 0.2, _st())
+            if rc == 1:
+                L.check(L.load().xmc_conv_igemm(C.byref(d), _st()), "xmc_conv_igemm(dgrad)")
+                L.call("xmc_signmask_apply", _p(dy), _p(src_bits), _p(dym), dy.numel(), 0.2, _code(dy.dtype), _st())
+            else:
+                L.check(rc, "xmc_conv_pw1x1_masked_src")
+        return dx, dym
     with prof.launch("igemm_kernel (conv fwd+dgrad, MFMA implicit GEMM)", 2.0 * N * OH * OW * geom.cout * geom.cin * geom.k * geom.k,
                      f"dgrad {dy.dtype} N{N} {H}x{W} {geom.cin}->{geom.cout} k{geom.k}s{geom.s}", _nbytes(dy, wpk, dx, mask, res, dxp)):
         L.check(L.load().xmc_conv_igemm(C.byref(d), _st()), "xmc_conv_igemm(dgrad)")
@@ -1473,11 +1487,18 @@ class ResDBwdFn(torch.autograd.Function):
             #   <dout, branch> = <s * dout, C2 h1> = <C2^T (s * dout), h1>
             # so the data gradient of conv_r[2] runs on the UNSCALED s * dout, accumulates the dot with h1 -- the tensor it reads as
             # its LeakyReLU' mask anyway -- before it applies gamma, and the weight gradient takes gamma as its scale.
-            gr = torch.empty_like(dout)
-            L.call("xmc_signmask_apply", _p(dout), _p(res), _p(gr), dout.numel(), 0.2, _code(dt), _st())
+            # s * dout comes out of the kernel that streams dout for the shortcut's data gradient where there is one (a learned 1x1
+            # shortcut whose input gradient is needed), else from the mask pass
+            gr = dxp_early = None
+            if learned and need[0] and "no_pw1x1_masked_src" not in _DEBUG_DISPATCH:
+                dxp_early, gr = _conv_dgrad_raw(dout, ws, gs, (xp.shape[1], xp.shape[2]), dt, src_bits=res)
+            if gr is None:
+                gr = torch.empty_like(dout)
+                L.call("xmc_signmask_apply", _p(dout), _p(res), _p(gr), dout.numel(), 0.2, _code(dt), _st())
             dw2 = _conv_wgrad_raw(h1, gr, g2, scale=al).view(w2.shape) if (need[2] and not skip_w) else None
             gh = _conv_dgrad_raw(gr, w2, g2, (h1.shape[1], h1.shape[2]), dt, mask=h1, alpha=al, dot=dgam)
         else:
+            dxp_early = None
             gr = torch.empty_like(res)
             L.call("xmc_scale_mask_dot", _p(dout), _p(res), _p(al), _p(gr), _p(dgam), res.numel(), _code(dt), _st())
             dw2 = _conv_wgrad_raw(h1, gr, g2).view(w2.shape) if (need[2] and not skip_w) else None
@@ -1493,7 +1514,7 @@ class ResDBwdFn(torch.autograd.Function):
                 else:
                     dws = _conv_wgrad_raw(xp, dout, gs)
                 dws = dws.view(ws.shape)
-            dxp = _conv_dgrad_raw(dout, ws, gs, (xp.shape[1], xp.shape[2]), dt) if need[0] else None
+            dxp = dxp_early if dxp_early is not None else (_conv_dgrad_raw(dout, ws, gs, (xp.shape[1], xp.shape[2]), dt) if need[0] else None)
         else:
             dxp = dout
         dx = None
