@@ -390,7 +390,7 @@ __global__ void affine2_fwd_kernel(const void* x, const float* g0, const float* 
 // other: four dependent round trips per step and half-line accesses -- 3.9 ms per iteration for what the pooling pass did in 0.5.)
 // Needs C8 a power of two <= 32 (the column neighbour is lane ^ C8), even W, H.
 template <int DT, bool POOL>
-__global__ __launch_bounds__(NT, POOL ? 2 : 4) void affine2_bwd_kernel(        // POOL: two pixels' operands live at once, 128 registers spill
+__global__ __launch_bounds__(NT, 2) void affine2_bwd_kernel(        // two pixels' operands live at once: 128 registers spill
                                    const void* x, const void* dy, const float* g0, const float* b0, const float* g1,
                                    const float* b1, void* dx, float* dg0, float* db0, float* dg1, float* db1,
                                    int HW, int C8, int pix_per_block, float slope, const void* dx_in,
@@ -442,14 +442,21 @@ __global__ __launch_bounds__(NT, POOL ? 2 : 4) void affine2_bwd_kernel(        /
     };
     const int p_end = min(HW, (int)(blockIdx.x + 1) * pix_per_block);
     if (g < groups)
-        for (int p = blockIdx.x * pix_per_block + g; p < p_end; p += groups) {
+        for (int p = blockIdx.x * pix_per_block + g; p < p_end; p += POOL ? groups : 2 * groups) {
             if (!POOL) {
-                float xv[8], dv[8], o[8];
+                // two pixels' operands in flight per thread (one pixel per iteration measured 4.1 TB/s where the pooled form, which
+                // has always loaded two, reaches 4.8)
+                float xv[8], dv[8], o[8], xw[8], dw[8], ow[8];
                 const size_t idx = ((size_t)n * HW + p) * C8 + cc;
+                const bool second = p + groups < p_end;
+                const size_t idx2 = second ? idx + (size_t)groups * C8 : idx;
                 Vec8<DT>::load(x, idx, xv);
+                Vec8<DT>::load(x, idx2, xw);
                 Vec8<DT>::load(dy, idx, dv);
-                if (dx_in) Vec8<DT>::load(dx_in, idx, o);
+                Vec8<DT>::load(dy, idx2, dw);
+                if (dx_in) { Vec8<DT>::load(dx_in, idx, o); Vec8<DT>::load(dx_in, idx2, ow); }
                 pixel(idx, xv, dv, o, nullptr);
+                if (second) pixel(idx2, xw, dw, ow, nullptr);
             } else {
                 const int W = 2 * Wq;
                 const int qy = p / W, col = p - qy * W;
