@@ -24,9 +24,15 @@
 extern "C" {
 #endif
 
-/* 2: XmcConvDesc gained dst2 / dst_pool / round_act / groups, alpha applies only with alpha_dev, return codes are
- *    0 / XMC_E* / -(1000 + hipError_t); xmc_half_format() added.  lib.py refuses a library of another version. */
-#define XMC_ABI_VERSION 5
+/* ABI history (lib.py refuses a library of another version):
+ * 2: XmcConvDesc gained dst2 / dst_pool / round_act / groups, alpha applies only with alpha_dev, return codes are
+ *    0 / XMC_E* / -(1000 + hipError_t); xmc_half_format() added.
+ * 3: XmcConvDesc.post_act / pool_scale (an activation after the residual; the scale of the pooled third output);
+ *    xmc_adam_step gained grad_scale.
+ * 4: XmcConvDesc.sign_bits / dot (a discriminator block keeps sign bits; d(gamma) from a data-gradient epilogue).
+ * 5: xmc_conv_pw1x1_masked_src (the sign-mask pass as a by-product of the shortcut's data gradient).
+ * 6: xmc_adam_step_scaled (dynamic loss scale with a found-inf skip); xmc_gp_finish gained inv_s2. */
+#define XMC_ABI_VERSION 6
 
 /* XMC_BF16 names the 16-bit storage / MFMA-operand format THIS BUILD of the library was compiled for: bf16 in
  * libxmc_gan_hip.so, IEEE half in libxmc_gan_hip_f16.so (same sources, same entry points; xmc_half_format()). */
@@ -387,13 +393,24 @@ typedef struct XmcAdamEntry {
 int xmc_adam_chunk_elems(void);
 int xmc_adam_step(const XmcAdamEntry* table_dev, int ntensors, const int32_t* chunks_dev, int nchunks,
                   float lr, float beta1, float beta2, float eps, float grad_scale, void* stream);
+/* The same update under a DYNAMIC loss scale (the IEEE-half mode; the reference is f32 and has none -- the rule is
+ * torch.cuda.amp.GradScaler's).  scale_dev: float[2] = {scale, 1 / scale}; flags_dev: int32[4] = {a gradient of this step is
+ * not finite, consecutive finite steps, that flag at the last finished step, steps skipped so far}.  `mode` is a set of phases,
+ * run in this order: XMC_ADAM_CHECK raises the flag if any gradient element of the table is inf / NaN; XMC_ADAM_UPDATE reads the
+ * gradients times 1 / scale and updates -- NOTHING (parameters, moments, step counters) while the flag is up; XMC_ADAM_RESCALE
+ * ends an optimizer step: scale x backoff after a skipped step, x growth after `interval` finite steps in a row, flag cleared.
+ * (An optimizer with several parameter groups checks all of them before it updates any.)  All on the device: capturable. */
+enum { XMC_ADAM_CHECK = 1, XMC_ADAM_UPDATE = 2, XMC_ADAM_RESCALE = 4 };
+int xmc_adam_step_scaled(const XmcAdamEntry* table_dev, int ntensors, const int32_t* chunks_dev, int nchunks,
+                         float lr, float beta1, float beta2, float eps, float* scale_dev, int32_t* flags_dev,
+                         int mode, float growth, float backoff, int interval, void* stream);
 
 /* ---- matching-aware gradient penalty, train_gan.py:241-247:  2 * mean_b ||[d logit / d img_b, d logit / d sent_b]||_2^6 ---------
  * ss[b] += sum_k x[b][k]^2 over an f32 block [B, cols] (cols % 4 == 0; ss zeroed by the caller, blocks accumulate);
  * gp = mean_b ss[b]^3 and coef[b] = 6 ss[b]^2 / B (so that d gp / d x[b][k] = coef[b] * x[b][k]);
  * y = (*g) * coef[b] * x : the gradient of gp w.r.t. one block, scaled by the incoming gradient *g (device scalar). */
 int xmc_rows_sumsq(const float* x, float* ss, int B, int64_t cols, void* stream);
-int xmc_gp_finish(const float* ss, int B, float* gp, float* coef, void* stream);
+int xmc_gp_finish(const float* ss, int B, float* gp, float* coef, float inv_s2, void* stream);   /* inv_s2: the blocks hold s * g; 0 or 1 = unscaled */
 int xmc_rows_scale(const float* x, const float* coef, const float* g, float* y, int B, int64_t cols, void* stream);
 
 /* ---- per-sample concept algebra of the sentence-conditioned attention-modulation block (df_concept_gan.py:213-253, 273-326) ----

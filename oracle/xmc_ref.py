@@ -47,7 +47,9 @@ _QGRAD = True             # round the gradient that flows back through a storage
 #   d.pool the pooled shortcut input                  d.sc  the 1x1 shortcut output        d.sum  the block sum
 #   d.w    packed discriminator weights               h.c / h.m / h.w  COND_DNET: condition, joint_conv.0 output, weights
 #   g.stem, g.aff (affine-affine-LeakyReLU passes), g.c1, g.c2, g.sc, g.sum, g.act (tail LeakyReLU), g.img, g.w
-QUANT_SITES = ("d.img", "d.conv_img", "d.r0", "d.r2", "d.pool", "d.sc", "d.sum", "d.w", "h.c", "h.m", "h.w",
+#   d.last the LAST block sum (the [B,16*NCH,4,4] feature map COND_DNET reads): a site of its own only when it is skipped -- the
+#          engine's "f32 head" option keeps that map, the condition, joint_conv.0's output and the head's weights in f32
+QUANT_SITES = ("d.img", "d.conv_img", "d.r0", "d.r2", "d.pool", "d.sc", "d.sum", "d.last", "d.w", "h.c", "h.m", "h.w",
                "g.stem", "g.aff", "g.c1", "g.c2", "g.sc", "g.sum", "g.act", "g.img", "g.w")
 
 
@@ -872,10 +874,11 @@ def _netd_forward_q(P, h: Hyper, x, a, second_order=False):
         s = q(F.avg_pool2d(out, 2), "d.pool")
         if a["cin"][i] != a["cout"][i]:
             s = q(F.conv2d(s, qw(sn_weight(P, f"{p}.conv_s.weight"), "d.w"), P[f"{p}.conv_s.bias"]), "d.sc")
+        site = "d.last" if (i == a["depth"] - 1 and "d.last" in _QSKIP) else "d.sum"
         if second_order or "d.r2" in _QSKIP:
-            out = q(s + P[f"{p}.gamma"] * q(F.leaky_relu(z, LRELU), "d.r2"), "d.sum")
+            out = q(s + P[f"{p}.gamma"] * q(F.leaky_relu(z, LRELU), "d.r2"), site)
         else:
-            out = q(s + _QBranchTimesGamma.apply(z, P[f"{p}.gamma"]), "d.sum")
+            out = q(s + _QBranchTimesGamma.apply(z, P[f"{p}.gamma"]), site)
     return out
 
 

@@ -1,7 +1,7 @@
 # round 3: the rocprofv3 passes whose summaries are committed next to this script (run on a GPU box from the repo root)
 set -e
 cd /tmp && export TMPDIR=/tmp
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}"
 O=gpurun_out/r03prof
 mkdir -p $O
 rocprofv3 --kernel-trace --stats -f csv -d $O/stats -- python bench.py --no_alt_precision --no_parity > $O/r03_bench_under_rocprof_256px_b256.json 2> $O/stats.err

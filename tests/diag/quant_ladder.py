@@ -39,6 +39,20 @@ RUNGS = [
      tuple(t for t in X.QUANT_SITES if t not in ("d.r0", "d.r2", "g.c1", "g.c2", "g.aff", "d.w", "g.w"))),
     ("WHAT-IF: all sites IEEE half (f16: 11 significant bits, same MFMA rate) instead of bf16 (8 bits)", "f16"),
 ]
+# round 4: the rungs above the all-half mode (`--fmt f16`): which f32 islands would bring the LOGIT vectors inside 1e-3?
+RUNGS_F16 = [
+    ("all sites IEEE half (the f16 mode)", ()),
+    ("f32 head: last feature map + COND_DNET (condition, joint_conv.0 output, head weights)", ("d.last", "h.")),
+    ("f32 head + D weights f32", ("d.last", "h.", "d.w")),
+    ("f32 head + D trunk f32 (pool, shortcut, block sum)", ("d.last", "h.", "d.pool", "d.sc", "d.sum")),
+    ("D + head f32, G half", ("d.", "h.")),
+    ("G f32, D + head half", ("g.",)),
+    ("weights f32, activations half", ("d.w", "g.w", "h.w")),
+    ("activations f32, weights half", tuple(t for t in X.QUANT_SITES if not t.endswith(".w"))),
+]
+
+
+FMT = torch.bfloat16
 
 
 def one_step(h, PG, PD, batch, skip=None):
@@ -50,7 +64,7 @@ def one_step(h, PG, PD, batch, skip=None):
     if skip == "f16":
         with X.quant(True, fmt=torch.float16):
             return X.train_step(PG, PD, oG, oD, h, batch)
-    with X.quant(True, skip=skip):
+    with X.quant(True, skip=skip, fmt=FMT):
         return X.train_step(PG, PD, oG, oD, h, batch)
 
 
@@ -61,8 +75,8 @@ def errors(o, ref):
             e = abs(o[k] - ref[k]) / max(abs(ref[k]), 1e-12)
             if e > worst:
                 worst, which = e, k
-    lg = max(((o[k] - ref[k]).norm() / ref[k].norm()).item() for k in ("logit_real", "logit_fake"))
-    return worst, which, lg
+    lg = tuple(((o[k] - ref[k]).norm() / ref[k].norm()).item() for k in ("logit_real", "logit_fake"))
+    return worst, which, max(lg), lg
 
 
 def main():
@@ -73,12 +87,17 @@ def main():
     ap.add_argument("--seeds", type=int, default=3)
     ap.add_argument("--gamma", type=float, default=0.1)
     ap.add_argument("--cfg", type=str, default="df_gan_damsm_nomagp.yml")
+    ap.add_argument("--fmt", type=str, default="bf16", choices=["bf16", "f16"], help="f16: the rungs above the all-half mode")
+    ap.add_argument("--params", type=str, default="synth,ref")
     a = ap.parse_args()
+    global FMT, RUNGS
+    if a.fmt == "f16":
+        FMT, RUNGS = torch.float16, RUNGS_F16
     torch.set_num_threads(max(1, os.cpu_count() or 1))
     cfg, h = setup_cfg(a.cfg, **{"TRAIN.NCH": a.nch, "IMG.SIZE": a.size})
     print(f"# {a.cfg}, {a.size}x{a.size}, NCH={a.nch}, batch {a.batch}, {a.seeds} seeds; worst relative loss error (which loss) | "
           f"logit rel. L2 error; bar 1e-3")
-    for pname in ("synth", "ref"):
+    for pname in a.params.split(","):
         print(f"## parameters: {pname}" + (f" (block gammas {a.gamma})" if pname == "ref" else ""))
         rows = {r[0]: [] for r in RUNGS}
         for s in range(a.seeds):
@@ -94,7 +113,7 @@ def main():
             r = rows[name]
             w = max(r, key=lambda t: t[0])
             print(f"{name:90s} loss {w[0]:.2e} ({w[1]:13s}) median {sorted(t[0] for t in r)[len(r) // 2]:.2e} | "
-                  f"logit {max(t[2] for t in r):.2e}")
+                  f"logit {max(t[2] for t in r):.2e} (real {max(t[3][0] for t in r):.2e}, fake {max(t[3][1] for t in r):.2e})", flush=True)
 
 
 if __name__ == "__main__":

@@ -55,7 +55,9 @@ class GradTap:
         orig = opt.step
 
         def step(*a, **k):
-            gs = float(k.get("grad_scale", 1.0))      # IEEE-half mode: the backward ran on loss_scale * loss
+            gs = float(k.get("grad_scale", 1.0))
+            if k.get("scaler") is not None:           # IEEE-half mode: the backward ran on the scaler's scale x the loss
+                gs = float(k["scaler"].sf[1])
             self.records.append({n: (None if p.grad is None else p.grad.detach().float().cpu().clone() * gs) for n, p in self.named})
             return orig(*a, **k)
 

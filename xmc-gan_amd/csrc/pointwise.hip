@@ -785,12 +785,14 @@ __global__ void rows_sumsq_kernel(const float* __restrict__ x, float* __restrict
     }
 }
 // gp = mean_b ss[b]^3 (= mean ||g_b||^6), coef[b] = d gp / d ss[b] * 2 = 6 ss[b]^2 / B   (so that d gp / d g = coef[b] * g)
-__global__ void gp_finish_kernel(const float* __restrict__ ss, int B, float* __restrict__ gp, float* __restrict__ coef) {
+// inv_s2: the blocks hold s * g (the IEEE-half mode runs the inner backward of MA-GP on s x ones): ss / s^2 is the true sum of
+// squares and d gp / d (s g) = coef / s^2 * (s g).  1 otherwise.
+__global__ void gp_finish_kernel(const float* __restrict__ ss, int B, float* __restrict__ gp, float* __restrict__ coef, float inv_s2) {
     float s = 0.f;
     for (int b = threadIdx.x; b < B; b += blockDim.x) {
-        const float v = ss[b];
+        const float v = ss[b] * inv_s2;
         s += v * v * v;
-        coef[b] = 6.f * v * v / (float)B;
+        coef[b] = 6.f * v * v / (float)B * inv_s2;
     }
     s = wave_sum(s);
     __shared__ float part[NT / 64];
@@ -1218,9 +1220,9 @@ extern "C" int xmc_rows_sumsq(const float* x, float* ss, int B, int64_t cols, vo
     XMC_LAUNCH_CHECK();
     return 0;
 }
-extern "C" int xmc_gp_finish(const float* ss, int B, float* gp, float* coef, void* s) {
+extern "C" int xmc_gp_finish(const float* ss, int B, float* gp, float* coef, float inv_s2, void* s) {
     if (!ss || !gp || !coef || B < 1) return XMC_EINVAL;
-    hipLaunchKernelGGL(gp_finish_kernel, dim3(1), dim3(NT), 0, ST(s), ss, B, gp, coef);
+    hipLaunchKernelGGL(gp_finish_kernel, dim3(1), dim3(NT), 0, ST(s), ss, B, gp, coef, inv_s2 == 0.f ? 1.f : inv_s2);
     XMC_LAUNCH_CHECK();
     return 0;
 }

@@ -34,6 +34,7 @@ def set_precision(p):
     global _PRECISION
     assert p in ("bf16", "f16", "fp32")
     _PRECISION = p
+    reset_loss_scalers()
     L.use_variant("f16" if p == "f16" else "bf16")
     bump_weights_epoch()           # packed weights of the other format / library are not ours
 
@@ -46,18 +47,76 @@ def act_dtype():
     return {"bf16": torch.bfloat16, "f16": torch.float16, "fp32": torch.float32}[_PRECISION]
 
 
-# f16 activations gradients: a hinge / InfoNCE gradient of 1/B spread over a 256x256x32 map is ~1e-6 per element, far into
-# the subnormal range of IEEE half (spacing 6e-8).  The iteration therefore differentiates LOSS_SCALE * loss and the optimizer
-# kernel divides the (f32) parameter gradients by it again (train_gan.gan_iteration, optim.HipAdam.step(grad_scale=)); a power
-# of two, so bf16 / fp32 results would not change either -- they run unscaled.
-LOSS_SCALE_F16 = float(os.environ.get("XMC_LOSS_SCALE", 4096.0))
+# f16 activation gradients: a hinge / InfoNCE gradient of 1/B spread over a 256x256x32 map is ~1e-6 per element, far into
+# the subnormal range of IEEE half (spacing 6e-8).  The iteration therefore differentiates scale * loss and the optimizer
+# kernel divides the (f32) parameter gradients by it again (train_gan.gan_iteration, optim.HipAdam.step(scaler=)); powers of
+# two, so the result does not depend on the scale while nothing leaves the format's range.  bf16 / fp32 run unscaled.
+# The scale is DYNAMIC (round 4; it was a fixed 4096): one device-resident `LossScaler` per backward phase -- "D", "GP" (the
+# outer backward of the matching-aware gradient penalty), "G" -- with torch.cuda.amp.GradScaler's rule: a step whose gradients
+# hold an inf / NaN is skipped inside the Adam kernel (parameters, moments and step counters untouched) and halves the scale;
+# `growth_interval` finite steps in a row double it.  Everything stays on the device, so the iteration remains capturable.
+LOSS_SCALE_F16 = float(os.environ.get("XMC_LOSS_SCALE", 4096.0))          # initial value
+LOSS_SCALE_GROWTH_INTERVAL = int(os.environ.get("XMC_LOSS_SCALE_INTERVAL", 2000))
+# The INNER backward of MA-GP (d logit / d inputs, a forward quantity of the outer graph) starts from GP_INNER_SCALE x ones
+# instead of ones and `grad_penalty` divides it out of the norm: d logit / d pixel of a 256x256 image is 1e-6 .. 1e-3, among
+# or next to the subnormals of IEEE half.  Fixed: an overflow here means a gradient element above 65504 / 256, i.e. a diverged
+# run (it would surface as a skipped GP step, and the outer scaler's back-off cannot cure it -- `train()` reports skips).
+GP_INNER_SCALE_F16 = float(os.environ.get("XMC_GP_INNER_SCALE", 256.0))
+
+
+class LossScaler:
+    """device-resident dynamic loss scale: ``sf`` = [scale, 1/scale] (f32), ``si`` = [found-inf flag of the running step, finite
+    steps in a row, the flag at the last finished step, steps skipped so far] (int32); updated by `xmc_adam_step_scaled`."""
+
+    def __init__(self, device, init=None, growth=2.0, backoff=0.5, interval=None):
+        init = LOSS_SCALE_F16 if init is None else float(init)
+        self.sf = torch.tensor([init, 1.0 / init], dtype=torch.float32, device=device)
+        self.si = torch.zeros(4, dtype=torch.int32, device=device)
+        self.growth, self.backoff = float(growth), float(backoff)
+        self.interval = LOSS_SCALE_GROWTH_INTERVAL if interval is None else int(interval)
+
+    def scale(self, loss):
+        return loss * self.sf[0]
+
+    def stats(self):
+        """host view (synchronises): current scale, whether the last step was skipped, steps skipped so far"""
+        sf, si = self.sf.tolist(), self.si.tolist()
+        return dict(scale=sf[0], last_step_skipped=bool(si[2]), skipped_steps=int(si[3]))
+
+
+_scalers = {}
+
+
+def loss_scaler(phase, device):
+    """the `LossScaler` of a backward phase ("D", "GP", "G") in the IEEE-half mode, None in the other modes.  Created on first use
+    (outside graph capture: the warm-up iterations come first) and kept across iterations."""
+    if _PRECISION != "f16":
+        return None
+    key = (phase, torch.device(device).index)
+    sc = _scalers.get(key)
+    if sc is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("loss scaler created during graph capture; run a warm-up iteration first")
+        sc = _scalers[key] = LossScaler(device)
+    return sc
+
+
+def reset_loss_scalers():
+    _scalers.clear()
+
+
+def loss_scaler_stats():
+    return {f"{ph}": sc.stats() for (ph, _), sc in _scalers.items()}
+
+
+def gp_inner_scale():
+    return GP_INNER_SCALE_F16 if _PRECISION == "f16" else 1.0
 
 
 def loss_scale(phase="step"):
-    """factor the D / G backward passes run on.  The MA-GP backward (`phase="gp"`) runs unscaled: its seeds are 6 ||g||^4 g / B
-    on a gradient norm that is O(1)..O(30) for an untrained discriminator -- a fixed power of two would overflow IEEE half
-    (65504) at the upper end; its first-order pass starts from ones, not from 1/B, and sits in the normal range."""
-    return LOSS_SCALE_F16 if (_PRECISION == "f16" and phase == "step") else 1.0
+    """INITIAL factor of the D / G backward passes (the running value lives in `loss_scaler(phase)`); the rounding oracle of the
+    tests rounds gradient tensors at this scale."""
+    return LOSS_SCALE_F16 if _PRECISION == "f16" else 1.0
 
 
 class composable:
@@ -581,6 +640,39 @@ class _ZeroArena:
 _arena = _ZeroArena()
 
 
+class _EscapeBlocks:
+    """Zero-filled f32 accumulators that LEAVE the kernels as tensors the caller may keep: forward outputs of `DotFn` / `ColSumFn`,
+    parameter gradients (a block's d(gamma), the concept heads' weight gradients) -- autograd's AccumulateGrad adopts such a
+    tensor as ``p.grad`` without copying it.  They must not alias memory that `new_iteration()` re-zeroes and re-issues, so they
+    are slices of a block that is allocated FRESH once per iteration (one fill) and never recycled: what a slice's owner holds
+    stays valid for as long as it holds it (``zero_grad(set_to_none=False)``, gradient accumulation over iterations, a caller
+    keeping ``.grad``)."""
+
+    GRANULE, MIN_BLOCK = 64, 1 << 14
+
+    def __init__(self):
+        self.buf, self.off = {}, {}
+
+    def new_iteration(self, device):
+        self.buf.pop((device.type, device.index), None)          # owners of its slices keep the storage alive
+
+    def zeros(self, shape, device):
+        key = (device.type, device.index)
+        n = 1
+        for s_ in shape:
+            n *= s_
+        n4 = (n + self.GRANULE - 1) // self.GRANULE * self.GRANULE
+        buf, off = self.buf.get(key), self.off.get(key, 0)
+        if buf is None or off + n4 > buf.numel():
+            buf = self.buf[key] = torch.zeros(max(self.MIN_BLOCK, n4), dtype=torch.float32, device=device)
+            off = 0
+        self.off[key] = off + n4
+        return buf[off:off + n].view(shape)
+
+
+_escape = _EscapeBlocks()
+
+
 def _zeros_f32(shape, device):
     """zero-filled f32 scratch for an accumulator the kernels add into (dot products, per-channel sums, small parameter gradients):
     a slice of the per-iteration arena (one memset per iteration) instead of one fill launch each -- ~100 launches per iteration in
@@ -592,23 +684,47 @@ def _zeros_f32(shape, device):
     return _arena.zeros(tuple(shape), torch.device(device))
 
 
+def _zeros_f32_out(shape, device):
+    """zero-filled f32 accumulator whose tensor escapes to the caller (`_EscapeBlocks`)"""
+    if isinstance(shape, int):
+        shape = (shape,)
+    if "no_arena_scalars" in _DEBUG_DISPATCH:
+        return torch.zeros(tuple(shape), dtype=torch.float32, device=device)
+    return _escape.zeros(tuple(shape), torch.device(device))
+
+
 def new_iteration(device):
     """Call once at the start of a training iteration (before any backward): re-zeroes the weight-gradient scratch arena."""
     _arena.new_iteration(torch.device(device))
+    _escape.new_iteration(torch.device(device))
     _pooled_grads.clear()
 
 
-# By-products handed from one backward node to the next: {(data_ptr, shape, dtype) of a gradient tensor: its 2x2 sum pool}.  The
-# node that WRITES the gradient of a generator block's output (the next block's affine backward) can pool it in the same pass;
-# the node that CONSUMES it (GBlockEndFn.backward, which needs the pooled tensor as the gradient of the half-resolution shortcut)
-# pops the entry instead of launching a pooling pass.  Autograd hands a single-consumer gradient over as the same tensor, and the
-# producer's tensor is alive until then, so the key is unique while it is in the table; entries nobody popped die with the
-# iteration (new_iteration) -- and a missing entry only means the pooling pass runs.
+# By-products handed from one backward node to the next: {(data_ptr, shape, dtype) of a gradient tensor: (the tensor, its 2x2 sum
+# pool)}.  The node that WRITES the gradient of a generator block's output (the next block's affine backward) can pool it in the
+# same pass; the node that CONSUMES it (GBlockEndFn.backward, which needs the pooled tensor as the gradient of the half-resolution
+# shortcut) takes the entry instead of launching a pooling pass.  The entry HOLDS the gradient tensor, so its address cannot be
+# re-issued while the entry exists (the key is unique by construction, not by allocator behaviour), and the consumer checks that
+# what autograd handed it is that very storage, unmodified (a hook, a second consumer or a cast gives it another tensor: then the
+# pooling pass runs).  Entries nobody took die with the iteration (new_iteration).
 _pooled_grads = {}
 
 
 def _pool_key(t):
     return (t.data_ptr(), tuple(t.shape), t.dtype)
+
+
+def _pooled_put(dx, dxp):
+    _pooled_grads[_pool_key(dx)] = (dx, dx._version, dxp)
+
+
+def _pooled_take(dz):
+    ent = _pooled_grads.pop(_pool_key(dz), None)
+    if ent is None:
+        return None
+    dx, ver, dxp = ent
+    same = dx.untyped_storage().data_ptr() == dz.untyped_storage().data_ptr() and dx.stride() == dz.stride() and dx._version == ver
+    return dxp if same else None
 
 
 def _conv_wgrad_raw(x, dy, geom, scale=None, up=False, want_bias=False, bias_dot=None, dot=None):
@@ -840,7 +956,7 @@ def _axpby_bwd_fused(dy, b, alpha, up, ymask=None, want_db=True):
     al = alpha.detach().reshape(-1).float()
     db = torch.empty_like(dy) if want_db else None
     da = torch.empty((N, H, W, Cc), dtype=dy.dtype, device=dy.device) if (up or ymask is not None) else None
-    dot = _zeros_f32(1, dy.device)
+    dot = _zeros_f32_out(1, dy.device)
     L.call("xmc_axpby_bwd", _p(dy), _p(b), _p(al), _p(db), _p(da), _p(dot), N, H, W, Cc, 1 if up else 0, _p(ymask), _code(dy.dtype), _st())
     return da, db, dot.reshape(alpha.shape).to(alpha.dtype)
 
@@ -992,12 +1108,12 @@ class GBlockEndFn(torch.autograd.Function):
             dz, dsc = _conv_dgrad_raw(dpre, w_out, geom_out, (H, W), dt, mask=y, want_sumpool=True)
         else:
             dz = dy
-            dsc = _pooled_grads.pop(_pool_key(dz), None)          # written by the producer of dy in the pass that wrote dy
+            dsc = _pooled_take(dz)          # written by the producer of dy in the pass that wrote dy
             if dsc is None:
                 dsc = torch.empty((N, H // 2, W // 2, dz.shape[3]), dtype=dt, device=dz.device)
                 L.call("xmc_sumpool2", _p(dz), _p(dsc), N, H, W, dz.shape[3], 1.0, _code(dt), _st())
         al = gamma.detach().reshape(-1).float()
-        dot = _zeros_f32(1, dz.device)
+        dot = _zeros_f32_out(1, dz.device)
         dw2 = db2 = None
         if ctx.has_b2:
             # (the bias term of d(gamma) rides on the unpack of the bias gradient, so that launch runs even when the weight gradients are
@@ -1342,7 +1458,7 @@ class DotFn(torch.autograd.Function):
         a, b = a.contiguous(), b.contiguous()
         if a.dtype != b.dtype:
             b = b.to(a.dtype)
-        out = _zeros_f32(1, a.device)
+        out = _zeros_f32_out(1, a.device)
         L.call("xmc_dot", _p(a), _p(b), _p(out), a.numel(), _code(a.dtype), _st())
         ctx.save_for_backward(a, b)
         return out
@@ -1481,7 +1597,7 @@ class ResDBwdFn(torch.autograd.Function):
             dout = dout.to(dt)
         # residual branch: g2 = gamma * dout * LeakyReLU'(res), d(gamma) = <dout, res>
         al = gamma.detach().reshape(-1).float()
-        dgam = _zeros_f32(1, x.device)
+        dgam = _zeros_f32_out(1, x.device)
         if res.dtype == torch.uint8:
             # `res` holds only the branch's sign bits.  With s = LeakyReLU'(branch) and branch = s * C2 h1:
             #   <dout, branch> = <s * dout, C2 h1> = <C2^T (s * dout), h1>
@@ -1552,7 +1668,7 @@ class ResDBwdFn(torch.autograd.Function):
         if ctx.needs_input_grad[8]:
             u = torch.empty_like(c2)
             L.call("xmc_lrelu_mask", _p(c2), _p(res), _p(u), c2.numel(), 0.2, _code(dt), _st())
-            dg = _zeros_f32(1, g.device)
+            dg = _zeros_f32_out(1, g.device)
             L.call("xmc_dot", _p(dout), _p(u), _p(dg), u.numel(), _code(dt), _st())
             dgamma = dg.reshape(gamma.shape).to(gamma.dtype)
         dw0 = dw2 = dws = None
@@ -1580,7 +1696,7 @@ class ColSumFn(torch.autograd.Function):
     def forward(ctx, x):
         x = x.contiguous()
         Cc = x.shape[-1]
-        out = _zeros_f32(Cc, x.device)
+        out = _zeros_f32_out(Cc, x.device)
         L.call("xmc_colsum", _p(x), _p(out), x.numel() // Cc, Cc, _code(x.dtype), _st())
         ctx.shape, ctx.dtype = x.shape, x.dtype
         return out
@@ -1797,7 +1913,7 @@ class Affine2LreluSkipFn(torch.autograd.Function):
         if ctx.pool and x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0 and x.shape[3] // 8 in (1, 2, 4, 8, 16, 32):
             # x is the output of the previous generator block, whose backward needs the 2x2 sum pool of this gradient
             dx, red, dxp = _affine_bwd_raw(x, dy.contiguous(), ps, 0.2, dx_acc=dskip, want_sumpool=True)
-            _pooled_grads[_pool_key(dx)] = dxp
+            _pooled_put(dx, dxp)
         else:
             dx, red = _affine_bwd_raw(x, dy.contiguous(), ps, 0.2, dx_acc=dskip)
         return dx, red[0], red[1], red[2], red[3], None
@@ -1986,7 +2102,7 @@ class ConceptQueryFn(torch.autograd.Function):
         B, E = sent.shape
         dq = dq.contiguous().float()
         dsent = torch.empty_like(sent)
-        flat = _zeros_f32(64 * E + 128, sent.device)      # one slice for all accumulators
+        flat = _zeros_f32_out(64 * E + 128, sent.device)      # one slice for all accumulators
         dw = flat[:64 * E].view(64, E)
         dgw = flat[64 * E:64 * E + 64] if gnw is not None else None
         dgb = flat[64 * E + 64:] if gnw is not None else None
@@ -2021,7 +2137,7 @@ class ConceptGQueryFn(torch.autograd.Function):
         B = q0.shape[0]
         dq = dq.contiguous().float()
         dq0 = torch.empty_like(q0)
-        flat = _zeros_f32(64 * 8 + 128, q0.device)
+        flat = _zeros_f32_out(64 * 8 + 128, q0.device)
         dw = flat[:512].view(64, 8)
         dgw = flat[512:576] if gnw is not None else None
         dgb = flat[576:] if gnw is not None else None
@@ -2043,7 +2159,7 @@ def _head_bwd_raw(pooled, sent, hid, ps, dgamma, dbeta):
     B, E = sent.shape
     dpooled, dsent = torch.empty_like(pooled), torch.empty_like(sent)
     sizes = [(p_.numel() + 3) // 4 * 4 for p_ in ps]                      # 16-byte aligned slices of ONE zero-filled buffer
-    flat = _zeros_f32(sum(sizes), sent.device)
+    flat = _zeros_f32_out(sum(sizes), sent.device)
     grads, off = [], 0
     for p_, n_ in zip(ps, sizes):
         grads.append(flat[off:off + p_.numel()].view(p_.shape))
@@ -2155,7 +2271,7 @@ class GradPenaltyFn(torch.autograd.Function):
     `autograd.grad(create_graph=True)`, so the gradients returned here continue into the second-order graph of D."""
 
     @staticmethod
-    def forward(ctx, *blocks):
+    def forward(ctx, inner_scale, *blocks):
         B = blocks[0].shape[0]
         flat = []
         for g in blocks:
@@ -2169,7 +2285,7 @@ class GradPenaltyFn(torch.autograd.Function):
             L.call("xmc_rows_sumsq", _p(g), _p(ss), B, g.shape[1], _st())
         gp = torch.empty(1, dtype=torch.float32, device=ss.device)
         coef = torch.empty(B, dtype=torch.float32, device=ss.device)
-        L.call("xmc_gp_finish", _p(ss), B, _p(gp), _p(coef), _st())
+        L.call("xmc_gp_finish", _p(ss), B, _p(gp), _p(coef), 1.0 / float(inner_scale) ** 2, _st())
         ctx.shapes = [tuple(b.shape) for b in blocks]
         ctx.dtypes = [b.dtype for b in blocks]
         ctx.save_for_backward(coef, *flat)
@@ -2189,11 +2305,12 @@ class GradPenaltyFn(torch.autograd.Function):
             for v in shp[1:]:
                 n *= v
             outs.append(y[:, :n].reshape(shp).to(dt))
-        return tuple(outs)
+        return (None, *outs)
 
 
-def grad_penalty(*blocks):
-    return GradPenaltyFn.apply(*blocks)
+def grad_penalty(*blocks, inner_scale=1.0):
+    """``inner_scale``: the blocks hold inner_scale x the gradients (see `gp_inner_scale`)"""
+    return GradPenaltyFn.apply(float(inner_scale), *blocks)
 
 
 def cosine_scores(a, b):

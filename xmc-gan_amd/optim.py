@@ -114,21 +114,38 @@ class HipAdam(torch.optim.Optimizer):
         return self._tables[key][:4]
 
     @torch.no_grad()
-    def step(self, closure=None, grad_scale=1.0):
-        """``grad_scale``: factor applied to every gradient element as the kernel reads it (the IEEE-half mode passes
-        1 / loss scale; 1.0 is torch.optim.Adam exactly)."""
+    def step(self, closure=None, grad_scale=1.0, scaler=None):
+        """``grad_scale``: factor applied to every gradient element as the kernel reads it; 1.0 is torch.optim.Adam exactly.
+        ``scaler`` (an `ops.LossScaler`, the IEEE-half mode): the gradients are those of scale x loss -- they are read times
+        1 / scale; if ANY of them (over all parameter groups) is inf / NaN the step is skipped on the device (no parameter,
+        moment or step counter changes) and the scale backs off; the scaler's counters say so afterwards."""
         assert closure is None
+        groups = []
         for group in self.param_groups:
             ps = [p for p in group["params"] if p.grad is not None]
             if not ps:
                 continue
             if not ps[0].is_cuda:
                 raise RuntimeError("HipAdam runs on the GPU only (no CPU fallback)")
-            tab, ch, nt, nc = self._table(ps, ps[0].device)
-            b1, b2 = group["betas"]
-            L.call("xmc_adam_step", C.c_void_p(tab.data_ptr()), nt, C.c_void_p(ch.data_ptr()), nc,
-                   float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(grad_scale),
-                   C.c_void_p(torch.cuda.current_stream().cuda_stream))
+            groups.append((group, self._table(ps, ps[0].device)))
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream) if groups else None
+        if scaler is None:
+            for group, (tab, ch, nt, nc) in groups:
+                b1, b2 = group["betas"]
+                L.call("xmc_adam_step", C.c_void_p(tab.data_ptr()), nt, C.c_void_p(ch.data_ptr()), nc,
+                       float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(grad_scale), st)
+        else:
+            assert grad_scale == 1.0
+            CHECK, UPDATE, RESCALE = 1, 2, 4
+            # every group is checked before any is updated; the last update also ends the scaler's step
+            passes = [CHECK | UPDATE] if len(groups) == 1 else [CHECK, UPDATE]
+            for mode in passes:
+                for gi, (group, (tab, ch, nt, nc)) in enumerate(groups):
+                    b1, b2 = group["betas"]
+                    m = mode | (RESCALE if (mode & UPDATE) and gi == len(groups) - 1 else 0)
+                    L.call("xmc_adam_step_scaled", C.c_void_p(tab.data_ptr()), nt, C.c_void_p(ch.data_ptr()), nc,
+                           float(group["lr"]), float(b1), float(b2), float(group["eps"]), C.c_void_p(scaler.sf.data_ptr()),
+                           C.c_void_p(scaler.si.data_ptr()), m, scaler.growth, scaler.backoff, scaler.interval, st)
         # the kernels wrote the parameters behind autograd's back: invalidate their packed copies and re-pack, in one launch,
         # the ones that exist (ops._PackEntry)
         changed = [p for group in self.param_groups for p in group["params"] if p.grad is not None]

@@ -205,11 +205,13 @@ def gan_iteration(netG, netD, optimizerG, optimizerD, imgs, sent_embs, words_emb
     errD = errD_real + (mis_loss * T.SMOOTH.MISMATCH) + enc_loss
     netG.zero_grad()
     netD.zero_grad()
-    ls = ops.loss_scale()            # 1 unless the IEEE-half mode is on (ops.set_precision): keeps 1/B-sized gradients normal
-    unscale = dict(grad_scale=1.0 / ls) if ls != 1.0 else {}       # HipAdam divides the f32 parameter gradients by it again
-    (errD * ls if ls != 1.0 else errD).backward()
+    # IEEE-half mode only (ops.set_precision): each backward runs on a dynamic, device-resident scale x its loss (keeps 1/B-sized
+    # gradients normal), HipAdam reads the f32 parameter gradients times 1 / scale and SKIPS the step on the device when one
+    # of them is inf / NaN (after the all-reduce, so every rank decides alike).  None in the other modes.
+    sc_d = ops.loss_scaler("D", imgs.device)
+    (sc_d.scale(errD) if sc_d is not None else errD).backward()
     parallel.allreduce_mean_grads(netD.parameters())
-    optimizerD.step(**unscale)
+    optimizerD.step(scaler=sc_d)
     out.update(errD=errD.detach(), errD_real=errD_real.detach(), errD_fake=errD_fake.detach())
 
     # ---- matching-aware gradient penalty on real pairs (train_gan.py:231-252)
@@ -222,23 +224,25 @@ def gan_iteration(netG, netD, optimizerG, optimizerD, imgs, sent_embs, words_emb
         with (ops.composable() if cfg.DISC.SPEC_NORM else contextlib.nullcontext()), ops.second_order():
             features = netD(interpolated)
             o = netD.COND_DNET(features, sent_inter)
+        s_in = ops.gp_inner_scale()    # IEEE-half mode: the inner backward runs on s_in x ones, the penalty divides it out
         with ops.no_wgrad():           # first-order pass only needs d(logit)/d(inputs)
             grads = torch.autograd.grad(outputs=o[0], inputs=(interpolated, sent_inter),
-                                        grad_outputs=torch.ones_like(o[0]), retain_graph=True, create_graph=True,
+                                        grad_outputs=torch.full_like(o[0], s_in), retain_graph=True, create_graph=True,
                                         only_inputs=True)
         # mean(||cat(grad0, grad1)||_2 ** 6) (241-247) in two passes over the 3*S*S-wide image gradient, no concatenation
-        d_loss_gp = ops.grad_penalty(grads[0], grads[1])
+        d_loss_gp = ops.grad_penalty(grads[0], grads[1], inner_scale=s_in)
         d_loss = 2.0 * d_loss_gp
         optimizerD.zero_grad()
         optimizerG.zero_grad()
-        d_loss.backward()
+        sc_gp = ops.loss_scaler("GP", imgs.device)
+        (sc_gp.scale(d_loss) if sc_gp is not None else d_loss).backward()
         # the reference's autograd hands zero (not None) grads to every bias that feeds the logit
         # (their only path is through LeakyReLU'' == 0), which still advances Adam's moments/step.
         for name, p_ in netD.named_parameters():
             if p_.grad is None and name.endswith('.bias') and 'proj_match' not in name and _bias_on_logit_path(netD, name):
                 p_.grad = torch.zeros_like(p_)
         parallel.allreduce_mean_grads(netD.parameters())
-        optimizerD.step()
+        optimizerD.step(scaler=sc_gp)
         out['d_loss_gp'] = d_loss_gp.detach()
 
     # ---- generator step (train_gan.py:254-291)
@@ -270,11 +274,12 @@ def gan_iteration(netG, netD, optimizerG, optimizerD, imgs, sent_embs, words_emb
             errG = errG_fake + enc_loss
             netG.zero_grad()
             netD.zero_grad()
-            (errG * ls if ls != 1.0 else errG).backward()
+            sc_g = ops.loss_scaler("G", imgs.device)
+            (sc_g.scale(errG) if sc_g is not None else errG).backward()
         finally:
             _set_requires_grad(netD, True)
         parallel.allreduce_mean_grads(netG.parameters())
-        optimizerG.step(**unscale)
+        optimizerG.step(scaler=sc_g)
         it_state['i'] = 0
         out.update(errG=errG.detach(), errG_fake=errG_fake.detach())
     out['fake'] = fake.detach()
@@ -393,6 +398,13 @@ def train(train_loader, test_loader, state_epoch, text_encoder, netG, netD, opti
                 return last
         if parallel.rank() == 0:
             _log_epoch_scalars(writer, last, epoch)
+        # IEEE-half mode: the dynamic loss scales and the optimizer steps the found-inf check skipped so far (one host read per epoch)
+        sc_stats = ops.loss_scaler_stats()
+        if sc_stats:
+            last['loss_scale'] = sc_stats
+            logger.info('loss scale ' + ' '.join(f"{k}: {v['scale']:g} ({v['skipped_steps']} skipped)" for k, v in sc_stats.items()))
+            if all(v['scale'] <= 1.0 and v['last_step_skipped'] for v in sc_stats.values()):
+                raise FloatingPointError('every backward of the f16 mode overflows at loss scale 1: the run has diverged')
         if visual and fixed is not None:
             with torch.no_grad():
                 netG.eval()
