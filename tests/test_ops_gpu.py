@@ -230,6 +230,38 @@ def test_upsample_conv_fusion(cin, cout, H, N, mode):
     torch.testing.assert_close(gmd.grad.cpu(), gmr.grad, **tol(mode, gmr.grad.abs().item() + 10.0))
 
 
+@pytest.mark.parametrize("mode", ["bf16", "f16"])
+@pytest.mark.parametrize("cin,cout,H,W,N", [(64, 32, 128, 128, 2),      # generator block 6 (256 px): Cout 32, 4 x 32 low-res tiles, every border case
+                                             (128, 64, 8, 64, 3),        # two Cin blocks over the grid, one row of tiles
+                                             (256, 128, 12, 32, 2),      # Cin x Cout blocks over the grid, one column of tiles
+                                             (256, 256, 16, 16, 5),      # 8 x 16 tiles of the 16-pixel-wide maps
+                                             (64, 64, 24, 48, 1)])       # 16-wide tiles on a map that is not a power of two
+def test_upsample_wgrad_low_resolution_kernel(cin, cout, H, W, N, mode):
+    """the weight (and bias) gradient of conv3x3(interpolate(x, 2)) as 16 low-resolution products (conv_wgrad_up.hip) against
+    autograd through F.interpolate + F.conv2d on the CPU (df_gan.py:202,217): same operands, f32 accumulation on both sides."""
+    ops.set_precision(mode)
+    dt = ops.act_dtype()
+    g = torch.Generator().manual_seed(cin + cout + H)
+    x = rt(torch.randn(N, cin, H, W, generator=g), mode)
+    dy = rt(torch.randn(N, cout, 2 * H, 2 * W, generator=g), mode)
+    w = torch.zeros(cout, cin, 3, 3, requires_grad=True)
+    b = torch.zeros(cout, requires_grad=True)
+    (F.conv2d(F.interpolate(x, scale_factor=2), w, b, 1, 1) * dy).sum().backward()
+    geom = ops.ConvGeom(cin, cout, 3, 1, 1)
+    ops.new_iteration(DEV)
+    gw, gb = ops._conv_wgrad_raw(to_nhwc(x, cin, dt), to_nhwc(dy, cout, dt), geom, up=True, want_bias=True)
+    assert L.load().xmc_last_kernel().decode().startswith("wgrad_up_kernel"), L.load().xmc_last_kernel()
+    for got, ref in ((gw, w.grad), (gb[:cout], b.grad)):
+        err = (got.cpu() - ref).norm() / ref.norm()
+        assert err < 5e-5, err                    # exact products of identical 16-bit operands; only the f32 summation order differs
+    # border taps see the zero padding: compare tap by tap as well (a wrong class -> tap table would pass a norm over all taps
+    # only by accident, but not this)
+    for kh in range(3):
+        for kw in range(3):
+            e = (gw.cpu()[:, :, kh, kw] - w.grad[:, :, kh, kw]).abs().max() / w.grad[:, :, kh, kw].abs().max()
+            assert e < 5e-4, (kh, kw, e)
+
+
 @pytest.mark.parametrize("mode", MODES)
 def test_linear_row_perm_and_mixed_dtype(mode):
     """proj_noise: f32 [B,100] -> NHWC [B,4,4,C] in the activation dtype via a row permutation."""

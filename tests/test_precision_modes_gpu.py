@@ -43,9 +43,9 @@ def _restore_precision():
 @pytest.mark.parametrize("kind", ["synth", "ref"])
 @pytest.mark.parametrize("yml", ["df_gan_damsm_nomagp.yml", "df_gan_damsm.yml"])
 def test_f16_mode_losses_within_1e_3_of_f32_reference(yml, kind):
-    """first G+D iteration in the IEEE-half mode vs the plain f32 oracle: every loss scalar within 1e-3 relative (north_star),
-    the real-pair logit vector within 2e-3 relative L2; against the oracle rounding to half where the engine stores a tensor
-    (kernel error proper) 5e-4."""
+    """first G+D iteration in the IEEE-half mode vs the plain f32 oracle: every loss scalar (D step, MA-GP, G step) and the
+    real-pair logit vector within 1e-3 relative (north_star); against the oracle rounding to half where the engine stores a
+    tensor (kernel error proper) 5e-4."""
     ops.set_precision("f16")
     cfg, h = setup_cfg(yml)
     PG, PD = _params(h, kind, 0)
@@ -61,10 +61,10 @@ def test_f16_mode_losses_within_1e_3_of_f32_reference(yml, kind):
     sel = lambda d_, keys: {k: v for k, v in d_.items() if k in keys}
     wl = compare_losses(sel(p[0], dkeys), sel(o[0], dkeys), 1e-3, 1e-4)
     gkeys = ("errG_fake", "gs_loss", "disc_loss", "errG")
-    wl = max(wl, compare_losses(sel(p[0], gkeys), sel(o[0], gkeys), 3e-3 if h.magp else 1e-3, 1e-4))
-    wq = compare_losses(p[0], oq[0], 3e-3 if h.magp else 5e-4, 1e-4)
+    wl = max(wl, compare_losses(sel(p[0], gkeys), sel(o[0], gkeys), 1e-3, 1e-4))      # measured 3.4e-4 .. 4.6e-4, MA-GP included
+    wq = compare_losses(p[0], oq[0], 5e-4, 1e-4)
     lg = rel_err(_logits(h, PG, PD, batches[0]), o[0]["logit_real"])
-    assert lg <= 2e-3, lg
+    assert lg <= 1e-3, lg                                                              # measured 4.4e-4 (synth) / 6.6e-4 (ref)
     # gradients: against the half-rounding oracle (same storage points): single tensors 0.1, all tensors of a backward as one vector
     # D 1e-2, G 3e-2 (measured 1.3e-2; x2 behind the penalty step)
     gd = compare_grads(tapD.records[0], oq[0]["grads_D"], 0.1, "f16 D ", 2e-2, 1e-2)
@@ -95,11 +95,13 @@ def _logits_on(netG, netD, b, img):
         return netD.COND_DNET(netD(img.to(DEV)), sent_embs=ps)[0].float().cpu()
 
 
-# (mode, bar on the losses, bar on the logit vectors) against the PLAIN f32 oracle at the benched image size.  fp32 is the mode that
-# meets north_star's 1e-3 there; the 16-bit bars are the formats' measured floors at 7 + 6 blocks of depth (the ladder,
-# tests/diag/quant_ladder.py --size 256 [--fmt f16], reproduces them on the CPU: bf16 ~2e-2, f16 1.6e-3 / 3.8e-3), with the kernel
-# error proper -- the product against the oracle that rounds where the engine stores -- asserted beside them.
-FULLSIZE_BARS = {"fp32": (1e-3, 1e-3, None), "f16": (4e-3, 8e-3, 1.5e-3), "bf16": (6e-2, 8e-2, 2e-2)}
+# (mode, bar on the losses, bar on the logit vectors, bar on the losses against the ROUNDING oracle = kernel error proper) at the
+# benched image size; the first two against the PLAIN f32 oracle.
+# Measured (round 4, parameters of seed 5/6): fp32 4.8e-7 / 1.8e-6; f16 losses 6.2e-4, logits 2.8e-4 (real) / 1.25e-3 (generated),
+# kernel error 1.9e-4; bf16 6.3e-3, 3.5e-3 / 1.4e-2, kernel error 5.8e-4.  bench.py's own leg (parameters of seed 1/2) has f16 at
+# 2.2e-4 / 5.1e-4 / 5.7e-4 -- inside the bar on every count -- and bf16 at 2.2e-3 / 2.7e-3 / 3.8e-3: at this depth the half mode sits
+# AT the bar on the generated-image logit vector (seed-dependent, 0.6 .. 1.3e-3) and inside it on everything else.
+FULLSIZE_BARS = {"fp32": (1e-3, 1e-3, None), "f16": (1e-3, 2e-3, 5e-4), "bf16": (2e-2, 4e-2, 2e-3)}
 
 
 @pytest.mark.parametrize("mode", ["fp32", "f16", "bf16"])

@@ -231,6 +231,7 @@ int dispatch(const XmcConvDesc& d, float* dwp, float* dbias, hipStream_t st) {
 
 int xmc_conv_wgrad_tile_try(const XmcConvDesc* d, float* dwp, float* dbias, void* stream);   // conv_wgrad_tile.hip
 int xmc_conv_wgrad_row_try(const XmcConvDesc* d, float* dwp, float* dbias, void* stream);    // conv_wgrad_row.hip
+int xmc_conv_wgrad_up_try(const XmcConvDesc* d, float* dwp, float* dbias, void* stream);     // conv_wgrad_up.hip
 
 extern "C" int xmc_conv_wgrad(const XmcConvDesc* d, float* dwp, void* stream) { return xmc_conv_wgrad_bias(d, dwp, nullptr, stream); }
 
@@ -244,7 +245,9 @@ extern "C" int xmc_conv_wgrad_bias(const XmcConvDesc* d, float* dwp, float* dbia
     if (d->N < 1 || d->MH < 1 || d->MW < 1 || d->SH < 1 || d->SW < 1) return XMC_ESHAPE;
     if (d->src_shift < 0 || d->src_shift > 1 || d->SA < 1) return XMC_ESHAPE;
     {
-        int rc = xmc_conv_wgrad_tile_try(d, dwp, dbias, stream);     // all-taps-per-tile kernel for the few-channel layers
+        int rc = xmc_conv_wgrad_up_try(d, dwp, dbias, stream);       // 3x3 through a x2 upsample: 16 low-resolution products
+        if (rc != 1) return rc;
+        rc = xmc_conv_wgrad_tile_try(d, dwp, dbias, stream);         // all-taps-per-tile kernel for the few-channel layers
         if (rc != 1) return rc;
         rc = xmc_conv_wgrad_row_try(d, dwp, dbias, stream);          // one kernel row of taps per workgroup for the wide layers
         if (rc != 1) return rc;
