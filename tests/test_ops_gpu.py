@@ -66,7 +66,9 @@ CONV_CASES = [
     (3, 32, 3, 1, 1, 32, 2),       # conv_img: Cin 3->8 (one padded 16-block)
     (32, 3, 3, 1, 1, 32, 2),       # conv_out: Cout 3->8
     (32, 32, 3, 1, 1, 32, 3),
-    (64, 64, 3, 1, 1, 64, 1),
+    (64, 64, 3, 1, 1, 64, 1),      # row-reuse form (round 4): 3 (Cin block, kw) groups per wave, 2 Cout groups
+    (32, 64, 3, 1, 1, 32, 2),      # ... 4 Cout groups x 2 group slices
+    (64, 64, 3, 1, 1, 40, 2),      # H = 40: five tile rows (top / inner / bottom borders), W = 40 declines (not a multiple of 32)
     (64, 32, 1, 1, 0, 32, 2),
     # streaming kernel for 8-channel sources (conv_thin.hip): conv_img forward / conv_out dgrad on maps with H % 8 == 0, W % 32 == 0
     (3, 64, 3, 1, 1, 64, 1),       # 64 output channels, several tiles per image

@@ -349,6 +349,220 @@ __global__ __launch_bounds__(NT, ((SA == 1 && NT == 256) ? WtOcc<NCO, NCI>::v : 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Row-reuse form of the all-taps kernel for the full 3x3 tap set on 8 x 32 tiles (round 4).  The kernel above measures LDS-BOUND:
+// per tile its eight waves issue 1152 transposing reads (590 KB = 2.3 us at 128 B/clk) for 1.25 us of MFMAs, because every
+// (Cin block, tap) item reads its own shifted x fragment in every K step.  But K step r (tile row r) with tap row kh reads patch
+// row r + kh: of the three patch rows a (Cin block, kw) GROUP needs in step r, two were already read in step r - 1.  So a wave owns
+// whole groups -- the three kh taps of a (Cin block, kw) pair -- keeps their three row fragments in registers (rotating) and reads
+// ONE new row fragment per group and step: 3 x fragments + CBW dy fragments for 9 * CBW MFMAs (0.56 reads per MFMA at CBW = 2,
+// 0.9 above), 736 reads per tile.  Waves = NCG Cout groups x (8 / NCG) group slices, three groups = nine items per wave.
+// Same staging (tables, unconditional loads, one tile prefetched into registers), same LDS images, same atomics at the end.
+template <int NCO, int NCI, int NCG>
+__global__ __launch_bounds__(512) void wgrad_tile_rr_kernel(const XmcConvDesc d, float* __restrict__ dwp, float* __restrict__ dbias, const WTCfg t) {
+    constexpr int NT = 512, TH = 8, TW = 32, KS = 8, PH = 10, PW = 34;
+    constexpr int CDP = NCO * 16, CSP = NCI * 16;
+    constexpr int YS = CDP * 2 + 32, XS = CSP * 2 + 32;
+    constexpr int CBW = NCO / NCG, NS = 8 / NCG;
+    constexpr int GPW = NCI * 3 / NS;                          // (Cin block, kw) groups per wave
+    static_assert(GPW * NS == NCI * 3 && CBW * NCG == NCO, "waves tile the (group, Cout block) grid");
+    constexpr int MAXI = GPW * 3;
+    constexpr int YCH = CDP / 8, XCH = CSP / 8;
+    constexpr int YIT = TH * TW * YCH / NT;
+    constexpr int XIT = (PH * PW * XCH + NT - 1) / NT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* ydy = smem;                                // [256][YS]
+    unsigned char* xp = smem + TH * TW * YS;                  // [PH * PW][XS]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cg = wave % NCG, slice = wave / NCG;
+    const int tpi = t.tiles_y * t.tiles_x;
+    const int cd_units = d.CD / 8, cs_units = d.CS / 8;
+    const int ci0 = blockIdx.y * 64, co0 = blockIdx.z * 64;
+    const int ciu0 = ci0 >> 3, cou0 = co0 >> 3;
+    const u32x4* __restrict__ x16 = reinterpret_cast<const u32x4*>(d.src);
+    const u32x4* __restrict__ y16 = reinterpret_cast<const u32x4*>(d.dst);
+    const int sh = d.src_shift;
+
+    f32x4 acc[MAXI][CBW];
+#pragma unroll
+    for (int j = 0; j < MAXI; ++j)
+#pragma unroll
+        for (int c = 0; c < CBW; ++c) acc[j][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int ych = tid % YCH, xch = tid % XCH;
+    const bool yok = cou0 + ych < cd_units;
+    static_assert((NT / YCH) % TW == 0, "dy units of a thread differ by whole tile rows");
+    const unsigned yoff0 = yok ? (unsigned)((((tid / YCH) / TW) * d.MW + ((tid / YCH) % TW)) * cd_units + cou0 + ych) : 0u;
+    const unsigned ystep = yok ? (unsigned)(((NT / YCH) / TW) * d.MW * cd_units) : 0u;
+    const int shs = d.SH << sh, sws = d.SW << sh;
+    const int row0 = -1 >> sh, col0 = -1 >> sh;               // patch origin (tile - 1) at the stored resolution (floor)
+    const unsigned xsafe = (unsigned)(((0 - row0) * d.SW + (0 - col0)) * cs_units);
+    unsigned xoff[XIT];
+    unsigned xhalo = 0, xin = 0;
+    static_assert(XIT <= 8, "halo bits");
+#pragma unroll
+    for (int it = 0; it < XIT; ++it) {
+        const int pp = (tid + it * NT) / XCH;
+        const int py = pp / PW, px = pp - py * PW;
+        const bool in = pp < PH * PW && ciu0 + xch < cs_units;
+        xin |= in ? (1u << it) : 0u;
+        xoff[it] = in ? (unsigned)(((((py - 1) >> sh) - row0) * d.SW + (((px - 1) >> sh) - col0)) * cs_units + ciu0 + xch) : xsafe;
+        const unsigned hb = !in ? 0u : ((py - 1 < 0 ? 1u : 0u) | (py - 1 >= shs - (t.tiles_y - 1) * TH ? 2u : 0u) |
+                                        (px - 1 < 0 ? 4u : 0u) | (px - 1 >= sws - (t.tiles_x - 1) * TW ? 8u : 0u));
+        xhalo |= hb << (4 * it);
+    }
+    u32x4 yv[YIT], xv[XIT];
+    unsigned xzero = 0;
+    auto prefetch = [&](int tile) {
+        const int img = __builtin_amdgcn_readfirstlane(tile / tpi), trem = tile - img * tpi;
+        const int ty = __builtin_amdgcn_readfirstlane(trem / t.tiles_x), tx = trem - ty * t.tiles_x;
+        const int a0 = ty * TH, b0 = tx * TW;
+        const u32x4* __restrict__ yb = y16 + (((size_t)img * d.MH + a0) * d.MW + b0) * cd_units;
+#pragma unroll
+        for (int it = 0; it < YIT; ++it) yv[it] = yb[yoff0 + it * ystep];
+        const unsigned border = (ty == 0 ? 1u : 0u) | (ty == t.tiles_y - 1 ? 2u : 0u) | (tx == 0 ? 4u : 0u) | (tx == t.tiles_x - 1 ? 8u : 0u);
+        const long long xbase = (((long long)img * d.SH + ((a0 >> sh) + row0)) * d.SW + ((b0 >> sh) + col0)) * cs_units;
+        const u32x4* __restrict__ xb = x16 + xbase;
+        xzero = 0;
+#pragma unroll
+        for (int it = 0; it < XIT; ++it) {
+            const bool out = (((xhalo >> (4 * it)) & 15u) & border) != 0;
+            xv[it] = xb[out ? xsafe : xoff[it]];
+            xzero |= out ? (1u << it) : 0u;
+        }
+    };
+
+    float bsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bool do_bias = dbias != nullptr && blockIdx.y == 0;
+    int tile = blockIdx.x;
+    if (tile < t.ntiles) prefetch(tile);
+    const int fr = lane & 15, fg = lane >> 4;
+    const int q = fr >> 2, pp4 = fr & 3;
+    // group gi of this wave: g = slice + gi * NS -> Cin block g / 3, tap column g % 3; LDS byte offset of its row-0 fragment
+    int goff[GPW];
+#pragma unroll
+    for (int gi = 0; gi < GPW; ++gi) {
+        const int g = slice + gi * NS;
+        goff[gi] = (g % 3) * XS + (g / 3) * 32;
+    }
+    const unsigned char* afrag = ydy + (size_t)(4 * fg + q) * YS + (cg * CBW * 16 + 4 * pp4) * 2;
+    const unsigned char* bfrag = xp + (size_t)(4 * fg + q) * XS + (4 * pp4) * 2;
+    const unsigned char *afr = afrag, *bfr = bfrag;
+
+    for (; tile < t.ntiles; tile += gridDim.x) {
+        __syncthreads();                                      // previous tile's reads are done
+#pragma unroll
+        for (int it = 0; it < YIT; ++it) {
+            u32x4 v = yv[it];
+            if (!yok) v = u32x4{0, 0, 0, 0};
+            *reinterpret_cast<u32x4*>(ydy + ((tid + it * NT) / YCH) * YS + ych * 16) = v;
+        }
+        if (do_bias) {
+#pragma unroll
+            for (int it = 0; it < YIT; ++it) {
+                const bf16x8 h = __builtin_bit_cast(bf16x8, yv[it]);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) bsum[k] += yok ? (float)h[k] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < XIT; ++it) {
+            u32x4 v = xv[it];
+            if ((xzero >> it) & 1) v = u32x4{0, 0, 0, 0};
+            if ((xin >> it) & 1) *reinterpret_cast<u32x4*>(xp + ((tid + it * NT) / XCH) * XS + xch * 16) = v;
+        }
+        __syncthreads();
+        if (tile + (int)gridDim.x < t.ntiles) prefetch(tile + gridDim.x);
+        {
+            int zq = 0;
+            asm volatile("" : "+v"(zq));
+            afr = afrag + zq; bfr = bfrag + zq;
+        }
+        bf16x8 af[2][CBW], xf[GPW][3];
+        auto rd_a = [&](int r, bf16x8* a) {
+#pragma unroll
+            for (int c = 0; c < CBW; ++c) {
+                const unsigned char* ab = afr + (size_t)(r * 32) * YS + c * 32;
+                bf16x4 alo = xmc_ds_read_tr16((ab));
+                bf16x4 ahi = xmc_ds_read_tr16((ab + 16 * YS));
+                a[c] = bf16x8{alo[0], alo[1], alo[2], alo[3], ahi[0], ahi[1], ahi[2], ahi[3]};
+            }
+        };
+        auto rd_x = [&](int gi, int prow) -> bf16x8 {          // patch row `prow` of group gi, columns kw .. kw + 31
+            const unsigned char* bb = bfr + (prow * PW) * XS + goff[gi];
+            bf16x4 blo = xmc_ds_read_tr16((bb));
+            bf16x4 bhi = xmc_ds_read_tr16((bb + 16 * XS));
+            return bf16x8{blo[0], blo[1], blo[2], blo[3], bhi[0], bhi[1], bhi[2], bhi[3]};
+        };
+        rd_a(0, af[0]);
+#pragma unroll
+        for (int gi = 0; gi < GPW; ++gi) {
+            xf[gi][0] = rd_x(gi, 0);
+            xf[gi][1] = rd_x(gi, 1);
+        }
+#pragma unroll
+        for (int r = 0; r < KS; ++r) {
+            // the new patch row (r + 2) of every group and the dy fragments of step r + 1 are requested in front of the MFMAs on the
+            // two rows that are already in registers (kh = 0, 1); the MFMAs on the new row (kh = 2) come last
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll
+                for (int gi = 0; gi < GPW; ++gi) {
+                    if (kh == 0) xf[gi][(r + 2) % 3] = rd_x(gi, r + 2);
+                    if (kh == 1 && gi == 0 && r + 1 < KS) rd_a(r + 1, af[(r + 1) & 1]);
+#pragma unroll
+                    for (int c = 0; c < CBW; ++c)
+                        acc[gi * 3 + kh][c] = XMC_MFMA_16x16x32(af[r & 1][c], xf[gi][(r + kh) % 3], acc[gi * 3 + kh][c], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    }
+
+    if (do_bias) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float v = bsum[k];
+            for (int o = 32; o >= YCH; o >>= 1) v += __shfl_xor(v, o, 64);
+            int ch = co0 + (lane % YCH) * 8 + k;
+            if (lane < YCH && ch < d.CD) atomicAdd(&dbias[(blockIdx.x & (XMC_BIAS_REPLICAS - 1)) * d.CD + ch], v);
+        }
+    }
+#pragma unroll
+    for (int gi = 0; gi < GPW; ++gi) {
+        const int g = slice + gi * NS, ib = g / 3, kw = g % 3;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            float* __restrict__ sl = dwp + (size_t)d.wi[0][kh * 3 + kw] * d.CDw * d.CS;
+#pragma unroll
+            for (int c = 0; c < CBW; ++c)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int co = co0 + (cg * CBW + c) * 16 + fg * 4 + rr, ci = ci0 + ib * 16 + fr;
+                    if (co < d.CDw && co < co0 + CDP && ci < d.CS) atomicAdd(&sl[(size_t)co * d.CS + ci], acc[gi * 3 + kh][c][rr]);
+                }
+        }
+    }
+}
+
+template <int NCO, int NCI, int NCG>
+int launch_wt_rr(const XmcConvDesc& d, float* dwp, float* dbias, const WTCfg& t, hipStream_t st) {
+    constexpr int YS = NCO * 32 + 32, XS = NCI * 32 + 32;
+    const size_t lds = (size_t)256 * YS + (size_t)10 * 34 * XS;
+    if (lds > XMC_MAX_DYN_LDS) return 1;
+    XMC_ALLOW_BIG_LDS((wgrad_tile_rr_kernel<NCO, NCI, NCG>));
+    const int ny = (d.CS + 63) / 64, nz = (d.CD + 63) / 64;
+    int gx = 256 / (ny * nz);
+    if (gx < 1) gx = 1;
+    if (gx > t.ntiles) gx = t.ntiles;
+    hipLaunchKernelGGL((wgrad_tile_rr_kernel<NCO, NCI, NCG>), dim3(gx, ny, nz), dim3(512), lds, st, d, dwp, dbias, t);
+    xmc_note_kernel("wgrad_tile_rr_kernel<%d, %d, %d>", NCO, NCI, NCG);
+    XMC_LAUNCH_CHECK();
+    return 0;
+}
+
 template <int NCO, int NCI, int NT = 256, int SA = 1, int KT = 9, int CBW = 1, bool DIAG = false, bool T16 = false>
 int launch_wt(const XmcConvDesc& d, float* dwp, float* dbias, const WTCfg& t, hipStream_t st) {
     constexpr int YS = NCO * 32 + 32, XS = NCI * 32 + 32;
@@ -411,6 +625,15 @@ int xmc_conv_wgrad_tile_try(const XmcConvDesc* d, float* dwp, float* dbias, void
     if (t16) {        // the wide layers on 16-pixel-wide maps (the row kernel otherwise: 540-600 TF/s)
         if (nco == 4 && nci == 4) return launch_wt<4, 4, 512, 1, 9, 4, false, true>(*d, dwp, dbias, t, st);
         return 1;
+    }
+    // the full 3x3 tap set in row-major order on 8 x 32 tiles: the row-reuse form (0.56 LDS reads per MFMA instead of 0.9)
+    static const bool no_rr = xmc_debug_off("no_wt_rr");
+    bool std33 = d->ntaps == 9 && t.PH == 10 && t.PW == 34 && d->groups <= 1;
+    for (int k = 0; k < 9 && std33; ++k) std33 = d->dh[0][k] == k / 3 - 1 && d->dw[0][k] == k % 3 - 1;
+    if (!no_rr && std33) {
+        if (nco == 4 && nci == 4) return launch_wt_rr<4, 4, 2>(*d, dwp, dbias, t, st);
+        if (nco == 2 && nci == 4) return launch_wt_rr<2, 4, 2>(*d, dwp, dbias, t, st);
+        if (nco == 4 && nci == 2) return launch_wt_rr<4, 2, 4>(*d, dwp, dbias, t, st);
     }
 #define WT_CASE(a, b) if (nco == a && nci == b) return launch_wt<a, b, 256, 1, 9, (a >= 2 ? 2 : 1)>(*d, dwp, dbias, t, st);
     // (4,4) = 64x64 channels with 4 waves needs 144 accumulator + 76 staging registers per lane and measured slower than
