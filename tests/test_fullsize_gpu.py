@@ -127,30 +127,55 @@ def test_full_size_backward_equals_sum_of_batch_slices(size, batch, mode):
     print(f"\n[{size}px b{batch} {mode}] dgrad slices {rel_err(dx[:hb], dx0):.1e}, wgrad full vs sum of halves worst {worst:.1e}")
 
 
-@pytest.mark.parametrize("mode", ["fp32", "bf16"])
-def test_config2_generator_full_batch_equals_slices(mode):
-    """config 2's generator at batch 64: forward and weight gradients of the full batch == those of its batch-8 slices (the
-    batch size the oracle-pinned NCH=32 iteration test runs at)."""
+@pytest.mark.parametrize("yml,size,batch,nsl,mode", [
+    ("df_gan_damsm_nomagp.yml", 64, 64, 8, "fp32"), ("df_gan_damsm_nomagp.yml", 64, 64, 8, "bf16"),                         # config 2
+    ("concept_in_df_gan_damsm_nomagp.yml", 128, 64, 8, "fp32"), ("concept_in_df_gan_damsm_nomagp.yml", 128, 64, 8, "bf16"),  # config 3
+    ("df_gan_damsm_nomagp.yml", 256, 256, 2, "bf16")])                                                                        # configs 4 / 5
+def test_generator_full_batch_equals_slices(yml, size, batch, nsl, mode):
+    """The generators of BASELINE configs 2, 3 (word-region attention modulation, 128 px, the real width NCH = 32) and 4 / 5 at their
+    REAL batch: forward and weight gradients of the full batch == those of its batch slices (8 slices of 8 samples -- the batch
+    size the oracle-pinned iteration tests run at -- or, at 256 images of 256 px, the two halves).  The generators do not couple
+    the samples of a batch (GroupNorm is per sample), the loss is linear in the image, and kernel dispatch is size-dependent:
+    the full batch takes the persistent / multi-image / large-launch kernels, the slices the small-launch ones."""
     ops.set_precision(mode)
-    cfg, h = setup_cfg("df_gan_damsm_nomagp.yml")
+    cfg, h = setup_cfg(yml, **{"IMG.SIZE": size})
+    assert h.nch == 32
     PG, PD = X.synth_params(X.gen_shapes(h), 3), X.synth_params(X.netd_shapes(h), 4)
-    b = {k_: v.to(DEV) for k_, v in X.synth_batch(h, 64, seed=32, words_len=cfg.TEXT.MAX_LENGTH).items()}
+    b = {k_: v.to(DEV) for k_, v in X.synth_batch(h, batch, seed=32, words_len=cfg.TEXT.MAX_LENGTH).items()}
     netG, _, _, _ = build_product(h, PG, PD)
-    r = torch.randn(64, 3, 64, 64, generator=torch.Generator().manual_seed(6)).to(DEV)
+    r = torch.randn(batch, 3, size, size, generator=torch.Generator().manual_seed(6)).to(DEV)
 
     def run(sl):
         netG.zero_grad()
+        ops.new_iteration(DEV)
         img = netG(noise=b["noise"][sl], sent_embs=b["sent_embs"][sl], words_embs=b["words_embs"][sl], mask=b["mask"][sl])
         (img * r[sl]).sum().backward()
         return img.detach().clone(), {n: p.grad.detach().clone() for n, p in netG.named_parameters() if p.grad is not None}
 
-    img, gw = run(slice(0, 64))
+    img, gw = run(slice(0, batch))
     acc = None
     t = 1e-5 if mode == "fp32" else 2e-2
-    for i in range(8):
-        im_i, gw_i = run(slice(8 * i, 8 * i + 8))
-        assert mean_abs_err(img[8 * i:8 * i + 8], im_i) < t
+    per = batch // nsl
+    worst_img = 0.0
+    for i in range(nsl):
+        im_i, gw_i = run(slice(per * i, per * (i + 1)))
+        worst_img = max(worst_img, mean_abs_err(img[per * i:per * (i + 1)], im_i))
         acc = gw_i if acc is None else {n: acc[n] + gw_i[n] for n in acc}
-    worst = max(rel_err(gw[n], acc[n]) for n in gw)
-    assert worst < (2e-4 if mode == "fp32" else 3e-2), worst
-    print(f"\n[G 64px b64 {mode}] weight gradients full vs sum of 8 slices: worst {worst:.1e}")
+    assert worst_img < t, worst_img
+    assert set(gw) == set(acc)
+    # per tensor, relative to its own norm or (tensors that are zero up to rounding: a GroupNorm bias in front of a softmax shifts
+    # every logit alike and has NO gradient) to a floor of the largest tensor norm, as compare_grads does
+    big = max(acc[n].norm().item() for n in acc)
+    fl = 1e-4 if mode == "fp32" else 2e-2
+    errs = {n: ((gw[n] - acc[n]).norm() / max(acc[n].norm().item(), fl * big)).item() for n in gw}
+    worst = max(errs, key=errs.get)
+    tot = rel_err(torch.cat([gw[n].flatten() for n in gw]), torch.cat([acc[n].flatten() for n in gw]))
+    print(f"\n[G {yml} {size}px b{batch} {mode}] image {worst_img:.1e}; weight gradients full vs sum of {nsl} slices: worst {errs[worst]:.1e} "
+          f"({worst}), all tensors as one vector {tot:.1e}")
+    # fp32: f32 accumulation in another order (atomics, tile order).  The attention-modulation generator's query / key parameters
+    # carry a heavily cancelling sum over 16 384 regions (tests/test_models_gpu.py): their f32 run-to-run spread is 1e-3 .. 5e-3
+    wbar = (2e-4 if h.gen == "DF_GEN" else 2e-3) if mode == "fp32" else 3e-2        # measured 5e-6 / 5.6e-4 / 8e-6
+    if mode == "bf16" and h.gen != "DF_GEN":
+        wbar = 0.3          # (measured 0.13; vector 1.6e-2) per tensor: a gross-error guard for those cancelling sums at 8-bit storage; the vector bound is the check
+    assert errs[worst] < wbar, (worst, errs[worst])
+    assert tot < (1e-3 if mode == "fp32" else 3e-2), tot
