@@ -467,6 +467,8 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
                 if (mc == MC - 1) __syncthreads();    // B2: patch may be overwritten
                 // epilogue from registers: acc[pb][c][8v + r] = pixel wm*64 + pb*32 + l32, channel n0 + 32c + 16hh + 8v + r
                 bf16x8* __restrict__ dst8 = reinterpret_cast<bf16x8*>(d.dst);
+                unsigned sgn[2] = {0u, 0u};           // packed sign bytes of this lane's four units, per pixel block
+                const bool pack_sign = e_sign && NB == 2 && d.CD == 64;
 #pragma unroll
                 for (int c = 0; c < NB; ++c) {
                     const int ub = c * 4 + hh * 2;        // first of this lane's two 8-channel units of the block
@@ -497,7 +499,11 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
                                 unsigned sb = 0;
 #pragma unroll
                                 for (int r = 0; r < 8; ++r) sb |= (v[r] > 0.f ? 1u : 0u) << r;
-                                reinterpret_cast<unsigned char*>(d.sign_bits)[idx8] = (unsigned char)sb;
+                                // one byte per 8-channel unit.  A lane owns units hh*2 + {0,1} (c = 0) and 4 + hh*2 + {0,1} (c = 1) of its
+                                // pixel: with all 8 units of the pixel in play (CD == 64) the bytes are collected and the pixel's 8 sign
+                                // bytes leave as ONE dword per lane (below) instead of four byte stores per lane and pixel block
+                                if (pack_sign) sgn[pb] |= sb << (8 * (2 * c + v2));
+                                else reinterpret_cast<unsigned char*>(d.sign_bits)[idx8] = (unsigned char)sb;
                             }
                             if (e_round) {
                                 bf16x8 o2;
@@ -563,6 +569,18 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
                                 }
                             }
                         }
+                    }
+                }
+                if (e_sign && pack_sign) {
+                    // lane halves hh = 0 / 1 of a pixel hold bytes {0,1 | 4,5} / {2,3 | 6,7}: swap the halves they do not store, then
+                    // lane (l32, hh) writes bytes 4*hh .. 4*hh+3 -- 32 pixels x 8 bytes = 256 contiguous bytes per store instruction
+#pragma unroll
+                    for (int pb = 0; pb < 2; ++pb) {
+                        const unsigned keep = hh == 0 ? (sgn[pb] & 0xFFFFu) : (sgn[pb] >> 16);
+                        const unsigned send = hh == 0 ? (sgn[pb] >> 16) : (sgn[pb] & 0xFFFFu);
+                        const unsigned recv = (unsigned)__shfl_xor((int)send, 32, 64);
+                        const unsigned word = hh == 0 ? (keep | (recv << 16)) : (recv | (keep << 16));
+                        reinterpret_cast<unsigned*>(d.sign_bits)[(size_t)(eo[pb] >> 2) + hh] = word;      // eo = pixel * 8 sign bytes
                     }
                 }
             }
