@@ -31,8 +31,9 @@ extern "C" {
  *    xmc_adam_step gained grad_scale.
  * 4: XmcConvDesc.sign_bits / dot (a discriminator block keeps sign bits; d(gamma) from a data-gradient epilogue).
  * 5: xmc_conv_pw1x1_masked_src (the sign-mask pass as a by-product of the shortcut's data gradient).
- * 6: xmc_adam_step_scaled (dynamic loss scale with a found-inf skip); xmc_gp_finish gained inv_s2. */
-#define XMC_ABI_VERSION 6
+ * 6: xmc_adam_step_scaled (dynamic loss scale with a found-inf skip); xmc_gp_finish gained inv_s2.
+ * 7: xmc_dstem_* (the discriminator's stem composed into one convolution from the image). */
+#define XMC_ABI_VERSION 7
 
 /* XMC_BF16 names the 16-bit storage / MFMA-operand format THIS BUILD of the library was compiled for: bf16 in
  * libxmc_gan_hip.so, IEEE half in libxmc_gan_hip_f16.so (same sources, same entry points; xmc_half_format()). */
@@ -439,6 +440,34 @@ int xmc_concept_head_fwd(const float* ctx, const float* sent, const float* const
 int xmc_concept_head_bwd(const float* ctx, const float* sent, const float* hid, const float* const* params, const float* dgamma,
                          const float* dbeta, float* dctx, float* dsent, float* const* grads, float* scratch, int B, int E,
                          void* stream);
+
+/* ---- the discriminator's stem as one convolution from the image (csrc/dstem.hip) -------------------------------------------------
+ * conv_img (df_gan.py:114,127) feeds the first resD block without an activation, so conv_r[0] o conv_img is a 6x6 stride-2 pad-2
+ * convolution of the image and conv_s o avg_pool2d o conv_img a 4x4 stride-2 pad-1 one (df_gan.py:272-291).  img [N,H,W,8] in the
+ * 16-bit format; composed weights f32 [128][36 taps = ta*6+tb][8] and biases f32 [128]: rows 0-63 give h1 = lrelu(.)
+ * [N,H/2,W/2,64], rows 64-127 the shortcut sc [N,H/2,W/2,64].  Exact except for h1's pixels on the image border (conv_r[0] pads
+ * conv_img's OUTPUT with zeros): the host recomputes those (ops.DStemBlockFn).  H % 16 == 0, W % 64 == 0.
+ *  pack:  composed weights -> wfrag (72 KB, MFMA fragment order, 16-bit);  fwd: h1, sc;
+ *  wgrad: dw[128][36][8], dbias[128] (f32, zeroed by the caller) += sums over output pixels of (dh1 | dsc)(pixel) x patch(pixel) and
+ *         of (dh1 | dsc); with skip_border the border pixels of dh1 do not contribute. */
+/* the composition itself and its adjoint (parameter-sized f32 work, one thread per element): conv_img.weight [32][3][3][3] and .bias
+ * [32], conv_r[0].weight [64][32][4][4], conv_s.weight [64][32] and .bias [64] (or NULL) -> the four tables; and the tables'
+ * gradients -> the parameters' gradients (written, not accumulated). */
+int xmc_dstem_compose(const float* wi, const float* bi, const float* w0, const float* ws, const float* bs, float* W, float* bias, float* D,
+                      float* DB, void* stream);
+int xmc_dstem_compose_bwd(const float* wi, const float* bi, const float* w0, const float* ws, const float* dW, const float* dbias,
+                          const float* dD, const float* dDB, float* dwi, float* dbi, float* dw0, float* dws, float* dbs, void* stream);
+int xmc_dstem_pack(const float* wsets, void* wfrag, void* stream);
+int xmc_dstem_fwd(const void* img, const void* wfrag, const float* bias, void* h1, void* sc, int N, int H, int W, float slope, void* stream);
+int xmc_dstem_wgrad(const void* img, const void* dh1, const void* dsc, float* dw, float* dbias, int N, int H, int W, int skip_border,
+                    void* stream);
+/* h1's border pixels (conv_r[0]'s zero padding of conv_img's output): correction tables D f32 [64][28][8] (taps 0-5 first row by
+ * window column, 6-11 last row, 12-17 first column by window row, 18-23 last column, 24-27 corners) and DB f32 [64][8] (their
+ * constant terms), linear in the parameters like the composed weights.  border_fwd recomputes h1 on the border from the image with
+ * w (f32 [128][36][8], rows 0-63 used) + D; border_wgrad: dD, dDB (zeroed by the caller) += sums over border pixels. */
+int xmc_dstem_border_fwd(const void* img, const float* w, const float* bias, const float* D, const float* DB, void* h1, int N, int H, int W,
+                         float slope, void* stream);
+int xmc_dstem_border_wgrad(const void* img, const void* dh1, float* dD, float* dDB, int N, int H, int W, void* stream);
 
 #ifdef __cplusplus
 }

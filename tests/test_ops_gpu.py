@@ -1116,3 +1116,129 @@ def test_generator_block_end_node_equals_composed_operators(mode, C, H, tail, ga
         else:
             ec = (cp - truth).abs().max().item() / scl
             assert ef <= 2 * ec + 1e-2, (nm, ef, ec)
+
+
+@pytest.mark.parametrize("mode", ["bf16", "f16"])
+@pytest.mark.parametrize("N,H,W", [(2, 64, 64), (3, 32, 128), (1, 256, 256)])
+def test_discriminator_stem_composition_kernels(N, H, W, mode):
+    """csrc/dstem.hip: conv_img -> conv_r[0] (4x4 stride 2) and conv_img -> avg_pool2d -> conv_s as one 6x6 stride-2 convolution of
+    the image with composed weights (ops.compose_dstem), against the two-stage computation in f32 on the CPU (df_gan.py:114,127,
+    272-291): interior pixels of h1 and every pixel of the shortcut must agree, and after the border kernel every pixel of h1; the
+    weight-gradient kernel against autograd through the same composed convolution (the gradients of the border tables are checked
+    end to end by test_composed_stem_block_equals_conv_img_plus_block)."""
+    ops.set_precision(mode)
+    dt = ops.act_dtype()
+    g = torch.Generator().manual_seed(N + H)
+    x = rt(torch.rand(N, 3, H, W, generator=g) * 2 - 1, mode)
+    w_img, b_img = torch.randn(32, 3, 3, 3, generator=g) / math.sqrt(27), torch.randn(32, generator=g) * 0.1
+    w0 = torch.randn(64, 32, 4, 4, generator=g) / math.sqrt(512)
+    ws, bs = torch.randn(64, 32, 1, 1, generator=g) / math.sqrt(32), torch.randn(64, generator=g) * 0.1
+    ci = F.conv2d(x, w_img, b_img, 1, 1)
+    h1_ref = F.leaky_relu(F.conv2d(ci, w0, None, 2, 1), 0.2)
+    sc_ref = F.conv2d(F.avg_pool2d(ci, 2), ws, bs)
+    wsets, bias, D, DB = ops.compose_dstem(w_img.to(DEV), b_img.to(DEV), w0.to(DEV), ws.to(DEV), bs.to(DEV))
+    # the composition itself, in f32 on the CPU: a 6x6 stride-2 pad-2 convolution
+    wc = wsets.cpu().view(128, 6, 6, 8).permute(0, 3, 1, 2)[:, :3]
+    yc = F.conv2d(x, wc, bias.cpu(), 2, 2)
+    assert (F.leaky_relu(yc[:, :64], 0.2) - h1_ref)[:, :, 1:-1, 1:-1].abs().max() < 1e-4 and (yc[:, 64:] - sc_ref).abs().max() < 1e-4
+    xin = to_nhwc(x, 8, dt)
+    h1, sc = ops._dstem_fwd_raw(xin, wsets, bias)
+    assert L.load().xmc_last_kernel().decode() == "dstem_fwd_kernel"
+    t = dict(rtol=2e-2, atol=2e-2 * h1_ref.abs().max().item()) if mode == "bf16" else dict(rtol=3e-3, atol=3e-3 * h1_ref.abs().max().item())
+    torch.testing.assert_close(from_nhwc(h1, 64)[:, :, 1:-1, 1:-1], h1_ref[:, :, 1:-1, 1:-1], **t)
+    torch.testing.assert_close(from_nhwc(sc, 64), sc_ref, **t)
+    # ... and with the border corrections (conv_r[0]'s zero padding of conv_img's output) every pixel of h1
+    ops._dstem_border_fwd_raw(xin, wsets, bias, D, DB, h1)
+    torch.testing.assert_close(from_nhwc(h1, 64), h1_ref, **t)
+    # weight gradient: d/dW of sum(y * r) for y = conv6x6(x; W) = sum_pixels r (x) patch; border pixels of the h1 half excluded
+    r = rt(torch.randn(N, 128, H // 2, W // 2, generator=g), mode)
+    rm = r.clone()
+    rm[:, :64, 0] = 0; rm[:, :64, -1] = 0; rm[:, :64, :, 0] = 0; rm[:, :64, :, -1] = 0
+    wc8 = torch.zeros(128, 8, 6, 6, requires_grad=True)
+    bc = torch.zeros(128, requires_grad=True)
+    x8 = torch.cat((x, torch.zeros(N, 5, H, W)), 1)
+    (F.conv2d(x8, wc8, bc, 2, 2) * rm).sum().backward()
+    ops.new_iteration(DEV)
+    dw, db, _, _ = ops._dstem_wgrad_raw(xin, to_nhwc(r[:, :64], 64, dt), to_nhwc(r[:, 64:], 64, dt), skip_border=True, border=False)
+    ref = wc8.grad.permute(0, 2, 3, 1).reshape(128, 36, 8)
+    assert ((dw.cpu() - ref).norm() / ref.norm()) < 5e-5, (dw.cpu() - ref).norm() / ref.norm()
+    assert ((db.cpu() - bc.grad).norm() / bc.grad.norm()) < 5e-5
+
+
+@pytest.mark.parametrize("mode,N,S", [("f16", 3, 64), ("bf16", 2, 128), ("bf16", 8, 64)])
+def test_composed_stem_block_equals_conv_img_plus_block(mode, N, S):
+    """ops.DStemBlockFn (conv_img + the first discriminator block on the composed stem, border pixels on strips) against the form it
+    replaces -- conv_img, then ops.ResDFn -- on the same parameters and image: block output, pooled output and the gradients of all
+    seven parameter tensors under a random linear loss.  The two forms round different intermediates to 16 bits (the composed one
+    fewer), so they are compared with each other at the format's tolerance and, border pixels included, with the f32 CPU reference."""
+    ops.set_precision(mode)
+    dt = ops.act_dtype()
+    from xmc_gan.model.df_gan import resD
+    from xmc_gan.model.modules import HipConv2d
+    torch.manual_seed(5)
+    conv_img = HipConv2d(3, 32, 3, 1, 1).to(DEV)
+    blk = resD(32, 64, True).to(DEV)
+    with torch.no_grad():
+        blk.gamma.fill_(0.7)
+        conv_img.bias.normal_(0, 0.1)
+        blk.conv_s.bias.normal_(0, 0.1)
+    g = torch.Generator().manual_seed(N + S)
+    x = rt(torch.rand(N, 3, S, S, generator=g) * 2 - 1, mode)
+    xin = to_nhwc(x, 8, dt)
+    r = rt(torch.randn(N, 64, S // 2, S // 2, generator=g), mode)
+    params = [conv_img.weight, conv_img.bias, blk.conv_r[0].weight, blk.conv_r[2].weight, blk.conv_s.weight, blk.conv_s.bias, blk.gamma]
+
+    def grads(out):
+        for p_ in params:
+            p_.grad = None
+        ops.new_iteration(DEV)
+        (out.float() * to_nhwc(r, 64, torch.float32)).sum().backward()
+        return [p_.grad.detach().float().cpu().clone() for p_ in params]
+
+    ci, cip = conv_img(xin, want_pool=True)
+    out_o, pool_o = blk(ci, xp_hint=cip, want_pool=True)
+    g_o = grads(out_o)
+    r0, r2, s_ = blk.conv_r[0], blk.conv_r[2], blk.conv_s
+    out_n, pool_n = ops.DStemBlockFn.apply(xin, conv_img.weight, conv_img.bias, r0.weight, r2.weight, s_.weight, s_.bias, blk.gamma,
+                                           conv_img.geom, r0.geom, r2.geom, s_.geom, True)
+    g_n = grads(out_n)
+    # f32 reference on the CPU
+    P = [p_.detach().float().cpu().clone().requires_grad_() for p_ in params]
+    ci_r = F.conv2d(x, P[0], P[1], 1, 1)
+    br = F.leaky_relu(F.conv2d(F.leaky_relu(F.conv2d(ci_r, P[2], None, 2, 1), 0.2), P[3], None, 1, 1), 0.2)
+    out_r = F.conv2d(F.avg_pool2d(ci_r, 2), P[4], P[5]) + P[6] * br
+    (out_r * r).sum().backward()
+    tl = 2e-2 if mode == "bf16" else 3e-3
+    sc_ = out_r.abs().max().item()
+    torch.testing.assert_close(from_nhwc(out_n, 64), out_r.detach(), rtol=tl, atol=tl * sc_)
+    torch.testing.assert_close(from_nhwc(out_n, 64), from_nhwc(out_o, 64), rtol=tl, atol=tl * sc_)
+    torch.testing.assert_close(from_nhwc(pool_n, 64), F.avg_pool2d(out_r.detach(), 2), rtol=tl, atol=tl * sc_)
+    names = ["conv_img.weight", "conv_img.bias", "conv_r.0.weight", "conv_r.2.weight", "conv_s.weight", "conv_s.bias", "gamma"]
+    for n_, a, b, c in zip(names, g_n, g_o, P):
+        e_ref, e_old = rel_l2(a, c.grad), rel_l2(b, c.grad)
+        print(f"{n_:18s} composed vs f32 {e_ref:.2e}   conv_img + ResDFn vs f32 {e_old:.2e}")
+        assert e_ref < (3e-2 if mode == "bf16" else 4e-3) or e_ref < 1.5 * e_old + 1e-3, (n_, e_ref, e_old)
+
+
+def rel_l2(a, b):
+    return ((a - b).norm() / b.norm().clamp_min(1e-12)).item()
+
+
+def test_stem_composition_launches_equal_the_torch_statement():
+    """xmc_dstem_compose / xmc_dstem_compose_bwd against ops.compose_dstem (the same algebra in differentiable torch ops) and its
+    autograd adjoint: the four tables and the gradients of the five parameters for random table gradients."""
+    g = torch.Generator().manual_seed(11)
+    P = [torch.randn(32, 3, 3, 3, generator=g), torch.randn(32, generator=g), torch.randn(64, 32, 4, 4, generator=g) * 0.2,
+         torch.randn(64, 32, 1, 1, generator=g), torch.randn(64, generator=g)]
+    leaves = [p_.to(DEV).requires_grad_() for p_ in P]
+    ref = ops.compose_dstem(*leaves)
+    got = ops._dstem_compose_raw(*leaves)
+    for a, b in zip(got, ref):
+        assert a.shape == b.shape and rel_l2(a, b.detach()) < 1e-5
+    douts = [torch.randn(t.shape, generator=g).to(DEV) for t in ref]
+    for t in (douts[0], douts[2]):
+        t[..., 3:] = 0                                  # the kernels never write gradient into the padded channels
+    want = torch.autograd.grad(ref, leaves, douts)
+    have = ops._dstem_compose_bwd_raw(*leaves, *douts)
+    for name, a, b in zip(("conv_img.weight", "conv_img.bias", "conv_r.0.weight", "conv_s.weight", "conv_s.bias"), have, want):
+        assert rel_l2(a.reshape(b.shape), b) < 1e-5, (name, rel_l2(a.reshape(b.shape), b))

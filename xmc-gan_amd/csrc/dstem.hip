@@ -1,0 +1,695 @@
+// The discriminator's stem as ONE convolution from the image (round 4).
+//
+// Reference: NetD.forward runs `conv_img` (3x3, 3 -> ndf, bias; df_gan.py:114,127) and hands its output to the first resD block,
+// whose residual branch starts with a 4x4 stride-2 convolution WITHOUT an activation in between and whose shortcut is
+// conv_s(avg_pool2d(.)) (df_gan.py:272-291).  Both are linear in the image:
+//     conv_r[0](conv_img(x))          = a 6x6 stride-2 pad-2 convolution of x   with W_A = sum_mid W_0 (*) W_img
+//     conv_s(avg_pool2d(conv_img(x))) = a 4x4 stride-2 pad-1 convolution of x   with W_B = W_s . (pool (*) W_img)
+// (conv_img's bias becomes a constant per output channel away from the border).  The 32-channel full-resolution tensor conv_img writes -- 2.1 GB at 256x256 x 512 images, the largest
+// tensor of the step, read back by two forward and three backward kernels -- never exists, and the 4x4 convolution's K = 512
+// becomes K = 108.  conv_r[0] pads conv_img's OUTPUT with zeros, which the composition does not see: output pixels on the image
+// border are recomputed the reference's way on 4-pixel-wide strips by the host (ops.DStemFn), everything else is exact algebra.
+//
+// Layouts: image [N,H,W,8] (channels 0-2 image, the rest ignored: their weights are zero); composed weights f32 [128][36 taps (ta*6+tb)][8]: rows 0-63
+// = W_A (LeakyReLU'd output h1 [N,H/2,W/2,64]), rows 64-127 = W_B embedded in the 6x6 window (shortcut sc [N,H/2,W/2,64]).
+//   xmc_dstem_pack    composed weights -> MFMA A-fragment order (16-bit), rows permuted so that a lane ends with 8 consecutive channels
+//   xmc_dstem_fwd     h1 = lrelu(W_A * x + b_A), sc = W_B * x + b_B       (bias f32 [128]: the composed biases, constant over the interior)
+//   xmc_dstem_wgrad   dW[128][36][8] += sum_pixels (dh1 | dsc) (x) patch(x), dbias[128] += sum_pixels (dh1 | dsc)
+//                     (border pixels of dh1 optionally excluded)
+#include "common.h"
+
+namespace {
+
+constexpr int kTaps = 36, kKSteps = 9;          // 36 taps x 8 channels = 9 MFMA K steps of 32 (4 taps each)
+
+// one thread per (fragment, lane): fragment f = (half * 4 + j) * 9 + s holds W[co(half, j, row)][tap 4s + kg][0..7]
+__global__ void dstem_pack_kernel(const float* __restrict__ w, bf16x8* __restrict__ frag) {
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= 8 * kKSteps * 64) return;
+    const int lane = id & 63, f = id >> 6;
+    const int s = f % kKSteps, hj = f / kKSteps, half = hj >> 2, j = hj & 3;
+    const int q = lane & 15, kg = lane >> 4;
+    const int co = half * 64 + (j >> 1) * 32 + (q >> 2) * 8 + (j & 1) * 4 + (q & 3);
+    const float* src = w + ((size_t)co * kTaps + 4 * s + kg) * 8;
+    bf16x8 o;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) o[c] = (xmc_h16)src[c];
+    frag[id] = o;
+}
+
+// Persistent 8-wave workgroup, tile = 4 output rows x 32 output columns.  Wave (pg = w & 3, half = w >> 2) owns output row pg of
+// the tile (two 16-pixel blocks) and 64 of the 128 output channels, and keeps ITS weights -- 9 K steps x 4 row blocks of A
+// fragments, 144 registers -- for the whole launch: the K loop reads only pixel fragments from LDS (one ds_read_b128 per four
+// MFMAs: the 16 bytes of a source pixel ARE a lane's eight K values).  Source patch (12 x 68 pixels, zero outside the image) in
+// two column-parity planes per row so that the pixels of consecutive output columns under one tap are consecutive 16-byte slots;
+// double-buffered, next tile's patch prefetched into registers: one barrier per tile.
+__global__ __launch_bounds__(512) void dstem_fwd_kernel(const u32x4* __restrict__ img, const u32x4* __restrict__ frag, const float* __restrict__ bias,
+                                                       bf16x8* __restrict__ h1, bf16x8* __restrict__ sc, int N, int H, int W, float slope, int ntiles) {
+    constexpr int TR = 4, TC = 32, PR = 2 * TR + 4, PC = 2 * TC + 4, PLANE = PC / 2;      // 12 x 68 patch, 34 slots per plane
+    constexpr int PUNITS = PR * PC;                                                       // 816 sixteen-byte units
+    __shared__ u32x4 patch[2][PR * 2 * PLANE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pg = wave & 3, half = wave >> 2;
+    const int p = lane & 15, g = lane >> 4;
+    const int OH = H >> 1, OW = W >> 1;
+    const int tiles_x = OW / TC, tpi = (OH / TR) * tiles_x;
+
+    u32x4 afr[kKSteps][4];
+#pragma unroll
+    for (int s = 0; s < kKSteps; ++s)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) afr[s][j] = frag[((half * 4 + j) * kKSteps + s) * 64 + lane];
+    // this lane's tap of K step s is 4s + g: slot offset inside the patch, relative to the pixel's own slot
+    int toff[kKSteps];
+#pragma unroll
+    for (int s = 0; s < kKSteps; ++s) {
+        const int t = 4 * s + g, ta = t / 6, tb = t - ta * 6;
+        toff[s] = (ta * 2 + (tb & 1)) * PLANE + (tb >> 1);
+    }
+    const int pbase = (2 * pg * 2) * PLANE + p;               // output pixel (pg, p) of block 0: source row 2 pg, plane 0, slot p
+    float bv[2][8];                                           // bias of this lane's channels u * 32 + g * 8 + [0, 8)
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) bv[u][c] = bias[half * 64 + u * 32 + g * 8 + c];
+
+    // staging: units u = tid, tid + 512 (816 of them)
+    int urow[2], ucol[2], udst[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int u = tid + it * 512;
+        urow[it] = u / PC; ucol[it] = u - urow[it] * PC;
+        udst[it] = (urow[it] * 2 + (ucol[it] & 1)) * PLANE + (ucol[it] >> 1);
+    }
+    u32x4 pv[2];
+    auto prefetch = [&](int tile) {
+        const int n = tile / tpi, trem = tile - n * tpi;
+        const int a0 = (trem / tiles_x) * TR, b0 = (trem % tiles_x) * TC;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int sy = 2 * a0 - 2 + urow[it], sx = 2 * b0 - 2 + ucol[it];
+            const bool ok = tid + it * 512 < PUNITS && (unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W;
+            pv[it] = ok ? img[((size_t)n * H + sy) * W + sx] : u32x4{0, 0, 0, 0};
+        }
+    };
+    int tile = blockIdx.x, buf = 0;
+    if (tile < ntiles) prefetch(tile);
+    for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+            if (tid + it * 512 < PUNITS) patch[buf][udst[it]] = pv[it];
+        __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);
+        f32x4 acc[2][4];
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[pb][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const u32x4* pp = patch[buf] + pbase;
+#pragma unroll
+        for (int s = 0; s < kKSteps; ++s) {
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb) {
+                const u32x4 bf = pp[toff[s] + pb * 16];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[pb][j] = XMC_MFMA_16x16x32(__builtin_bit_cast(bf16x8, afr[s][j]), __builtin_bit_cast(bf16x8, bf), acc[pb][j], 0, 0, 0);
+            }
+        }
+        // lane (p, g): channels u * 32 + g * 8 + [0, 8) of this wave's 64, u = 0, 1 (row blocks 2u and 2u + 1)
+        const int n = tile / tpi, trem = tile - n * tpi;
+        const int oy = (trem / tiles_x) * TR + pg, ox0 = (trem % tiles_x) * TC + p;
+        bf16x8* __restrict__ dst = half == 0 ? h1 : sc;
+        const float sl = half == 0 ? slope : 1.f;
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb) {
+            const size_t pix = ((size_t)n * OH + oy) * OW + ox0 + pb * 16;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                bf16x8 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v0 = acc[pb][2 * u][r] + bv[u][r], v1 = acc[pb][2 * u + 1][r] + bv[u][4 + r];
+                    o[r] = (xmc_h16)fmaxf(v0, v0 * sl);
+                    o[4 + r] = (xmc_h16)fmaxf(v1, v1 * sl);
+                }
+                dst[pix * 8 + u * 4 + g] = o;
+            }
+        }
+    }
+}
+
+// Weight gradient of the composed stem: dW[co][tap][c] += sum over output pixels of dy[pixel][co] * x[2 pixel + tap - 2][c], with
+// dy = (dh1 | dsc).  GEMM view: M = 128 output channels, N = 288 (tap, channel) pairs, K = pixels.  Both operands are pixel-major,
+// i.e. K-strided: fragments come from transposing LDS reads (ds_read_b64_tr_b16) as in the other weight-gradient kernels.  A
+// 16-wide N block is a PAIR of horizontally adjacent taps x 8 channels: a lane's transposing read takes 8 bytes (4 channels) of the
+// pixel unit of ITS tap.  Wave w owns the 16 output channels of row block w and all 18 tap pairs (72 accumulator registers); K
+// step r is output row r of the tile (32 pixels), whose tap row ta reads patch row 2r + ta -- the fragments of tap rows 2..5 of
+// step r are those of rows 0..3 of step r + 1, so a step reads 6 new tap-pair fragments, not 18.
+// Tile = 8 output rows x 32 columns; dy tile [256][128 + pad] and the 20 x 68 source patch in LDS, next tile prefetched into
+// registers; one atomic per weight per workgroup at the end.
+__global__ __launch_bounds__(512) void dstem_wgrad_kernel(const u32x4* __restrict__ img, const u32x4* __restrict__ dh1, const u32x4* __restrict__ dsc,
+                                                         float* __restrict__ dw, float* __restrict__ dbias, int N, int H, int W, int skip_border,
+                                                         int ntiles) {
+    constexpr int TR = 8, TC = 32, PR = 2 * TR + 4, PC = 2 * TC + 4;                      // 20 x 68 patch
+    constexpr int PLANE = PC / 2 + 2;        // 34 slots per column-parity plane, padded to 36: the two taps of a pair sit in different
+                                             // planes, 576 bytes = 16 banks apart
+    constexpr int PUNITS = PR * PC;                                                       // 1360 units
+    constexpr int YS = 128 * 2 + 32;                                                      // dy row stride (bytes): 128 channels + pad
+    constexpr int XIT = (PUNITS + 511) / 512;                                             // 3
+    constexpr int YIT = TR * TC * 16 / 512;                                               // 8 sixteen-byte units of dy per thread
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* ydy = smem;                                // [256][YS]
+    unsigned char* xp = smem + TR * TC * YS;                  // [PR][2 planes][PLANE] x 16 bytes
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int OH = H >> 1, OW = W >> 1;
+    const int tiles_x = OW / TC, tiles_y = OH / TR, tpi = tiles_y * tiles_x;
+
+    f32x4 acc[18];
+#pragma unroll
+    for (int j = 0; j < 18; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // dy staging: unit (pixel, chunk) = tid / 16 + it * 32, tid % 16; chunks 0-7 from dh1, 8-15 from dsc
+    const int ych = tid & 15, ypix0 = tid >> 4;
+    const u32x4* __restrict__ ysrc = ych < 8 ? dh1 : dsc;
+    const int ychs = ych & 7;
+    int xrow[XIT], xcol[XIT], xdst[XIT];
+#pragma unroll
+    for (int it = 0; it < XIT; ++it) {
+        const int u = tid + it * 512;
+        xrow[it] = u / PC; xcol[it] = u - xrow[it] * PC;
+        xdst[it] = ((xrow[it] * 2 + (xcol[it] & 1)) * PLANE + (xcol[it] >> 1)) * 16;
+    }
+    u32x4 yv[YIT], xv[XIT];
+    float bsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto prefetch = [&](int tile) {
+        const int n = tile / tpi, trem = tile - n * tpi;
+        const int a0 = (trem / tiles_x) * TR, b0 = (trem % tiles_x) * TC;
+#pragma unroll
+        for (int it = 0; it < YIT; ++it) {
+            const int pix = ypix0 + it * 32, py = pix >> 5, px = pix & 31;
+            u32x4 v = ysrc[(((size_t)n * OH + a0 + py) * OW + b0 + px) * 8 + ychs];
+            // the composed weights do not hold for h1's pixels on the image border (the host recomputes those): no gradient from them
+            if (skip_border && ych < 8) {
+                const int oy = a0 + py, ox = b0 + px;
+                if (oy == 0 || oy == OH - 1 || ox == 0 || ox == OW - 1) v = u32x4{0, 0, 0, 0};
+            }
+            yv[it] = v;
+        }
+#pragma unroll
+        for (int it = 0; it < XIT; ++it) {
+            const int sy = 2 * a0 - 2 + xrow[it], sx = 2 * b0 - 2 + xcol[it];
+            const bool ok = tid + it * 512 < PUNITS && (unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W;
+            xv[it] = ok ? img[((size_t)n * H + sy) * W + sx] : u32x4{0, 0, 0, 0};
+        }
+    };
+    const int fr = lane & 15, fg = lane >> 4;
+    const int q = fr >> 2, pp4 = fr & 3;
+    // A' fragment: dy^T [co = 16 wave + fr][pixel 4 fg + q (+16)]: 8 bytes = 4 channels at channel offset 4 pp4 of the wave's block
+    const unsigned char* afrag = ydy + (size_t)(4 * fg + q) * YS + (wave * 16 + 4 * pp4) * 2;
+    // B fragment of tap pair (ta, 2 tp + {0, 1}): lane (q, pp4) reads the unit of output pixel 4 fg + q under tap 2 tp + (pp4 >> 1),
+    // bytes 8 (pp4 & 1) .. +7: source column 2 px + tb -> plane tb & 1, slot px + (tb >> 1)
+    const int tbl = pp4 >> 1;                                 // which tap of the pair this lane reads
+    int boff[3];                                              // per pair column tp: byte offset (plane, slot shift, channel half)
+#pragma unroll
+    for (int tp = 0; tp < 3; ++tp) {
+        const int tb = 2 * tp + tbl;
+        boff[tp] = ((tb & 1) * PLANE + (tb >> 1) + 4 * fg + q) * 16 + (pp4 & 1) * 8;
+    }
+    int tile = blockIdx.x;
+    if (tile < ntiles) prefetch(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
+        __syncthreads();                                      // previous tile's reads are done
+#pragma unroll
+        for (int it = 0; it < YIT; ++it) {
+            *reinterpret_cast<u32x4*>(ydy + (size_t)(ypix0 + it * 32) * YS + ych * 16) = yv[it];
+            const bf16x8 hv = __builtin_bit_cast(bf16x8, yv[it]);     // bias gradient: this thread always stages channel chunk ych
+#pragma unroll
+            for (int k = 0; k < 8; ++k) bsum[k] += (float)hv[k];
+        }
+#pragma unroll
+        for (int it = 0; it < XIT; ++it)
+            if (tid + it * 512 < PUNITS) *reinterpret_cast<u32x4*>(xp + xdst[it]) = xv[it];
+        __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);
+        int zq = 0;
+        asm volatile("" : "+v"(zq));                          // opaque zero: keeps the fragment addresses out of the tile loop's live set
+        const unsigned char* afr = afrag + zq;
+        const unsigned char* bfr = xp + zq;
+        auto rd_a = [&](int r) -> bf16x8 {
+            const unsigned char* ab = afr + (size_t)(r * 32) * YS;
+            bf16x4 lo = xmc_ds_read_tr16(ab), hi = xmc_ds_read_tr16(ab + 16 * YS);
+            return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        };
+        auto rd_b = [&](int prow, int tp) -> bf16x8 {         // patch row `prow`, tap pair column tp, output pixels 0..31 of a row
+            const unsigned char* bb = bfr + (size_t)(prow * 2 * PLANE) * 16 + boff[tp];
+            bf16x4 lo = xmc_ds_read_tr16(bb), hi = xmc_ds_read_tr16(bb + 16 * 16);
+            return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        };
+        bf16x8 bq[6][3];                                      // [patch row slot (row % 6)][pair column]
+#pragma unroll
+        for (int pr = 0; pr < 4; ++pr)
+#pragma unroll
+            for (int tp = 0; tp < 3; ++tp) bq[pr][tp] = rd_b(pr, tp);
+        bf16x8 af = rd_a(0);
+#pragma unroll
+        for (int r = 0; r < TR; ++r) {
+            // output row r: tap row ta reads patch row 2r + ta; rows 2r + 4, 2r + 5 are new
+#pragma unroll
+            for (int tp = 0; tp < 3; ++tp) {
+                bq[(2 * r + 4) % 6][tp] = rd_b(2 * r + 4, tp);
+                bq[(2 * r + 5) % 6][tp] = rd_b(2 * r + 5, tp);
+            }
+            bf16x8 afn = af;
+            if (r + 1 < TR) afn = rd_a(r + 1);
+#pragma unroll
+            for (int ta = 0; ta < 6; ++ta)
+#pragma unroll
+                for (int tp = 0; tp < 3; ++tp)
+                    acc[ta * 3 + tp] = XMC_MFMA_16x16x32(af, bq[(2 * r + ta) % 6][tp], acc[ta * 3 + tp], 0, 0, 0);
+            af = afn;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // bias gradient: lanes with equal lane & 15 hold the same channel chunk
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        float v = bsum[k];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (lane < 16) atomicAdd(&dbias[lane * 8 + k], v);
+    }
+    // D[row = co][col = (tap of the pair, channel)]: lane (fr, fg) holds rows 4 fg + rr of column fr
+#pragma unroll
+    for (int ta = 0; ta < 6; ++ta)
+#pragma unroll
+        for (int tp = 0; tp < 3; ++tp)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int co = wave * 16 + fg * 4 + rr, tap = ta * 6 + 2 * tp + (fr >> 3), c = fr & 7;
+                atomicAdd(&dw[((size_t)co * kTaps + tap) * 8 + c], acc[ta * 3 + tp][rr]);
+            }
+}
+
+// ---- composition of the stem's weights (and its adjoint) ----------------------------------------------------------------------------
+// W[o][ta*6+tb][c]      = sum_mid sum_{kh+ih=ta, kw+iw=tb} w0[o][mid][kh][kw] * wi[mid][c][ih][iw]                        o < 64
+// W[64+o][ta*6+tb][c]   = sum_mid ws[o][mid] * 1/4 sum_{u+ih=ta-1, v+iw=tb-1, u,v in {0,1}} wi[mid][c][ih][iw]            1 <= ta,tb <= 4
+// bias[o] = sum w0[o][mid][.][.] bi[mid];  bias[64+o] = sum ws[o][mid] bi[mid] + bs[o];  D / DB: the border tables (below)
+// One thread per output element; mid = 32 conv_img channels, c < 3 image channels (the rest of the 8 stay zero).
+struct ComposeArgs {
+    const float *wi, *bi, *w0, *ws, *bs;                     // [32][3][3][3], [32], [64][32][4][4], [64][32], [64] or NULL
+    float *W, *bias, *D, *DB;                                // [128][36][8], [128], [64][28][8], [64][8]
+};
+__device__ __forceinline__ float wi_at(const float* wi, int m, int c, int ih, int iw) {
+    return ((unsigned)ih < 3u && (unsigned)iw < 3u) ? wi[((m * 3 + c) * 3 + ih) * 3 + iw] : 0.f;
+}
+// border table row t of D -> which (kh, kw) taps of w0 and which fixed (ih | iw) of wi it sums over; see compose_dstem (ops.py)
+__global__ void dstem_compose_kernel(ComposeArgs a) {
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    constexpr int NW = 128 * 36 * 8, NB = 128, ND = 64 * 28 * 8, NDB = 64 * 8;
+    if (id < NW) {
+        const int c = id & 7, t = (id >> 3) % 36, o = id / (36 * 8);
+        const int ta = t / 6, tb = t - ta * 6;
+        float s = 0.f;
+        if (c < 3) {
+            if (o < 64) {
+                for (int m = 0; m < 32; ++m)
+                    for (int kh = 0; kh < 4; ++kh)
+                        for (int kw = 0; kw < 4; ++kw) s += a.w0[((o * 32 + m) * 4 + kh) * 4 + kw] * wi_at(a.wi, m, c, ta - kh, tb - kw);
+            } else {
+                for (int m = 0; m < 32; ++m) {
+                    float p = 0.f;
+                    for (int u = 0; u < 2; ++u)
+                        for (int v = 0; v < 2; ++v) p += wi_at(a.wi, m, c, ta - 1 - u, tb - 1 - v);
+                    s += a.ws[(o - 64) * 32 + m] * 0.25f * p;
+                }
+                if (ta < 1 || ta > 4 || tb < 1 || tb > 4) s = 0.f;
+            }
+        }
+        a.W[id] = s;
+    } else if (id < NW + NB) {
+        const int o = id - NW;
+        float s = 0.f;
+        if (o < 64) {
+            for (int m = 0; m < 32; ++m) {
+                float q = 0.f;
+                for (int k = 0; k < 16; ++k) q += a.w0[(o * 32 + m) * 16 + k];
+                s += q * a.bi[m];
+            }
+        } else {
+            for (int m = 0; m < 32; ++m) s += a.ws[(o - 64) * 32 + m] * a.bi[m];
+            if (a.bs) s += a.bs[o - 64];
+        }
+        a.bias[o] = s;
+    } else if (id < NW + NB + ND) {
+        const int j = id - NW - NB, c = j & 7, t = (j >> 3) % 28, o = j / (28 * 8);
+        float s = 0.f;
+        if (c < 3) {
+            for (int m = 0; m < 32; ++m) {
+                const float* w0 = a.w0 + (o * 32 + m) * 16;
+                if (t < 6) { for (int kw = 0; kw < 4; ++kw) s -= w0[0 * 4 + kw] * wi_at(a.wi, m, c, 2, t - kw); }
+                else if (t < 12) { for (int kw = 0; kw < 4; ++kw) s -= w0[3 * 4 + kw] * wi_at(a.wi, m, c, 0, t - 6 - kw); }
+                else if (t < 18) { for (int kh = 0; kh < 4; ++kh) s -= w0[kh * 4 + 0] * wi_at(a.wi, m, c, t - 12 - kh, 2); }
+                else if (t < 24) { for (int kh = 0; kh < 4; ++kh) s -= w0[kh * 4 + 3] * wi_at(a.wi, m, c, t - 18 - kh, 0); }
+                else if (t == 24) s += w0[0] * wi_at(a.wi, m, c, 2, 2);
+                else if (t == 25) s += w0[3] * wi_at(a.wi, m, c, 2, 0);
+                else if (t == 26) s += w0[12] * wi_at(a.wi, m, c, 0, 2);
+                else s += w0[15] * wi_at(a.wi, m, c, 0, 0);
+            }
+        }
+        a.D[j] = s;
+    } else if (id < NW + NB + ND + NDB) {
+        const int j = id - NW - NB - ND, e = j & 7, o = j >> 3;
+        float s = 0.f;
+        for (int m = 0; m < 32; ++m) {
+            const float* w0 = a.w0 + (o * 32 + m) * 16;
+            float q;
+            if (e == 0) q = -(w0[0] + w0[1] + w0[2] + w0[3]);
+            else if (e == 1) q = -(w0[12] + w0[13] + w0[14] + w0[15]);
+            else if (e == 2) q = -(w0[0] + w0[4] + w0[8] + w0[12]);
+            else if (e == 3) q = -(w0[3] + w0[7] + w0[11] + w0[15]);
+            else if (e == 4) q = w0[0];
+            else if (e == 5) q = w0[3];
+            else if (e == 6) q = w0[12];
+            else q = w0[15];
+            s += q * a.bi[m];
+        }
+        a.DB[j] = s;
+    }
+}
+
+// adjoint: gradients of the five parameters from the gradients of the four tables.  One thread per parameter element.
+struct ComposeBwdArgs {
+    const float *wi, *bi, *w0, *ws;
+    const float *dW, *dbias, *dD, *dDB;
+    float *dwi, *dbi, *dw0, *dws, *dbs;                      // dbs may be NULL
+};
+__device__ __forceinline__ float dW_at(const float* dW, int o, int ta, int tb, int c) {
+    return ((unsigned)ta < 6u && (unsigned)tb < 6u) ? dW[((size_t)o * 36 + ta * 6 + tb) * 8 + c] : 0.f;
+}
+__device__ __forceinline__ float dD_at(const float* dD, int o, int t0, int t, int c) {      // six-tap line t0 .. t0 + 5
+    return (unsigned)t < 6u ? dD[((size_t)o * 28 + t0 + t) * 8 + c] : 0.f;
+}
+__global__ void dstem_compose_bwd_kernel(ComposeBwdArgs a) {
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    constexpr int NWI = 32 * 27, NBI = 32, NW0 = 64 * 32 * 16, NWS = 64 * 32, NBS = 64;
+    if (id < NWI) {                                          // dwi[m][c][ih][iw]
+        const int iw = id % 3, ih = (id / 3) % 3, c = (id / 9) % 3, m = id / 27;
+        float s = 0.f;
+        for (int o = 0; o < 64; ++o) {
+            const float* w0 = a.w0 + (o * 32 + m) * 16;
+            for (int kh = 0; kh < 4; ++kh)
+                for (int kw = 0; kw < 4; ++kw) s += dW_at(a.dW, o, kh + ih, kw + iw, c) * w0[kh * 4 + kw];
+            float p = 0.f;
+            for (int u = 0; u < 2; ++u)
+                for (int v = 0; v < 2; ++v) p += dW_at(a.dW, 64 + o, 1 + u + ih, 1 + v + iw, c);
+            s += 0.25f * p * a.ws[o * 32 + m];
+            if (ih == 2) for (int kw = 0; kw < 4; ++kw) s -= dD_at(a.dD, o, 0, kw + iw, c) * w0[kw];
+            if (ih == 0) for (int kw = 0; kw < 4; ++kw) s -= dD_at(a.dD, o, 6, kw + iw, c) * w0[12 + kw];
+            if (iw == 2) for (int kh = 0; kh < 4; ++kh) s -= dD_at(a.dD, o, 12, kh + ih, c) * w0[kh * 4];
+            if (iw == 0) for (int kh = 0; kh < 4; ++kh) s -= dD_at(a.dD, o, 18, kh + ih, c) * w0[kh * 4 + 3];
+            if (ih == 2 && iw == 2) s += a.dD[((size_t)o * 28 + 24) * 8 + c] * w0[0];
+            if (ih == 2 && iw == 0) s += a.dD[((size_t)o * 28 + 25) * 8 + c] * w0[3];
+            if (ih == 0 && iw == 2) s += a.dD[((size_t)o * 28 + 26) * 8 + c] * w0[12];
+            if (ih == 0 && iw == 0) s += a.dD[((size_t)o * 28 + 27) * 8 + c] * w0[15];
+        }
+        a.dwi[id] = s;
+    } else if (id < NWI + NBI) {                             // dbi[m]
+        const int m = id - NWI;
+        float s = 0.f;
+        for (int o = 0; o < 64; ++o) {
+            const float* w0 = a.w0 + (o * 32 + m) * 16;
+            float q = 0.f;
+            for (int k = 0; k < 16; ++k) q += w0[k];
+            s += a.dbias[o] * q + a.dbias[64 + o] * a.ws[o * 32 + m];
+            const float* g = a.dDB + o * 8;
+            s -= g[0] * (w0[0] + w0[1] + w0[2] + w0[3]) + g[1] * (w0[12] + w0[13] + w0[14] + w0[15]) + g[2] * (w0[0] + w0[4] + w0[8] + w0[12]) +
+                 g[3] * (w0[3] + w0[7] + w0[11] + w0[15]);
+            s += g[4] * w0[0] + g[5] * w0[3] + g[6] * w0[12] + g[7] * w0[15];
+        }
+        a.dbi[m] = s;
+    } else if (id < NWI + NBI + NW0) {                       // dw0[o][m][kh][kw]
+        const int j = id - NWI - NBI, kw = j & 3, kh = (j >> 2) & 3, m = (j >> 4) & 31, o = j >> 9;
+        float s = a.bi[m] * a.dbias[o];
+        const float* g = a.dDB + o * 8;
+        for (int c = 0; c < 3; ++c)
+            for (int ih = 0; ih < 3; ++ih)
+                for (int iw = 0; iw < 3; ++iw) s += dW_at(a.dW, o, kh + ih, kw + iw, c) * a.wi[((m * 3 + c) * 3 + ih) * 3 + iw];
+        if (kh == 0) {
+            s -= a.bi[m] * g[0];
+            for (int c = 0; c < 3; ++c)
+                for (int iw = 0; iw < 3; ++iw) s -= dD_at(a.dD, o, 0, kw + iw, c) * a.wi[((m * 3 + c) * 3 + 2) * 3 + iw];
+        }
+        if (kh == 3) {
+            s -= a.bi[m] * g[1];
+            for (int c = 0; c < 3; ++c)
+                for (int iw = 0; iw < 3; ++iw) s -= dD_at(a.dD, o, 6, kw + iw, c) * a.wi[((m * 3 + c) * 3 + 0) * 3 + iw];
+        }
+        if (kw == 0) {
+            s -= a.bi[m] * g[2];
+            for (int c = 0; c < 3; ++c)
+                for (int ih = 0; ih < 3; ++ih) s -= dD_at(a.dD, o, 12, kh + ih, c) * a.wi[((m * 3 + c) * 3 + ih) * 3 + 2];
+        }
+        if (kw == 3) {
+            s -= a.bi[m] * g[3];
+            for (int c = 0; c < 3; ++c)
+                for (int ih = 0; ih < 3; ++ih) s -= dD_at(a.dD, o, 18, kh + ih, c) * a.wi[((m * 3 + c) * 3 + ih) * 3 + 0];
+        }
+        const int corner = (kh == 0 && kw == 0) ? 0 : (kh == 0 && kw == 3) ? 1 : (kh == 3 && kw == 0) ? 2 : (kh == 3 && kw == 3) ? 3 : -1;
+        if (corner >= 0) {
+            const int ih = corner < 2 ? 2 : 0, iw = (corner & 1) ? 0 : 2;
+            s += a.bi[m] * g[4 + corner];
+            for (int c = 0; c < 3; ++c) s += a.dD[((size_t)o * 28 + 24 + corner) * 8 + c] * a.wi[((m * 3 + c) * 3 + ih) * 3 + iw];
+        }
+        a.dw0[j] = s;
+    } else if (id < NWI + NBI + NW0 + NWS) {                 // dws[o][m]
+        const int j = id - NWI - NBI - NW0, m = j & 31, o = j >> 5;
+        float s = a.dbias[64 + o] * a.bi[m];
+        for (int c = 0; c < 3; ++c)
+            for (int ta = 1; ta < 5; ++ta)
+                for (int tb = 1; tb < 5; ++tb) {
+                    float p = 0.f;
+                    for (int u = 0; u < 2; ++u)
+                        for (int v = 0; v < 2; ++v) p += wi_at(a.wi, m, c, ta - 1 - u, tb - 1 - v);
+                    s += a.dW[((size_t)(64 + o) * 36 + ta * 6 + tb) * 8 + c] * 0.25f * p;
+                }
+        a.dws[j] = s;
+    } else if (id < NWI + NBI + NW0 + NWS + NBS) {
+        const int o = id - NWI - NBI - NW0 - NWS;
+        if (a.dbs) a.dbs[o] = a.dbias[64 + o];
+    }
+}
+
+// ---- the border of h1 ------------------------------------------------------------------------------------------------------------
+// conv_r[0] pads conv_img's output with zeros; the composed convolution instead sees conv_img evaluated one pixel outside the image.
+// For an output pixel in the first row that surplus is  sum_kw W_0[kh = 0, kw] . conv_img(row -1)  and conv_img(row -1) reads image
+// row 0 only (through its last tap row): a 6-tap row correction on tap row a = 2 of the composed window; likewise the last row
+// (a = 3), the first / last column (b = 2 / 3) and the four corners (single taps, added back once).  The corrections are linear in
+// (w0, w_img, b_img) like the composed weights themselves (ops.compose_dstem builds them):
+//   D  f32 [64][28][8]: taps 0-5 top (by b), 6-11 bottom, 12-17 left (by a), 18-23 right, 24-27 corners TL TR BL BR
+//   DB f32 [64][8]    : their constant terms (conv_img's bias through the dropped taps), same order
+// The border kernels touch 4 (OH + OW) - 4 pixels per image -- 3 % of the map at 128 x 128 -- with plain f32 FMAs:
+//   dstem_border_fwd    recomputes h1 there from the image with W + D (f32 weights), overwriting what the main kernel wrote
+//   dstem_border_wgrad  dD, dDB += sum over border pixels of dh1 (x) image taps (the composed weights' own gradient takes ALL pixels)
+__device__ __forceinline__ void border_pixel(int i, int OH, int OW, int& py, int& px) {      // i-th pixel of the perimeter
+    if (i < OW) { py = 0; px = i; }
+    else if (i < 2 * OW) { py = OH - 1; px = i - OW; }
+    else { const int j = i - 2 * OW; py = 1 + (j >> 1); px = (j & 1) ? OW - 1 : 0; }
+}
+
+// one thread per border pixel, all 64 channels (weights broadcast from LDS: every lane reads the same address)
+__global__ __launch_bounds__(256) void dstem_border_fwd_kernel(const u32x4* __restrict__ img, const float* __restrict__ w, const float* __restrict__ bias,
+                                                              const float* __restrict__ D, const float* __restrict__ DB, bf16x8* __restrict__ h1, int N,
+                                                              int H, int W, float slope) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    f32x4* wl = reinterpret_cast<f32x4*>(smem);               // [36 + 28 taps][64 co] x (c0, c1, c2, 0)
+    float* dbl = reinterpret_cast<float*>(wl + 64 * 64);      // [8][64]
+    float* bl = dbl + 8 * 64;                                 // [64]
+    const int tid = threadIdx.x;
+    for (int id = tid; id < 64 * 64; id += 256) {
+        const int t = id >> 6, o = id & 63;
+        wl[id] = t < 36 ? *reinterpret_cast<const f32x4*>(w + ((size_t)o * 36 + t) * 8) : *reinterpret_cast<const f32x4*>(D + ((size_t)o * 28 + t - 36) * 8);
+    }
+    for (int id = tid; id < 8 * 64; id += 256) dbl[id] = DB[(id & 63) * 8 + (id >> 6)];
+    if (tid < 64) bl[tid] = bias[tid];
+    __syncthreads();
+    const int OH = H >> 1, OW = W >> 1, P = 2 * OW + 2 * (OH - 2);
+    const long long gid = (long long)blockIdx.x * 256 + tid;
+    if (gid >= (long long)N * P) return;
+    const int n = (int)(gid / P), i = (int)(gid - (long long)n * P);
+    int py, px;
+    border_pixel(i, OH, OW, py, px);
+    float v[64];
+#pragma unroll
+    for (int k = 0; k < 64; ++k) v[k] = bl[k];
+    auto tap = [&](int t, int sy, int sx) {                   // v += (weights of table row t) . image pixel (sy, sx)
+        if ((unsigned)sy >= (unsigned)H || (unsigned)sx >= (unsigned)W) return;
+        const bf16x8 xv = __builtin_bit_cast(bf16x8, img[((size_t)n * H + sy) * W + sx]);
+        const float x0 = (float)xv[0], x1 = (float)xv[1], x2 = (float)xv[2];
+        const f32x4* wt = wl + t * 64;
+#pragma unroll
+        for (int k = 0; k < 64; ++k) {
+            const f32x4 ww = wt[k];
+            v[k] += ww[0] * x0 + ww[1] * x1 + ww[2] * x2;
+        }
+    };
+    for (int a = 0; a < 6; ++a)
+        for (int b = 0; b < 6; ++b) tap(a * 6 + b, 2 * py - 2 + a, 2 * px - 2 + b);
+    const bool top = py == 0, bot = py == OH - 1, lef = px == 0, rig = px == OW - 1;
+    auto cst = [&](int j) {
+#pragma unroll
+        for (int k = 0; k < 64; ++k) v[k] += dbl[j * 64 + k];
+    };
+    if (top) { cst(0); for (int t = 0; t < 6; ++t) tap(36 + t, 0, 2 * px - 2 + t); }
+    if (bot) { cst(1); for (int t = 0; t < 6; ++t) tap(42 + t, H - 1, 2 * px - 2 + t); }
+    if (lef) { cst(2); for (int t = 0; t < 6; ++t) tap(48 + t, 2 * py - 2 + t, 0); }
+    if (rig) { cst(3); for (int t = 0; t < 6; ++t) tap(54 + t, 2 * py - 2 + t, W - 1); }
+    if (top && lef) { cst(4); tap(60, 0, 0); }
+    if (top && rig) { cst(5); tap(61, 0, W - 1); }
+    if (bot && lef) { cst(6); tap(62, H - 1, 0); }
+    if (bot && rig) { cst(7); tap(63, H - 1, W - 1); }
+    bf16x8* dst = h1 + (((size_t)n * OH + py) * OW + px) * 8;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        bf16x8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const float t = v[u * 8 + k]; o[k] = (xmc_h16)fmaxf(t, t * slope); }
+        dst[u] = o;
+    }
+}
+
+// one workgroup per (image, side): the side's line of dh1 [L][64] and the image line it reads in LDS, one thread per output
+__global__ __launch_bounds__(256) void dstem_border_wgrad_kernel(const u32x4* __restrict__ img, const bf16x8* __restrict__ dh1, float* __restrict__ dD,
+                                                                float* __restrict__ dDB, int N, int H, int W) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int n = blockIdx.x, side = blockIdx.y, tid = threadIdx.x;       // side: 0 top, 1 bottom, 2 left, 3 right
+    const int OH = H >> 1, OW = W >> 1;
+    const bool rows = side < 2;
+    const int L = rows ? OW : OH, XL = (rows ? W : H) + 4;                 // image line with two zero pixels either side
+    float* gl = reinterpret_cast<float*>(smem);                           // [L][64]
+    float* xl = gl + (size_t)L * 64;                                      // [XL][4]
+    for (int id = tid; id < L * 8; id += 256) {
+        const int i = id >> 3, ch = id & 7;
+        const int py = rows ? (side == 0 ? 0 : OH - 1) : i, px = rows ? i : (side == 2 ? 0 : OW - 1);
+        const bf16x8 t = dh1[(((size_t)n * OH + py) * OW + px) * 8 + ch];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) gl[i * 64 + ch * 8 + k] = (float)t[k];
+    }
+    for (int id = tid; id < XL; id += 256) {
+        const int s_ = id - 2;
+        float a = 0.f, b = 0.f, c = 0.f;
+        if (s_ >= 0 && s_ < XL - 4) {
+            const int sy = rows ? (side == 0 ? 0 : H - 1) : s_, sx = rows ? s_ : (side == 2 ? 0 : W - 1);
+            const bf16x8 t = __builtin_bit_cast(bf16x8, img[((size_t)n * H + sy) * W + sx]);
+            a = (float)t[0]; b = (float)t[1]; c = (float)t[2];
+        }
+        xl[id * 4 + 0] = a; xl[id * 4 + 1] = b; xl[id * 4 + 2] = c; xl[id * 4 + 3] = 0.f;
+    }
+    __syncthreads();
+    const int t0 = side * 6;
+    for (int id = tid; id < 64 * 18; id += 256) {                          // (o, tap t, channel c): sum_i dh1[i][o] * x[2 i - 2 + t][c]
+        const int o = id / 18, r = id - o * 18, t = r / 3, c = r - t * 3;
+        float s_ = 0.f;
+        for (int i = 0; i < L; ++i) s_ += gl[i * 64 + o] * xl[(2 * i + t) * 4 + c];
+        atomicAdd(&dD[((size_t)o * 28 + t0 + t) * 8 + c], s_);
+    }
+    for (int id = tid; id < 64; id += 256) {
+        float s_ = 0.f;
+        for (int i = 0; i < L; ++i) s_ += gl[i * 64 + id];
+        atomicAdd(&dDB[id * 8 + side], s_);
+    }
+    if (rows) {                                                           // corners: (first | last) pixel of the top / bottom line
+        for (int id = tid; id < 2 * 64 * 4; id += 256) {
+            const int which = id >> 8, o = (id >> 2) & 63, c = id & 3;     // which: 0 = left end, 1 = right end
+            const int i = which ? L - 1 : 0, xi = which ? XL - 3 : 2;      // image column 0 / W - 1 in the padded line
+            const int tcorner = 24 + side * 2 + which;
+            const float g_ = gl[i * 64 + o];
+            if (c < 3) atomicAdd(&dD[((size_t)o * 28 + tcorner) * 8 + c], g_ * xl[xi * 4 + c]);
+            else atomicAdd(&dDB[o * 8 + tcorner - 20], g_);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int xmc_dstem_pack(const float* wsets, void* wfrag, void* stream) {
+    if (!wsets || !wfrag) return XMC_EINVAL;
+    hipLaunchKernelGGL(dstem_pack_kernel, dim3((8 * kKSteps * 64 + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), wsets,
+                       reinterpret_cast<bf16x8*>(wfrag));
+    XMC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int xmc_dstem_fwd(const void* img, const void* wfrag, const float* bias, void* h1, void* sc, int N, int H, int W, float slope,
+                             void* stream) {
+    if (!img || !wfrag || !bias || !h1 || !sc || N < 1) return XMC_EINVAL;
+    if (H < 8 || W < 64 || H % 8 != 0 || W % 64 != 0) return XMC_ESHAPE;
+    const int ntiles = N * (H / 8) * (W / 64);
+    const int grid = ntiles < 256 ? ntiles : 256;
+    hipLaunchKernelGGL(dstem_fwd_kernel, dim3(grid), dim3(512), 0, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const u32x4*>(img),
+                       reinterpret_cast<const u32x4*>(wfrag), bias, reinterpret_cast<bf16x8*>(h1), reinterpret_cast<bf16x8*>(sc), N, H, W, slope,
+                       ntiles);
+    xmc_note_kernel("dstem_fwd_kernel");
+    XMC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int xmc_dstem_compose(const float* wi, const float* bi, const float* w0, const float* ws, const float* bs, float* W, float* bias,
+                                 float* D, float* DB, void* stream) {
+    if (!wi || !bi || !w0 || !ws || !W || !bias || !D || !DB) return XMC_EINVAL;
+    ComposeArgs a{wi, bi, w0, ws, bs, W, bias, D, DB};
+    constexpr int n = 128 * 36 * 8 + 128 + 64 * 28 * 8 + 64 * 8;
+    hipLaunchKernelGGL(dstem_compose_kernel, dim3((n + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+    XMC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int xmc_dstem_compose_bwd(const float* wi, const float* bi, const float* w0, const float* ws, const float* dW, const float* dbias,
+                                     const float* dD, const float* dDB, float* dwi, float* dbi, float* dw0, float* dws, float* dbs, void* stream) {
+    if (!wi || !bi || !w0 || !ws || !dW || !dbias || !dD || !dDB || !dwi || !dbi || !dw0 || !dws) return XMC_EINVAL;
+    ComposeBwdArgs a{wi, bi, w0, ws, dW, dbias, dD, dDB, dwi, dbi, dw0, dws, dbs};
+    constexpr int n = 32 * 27 + 32 + 64 * 32 * 16 + 64 * 32 + 64;
+    hipLaunchKernelGGL(dstem_compose_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+    XMC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int xmc_dstem_border_fwd(const void* img, const float* w, const float* bias, const float* D, const float* DB, void* h1, int N, int H,
+                                    int W, float slope, void* stream) {
+    if (!img || !w || !bias || !D || !DB || !h1 || N < 1) return XMC_EINVAL;
+    if (H < 16 || W < 64 || H % 16 != 0 || W % 64 != 0) return XMC_ESHAPE;
+    const long long px = (long long)N * (2 * (W / 2) + 2 * (H / 2 - 2));
+    const size_t lds = (size_t)64 * 64 * 16 + 8 * 64 * 4 + 64 * 4;
+    XMC_ALLOW_BIG_LDS(dstem_border_fwd_kernel);
+    hipLaunchKernelGGL(dstem_border_fwd_kernel, dim3((unsigned)((px + 255) / 256)), dim3(256), lds, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const u32x4*>(img), w, bias, D, DB, reinterpret_cast<bf16x8*>(h1), N, H, W, slope);
+    XMC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int xmc_dstem_border_wgrad(const void* img, const void* dh1, float* dD, float* dDB, int N, int H, int W, void* stream) {
+    if (!img || !dh1 || !dD || !dDB || N < 1) return XMC_EINVAL;
+    if (H < 16 || W < 64 || H % 16 != 0 || W % 64 != 0 || H > 1024 || W > 1024) return XMC_ESHAPE;
+    const int L = (H > W ? H : W) / 2, XL = (H > W ? H : W) + 4;
+    const size_t lds = (size_t)L * 64 * 4 + (size_t)XL * 16;
+    XMC_ALLOW_BIG_LDS(dstem_border_wgrad_kernel);
+    hipLaunchKernelGGL(dstem_border_wgrad_kernel, dim3(N, 4), dim3(256), lds, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const u32x4*>(img), reinterpret_cast<const bf16x8*>(dh1), dD, dDB, N, H, W);
+    XMC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int xmc_dstem_wgrad(const void* img, const void* dh1, const void* dsc, float* dw, float* dbias, int N, int H, int W,
+                               int skip_border, void* stream) {
+    if (!img || !dh1 || !dsc || !dw || !dbias || N < 1) return XMC_EINVAL;
+    if (H < 16 || W < 64 || H % 16 != 0 || W % 64 != 0) return XMC_ESHAPE;
+    const int ntiles = N * (H / 16) * (W / 64);
+    const int grid = ntiles < 256 ? ntiles : 256;
+    const size_t lds = (size_t)256 * (128 * 2 + 32) + (size_t)20 * 2 * 36 * 16;
+    XMC_ALLOW_BIG_LDS(dstem_wgrad_kernel);
+    hipLaunchKernelGGL(dstem_wgrad_kernel, dim3(grid), dim3(512), lds, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const u32x4*>(img),
+                       reinterpret_cast<const u32x4*>(dh1), reinterpret_cast<const u32x4*>(dsc), dw, dbias, N, H, W, skip_border, ntiles);
+    xmc_note_kernel("dstem_wgrad_kernel");
+    XMC_LAUNCH_CHECK();
+    return 0;
+}

@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("XMC_LIB_PATH", os.path.join(HERE, "libxmc_gan_hip.so"))   # override: kernel experiments
 LIB_PATH_F16 = os.environ.get("XMC_LIB_PATH_F16", os.path.join(HERE, "libxmc_gan_hip_f16.so"))
-ABI_VERSION = 6          # include/xmc_gan_hip.h XMC_ABI_VERSION; the ctypes structures below mirror that version
+ABI_VERSION = 7          # include/xmc_gan_hip.h XMC_ABI_VERSION; the ctypes structures below mirror that version
 
 # BF16 is the dtype code of "the 16-bit storage format of the loaded build": bf16 in libxmc_gan_hip.so, IEEE half in
 # libxmc_gan_hip_f16.so (the same sources compiled with -DXMC_H16_IS_F16; `use_variant`)
@@ -125,6 +125,13 @@ _SIGS = {
     "xmc_adam_chunk_elems": [],
     "xmc_adam_step": [vp, i32, vp, i32, f32, f32, f32, f32, f32, vp],
     "xmc_adam_step_scaled": [vp, i32, vp, i32, f32, f32, f32, f32, vp, vp, i32, f32, f32, i32, vp],
+    "xmc_dstem_compose": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+    "xmc_dstem_compose_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+    "xmc_dstem_pack": [vp, vp, vp],
+    "xmc_dstem_fwd": [vp, vp, vp, vp, vp, i32, i32, i32, f32, vp],
+    "xmc_dstem_wgrad": [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    "xmc_dstem_border_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp],
+    "xmc_dstem_border_wgrad": [vp, vp, vp, vp, i32, i32, i32, vp],
 }
 _RESTYPE = {"xmc_contrastive_ws_bytes": i64, "xmc_attn_pool_ws_floats": i64, "xmc_last_kernel": C.c_char_p}
 EXPORTS = tuple(_SIGS)

@@ -763,6 +763,104 @@ def _conv_wgrad_raw(x, dy, geom, scale=None, up=False, want_bias=False, bias_dot
     return gw
 
 
+# ------------------------------------------------------------------------------------------ discriminator stem (csrc/dstem.hip)
+def compose_dstem(w_img, b_img, w0, ws, bs):
+    """conv_img followed (without an activation) by the first resD block's conv_r[0] and by its pooled 1x1 shortcut, as ONE set of
+    convolution weights on the image (df_gan.py:114,127,272-291; derivation in csrc/dstem.hip):
+        W[0:64]   = sum_mid w0 (*) w_img                 6x6, stride 2, pad 2    (the residual branch's first convolution)
+        W[64:128] = ws . (2x2 box / 4 (*) w_img)         4x4, stride 2, pad 1, embedded in the 6x6 window (the shortcut)
+    plus the corrections of the residual branch on the image border, where conv_r[0] pads conv_img's OUTPUT with zeros: what the
+    dropped taps (kh = 0 in the first output row, kh = 3 in the last, kw = 0 / 3 in the first / last column; corners added back
+    once) contributed through the one image row / column conv_img reads from outside.
+    returns (W f32 [128,36,8], bias f32 [128], D f32 [64,28,8], DB f32 [64,8]) -- layouts in include/xmc_gan_hip.h.  Parameter-sized
+    f32 algebra.  THIS function is the readable statement of it in differentiable torch ops and the reference the tests hold the
+    product's own launches against: `xmc_dstem_compose` (forward) and `xmc_dstem_compose_bwd` (its adjoint: the gradients of these
+    tables, from `xmc_dstem_wgrad` / `xmc_dstem_border_wgrad`, back to the five parameters)."""
+    F = torch.nn.functional
+    co, mid = w0.shape[0], w0.shape[1]
+    w0, b_img = w0.float(), b_img.float()
+    wie = F.pad(w_img.float(), (0, 0, 0, 0, 0, 8 - w_img.shape[1]))                       # [mid, 8, 3, 3]
+    wa = F.conv_transpose2d(w0, wie)                                                        # [co, 8, 6, 6]: full correlation over mid
+    box = torch.full((1, 1, 2, 2), 0.25, dtype=torch.float32, device=w_img.device)
+    wp = F.conv_transpose2d(wie.reshape(mid * 8, 1, 3, 3), box).reshape(mid, 8, 4, 4)     # avg_pool2d o conv_img
+    wb = torch.einsum("om,mcab->ocab", ws.float()[:, :, 0, 0], wp)
+    w = torch.cat((wa, F.pad(wb, (1, 1, 1, 1)))).permute(0, 2, 3, 1).reshape(2 * co, 36, 8)
+    ba = torch.einsum("omhw,m->o", w0, b_img)
+    bb = ws.float()[:, :, 0, 0] @ b_img + (bs.float() if bs is not None else 0.0)
+    ct1 = F.conv_transpose1d
+    lines = [-ct1(w0[:, :, 0, :], wie[:, :, 2, :]), -ct1(w0[:, :, 3, :], wie[:, :, 0, :]),          # first / last row, by window column
+             -ct1(w0[:, :, :, 0], wie[:, :, :, 2]), -ct1(w0[:, :, :, 3], wie[:, :, :, 0])]          # first / last column, by window row
+    corners = [(0, 0, 2, 2), (0, 3, 2, 0), (3, 0, 0, 2), (3, 3, 0, 0)]                              # (kh, kw, ih, iw) of TL TR BL BR
+    D = torch.cat([t.permute(0, 2, 1) for t in lines] + [(w0[:, :, kh, kw] @ wie[:, :, ih, iw]).unsqueeze(1) for kh, kw, ih, iw in corners], 1)
+    DB = torch.stack([-(w0[:, :, 0, :].sum(2) @ b_img), -(w0[:, :, 3, :].sum(2) @ b_img), -(w0[:, :, :, 0].sum(2) @ b_img),
+                      -(w0[:, :, :, 3].sum(2) @ b_img)] + [w0[:, :, kh, kw] @ b_img for kh, kw, _, _ in corners], 1)
+    return w.contiguous(), torch.cat((ba, bb)).contiguous(), D.contiguous(), DB.contiguous()
+
+
+def _dstem_compose_raw(w_img, b_img, w0, ws, bs):
+    """`compose_dstem` as one launch (xmc_dstem_compose): the four f32 tables of the composed stem"""
+    _need_cuda(w_img, w0)
+    dev = w_img.device
+    assert tuple(w_img.shape) == (32, 3, 3, 3) and tuple(w0.shape) == (64, 32, 4, 4) and tuple(ws.shape[:2]) == (64, 32)
+    flat = torch.empty(128 * 36 * 8 + 128 + 64 * 28 * 8 + 64 * 8, dtype=torch.float32, device=dev)
+    W, b = flat[:36864].view(128, 36, 8), flat[36864:36992]
+    D, DB = flat[36992:36992 + 14336].view(64, 28, 8), flat[36992 + 14336:].view(64, 8)
+    f = lambda t: None if t is None else t.detach().float().contiguous()
+    wi_, bi_, w0_, ws_, bs_ = f(w_img), f(b_img), f(w0), f(ws), f(bs)
+    L.call("xmc_dstem_compose", _p(wi_), _p(bi_), _p(w0_), _p(ws_), _p(bs_), _p(W), _p(b), _p(D), _p(DB), _st())
+    return W, b, D, DB
+
+
+def _dstem_compose_bwd_raw(w_img, b_img, w0, ws, bs, dW, dbias, dD, dDB):
+    """gradients of (w_img, b_img, w0, ws, bs) from the gradients of the four tables (xmc_dstem_compose_bwd)"""
+    f = lambda t: t.detach().float().contiguous()
+    wi_, bi_, w0_, ws_ = f(w_img), f(b_img), f(w0), f(ws)
+    dwi, dbi, dw0, dws = (torch.empty_like(t) for t in (wi_, bi_, w0_, ws_))
+    dbs = torch.empty(64, dtype=torch.float32, device=wi_.device) if bs is not None else None
+    L.call("xmc_dstem_compose_bwd", _p(wi_), _p(bi_), _p(w0_), _p(ws_), _p(dW.contiguous()), _p(dbias.contiguous()), _p(dD.contiguous()),
+           _p(dDB.contiguous()), _p(dwi), _p(dbi), _p(dw0), _p(dws), _p(dbs), _st())
+    return dwi, dbi, dw0, dws, dbs
+
+
+def _dstem_fwd_raw(xin, wsets, bias, slope=0.2):
+    """h1 = lrelu(W_A * x + b_A) [N,H/2,W/2,64], sc = W_B * x + b_B [N,H/2,W/2,64] from the image xin [N,H,W,8] (border pixels of h1
+    are the composition's, not the reference's: see DStemBlockFn)."""
+    _need_cuda(xin, wsets)
+    N, H, W, _ = xin.shape
+    wfrag = torch.empty(8 * 9 * 64 * 8, dtype=xin.dtype, device=xin.device)
+    L.call("xmc_dstem_pack", _p(wsets), _p(wfrag), _st())
+    h1 = torch.empty((N, H // 2, W // 2, 64), dtype=xin.dtype, device=xin.device)
+    sc = torch.empty_like(h1)
+    with prof.launch("igemm_kernel (conv fwd+dgrad, MFMA implicit GEMM)", 2.0 * N * (H // 2) * (W // 2) * 64 * (3 * 36 + 3 * 16 + 32 * 16 * 0),
+                     f"dstem-fwd {xin.dtype} N{N} {H}x{W} 3->64+64 k6s2", _nbytes(xin, h1, sc)):
+        L.call("xmc_dstem_fwd", _p(xin), _p(wfrag), _p(bias), _p(h1), _p(sc), N, H, W, float(slope), _st())
+    return h1, sc
+
+
+def _dstem_border_fwd_raw(xin, wsets, bias, D, DB, h1, slope=0.2):
+    """overwrite h1's border pixels with the reference's values (composed weights + border corrections, f32 arithmetic)"""
+    N, H, W, _ = xin.shape
+    L.call("xmc_dstem_border_fwd", _p(xin), _p(wsets), _p(bias), _p(D), _p(DB), _p(h1), N, H, W, float(slope), _st())
+
+
+def _dstem_wgrad_raw(xin, dh1, dsc, skip_border=False, border=True):
+    """gradients of the composed weights / biases and (``border``) of the border corrections:
+    (dW f32 [128,36,8], dbias f32 [128], dD f32 [64,28,8], dDB f32 [64,8])"""
+    _need_cuda(xin, dh1, dsc)
+    N, H, W, _ = xin.shape
+    dh1, dsc = dh1.contiguous(), dsc.contiguous()
+    n_w, n_d = 128 * 36 * 8, 64 * 28 * 8
+    flat = _arena.zeros((n_w + 128 + n_d + 64 * 8,), xin.device)
+    dw, db = flat[:n_w].view(128, 36, 8), flat[n_w:n_w + 128]
+    dD, dDB = flat[n_w + 128:n_w + 128 + n_d].view(64, 28, 8), flat[n_w + 128 + n_d:].view(64, 8)
+    with prof.launch("wgrad_kernel (conv weight gradient, MFMA + split-K atomics)", 2.0 * N * (H // 2) * (W // 2) * 64 * (3 * 36 + 3 * 16),
+                     f"dstem-wgrad {xin.dtype} N{N} {H}x{W} 3->64+64 k6s2", _nbytes(xin, dh1, dsc)):
+        L.call("xmc_dstem_wgrad", _p(xin), _p(dh1), _p(dsc), _p(dw), _p(db), N, H, W, 1 if skip_border else 0, _st())
+    if border:
+        L.call("xmc_dstem_border_wgrad", _p(xin), _p(dh1), _p(dD), _p(dDB), N, H, W, _st())
+    return dw, db, dD, dDB
+
+
 # ------------------------------------------------------------------------------------------ conv / linear
 class ConvFn(torch.autograd.Function):
     """y = act(conv2d(x, w) + b).  F.conv2d / nn.Linear call sites: df_gan.py:73-74,86,144,157-159,187-188,
@@ -1567,6 +1665,90 @@ class ResDFn(torch.autograd.Function):
                                "ops.second_order() to differentiate its backward (the MA-GP pattern)")
         outs = ResDBwdFn.apply(dout, x, xp, h1, res, w0, w2, ws, gamma, ctx.geoms, ctx.learned, ctx.has_bs, need, _skip_wgrad())
         return tuple(outs) + (None, None, None, None, None)
+
+
+def dstem_eligible(xin, c_img, c_sc, c_out):
+    """the composed-stem path (DStemBlockFn) takes 16-bit images whose size tiles (H % 16 == 0, W % 64 == 0) at the widths the
+    kernel is built for (conv_img: 3 -> 32, first block: 32 -> 64 with its learned shortcut)"""
+    return (xin.is_cuda and xin.dtype != torch.float32 and xin.shape[3] == 8 and xin.shape[1] % 16 == 0 and xin.shape[2] % 64 == 0 and
+            c_img == 32 and c_out == 64 and c_sc and "no_dstem" not in _DEBUG_DISPATCH)
+
+
+class DStemBlockFn(torch.autograd.Function):
+    """conv_img and the first discriminator block (df_gan.py:114,127,269-291) as one first-order node on the COMPOSED stem
+    (csrc/dstem.hip, `compose_dstem`): the image goes straight to h1 = lrelu(conv_r[0](conv_img(x))) and to the shortcut
+    conv_s(avg_pool2d(conv_img(x))); conv_img's 32-channel full-resolution output and its pooled copy are never written, and the
+    backward needs neither them nor their gradients -- the weight gradients of conv_img, conv_r[0] and conv_s come from ONE
+    weight-gradient launch on the image (gradients of the composed weights; a second, tiny one for the border corrections)
+    through autograd on the composition.
+    The rest of the block is ResDFn's: conv_r[2] + LeakyReLU + block sum (+ sign bits, + pooled output) in one launch, its data
+    gradient with the LeakyReLU' mask of h1 and d(gamma) in the epilogue.  Used when the image needs no gradient (the D step; the
+    G step's no-grad pass over the real batch): the G step's pass over the generated batch keeps conv_img + ResDFn."""
+
+    @staticmethod
+    def forward(ctx, xin, w_img, b_img, w0, w2, ws, bs, gamma, g_img, g0, g2, gs, want_pool=False):
+        assert not _second_order(), "the composed stem has no second-order form: NetD.forward routes MA-GP passes to ResDFn"
+        xin = xin.contiguous()
+        dt = xin.dtype
+        N, H, W, _ = xin.shape
+        OH, OW = H // 2, W // 2
+        wsets, bias, D, DB = _dstem_compose_raw(w_img, b_img, w0, ws, bs)
+        h1, sc = _dstem_fwd_raw(xin, wsets, bias)
+        _dstem_border_fwd_raw(xin, wsets, bias, D, DB, h1)          # conv_r[0]'s zero padding of conv_img's output: 3 % of the pixels
+        al = gamma.detach().reshape(-1).float()
+        keep = any(ctx.needs_input_grad[1:8])
+        pool_ok = want_pool and res_pool_ok(h1, g2)
+        r = _conv_fwd_raw(h1, w2, None, g2, L.ACT_LRELU, dt, res=sc, alpha=al, want_sign=keep, want_pool=pool_ok, round_act=True)
+        r = r if isinstance(r, tuple) else (r,)
+        out = r[0]
+        bits = r[1] if keep else None
+        outp = r[-1] if pool_ok else None
+        ctx.geoms = (g_img, g0, g2, gs)
+        ctx.has_bs = bs is not None
+        ctx.save_for_backward(xin, h1, bits, w_img, b_img, w0, w2, ws, bs, gamma)
+        if want_pool:
+            if outp is None:
+                outp = torch.empty((N, out.shape[1] // 2, out.shape[2] // 2, out.shape[3]), dtype=dt, device=xin.device)
+                L.call("xmc_sumpool2", _p(out), _p(outp), N, out.shape[1], out.shape[2], out.shape[3], 0.25, _code(dt), _st())
+            ctx.mark_non_differentiable(outp)
+            ctx.set_materialize_grads(False)
+            return out, outp
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dout, _doutp=None):
+        nin = 13
+        if dout is None:
+            return (None,) * nin
+        if ctx.needs_input_grad[0]:
+            raise RuntimeError("DStemBlockFn: no gradient with respect to the image (NetD.forward keeps conv_img + ResDFn for that)")
+        xin, h1, bits, w_img, b_img, w0, w2, ws, bs, gamma = ctx.saved_tensors
+        g_img, g0, g2, gs = ctx.geoms
+        dt = xin.dtype
+        N, H, W, _ = xin.shape
+        OH, OW = H // 2, W // 2
+        dout = dout.contiguous()
+        if dout.dtype != dt:
+            dout = dout.to(dt)
+        skip_w = _skip_wgrad()
+        al = gamma.detach().reshape(-1).float()
+        dgam = _zeros_f32_out(1, xin.device)
+        # residual branch, as ResDBwdFn on sign bits: gr = s * dout, d(gamma) from the data gradient's epilogue
+        gr = torch.empty_like(dout)
+        L.call("xmc_signmask_apply", _p(dout), _p(bits), _p(gr), dout.numel(), 0.2, _code(dt), _st())
+        dw2 = _conv_wgrad_raw(h1, gr, g2, scale=al).view(w2.shape) if (ctx.needs_input_grad[4] and not skip_w) else None
+        gh = _conv_dgrad_raw(gr, w2, g2, (OH, OW), dt, mask=h1, alpha=al, dot=dgam)          # d h1 in front of its LeakyReLU
+        dgamma = dgam.reshape(gamma.shape).to(gamma.dtype) if ctx.needs_input_grad[7] else None
+        if skip_w:
+            return (None, None, None, None, dw2, None, None, dgamma) + (None,) * 5
+        # gradients of the composed weights (every pixel) and of the border corrections (border pixels of h1), then back through the
+        # composition to the five parameters
+        tabs = _dstem_wgrad_raw(xin, gh, dout)
+        dwi, dbi, dw0, dws, dbs = _dstem_compose_bwd_raw(w_img, b_img, w0, ws, bs, *tabs)
+        dwi, dw0, dws = dwi.view(w_img.shape), dw0.view(w0.shape), dws.view(ws.shape)
+        return (None, dwi.to(w_img.dtype), dbi.to(b_img.dtype), dw0.to(w0.dtype), dw2, dws.to(ws.dtype),
+                None if dbs is None else dbs.to(bs.dtype), dgamma) + (None,) * 5
 
 
 class ResDBwdFn(torch.autograd.Function):

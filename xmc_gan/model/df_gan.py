@@ -148,12 +148,26 @@ class NetD(nn.Module):
         src = x if nhwc8 is None else nhwc8
         leaf_in = torch.is_tensor(src) and src.requires_grad and src.is_leaf
         with ops.second_order(leaf_in or ops.second_order_active()):
-            if ops.fused_blocks() and xin.is_cuda and xin.shape[1] % 2 == 0:
+            nblk = len(self.downblocks)
+            b0 = self.downblocks[0]
+            first = 0
+            # conv_img + the first block on the composed stem (ops.DStemBlockFn: the image straight to the block's first activation and
+            # to its shortcut; conv_img's output never exists) wherever the image itself needs no gradient and no second-order pass
+            # follows: the D step and the G step's pass over the real batch
+            if (ops.fused_blocks() and not self.conv_img.spec_norm and not ops.second_order_active() and b0.downsample
+                    and not (torch.is_grad_enabled() and xin.requires_grad)
+                    and ops.dstem_eligible(xin, self.conv_img.out_channels, b0.learned_shortcut, b0.conv_r[0].out_channels)):
+                r0, r2, s_ = b0.conv_r[0], b0.conv_r[2], b0.conv_s
+                out, pooled = ops.DStemBlockFn.apply(xin, self.conv_img.weight, self.conv_img.bias, r0.weight, r2.weight, s_.weight, s_.bias,
+                                                     b0.gamma, self.conv_img.geom, r0.geom, r2.geom, s_.geom, nblk > 1)
+                first = 1
+            elif ops.fused_blocks() and xin.is_cuda and xin.shape[1] % 2 == 0:
                 out, pooled = self.conv_img(xin, want_pool=True)
             else:
                 out = self.conv_img(xin)
-            nblk = len(self.downblocks)
             for i, block in enumerate(self.downblocks):
+                if i < first:
+                    continue
                 out, pooled = block(out, xp_hint=pooled, want_pool=i + 1 < nblk)
         return as_nchw_view(out)
 
