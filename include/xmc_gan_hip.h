@@ -465,8 +465,8 @@ int xmc_dstem_wgrad(const void* img, const void* dh1, const void* dsc, float* dw
  * window column, 6-11 last row, 12-17 first column by window row, 18-23 last column, 24-27 corners) and DB f32 [64][8] (their
  * constant terms), linear in the parameters like the composed weights.  border_fwd recomputes h1 on the border from the image with
  * w (f32 [128][36][8], rows 0-63 used) + D; border_wgrad: dD, dDB (zeroed by the caller) += sums over border pixels. */
-int xmc_dstem_border_fwd(const void* img, const float* w, const float* bias, const float* D, const float* DB, void* h1, int N, int H, int W,
-                         float slope, void* stream);
+int xmc_dstem_border_fwd(const void* img, const float* w, const float* bias, const float* D, const float* DB, void* frag_scratch /* 64 KB */,
+                         void* h1, int N, int H, int W, float slope, void* stream);
 int xmc_dstem_border_wgrad(const void* img, const void* dh1, float* dD, float* dDB, int N, int H, int W, void* stream);
 
 #ifdef __cplusplus

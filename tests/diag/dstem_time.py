@@ -30,10 +30,13 @@ for N in (256, 512):
     w0 = torch.randn(64, 32, 4, 4, device=dev) * 0.05
     ws, bs = torch.randn(64, 32, 1, 1, device=dev) * 0.2, torch.randn(64, device=dev) * 0.1
     g_img, g0, gs = ops.ConvGeom(3, 32, 3, 1, 1), ops.ConvGeom(32, 64, 4, 2, 1), ops.ConvGeom(32, 64, 1, 1, 0)
-    wsets, bias = ops.compose_dstem(w_img, b_img, w0, ws, bs)
+    wsets, bias, D, DB = ops._dstem_compose_raw(w_img, b_img, w0, ws, bs)
+    timeit("composition of the weights (4 tables)", lambda: ops._dstem_compose_raw(w_img, b_img, w0, ws, bs))
     bi, bsp = ops._bias_padded(b_img, g_img), ops._bias_padded(bs, gs)
     print(f"N{N} {H}x{W}")
     timeit("composed stem forward (h1, sc)", lambda: ops._dstem_fwd_raw(x, wsets, bias))
+    h1_, _ = ops._dstem_fwd_raw(x, wsets, bias)
+    timeit("  + border pixels of h1", lambda: ops._dstem_border_fwd_raw(x, wsets, bias, D, DB, h1_))
     ci, cip = ops._conv_fwd_raw(x, w_img, bi, g_img, L.ACT_NONE, dt, want_pool=True)
     timeit("  replaces: conv_img (+ pooled output)", lambda: ops._conv_fwd_raw(x, w_img, bi, g_img, L.ACT_NONE, dt, want_pool=True))
     timeit("            conv_r[0] 4x4 s2 32 -> 64", lambda: ops._conv_fwd_raw(ci, w0, None, g0, L.ACT_LRELU, dt))
@@ -44,7 +47,9 @@ for N in (256, 512):
     def wg():
         ops.new_iteration(dev)
         return ops._dstem_wgrad_raw(x, dh1, dsc)
-    timeit("composed stem weight gradient", wg)
+    timeit("composed stem weight gradient (+ border tables)", wg)
+    tabs = wg()
+    timeit("  + adjoint of the composition", lambda: ops._dstem_compose_bwd_raw(w_img, b_img, w0, ws, bs, *tabs))
 
     def old_w0():
         ops.new_iteration(dev)

@@ -378,7 +378,8 @@ __global__ void dstem_compose_kernel(ComposeArgs a) {
     }
 }
 
-// adjoint: gradients of the five parameters from the gradients of the four tables.  One thread per parameter element.
+// adjoint: gradients of the five parameters from the gradients of the four tables.  One thread per element of w0 / ws / bs; the
+// conv_img gradients sum over the 64 output channels: one 64-thread block per element, summed by the wave.
 struct ComposeBwdArgs {
     const float *wi, *bi, *w0, *ws;
     const float *dW, *dbias, *dD, *dDB;
@@ -390,46 +391,49 @@ __device__ __forceinline__ float dW_at(const float* dW, int o, int ta, int tb, i
 __device__ __forceinline__ float dD_at(const float* dD, int o, int t0, int t, int c) {      // six-tap line t0 .. t0 + 5
     return (unsigned)t < 6u ? dD[((size_t)o * 28 + t0 + t) * 8 + c] : 0.f;
 }
+__global__ __launch_bounds__(64) void dstem_compose_bwd_wi_kernel(ComposeBwdArgs a) {
+    // blocks 0 .. 863: dwi[m][c][ih][iw]; blocks 864 .. 895: dbi[m]; thread o = one output channel's share, summed by the wave
+    const int o = threadIdx.x, b = blockIdx.x;
+    float s = 0.f;
+    if (b < 32 * 27) {
+        const int iw = b % 3, ih = (b / 3) % 3, c = (b / 9) % 3, m = b / 27;
+        const float* w0 = a.w0 + (o * 32 + m) * 16;
+        for (int kh = 0; kh < 4; ++kh)
+            for (int kw = 0; kw < 4; ++kw) s += dW_at(a.dW, o, kh + ih, kw + iw, c) * w0[kh * 4 + kw];
+        float p = 0.f;
+        for (int u = 0; u < 2; ++u)
+            for (int v = 0; v < 2; ++v) p += dW_at(a.dW, 64 + o, 1 + u + ih, 1 + v + iw, c);
+        s += 0.25f * p * a.ws[o * 32 + m];
+        if (ih == 2) for (int kw = 0; kw < 4; ++kw) s -= dD_at(a.dD, o, 0, kw + iw, c) * w0[kw];
+        if (ih == 0) for (int kw = 0; kw < 4; ++kw) s -= dD_at(a.dD, o, 6, kw + iw, c) * w0[12 + kw];
+        if (iw == 2) for (int kh = 0; kh < 4; ++kh) s -= dD_at(a.dD, o, 12, kh + ih, c) * w0[kh * 4];
+        if (iw == 0) for (int kh = 0; kh < 4; ++kh) s -= dD_at(a.dD, o, 18, kh + ih, c) * w0[kh * 4 + 3];
+        if (ih == 2 && iw == 2) s += a.dD[((size_t)o * 28 + 24) * 8 + c] * w0[0];
+        if (ih == 2 && iw == 0) s += a.dD[((size_t)o * 28 + 25) * 8 + c] * w0[3];
+        if (ih == 0 && iw == 2) s += a.dD[((size_t)o * 28 + 26) * 8 + c] * w0[12];
+        if (ih == 0 && iw == 0) s += a.dD[((size_t)o * 28 + 27) * 8 + c] * w0[15];
+        s = wave_sum(s);
+        if (o == 0) a.dwi[b] = s;
+    } else {
+        const int m = b - 32 * 27;
+        const float* w0 = a.w0 + (o * 32 + m) * 16;
+        float q = 0.f;
+        for (int k = 0; k < 16; ++k) q += w0[k];
+        s = a.dbias[o] * q + a.dbias[64 + o] * a.ws[o * 32 + m];
+        const float* g = a.dDB + o * 8;
+        s -= g[0] * (w0[0] + w0[1] + w0[2] + w0[3]) + g[1] * (w0[12] + w0[13] + w0[14] + w0[15]) + g[2] * (w0[0] + w0[4] + w0[8] + w0[12]) +
+             g[3] * (w0[3] + w0[7] + w0[11] + w0[15]);
+        s += g[4] * w0[0] + g[5] * w0[3] + g[6] * w0[12] + g[7] * w0[15];
+        s = wave_sum(s);
+        if (o == 0) a.dbi[m] = s;
+    }
+}
+
 __global__ void dstem_compose_bwd_kernel(ComposeBwdArgs a) {
+    constexpr int NW0 = 64 * 32 * 16, NWS = 64 * 32, NBS = 64;      // (dwi / dbi: dstem_compose_bwd_wi_kernel)
     const int id = blockIdx.x * blockDim.x + threadIdx.x;
-    constexpr int NWI = 32 * 27, NBI = 32, NW0 = 64 * 32 * 16, NWS = 64 * 32, NBS = 64;
-    if (id < NWI) {                                          // dwi[m][c][ih][iw]
-        const int iw = id % 3, ih = (id / 3) % 3, c = (id / 9) % 3, m = id / 27;
-        float s = 0.f;
-        for (int o = 0; o < 64; ++o) {
-            const float* w0 = a.w0 + (o * 32 + m) * 16;
-            for (int kh = 0; kh < 4; ++kh)
-                for (int kw = 0; kw < 4; ++kw) s += dW_at(a.dW, o, kh + ih, kw + iw, c) * w0[kh * 4 + kw];
-            float p = 0.f;
-            for (int u = 0; u < 2; ++u)
-                for (int v = 0; v < 2; ++v) p += dW_at(a.dW, 64 + o, 1 + u + ih, 1 + v + iw, c);
-            s += 0.25f * p * a.ws[o * 32 + m];
-            if (ih == 2) for (int kw = 0; kw < 4; ++kw) s -= dD_at(a.dD, o, 0, kw + iw, c) * w0[kw];
-            if (ih == 0) for (int kw = 0; kw < 4; ++kw) s -= dD_at(a.dD, o, 6, kw + iw, c) * w0[12 + kw];
-            if (iw == 2) for (int kh = 0; kh < 4; ++kh) s -= dD_at(a.dD, o, 12, kh + ih, c) * w0[kh * 4];
-            if (iw == 0) for (int kh = 0; kh < 4; ++kh) s -= dD_at(a.dD, o, 18, kh + ih, c) * w0[kh * 4 + 3];
-            if (ih == 2 && iw == 2) s += a.dD[((size_t)o * 28 + 24) * 8 + c] * w0[0];
-            if (ih == 2 && iw == 0) s += a.dD[((size_t)o * 28 + 25) * 8 + c] * w0[3];
-            if (ih == 0 && iw == 2) s += a.dD[((size_t)o * 28 + 26) * 8 + c] * w0[12];
-            if (ih == 0 && iw == 0) s += a.dD[((size_t)o * 28 + 27) * 8 + c] * w0[15];
-        }
-        a.dwi[id] = s;
-    } else if (id < NWI + NBI) {                             // dbi[m]
-        const int m = id - NWI;
-        float s = 0.f;
-        for (int o = 0; o < 64; ++o) {
-            const float* w0 = a.w0 + (o * 32 + m) * 16;
-            float q = 0.f;
-            for (int k = 0; k < 16; ++k) q += w0[k];
-            s += a.dbias[o] * q + a.dbias[64 + o] * a.ws[o * 32 + m];
-            const float* g = a.dDB + o * 8;
-            s -= g[0] * (w0[0] + w0[1] + w0[2] + w0[3]) + g[1] * (w0[12] + w0[13] + w0[14] + w0[15]) + g[2] * (w0[0] + w0[4] + w0[8] + w0[12]) +
-                 g[3] * (w0[3] + w0[7] + w0[11] + w0[15]);
-            s += g[4] * w0[0] + g[5] * w0[3] + g[6] * w0[12] + g[7] * w0[15];
-        }
-        a.dbi[m] = s;
-    } else if (id < NWI + NBI + NW0) {                       // dw0[o][m][kh][kw]
-        const int j = id - NWI - NBI, kw = j & 3, kh = (j >> 2) & 3, m = (j >> 4) & 31, o = j >> 9;
+    if (id < NW0) {                                          // dw0[o][m][kh][kw]
+        const int j = id, kw = j & 3, kh = (j >> 2) & 3, m = (j >> 4) & 31, o = j >> 9;
         float s = a.bi[m] * a.dbias[o];
         const float* g = a.dDB + o * 8;
         for (int c = 0; c < 3; ++c)
@@ -462,8 +466,8 @@ __global__ void dstem_compose_bwd_kernel(ComposeBwdArgs a) {
             for (int c = 0; c < 3; ++c) s += a.dD[((size_t)o * 28 + 24 + corner) * 8 + c] * a.wi[((m * 3 + c) * 3 + ih) * 3 + iw];
         }
         a.dw0[j] = s;
-    } else if (id < NWI + NBI + NW0 + NWS) {                 // dws[o][m]
-        const int j = id - NWI - NBI - NW0, m = j & 31, o = j >> 5;
+    } else if (id < NW0 + NWS) {                             // dws[o][m]
+        const int j = id - NW0, m = j & 31, o = j >> 5;
         float s = a.dbias[64 + o] * a.bi[m];
         for (int c = 0; c < 3; ++c)
             for (int ta = 1; ta < 5; ++ta)
@@ -474,8 +478,8 @@ __global__ void dstem_compose_bwd_kernel(ComposeBwdArgs a) {
                     s += a.dW[((size_t)(64 + o) * 36 + ta * 6 + tb) * 8 + c] * 0.25f * p;
                 }
         a.dws[j] = s;
-    } else if (id < NWI + NBI + NW0 + NWS + NBS) {
-        const int o = id - NWI - NBI - NW0 - NWS;
+    } else if (id < NW0 + NWS + NBS) {
+        const int o = id - NW0 - NWS;
         if (a.dbs) a.dbs[o] = a.dbias[64 + o];
     }
 }
@@ -488,8 +492,8 @@ __global__ void dstem_compose_bwd_kernel(ComposeBwdArgs a) {
 // (w0, w_img, b_img) like the composed weights themselves (ops.compose_dstem builds them):
 //   D  f32 [64][28][8]: taps 0-5 top (by b), 6-11 bottom, 12-17 left (by a), 18-23 right, 24-27 corners TL TR BL BR
 //   DB f32 [64][8]    : their constant terms (conv_img's bias through the dropped taps), same order
-// The border kernels touch 4 (OH + OW) - 4 pixels per image -- 3 % of the map at 128 x 128 -- with plain f32 FMAs:
-//   dstem_border_fwd    recomputes h1 there from the image with W + D (f32 weights), overwriting what the main kernel wrote
+// The border kernels touch 2 (OH + OW) - 4 pixels per image -- 3 % of the map at 128 x 128:
+//   dstem_border_fwd    recomputes h1 there from the image with W + D as a small MFMA GEMM, overwriting what the main kernel wrote
 //   dstem_border_wgrad  dD, dDB += sum over border pixels of dh1 (x) image taps (the composed weights' own gradient takes ALL pixels)
 __device__ __forceinline__ void border_pixel(int i, int OH, int OW, int& py, int& px) {      // i-th pixel of the perimeter
     if (i < OW) { py = 0; px = i; }
@@ -497,64 +501,89 @@ __device__ __forceinline__ void border_pixel(int i, int OH, int OW, int& py, int
     else { const int j = i - 2 * OW; py = 1 + (j >> 1); px = (j & 1) ? OW - 1 : 0; }
 }
 
-// one thread per border pixel, all 64 channels (weights broadcast from LDS: every lane reads the same address)
-__global__ __launch_bounds__(256) void dstem_border_fwd_kernel(const u32x4* __restrict__ img, const float* __restrict__ w, const float* __restrict__ bias,
-                                                              const float* __restrict__ D, const float* __restrict__ DB, bf16x8* __restrict__ h1, int N,
-                                                              int H, int W, float slope) {
+// MFMA fragments of the border kernel's weights: 64 "taps" (36 composed + 28 corrections) x 8 channels = 16 K steps, 64 output
+// channels = 4 row blocks; fragment f = j * 16 + s, rows permuted as in dstem_pack_kernel
+__global__ void dstem_border_pack_kernel(const float* __restrict__ w, const float* __restrict__ D, bf16x8* __restrict__ frag) {
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= 4 * 16 * 64) return;
+    const int lane = id & 63, f = id >> 6, s = f & 15, j = f >> 4;
+    const int q = lane & 15, kg = lane >> 4;
+    const int co = (j >> 1) * 32 + (q >> 2) * 8 + (j & 1) * 4 + (q & 3), t = 4 * s + kg;
+    const float* src = t < 36 ? w + ((size_t)co * 36 + t) * 8 : D + ((size_t)co * 28 + t - 36) * 8;
+    bf16x8 o;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) o[c] = (xmc_h16)src[c];
+    frag[id] = o;
+}
+
+// The border pixels of h1 as a small GEMM: per 16 pixels, K = 64 taps x 8 channels, the lane's 16-byte image unit straight from
+// global memory into the MFMA B operand (zero where the tap does not apply to the pixel: outside the image, or a correction line of
+// a side the pixel is not on).  Weights (64 KB of fragments) in LDS, staged once per workgroup; each wave walks 16-pixel blocks.
+__global__ __launch_bounds__(256) void dstem_border_fwd_kernel(const u32x4* __restrict__ img, const u32x4* __restrict__ frag, const float* __restrict__ bias,
+                                                              const float* __restrict__ DB, bf16x8* __restrict__ h1, int N, int H, int W, float slope) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    f32x4* wl = reinterpret_cast<f32x4*>(smem);               // [36 + 28 taps][64 co] x (c0, c1, c2, 0)
-    float* dbl = reinterpret_cast<float*>(wl + 64 * 64);      // [8][64]
-    float* bl = dbl + 8 * 64;                                 // [64]
-    const int tid = threadIdx.x;
-    for (int id = tid; id < 64 * 64; id += 256) {
-        const int t = id >> 6, o = id & 63;
-        wl[id] = t < 36 ? *reinterpret_cast<const f32x4*>(w + ((size_t)o * 36 + t) * 8) : *reinterpret_cast<const f32x4*>(D + ((size_t)o * 28 + t - 36) * 8);
-    }
-    for (int id = tid; id < 8 * 64; id += 256) dbl[id] = DB[(id & 63) * 8 + (id >> 6)];
-    if (tid < 64) bl[tid] = bias[tid];
+    u32x4* wl = reinterpret_cast<u32x4*>(smem);               // [4 blocks][16 K steps][64 lanes]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int id = tid; id < 4 * 16 * 64; id += 256) wl[id] = frag[id];
     __syncthreads();
     const int OH = H >> 1, OW = W >> 1, P = 2 * OW + 2 * (OH - 2);
-    const long long gid = (long long)blockIdx.x * 256 + tid;
-    if (gid >= (long long)N * P) return;
-    const int n = (int)(gid / P), i = (int)(gid - (long long)n * P);
-    int py, px;
-    border_pixel(i, OH, OW, py, px);
-    float v[64];
+    const long long nblk = ((long long)N * P + 15) / 16;
+    const int p = lane & 15, g = lane >> 4;
+    float bv[2][8], dbv[2][8][8];
 #pragma unroll
-    for (int k = 0; k < 64; ++k) v[k] = bl[k];
-    auto tap = [&](int t, int sy, int sx) {                   // v += (weights of table row t) . image pixel (sy, sx)
-        if ((unsigned)sy >= (unsigned)H || (unsigned)sx >= (unsigned)W) return;
-        const bf16x8 xv = __builtin_bit_cast(bf16x8, img[((size_t)n * H + sy) * W + sx]);
-        const float x0 = (float)xv[0], x1 = (float)xv[1], x2 = (float)xv[2];
-        const f32x4* wt = wl + t * 64;
+    for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int k = 0; k < 64; ++k) {
-            const f32x4 ww = wt[k];
-            v[k] += ww[0] * x0 + ww[1] * x1 + ww[2] * x2;
+        for (int c = 0; c < 8; ++c) {
+            bv[u][c] = bias[u * 32 + g * 8 + c];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dbv[u][c][e] = DB[(u * 32 + g * 8 + c) * 8 + e];
         }
-    };
-    for (int a = 0; a < 6; ++a)
-        for (int b = 0; b < 6; ++b) tap(a * 6 + b, 2 * py - 2 + a, 2 * px - 2 + b);
-    const bool top = py == 0, bot = py == OH - 1, lef = px == 0, rig = px == OW - 1;
-    auto cst = [&](int j) {
+    for (long long blk = (long long)blockIdx.x * 4 + wave; blk < nblk; blk += (long long)gridDim.x * 4) {
+        const long long gid = blk * 16 + p;
+        const bool live = gid < (long long)N * P;
+        const int n = live ? (int)(gid / P) : 0, i = live ? (int)(gid - (long long)n * P) : 0;
+        int py, px;
+        border_pixel(i, OH, OW, py, px);
+        const bool top = py == 0, bot = py == OH - 1, lef = px == 0, rig = px == OW - 1;
+        f32x4 acc[4] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-        for (int k = 0; k < 64; ++k) v[k] += dbl[j * 64 + k];
-    };
-    if (top) { cst(0); for (int t = 0; t < 6; ++t) tap(36 + t, 0, 2 * px - 2 + t); }
-    if (bot) { cst(1); for (int t = 0; t < 6; ++t) tap(42 + t, H - 1, 2 * px - 2 + t); }
-    if (lef) { cst(2); for (int t = 0; t < 6; ++t) tap(48 + t, 2 * py - 2 + t, 0); }
-    if (rig) { cst(3); for (int t = 0; t < 6; ++t) tap(54 + t, 2 * py - 2 + t, W - 1); }
-    if (top && lef) { cst(4); tap(60, 0, 0); }
-    if (top && rig) { cst(5); tap(61, 0, W - 1); }
-    if (bot && lef) { cst(6); tap(62, H - 1, 0); }
-    if (bot && rig) { cst(7); tap(63, H - 1, W - 1); }
-    bf16x8* dst = h1 + (((size_t)n * OH + py) * OW + px) * 8;
+        for (int s = 0; s < 16; ++s) {
+            const int t = 4 * s + g;
+            int sy, sx;
+            if (s < 9) { sy = 2 * py - 2 + t / 6; sx = 2 * px - 2 + t % 6; }
+            else {
+                const int e = t - 36;                          // 0-5 top, 6-11 bottom, 12-17 left, 18-23 right, 24-27 corners
+                if (e < 6) { sy = top ? 0 : -1; sx = 2 * px - 2 + e; }
+                else if (e < 12) { sy = bot ? H - 1 : -1; sx = 2 * px - 2 + e - 6; }
+                else if (e < 18) { sy = 2 * py - 2 + e - 12; sx = lef ? 0 : -1; }
+                else if (e < 24) { sy = 2 * py - 2 + e - 18; sx = rig ? W - 1 : -1; }
+                else {
+                    const bool on = e == 24 ? (top && lef) : e == 25 ? (top && rig) : e == 26 ? (bot && lef) : (bot && rig);
+                    sy = on ? ((e & 2) ? H - 1 : 0) : -1;
+                    sx = (e & 1) ? W - 1 : 0;
+                }
+            }
+            const bool ok = live && (unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W;
+            const u32x4 bf = ok ? img[((size_t)n * H + sy) * W + sx] : u32x4{0, 0, 0, 0};
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        bf16x8 o;
+            for (int j = 0; j < 4; ++j)
+                acc[j] = XMC_MFMA_16x16x32(__builtin_bit_cast(bf16x8, wl[(j * 16 + s) * 64 + lane]), __builtin_bit_cast(bf16x8, bf), acc[j], 0, 0, 0);
+        }
+        if (!live) continue;
+        const float ft = top ? 1.f : 0.f, fb = bot ? 1.f : 0.f, fl = lef ? 1.f : 0.f, fr_ = rig ? 1.f : 0.f;
+        bf16x8* dst = h1 + (((size_t)n * OH + py) * OW + px) * 8;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { const float t = v[u * 8 + k]; o[k] = (xmc_h16)fmaxf(t, t * slope); }
-        dst[u] = o;
+        for (int u = 0; u < 2; ++u) {
+            bf16x8 o;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float* e = dbv[u][c];
+                float v = (c < 4 ? acc[2 * u][c] : acc[2 * u + 1][c - 4]) + bv[u][c];
+                v += ft * e[0] + fb * e[1] + fl * e[2] + fr_ * e[3] + ft * fl * e[4] + ft * fr_ * e[5] + fb * fl * e[6] + fb * fr_ * e[7];
+                o[c] = (xmc_h16)fmaxf(v, v * slope);
+            }
+            dst[u * 4 + g] = o;
+        }
     }
 }
 
@@ -648,21 +677,26 @@ extern "C" int xmc_dstem_compose_bwd(const float* wi, const float* bi, const flo
                                      const float* dD, const float* dDB, float* dwi, float* dbi, float* dw0, float* dws, float* dbs, void* stream) {
     if (!wi || !bi || !w0 || !ws || !dW || !dbias || !dD || !dDB || !dwi || !dbi || !dw0 || !dws) return XMC_EINVAL;
     ComposeBwdArgs a{wi, bi, w0, ws, dW, dbias, dD, dDB, dwi, dbi, dw0, dws, dbs};
-    constexpr int n = 32 * 27 + 32 + 64 * 32 * 16 + 64 * 32 + 64;
+    constexpr int n = 64 * 32 * 16 + 64 * 32 + 64;
     hipLaunchKernelGGL(dstem_compose_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+    hipLaunchKernelGGL(dstem_compose_bwd_wi_kernel, dim3(32 * 27 + 32), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), a);
     XMC_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int xmc_dstem_border_fwd(const void* img, const float* w, const float* bias, const float* D, const float* DB, void* h1, int N, int H,
-                                    int W, float slope, void* stream) {
-    if (!img || !w || !bias || !D || !DB || !h1 || N < 1) return XMC_EINVAL;
+extern "C" int xmc_dstem_border_fwd(const void* img, const float* w, const float* bias, const float* D, const float* DB, void* frag_scratch,
+                                    void* h1, int N, int H, int W, float slope, void* stream) {
+    if (!img || !w || !bias || !D || !DB || !frag_scratch || !h1 || N < 1) return XMC_EINVAL;
     if (H < 16 || W < 64 || H % 16 != 0 || W % 64 != 0) return XMC_ESHAPE;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(dstem_border_pack_kernel, dim3(16), dim3(256), 0, st, w, D, reinterpret_cast<bf16x8*>(frag_scratch));
     const long long px = (long long)N * (2 * (W / 2) + 2 * (H / 2 - 2));
-    const size_t lds = (size_t)64 * 64 * 16 + 8 * 64 * 4 + 64 * 4;
+    const long long nblk = (px + 15) / 16;
+    const int grid = (int)(nblk / 4 < 512 ? (nblk + 3) / 4 : 512);
+    const size_t lds = (size_t)4 * 16 * 64 * 16;
     XMC_ALLOW_BIG_LDS(dstem_border_fwd_kernel);
-    hipLaunchKernelGGL(dstem_border_fwd_kernel, dim3((unsigned)((px + 255) / 256)), dim3(256), lds, reinterpret_cast<hipStream_t>(stream),
-                       reinterpret_cast<const u32x4*>(img), w, bias, D, DB, reinterpret_cast<bf16x8*>(h1), N, H, W, slope);
+    hipLaunchKernelGGL(dstem_border_fwd_kernel, dim3(grid), dim3(256), lds, st, reinterpret_cast<const u32x4*>(img),
+                       reinterpret_cast<const u32x4*>(frag_scratch), bias, DB, reinterpret_cast<bf16x8*>(h1), N, H, W, slope);
     XMC_LAUNCH_CHECK();
     return 0;
 }

@@ -840,7 +840,8 @@ def _dstem_fwd_raw(xin, wsets, bias, slope=0.2):
 def _dstem_border_fwd_raw(xin, wsets, bias, D, DB, h1, slope=0.2):
     """overwrite h1's border pixels with the reference's values (composed weights + border corrections, f32 arithmetic)"""
     N, H, W, _ = xin.shape
-    L.call("xmc_dstem_border_fwd", _p(xin), _p(wsets), _p(bias), _p(D), _p(DB), _p(h1), N, H, W, float(slope), _st())
+    wt = torch.empty(64 * 1024, dtype=torch.uint8, device=xin.device)              # the kernel's MFMA fragments of W + D (16-bit)
+    L.call("xmc_dstem_border_fwd", _p(xin), _p(wsets), _p(bias), _p(D), _p(DB), _p(wt), _p(h1), N, H, W, float(slope), _st())
 
 
 def _dstem_wgrad_raw(xin, dh1, dsc, skip_border=False, border=True):
