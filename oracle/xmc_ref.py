@@ -861,19 +861,61 @@ def netd_forward(P, h: Hyper, x, second_order=False):
     return out
 
 
+def _dstem_compose_q(P):
+    """The engine's composed discriminator stem (round 4, csrc/dstem.hip): conv_img feeds the first block without an activation, so
+    conv_r[0] o conv_img is a 6x6 stride-2 pad-2 convolution of the image and conv_s o avg_pool2d o conv_img a 4x4 stride-2 pad-1
+    one (df_gan.py:114,127,272-291).  Returns (W_A [2ndf,3,6,6], b_A, W_B [2ndf,3,4,4], b_B) as differentiable functions of the five
+    parameters: what the engine rounds to 16 bits ONCE, in place of conv_img's output and the two weight tensors separately."""
+    wi, bi = P["conv_img.weight"], P["conv_img.bias"]
+    w0, ws, bs = P["downblocks.0.conv_r.0.weight"], P["downblocks.0.conv_s.weight"], P["downblocks.0.conv_s.bias"]
+    wa = F.conv_transpose2d(w0, wi)                                       # full correlation over conv_img's channels
+    ba = torch.einsum("omhw,m->o", w0, bi)
+    box = torch.full((1, 1, 2, 2), 0.25, dtype=wi.dtype)
+    wp = F.conv_transpose2d(wi.reshape(-1, 1, 3, 3), box).reshape(wi.shape[0], wi.shape[1], 4, 4)
+    wb = torch.einsum("om,mcab->ocab", ws[:, :, 0, 0], wp)
+    return wa, ba, wb, ws[:, :, 0, 0] @ bi + bs
+
+
+def dstem_applies(h: Hyper, x, second_order=False):
+    """where the engine takes the composed stem: 16-bit modes at the width it is built for (ndf = 32), images that tile, no
+    spectral norm, no second-order pass (ops.dstem_eligible / NetD.forward)"""
+    return h.nch == 32 and not h.spec_norm and not second_order and x.shape[2] % 16 == 0 and x.shape[3] % 64 == 0
+
+
 def _netd_forward_q(P, h: Hyper, x, a, second_order=False):
     """DF_DISC with the engine's storage points (image, every convolution output, the pooled shortcut input, the block sum) and
     its order on the shortcut: average pool first, then the 1x1 convolution (they commute; df_gan.py:286-291).
     ``second_order``: the pass whose backward is differentiated again (MA-GP) -- there the engine stores the residual branch and
-    rounds gamma * s * dout in one pointwise pass; everywhere else it stores the branch's sign bits (_QBranchTimesGamma)."""
-    out = q(F.conv2d(q(x, "d.img"), qw(sn_weight(P, "conv_img.weight"), "d.w"), P["conv_img.bias"], 1, 1), "d.conv_img")
+    rounds gamma * s * dout in one pointwise pass; everywhere else it stores the branch's sign bits (_QBranchTimesGamma).
+    Where the engine runs conv_img and the first block on the composed stem (`dstem_applies`) the first block's first activation
+    and its shortcut come straight from the rounded image through the rounded COMPOSED weights: conv_img's output, its pooled copy
+    and the separate roundings of the three weight tensors do not exist (the block's border pixels, which the engine computes with
+    separately rounded correction tables, are taken from the same composed convolution of the un-composed f32 form here: 3 % of the
+    map, a rounding-level difference)."""
+    stem = dstem_applies(h, x, second_order) and "d.conv_img" not in _QSKIP
+    xq = q(x, "d.img")
+    if stem:
+        wa, ba, wb, bb = _dstem_compose_q(P)
+        ci = F.conv2d(xq, P["conv_img.weight"], P["conv_img.bias"], 1, 1)                       # f32, never stored: border pixels only
+        r_exact = F.conv2d(ci, P["downblocks.0.conv_r.0.weight"], None, 2, 1)
+        r_comp = F.conv2d(xq, qw(wa, "d.w"), ba, 2, 2)
+        m = torch.zeros_like(r_comp[:1, :1])
+        m[:, :, 1:-1, 1:-1] = 1.0
+        r0 = q(F.leaky_relu(m * r_comp + (1.0 - m) * r_exact, LRELU), "d.r0")
+        s0 = q(F.conv2d(xq, qw(wb, "d.w"), bb, 2, 1), "d.sc")
+        out = None
+    else:
+        out = q(F.conv2d(xq, qw(sn_weight(P, "conv_img.weight"), "d.w"), P["conv_img.bias"], 1, 1), "d.conv_img")
     for i in range(1, a["depth"]):
         p = f"downblocks.{i - 1}"
-        r = q(F.leaky_relu(F.conv2d(out, qw(sn_weight(P, f"{p}.conv_r.0.weight"), "d.w"), None, 2, 1), LRELU), "d.r0")
+        if stem and i == 1:
+            r, s = r0, s0
+        else:
+            r = q(F.leaky_relu(F.conv2d(out, qw(sn_weight(P, f"{p}.conv_r.0.weight"), "d.w"), None, 2, 1), LRELU), "d.r0")
+            s = q(F.avg_pool2d(out, 2), "d.pool")
+            if a["cin"][i] != a["cout"][i]:
+                s = q(F.conv2d(s, qw(sn_weight(P, f"{p}.conv_s.weight"), "d.w"), P[f"{p}.conv_s.bias"]), "d.sc")
         z = F.conv2d(r, qw(sn_weight(P, f"{p}.conv_r.2.weight"), "d.w"), None, 1, 1)
-        s = q(F.avg_pool2d(out, 2), "d.pool")
-        if a["cin"][i] != a["cout"][i]:
-            s = q(F.conv2d(s, qw(sn_weight(P, f"{p}.conv_s.weight"), "d.w"), P[f"{p}.conv_s.bias"]), "d.sc")
         site = "d.last" if (i == a["depth"] - 1 and "d.last" in _QSKIP) else "d.sum"
         if second_order or "d.r2" in _QSKIP:
             out = q(s + P[f"{p}.gamma"] * q(F.leaky_relu(z, LRELU), "d.r2"), site)

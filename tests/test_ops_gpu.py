@@ -1184,16 +1184,16 @@ def test_composed_stem_block_equals_conv_img_plus_block(mode, N, S):
         blk.conv_s.bias.normal_(0, 0.1)
     g = torch.Generator().manual_seed(N + S)
     x = rt(torch.rand(N, 3, S, S, generator=g) * 2 - 1, mode)
-    xin = to_nhwc(x, 8, dt)
+    xin = to_nhwc(x, 8, dt).requires_grad_()
     r = rt(torch.randn(N, 64, S // 2, S // 2, generator=g), mode)
     params = [conv_img.weight, conv_img.bias, blk.conv_r[0].weight, blk.conv_r[2].weight, blk.conv_s.weight, blk.conv_s.bias, blk.gamma]
 
     def grads(out):
-        for p_ in params:
+        for p_ in params + [xin]:
             p_.grad = None
         ops.new_iteration(DEV)
         (out.float() * to_nhwc(r, 64, torch.float32)).sum().backward()
-        return [p_.grad.detach().float().cpu().clone() for p_ in params]
+        return [p_.grad.detach().float().cpu().clone() for p_ in params] + [from_nhwc(xin.grad, 3)]
 
     ci, cip = conv_img(xin, want_pool=True)
     out_o, pool_o = blk(ci, xp_hint=cip, want_pool=True)
@@ -1203,8 +1203,8 @@ def test_composed_stem_block_equals_conv_img_plus_block(mode, N, S):
                                            conv_img.geom, r0.geom, r2.geom, s_.geom, True)
     g_n = grads(out_n)
     # f32 reference on the CPU
-    P = [p_.detach().float().cpu().clone().requires_grad_() for p_ in params]
-    ci_r = F.conv2d(x, P[0], P[1], 1, 1)
+    P = [p_.detach().float().cpu().clone().requires_grad_() for p_ in params] + [x.clone().requires_grad_()]
+    ci_r = F.conv2d(P[7], P[0], P[1], 1, 1)
     br = F.leaky_relu(F.conv2d(F.leaky_relu(F.conv2d(ci_r, P[2], None, 2, 1), 0.2), P[3], None, 1, 1), 0.2)
     out_r = F.conv2d(F.avg_pool2d(ci_r, 2), P[4], P[5]) + P[6] * br
     (out_r * r).sum().backward()
@@ -1213,7 +1213,7 @@ def test_composed_stem_block_equals_conv_img_plus_block(mode, N, S):
     torch.testing.assert_close(from_nhwc(out_n, 64), out_r.detach(), rtol=tl, atol=tl * sc_)
     torch.testing.assert_close(from_nhwc(out_n, 64), from_nhwc(out_o, 64), rtol=tl, atol=tl * sc_)
     torch.testing.assert_close(from_nhwc(pool_n, 64), F.avg_pool2d(out_r.detach(), 2), rtol=tl, atol=tl * sc_)
-    names = ["conv_img.weight", "conv_img.bias", "conv_r.0.weight", "conv_r.2.weight", "conv_s.weight", "conv_s.bias", "gamma"]
+    names = ["conv_img.weight", "conv_img.bias", "conv_r.0.weight", "conv_r.2.weight", "conv_s.weight", "conv_s.bias", "gamma", "image"]
     for n_, a, b, c in zip(names, g_n, g_o, P):
         e_ref, e_old = rel_l2(a, c.grad), rel_l2(b, c.grad)
         print(f"{n_:18s} composed vs f32 {e_ref:.2e}   conv_img + ResDFn vs f32 {e_old:.2e}")

@@ -45,7 +45,9 @@ __global__ void dstem_pack_kernel(const float* __restrict__ w, bf16x8* __restric
 // double-buffered, next tile's patch prefetched into registers: one barrier per tile.
 __global__ __launch_bounds__(512) void dstem_fwd_kernel(const u32x4* __restrict__ img, const u32x4* __restrict__ frag, const float* __restrict__ bias,
                                                        bf16x8* __restrict__ h1, bf16x8* __restrict__ sc, int N, int H, int W, float slope, int ntiles) {
-    constexpr int TR = 4, TC = 32, PR = 2 * TR + 4, PC = 2 * TC + 4, PLANE = PC / 2;      // 12 x 68 patch, 34 slots per plane
+    constexpr int TR = 4, TC = 32, PR = 2 * TR + 4, PC = 2 * TC + 4;                      // 12 x 68 patch
+    constexpr int PLANE = PC / 2 + 2;        // 34 slots per column-parity plane, padded to 36: consecutive source pixels alternate planes,
+                                             // 576 bytes = 16 banks apart (34: SQ_LDS_BANK_CONFLICT 0.5 per active cycle on the patch stores)
     constexpr int PUNITS = PR * PC;                                                       // 816 sixteen-byte units
     __shared__ u32x4 patch[2][PR * 2 * PLANE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

@@ -1683,8 +1683,8 @@ class DStemBlockFn(torch.autograd.Function):
     weight-gradient launch on the image (gradients of the composed weights; a second, tiny one for the border corrections)
     through autograd on the composition.
     The rest of the block is ResDFn's: conv_r[2] + LeakyReLU + block sum (+ sign bits, + pooled output) in one launch, its data
-    gradient with the LeakyReLU' mask of h1 and d(gamma) in the epilogue.  Used when the image needs no gradient (the D step; the
-    G step's no-grad pass over the real batch): the G step's pass over the generated batch keeps conv_img + ResDFn."""
+    gradient with the LeakyReLU' mask of h1 and d(gamma) in the epilogue.  The gradient of the image, where asked for (the G step's
+    pass over the generated batch), comes from the un-composed transposed chain, which needs no stored activation."""
 
     @staticmethod
     def forward(ctx, xin, w_img, b_img, w0, w2, ws, bs, gamma, g_img, g0, g2, gs, want_pool=False):
@@ -1697,7 +1697,7 @@ class DStemBlockFn(torch.autograd.Function):
         h1, sc = _dstem_fwd_raw(xin, wsets, bias)
         _dstem_border_fwd_raw(xin, wsets, bias, D, DB, h1)          # conv_r[0]'s zero padding of conv_img's output: 3 % of the pixels
         al = gamma.detach().reshape(-1).float()
-        keep = any(ctx.needs_input_grad[1:8])
+        keep = any(ctx.needs_input_grad[:8])
         pool_ok = want_pool and res_pool_ok(h1, g2)
         r = _conv_fwd_raw(h1, w2, None, g2, L.ACT_LRELU, dt, res=sc, alpha=al, want_sign=keep, want_pool=pool_ok, round_act=True)
         r = r if isinstance(r, tuple) else (r,)
@@ -1722,8 +1722,6 @@ class DStemBlockFn(torch.autograd.Function):
         nin = 13
         if dout is None:
             return (None,) * nin
-        if ctx.needs_input_grad[0]:
-            raise RuntimeError("DStemBlockFn: no gradient with respect to the image (NetD.forward keeps conv_img + ResDFn for that)")
         xin, h1, bits, w_img, b_img, w0, w2, ws, bs, gamma = ctx.saved_tensors
         g_img, g0, g2, gs = ctx.geoms
         dt = xin.dtype
@@ -1736,19 +1734,33 @@ class DStemBlockFn(torch.autograd.Function):
         al = gamma.detach().reshape(-1).float()
         dgam = _zeros_f32_out(1, xin.device)
         # residual branch, as ResDBwdFn on sign bits: gr = s * dout, d(gamma) from the data gradient's epilogue
-        gr = torch.empty_like(dout)
-        L.call("xmc_signmask_apply", _p(dout), _p(bits), _p(gr), dout.numel(), 0.2, _code(dt), _st())
+        need_x = ctx.needs_input_grad[0]
+        gr = dxp = None
+        if need_x and "no_pw1x1_masked_src" not in _DEBUG_DISPATCH:      # the shortcut's data gradient streams dout anyway: gr is its by-product
+            dxp, gr = _conv_dgrad_raw(dout, ws, gs, (OH, OW), dt, src_bits=bits)
+        if gr is None:
+            gr = torch.empty_like(dout)
+            L.call("xmc_signmask_apply", _p(dout), _p(bits), _p(gr), dout.numel(), 0.2, _code(dt), _st())
         dw2 = _conv_wgrad_raw(h1, gr, g2, scale=al).view(w2.shape) if (ctx.needs_input_grad[4] and not skip_w) else None
         gh = _conv_dgrad_raw(gr, w2, g2, (OH, OW), dt, mask=h1, alpha=al, dot=dgam)          # d h1 in front of its LeakyReLU
         dgamma = dgam.reshape(gamma.shape).to(gamma.dtype) if ctx.needs_input_grad[7] else None
-        if skip_w:
-            return (None, None, None, None, dw2, None, None, dgamma) + (None,) * 5
+        dx = None
+        if need_x:
+            # The gradient of the IMAGE (the G step's pass over the generated batch) takes the un-composed chain -- conv_r[0]^T with the
+            # pooled shortcut gradient as its row-indexed residual, then conv_img^T -- which needs weights and gradients only, none of
+            # the activations the composed forward did not write.
+            if dxp is None:
+                dxp = _conv_dgrad_raw(dout, ws, gs, (OH, OW), dt)
+            dci = _conv_dgrad_raw(gh, w0, g0, (H, W), dt, res=dxp, res_rows=True, res_scale=0.25)
+            dx = _conv_dgrad_raw(dci, w_img, g_img, (H, W), dt)
+        if skip_w or not any(ctx.needs_input_grad[1:7]):
+            return (dx, None, None, None, dw2, None, None, dgamma) + (None,) * 5
         # gradients of the composed weights (every pixel) and of the border corrections (border pixels of h1), then back through the
         # composition to the five parameters
         tabs = _dstem_wgrad_raw(xin, gh, dout)
         dwi, dbi, dw0, dws, dbs = _dstem_compose_bwd_raw(w_img, b_img, w0, ws, bs, *tabs)
         dwi, dw0, dws = dwi.view(w_img.shape), dw0.view(w0.shape), dws.view(ws.shape)
-        return (None, dwi.to(w_img.dtype), dbi.to(b_img.dtype), dw0.to(w0.dtype), dw2, dws.to(ws.dtype),
+        return (dx, dwi.to(w_img.dtype), dbi.to(b_img.dtype), dw0.to(w0.dtype), dw2, dws.to(ws.dtype),
                 None if dbs is None else dbs.to(bs.dtype), dgamma) + (None,) * 5
 
 

@@ -152,10 +152,9 @@ class NetD(nn.Module):
             b0 = self.downblocks[0]
             first = 0
             # conv_img + the first block on the composed stem (ops.DStemBlockFn: the image straight to the block's first activation and
-            # to its shortcut; conv_img's output never exists) wherever the image itself needs no gradient and no second-order pass
-            # follows: the D step and the G step's pass over the real batch
+            # to its shortcut; conv_img's output never exists) wherever no second-order pass follows (MA-GP differentiates the
+            # backward of this forward: conv_img + ResDFn there)
             if (ops.fused_blocks() and not self.conv_img.spec_norm and not ops.second_order_active() and b0.downsample
-                    and not (torch.is_grad_enabled() and xin.requires_grad)
                     and ops.dstem_eligible(xin, self.conv_img.out_channels, b0.learned_shortcut, b0.conv_r[0].out_channels)):
                 r0, r2, s_ = b0.conv_r[0], b0.conv_r[2], b0.conv_s
                 out, pooled = ops.DStemBlockFn.apply(xin, self.conv_img.weight, self.conv_img.bias, r0.weight, r2.weight, s_.weight, s_.bias,
