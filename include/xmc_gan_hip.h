@@ -468,6 +468,11 @@ int xmc_dstem_wgrad(const void* img, const void* dh1, const void* dsc, float* dw
 int xmc_dstem_border_fwd(const void* img, const float* w, const float* bias, const float* D, const float* DB, void* frag_scratch /* 64 KB */,
                          void* h1, int N, int H, int W, float slope, void* stream);
 int xmc_dstem_border_wgrad(const void* img, const void* dh1, float* dD, float* dDB, int N, int H, int W, void* stream);
+/* gradient of the image: dimg [N,H,W,8] (16-bit format; channels 3-7 written as zero) = W^T (dh1 | dsc) + D^T dh1 on the border: one
+ * 3x3 convolution over the low-resolution gradient map whose MFMA rows are (image channel, output-parity class), then the border
+ * corrections added to image rows 0 / H-1 and columns 0 / W-1.  frag_scratch: 36 KB. */
+int xmc_dstem_dgrad(const void* dh1, const void* dsc, const float* wsets, const float* D, void* frag_scratch, void* dimg, int N, int H, int W,
+                    void* stream);
 
 #ifdef __cplusplus
 }

@@ -63,6 +63,10 @@ for N in (256, 512):
     timeit("            wgrad conv_img", old_wi)
     timeit("            dgrad conv_r[0] (d conv_img out)", lambda: ops._conv_dgrad_raw(dh1, w0, g0, (H, W), dt))
 
+    timeit("composed stem image gradient (+ border)", lambda: ops._dstem_dgrad_raw(dh1, dsc, wsets, D, H, W))
+    timeit("  replaces: dgrad conv_img (d image)", lambda: ops._conv_dgrad_raw(dci, w_img, g_img, (H, W), dt))
+    timeit("            dgrad conv_s (d pooled map)", lambda: ops._conv_dgrad_raw(dsc, ws, gs, (H // 2, W // 2), dt))
+
     def old_ws():
         ops.new_iteration(dev)
         return ops._conv_wgrad_raw(cip, dsc, gs, want_bias=True)

@@ -1163,6 +1163,17 @@ def test_discriminator_stem_composition_kernels(N, H, W, mode):
     ref = wc8.grad.permute(0, 2, 3, 1).reshape(128, 36, 8)
     assert ((dw.cpu() - ref).norm() / ref.norm()) < 5e-5, (dw.cpu() - ref).norm() / ref.norm()
     assert ((db.cpu() - bc.grad).norm() / bc.grad.norm()) < 5e-5
+    # gradient of the image: the adjoint of the composed stem incl. its border corrections == autograd through the two-stage form
+    xr = x.clone().requires_grad_()
+    cir = F.conv2d(xr, w_img, b_img, 1, 1)
+    ((F.conv2d(cir, w0, None, 2, 1) * r[:, :64]).sum() + (F.conv2d(F.avg_pool2d(cir, 2), ws, bs) * r[:, 64:]).sum()).backward()
+    dimg = ops._dstem_dgrad_raw(to_nhwc(r[:, :64], 64, dt), to_nhwc(r[:, 64:], 64, dt), wsets, D, H, W)
+    assert L.load().xmc_last_kernel().decode() == "dstem_dgrad_kernel"
+    got = from_nhwc(dimg, 3)
+    e_all, e_in = rel_l2(got, xr.grad), rel_l2(got[:, :, 2:-2, 2:-2], xr.grad[:, :, 2:-2, 2:-2])
+    e_b = rel_l2(torch.cat((got[:, :, 0], got[:, :, -1], got[:, :, :, 0], got[:, :, :, -1]), 2), torch.cat((xr.grad[:, :, 0], xr.grad[:, :, -1], xr.grad[:, :, :, 0], xr.grad[:, :, :, -1]), 2))
+    assert max(e_all, e_in, e_b) < (1.5e-2 if mode == "bf16" else 3e-3), (e_all, e_in, e_b)
+    assert float(dimg[..., 3:].abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("mode,N,S", [("f16", 3, 64), ("bf16", 2, 128), ("bf16", 8, 64)])

@@ -486,6 +486,155 @@ __global__ void dstem_compose_bwd_kernel(ComposeBwdArgs a) {
     }
 }
 
+// ---- gradient of the image ------------------------------------------------------------------------------------------------------------
+// dx[2a + py][2b + px][c] = sum over the three low-res offsets d = +1, 0, -1 per dimension, the 128 gradient channels o:
+//      W[o][ta = py + 2 (1 - dh)][tb = px + 2 (1 - dw)][c] * dy[a + dh][b + dw][o]             dy = (dh1 | dsc)
+// i.e. ONE 3x3 convolution over the low-resolution gradient map whose 12 output "channels" are (image channel c, parity class):
+// the four classes share every dy fragment.  MFMA rows = c * 4 + class (12 of 16 used), K = 9 offsets x 128 channels, columns =
+// low-res pixels; a lane ends with the four classes of ONE image channel of its pixel, three lanes (g = c) hold a 2x2 block of
+// image pixels.  Structure of thin_out_kernel (conv_thin.hip): weights in registers (36 fragments), 8 x 16 low-res tiles with the
+// 10 x 18 halo patch of both gradient tensors in LDS, next tile prefetched into registers.
+// dstem_pack_t: the composed weights -> those 36 fragments: fragment (t = dh_i * 3 + dw_i, kc) holds, for row (c, class) and the
+// 32 gradient channels of chunk kc, W[32 kc + k][ta][tb][c].
+__global__ void dstem_pack_t_kernel(const float* __restrict__ w, bf16x8* __restrict__ frag) {
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= 9 * 4 * 64) return;
+    const int lane = id & 63, f = id >> 6, kc = f & 3, t = f >> 2;
+    const int row = lane & 15, kg = lane >> 4;
+    const int c = row >> 2, cls = row & 3, py = cls >> 1, px = cls & 1;
+    const int dhi = t / 3, dwi = t - dhi * 3;                 // offset d = 1 - index: +1, 0, -1
+    const int ta = py + 2 * dhi, tb = px + 2 * dwi;
+    bf16x8 o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int och = kc * 32 + kg * 8 + k;
+        o[k] = (xmc_h16)(c < 3 ? w[((size_t)och * kTaps + ta * 6 + tb) * 8 + c] : 0.f);
+    }
+    frag[id] = o;
+}
+
+constexpr int DG_H = 8, DG_W = 16, DG_PH = DG_H + 2, DG_PW = DG_W + 2, DG_PSTR = 16 * 16 + 16;      // low-res tile, halo patch, pixel stride
+__global__ __launch_bounds__(256) void dstem_dgrad_kernel(const u32x4* __restrict__ dh1, const u32x4* __restrict__ dsc, const u32x4* __restrict__ frag,
+                                                         bf16x8* __restrict__ dimg, int N, int H, int W, int ntiles) {
+    constexpr int NUN = DG_PH * DG_PW * 16, MAXU = (NUN + 255) / 256;          // 2880 sixteen-byte units: 12 per thread
+    __shared__ __attribute__((aligned(16))) unsigned char smem[DG_PH * DG_PW * DG_PSTR];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 15, kb = lane >> 4;
+    const int OH = H >> 1, OW = W >> 1;
+    const int tiles_x = OW / DG_W, tiles_y = OH / DG_H;
+    bf16x8 wa[36];
+    int loff[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int dh = 1 - t / 3, dw = 1 - t % 3;
+        loff[t] = ((dh + 1) * DG_PW + dw + 1 + col) * DG_PSTR + kb * 16;
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) wa[t * 4 + kc] = __builtin_bit_cast(bf16x8, frag[(t * 4 + kc) * 64 + lane]);
+    }
+    u32x4 pv[MAXU];
+    auto prefetch = [&](int tile) {
+        const int n = tile / (tiles_y * tiles_x), tr = tile - n * (tiles_y * tiles_x);
+        const int y0 = (tr / tiles_x) * DG_H - 1, x0 = (tr % tiles_x) * DG_W - 1;
+#pragma unroll
+        for (int it = 0; it < MAXU; ++it) {
+            const int id = tid + it * 256;
+            const int pp = id >> 4, ch = id & 15;
+            const int py = pp / DG_PW, px = pp - py * DG_PW;
+            const int sy = y0 + py, sx = x0 + px;
+            const bool ok = id < NUN && (unsigned)sy < (unsigned)OH && (unsigned)sx < (unsigned)OW;
+            const u32x4* src = ch < 8 ? dh1 : dsc;
+            pv[it] = ok ? src[(((size_t)n * OH + sy) * OW + sx) * 8 + (ch & 7)] : u32x4{0, 0, 0, 0};
+        }
+    };
+    int tile = blockIdx.x;
+    if (tile < ntiles) prefetch(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < MAXU; ++it) {
+            const int id = tid + it * 256;
+            if (id < NUN) *reinterpret_cast<u32x4*>(smem + (id >> 4) * DG_PSTR + (id & 15) * 16) = pv[it];
+        }
+        __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);
+        const int n = tile / (tiles_y * tiles_x), tr = tile - n * (tiles_y * tiles_x);
+        const int y0 = (tr / tiles_x) * DG_H, x0 = (tr % tiles_x) * DG_W;
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int r = wave * 2 + rr;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int kc = 0; kc < 4; ++kc) {
+                    const bf16x8 b = *reinterpret_cast<const bf16x8*>(smem + r * DG_PW * DG_PSTR + loff[t] + kc * 64);
+                    acc = XMC_MFMA_16x16x32(wa[t * 4 + kc], b, acc, 0, 0, 0);
+                }
+            // lane (col, kb = c): acc[class] for image channel c of low-res pixel (y0 + r, x0 + col).  The lanes c = 1, 2 hand their
+            // four values to the c = 0 lane, which writes the 2x2 block's four 16-byte pixels
+            float v1[4], v2[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                v1[k] = __shfl(acc[k], col + 16, 64);
+                v2[k] = __shfl(acc[k], col + 32, 64);
+            }
+            if (kb == 0) {
+                const int a = y0 + r, b = x0 + col;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    bf16x8 o;
+                    o[0] = (xmc_h16)acc[k]; o[1] = (xmc_h16)v1[k]; o[2] = (xmc_h16)v2[k];
+#pragma unroll
+                    for (int z = 3; z < 8; ++z) o[z] = (xmc_h16)0.f;
+                    dimg[((size_t)n * H + 2 * a + (k >> 1)) * W + 2 * b + (k & 1)] = o;
+                }
+            }
+        }
+    }
+}
+
+// the border corrections' part of the image gradient: D's taps read image row 0 / H - 1 and column 0 / W - 1 only, so only those
+// image pixels receive it.  One thread per (image, line pixel): dx(line pixel) += sum over the border output pixels q that read it
+// and the 64 channels of D[o][tap][c] * dh1(q)[o]; corner taps with the row lines.  Read-modify-write of dstem_dgrad_kernel's
+// output, in two launches (phase 0: the two rows, phase 1: the two columns -- the corner pixels belong to both).
+__global__ __launch_bounds__(256) void dstem_border_dgrad_kernel(const bf16x8* __restrict__ dh1, const float* __restrict__ D, bf16x8* __restrict__ dimg,
+                                                                int N, int H, int W, int phase) {
+    const int OH = H >> 1, OW = W >> 1;
+    const int len = phase == 0 ? W : H, per = 2 * len;
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (long long)N * per) return;
+    const int n = (int)(gid / per), i = (int)(gid - (long long)n * per);
+    const int side = phase * 2 + (i >= len ? 1 : 0), pos = i >= len ? i - len : i;
+    const bool rows = phase == 0;
+    const int L = rows ? OW : OH;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    auto add = [&](int oy, int ox, int tap) {                 // += D[.][tap][c] . dh1(oy, ox)
+        const bf16x8* g = dh1 + (((size_t)n * OH + oy) * OW + ox) * 8;
+        for (int u = 0; u < 8; ++u) {
+            const bf16x8 gv = g[u];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float gk = (float)gv[k];
+                const float* dd = D + ((size_t)(u * 8 + k) * 28 + tap) * 8;
+                s0 += gk * dd[0]; s1 += gk * dd[1]; s2 += gk * dd[2];
+            }
+        }
+    };
+    // image line position pos is read by border output pixel q through tap t with 2 q - 2 + t == pos
+    for (int t = (pos & 1); t < 6; t += 2) {
+        const int q = (pos + 2 - t) >> 1;
+        if (q < 0 || q >= L) continue;
+        add(rows ? (side == 0 ? 0 : OH - 1) : q, rows ? q : (side == 2 ? 0 : OW - 1), side * 6 + t);
+    }
+    if (rows && (pos == 0 || pos == W - 1))                   // corner taps 24..27 read image pixels (0,0), (0,W-1), (H-1,0), (H-1,W-1)
+        add(side == 0 ? 0 : OH - 1, pos == 0 ? 0 : OW - 1, 24 + side * 2 + (pos == 0 ? 0 : 1));
+    const int y = rows ? (side == 0 ? 0 : H - 1) : pos, x = rows ? pos : (side == 2 ? 0 : W - 1);
+    bf16x8* p = dimg + ((size_t)n * H + y) * W + x;
+    bf16x8 o = *p;
+    o[0] = (xmc_h16)((float)o[0] + s0); o[1] = (xmc_h16)((float)o[1] + s1); o[2] = (xmc_h16)((float)o[2] + s2);
+    *p = o;
+}
+
 // ---- the border of h1 ------------------------------------------------------------------------------------------------------------
 // conv_r[0] pads conv_img's output with zeros; the composed convolution instead sees conv_img evaluated one pixel outside the image.
 // For an output pixel in the first row that surplus is  sum_kw W_0[kh = 0, kw] . conv_img(row -1)  and conv_img(row -1) reads image
@@ -711,6 +860,26 @@ extern "C" int xmc_dstem_border_wgrad(const void* img, const void* dh1, float* d
     XMC_ALLOW_BIG_LDS(dstem_border_wgrad_kernel);
     hipLaunchKernelGGL(dstem_border_wgrad_kernel, dim3(N, 4), dim3(256), lds, reinterpret_cast<hipStream_t>(stream),
                        reinterpret_cast<const u32x4*>(img), reinterpret_cast<const bf16x8*>(dh1), dD, dDB, N, H, W);
+    XMC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int xmc_dstem_dgrad(const void* dh1, const void* dsc, const float* wsets, const float* D, void* frag_scratch, void* dimg, int N, int H,
+                               int W, void* stream) {
+    if (!dh1 || !dsc || !wsets || !D || !frag_scratch || !dimg || N < 1) return XMC_EINVAL;
+    if (H < 16 || W < 64 || H % 16 != 0 || W % 64 != 0) return XMC_ESHAPE;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(dstem_pack_t_kernel, dim3(9), dim3(256), 0, st, wsets, reinterpret_cast<bf16x8*>(frag_scratch));
+    const int ntiles = N * (H / 2 / DG_H) * (W / 2 / DG_W);
+    const int grid = ntiles < 512 ? ntiles : 512;
+    hipLaunchKernelGGL(dstem_dgrad_kernel, dim3(grid), dim3(256), 0, st, reinterpret_cast<const u32x4*>(dh1), reinterpret_cast<const u32x4*>(dsc),
+                       reinterpret_cast<const u32x4*>(frag_scratch), reinterpret_cast<bf16x8*>(dimg), N, H, W, ntiles);
+    xmc_note_kernel("dstem_dgrad_kernel");
+    for (int phase = 0; phase < 2; ++phase) {
+        const long long n = (long long)N * 2 * (phase == 0 ? W : H);
+        hipLaunchKernelGGL(dstem_border_dgrad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const bf16x8*>(dh1), D,
+                           reinterpret_cast<bf16x8*>(dimg), N, H, W, phase);
+    }
     XMC_LAUNCH_CHECK();
     return 0;
 }

@@ -132,6 +132,7 @@ _SIGS = {
     "xmc_dstem_wgrad": [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "xmc_dstem_border_fwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp],
     "xmc_dstem_border_wgrad": [vp, vp, vp, vp, i32, i32, i32, vp],
+    "xmc_dstem_dgrad": [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
 }
 _RESTYPE = {"xmc_contrastive_ws_bytes": i64, "xmc_attn_pool_ws_floats": i64, "xmc_last_kernel": C.c_char_p}
 EXPORTS = tuple(_SIGS)

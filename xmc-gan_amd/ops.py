@@ -844,6 +844,19 @@ def _dstem_border_fwd_raw(xin, wsets, bias, D, DB, h1, slope=0.2):
     L.call("xmc_dstem_border_fwd", _p(xin), _p(wsets), _p(bias), _p(D), _p(DB), _p(wt), _p(h1), N, H, W, float(slope), _st())
 
 
+def _dstem_dgrad_raw(dh1, dsc, wsets, D, H, W):
+    """gradient of the image [N,H,W,8] from (d h1 in front of its LeakyReLU, d shortcut): the adjoint of the composed stem"""
+    _need_cuda(dh1, dsc)
+    N = dh1.shape[0]
+    dh1, dsc = dh1.contiguous(), dsc.contiguous()
+    frag = torch.empty(36 * 1024, dtype=torch.uint8, device=dh1.device)
+    dimg = torch.empty((N, H, W, 8), dtype=dh1.dtype, device=dh1.device)
+    with prof.launch("igemm_kernel (conv fwd+dgrad, MFMA implicit GEMM)", 2.0 * N * (H // 2) * (W // 2) * 64 * (3 * 36 + 3 * 16),
+                     f"dstem-dgrad {dh1.dtype} N{N} {H}x{W} 64+64->3 k6s2", _nbytes(dh1, dsc, dimg)):
+        L.call("xmc_dstem_dgrad", _p(dh1), _p(dsc), _p(wsets), _p(D), _p(frag), _p(dimg), N, H, W, _st())
+    return dimg
+
+
 def _dstem_wgrad_raw(xin, dh1, dsc, skip_border=False, border=True):
     """gradients of the composed weights / biases and (``border``) of the border corrections:
     (dW f32 [128,36,8], dbias f32 [128], dD f32 [64,28,8], dDB f32 [64,8])"""
@@ -1684,7 +1697,7 @@ class DStemBlockFn(torch.autograd.Function):
     through autograd on the composition.
     The rest of the block is ResDFn's: conv_r[2] + LeakyReLU + block sum (+ sign bits, + pooled output) in one launch, its data
     gradient with the LeakyReLU' mask of h1 and d(gamma) in the epilogue.  The gradient of the image, where asked for (the G step's
-    pass over the generated batch), comes from the un-composed transposed chain, which needs no stored activation."""
+    pass over the generated batch), is the adjoint of the composed stem: one launch on the low-resolution gradients."""
 
     @staticmethod
     def forward(ctx, xin, w_img, b_img, w0, w2, ws, bs, gamma, g_img, g0, g2, gs, want_pool=False):
@@ -1706,7 +1719,7 @@ class DStemBlockFn(torch.autograd.Function):
         outp = r[-1] if pool_ok else None
         ctx.geoms = (g_img, g0, g2, gs)
         ctx.has_bs = bs is not None
-        ctx.save_for_backward(xin, h1, bits, w_img, b_img, w0, w2, ws, bs, gamma)
+        ctx.save_for_backward(xin, h1, bits, w_img, b_img, w0, w2, ws, bs, gamma, wsets, D)
         if want_pool:
             if outp is None:
                 outp = torch.empty((N, out.shape[1] // 2, out.shape[2] // 2, out.shape[3]), dtype=dt, device=xin.device)
@@ -1722,7 +1735,7 @@ class DStemBlockFn(torch.autograd.Function):
         nin = 13
         if dout is None:
             return (None,) * nin
-        xin, h1, bits, w_img, b_img, w0, w2, ws, bs, gamma = ctx.saved_tensors
+        xin, h1, bits, w_img, b_img, w0, w2, ws, bs, gamma, wsets, D = ctx.saved_tensors
         g_img, g0, g2, gs = ctx.geoms
         dt = xin.dtype
         N, H, W, _ = xin.shape
@@ -1735,24 +1748,21 @@ class DStemBlockFn(torch.autograd.Function):
         dgam = _zeros_f32_out(1, xin.device)
         # residual branch, as ResDBwdFn on sign bits: gr = s * dout, d(gamma) from the data gradient's epilogue
         need_x = ctx.needs_input_grad[0]
-        gr = dxp = None
-        if need_x and "no_pw1x1_masked_src" not in _DEBUG_DISPATCH:      # the shortcut's data gradient streams dout anyway: gr is its by-product
-            dxp, gr = _conv_dgrad_raw(dout, ws, gs, (OH, OW), dt, src_bits=bits)
-        if gr is None:
-            gr = torch.empty_like(dout)
-            L.call("xmc_signmask_apply", _p(dout), _p(bits), _p(gr), dout.numel(), 0.2, _code(dt), _st())
+        gr = torch.empty_like(dout)
+        L.call("xmc_signmask_apply", _p(dout), _p(bits), _p(gr), dout.numel(), 0.2, _code(dt), _st())
         dw2 = _conv_wgrad_raw(h1, gr, g2, scale=al).view(w2.shape) if (ctx.needs_input_grad[4] and not skip_w) else None
         gh = _conv_dgrad_raw(gr, w2, g2, (OH, OW), dt, mask=h1, alpha=al, dot=dgam)          # d h1 in front of its LeakyReLU
         dgamma = dgam.reshape(gamma.shape).to(gamma.dtype) if ctx.needs_input_grad[7] else None
         dx = None
         if need_x:
-            # The gradient of the IMAGE (the G step's pass over the generated batch) takes the un-composed chain -- conv_r[0]^T with the
-            # pooled shortcut gradient as its row-indexed residual, then conv_img^T -- which needs weights and gradients only, none of
-            # the activations the composed forward did not write.
-            if dxp is None:
+            # the gradient of the IMAGE (the G step's pass over the generated batch): the adjoint of the composed stem, one launch
+            # on the low-resolution gradients (+ the border corrections); "dstem_old_dgrad": the un-composed transposed chain
+            if "dstem_old_dgrad" in _DEBUG_DISPATCH:
                 dxp = _conv_dgrad_raw(dout, ws, gs, (OH, OW), dt)
-            dci = _conv_dgrad_raw(gh, w0, g0, (H, W), dt, res=dxp, res_rows=True, res_scale=0.25)
-            dx = _conv_dgrad_raw(dci, w_img, g_img, (H, W), dt)
+                dci = _conv_dgrad_raw(gh, w0, g0, (H, W), dt, res=dxp, res_rows=True, res_scale=0.25)
+                dx = _conv_dgrad_raw(dci, w_img, g_img, (H, W), dt)
+            else:
+                dx = _dstem_dgrad_raw(gh, dout, wsets, D, H, W)
         if skip_w or not any(ctx.needs_input_grad[1:7]):
             return (dx, None, None, None, dw2, None, None, dgamma) + (None,) * 5
         # gradients of the composed weights (every pixel) and of the border corrections (border pixels of h1), then back through the
