@@ -32,8 +32,9 @@ extern "C" {
  * 4: XmcConvDesc.sign_bits / dot (a discriminator block keeps sign bits; d(gamma) from a data-gradient epilogue).
  * 5: xmc_conv_pw1x1_masked_src (the sign-mask pass as a by-product of the shortcut's data gradient).
  * 6: xmc_adam_step_scaled (dynamic loss scale with a found-inf skip); xmc_gp_finish gained inv_s2.
- * 7: xmc_dstem_* (the discriminator's stem composed into one convolution from the image). */
-#define XMC_ABI_VERSION 7
+ * 7: xmc_dstem_* (the discriminator's stem composed into one convolution from the image).
+ * 8: XmcConvDesc.mask_bits, xmc_conv_ptile_bits / xmc_conv_wgrad_bits (the sign mask applied in the consumers' staging). */
+#define XMC_ABI_VERSION 8
 
 /* XMC_BF16 names the 16-bit storage / MFMA-operand format THIS BUILD of the library was compiled for: bf16 in
  * libxmc_gan_hip.so, IEEE half in libxmc_gan_hip_f16.so (same sources, same entry points; xmc_half_format()). */
@@ -119,6 +120,11 @@ typedef struct XmcConvDesc {
      *             that is <dout, branch> = d(gamma) of `shortcut + gamma * branch` (df_gan.py:284) without the branch tensor. */
     void* sign_bits;
     float* dot;
+    /* mask_bits (ABI 8; honoured by xmc_conv_ptile_bits / xmc_conv_wgrad_bits ONLY -- every other entry rejects a descriptor that sets
+     *             it): sign bytes (layout of sign_bits) of the gradient operand -- `src` of a data gradient, `dst` (dy) of a weight
+     *             gradient.  The kernel reads operand x LeakyReLU'(bits) (1 or 0.2, rounded to the 16-bit format as
+     *             xmc_signmask_apply would store it) while it stages the operand: the masked tensor is never written. */
+    const void* mask_bits;
 } XmcConvDesc;
 
 int xmc_abi_version(void);
@@ -203,6 +209,11 @@ int xmc_signmask_apply(const void* dy, const void* bits, void* dx, int64_t n, fl
  * XmcConvDesc.sign_bits layout of the source tensor -- the backward of a block reads `dout` once for both.  Returns 1 (nothing
  * launched) when the shape is not one the streaming kernels take; the caller then uses xmc_conv_igemm + xmc_signmask_apply.  (ABI 5) */
 int xmc_conv_pw1x1_masked_src(const XmcConvDesc* d, const void* src_bits, void* src_masked, float slope, void* stream);
+/* The same masked operand WITHOUT writing it: the data gradient (weights-resident kernel, Cin / Cout <= 64, unit stride) and the 3x3
+ * weight gradient (row-reuse kernel, W % 32 == 0, H % 8 == 0) apply d->mask_bits while they stage the gradient operand.  Return 1
+ * when the shape is not theirs (the caller then runs xmc_signmask_apply and the plain entry), 0 on success, < 0 on error. */
+int xmc_conv_ptile_bits(const XmcConvDesc* d, void* stream);
+int xmc_conv_wgrad_bits(const XmcConvDesc* d, float* dwp, void* stream);
 int xmc_tanh_bwd(const void* dy, const void* y, void* dx, int64_t n, int dtype, void* stream);
 /* y = a + (*alpha_dev) * b                  (shortcut + gamma*residual, df_gan.py:200,284) */
 int xmc_axpby(const void* a, const void* b, const float* alpha_dev, void* y, int64_t n, int dtype, void* stream);

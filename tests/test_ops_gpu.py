@@ -679,6 +679,42 @@ def test_shortcut_data_gradient_writes_the_masked_gradient_as_a_by_product(N, H,
     assert torch.equal(dx, dx_ref)
 
 
+@pytest.mark.parametrize("mode", ["bf16", "f16"])
+@pytest.mark.parametrize("N,H,W,cin,cout,fused", [(3, 32, 64, 64, 64, True), (2, 128, 128, 64, 64, True), (5, 16, 32, 32, 64, True),
+                                                  (2, 16, 16, 128, 128, False), (2, 24, 24, 64, 64, False)])
+def test_sign_mask_applied_while_the_gradient_is_staged(N, H, W, cin, cout, fused, mode):
+    """XmcConvDesc.mask_bits (xmc_conv_ptile_bits / xmc_conv_wgrad_bits, include/xmc_gan_hip.h): the consumers of a block's masked
+    gradient read dout and its sign bytes and never see the masked tensor in memory.  The data gradient (with the epilogue options
+    the block uses) must equal the two-launch form bit for bit; the weight gradient sums the same products in the same kernel, so
+    only the order of its final atomics differs (rel L2 <= 1e-6).  Shapes the staging kernels decline (`fused` False) take the mask
+    pass once, shared by both consumers."""
+    ops.set_precision(mode)
+    dt = ops.act_dtype()
+    g = torch.Generator().manual_seed(N * 7 + H + cin)
+    dout = torch.randn(N, H, W, cout, generator=g).to(DEV).to(dt)
+    bits = torch.randint(0, 256, (N, H, W, cout // 8), generator=g, dtype=torch.int64).to(torch.uint8).to(DEV)
+    h1 = torch.randn(N, H, W, cin, generator=g).to(DEV).to(dt)
+    w2 = (torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(9 * cin)).to(DEV)
+    g2 = ops.ConvGeom(cin, cout, 3, 1, 1)
+    al = torch.tensor([0.41], device=DEV)
+    gr = torch.empty_like(dout)
+    L.call("xmc_signmask_apply", dout.data_ptr(), bits.data_ptr(), gr.data_ptr(), dout.numel(), 0.2, ops._code(dt), ops._st())
+    dot_ref, dot_got = torch.zeros(1, device=DEV), torch.zeros(1, device=DEV)
+    dx_ref = ops._conv_dgrad_raw(gr, w2, g2, (H, W), dt, mask=h1, alpha=al, dot=dot_ref)
+    dw_ref = ops._conv_wgrad_raw(h1, gr, g2, scale=al)
+    st = ops._StagedMask(dout, bits)
+    dx = ops._conv_dgrad_raw(st, w2, g2, (H, W), dt, mask=h1, alpha=al, dot=dot_got)
+    kd = L.load().xmc_last_kernel().decode()
+    dw = ops._conv_wgrad_raw(h1, st, g2, scale=al)
+    kw = L.load().xmc_last_kernel().decode()
+    print(kd, "/", kw)
+    assert (st._full is None) == fused, (kd, kw)
+    assert torch.equal(dx, dx_ref)
+    assert abs(dot_got.item() - dot_ref.item()) <= 1e-5 * abs(dot_ref.item()) + 1e-4
+    assert rel_l2(dw, dw_ref) <= 1e-6
+    ops.set_precision("bf16")
+
+
 def test_fused_discriminator_block_refuses_second_derivative_without_the_branch():
     """A block that kept only sign bits cannot be differentiated twice: it says so instead of returning a wrong penalty."""
     from xmc_gan.model.df_gan import resD

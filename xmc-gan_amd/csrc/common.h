@@ -76,6 +76,17 @@ __device__ __forceinline__ float tanh_fast(float v) {
     return 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
 }
 __device__ __forceinline__ float lrelu_slope(float ref) { return ref > 0.f ? 1.f : XMC_LRELU; }
+// one 16-byte unit (8 channels) x LeakyReLU' from its sign byte (bit k set: channel k positive), rounded back to the 16-bit format:
+// what xmc_signmask_apply stores, computed where the unit is staged (XmcConvDesc.mask_bits)
+__device__ __forceinline__ u32x4 xmc_apply_sign_bits(u32x4 v, unsigned b) {
+    bf16x8 h = __builtin_bit_cast(bf16x8, v);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float f = (float)h[k];
+        h[k] = (xmc_h16)(((b >> k) & 1u) ? f : XMC_LRELU * f);
+    }
+    return __builtin_bit_cast(u32x4, h);
+}
 
 // 8 consecutive channels <-> 8 floats, for either storage type
 template <int DT> struct Vec8;

@@ -317,6 +317,8 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
             halo[it] = !in ? 0u : ((py < -dh0 ? 1u : 0u) | (py >= t.TH * SA - dh0 ? 2u : 0u) | (px < -dw0 ? 4u : 0u) | (px >= t.TW * SA - dw0 ? 8u : 0u));
         }
         u32x4 pv[PIT];
+        unsigned char pb8[PIT];                   // sign bytes of the staged units (XmcConvDesc.mask_bits: the source is a masked gradient)
+        const unsigned char* __restrict__ bits8 = reinterpret_cast<const unsigned char*>(d.mask_bits);
         unsigned okmask = 0;
         auto issue = [&](int tile) {
             const int img = tile / tpi, trem = tile - img * tpi;
@@ -331,6 +333,7 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
             for (int it = 0; it < PIT; ++it) {
                 const bool ok = (halo[it] & border) == 0;
                 pv[it] = src16[(unsigned)(base + (ok ? psrc[it] : 0))];
+                if (bits8) pb8[it] = bits8[(unsigned)(base + (ok ? psrc[it] : 0))];
                 okmask |= ok ? (1u << it) : 0u;
             }
             okmask &= inpatch;
@@ -346,6 +349,7 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
                     lp = (py * 2 + (px & 1)) * (PW >> 1) + (px >> 1);
                 }
                 u32x4 v = pv[it];
+                if (bits8) v = xmc_apply_sign_bits(v, pb8[it]);
                 if (!all_ok && !((okmask >> it) & 1)) v = u32x4{0, 0, 0, 0};       // padding (border tiles only)
                 if ((inpatch >> it) & 1) *reinterpret_cast<u32x4*>(patch + lp * pstride + pchunk * 16) = v;
             }
@@ -1081,6 +1085,19 @@ static int tile_plan(const XmcConvDesc* d, TileCfg* t) {
 int xmc_conv_ptile_pool_try(const XmcConvDesc* d, void* stream) {
     TileCfg t;
     if (!d->dst_pool || d->out_dtype != XMC_BF16 || d->SA != 1 || d->DA != 1 || d->nclass != 1 || (d->DH & 1) || (d->DW & 1)) return 1;
+    if (!tile_plan(d, &t)) return 1;
+    if (!(d->CS <= 64 && t.slab == d->CS && d->CDw <= 64) || xmc_debug_off("no_ptile")) return 1;
+    const int rc = d->CDw == 64 ? launch_ptile<64>(*d, t, reinterpret_cast<hipStream_t>(stream))
+                                : launch_ptile<32>(*d, t, reinterpret_cast<hipStream_t>(stream));
+    return rc == XMC_ESHAPE ? 1 : rc;
+}
+
+// data gradient whose source is masked by sign bytes while it is staged (XmcConvDesc.mask_bits): the persistent kernel only
+extern "C" int xmc_conv_ptile_bits(const XmcConvDesc* d, void* stream) {
+    if (!d || !d->src || !d->wpk || !d->dst || !d->mask_bits) return XMC_EINVAL;
+    static const bool off = xmc_debug_off("no_stage_bits");
+    if (off || d->dtype != XMC_BF16 || d->SA != 1 || d->DA != 1 || d->nclass != 1 || d->src_shift != 0 || d->dst_pool) return 1;
+    TileCfg t;
     if (!tile_plan(d, &t)) return 1;
     if (!(d->CS <= 64 && t.slab == d->CS && d->CDw <= 64) || xmc_debug_off("no_ptile")) return 1;
     const int rc = d->CDw == 64 ? launch_ptile<64>(*d, t, reinterpret_cast<hipStream_t>(stream))

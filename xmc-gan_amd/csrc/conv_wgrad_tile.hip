@@ -414,14 +414,20 @@ __global__ __launch_bounds__(512) void wgrad_tile_rr_kernel(const XmcConvDesc d,
         xhalo |= hb << (4 * it);
     }
     u32x4 yv[YIT], xv[XIT];
+    unsigned char yb8[YIT];                                   // sign bytes of the dy units (XmcConvDesc.mask_bits: dy is a masked gradient)
+    const unsigned char* __restrict__ bits8 = reinterpret_cast<const unsigned char*>(d.mask_bits);
     unsigned xzero = 0;
     auto prefetch = [&](int tile) {
         const int img = __builtin_amdgcn_readfirstlane(tile / tpi), trem = tile - img * tpi;
         const int ty = __builtin_amdgcn_readfirstlane(trem / t.tiles_x), tx = trem - ty * t.tiles_x;
         const int a0 = ty * TH, b0 = tx * TW;
-        const u32x4* __restrict__ yb = y16 + (((size_t)img * d.MH + a0) * d.MW + b0) * cd_units;
+        const size_t ybase = (((size_t)img * d.MH + a0) * d.MW + b0) * cd_units;
+        const u32x4* __restrict__ yb = y16 + ybase;
 #pragma unroll
-        for (int it = 0; it < YIT; ++it) yv[it] = yb[yoff0 + it * ystep];
+        for (int it = 0; it < YIT; ++it) {
+            yv[it] = yb[yoff0 + it * ystep];
+            if (bits8) yb8[it] = bits8[ybase + yoff0 + it * ystep];
+        }
         const unsigned border = (ty == 0 ? 1u : 0u) | (ty == t.tiles_y - 1 ? 2u : 0u) | (tx == 0 ? 4u : 0u) | (tx == t.tiles_x - 1 ? 8u : 0u);
         const long long xbase = (((long long)img * d.SH + ((a0 >> sh) + row0)) * d.SW + ((b0 >> sh) + col0)) * cs_units;
         const u32x4* __restrict__ xb = x16 + xbase;
@@ -456,6 +462,7 @@ __global__ __launch_bounds__(512) void wgrad_tile_rr_kernel(const XmcConvDesc d,
 #pragma unroll
         for (int it = 0; it < YIT; ++it) {
             u32x4 v = yv[it];
+            if (bits8) { v = xmc_apply_sign_bits(v, yb8[it]); yv[it] = v; }
             if (!yok) v = u32x4{0, 0, 0, 0};
             *reinterpret_cast<u32x4*>(ydy + ((tid + it * NT) / YCH) * YS + ych * 16) = v;
         }
@@ -585,8 +592,20 @@ int launch_wt(const XmcConvDesc& d, float* dwp, float* dbias, const WTCfg& t, hi
 
 }  // namespace
 
+static int wgrad_tile_go(const XmcConvDesc* d, float* dwp, float* dbias, void* stream, bool rr_only);
+
 // 0 = launched, 1 = not eligible (caller falls back to the generic kernel), other = error
-int xmc_conv_wgrad_tile_try(const XmcConvDesc* d, float* dwp, float* dbias, void* stream) {
+int xmc_conv_wgrad_tile_try(const XmcConvDesc* d, float* dwp, float* dbias, void* stream) { return wgrad_tile_go(d, dwp, dbias, stream, false); }
+
+// weight gradient whose dy operand is masked by sign bytes while it is staged (XmcConvDesc.mask_bits): the row-reuse kernel only
+extern "C" int xmc_conv_wgrad_bits(const XmcConvDesc* d, float* dwp, void* stream) {
+    if (!d || !d->src || !d->dst || !dwp || !d->mask_bits) return XMC_EINVAL;
+    static const bool off = xmc_debug_off("no_stage_bits");
+    if (off || d->src_shift != 0 || d->SA != 1) return 1;
+    return wgrad_tile_go(d, dwp, nullptr, stream, true);
+}
+
+static int wgrad_tile_go(const XmcConvDesc* d, float* dwp, float* dbias, void* stream, bool rr_only) {
     static const bool off = xmc_debug_off("no_wtile");
     if (off) return 1;
     if (d->dtype != XMC_BF16 || d->src_shift < 0 || d->src_shift > 1) return 1;
@@ -617,6 +636,7 @@ int xmc_conv_wgrad_tile_try(const XmcConvDesc* d, float* dwp, float* dbias, void
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int nco = d->CD <= 16 ? 1 : (d->CD <= 32 ? 2 : 4);
     const int nci = d->CS <= 16 ? 1 : (d->CS <= 32 ? 2 : 4);
+    if (rr_only && (s2 || t16)) return 1;
     if (s2) {
         if (nco == 4 && nci == 2) return launch_wt<4, 2, 512, 2, 16, 4>(*d, dwp, dbias, t, st);
         if (nco == 2 && nci == 1) return launch_wt<2, 1, 256, 2, 16, 2>(*d, dwp, dbias, t, st);
@@ -635,6 +655,7 @@ int xmc_conv_wgrad_tile_try(const XmcConvDesc* d, float* dwp, float* dbias, void
         if (nco == 2 && nci == 4) return launch_wt_rr<2, 4, 2>(*d, dwp, dbias, t, st);
         if (nco == 4 && nci == 2) return launch_wt_rr<4, 2, 4>(*d, dwp, dbias, t, st);
     }
+    if (rr_only) return 1;
 #define WT_CASE(a, b) if (nco == a && nci == b) return launch_wt<a, b, 256, 1, 9, (a >= 2 ? 2 : 1)>(*d, dwp, dbias, t, st);
     // (4,4) = 64x64 channels with 4 waves needs 144 accumulator + 76 staging registers per lane and measured slower than
     // the split-K kernel (166 vs 230 TF/s); it runs with 8 waves instead (below)

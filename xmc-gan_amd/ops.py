@@ -525,12 +525,31 @@ def _conv_fwd_raw(x, w, bias, geom, act, out_dtype, res=None, alpha=None, up=Fal
     return y if len(outs) == 1 else tuple(outs)
 
 
+class _StagedMask:
+    """A gradient that is read as ``dy x LeakyReLU'(bits)`` (bits: sign bytes in dy's layout) by kernels that apply the mask while
+    they stage the operand (XmcConvDesc.mask_bits: xmc_conv_ptile_bits, xmc_conv_wgrad_bits).  A consumer whose shape those kernels
+    do not take asks for ``materialised()``: one mask pass (xmc_signmask_apply), shared by the consumers of this object."""
+
+    def __init__(self, dy, bits):
+        assert bits.dtype == torch.uint8 and bits.numel() * 8 == dy.numel() and dy.is_contiguous()
+        self.dy, self.bits, self._full = dy, bits, None
+
+    def materialised(self):
+        if self._full is None:
+            self._full = torch.empty_like(self.dy)
+            L.call("xmc_signmask_apply", _p(self.dy), _p(self.bits), _p(self._full), self.dy.numel(), 0.2, _code(self.dy.dtype), _st())
+        return self._full
+
+
 def _conv_dgrad_raw(dy, w, geom, in_hw, in_dtype, mask=None, res=None, res_rows=False, res_scale=1.0, alpha=None, want_sumpool=False,
                     dot=None, src_bits=None):
     """dx [N,H,W,cin_p] from dy [N,OH,OW,cout_p].  Epilogue options: ``mask`` (dx layout): dx *= LeakyReLU'(mask);
     ``res``: dx += res_scale * res, with ``res_rows`` the residual is [N,H/s,W/s,cin_p] and every pixel of it is added to its
     s x s block of dx (s == 2: the adjoint of avg_pool2d, df_gan.py:290).  ``want_sumpool`` (stride 1): returns (dx, 2x2 sum pool
     of dx) -- the adjoint of a nearest x2 upsample, the gradient of a generator block's half-resolution shortcut."""
+    staged = dy if isinstance(dy, _StagedMask) else None        # dy x LeakyReLU'(bits), masked where the kernel stages it
+    if staged is not None:
+        dy = staged.dy
     _need_cuda(dy, w)
     N, OH, OW, CDy = dy.shape
     H, W = in_hw
@@ -594,6 +613,16 @@ def _conv_dgrad_raw(dy, w, geom, in_hw, in_dtype, mask=None, res=None, res_rows=
             else:
                 L.check(rc, "xmc_conv_pw1x1_masked_src")
         return dx, dym
+    if staged is not None:
+        d.mask_bits = staged.bits.data_ptr()
+        with prof.launch("igemm_kernel (conv fwd+dgrad, MFMA implicit GEMM)", 2.0 * N * OH * OW * geom.cout * geom.cin * geom.k * geom.k,
+                         f"dgrad+bits {dy.dtype} N{N} {H}x{W} {geom.cin}->{geom.cout} k{geom.k}s{geom.s}", _nbytes(dy, wpk, dx, mask, res, dxp)):
+            rc = L.load().xmc_conv_ptile_bits(C.byref(d), _st())
+        if rc == 0:
+            return (dx, dxp) if want_sumpool else dx
+        if rc != 1:
+            L.check(rc, "xmc_conv_ptile_bits")
+        d.mask_bits, d.src = None, staged.materialised().data_ptr()
     with prof.launch("igemm_kernel (conv fwd+dgrad, MFMA implicit GEMM)", 2.0 * N * OH * OW * geom.cout * geom.cin * geom.k * geom.k,
                      f"dgrad {dy.dtype} N{N} {H}x{W} {geom.cin}->{geom.cout} k{geom.k}s{geom.s}", _nbytes(dy, wpk, dx, mask, res, dxp)):
         L.check(L.load().xmc_conv_igemm(C.byref(d), _st()), "xmc_conv_igemm(dgrad)")
@@ -730,6 +759,9 @@ def _pooled_take(dz):
 def _conv_wgrad_raw(x, dy, geom, scale=None, up=False, want_bias=False, bias_dot=None, dot=None):
     """gw [Co,Ci,k,k] f32 from x [N,H,W,cs_p], dy [N,OH,OW,cd_p] (and the bias gradient [cd_p] f32 from the same launch).
     ``bias_dot`` (f32 [>= cout]) / ``dot`` (f32 [1]): dot += <bias_dot, unscaled bias gradient> (xmc_unpack_wgrad_bias_dot)."""
+    staged = dy if isinstance(dy, _StagedMask) else None        # dy x LeakyReLU'(bits), masked where the kernel stages it
+    if staged is not None:
+        dy = staged.dy
     _need_cuda(x, dy)
     N, H, W, CS = x.shape
     _, OH, OW, CDy = dy.shape
@@ -746,9 +778,21 @@ def _conv_wgrad_raw(x, dy, geom, scale=None, up=False, want_bias=False, bias_dot
     d.dtype, d.out_dtype = _code(x.dtype), L.F32
     d.groups = geom.groups
     _fill_taps(d, 0, [(kh - geom.p, kw - geom.p, kh * geom.k + kw) for kh in range(geom.k) for kw in range(geom.k)])
-    with prof.launch("wgrad_kernel (conv weight gradient, MFMA + split-K atomics)", 2.0 * N * OH * OW * geom.cout * geom.cin * geom.k * geom.k,
-                     f"wgrad {x.dtype} N{N} {H}x{W} {geom.cin}->{geom.cout} k{geom.k}s{geom.s}", _nbytes(x, dy, dwp)):
-        L.check(L.load().xmc_conv_wgrad_bias(C.byref(d), _p(dwp), _p(gb), _st()), "xmc_conv_wgrad")
+    rc = 1
+    if staged is not None and not want_bias:
+        d.mask_bits = staged.bits.data_ptr()
+        with prof.launch("wgrad_kernel (conv weight gradient, MFMA + split-K atomics)", 2.0 * N * OH * OW * geom.cout * geom.cin * geom.k * geom.k,
+                         f"wgrad+bits {x.dtype} N{N} {H}x{W} {geom.cin}->{geom.cout} k{geom.k}s{geom.s}", _nbytes(x, dy, dwp)):
+            rc = L.load().xmc_conv_wgrad_bits(C.byref(d), _p(dwp), _st())
+        if rc not in (0, 1):
+            L.check(rc, "xmc_conv_wgrad_bits")
+        d.mask_bits = None
+    if rc == 1:
+        if staged is not None:
+            d.dst = staged.materialised().data_ptr()
+        with prof.launch("wgrad_kernel (conv weight gradient, MFMA + split-K atomics)", 2.0 * N * OH * OW * geom.cout * geom.cin * geom.k * geom.k,
+                         f"wgrad {x.dtype} N{N} {H}x{W} {geom.cin}->{geom.cout} k{geom.k}s{geom.s}", _nbytes(x, dy, dwp)):
+            L.check(L.load().xmc_conv_wgrad_bias(C.byref(d), _p(dwp), _p(gb), _st()), "xmc_conv_wgrad")
     gw = torch.empty((geom.cout, geom.cin // geom.groups, geom.k, geom.k), dtype=torch.float32, device=x.device)
     if want_bias:
         assert geom.groups == 1
@@ -1748,8 +1792,8 @@ class DStemBlockFn(torch.autograd.Function):
         dgam = _zeros_f32_out(1, xin.device)
         # residual branch, as ResDBwdFn on sign bits: gr = s * dout, d(gamma) from the data gradient's epilogue
         need_x = ctx.needs_input_grad[0]
-        gr = torch.empty_like(dout)
-        L.call("xmc_signmask_apply", _p(dout), _p(bits), _p(gr), dout.numel(), 0.2, _code(dt), _st())
+        # (gr is never written: both of its consumers apply the sign bytes while they stage dout -- _StagedMask)
+        gr = _StagedMask(dout, bits)
         dw2 = _conv_wgrad_raw(h1, gr, g2, scale=al).view(w2.shape) if (ctx.needs_input_grad[4] and not skip_w) else None
         gh = _conv_dgrad_raw(gr, w2, g2, (OH, OW), dt, mask=h1, alpha=al, dot=dgam)          # d h1 in front of its LeakyReLU
         dgamma = dgam.reshape(gamma.shape).to(gamma.dtype) if ctx.needs_input_grad[7] else None
