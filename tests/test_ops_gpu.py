@@ -75,7 +75,8 @@ CONV_CASES = [
     (64, 3, 3, 1, 1, 32, 3),       # its mirror: the dgrad has the 8-channel source
     # 256x128 tiles of the gather kernel: Cout % 128 == 0 and >= 65536 output pixels
     (128, 128, 3, 1, 1, 72, 13),   # M = 67392: last 256-row tile is partial
-    (64, 128, 4, 2, 1, 128, 16),   # stride-2 forward; its dgrad = 4 parity classes
+    (64, 128, 4, 2, 1, 128, 16),   # stride-2 forward; its dgrad = 4 parity classes (128 -> 64: a class's weights resident, ptile3 slab 128)
+    (64, 128, 4, 2, 1, 64, 3),     # ... one tile column per class grid row: every tile touches the left and the right border
     (32, 256, 1, 1, 0, 64, 16),    # 1x1: a single K step
     # 256x256 tiles (8 waves) of the gather kernel: Cout % 256 == 0 and >= 65536 output pixels
     (128, 256, 4, 2, 1, 64, 72),   # stride-2 forward, M = 73728: partial last tile; dgrad: 4 classes with Cout 128

@@ -343,6 +343,7 @@ int xmc_conv_pw1x1_try(const XmcConvDesc* d, void* stream);                     
 int xmc_conv_wtile_try(const XmcConvDesc* d, void* stream);                           // conv_wtile.hip
 int xmc_conv_wtile3_try(const XmcConvDesc* d, void* stream);                          // conv_wtile3.hip
 int xmc_conv_ptile_pool_try(const XmcConvDesc* d, void* stream);                      // conv_tile.hip
+int xmc_conv_ptile_slab128_try(const XmcConvDesc* d, void* stream);                   // conv_tile.hip
 int xmc_conv_group_try(const XmcConvDesc* d, void* stream);                           // conv_group.hip
 int xmc_conv_thin_out_try(const XmcConvDesc* d, void* stream);                        // conv_thin.hip
 
@@ -383,6 +384,7 @@ extern "C" int xmc_conv_igemm(const XmcConvDesc* d, void* stream) {
         if (rc > 0) rc = xmc_conv_thin_try(&dd, stream);
         if (rc > 0) rc = xmc_conv_thin_out_try(&dd, stream);
         if (rc > 0) rc = xmc_conv_pw1x1_try(&dd, stream);
+        if (rc > 0) rc = xmc_conv_ptile_slab128_try(&dd, stream);
         if (rc > 0 && !no_wt3) rc = xmc_conv_wtile3_try(&dd, stream);
         if (rc > 0 && !no_wt2) rc = xmc_conv_wtile_try(&dd, stream);
         if (rc > 0) rc = xmc_conv_tile_try(&dd, stream);

@@ -932,6 +932,25 @@ int launch_ptile(const XmcConvDesc& d, const TileCfg& t, hipStream_t st) {
     if (gx < 1) gx = 1;
     if (gx > ntiles) gx = ntiles;
     dim3 grid((unsigned)gx, (unsigned)(d.CDw / BN), (unsigned)d.nclass);
+    if (t.slab == 128) {                                                // one class per blockIdx.z, its four 128-deep slices resident
+        if (BN != 64 || d.ntaps != 4 || d.sign_bits || d.dot) return XMC_ESHAPE;
+        const int epis = xmc_debug_off("no_ptile_epi") ? -1 : (xmc_epi_mask(d) & ~kEpiBias);
+#define XMC_PT3W(E)                                                                                                         \
+        if (epis == (E)) {                                                                                                  \
+            XMC_ALLOW_BIG_LDS((ptile3_kernel<64, 128, 4, 1, 1, false, (E)>));                                               \
+            hipLaunchKernelGGL((ptile3_kernel<64, 128, 4, 1, 1, false, (E)>), grid, dim3(512), lds, st, d, t, ntiles);      \
+        } else
+        XMC_PT3W(kEpiRes) XMC_PT3W(0)
+#undef XMC_PT3W
+        {
+            xmc_note_generic_epi("ptile3<128>", epis);
+            XMC_ALLOW_BIG_LDS((ptile3_kernel<64, 128, 4, 1>));
+            hipLaunchKernelGGL((ptile3_kernel<64, 128, 4, 1>), grid, dim3(512), lds, st, d, t, ntiles);
+        }
+        xmc_note_kernel("ptile3_kernel<64, 128, 4, 1>");
+        XMC_LAUNCH_CHECK();
+        return 0;
+    }
     // all 4 output-parity classes from one staged patch when their 16 weight slices fit beside it
     if (d.nclass == 4 && d.ntaps == 4 && t.PHu * t.PWu <= 384) {
         const size_t ldsm = (size_t)((t.PHu * t.PWu * pstride + 15) & ~15) + (size_t)16 * BN * pstride;
@@ -1058,6 +1077,11 @@ static int tile_plan(const XmcConvDesc* d, TileCfg* t) {
     t->TH = TH; t->TW = TW; t->log2TW = TW == 32 ? 5 : 4;
     t->tiles_y = d->MH / TH; t->tiles_x = d->MW / TW;
     t->slab = (d->CS % 64 == 0) ? 64 : 32;
+    // 128 -> 64 channels, 2x2 tap classes (the data gradient of a block's 4x4 stride-2 convolution, df_gan.py:272-273): ALL 128 source
+    // channels of a class's four weight slices stay in LDS (4 x 64 x 288 B beside a 9 x 33 pixel patch: 159 KB), so nothing is streamed
+    // per tile but the patch -- the streamed-weights kernel moved 140 KB per class tile through the vector-memory path for 128 MFMAs a wave
+    static const bool no_s128 = xmc_debug_off("no_ptile_slab128");
+    if (!no_s128 && d->CS == 128 && d->SA == 1 && d->ntaps == 4 && d->nclass == 4 && d->CDw == 64 && d->out_dtype == XMC_BF16) t->slab = 128;
     for (int z = 0; z < d->nclass; ++z) {
         int hmin = 127, hmax = -128, wmin = 127, wmax = -128;
         for (int k = 0; k < d->ntaps; ++k) {
@@ -1067,7 +1091,7 @@ static int tile_plan(const XmcConvDesc* d, TileCfg* t) {
         }
         t->dh0[z] = hmin; t->dw0[z] = wmin;
         t->PH[z] = d->SA * (TH - 1) + (hmax - hmin + 1); t->PW[z] = d->SA * (TW - 1) + (wmax - wmin + 1);
-        if (s2 ? (t->PH[z] > 18 || t->PW[z] > 34 || (t->PW[z] & 1)) : (t->PH[z] * t->PW[z] > 12 * (256 / (t->slab / 8)))) return 0;   // staging registers (PIT)
+        if (s2 ? (t->PH[z] > 18 || t->PW[z] > 34 || (t->PW[z] & 1)) : (t->PH[z] * t->PW[z] > (t->slab == 128 ? 384 : 12 * (256 / (t->slab / 8))))) return 0;   // staging registers (PIT)
     }
     {
         int hmin = 127, hmax = -128, wmin = 127, wmax = -128;
@@ -1105,10 +1129,20 @@ extern "C" int xmc_conv_ptile_bits(const XmcConvDesc* d, void* stream) {
     return rc == XMC_ESHAPE ? 1 : rc;
 }
 
+// the 128 -> 64 channel class data gradient with its weights resident (tile_plan: slab 128), asked BEFORE the streamed-weights kernels
+int xmc_conv_ptile_slab128_try(const XmcConvDesc* d, void* stream) {
+    if (d->CS != 128 || d->CDw != 64 || d->ntaps != 4 || d->nclass != 4 || d->dst_pool || xmc_debug_off("no_ptile")) return 1;
+    TileCfg t;
+    if (!tile_plan(d, &t) || t.slab != 128) return 1;
+    const int rc = launch_ptile<64>(*d, t, reinterpret_cast<hipStream_t>(stream));
+    return rc == XMC_ESHAPE ? 1 : rc;
+}
+
 // entry used by xmc_conv_igemm's dispatcher (conv_igemm.hip)
 int xmc_conv_tile_try(const XmcConvDesc* d, void* stream) {
     TileCfg t;
     if (!tile_plan(d, &t)) return 1;   // not eligible
+    if (t.slab == 128) return 1;       // (that case was offered to xmc_conv_ptile_slab128_try and declined)
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     int rc;
     static const bool no_pt = xmc_debug_off("no_ptile");
