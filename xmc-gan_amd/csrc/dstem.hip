@@ -142,34 +142,39 @@ __global__ __launch_bounds__(512) void dstem_fwd_kernel(const u32x4* __restrict_
 }
 
 // Weight gradient of the composed stem: dW[co][tap][c] += sum over output pixels of dy[pixel][co] * x[2 pixel + tap - 2][c], with
-// dy = (dh1 | dsc).  GEMM view: M = 128 output channels, N = 288 (tap, channel) pairs, K = pixels.  Both operands are pixel-major,
+// dy = (dh1 | dsc).  GEMM view: M = 128 output channels, N = (tap, channel) pairs, K = pixels.  Both operands are pixel-major,
 // i.e. K-strided: fragments come from transposing LDS reads (ds_read_b64_tr_b16) as in the other weight-gradient kernels.  A
-// 16-wide N block is a PAIR of horizontally adjacent taps x 8 channels: a lane's transposing read takes 8 bytes (4 channels) of the
-// pixel unit of ITS tap.  Wave w owns the 16 output channels of row block w and all 18 tap pairs (72 accumulator registers); K
-// step r is output row r of the tile (32 pixels), whose tap row ta reads patch row 2r + ta -- the fragments of tap rows 2..5 of
-// step r are those of rows 0..3 of step r + 1, so a step reads 6 new tap-pair fragments, not 18.
-// Tile = 8 output rows x 32 columns; dy tile [256][128 + pad] and the 20 x 68 source patch in LDS, next tile prefetched into
-// registers; one atomic per weight per workgroup at the end.
-__global__ __launch_bounds__(512) void dstem_wgrad_kernel(const u32x4* __restrict__ img, const u32x4* __restrict__ dh1, const u32x4* __restrict__ dsc,
+// transposing read takes 8 bytes = FOUR channels of a pixel unit, and only three channels of the unit are image: a 16-wide N block
+// is four consecutive taps (in window order t = ta * 6 + tb) x the unit's first four channels -- 9 blocks cover the 36 taps, every
+// column but the fourth of a tap is useful (the first version's block was a tap pair x 8 channels: 18 blocks, 5 of 8 columns zero).
+// Wave w owns the 16 output channels of row block w and all 9 tap quads (36 accumulator registers); K step r is output row r of
+// the tile (32 pixels), whose tap row ta reads patch row 2r + ta: quad j of step r + 1 reads what quad j + 3 (12 taps = two tap
+// rows on) read in step r, so a step reads 3 new quad fragments, not 9.
+// Tile = 4 output rows x 32 columns; dy tile [128][128 + pad] and the 12 x 68 source patch in LDS (46 KB), next tile prefetched
+// into registers; <= 128 registers, so TWO workgroups share a CU and one's wait for its prefetch is the other's K loop (the kernel
+// moves 75 KB per 72 MFMAs of a wave: with one workgroup per CU a tile cost the memory latency, 16 k cycles, whatever the MFMA
+// count).  One atomic per weight per workgroup at the end (channels 4-7 of dW are not written: they multiply zeros).
+constexpr int kWgTR = 4;
+__global__ __launch_bounds__(512, 4) void dstem_wgrad_kernel(const u32x4* __restrict__ img, const u32x4* __restrict__ dh1, const u32x4* __restrict__ dsc,
                                                          float* __restrict__ dw, float* __restrict__ dbias, int N, int H, int W, int skip_border,
                                                          int ntiles) {
-    constexpr int TR = 8, TC = 32, PR = 2 * TR + 4, PC = 2 * TC + 4;                      // 20 x 68 patch
-    constexpr int PLANE = PC / 2 + 2;        // 34 slots per column-parity plane, padded to 36: the two taps of a pair sit in different
-                                             // planes, 576 bytes = 16 banks apart
+    constexpr int TR = kWgTR, TC = 32, PR = 2 * TR + 4, PC = 2 * TC + 4;                  // 12 x 68 patch
+    constexpr int PLANE = 48;                // 8-byte slots (channels 0-3 of a pixel) per column-parity plane: 34 used; 384 bytes = 32 banks, so the
+                                             // two planes a quad's taps read (16 consecutive slots each) cover the 64 banks once per pair
     constexpr int PUNITS = PR * PC;                                                       // 1360 units
     constexpr int YS = 128 * 2 + 32;                                                      // dy row stride (bytes): 128 channels + pad
-    constexpr int XIT = (PUNITS + 511) / 512;                                             // 3
-    constexpr int YIT = TR * TC * 16 / 512;                                               // 8 sixteen-byte units of dy per thread
+    constexpr int XIT = (PUNITS + 511) / 512;                                             // 2
+    constexpr int YIT = TR * TC * 16 / 512;                                               // 4 sixteen-byte units of dy per thread
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* ydy = smem;                                // [256][YS]
-    unsigned char* xp = smem + TR * TC * YS;                  // [PR][2 planes][PLANE] x 16 bytes
+    unsigned char* xp = smem + TR * TC * YS;                  // [PR][2 planes][PLANE] x 8 bytes
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int OH = H >> 1, OW = W >> 1;
     const int tiles_x = OW / TC, tiles_y = OH / TR, tpi = tiles_y * tiles_x;
 
-    f32x4 acc[18];
+    f32x4 acc[9];
 #pragma unroll
-    for (int j = 0; j < 18; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < 9; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // dy staging: unit (pixel, chunk) = tid / 16 + it * 32, tid % 16; chunks 0-7 from dh1, 8-15 from dsc
     const int ych = tid & 15, ypix0 = tid >> 4;
@@ -180,9 +185,10 @@ __global__ __launch_bounds__(512) void dstem_wgrad_kernel(const u32x4* __restric
     for (int it = 0; it < XIT; ++it) {
         const int u = tid + it * 512;
         xrow[it] = u / PC; xcol[it] = u - xrow[it] * PC;
-        xdst[it] = ((xrow[it] * 2 + (xcol[it] & 1)) * PLANE + (xcol[it] >> 1)) * 16;
+        xdst[it] = ((xrow[it] * 2 + (xcol[it] & 1)) * PLANE + (xcol[it] >> 1)) * 8;
     }
-    u32x4 yv[YIT], xv[XIT];
+    u32x4 yv[YIT];
+    u32x2 xv[XIT];                                            // channels 0-3 of a source pixel (three of them image)
     float bsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     auto prefetch = [&](int tile) {
         const int n = tile / tpi, trem = tile - n * tpi;
@@ -202,21 +208,20 @@ __global__ __launch_bounds__(512) void dstem_wgrad_kernel(const u32x4* __restric
         for (int it = 0; it < XIT; ++it) {
             const int sy = 2 * a0 - 2 + xrow[it], sx = 2 * b0 - 2 + xcol[it];
             const bool ok = tid + it * 512 < PUNITS && (unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W;
-            xv[it] = ok ? img[((size_t)n * H + sy) * W + sx] : u32x4{0, 0, 0, 0};
+            xv[it] = ok ? *reinterpret_cast<const u32x2*>(img + ((size_t)n * H + sy) * W + sx) : u32x2{0, 0};
         }
     };
     const int fr = lane & 15, fg = lane >> 4;
     const int q = fr >> 2, pp4 = fr & 3;
     // A' fragment: dy^T [co = 16 wave + fr][pixel 4 fg + q (+16)]: 8 bytes = 4 channels at channel offset 4 pp4 of the wave's block
     const unsigned char* afrag = ydy + (size_t)(4 * fg + q) * YS + (wave * 16 + 4 * pp4) * 2;
-    // B fragment of tap pair (ta, 2 tp + {0, 1}): lane (q, pp4) reads the unit of output pixel 4 fg + q under tap 2 tp + (pp4 >> 1),
-    // bytes 8 (pp4 & 1) .. +7: source column 2 px + tb -> plane tb & 1, slot px + (tb >> 1)
-    const int tbl = pp4 >> 1;                                 // which tap of the pair this lane reads
-    int boff[3];                                              // per pair column tp: byte offset (plane, slot shift, channel half)
+    // B fragment of tap quad j: lane (q, pp4) reads channels 0-3 of the unit of output pixel 4 fg + q under tap t = 4 j + pp4 =
+    // (ta, tb): patch row 2r + ta, source column 2 px + tb -> plane tb & 1, slot px + (tb >> 1)
+    int boff[9];
 #pragma unroll
-    for (int tp = 0; tp < 3; ++tp) {
-        const int tb = 2 * tp + tbl;
-        boff[tp] = ((tb & 1) * PLANE + (tb >> 1) + 4 * fg + q) * 16 + (pp4 & 1) * 8;
+    for (int j = 0; j < 9; ++j) {
+        const int tq = 4 * j + pp4, ta = tq / 6, tb = tq - 6 * ta;
+        boff[j] = ((ta * 2 + (tb & 1)) * PLANE + (tb >> 1) + 4 * fg + q) * 8;
     }
     int tile = blockIdx.x;
     if (tile < ntiles) prefetch(tile);
@@ -231,7 +236,7 @@ __global__ __launch_bounds__(512) void dstem_wgrad_kernel(const u32x4* __restric
         }
 #pragma unroll
         for (int it = 0; it < XIT; ++it)
-            if (tid + it * 512 < PUNITS) *reinterpret_cast<u32x4*>(xp + xdst[it]) = xv[it];
+            if (tid + it * 512 < PUNITS) *reinterpret_cast<u32x2*>(xp + xdst[it]) = xv[it];
         __syncthreads();
         if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);
         int zq = 0;
@@ -243,54 +248,56 @@ __global__ __launch_bounds__(512) void dstem_wgrad_kernel(const u32x4* __restric
             bf16x4 lo = xmc_ds_read_tr16(ab), hi = xmc_ds_read_tr16(ab + 16 * YS);
             return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         };
-        auto rd_b = [&](int prow, int tp) -> bf16x8 {         // patch row `prow`, tap pair column tp, output pixels 0..31 of a row
-            const unsigned char* bb = bfr + (size_t)(prow * 2 * PLANE) * 16 + boff[tp];
-            bf16x4 lo = xmc_ds_read_tr16(bb), hi = xmc_ds_read_tr16(bb + 16 * 16);
+        auto rd_b = [&](int r, int j) -> bf16x8 {             // output row r (pixels 0..31), tap quad j
+            const unsigned char* bb = bfr + (size_t)(2 * r * 2 * PLANE) * 8 + boff[j];
+            bf16x4 lo = xmc_ds_read_tr16(bb), hi = xmc_ds_read_tr16(bb + 16 * 8);
             return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         };
-        bf16x8 bq[6][3];                                      // [patch row slot (row % 6)][pair column]
+        bf16x8 bq[9];                                         // slot (j + 3 r) % 9 holds quad j of step r
 #pragma unroll
-        for (int pr = 0; pr < 4; ++pr)
-#pragma unroll
-            for (int tp = 0; tp < 3; ++tp) bq[pr][tp] = rd_b(pr, tp);
+        for (int j = 0; j < 6; ++j) bq[j] = rd_b(0, j);
         bf16x8 af = rd_a(0);
 #pragma unroll
         for (int r = 0; r < TR; ++r) {
-            // output row r: tap row ta reads patch row 2r + ta; rows 2r + 4, 2r + 5 are new
 #pragma unroll
-            for (int tp = 0; tp < 3; ++tp) {
-                bq[(2 * r + 4) % 6][tp] = rd_b(2 * r + 4, tp);
-                bq[(2 * r + 5) % 6][tp] = rd_b(2 * r + 5, tp);
-            }
+            for (int j = 6; j < 9; ++j) bq[(j + 3 * r) % 9] = rd_b(r, j);      // tap rows 4, 5 of this output row are new
             bf16x8 afn = af;
             if (r + 1 < TR) afn = rd_a(r + 1);
 #pragma unroll
-            for (int ta = 0; ta < 6; ++ta)
-#pragma unroll
-                for (int tp = 0; tp < 3; ++tp)
-                    acc[ta * 3 + tp] = XMC_MFMA_16x16x32(af, bq[(2 * r + ta) % 6][tp], acc[ta * 3 + tp], 0, 0, 0);
+            for (int j = 0; j < 9; ++j) acc[j] = XMC_MFMA_16x16x32(af, bq[(j + 3 * r) % 9], acc[j], 0, 0, 0);
             af = afn;
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    // bias gradient: lanes with equal lane & 15 hold the same channel chunk
+    // bias gradient: lanes with equal lane & 15 hold the same channel chunk; the eight waves are summed through LDS so that a workgroup
+    // sends ONE atomic per channel (one per wave was 4096 atomics on each of 128 addresses in four cache lines at batch 512: ~0.5 ms of
+    // serialised read-modify-writes behind a 0.2 ms kernel)
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);              // [8 waves][128]
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         float v = bsum[k];
         v += __shfl_xor(v, 16, 64);
         v += __shfl_xor(v, 32, 64);
-        if (lane < 16) atomicAdd(&dbias[lane * 8 + k], v);
+        if (lane < 16) red[wave * 128 + lane * 8 + k] = v;
     }
-    // D[row = co][col = (tap of the pair, channel)]: lane (fr, fg) holds rows 4 fg + rr of column fr
+    __syncthreads();
+    if (tid < 128) {
+        float v = 0.f;
 #pragma unroll
-    for (int ta = 0; ta < 6; ++ta)
+        for (int w = 0; w < 8; ++w) v += red[w * 128 + tid];
+        atomicAdd(&dbias[tid], v);
+    }
+    // D[row = co][col = (tap of the quad, channel < 4)]: lane (fr, fg) holds rows 4 fg + rr of column fr
+    if ((fr & 3) < 3) {
 #pragma unroll
-        for (int tp = 0; tp < 3; ++tp)
+        for (int j = 0; j < 9; ++j)
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
-                const int co = wave * 16 + fg * 4 + rr, tap = ta * 6 + 2 * tp + (fr >> 3), c = fr & 7;
-                atomicAdd(&dw[((size_t)co * kTaps + tap) * 8 + c], acc[ta * 3 + tp][rr]);
+                const int co = wave * 16 + fg * 4 + rr, tap = 4 * j + (fr >> 2), c = fr & 3;
+                atomicAdd(&dw[((size_t)co * kTaps + tap) * 8 + c], acc[j][rr]);
             }
+    }
 }
 
 // ---- composition of the stem's weights (and its adjoint) ----------------------------------------------------------------------------
@@ -888,9 +895,9 @@ extern "C" int xmc_dstem_wgrad(const void* img, const void* dh1, const void* dsc
                                int skip_border, void* stream) {
     if (!img || !dh1 || !dsc || !dw || !dbias || N < 1) return XMC_EINVAL;
     if (H < 16 || W < 64 || H % 16 != 0 || W % 64 != 0) return XMC_ESHAPE;
-    const int ntiles = N * (H / 16) * (W / 64);
-    const int grid = ntiles < 256 ? ntiles : 256;
-    const size_t lds = (size_t)256 * (128 * 2 + 32) + (size_t)20 * 2 * 36 * 16;
+    const int ntiles = N * (H / (2 * kWgTR)) * (W / 64);
+    const int grid = ntiles < 512 ? ntiles : 512;
+    const size_t lds = (size_t)kWgTR * 32 * (128 * 2 + 32) + (size_t)(2 * kWgTR + 4) * 2 * 48 * 8;
     XMC_ALLOW_BIG_LDS(dstem_wgrad_kernel);
     hipLaunchKernelGGL(dstem_wgrad_kernel, dim3(grid), dim3(512), lds, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const u32x4*>(img),
                        reinterpret_cast<const u32x4*>(dh1), reinterpret_cast<const u32x4*>(dsc), dw, dbias, N, H, W, skip_border, ntiles);
