@@ -458,7 +458,7 @@ int xmc_concept_head_bwd(const float* ctx, const float* sent, const float* hid, 
  * 16-bit format; composed weights f32 [128][36 taps = ta*6+tb][8] and biases f32 [128]: rows 0-63 give h1 = lrelu(.)
  * [N,H/2,W/2,64], rows 64-127 the shortcut sc [N,H/2,W/2,64].  Exact except for h1's pixels on the image border (conv_r[0] pads
  * conv_img's OUTPUT with zeros): the host recomputes those (ops.DStemBlockFn).  H % 16 == 0, W % 64 == 0.
- *  pack:  composed weights -> wfrag (72 KB, MFMA fragment order, 16-bit);  fwd: h1, sc;
+ *  pack:  composed weights -> wfrag (40 KB, MFMA fragment order, 16-bit: 8 row blocks x 5 K steps of tap pairs x 4 channels);  fwd: h1, sc;
  *  wgrad: dw[128][36][8], dbias[128] (f32, zeroed by the caller) += sums over output pixels of (dh1 | dsc)(pixel) x patch(pixel) and
  *         of (dh1 | dsc); with skip_border the border pixels of dh1 do not contribute. */
 /* the composition itself and its adjoint (parameter-sized f32 work, one thread per element): conv_img.weight [32][3][3][3] and .bias

@@ -20,9 +20,10 @@
 
 namespace {
 
-constexpr int kTaps = 36, kKSteps = 9;          // 36 taps x 8 channels = 9 MFMA K steps of 32 (4 taps each)
+constexpr int kTaps = 36, kKSteps = 5;          // 36 taps x the first 4 channels of a pixel unit = 18 tap pairs of 8 K values: 4.5 MFMA K steps of 32
 
-// one thread per (fragment, lane): fragment f = (half * 4 + j) * 9 + s holds W[co(half, j, row)][tap 4s + kg][0..7]
+// one thread per (fragment, lane): fragment f = (half * 4 + j) * 5 + s holds, for row co(half, j, lane & 15) and tap pair m = 4s + (lane >> 4),
+// W[co][tap 2m][0..3] | W[co][tap 2m + 1][0..3] (pairs 18, 19 of the last step: zeros)
 __global__ void dstem_pack_kernel(const float* __restrict__ w, bf16x8* __restrict__ frag) {
     const int id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= 8 * kKSteps * 64) return;
@@ -30,60 +31,56 @@ __global__ void dstem_pack_kernel(const float* __restrict__ w, bf16x8* __restric
     const int s = f % kKSteps, hj = f / kKSteps, half = hj >> 2, j = hj & 3;
     const int q = lane & 15, kg = lane >> 4;
     const int co = half * 64 + (j >> 1) * 32 + (q >> 2) * 8 + (j & 1) * 4 + (q & 3);
-    const float* src = w + ((size_t)co * kTaps + 4 * s + kg) * 8;
+    const int m = 4 * s + kg;
     bf16x8 o;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) o[c] = (xmc_h16)src[c];
+    for (int c = 0; c < 8; ++c) o[c] = (xmc_h16)(m < kTaps / 2 ? w[((size_t)co * kTaps + 2 * m + (c >> 2)) * 8 + (c & 3)] : 0.f);
     frag[id] = o;
 }
 
-// Persistent 8-wave workgroup, tile = 4 output rows x 32 output columns.  Wave (pg = w & 3, half = w >> 2) owns output row pg of
-// the tile (two 16-pixel blocks) and 64 of the 128 output channels, and keeps ITS weights -- 9 K steps x 4 row blocks of A
-// fragments, 144 registers -- for the whole launch: the K loop reads only pixel fragments from LDS (one ds_read_b128 per four
-// MFMAs: the 16 bytes of a source pixel ARE a lane's eight K values).  Source patch (12 x 68 pixels, zero outside the image) in
-// two column-parity planes per row so that the pixels of consecutive output columns under one tap are consecutive 16-byte slots;
-// double-buffered, next tile's patch prefetched into registers: one barrier per tile.
-__global__ __launch_bounds__(512) void dstem_fwd_kernel(const u32x4* __restrict__ img, const u32x4* __restrict__ frag, const float* __restrict__ bias,
-                                                       bf16x8* __restrict__ h1, bf16x8* __restrict__ sc, int N, int H, int W, float slope, int ntiles) {
+// Persistent 8-wave workgroup, tile = 4 output rows x 32 output columns.  Wave (rp = w & 1, cq = w >> 1) owns output rows 2 rp,
+// 2 rp + 1 of the tile (four 16-pixel blocks) and 32 of the 128 output channels, and keeps ITS weights -- 5 K steps x 2 row blocks
+// of A fragments, 40 registers -- for the whole launch: the K loop reads only pixel fragments from LDS.  Only the first four channels
+// of a pixel unit are staged (three of them are image): the source patch (12 x 68 pixels, zero outside the image) is row-major with
+// 8 bytes per pixel, so the two taps (ta, tb), (ta, tb + 1), tb even, of output pixel px are the 16 contiguous bytes at column
+// 2 px + tb -- ONE ds_read_b128 is a lane's eight K values (2 taps x 4 channels), consecutive output pixels are consecutive
+// 16-byte slots, and the window's 36 taps are 4.5 K steps of 32 (the first version's K was tap x 8 channels: 9 steps, 5 of 8
+// values zero).  Double-buffered patch, next tile prefetched into registers: one barrier per tile; <= 128 registers, so two
+// workgroups share a CU and one's wait for its prefetch is the other's K loop.
+__global__ __launch_bounds__(512, 4) void dstem_fwd_kernel(const u32x4* __restrict__ img, const u32x4* __restrict__ frag, const float* __restrict__ bias,
+                                                          bf16x8* __restrict__ h1, bf16x8* __restrict__ sc, int N, int H, int W, float slope, int ntiles) {
     constexpr int TR = 4, TC = 32, PR = 2 * TR + 4, PC = 2 * TC + 4;                      // 12 x 68 patch
-    constexpr int PLANE = PC / 2 + 2;        // 34 slots per column-parity plane, padded to 36: consecutive source pixels alternate planes,
-                                             // 576 bytes = 16 banks apart (34: SQ_LDS_BANK_CONFLICT 0.5 per active cycle on the patch stores)
-    constexpr int PUNITS = PR * PC;                                                       // 816 sixteen-byte units
-    __shared__ u32x4 patch[2][PR * 2 * PLANE];
+    constexpr int PUNITS = PR * PC;                                                       // 816 eight-byte units
+    __shared__ __attribute__((aligned(16))) u32x2 patch[2][PUNITS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int pg = wave & 3, half = wave >> 2;
+    const int rp = wave & 1, cq = wave >> 1;
     const int p = lane & 15, g = lane >> 4;
     const int OH = H >> 1, OW = W >> 1;
     const int tiles_x = OW / TC, tpi = (OH / TR) * tiles_x;
 
-    u32x4 afr[kKSteps][4];
+    u32x4 afr[kKSteps][2];
 #pragma unroll
     for (int s = 0; s < kKSteps; ++s)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) afr[s][j] = frag[((half * 4 + j) * kKSteps + s) * 64 + lane];
-    // this lane's tap of K step s is 4s + g: slot offset inside the patch, relative to the pixel's own slot
+        for (int j = 0; j < 2; ++j) afr[s][j] = frag[((cq * 2 + j) * kKSteps + s) * 64 + lane];
+    // this lane's tap pair of K step s is m = 4s + g = (ta, tb = 2 (m % 3)): 8-byte unit offset inside the patch relative to the output
+    // pixel's own unit (row 2 py, column 2 px); the padded pairs 18, 19 re-read pair 0 (their weights are zero, the data must be finite)
     int toff[kKSteps];
 #pragma unroll
     for (int s = 0; s < kKSteps; ++s) {
-        const int t = 4 * s + g, ta = t / 6, tb = t - ta * 6;
-        toff[s] = (ta * 2 + (tb & 1)) * PLANE + (tb >> 1);
+        const int m = 4 * s + g, mm = m < kTaps / 2 ? m : 0;
+        toff[s] = (mm / 3) * PC + 2 * (mm % 3);
     }
-    const int pbase = (2 * pg * 2) * PLANE + p;               // output pixel (pg, p) of block 0: source row 2 pg, plane 0, slot p
-    float bv[2][8];                                           // bias of this lane's channels u * 32 + g * 8 + [0, 8)
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int c = 0; c < 8; ++c) bv[u][c] = bias[half * 64 + u * 32 + g * 8 + c];
+    const int pbase = 4 * rp * PC + 2 * p;                    // output pixel (row 2 rp, column p): block b = (row b >> 1, columns 16 (b & 1) ..)
 
     // staging: units u = tid, tid + 512 (816 of them)
-    int urow[2], ucol[2], udst[2];
+    int urow[2], ucol[2];
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
         const int u = tid + it * 512;
         urow[it] = u / PC; ucol[it] = u - urow[it] * PC;
-        udst[it] = (urow[it] * 2 + (ucol[it] & 1)) * PLANE + (ucol[it] >> 1);
     }
-    u32x4 pv[2];
+    u32x2 pv[2];
     auto prefetch = [&](int tile) {
         const int n = tile / tpi, trem = tile - n * tpi;
         const int a0 = (trem / tiles_x) * TR, b0 = (trem % tiles_x) * TC;
@@ -91,52 +88,51 @@ __global__ __launch_bounds__(512) void dstem_fwd_kernel(const u32x4* __restrict_
         for (int it = 0; it < 2; ++it) {
             const int sy = 2 * a0 - 2 + urow[it], sx = 2 * b0 - 2 + ucol[it];
             const bool ok = tid + it * 512 < PUNITS && (unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W;
-            pv[it] = ok ? img[((size_t)n * H + sy) * W + sx] : u32x4{0, 0, 0, 0};
+            pv[it] = ok ? *reinterpret_cast<const u32x2*>(img + ((size_t)n * H + sy) * W + sx) : u32x2{0, 0};
         }
     };
+    bf16x8* __restrict__ dst = cq < 2 ? h1 : sc;
+    const float sl = cq < 2 ? slope : 1.f;
+    const float* bp = bias + cq * 32 + g * 8;
+    const f32x4 b0v = *reinterpret_cast<const f32x4*>(bp), b1v = *reinterpret_cast<const f32x4*>(bp + 4);
     int tile = blockIdx.x, buf = 0;
     if (tile < ntiles) prefetch(tile);
     for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
 #pragma unroll
         for (int it = 0; it < 2; ++it)
-            if (tid + it * 512 < PUNITS) patch[buf][udst[it]] = pv[it];
+            if (tid + it * 512 < PUNITS) patch[buf][tid + it * 512] = pv[it];
         __syncthreads();
         if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);
-        f32x4 acc[2][4];
+        f32x4 acc[4][2];
 #pragma unroll
-        for (int pb = 0; pb < 2; ++pb)
+        for (int b = 0; b < 4; ++b)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[pb][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const u32x4* pp = patch[buf] + pbase;
+            for (int j = 0; j < 2; ++j) acc[b][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const u32x2* pp = patch[buf] + pbase;
 #pragma unroll
         for (int s = 0; s < kKSteps; ++s) {
 #pragma unroll
-            for (int pb = 0; pb < 2; ++pb) {
-                const u32x4 bf = pp[toff[s] + pb * 16];
+            for (int b = 0; b < 4; ++b) {
+                const u32x4 bf = *reinterpret_cast<const u32x4*>(pp + toff[s] + (b >> 1) * 2 * PC + (b & 1) * 32);
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[pb][j] = XMC_MFMA_16x16x32(__builtin_bit_cast(bf16x8, afr[s][j]), __builtin_bit_cast(bf16x8, bf), acc[pb][j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j)
+                    acc[b][j] = XMC_MFMA_16x16x32(__builtin_bit_cast(bf16x8, afr[s][j]), __builtin_bit_cast(bf16x8, bf), acc[b][j], 0, 0, 0);
             }
         }
-        // lane (p, g): channels u * 32 + g * 8 + [0, 8) of this wave's 64, u = 0, 1 (row blocks 2u and 2u + 1)
+        // lane (p, g): channels cq * 32 + g * 8 + [0, 8) (row block 0: the first four, row block 1: the last four)
         const int n = tile / tpi, trem = tile - n * tpi;
-        const int oy = (trem / tiles_x) * TR + pg, ox0 = (trem % tiles_x) * TC + p;
-        bf16x8* __restrict__ dst = half == 0 ? h1 : sc;
-        const float sl = half == 0 ? slope : 1.f;
+        const int oy0 = (trem / tiles_x) * TR + 2 * rp, ox0 = (trem % tiles_x) * TC + p;
 #pragma unroll
-        for (int pb = 0; pb < 2; ++pb) {
-            const size_t pix = ((size_t)n * OH + oy) * OW + ox0 + pb * 16;
+        for (int b = 0; b < 4; ++b) {
+            const size_t pix = ((size_t)n * OH + oy0 + (b >> 1)) * OW + ox0 + (b & 1) * 16;
+            bf16x8 o;
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                bf16x8 o;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float v0 = acc[pb][2 * u][r] + bv[u][r], v1 = acc[pb][2 * u + 1][r] + bv[u][4 + r];
-                    o[r] = (xmc_h16)fmaxf(v0, v0 * sl);
-                    o[4 + r] = (xmc_h16)fmaxf(v1, v1 * sl);
-                }
-                dst[pix * 8 + u * 4 + g] = o;
+            for (int r = 0; r < 4; ++r) {
+                const float v0 = acc[b][0][r] + b0v[r], v1 = acc[b][1][r] + b1v[r];
+                o[r] = (xmc_h16)fmaxf(v0, v0 * sl);
+                o[4 + r] = (xmc_h16)fmaxf(v1, v1 * sl);
             }
+            dst[pix * 8 + (cq & 1) * 4 + g] = o;
         }
     }
 }
@@ -812,7 +808,7 @@ extern "C" int xmc_dstem_fwd(const void* img, const void* wfrag, const float* bi
     if (!img || !wfrag || !bias || !h1 || !sc || N < 1) return XMC_EINVAL;
     if (H < 8 || W < 64 || H % 8 != 0 || W % 64 != 0) return XMC_ESHAPE;
     const int ntiles = N * (H / 8) * (W / 64);
-    const int grid = ntiles < 256 ? ntiles : 256;
+    const int grid = ntiles < 512 ? ntiles : 512;
     hipLaunchKernelGGL(dstem_fwd_kernel, dim3(grid), dim3(512), 0, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const u32x4*>(img),
                        reinterpret_cast<const u32x4*>(wfrag), bias, reinterpret_cast<bf16x8*>(h1), reinterpret_cast<bf16x8*>(sc), N, H, W, slope,
                        ntiles);

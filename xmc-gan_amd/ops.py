@@ -871,7 +871,7 @@ def _dstem_fwd_raw(xin, wsets, bias, slope=0.2):
     are the composition's, not the reference's: see DStemBlockFn)."""
     _need_cuda(xin, wsets)
     N, H, W, _ = xin.shape
-    wfrag = torch.empty(8 * 9 * 64 * 8, dtype=xin.dtype, device=xin.device)
+    wfrag = torch.empty(8 * 5 * 64 * 8, dtype=xin.dtype, device=xin.device)         # 8 row blocks x 5 K steps of MFMA A fragments
     L.call("xmc_dstem_pack", _p(wsets), _p(wfrag), _st())
     h1 = torch.empty((N, H // 2, W // 2, 64), dtype=xin.dtype, device=xin.device)
     sc = torch.empty_like(h1)
