@@ -407,8 +407,8 @@ def main():
         roof = prof.summary(peak, pmc_traffic_lookup(S, B, a.cfg, a.precision))
         roof_hbm = prof.summary_hbm(PEAK_HBM_GBS, 1e3 * peak / PEAK_HBM_GBS)
         if os.environ.get("XMC_PROF_SHAPES") and rank == 0:
-            for fam, tag, n, ms, tf in prof.by_shape()[:max(60, int(os.environ["XMC_PROF_SHAPES"]))]:
-                print(f"{fam:52s} {tag:58s} n={n:3d} {ms:8.3f} ms {tf:8.1f} TF/s", file=sys.stderr)
+            for fam, tag, n, ms, tf, tbs in prof.by_shape()[:max(60, int(os.environ["XMC_PROF_SHAPES"]))]:
+                print(f"{fam:52s} {tag:58s} n={n:3d} {ms:8.3f} ms {tf:8.1f} TF/s {tbs:6.2f} TB/s", file=sys.stderr)
             print(f"max memory allocated: {torch.cuda.max_memory_allocated() / 2**30:.2f} GiB", file=sys.stderr)
         prof.disable()
         barrier()

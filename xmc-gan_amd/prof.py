@@ -108,11 +108,11 @@ def summary_hbm(peak_gbs, ridge_flop_per_byte, top=8):
 
 
 def by_shape():
-    """[(family, tag, launches, total_ms, tflops)] sorted by time (debug aid)."""
+    """[(family, tag, launches, total_ms, tflops, algorithmic TB/s)] sorted by time (debug aid)."""
     torch.cuda.synchronize()
     agg = {}
-    for family, flops, e0, e1, tag, kern, _nb in _recs:
-        a = agg.setdefault((kern or family.split(" ")[0], tag), [0, 0.0, 0.0])
-        a[0] += 1; a[1] += e0.elapsed_time(e1); a[2] += flops
-    rows = [(k[0], k[1], v[0], v[1], v[2] / 1e9 / max(v[1], 1e-9)) for k, v in agg.items()]
+    for family, flops, e0, e1, tag, kern, nb in _recs:
+        a = agg.setdefault((kern or family.split(" ")[0], tag), [0, 0.0, 0.0, 0.0])
+        a[0] += 1; a[1] += e0.elapsed_time(e1); a[2] += flops; a[3] += nb or 0
+    rows = [(k[0], k[1], v[0], v[1], v[2] / 1e9 / max(v[1], 1e-9), v[3] / 1e9 / max(v[1], 1e-9)) for k, v in agg.items()]
     return sorted(rows, key=lambda r: -r[3])
