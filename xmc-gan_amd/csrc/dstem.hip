@@ -741,54 +741,88 @@ __global__ __launch_bounds__(256) void dstem_border_fwd_kernel(const u32x4* __re
     }
 }
 
-// one workgroup per (image, side): the side's line of dh1 [L][64] and the image line it reads in LDS, one thread per output
+constexpr int kBwImgs = 8;
+// one workgroup per (8 images, side): the side's line of dh1 [L][64] and the image line it reads in LDS, one thread per output
 __global__ __launch_bounds__(256) void dstem_border_wgrad_kernel(const u32x4* __restrict__ img, const bf16x8* __restrict__ dh1, float* __restrict__ dD,
                                                                 float* __restrict__ dDB, int N, int H, int W) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int n = blockIdx.x, side = blockIdx.y, tid = threadIdx.x;       // side: 0 top, 1 bottom, 2 left, 3 right
+    const int side = blockIdx.y, tid = threadIdx.x;                       // side: 0 top, 1 bottom, 2 left, 3 right
     const int OH = H >> 1, OW = W >> 1;
     const bool rows = side < 2;
     const int L = rows ? OW : OH, XL = (rows ? W : H) + 4;                 // image line with two zero pixels either side
     float* gl = reinterpret_cast<float*>(smem);                           // [L][64]
     float* xl = gl + (size_t)L * 64;                                      // [XL][4]
-    for (int id = tid; id < L * 8; id += 256) {
-        const int i = id >> 3, ch = id & 7;
-        const int py = rows ? (side == 0 ? 0 : OH - 1) : i, px = rows ? i : (side == 2 ? 0 : OW - 1);
-        const bf16x8 t = dh1[(((size_t)n * OH + py) * OW + px) * 8 + ch];
+    // kBwImgs images per workgroup, summed in registers: one atomic per table entry and workgroup (one per IMAGE was 512 atomics on
+    // each address at batch 512, most of this kernel's time)
+    constexpr int NA = (64 * 18 + 255) / 256;
+    float accD[NA], accB = 0.f, accC[2] = {0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < 8; ++k) gl[i * 64 + ch * 8 + k] = (float)t[k];
-    }
-    for (int id = tid; id < XL; id += 256) {
-        const int s_ = id - 2;
-        float a = 0.f, b = 0.f, c = 0.f;
-        if (s_ >= 0 && s_ < XL - 4) {
-            const int sy = rows ? (side == 0 ? 0 : H - 1) : s_, sx = rows ? s_ : (side == 2 ? 0 : W - 1);
-            const bf16x8 t = __builtin_bit_cast(bf16x8, img[((size_t)n * H + sy) * W + sx]);
-            a = (float)t[0]; b = (float)t[1]; c = (float)t[2];
+    for (int a = 0; a < NA; ++a) accD[a] = 0.f;
+    const int n_end = min(N, ((int)blockIdx.x + 1) * kBwImgs);
+    for (int n = blockIdx.x * kBwImgs; n < n_end; ++n) {
+        __syncthreads();
+        for (int id = tid; id < L * 8; id += 256) {
+            const int i = id >> 3, ch = id & 7;
+            const int py = rows ? (side == 0 ? 0 : OH - 1) : i, px = rows ? i : (side == 2 ? 0 : OW - 1);
+            const bf16x8 t = dh1[(((size_t)n * OH + py) * OW + px) * 8 + ch];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) gl[i * 64 + ch * 8 + k] = (float)t[k];
         }
-        xl[id * 4 + 0] = a; xl[id * 4 + 1] = b; xl[id * 4 + 2] = c; xl[id * 4 + 3] = 0.f;
+        for (int id = tid; id < XL; id += 256) {
+            const int s_ = id - 2;
+            float a = 0.f, b = 0.f, c = 0.f;
+            if (s_ >= 0 && s_ < XL - 4) {
+                const int sy = rows ? (side == 0 ? 0 : H - 1) : s_, sx = rows ? s_ : (side == 2 ? 0 : W - 1);
+                const bf16x8 t = __builtin_bit_cast(bf16x8, img[((size_t)n * H + sy) * W + sx]);
+                a = (float)t[0]; b = (float)t[1]; c = (float)t[2];
+            }
+            xl[id * 4 + 0] = a; xl[id * 4 + 1] = b; xl[id * 4 + 2] = c; xl[id * 4 + 3] = 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < NA; ++a) {                                    // (o, tap t, channel c): sum_i dh1[i][o] * x[2 i - 2 + t][c]
+            const int id = tid + a * 256;
+            if (id < 64 * 18) {
+                const int o = id / 18, r = id - o * 18, t = r / 3, c = r - t * 3;
+                float s_ = 0.f;
+                for (int i = 0; i < L; ++i) s_ += gl[i * 64 + o] * xl[(2 * i + t) * 4 + c];
+                accD[a] += s_;
+            }
+        }
+        if (tid < 64) {
+            float s_ = 0.f;
+            for (int i = 0; i < L; ++i) s_ += gl[i * 64 + tid];
+            accB += s_;
+        }
+        if (rows) {                                                       // corners: (first | last) pixel of the top / bottom line
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const int id = tid + a * 256;
+                const int which = id >> 8, o = (id >> 2) & 63, c = id & 3; // which: 0 = left end, 1 = right end
+                const int i = which ? L - 1 : 0, xi = which ? XL - 3 : 2;  // image column 0 / W - 1 in the padded line
+                const float g_ = gl[i * 64 + o];
+                accC[a] += c < 3 ? g_ * xl[xi * 4 + c] : g_;
+            }
+        }
     }
-    __syncthreads();
     const int t0 = side * 6;
-    for (int id = tid; id < 64 * 18; id += 256) {                          // (o, tap t, channel c): sum_i dh1[i][o] * x[2 i - 2 + t][c]
-        const int o = id / 18, r = id - o * 18, t = r / 3, c = r - t * 3;
-        float s_ = 0.f;
-        for (int i = 0; i < L; ++i) s_ += gl[i * 64 + o] * xl[(2 * i + t) * 4 + c];
-        atomicAdd(&dD[((size_t)o * 28 + t0 + t) * 8 + c], s_);
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+        const int id = tid + a * 256;
+        if (id < 64 * 18) {
+            const int o = id / 18, r = id - o * 18, t = r / 3, c = r - t * 3;
+            atomicAdd(&dD[((size_t)o * 28 + t0 + t) * 8 + c], accD[a]);
+        }
     }
-    for (int id = tid; id < 64; id += 256) {
-        float s_ = 0.f;
-        for (int i = 0; i < L; ++i) s_ += gl[i * 64 + id];
-        atomicAdd(&dDB[id * 8 + side], s_);
-    }
-    if (rows) {                                                           // corners: (first | last) pixel of the top / bottom line
-        for (int id = tid; id < 2 * 64 * 4; id += 256) {
-            const int which = id >> 8, o = (id >> 2) & 63, c = id & 3;     // which: 0 = left end, 1 = right end
-            const int i = which ? L - 1 : 0, xi = which ? XL - 3 : 2;      // image column 0 / W - 1 in the padded line
+    if (tid < 64) atomicAdd(&dDB[tid * 8 + side], accB);
+    if (rows) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int id = tid + a * 256;
+            const int which = id >> 8, o = (id >> 2) & 63, c = id & 3;
             const int tcorner = 24 + side * 2 + which;
-            const float g_ = gl[i * 64 + o];
-            if (c < 3) atomicAdd(&dD[((size_t)o * 28 + tcorner) * 8 + c], g_ * xl[xi * 4 + c]);
-            else atomicAdd(&dDB[o * 8 + tcorner - 20], g_);
+            if (c < 3) atomicAdd(&dD[((size_t)o * 28 + tcorner) * 8 + c], accC[a]);
+            else atomicAdd(&dDB[o * 8 + tcorner - 20], accC[a]);
         }
     }
 }
@@ -861,7 +895,7 @@ extern "C" int xmc_dstem_border_wgrad(const void* img, const void* dh1, float* d
     const int L = (H > W ? H : W) / 2, XL = (H > W ? H : W) + 4;
     const size_t lds = (size_t)L * 64 * 4 + (size_t)XL * 16;
     XMC_ALLOW_BIG_LDS(dstem_border_wgrad_kernel);
-    hipLaunchKernelGGL(dstem_border_wgrad_kernel, dim3(N, 4), dim3(256), lds, reinterpret_cast<hipStream_t>(stream),
+    hipLaunchKernelGGL(dstem_border_wgrad_kernel, dim3((N + kBwImgs - 1) / kBwImgs, 4), dim3(256), lds, reinterpret_cast<hipStream_t>(stream),
                        reinterpret_cast<const u32x4*>(img), reinterpret_cast<const bf16x8*>(dh1), dD, dDB, N, H, W);
     XMC_LAUNCH_CHECK();
     return 0;
