@@ -62,6 +62,7 @@ CONV_CASES = [
     (64, 64, 4, 2, 1, 32, 2),      # forward on the gather kernel, dgrad = 4 parity classes of 2x2 taps on the tile kernel
     (32, 64, 1, 1, 0, 32, 2),      # 1x1 shortcut
     (192, 32, 3, 1, 1, 64, 1),     # three slabs, 64x64 map
+    (128, 32, 3, 1, 1, 32, 2),     # the attention blocks' output convolution; its dgrad (32 -> 128): weights-resident kernel in two 64-channel halves
     # all-taps-per-tile weight-gradient kernel (conv_wgrad_tile.hip): Cin,Cout <= 64 on maps with W % 32 == 0
     (3, 32, 3, 1, 1, 32, 2),       # conv_img: Cin 3->8 (one padded 16-block)
     (32, 3, 3, 1, 1, 32, 2),       # conv_out: Cout 3->8

@@ -1150,6 +1150,13 @@ int xmc_conv_tile_try(const XmcConvDesc* d, void* stream) {
         rc = d->CDw == 64 ? launch_ptile<64>(*d, t, st) : launch_ptile<32>(*d, t, st);
         if (rc != XMC_ESHAPE) return rc;
     }
+    // 32 -> 128 channels, 3x3 (the data gradient of the attention blocks' 128 -> 32 output convolutions, df_concept_gan.py:146-160): two
+    // 64-channel halves over blockIdx.y, each with its half of the weights resident (the non-persistent tile kernel ran it at 227 TF/s)
+    static const bool no_pt128 = xmc_debug_off("no_ptile_cd128");
+    if (!no_pt && !no_pt128 && d->CS == 32 && t.slab == 32 && d->CDw == 128 && d->SA == 1 && d->nclass == 1 && d->ntaps == 9) {
+        rc = launch_ptile<64>(*d, t, st);
+        if (rc != XMC_ESHAPE) return rc;
+    }
     if (d->SA != 1) return 1;                         // stride 2 exists only in the persistent kernel
     if (d->CDw % 128 == 0) rc = launch_tile<128, 2, 2>(*d, t, st);
     else if (d->CDw % 64 == 0) rc = launch_tile<64, 4, 1>(*d, t, st);
