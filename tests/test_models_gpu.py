@@ -126,7 +126,11 @@ def test_train_iteration_parity(yml, over, batch, steps, mode):
     if mode == "bf16" and h.gen == "DF_GEN" and not h.spec_norm:
         # kernel error proper: first iteration against the oracle that rounds where the engine rounds
         _, _, q_outs = run_oracle_steps(h, PG, PD, batches[:1], eps=PARITY_EPS, quant=True)
-        ql = compare_losses(p_outs[0], q_outs[0], QTOL["loss"], QTOL["latol"])
+        # (MA-GP: the generator-step losses are evaluated on a discriminator that has taken the PENALTY's Adam step, a function of
+        # ||dD/dx||^6 whose rounding points the oracle only approximates -- x2 on their bar, as for the G gradients below.  Full
+        # widths, batch 8: errG_fake 5.9e-3 .. 1.4e-2 from the rounding oracle depending only on which of three bit-different but
+        # equally exact kernel choices run the first block, tests/diag numbers in DESIGN.md section 5)
+        ql = compare_losses(p_outs[0], q_outs[0], QTOL["loss"], QTOL["latol"], after_gp=2.0)
         qf = mean_abs_err(p_outs[0]["fake"], q_outs[0]["fake"])
         assert qf <= QTOL["fwd"], qf
         qd = compare_grads(tapD.records[0], q_outs[0]["grads_D"], QTOL["grad"], "quant D ", 2e-2, QTOL["agg"])
