@@ -33,8 +33,10 @@ extern "C" {
  * 5: xmc_conv_pw1x1_masked_src (the sign-mask pass as a by-product of the shortcut's data gradient).
  * 6: xmc_adam_step_scaled (dynamic loss scale with a found-inf skip); xmc_gp_finish gained inv_s2.
  * 7: xmc_dstem_* (the discriminator's stem composed into one convolution from the image).
- * 8: XmcConvDesc.mask_bits, xmc_conv_ptile_bits / xmc_conv_wgrad_bits (the sign mask applied in the consumers' staging). */
-#define XMC_ABI_VERSION 8
+ * 8: XmcConvDesc.mask_bits, xmc_conv_ptile_bits / xmc_conv_wgrad_bits (the sign mask applied in the consumers' staging).
+ * 9: XmcConvDesc.sc_img / sc_frag / sc_bias, xmc_conv_ptile_scimg, xmc_dstem_pack_sc (the stem block's shortcut recomputed from the image in
+ *    its block-end kernel); xmc_dstem_fwd accepts sc == NULL. */
+#define XMC_ABI_VERSION 9
 
 /* XMC_BF16 names the 16-bit storage / MFMA-operand format THIS BUILD of the library was compiled for: bf16 in
  * libxmc_gan_hip.so, IEEE half in libxmc_gan_hip_f16.so (same sources, same entry points; xmc_half_format()). */
@@ -125,6 +127,13 @@ typedef struct XmcConvDesc {
      *             gradient.  The kernel reads operand x LeakyReLU'(bits) (1 or 0.2, rounded to the 16-bit format as
      *             xmc_signmask_apply would store it) while it stages the operand: the masked tensor is never written. */
     const void* mask_bits;
+    /* sc_img / sc_frag / sc_bias (ABI 9; honoured by xmc_conv_ptile_scimg ONLY): the block sum's residual operand is not read from
+     *             `res` but recomputed per tile from the IMAGE: res = round16(W_B * img + sc_bias), the composed stem's shortcut
+     *             (a 4x4 stride-2 pad-1 convolution of the [N, 2 MH, 2 MW, 8] image `sc_img`, xmc_dstem_* above).  `sc_frag`: W_B as
+     *             MFMA fragments (xmc_dstem_pack_sc), `sc_bias`: f32 [64].  The shortcut tensor is never written or read. */
+    const void* sc_img;
+    const void* sc_frag;
+    const float* sc_bias;
 } XmcConvDesc;
 
 int xmc_abi_version(void);
@@ -213,6 +222,9 @@ int xmc_conv_pw1x1_masked_src(const XmcConvDesc* d, const void* src_bits, void* 
  * weight gradient (row-reuse kernel, W % 32 == 0, H % 8 == 0) apply d->mask_bits while they stage the gradient operand.  Return 1
  * when the shape is not theirs (the caller then runs xmc_signmask_apply and the plain entry), 0 on success, < 0 on error. */
 int xmc_conv_ptile_bits(const XmcConvDesc* d, void* stream);
+/* 64 -> 64 channel 3x3 block end (sign bits and / or pooled output) whose residual is d->sc_img's composed shortcut, recomputed per tile
+ * (16 extra MFMAs per wave) instead of read from d->res (must be NULL).  1 = not this kernel's shape. */
+int xmc_conv_ptile_scimg(const XmcConvDesc* d, void* stream);
 int xmc_conv_wgrad_bits(const XmcConvDesc* d, float* dwp, void* stream);
 int xmc_tanh_bwd(const void* dy, const void* y, void* dx, int64_t n, int dtype, void* stream);
 /* y = a + (*alpha_dev) * b                  (shortcut + gamma*residual, df_gan.py:200,284) */
@@ -469,6 +481,9 @@ int xmc_dstem_compose(const float* wi, const float* bi, const float* w0, const f
 int xmc_dstem_compose_bwd(const float* wi, const float* bi, const float* w0, const float* ws, const float* dW, const float* dbias,
                           const float* dD, const float* dDB, float* dwi, float* dbi, float* dw0, float* dws, float* dbs, void* stream);
 int xmc_dstem_pack(const float* wsets, void* wfrag, void* stream);
+/* rows 64..127 of the composed weights (the shortcut: its 4x4 window inside the 6x6 one) -> sc_frag (8 KB: 4 K steps x 2 row blocks of
+ * 32x32x16 A fragments, rows permuted as the block-end kernel's weight rows) */
+int xmc_dstem_pack_sc(const float* wsets, void* sc_frag, void* stream);
 int xmc_dstem_fwd(const void* img, const void* wfrag, const float* bias, void* h1, void* sc, int N, int H, int W, float slope, void* stream);
 int xmc_dstem_wgrad(const void* img, const void* dh1, const void* dsc, float* dw, float* dbias, int N, int H, int W, int skip_border,
                     void* stream);

@@ -29,13 +29,13 @@ def test_library_loads_and_exports_every_declared_symbol(variant):
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/xmc_gan_hip.h but not exported"
     assert set(L.EXPORTS) == declared
-    assert lib.xmc_abi_version() == L.ABI_VERSION == 8
+    assert lib.xmc_abi_version() == L.ABI_VERSION == 9
     assert lib.xmc_adam_step_scaled(None, 1, None, 1, 0.0, 0.0, 0.0, 0.0, None, None, 7, 2.0, 0.5, 1, None) == -1
     # argument validation happens before any launch, so it is safe without a GPU
     d = L.ConvDesc()
     assert lib.xmc_conv_igemm(ctypes.byref(d), None) == -1
     assert lib.xmc_conv_wgrad(ctypes.byref(d), None, None) == -1
-    assert ctypes.sizeof(L.ConvDesc) == 392 and ctypes.sizeof(L.AdamEntry) == 48 and ctypes.sizeof(L.PackJob) == 64   # = the C structs
+    assert ctypes.sizeof(L.ConvDesc) == 416 and ctypes.sizeof(L.AdamEntry) == 48 and ctypes.sizeof(L.PackJob) == 64   # = the C structs
     # the entry points added for the callers either side of the step reject bad arguments the same way (nothing launched)
     import numpy as np
     assert np.dtype(L.GEMM_PROBLEM).itemsize == 88                    # sizeof(XmcGemmProblem)

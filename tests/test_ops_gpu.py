@@ -1214,6 +1214,47 @@ def test_discriminator_stem_composition_kernels(N, H, W, mode):
     assert float(dimg[..., 3:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("mode", ["bf16", "f16"])
+@pytest.mark.parametrize("N,H,W,keep,pool", [(3, 64, 64, True, True), (2, 128, 192, True, True), (5, 64, 128, False, True), (2, 32, 64, True, False)])
+def test_block_end_recomputes_the_stem_shortcut_from_the_image(N, H, W, keep, pool, mode):
+    """XmcConvDesc.sc_img (xmc_conv_ptile_scimg): the first block's conv_r[2] + block sum with its residual -- the composed stem's
+    shortcut -- recomputed per tile from the image (16 MFMAs per wave on an 18 x 66 pixel patch) against the same launch reading the
+    shortcut tensor the stem kernel would have written: output, sign bytes and pooled output.  Also: the stem kernel asked for no
+    shortcut writes the same h1."""
+    ops.set_precision(mode)
+    dt = ops.act_dtype()
+    g = torch.Generator().manual_seed(N * 11 + H + W)
+    x = rt(torch.rand(N, 3, H, W, generator=g) * 2 - 1, mode)
+    w_img, b_img = torch.randn(32, 3, 3, 3, generator=g) / math.sqrt(27), torch.randn(32, generator=g) * 0.1
+    w0 = torch.randn(64, 32, 4, 4, generator=g) / math.sqrt(512)
+    ws, bs = torch.randn(64, 32, 1, 1, generator=g) / math.sqrt(32), torch.randn(64, generator=g) * 0.1
+    w2 = (torch.randn(64, 64, 3, 3, generator=g) / math.sqrt(576)).to(DEV)
+    wsets, bias, D, DB = ops.compose_dstem(w_img.to(DEV), b_img.to(DEV), w0.to(DEV), ws.to(DEV), bs.to(DEV))
+    xin = to_nhwc(x, 8, dt)
+    h1, sc = ops._dstem_fwd_raw(xin, wsets, bias)
+    h1b, none = ops._dstem_fwd_raw(xin, wsets, bias, want_sc=False)
+    assert none is None and torch.equal(h1, h1b)
+    g2 = ops.ConvGeom(64, 64, 3, 1, 1)
+    al = torch.tensor([0.59], device=DEV)
+    ref = ops._conv_fwd_raw(h1, w2, None, g2, L.ACT_LRELU, dt, res=sc, alpha=al, want_sign=keep, want_pool=pool, round_act=True)
+    got = ops._conv_fwd_raw(h1, w2, None, g2, L.ACT_LRELU, dt, alpha=al, want_sign=keep, want_pool=pool, round_act=True,
+                            sc_img=ops._dstem_sc_operands(xin, wsets, bias))
+    if not pool:                  # only the two block-end sets with a pooled output exist with a recomputed shortcut: declined, nothing launched
+        assert got is None
+        return
+    assert got is not None and L.load().xmc_last_kernel().decode().endswith("sc>")
+    # the shortcut's f32 sum is accumulated in another order (32x32x16 MFMAs over window rows, the stem kernel: 16x16x32 over tap pairs),
+    # so its rounding to the 16-bit format differs by one ulp on a few elements in a thousand: sign bytes equal, values to 1e-4
+    if keep:
+        assert torch.equal(got[1], ref[1])
+    for a, b in zip(got, ref):
+        if a.dtype != torch.uint8:
+            e = rel_l2(a, b)
+            assert e <= (2e-3 if mode == "bf16" else 2e-4), e
+            assert (a.float() - b.float()).abs().max() <= (2.0 ** -7 if mode == "bf16" else 2.0 ** -10) * b.float().abs().max()
+    ops.set_precision("bf16")
+
+
 @pytest.mark.parametrize("mode,N,S", [("f16", 3, 64), ("bf16", 2, 128), ("bf16", 8, 64)])
 def test_composed_stem_block_equals_conv_img_plus_block(mode, N, S):
     """ops.DStemBlockFn (conv_img + the first discriminator block on the composed stem, border pixels on strips) against the form it

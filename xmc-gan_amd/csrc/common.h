@@ -191,7 +191,7 @@ __device__ __forceinline__ void epilogue_tail(const XmcConvDesc& d, size_t idx8,
 // unit the weights-resident kernel measured 0.535 ms where the same launch with its options folded takes 0.450 (conv_tile.hip), so
 // the option sets that occur in the training step get an instantiation each and everything else goes through the generic one.
 constexpr int kEpiBias = 1, kEpiLrelu = 2, kEpiRound = 4, kEpiDst2 = 8, kEpiAlpha = 16, kEpiMask = 32, kEpiRes = 64, kEpiPost = 128, kEpiPool = 256,
-              kEpiSign = 512, kEpiDot = 1024;
+              kEpiSign = 512, kEpiDot = 1024, kEpiScImg = 2048;     // ScImg: the residual recomputed from the image (XmcConvDesc.sc_img)
 constexpr int kEpiGSum = kEpiBias | kEpiRound | kEpiAlpha | kEpiRes;                      // generator c2 + block sum (ops.GBlockEndFn)
 constexpr int kEpiDKeep = kEpiLrelu | kEpiDst2 | kEpiAlpha | kEpiRes | kEpiPool;          // discriminator conv_r[2] + block end, kept for a backward
 constexpr int kEpiDFwd = kEpiLrelu | kEpiRound | kEpiAlpha | kEpiRes | kEpiPool;          // ... forward only
@@ -205,7 +205,7 @@ static inline int xmc_epi_mask(const XmcConvDesc& d) {
     if ((d.act != XMC_ACT_NONE && d.act != XMC_ACT_LRELU) || d.out_dtype != XMC_BF16) return -1;
     return (d.bias ? kEpiBias : 0) | (d.act == XMC_ACT_LRELU ? kEpiLrelu : 0) | ((d.round_act && !d.dst2) ? kEpiRound : 0) | (d.dst2 ? kEpiDst2 : 0) |
            (d.alpha_dev ? kEpiAlpha : 0) | (d.mask ? kEpiMask : 0) | (d.res ? kEpiRes : 0) | (d.post_act == XMC_ACT_LRELU ? kEpiPost : 0) |
-           (d.dst_pool ? kEpiPool : 0) | (d.sign_bits ? kEpiSign : 0) | (d.dot ? kEpiDot : 0);
+           (d.dst_pool ? kEpiPool : 0) | (d.sign_bits ? kEpiSign : 0) | (d.dot ? kEpiDot : 0) | (d.sc_img ? kEpiScImg : 0);
 }
 
 // residual index (in 8-channel units) of destination pixel (n, y, x) for the three residual layouts; (a, b) is the pixel's

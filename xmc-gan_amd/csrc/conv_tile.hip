@@ -277,6 +277,11 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
     unsigned char* patch = smem;
     const int patch_bytes = (PH * PW * pstride + 15) & ~15;
     unsigned char* wall = smem + patch_bytes;                                            // [ntaps][BN][pstride]
+    // SCI: the residual is the composed stem's shortcut, recomputed from the image (XmcConvDesc.sc_img): an 18 x 66 pixel image patch
+    // (rows 2 a0 - 1 .., columns 2 b0 - 1 .., the first four channels = 8 bytes of each pixel, row-major) behind the weights
+    constexpr bool SCI = M32 && EPI >= 0 && (EPI & kEpiScImg) != 0;
+    constexpr int IPH = 18, IPW = 66, IPU = IPH * IPW;
+    unsigned char* ipatch = wall + MC * (NTAPS > 0 ? NTAPS : 1) * BN * pstride;
     const u32x4* __restrict__ src16 = reinterpret_cast<const u32x4*>(d.src);
     const u32x4* __restrict__ w16 = reinterpret_cast<const u32x4*>(d.wpk);
 
@@ -316,6 +321,17 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
             psrc[it] = in ? ((dh0 + py) * d.SW + (dw0 + px)) * cs_units + pchunk : 0;
             halo[it] = !in ? 0u : ((py < -dh0 ? 1u : 0u) | (py >= t.TH * SA - dh0 ? 2u : 0u) | (px < -dw0 ? 4u : 0u) | (px >= t.TW * SA - dw0 ? 8u : 0u));
         }
+        constexpr int IIT = SCI ? (IPU + NS - 1) / NS : 1;           // image-patch units per staging thread (5)
+        u32x2 iv[IIT];
+        unsigned ihalo = 0;                       // 4 bits per unit: the patch's first / last row / column (outside the image on that border)
+        if (SCI) {
+#pragma unroll
+            for (int it = 0; it < IIT; ++it) {
+                const int u = rt + it * NS, iy = u / IPW, ix = u - iy * IPW;
+                ihalo |= (u < IPU ? ((iy == 0 ? 1u : 0u) | (iy == IPH - 1 ? 2u : 0u) | (ix == 0 ? 4u : 0u) | (ix == IPW - 1 ? 8u : 0u)) : 15u) << (4 * it);
+            }
+        }
+        const u32x4* __restrict__ img16 = reinterpret_cast<const u32x4*>(d.sc_img);
         u32x4 pv[PIT];
         unsigned char pb8[PIT];                   // sign bytes of the staged units (XmcConvDesc.mask_bits: the source is a masked gradient)
         const unsigned char* __restrict__ bits8 = reinterpret_cast<const unsigned char*>(d.mask_bits);
@@ -337,6 +353,16 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
                 okmask |= ok ? (1u << it) : 0u;
             }
             okmask &= inpatch;
+            if (SCI) {
+                const int IW = 2 * d.SW;
+                const long long ibase = ((long long)img * (2 * d.SH) + 2 * a0 - 1) * IW + 2 * b0 - 1;
+#pragma unroll
+                for (int it = 0; it < IIT; ++it) {
+                    const int u = rt + it * NS, iy = u / IPW, ix = u - iy * IPW;
+                    const bool ok = u < IPU && (((ihalo >> (4 * it)) & 15u) & border) == 0;
+                    iv[it] = ok ? *reinterpret_cast<const u32x2*>(img16 + (ibase + (long long)iy * IW + ix)) : u32x2{0, 0};
+                }
+            }
         };
         auto commit = [&]() {
             const bool all_ok = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_ballot_w64(okmask != inpatch) == 0);
@@ -352,6 +378,11 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
                 if (bits8) v = xmc_apply_sign_bits(v, pb8[it]);
                 if (!all_ok && !((okmask >> it) & 1)) v = u32x4{0, 0, 0, 0};       // padding (border tiles only)
                 if ((inpatch >> it) & 1) *reinterpret_cast<u32x4*>(patch + lp * pstride + pchunk * 16) = v;
+            }
+            if (SCI) {
+#pragma unroll
+                for (int it = 0; it < IIT; ++it)
+                    if (rt + it * NS < IPU) *reinterpret_cast<u32x2*>(ipatch + (rt + it * NS) * 8) = iv[it];
             }
         };
         if (tile0 < ntiles) {
@@ -389,14 +420,26 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
         const bool e_dst2 = RT ? d.dst2 != nullptr : (EPI & kEpiDst2) != 0;
         const bool e_alpha = RT ? d.alpha_dev != nullptr : (EPI & kEpiAlpha) != 0;
         const bool e_mask = RT ? d.mask != nullptr : (EPI & kEpiMask) != 0;
-        const bool e_res = RT ? d.res != nullptr : (EPI & kEpiRes) != 0;
+        const bool e_res = SCI ? true : (RT ? d.res != nullptr : (EPI & kEpiRes) != 0);        // SCI: the residual vectors are computed, not loaded
         const bool e_post = RT ? d.post_act == XMC_ACT_LRELU : (EPI & kEpiPost) != 0;
         const bool e_pool = RT ? d.dst_pool != nullptr : (EPI & kEpiPool) != 0;
         constexpr bool e_sign = !RT && (EPI & kEpiSign) != 0;       // sign bits / dot: compile-time sets only (the launcher declines otherwise)
         constexpr bool e_dot = !RT && (EPI & kEpiDot) != 0;
         float dacc = 0.f;                                  // running sum for XmcConvDesc.dot over this workgroup's tiles
         const float slope = RT ? (d.act == XMC_ACT_LRELU ? XMC_LRELU : (d.act == XMC_ACT_RELU ? 0.f : 1.f)) : ((EPI & kEpiLrelu) ? XMC_LRELU : 1.f);
-        const float rs = d.res_scale == 0.f ? 1.f : d.res_scale;
+        const float rs = SCI ? 1.f : (d.res_scale == 0.f ? 1.f : d.res_scale);
+        // SCI: the shortcut's weights W_B as A fragments (K step = window row u: lane half hh holds taps (u, 2 hh), (u, 2 hh + 1) x 4 channels),
+        // in registers for the whole launch; the image fragment of (pixel block, u) is ONE ds_read_b128 at row 2 py + u, column 2 px + 2 hh
+        u32x4 scw[SCI ? 4 : 1][SCI ? NB : 1];
+        int ibyte[2] = {0, 0};
+        if (SCI) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int c = 0; c < NB; ++c) scw[u][c] = reinterpret_cast<const u32x4*>(d.sc_frag)[(u * NB + c) * 64 + lane];
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb) ibyte[pb] = ((2 * pty[pb]) * IPW + 2 * ptx[pb] + 2 * hh) * 8;
+        }
         __syncthreads();                          // weights + first patch staged
         int toffr[MC * NTAPS];
 #pragma unroll
@@ -424,6 +467,40 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
 #pragma unroll
                 for (int pb = 0; pb < 2; ++pb) eo[pb] = dbase + ((pty[pb] * d.DA) * d.DW + ptx[pb] * d.DA) * cd8;
                 bf16x8 mkv[NB][2][2], rrv[NB][2][2];
+                if (SCI) {
+                    // shortcut of this tile from the staged image patch: 4 K steps x 2 pixel blocks x NB channel blocks, then + bias and
+                    // rounded to the 16-bit format -- the values the stem kernel used to store and this epilogue used to load
+                    f32x16 sca[2][NB];
+#pragma unroll
+                    for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+                        for (int c = 0; c < NB; ++c)
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) sca[pb][c][e] = 0.f;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int pb = 0; pb < 2; ++pb) {
+                            const u32x4 xi = *reinterpret_cast<const u32x4*>(ipatch + u * IPW * 8 + ibyte[pb]);
+#pragma unroll
+                            for (int c = 0; c < NB; ++c)
+                                sca[pb][c] = XMC_MFMA_32x32x16(__builtin_bit_cast(bf16x8, scw[u][c]), __builtin_bit_cast(bf16x8, xi), sca[pb][c], 0, 0, 0);
+                        }
+#pragma unroll
+                    for (int c = 0; c < NB; ++c)
+#pragma unroll
+                        for (int v2 = 0; v2 < 2; ++v2) {
+                            const float* bp = d.sc_bias + n0 + 32 * c + 16 * hh + 8 * v2;
+                            const f32x4 b0v = *reinterpret_cast<const f32x4*>(bp), b1v = *reinterpret_cast<const f32x4*>(bp + 4);
+#pragma unroll
+                            for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    rrv[c][pb][v2][r] = (xmc_h16)(sca[pb][c][8 * v2 + r] + b0v[r]);
+                                    rrv[c][pb][v2][4 + r] = (xmc_h16)(sca[pb][c][8 * v2 + 4 + r] + b1v[r]);
+                                }
+                        }
+                }
 #pragma unroll
                 for (int c = 0; c < NB; ++c) {
                     const int ub = c * 4 + hh * 2;
@@ -434,7 +511,7 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
                         for (int v2 = 0; v2 < 2; ++v2) {
                             const size_t idx8 = (size_t)(eo[pb] + ub + v2);
                             if (e_mask) mkv[c][pb][v2] = reinterpret_cast<const bf16x8*>(d.mask)[idx8];
-                            if (e_res) {
+                            if (e_res && !SCI) {
                                 size_t rix = idx8;
                                 if (d.res_mode == 1) rix = (size_t)(rbase + (pty[pb] * d.MW + ptx[pb]) * cd8 + ub + v2);
                                 else if (d.res_mode == 2)
@@ -893,6 +970,8 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
 
 template <int BN>
 int launch_ptile(const XmcConvDesc& d, const TileCfg& t, hipStream_t st) {
+    // (a descriptor with sc_img is served by the 32x32x16 block-end sets below or not at all)
+    if (d.sc_img && !(d.SA == 1 && d.ntaps == 9 && d.nclass == 1 && t.slab == 64 && d.out_dtype == XMC_BF16 && (d.dst_pool || d.sign_bits))) return XMC_ESHAPE;
     int maxpatch = 0;
     for (int z = 0; z < d.nclass; ++z) maxpatch = t.PH[z] * t.PW[z] > maxpatch ? t.PH[z] * t.PW[z] : maxpatch;
     if (d.SA == 2) {                                                  // 4x4 stride 2, 32 input channels: 612-pixel patch in planes
@@ -991,6 +1070,20 @@ int launch_ptile(const XmcConvDesc& d, const TileCfg& t, hipStream_t st) {
         int epi = xmc_epi_mask(d);
         static const bool no_epi = xmc_debug_off("no_ptile_epi");
         if (no_epi) epi = -1;
+        if (d.sc_img) {                           // the residual recomputed from the image (xmc_conv_ptile_scimg): two block-end sets, 8 x 32 tiles
+            if (BN != 64 || d.res || t.TW != 32 || d.CD != 64 || lds + 18 * 66 * 8 > XMC_MAX_DYN_LDS) return XMC_ESHAPE;
+#define XMC_PT3_SCI(E)                                                                                                   \
+            if (epi == (E)) {                                                                                            \
+                XMC_ALLOW_BIG_LDS((ptile3_kernel<64, 64, 9, 1, 1, true, (E)>));                                          \
+                hipLaunchKernelGGL((ptile3_kernel<64, 64, 9, 1, 1, true, (E)>), grid, dim3(512), lds + 18 * 66 * 8, st, d, t, ntiles); \
+                xmc_note_kernel("ptile3_kernel<64, 64, 9, 1, 1, true, sc>");                                             \
+                XMC_LAUNCH_CHECK();                                                                                      \
+                return 0;                                                                                                \
+            }
+            XMC_PT3_SCI((kEpiDKeepS & ~kEpiRes) | kEpiScImg) XMC_PT3_SCI((kEpiDFwd & ~kEpiRes) | kEpiScImg)
+#undef XMC_PT3_SCI
+            return XMC_ESHAPE;
+        }
 #define XMC_PT3_EPI(E)                                                                                                   \
         if (epi == (E)) {                                                                                                \
             XMC_ALLOW_BIG_LDS((ptile3_kernel<BN, 64, 9, 1, 1, true, (E)>));                                              \
@@ -1113,6 +1206,22 @@ int xmc_conv_ptile_pool_try(const XmcConvDesc* d, void* stream) {
     if (!(d->CS <= 64 && t.slab == d->CS && d->CDw <= 64) || xmc_debug_off("no_ptile")) return 1;
     const int rc = d->CDw == 64 ? launch_ptile<64>(*d, t, reinterpret_cast<hipStream_t>(stream))
                                 : launch_ptile<32>(*d, t, reinterpret_cast<hipStream_t>(stream));
+    return rc == XMC_ESHAPE ? 1 : rc;
+}
+
+// block end whose residual is recomputed from the image (XmcConvDesc.sc_img): the 32x32x16 role of the persistent kernel only
+extern "C" int xmc_conv_ptile_scimg(const XmcConvDesc* d, void* stream) {
+    if (!d || !d->src || !d->wpk || !d->dst || !d->sc_img || !d->sc_frag || !d->sc_bias) return XMC_EINVAL;
+    static const bool off = xmc_debug_off("no_scimg");
+    if (off || d->res || d->dtype != XMC_BF16 || d->out_dtype != XMC_BF16 || d->SA != 1 || d->DA != 1 || d->nclass != 1 || d->ntaps != 9 ||
+        d->src_shift != 0 || d->CS != 64 || d->CDw != 64 || d->CD != 64 || d->MW % 32 != 0 || d->MH % 8 != 0 || d->SH != d->MH || d->SW != d->MW ||
+        d->DH != d->MH || d->DW != d->MW || xmc_debug_off("no_ptile") || xmc_debug_off("no_ptile_m32") || xmc_debug_off("no_ptile_epi"))
+        return 1;
+    for (int k = 0; k < 9; ++k)
+        if (d->dh[0][k] < -1 || d->dh[0][k] > 1 || d->dw[0][k] < -1 || d->dw[0][k] > 1) return 1;
+    TileCfg t;
+    if (!tile_plan(d, &t) || t.slab != 64) return 1;
+    const int rc = launch_ptile<64>(*d, t, reinterpret_cast<hipStream_t>(stream));
     return rc == XMC_ESHAPE ? 1 : rc;
 }
 

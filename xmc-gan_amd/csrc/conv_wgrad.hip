@@ -244,7 +244,7 @@ extern "C" int xmc_conv_wgrad_bias(const XmcConvDesc* d, float* dwp, float* dbia
     if ((d->CS * esz) % 16 != 0 || (d->CD * esz) % 16 != 0 || d->CDw % 32 != 0 || d->CDw < d->CD) return XMC_EALIGN;
     if (d->N < 1 || d->MH < 1 || d->MW < 1 || d->SH < 1 || d->SW < 1) return XMC_ESHAPE;
     if (d->src_shift < 0 || d->src_shift > 1 || d->SA < 1) return XMC_ESHAPE;
-    if (d->mask_bits) return XMC_EINVAL;                        // only xmc_conv_wgrad_bits applies it
+    if (d->mask_bits || d->sc_img) return XMC_EINVAL;           // only xmc_conv_wgrad_bits / xmc_conv_ptile_scimg honour them
     {
         int rc = xmc_conv_wgrad_up_try(d, dwp, dbias, stream);       // 3x3 through a x2 upsample: 16 low-resolution products
         if (rc != 1) return rc;

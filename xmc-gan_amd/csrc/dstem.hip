@@ -38,6 +38,22 @@ __global__ void dstem_pack_kernel(const float* __restrict__ w, bf16x8* __restric
     frag[id] = o;
 }
 
+// the shortcut's weights (rows 64..127 of the composed table: a 4x4 stride-2 pad-1 window inside the 6x6 one) as A fragments of
+// v_mfma_f32_32x32x16 for the block-end kernel that recomputes the shortcut (conv_tile.hip, XmcConvDesc.sc_img): fragment (u, c), lane
+// (rho = lane & 31, hh = lane >> 5) holds W[64 + co][window tap (u + 1, 2 hh + 1)][0..3] | W[64 + co][(u + 1, 2 hh + 2)][0..3] with
+// co = 32 c + 16 ((rho >> 2) & 1) + 4 (rho >> 3) + (rho & 3) -- the row permutation of that kernel's own weight rows
+__global__ void dstem_pack_sc_kernel(const float* __restrict__ w, bf16x8* __restrict__ frag) {
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= 4 * 2 * 64) return;
+    const int lane = id & 63, f = id >> 6, u = f >> 1, c = f & 1;
+    const int rho = lane & 31, hh = lane >> 5;
+    const int co = 32 * c + 16 * ((rho >> 2) & 1) + 4 * (rho >> 3) + (rho & 3);
+    bf16x8 o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = (xmc_h16)w[((size_t)(64 + co) * kTaps + (u + 1) * 6 + 2 * hh + 1 + (k >> 2)) * 8 + (k & 3)];
+    frag[id] = o;
+}
+
 // Persistent 8-wave workgroup, tile = 4 output rows x 32 output columns.  Wave (rp = w & 1, cq = w >> 1) owns output rows 2 rp,
 // 2 rp + 1 of the tile (four 16-pixel blocks) and 32 of the 128 output channels, and keeps ITS weights -- 5 K steps x 2 row blocks
 // of A fragments, 40 registers -- for the whole launch: the K loop reads only pixel fragments from LDS.  Only the first four channels
@@ -103,6 +119,7 @@ __global__ __launch_bounds__(512, 4) void dstem_fwd_kernel(const u32x4* __restri
             if (tid + it * 512 < PUNITS) patch[buf][tid + it * 512] = pv[it];
         __syncthreads();
         if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);
+        if (dst == nullptr) continue;             // shortcut not wanted (recomputed by its consumer): these waves only stage
         f32x4 acc[4][2];
 #pragma unroll
         for (int b = 0; b < 4; ++b)
@@ -837,9 +854,16 @@ extern "C" int xmc_dstem_pack(const float* wsets, void* wfrag, void* stream) {
     return 0;
 }
 
+extern "C" int xmc_dstem_pack_sc(const float* wsets, void* sc_frag, void* stream) {
+    if (!wsets || !sc_frag) return XMC_EINVAL;
+    hipLaunchKernelGGL(dstem_pack_sc_kernel, dim3(2), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), wsets, reinterpret_cast<bf16x8*>(sc_frag));
+    XMC_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int xmc_dstem_fwd(const void* img, const void* wfrag, const float* bias, void* h1, void* sc, int N, int H, int W, float slope,
                              void* stream) {
-    if (!img || !wfrag || !bias || !h1 || !sc || N < 1) return XMC_EINVAL;
+    if (!img || !wfrag || !bias || !h1 || N < 1) return XMC_EINVAL;
     if (H < 8 || W < 64 || H % 8 != 0 || W % 64 != 0) return XMC_ESHAPE;
     const int ntiles = N * (H / 8) * (W / 64);
     const int grid = ntiles < 512 ? ntiles : 512;

@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("XMC_LIB_PATH", os.path.join(HERE, "libxmc_gan_hip.so"))   # override: kernel experiments
 LIB_PATH_F16 = os.environ.get("XMC_LIB_PATH_F16", os.path.join(HERE, "libxmc_gan_hip_f16.so"))
-ABI_VERSION = 8          # include/xmc_gan_hip.h XMC_ABI_VERSION; the ctypes structures below mirror that version
+ABI_VERSION = 9          # include/xmc_gan_hip.h XMC_ABI_VERSION; the ctypes structures below mirror that version
 
 # BF16 is the dtype code of "the 16-bit storage format of the loaded build": bf16 in libxmc_gan_hip.so, IEEE half in
 # libxmc_gan_hip_f16.so (the same sources compiled with -DXMC_H16_IS_F16; `use_variant`)
@@ -31,7 +31,7 @@ class ConvDesc(C.Structure):
                 ("wi", (C.c_int8 * MAX_TAPS) * MAX_CLASSES),
                 ("dph", C.c_int8 * MAX_CLASSES), ("dpw", C.c_int8 * MAX_CLASSES),
                 ("mask", vp), ("res_scale", f32), ("res_mode", i32), ("dst2", vp), ("dst_pool", vp), ("round_act", i32), ("groups", i32),
-                ("post_act", i32), ("pool_scale", f32), ("sign_bits", vp), ("dot", vp), ("mask_bits", vp)]
+                ("post_act", i32), ("pool_scale", f32), ("sign_bits", vp), ("dot", vp), ("mask_bits", vp), ("sc_img", vp), ("sc_frag", vp), ("sc_bias", vp)]
 
 
 # XmcGemmProblem as a numpy record (filled vectorised on the host, handed to xmc_gemm_group by pointer)
@@ -75,6 +75,7 @@ _SIGS = {
     "xmc_signmask_apply": [vp, vp, vp, i64, f32, i32, vp],
     "xmc_conv_pw1x1_masked_src": [C.POINTER(ConvDesc), vp, vp, f32, vp],
     "xmc_conv_ptile_bits": [C.POINTER(ConvDesc), vp],
+    "xmc_conv_ptile_scimg": [C.POINTER(ConvDesc), vp],
     "xmc_conv_wgrad_bits": [C.POINTER(ConvDesc), vp, vp],
     "xmc_tanh_bwd": [vp, vp, vp, i64, i32, vp],
     "xmc_axpby": [vp, vp, vp, vp, i64, i32, vp],
@@ -130,6 +131,7 @@ _SIGS = {
     "xmc_dstem_compose": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "xmc_dstem_compose_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "xmc_dstem_pack": [vp, vp, vp],
+    "xmc_dstem_pack_sc": [vp, vp, vp],
     "xmc_dstem_fwd": [vp, vp, vp, vp, vp, i32, i32, i32, f32, vp],
     "xmc_dstem_wgrad": [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "xmc_dstem_border_fwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp],

@@ -465,10 +465,12 @@ def _upconv_dgrad_raw(dy, w, geom, in_dtype):
 
 
 def _conv_fwd_raw(x, w, bias, geom, act, out_dtype, res=None, alpha=None, up=False, res_mode=0, want2=False, want_pool=False,
-                  round_act=False, mask=None, out=None, post_act=L.ACT_NONE, want_sign=False):
+                  round_act=False, mask=None, out=None, post_act=L.ACT_NONE, want_sign=False, sc_img=None):
     """y = act(conv(x, w) + bias) [*alpha] [+ res]; x [N,H,W,Cs]. ``up``: x is read through a fused nearest x2.
     ``res_mode`` 2: res is [N,OH/2,OW/2,C] and read through a nearest x2.  ``want2``: also return act(conv + bias) itself (the
-    branch value before alpha / res);  ``want_pool``: also return avg_pool2d(y, 2).  Extras are appended: (y[, y2][, ypool])."""
+    branch value before alpha / res);  ``want_pool``: also return avg_pool2d(y, 2).  Extras are appended: (y[, y2][, ypool]).
+    ``sc_img`` = (image [N,2 OH,2 OW,8], sc_frag, sc_bias): the residual is the composed stem's shortcut, recomputed from the image inside the
+    kernel (XmcConvDesc.sc_img, xmc_conv_ptile_scimg) -- returns None when the kernel declines the shape."""
     _need_cuda(x, w)
     N, H, W, CS = x.shape
     sh = 1 if up else 0
@@ -519,6 +521,17 @@ def _conv_fwd_raw(x, w, bias, geom, act, out_dtype, res=None, alpha=None, up=Fal
         yp = torch.empty((N, OH // 2, OW // 2, cd_p), dtype=out_dtype, device=x.device)
         d.dst_pool = yp.data_ptr()
         outs.append(yp)
+    if sc_img is not None:
+        img, frag, sbias = sc_img
+        assert res is None and tuple(img.shape) == (N, 2 * OH, 2 * OW, 8) and img.dtype == x.dtype and img.is_contiguous()
+        d.sc_img, d.sc_frag, d.sc_bias = img.data_ptr(), frag.data_ptr(), sbias.data_ptr()
+        with prof.launch("igemm_kernel (conv fwd+dgrad, MFMA implicit GEMM)", 2.0 * N * OH * OW * geom.cout * (geom.cin * geom.k * geom.k + 48),
+                         f"fwd+sc {x.dtype} N{N} {H}x{W} {geom.cin}->{geom.cout} k{geom.k}s{geom.s}", _nbytes(x, wpk, img, *outs)):
+            rc = L.load().xmc_conv_ptile_scimg(C.byref(d), _st())
+        if rc == 1:
+            return None
+        L.check(rc, "xmc_conv_ptile_scimg")
+        return y if len(outs) == 1 else tuple(outs)
     with prof.launch("igemm_kernel (conv fwd+dgrad, MFMA implicit GEMM)", 2.0 * N * OH * OW * geom.cout * geom.cin * geom.k * geom.k,
                      f"fwd {x.dtype} N{N} {H}x{W} {geom.cin}->{geom.cout} k{geom.k}s{geom.s}", _nbytes(x, wpk, res, mask, *outs)):
         L.check(L.load().xmc_conv_igemm(C.byref(d), _st()), "xmc_conv_igemm(fwd)")
@@ -866,19 +879,26 @@ def _dstem_compose_bwd_raw(w_img, b_img, w0, ws, bs, dW, dbias, dD, dDB):
     return dwi, dbi, dw0, dws, dbs
 
 
-def _dstem_fwd_raw(xin, wsets, bias, slope=0.2):
+def _dstem_fwd_raw(xin, wsets, bias, slope=0.2, want_sc=True):
     """h1 = lrelu(W_A * x + b_A) [N,H/2,W/2,64], sc = W_B * x + b_B [N,H/2,W/2,64] from the image xin [N,H,W,8] (border pixels of h1
-    are the composition's, not the reference's: see DStemBlockFn)."""
+    are the composition's, not the reference's: see DStemBlockFn).  ``want_sc`` False: sc is None (its consumer recomputes it)."""
     _need_cuda(xin, wsets)
     N, H, W, _ = xin.shape
     wfrag = torch.empty(8 * 5 * 64 * 8, dtype=xin.dtype, device=xin.device)         # 8 row blocks x 5 K steps of MFMA A fragments
     L.call("xmc_dstem_pack", _p(wsets), _p(wfrag), _st())
     h1 = torch.empty((N, H // 2, W // 2, 64), dtype=xin.dtype, device=xin.device)
-    sc = torch.empty_like(h1)
-    with prof.launch("igemm_kernel (conv fwd+dgrad, MFMA implicit GEMM)", 2.0 * N * (H // 2) * (W // 2) * 64 * (3 * 36 + 3 * 16 + 32 * 16 * 0),
-                     f"dstem-fwd {xin.dtype} N{N} {H}x{W} 3->64+64 k6s2", _nbytes(xin, h1, sc)):
+    sc = torch.empty_like(h1) if want_sc else None
+    with prof.launch("igemm_kernel (conv fwd+dgrad, MFMA implicit GEMM)", 2.0 * N * (H // 2) * (W // 2) * 64 * (3 * 36 + (3 * 16 if want_sc else 0)),
+                     f"dstem-fwd {xin.dtype} N{N} {H}x{W} 3->64{'+64' if want_sc else ''} k6s2", _nbytes(xin, h1, sc)):
         L.call("xmc_dstem_fwd", _p(xin), _p(wfrag), _p(bias), _p(h1), _p(sc), N, H, W, float(slope), _st())
     return h1, sc
+
+
+def _dstem_sc_operands(xin, wsets, bias):
+    """(image, sc_frag, sc_bias) for `_conv_fwd_raw(sc_img=...)`: the shortcut rows of the composed table as the block-end kernel's MFMA fragments"""
+    frag = torch.empty(4 * 2 * 64 * 8, dtype=xin.dtype, device=xin.device)
+    L.call("xmc_dstem_pack_sc", _p(wsets), _p(frag), _st())
+    return xin, frag, bias[64:128]
 
 
 def _dstem_border_fwd_raw(xin, wsets, bias, D, DB, h1, slope=0.2):
@@ -1751,12 +1771,22 @@ class DStemBlockFn(torch.autograd.Function):
         N, H, W, _ = xin.shape
         OH, OW = H // 2, W // 2
         wsets, bias, D, DB = _dstem_compose_raw(w_img, b_img, w0, ws, bs)
-        h1, sc = _dstem_fwd_raw(xin, wsets, bias)
-        _dstem_border_fwd_raw(xin, wsets, bias, D, DB, h1)          # conv_r[0]'s zero padding of conv_img's output: 3 % of the pixels
         al = gamma.detach().reshape(-1).float()
         keep = any(ctx.needs_input_grad[:8])
-        pool_ok = want_pool and res_pool_ok(h1, g2)
-        r = _conv_fwd_raw(h1, w2, None, g2, L.ACT_LRELU, dt, res=sc, alpha=al, want_sign=keep, want_pool=pool_ok, round_act=True)
+        pool_ok = want_pool and H % 4 == 0 and W % 4 == 0
+        # the shortcut (0.54 GB per 256 images, written here and read once by the block end) is recomputed from the image inside the
+        # block-end kernel where that kernel takes the shape: 16 more MFMAs per wave and tile on an 18 x 66 pixel image patch
+        fuse_sc = pool_ok and OH % 8 == 0 and OW % 32 == 0 and "no_scimg" not in _DEBUG_DISPATCH      # (its two epilogue sets write the pooled output)
+        h1, sc = _dstem_fwd_raw(xin, wsets, bias, want_sc=not fuse_sc)
+        _dstem_border_fwd_raw(xin, wsets, bias, D, DB, h1)          # conv_r[0]'s zero padding of conv_img's output: 3 % of the pixels
+        assert pool_ok == (want_pool and res_pool_ok(h1, g2))
+        if fuse_sc:
+            r = _conv_fwd_raw(h1, w2, None, g2, L.ACT_LRELU, dt, alpha=al, want_sign=keep, want_pool=pool_ok, round_act=True,
+                              sc_img=_dstem_sc_operands(xin, wsets, bias))
+            if r is None:
+                raise RuntimeError("xmc_conv_ptile_scimg declined a shape DStemBlockFn expects it to take")
+        else:
+            r = _conv_fwd_raw(h1, w2, None, g2, L.ACT_LRELU, dt, res=sc, alpha=al, want_sign=keep, want_pool=pool_ok, round_act=True)
         r = r if isinstance(r, tuple) else (r,)
         out = r[0]
         bits = r[1] if keep else None
