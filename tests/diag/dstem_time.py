@@ -35,6 +35,7 @@ for N in (256, 512):
     bi, bsp = ops._bias_padded(b_img, g_img), ops._bias_padded(bs, gs)
     print(f"N{N} {H}x{W}")
     timeit("composed stem forward (h1, sc)", lambda: ops._dstem_fwd_raw(x, wsets, bias))
+    timeit("  ... h1 only (shortcut recomputed by the block end)", lambda: ops._dstem_fwd_raw(x, wsets, bias, want_sc=False))
     h1_, _ = ops._dstem_fwd_raw(x, wsets, bias)
     timeit("  + border pixels of h1", lambda: ops._dstem_border_fwd_raw(x, wsets, bias, D, DB, h1_))
     ci, cip = ops._conv_fwd_raw(x, w_img, bi, g_img, L.ACT_NONE, dt, want_pool=True)

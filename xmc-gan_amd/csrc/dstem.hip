@@ -63,13 +63,17 @@ __global__ void dstem_pack_sc_kernel(const float* __restrict__ w, bf16x8* __rest
 // 16-byte slots, and the window's 36 taps are 4.5 K steps of 32 (the first version's K was tap x 8 channels: 9 steps, 5 of 8
 // values zero).  Double-buffered patch, next tile prefetched into registers: one barrier per tile; <= 128 registers, so two
 // workgroups share a CU and one's wait for its prefetch is the other's K loop.
+// H1ONLY (the shortcut is recomputed by its consumer, XmcConvDesc.sc_img): all eight waves on h1 -- wave (row = w & 3, cq = w >> 2) owns ONE
+// tile row (two 16-pixel blocks) and 32 of the 64 channels.
+template <bool H1ONLY>
 __global__ __launch_bounds__(512, 4) void dstem_fwd_kernel(const u32x4* __restrict__ img, const u32x4* __restrict__ frag, const float* __restrict__ bias,
                                                           bf16x8* __restrict__ h1, bf16x8* __restrict__ sc, int N, int H, int W, float slope, int ntiles) {
     constexpr int TR = 4, TC = 32, PR = 2 * TR + 4, PC = 2 * TC + 4;                      // 12 x 68 patch
     constexpr int PUNITS = PR * PC;                                                       // 816 eight-byte units
     __shared__ __attribute__((aligned(16))) u32x2 patch[2][PUNITS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int rp = wave & 1, cq = wave >> 1;
+    constexpr int NBLK = H1ONLY ? 2 : 4;         // 16-pixel blocks per wave
+    const int rp = H1ONLY ? (wave & 3) : (wave & 1), cq = H1ONLY ? (wave >> 2) : (wave >> 1);
     const int p = lane & 15, g = lane >> 4;
     const int OH = H >> 1, OW = W >> 1;
     const int tiles_x = OW / TC, tpi = (OH / TR) * tiles_x;
@@ -87,7 +91,7 @@ __global__ __launch_bounds__(512, 4) void dstem_fwd_kernel(const u32x4* __restri
         const int m = 4 * s + g, mm = m < kTaps / 2 ? m : 0;
         toff[s] = (mm / 3) * PC + 2 * (mm % 3);
     }
-    const int pbase = 4 * rp * PC + 2 * p;                    // output pixel (row 2 rp, column p): block b = (row b >> 1, columns 16 (b & 1) ..)
+    const int pbase = (H1ONLY ? 2 : 4) * rp * PC + 2 * p;     // output pixel (first row of the wave, column p): block b = (row b >> 1, columns 16 (b & 1) ..)
 
     // staging: units u = tid, tid + 512 (816 of them)
     int urow[2], ucol[2];
@@ -119,17 +123,16 @@ __global__ __launch_bounds__(512, 4) void dstem_fwd_kernel(const u32x4* __restri
             if (tid + it * 512 < PUNITS) patch[buf][tid + it * 512] = pv[it];
         __syncthreads();
         if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);
-        if (dst == nullptr) continue;             // shortcut not wanted (recomputed by its consumer): these waves only stage
-        f32x4 acc[4][2];
+        f32x4 acc[NBLK][2];
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
+        for (int b = 0; b < NBLK; ++b)
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[b][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         const u32x2* pp = patch[buf] + pbase;
 #pragma unroll
         for (int s = 0; s < kKSteps; ++s) {
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
+            for (int b = 0; b < NBLK; ++b) {
                 const u32x4 bf = *reinterpret_cast<const u32x4*>(pp + toff[s] + (b >> 1) * 2 * PC + (b & 1) * 32);
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
@@ -138,9 +141,9 @@ __global__ __launch_bounds__(512, 4) void dstem_fwd_kernel(const u32x4* __restri
         }
         // lane (p, g): channels cq * 32 + g * 8 + [0, 8) (row block 0: the first four, row block 1: the last four)
         const int n = tile / tpi, trem = tile - n * tpi;
-        const int oy0 = (trem / tiles_x) * TR + 2 * rp, ox0 = (trem % tiles_x) * TC + p;
+        const int oy0 = (trem / tiles_x) * TR + (H1ONLY ? 1 : 2) * rp, ox0 = (trem % tiles_x) * TC + p;
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
+        for (int b = 0; b < NBLK; ++b) {
             const size_t pix = ((size_t)n * OH + oy0 + (b >> 1)) * OW + ox0 + (b & 1) * 16;
             bf16x8 o;
 #pragma unroll
@@ -867,9 +870,14 @@ extern "C" int xmc_dstem_fwd(const void* img, const void* wfrag, const float* bi
     if (H < 8 || W < 64 || H % 8 != 0 || W % 64 != 0) return XMC_ESHAPE;
     const int ntiles = N * (H / 8) * (W / 64);
     const int grid = ntiles < 512 ? ntiles : 512;
-    hipLaunchKernelGGL(dstem_fwd_kernel, dim3(grid), dim3(512), 0, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const u32x4*>(img),
-                       reinterpret_cast<const u32x4*>(wfrag), bias, reinterpret_cast<bf16x8*>(h1), reinterpret_cast<bf16x8*>(sc), N, H, W, slope,
-                       ntiles);
+    if (sc)
+        hipLaunchKernelGGL(dstem_fwd_kernel<false>, dim3(grid), dim3(512), 0, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const u32x4*>(img),
+                           reinterpret_cast<const u32x4*>(wfrag), bias, reinterpret_cast<bf16x8*>(h1), reinterpret_cast<bf16x8*>(sc), N, H, W, slope,
+                           ntiles);
+    else
+        hipLaunchKernelGGL(dstem_fwd_kernel<true>, dim3(grid), dim3(512), 0, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const u32x4*>(img),
+                           reinterpret_cast<const u32x4*>(wfrag), bias, reinterpret_cast<bf16x8*>(h1), reinterpret_cast<bf16x8*>(sc), N, H, W, slope,
+                           ntiles);
     xmc_note_kernel("dstem_fwd_kernel");
     XMC_LAUNCH_CHECK();
     return 0;
