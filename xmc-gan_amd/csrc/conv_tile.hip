@@ -267,6 +267,14 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
     const int PH = MC > 1 ? t.PHu : t.PH[cls], PW = MC > 1 ? t.PWu : t.PW[cls];
     const int dh0 = MC > 1 ? t.dh0u : t.dh0[cls], dw0 = MC > 1 ? t.dw0u : t.dw0[cls];
     __shared__ int s_toff[XMC_MAX_TAPS];          // [class * ntaps + tap]
+    // 32x32x16 role: the bias vectors of this workgroup's channels (the convolution's, and the recomputed shortcut's) in LDS -- read from
+    // global memory inside the epilogue they were a round trip per tile between the last MFMA and the first store
+    __shared__ __attribute__((aligned(16))) float s_bias[M32 ? 2 * BN : 4];
+    if (M32 && tid >= 64 && tid < 64 + BN) {
+        const int ch = n0 + tid - 64;
+        s_bias[tid - 64] = (d.bias && ch < d.CD) ? d.bias[ch] : 0.f;
+        s_bias[BN + tid - 64] = (d.sc_bias && ch < d.CD) ? d.sc_bias[ch] : 0.f;
+    }
     if (tid < XMC_MAX_TAPS) {
         const int sl = tid < MC * d.ntaps ? tid : 0;
         const int c = MC > 1 ? sl / d.ntaps : cls, tt = MC > 1 ? sl % d.ntaps : sl;
@@ -490,7 +498,7 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
                     for (int c = 0; c < NB; ++c)
 #pragma unroll
                         for (int v2 = 0; v2 < 2; ++v2) {
-                            const float* bp = d.sc_bias + n0 + 32 * c + 16 * hh + 8 * v2;
+                            const float* bp = s_bias + BN + 32 * c + 16 * hh + 8 * v2;
                             const f32x4 b0v = *reinterpret_cast<const f32x4*>(bp), b1v = *reinterpret_cast<const f32x4*>(bp + 4);
 #pragma unroll
                             for (int pb = 0; pb < 2; ++pb)
@@ -564,7 +572,7 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
 #pragma unroll
                             for (int r = 0; r < 8; ++r) v[r] = acc[pb][c][8 * v2 + r];
                             if (e_bias) {
-                                const float* bp = d.bias + n0 + (ub + v2) * 8;
+                                const float* bp = s_bias + (ub + v2) * 8;
                                 const f32x4 b0v = *reinterpret_cast<const f32x4*>(bp), b1v = *reinterpret_cast<const f32x4*>(bp + 4);
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) { v[r] += b0v[r]; v[4 + r] += b1v[r]; }
