@@ -13,7 +13,8 @@
 namespace {
 
 constexpr int GT = 64;       // C tile is GT x GT
-constexpr int GK = 16;       // reduction chunk
+constexpr int GK = 64;       // reduction chunk per barrier pair: four 16-row loads per operand in flight at once (at 16 a launch was 16 serial
+                             // global round trips: ~45 us for 2 GFLOP; the MLP bank is 10 launches per iteration)
 constexpr int GLD = GT + 4;  // LDS row pitch (floats): 16-byte aligned rows, float4 reads conflict-free across the 16 tx / ty groups
 
 __device__ __forceinline__ void load_tile(float (*dst)[GLD], const float* __restrict__ base, int s_i, int s_r, int i0, int r0,
@@ -54,50 +55,48 @@ __global__ __launch_bounds__(256) void gemm_group_kernel(const ProbChunk chunk, 
     const int ntn = (p.N + GT - 1) / GT;
     const int lt = tile - p.tile0, ti = lt / ntn, tj = lt - ti * ntn;
     const int i0 = ti * GT, j0 = tj * GT;
-    const int tx = tid & 15, ty = tid >> 4;
-
-    float acc[4][4];
+    // v_mfma_f32_16x16x4_f32 (exact f32 products and sums, twice the plain-FMA rate: the bank is 2 GFLOP per launch and was
+    // VALU-bound at ~65 % of the vector peak, 44 us a launch).  Wave w owns rows [16 w, 16 w + 16) of the tile and its four 16-column
+    // blocks; lane (c = lane & 15, kq = lane >> 4) feeds A[row c][k0 + kq] and B[k0 + kq][16 jb + c] and ends with rows 4 kq + r of
+    // column c of each block.
+    const int lane = tid & 63, wv = tid >> 6, c16 = lane & 15, kq = lane >> 4;
+    f32x4 acc[4];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
-    float rs[4] = {0.f, 0.f, 0.f, 0.f};
-    const bool want_rs = p.rowsum != nullptr && tj == 0 && tx == 0;
+    for (int b = 0; b < 4; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float rs = 0.f;
+    const bool want_rs = p.rowsum != nullptr && tj == 0;
 
     for (int r0 = 0; r0 < p.K; r0 += GK) {
-        load_tile(As, p.A, p.sa_i, p.sa_r, i0, r0, p.M, p.K, tid);
-        load_tile(Bs, p.B, p.sb_j, p.sb_r, j0, r0, p.N, p.K, tid);
+#pragma unroll
+        for (int q = 0; q < GK / 16; ++q) {
+            load_tile(As + 16 * q, p.A, p.sa_i, p.sa_r, i0, r0 + 16 * q, p.M, p.K, tid);
+            load_tile(Bs + 16 * q, p.B, p.sb_j, p.sb_r, j0, r0 + 16 * q, p.N, p.K, tid);
+        }
         __syncthreads();
 #pragma unroll
-        for (int r = 0; r < GK; ++r) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(&As[r][ty * 4]);
-            const f32x4 b = *reinterpret_cast<const f32x4*>(&Bs[r][tx * 4]);
+        for (int k0 = 0; k0 < GK; k0 += 4) {
+            const float a = As[k0 + kq][wv * 16 + c16];
 #pragma unroll
-            for (int x = 0; x < 4; ++x)
-#pragma unroll
-                for (int y = 0; y < 4; ++y) acc[x][y] += a[x] * b[y];
-            if (want_rs) {
-#pragma unroll
-                for (int x = 0; x < 4; ++x) rs[x] += a[x];
-            }
+            for (int b = 0; b < 4; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Bs[k0 + kq][b * 16 + c16], acc[b], 0, 0, 0);
+            rs += a;
         }
         __syncthreads();
     }
 
-    if (want_rs) {
-#pragma unroll
-        for (int x = 0; x < 4; ++x)
-            if (i0 + ty * 4 + x < p.M) p.rowsum[i0 + ty * 4 + x] = rs[x];
+    if (want_rs) {                            // row sums of A: the four k-quarters of a row sit in lanes c, c + 16, c + 32, c + 48
+        rs += __shfl_xor(rs, 16, 64);
+        rs += __shfl_xor(rs, 32, 64);
+        if (kq == 0 && i0 + wv * 16 + c16 < p.M) p.rowsum[i0 + wv * 16 + c16] = rs;
     }
 #pragma unroll
-    for (int x = 0; x < 4; ++x) {
-        const int i = i0 + ty * 4 + x;
+    for (int r = 0; r < 4; ++r) {
+        const int i = i0 + wv * 16 + 4 * kq + r;
         if (i >= p.M) continue;
 #pragma unroll
-        for (int y = 0; y < 4; ++y) {
-            const int j = j0 + tx * 4 + y;
+        for (int b = 0; b < 4; ++b) {
+            const int j = j0 + b * 16 + c16;
             if (j >= p.N) continue;
-            float v = acc[x][y];
+            float v = acc[b][r];
             if (p.flags & XMC_GP_BIAS) v += p.bias[j];
             if (p.flags & XMC_GP_RELU) v = fmaxf(v, 0.f);
             if (p.flags & XMC_GP_MASK) v = p.mask[(size_t)i * p.N + j] > 0.f ? v : 0.f;
