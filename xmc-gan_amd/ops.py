@@ -1745,6 +1745,11 @@ class ResDFn(torch.autograd.Function):
         return tuple(outs) + (None, None, None, None, None)
 
 
+def debug_switch(token):
+    """True when `token` is listed in XMC_DEBUG_DISPATCH (A/B experiments; unset in production)"""
+    return token in _DEBUG_DISPATCH
+
+
 def dstem_eligible(xin, c_img, c_sc, c_out):
     """the composed-stem path (DStemBlockFn) takes 16-bit images whose size tiles (H % 16 == 0, W % 64 == 0) at the widths the
     kernel is built for (conv_img: 3 -> 32, first block: 32 -> 64 with its learned shortcut)"""

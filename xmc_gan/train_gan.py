@@ -144,7 +144,7 @@ def gan_iteration(netG, netD, optimizerG, optimizerD, imgs, sent_embs, words_emb
     # ---- discriminator step (train_gan.py:187-229)
     psent_embs = sent_embs if cfg.DISC.SEPERATE else netG.proj_sent(sent_embs.float())
     nhwc_g = bool(getattr(netG, 'nhwc_out', False))             # generator can hand out its image in the engine layout
-    batched = nhwc_g and isinstance(netD, DF_DISC) and not cfg.DISC.SPEC_NORM and ops.fused_blocks()
+    batched = nhwc_g and isinstance(netD, DF_DISC) and not cfg.DISC.SPEC_NORM and ops.fused_blocks() and not ops.debug_switch('no_d2b')
     # the discriminator's 2B-image input of the batched pass below: the real images are converted into its first half, the
     # generator's last convolution writes its second half (no concatenation pass)
     both_h = (torch.empty((2 * batch_size, imgs.shape[2], imgs.shape[3], 8), dtype=ops.act_dtype(), device=imgs.device)
@@ -161,7 +161,7 @@ def gan_iteration(netG, netD, optimizerG, optimizerD, imgs, sent_embs, words_emb
     # (193, 202) run as ONE pass over 2B images and the three COND_DNET calls (194, 203, 208) as one over 3B-1 rows: same
     # values, half the launches, twice the work per launch on the small maps at the end of D.  Not with spectral norm: there
     # every forward CALL advances the power iteration (modules.py:16-17), so the call pattern is part of the result.
-    if imgs_h is not None and fake_h is not None and not cfg.DISC.SPEC_NORM and ops.fused_blocks():
+    if imgs_h is not None and fake_h is not None and not cfg.DISC.SPEC_NORM and ops.fused_blocks() and not ops.debug_switch('no_d2b'):
         B = batch_size
         feats = netD(None, nhwc8=both_h if both_h is not None else torch.cat((imgs_h, fake_h.detach())))
         real_features, fake_features = feats[:B], feats[B:]
