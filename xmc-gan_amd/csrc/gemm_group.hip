@@ -15,7 +15,7 @@ namespace {
 constexpr int GT = 64;       // C tile is GT x GT
 constexpr int GK = 64;       // reduction chunk per barrier pair: four 16-row loads per operand in flight at once (at 16 a launch was 16 serial
                              // global round trips: ~45 us for 2 GFLOP; the MLP bank is 10 launches per iteration)
-constexpr int GLD = GT + 4;  // LDS row pitch (floats): 16-byte aligned rows, float4 reads conflict-free across the 16 tx / ty groups
+constexpr int GLD = GT + 16; // LDS row pitch (floats): the four k-rows a wave reads per MFMA step (lane >> 4) land 16 banks apart
 
 __device__ __forceinline__ void load_tile(float (*dst)[GLD], const float* __restrict__ base, int s_i, int s_r, int i0, int r0,
                                           int ni, int nr, int tid) {
