@@ -177,7 +177,7 @@ def test_grouped_conv_fwd_dgrad_wgrad(cin, cout, k, H, W, N, mode):
     wd = torch.nn.Parameter(w.to(DEV))
     y = ops.conv2d(xd, wd, None, geom)
     if mode == "bf16":
-        assert L.load().xmc_last_kernel().decode().startswith("gconv_"), L.load().xmc_last_kernel()
+        assert L.load().xmc_last_kernel().decode().startswith("gconv"), L.load().xmc_last_kernel()
     torch.testing.assert_close(from_nhwc(y, cout), yr.detach(), **tol(mode, yr.abs().max().item()))
     (y.float() * to_nhwc(r, cout, dt).float()).sum().backward()
     torch.testing.assert_close(from_nhwc(xd.grad, cin), xr.grad, **tol(mode, xr.grad.abs().max().item()))

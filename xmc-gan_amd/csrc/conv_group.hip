@@ -91,6 +91,77 @@ __global__ __launch_bounds__(512) void gconv_kernel(const XmcConvDesc d, int nun
     }
 }
 
+// 1x1 grouped layers with one MFMA per 16-channel column block (key / query 1x1: 8 -> 4 per group, and its data gradient 4 -> 8), Cout a
+// multiple of 64.  In the general kernel a wave owns ONE column block, so a pixel's 128 / 256 output bytes are written by 4 / 8 different
+// waves, 32 bytes each, at different times (the data gradient ran at 2.7 TB/s against the forward's 3.9), and the data gradient loaded the
+// same 16-byte unit in all four lane groups.  Here a wave owns FOUR consecutive column blocks (one 128-byte line of every pixel, written
+// by four back-to-back stores) and the waves of a workgroup split the pixels.  nun == 4 (forward): one load per column block, all four
+// K blocks live.  nun == 1 (data gradient): the four column blocks read four CONSECUTIVE units, so lane group kb loads unit u0 + kb ONCE
+// and column block b multiplies it with a weight fragment that is zero outside K block b.
+template <int NUN>
+__global__ __launch_bounds__(256) void gconv1x1_kernel(const XmcConvDesc d, int cig, int cog, int tiles) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 15, kb = lane >> 4;
+    const int csu = d.CS >> 3;
+    const u32x4* __restrict__ src = reinterpret_cast<const u32x4*>(d.src);
+    const u32x4* __restrict__ wpk = reinterpret_cast<const u32x4*>(d.wpk);
+    const int ng4 = d.CD >> 6;                                // 64-channel groups of column blocks
+    const int total = d.N * d.MH * d.MW;
+    for (int g4 = 0; g4 < ng4; ++g4) {
+        bf16x8 wa[4];
+        int unit[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int cb = g4 * 4 + b;
+            const int u0 = (((cb * 16) / cog) * cig) >> 3;
+            unit[b] = u0 + (NUN == 1 ? 0 : kb);
+            u32x4 w = {0, 0, 0, 0};
+            if (NUN == 1 ? kb == b : true) w = wpk[((size_t)d.wi[0][0] * d.CDw + cb * 16 + col) * csu + unit[b]];
+            wa[b] = __builtin_bit_cast(bf16x8, w);
+        }
+        const int ubase = unit[0] + (NUN == 1 ? kb : 0);       // NUN == 1: lane group kb carries the unit of column block kb
+        for (int t0 = (blockIdx.x * 4 + wave) * TI; t0 < tiles; t0 += gridDim.x * 4 * TI) {
+            u32x4 xb[TI][NUN == 1 ? 1 : 4];
+            bf16x4 rv[TI][4];                                 // the residual (another gradient of the same tensor), requested with the operands
+#pragma unroll
+            for (int t = 0; t < TI; ++t) {
+                const int p = (t0 + t) * 16 + col;
+                const size_t pq = (size_t)(p < total ? p : total - 1);
+                const size_t pc = pq * csu;
+                if (NUN == 1) xb[t][0] = src[pc + ubase];
+                else {
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) xb[t][b] = src[pc + unit[b]];
+                }
+                if (d.res) {
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                        rv[t][b] = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const xmc_h16*>(d.res) + pq * d.CD + (g4 * 4 + b) * 16 + kb * 4);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < TI; ++t) {
+                const int p = (t0 + t) * 16 + col;
+                if (t0 + t >= tiles) break;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    acc = XMC_MFMA_16x16x32(wa[b], __builtin_bit_cast(bf16x8, xb[t][NUN == 1 ? 0 : b]), acc, 0, 0, 0);
+                    if (p < total) {
+                        const size_t e = (size_t)p * d.CD + (g4 * 4 + b) * 16 + kb * 4;
+                        if (d.res) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) acc[i] += (float)rv[t][b][i];
+                        }
+                        bf16x4 o = {(xmc_h16)acc[0], (xmc_h16)acc[1], (xmc_h16)acc[2], (xmc_h16)acc[3]};
+                        *reinterpret_cast<bf16x4*>(reinterpret_cast<xmc_h16*>(d.dst) + e) = o;
+                    }
+                }
+            }
+        }
+    }
+}
+
 // 3x3 (taps within [-1, 1]^2) on maps with H % 8 == 0, W % 16 == 0: the direct form above pulls every unit through the
 // vector-memory path once per tap (9x, ~22 B/clk per CU: 104 us per call on average where the dense kernel took 111), so the
 // 8 x 16-pixel tile's halo patch (10 x 18 pixels, each byte once + 41 % halo) is staged in LDS and the B operands are
@@ -211,6 +282,23 @@ int xmc_conv_group_try(const XmcConvDesc* d, void* stream) {
         }
     }
     const int64_t total = (int64_t)d->N * d->MH * d->MW;
+    static const bool no_1x1 = xmc_debug_off("no_gconv1x1");
+    if (!no_1x1 && d->ntaps == 1 && nmf == 1 && d->CD % 64 == 0 && (nun == 1 || nun == 4) && d->dh[0][0] == 0 && d->dw[0][0] == 0 &&
+        total < (1ll << 27)) {
+        bool consecutive = true;                              // nun == 1: the four column blocks of a wave read consecutive units
+        if (nun == 1)
+            for (int cb = 0; cb < d->CD / 16; ++cb) consecutive = consecutive && ((((cb * 16) / cog) * cig) >> 3) == cb;
+        if (consecutive) {
+            const int tiles = (int)((total + 15) / 16);
+            int grid = (tiles + 4 * TI - 1) / (4 * TI);
+            if (grid > 256 * 8) grid = 256 * 8;
+            if (nun == 1) hipLaunchKernelGGL(gconv1x1_kernel<1>, dim3(grid), dim3(256), 0, st, *d, cig, cog, tiles);
+            else hipLaunchKernelGGL(gconv1x1_kernel<4>, dim3(grid), dim3(256), 0, st, *d, cig, cog, tiles);
+            xmc_note_kernel("gconv1x1_kernel<%d>", nun);
+            XMC_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     const int chunks = (int)((total + 16 * TI - 1) / (16 * TI));
     const int threads = d->CD / 16 * 64;
     int grid = chunks < 256 * 8 ? chunks : 256 * 8;
