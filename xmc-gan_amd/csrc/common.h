@@ -121,6 +121,26 @@ template <> struct Vec8<XMC_F32> {
     }
 };
 
+// XCD-aware walk of a persistent 1-D grid over `ntiles` tiles.  Workgroups are dealt to the chip's 8 XCDs round-robin by (linear) block
+// index and each XCD has its own L2; tiles that are neighbours in the image share halo rows / columns.  With tile = blockIdx.x + k *
+// gridDim.x two neighbours never meet in one L2 and every halo comes from memory again.  Here XCD x owns the contiguous tile range
+// [x T8, (x+1) T8) and its gridDim.x / 8 workgroups walk it side by side.  (gridDim.x not a multiple of 8: the plain walk -- which is
+// also how XMC_DEBUG_DISPATCH=no_xcd_map gets its A/B: the launchers then ask for one workgroup less, xmc_ab_grid.)
+struct XcdWalk { int first, step, end; };
+__device__ __forceinline__ XcdWalk xmc_xcd_walk(int ntiles) {
+    const int G = (int)gridDim.x, b = (int)blockIdx.x;
+#ifdef XMC_XCD_HELPER_OFF          /* build-time A/B of the walk outside conv_tile.hip */
+    return XcdWalk{b, G, ntiles};
+#endif
+    if ((G & 7) != 0 || G < 16) return XcdWalk{b, G, ntiles};
+    const int T8 = (ntiles + 7) >> 3, base = (b & 7) * T8;
+    return XcdWalk{base + (b >> 3), G >> 3, base + T8 < ntiles ? base + T8 : ntiles};
+}
+static inline int xmc_ab_grid(int g) {
+    static const bool off = xmc_debug_off("no_xcd_map");
+    return (off && g >= 16 && (g & 7) == 0) ? g - 1 : g;
+}
+
 // lane ^ 1 / lane ^ 2 exchange inside a quad as a DPP modifier of a VALU instruction: hipcc lowers __shfl_xor to ds_bpermute_b32, an
 // LDS-pipe instruction with its round trip (32 of them per tile in a pooled epilogue, beside the staging traffic)
 __device__ __forceinline__ float xmc_xor1(float v) {

@@ -211,9 +211,10 @@ __global__ __launch_bounds__(NW * 64, 2) void gconv_patch_kernel(const XmcConvDe
             pv[it] = ok ? src[(((size_t)n * d.SH + sy) * d.SW + sx) * csu + ch] : z;
         }
     };
-    int tile = blockIdx.x;
-    if (tile < ntiles) prefetch(tile);
-    for (; tile < ntiles; tile += gridDim.x) {
+    const XcdWalk xw = xmc_xcd_walk(ntiles);
+    int tile = xw.first;
+    if (tile < xw.end) prefetch(tile);
+    for (; tile < xw.end; tile += xw.step) {
         __syncthreads();                                          // the previous tile's fragment reads are done
 #pragma unroll
         for (int it = 0; it < MAXU; ++it) {
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gconv_patch_kernel(const XmcConvDe
             if (id < nunits) *reinterpret_cast<u32x4*>(smem + pp * pstr + ch * 16) = pv[it];
         }
         __syncthreads();
-        if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);
+        if (tile + xw.step < xw.end) prefetch(tile + xw.step);
         const int n = tile / (tiles_y * tiles_x), tr = tile - n * (tiles_y * tiles_x);
         const int y0 = (tr / tiles_x) * GT_H, x0 = (tr % tiles_x) * GT_W;
 #pragma unroll
@@ -274,8 +275,8 @@ int xmc_conv_group_try(const XmcConvDesc* d, void* stream) {
             const int tx = d->MW / GT_W, ty = d->MH / GT_H, ntiles = d->N * tx * ty;
             const size_t lds = (size_t)GP_H * GP_W * (d->CS * 2 + 16);
             const int grid = ntiles < 256 * 3 ? ntiles : 256 * 3;
-            if (d->CD == 128) hipLaunchKernelGGL(gconv_patch_kernel<8>, dim3(grid), dim3(512), lds, st, *d, nun, cig, cog, tx, ty, ntiles);
-            else hipLaunchKernelGGL(gconv_patch_kernel<4>, dim3(grid), dim3(256), lds, st, *d, nun, cig, cog, tx, ty, ntiles);
+            if (d->CD == 128) hipLaunchKernelGGL(gconv_patch_kernel<8>, dim3(xmc_ab_grid(grid)), dim3(512), lds, st, *d, nun, cig, cog, tx, ty, ntiles);
+            else hipLaunchKernelGGL(gconv_patch_kernel<4>, dim3(xmc_ab_grid(grid)), dim3(256), lds, st, *d, nun, cig, cog, tx, ty, ntiles);
             xmc_note_kernel("gconv_patch_kernel<%d>", d->CD / 16);
             XMC_LAUNCH_CHECK();
             return 0;

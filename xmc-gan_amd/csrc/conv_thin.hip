@@ -92,9 +92,10 @@ __global__ __launch_bounds__(256) void thin_in_kernel(const XmcConvDesc d, const
             okbits |= ok ? (1u << it) : 0u;
         }
     };
-    int tile = blockIdx.x;
-    if (tile < ntiles) issue(tile);
-    for (; tile < ntiles; tile += gridDim.x) {
+    const XcdWalk xw = xmc_xcd_walk(ntiles);
+    int tile = xw.first;
+    if (tile < xw.end) issue(tile);
+    for (; tile < xw.end; tile += xw.step) {
         const int img = tile / tpi, trem = tile - img * tpi;
         const int ty = trem / t.tiles_x, tx = trem - ty * t.tiles_x;
         __syncthreads();                          // previous tile's reads are done
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(256) void thin_in_kernel(const XmcConvDesc d, const
             if (ppix[it] >= 0) *reinterpret_cast<u32x4*>(patch + ppix[it] * 16) = v;
         }
         __syncthreads();
-        if (tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x);
+        if (tile + xw.step < xw.end) issue(tile + xw.step);
         const int dbase = ((img * d.DH + ty * TH) * d.DW + tx * TW) * cd8;
         // pixel blocks i and i+2 are vertical neighbours (rows 2*wm and 2*wm+1, same columns) of the same lane: they are
         // finished together so that the optional third output (2x2 average of the rounded result, XmcConvDesc.dst_pool) is a
@@ -425,9 +426,10 @@ __global__ __launch_bounds__(256, 2) void thin_out_kernel(const XmcConvDesc d, i
             pv[it] = ok ? src[(((size_t)n * d.SH + sy) * d.SW + sx) * CSU + ch] : z;
         }
     };
-    int tile = blockIdx.x;
-    if (tile < ntiles) prefetch(tile);
-    for (; tile < ntiles; tile += gridDim.x) {
+    const XcdWalk xw = xmc_xcd_walk(ntiles);
+    int tile = xw.first;
+    if (tile < xw.end) prefetch(tile);
+    for (; tile < xw.end; tile += xw.step) {
         __syncthreads();
 #pragma unroll
         for (int it = 0; it < MAXU; ++it) {
@@ -436,7 +438,7 @@ __global__ __launch_bounds__(256, 2) void thin_out_kernel(const XmcConvDesc d, i
             if (id < NUN) *reinterpret_cast<u32x4*>(smem + pp * PSTR + ch * 16) = pv[it];
         }
         __syncthreads();
-        if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);
+        if (tile + xw.step < xw.end) prefetch(tile + xw.step);
         const int n = tile / (tiles_y * tiles_x), tr = tile - n * (tiles_y * tiles_x);
         const int y0 = (tr / tiles_x) * TO_H, x0 = (tr % tiles_x) * TO_W;
 #pragma unroll
@@ -483,8 +485,8 @@ int xmc_conv_thin_out_try(const XmcConvDesc* d, void* stream) {
     const int tx = d->MW / TO_W, ty = d->MH / TO_H, ntiles = d->N * tx * ty;
     const int grid = ntiles < 256 * 8 ? ntiles : 256 * 8;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (d->CS == 32) hipLaunchKernelGGL((thin_out_kernel<1>), dim3(grid), dim3(256), 0, st, *d, tx, ty, ntiles);
-    else hipLaunchKernelGGL((thin_out_kernel<2>), dim3(grid), dim3(256), 0, st, *d, tx, ty, ntiles);
+    if (d->CS == 32) hipLaunchKernelGGL((thin_out_kernel<1>), dim3(xmc_ab_grid(grid)), dim3(256), 0, st, *d, tx, ty, ntiles);
+    else hipLaunchKernelGGL((thin_out_kernel<2>), dim3(xmc_ab_grid(grid)), dim3(256), 0, st, *d, tx, ty, ntiles);
     xmc_note_kernel("thin_out_kernel<%d>", d->CS / 32);
     XMC_LAUNCH_CHECK();
     return 0;
@@ -517,9 +519,9 @@ int xmc_conv_thin_try(const XmcConvDesc* d, void* stream) {
     if (gx > ntiles) gx = ntiles;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (d->CDw == 32) {
-        hipLaunchKernelGGL((thin_in_kernel<32>), dim3(gx), dim3(256), 0, st, *d, t, ntiles);
+        hipLaunchKernelGGL((thin_in_kernel<32>), dim3(xmc_ab_grid(gx)), dim3(256), 0, st, *d, t, ntiles);
     } else {
-        hipLaunchKernelGGL((thin_in_kernel<64>), dim3(gx), dim3(256), 0, st, *d, t, ntiles);
+        hipLaunchKernelGGL((thin_in_kernel<64>), dim3(xmc_ab_grid(gx)), dim3(256), 0, st, *d, t, ntiles);
     }
     xmc_note_kernel("thin_in_kernel<%d>", d->CDw);
     XMC_LAUNCH_CHECK();

@@ -29,6 +29,7 @@ struct TileCfg {
     int dh0[XMC_MAX_CLASSES], dw0[XMC_MAX_CLASSES];      // min tap offsets per class
     int PHu, PWu, dh0u, dw0u;    // union of the classes' patches (one staged patch serves all classes)
     int slab;                    // channels per slab (32 or 64)
+    int no_xcd;                  // XMC_DEBUG_DISPATCH=no_xcd_map: plain tile = blockIdx.x + k * gridDim.x walk (A/B)
 };
 
 template <int BN, int WM, int WN>
@@ -305,7 +306,14 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
         *reinterpret_cast<u32x4*>(wall + (tap * BN + prow) * pstride + ch * 16) =
             w16[((size_t)d.wi[MC > 1 ? tap / d.ntaps : cls][MC > 1 ? tap % d.ntaps : tap] * d.CDw + n0 + lrow) * cs_units + ch];
     }
-    const int tile0 = blockIdx.x, tstep = gridDim.x;
+    // XCD-aware tile walk.  Workgroups are dealt to the chip's 8 XCDs round-robin by blockIdx, each XCD has its own L2, and a tile shares
+    // its halo rows / columns with its neighbours: with tile = blockIdx.x + k * gridDim.x two neighbouring tiles NEVER meet in one L2 and
+    // every halo is fetched from memory again (FETCH_SIZE = 1.33x the source tensor).  Here XCD x owns the contiguous tile range
+    // [x T8, (x+1) T8) and its gridDim.x / 8 workgroups walk it side by side, so a halo row is in L2 when the tile below asks for it.
+    const bool xaware = (gridDim.x & 7) == 0 && gridDim.y == 1 && gridDim.z == 1 && !t.no_xcd;
+    const int T8 = (ntiles + 7) >> 3, xper = (int)gridDim.x >> 3;
+    const int xbase = xaware ? ((int)blockIdx.x & 7) * T8 : 0, xlim = xaware ? (xbase + T8 < ntiles ? xbase + T8 : ntiles) : ntiles;
+    const int tile0 = xaware ? xbase + ((int)blockIdx.x >> 3) : (int)blockIdx.x, tstep = xaware ? xper : (int)gridDim.x;
 
     if (stager) {
         // ------------------------------------------------------------------------------------------------ staging role
@@ -393,17 +401,17 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
                     if (rt + it * NS < IPU) *reinterpret_cast<u32x2*>(ipatch + (rt + it * NS) * 8) = iv[it];
             }
         };
-        if (tile0 < ntiles) {
+        if (tile0 < xlim) {
             issue(tile0);
             commit();
         }
         __syncthreads();                          // weights + first patch staged
-        for (int tile = tile0; tile < ntiles; tile += tstep) {
+        for (int tile = tile0; tile < xlim; tile += tstep) {
             const int next = tile + tstep;
             __syncthreads();                      // B1
-            if (next < ntiles) issue(next);
+            if (next < xlim) issue(next);
             __syncthreads();                      // B2: the compute waves are done reading the patch
-            if (next < ntiles) commit();
+            if (next < xlim) commit();
         }
     } else if constexpr (M32) {
         // ------------------------------------------------------------------------------------------------ compute role, 32x32x16
@@ -452,7 +460,7 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
         int toffr[MC * NTAPS];
 #pragma unroll
         for (int k = 0; k < MC * NTAPS; ++k) toffr[k] = __builtin_amdgcn_readfirstlane(s_toff[k]);
-        for (int tile = tile0; tile < ntiles; tile += tstep) {
+        for (int tile = tile0; tile < xlim; tile += tstep) {
             const int img = tile / tpi, trem = tile - img * tpi;
             const int a0 = (trem / t.tiles_x) * t.TH, b0 = (trem % t.tiles_x) * t.TW;
             __syncthreads();                      // B1: patch of this tile is in LDS
@@ -727,7 +735,7 @@ __global__ __launch_bounds__(512) void ptile3_kernel(const XmcConvDesc d, const 
 #pragma unroll
             for (int k = 0; k < MC * NTAPS; ++k) toffr[k] = __builtin_amdgcn_readfirstlane(s_toff[k]);
         }
-        for (int tile = tile0; tile < ntiles; tile += tstep) {
+        for (int tile = tile0; tile < xlim; tile += tstep) {
             const int img = tile / tpi, trem = tile - img * tpi;
             const int a0 = (trem / t.tiles_x) * t.TH, b0 = (trem % t.tiles_x) * t.TW;
             __syncthreads();                      // B1: patch of this tile is in LDS
@@ -1178,6 +1186,8 @@ static int tile_plan(const XmcConvDesc* d, TileCfg* t) {
     t->TH = TH; t->TW = TW; t->log2TW = TW == 32 ? 5 : 4;
     t->tiles_y = d->MH / TH; t->tiles_x = d->MW / TW;
     t->slab = (d->CS % 64 == 0) ? 64 : 32;
+    static const bool no_xcd = xmc_debug_off("no_xcd_map");
+    t->no_xcd = no_xcd ? 1 : 0;
     // 128 -> 64 channels, 2x2 tap classes (the data gradient of a block's 4x4 stride-2 convolution, df_gan.py:272-273): ALL 128 source
     // channels of a class's four weight slices stay in LDS (4 x 64 x 288 B beside a 9 x 33 pixel patch: 159 KB), so nothing is streamed
     // per tile but the patch -- the streamed-weights kernel moved 140 KB per class tile through the vector-memory path for 128 MFMAs a wave

@@ -166,8 +166,9 @@ __global__ __launch_bounds__(NT, ((SA == 1 && NT == 256) ? WtOcc<NCO, NCI>::v : 
     };
 
     float bsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int tile = blockIdx.x;
-    if (tile < t.ntiles) prefetch(tile);
+    const XcdWalk xw = xmc_xcd_walk(t.ntiles);
+    int tile = xw.first;
+    if (tile < xw.end) prefetch(tile);
     const int fr = lane & 15, fg = lane >> 4;
     const int q = fr >> 2, pp4 = fr & 3;
     const int nitems = NCI * d.ntaps;
@@ -242,7 +243,7 @@ __global__ __launch_bounds__(NT, ((SA == 1 && NT == 256) ? WtOcc<NCO, NCI>::v : 
     // accumulators of the three paths meet in phi nodes the register allocator did not coalesce (68 extra registers, spills).
     auto tiles = [&](auto variant) {
     constexpr int VNV = decltype(variant)::value;            // items per wave known at compile time; 0 = generic loop
-    for (; tile < t.ntiles; tile += gridDim.x) {
+    for (; tile < xw.end; tile += xw.step) {
         __syncthreads();                                      // previous tile's reads are done
 #pragma unroll
         for (int it = 0; it < YIT; ++it) {
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(NT, ((SA == 1 && NT == 256) ? WtOcc<NCO, NCI>::v : 
             }
         }
         __syncthreads();
-        if (tile + (int)gridDim.x < t.ntiles) prefetch(tile + gridDim.x);
+        if (tile + xw.step < xw.end) prefetch(tile + xw.step);
 
         // K loop: 32 pixels per step (one tile row; two rows of a 16 x 16 tile: the upper 16 pixels of a fragment are then one
         // patch row further down instead of 16 columns to the right)
@@ -442,8 +443,9 @@ __global__ __launch_bounds__(512) void wgrad_tile_rr_kernel(const XmcConvDesc d,
 
     float bsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const bool do_bias = dbias != nullptr && blockIdx.y == 0;
-    int tile = blockIdx.x;
-    if (tile < t.ntiles) prefetch(tile);
+    const XcdWalk xw = xmc_xcd_walk(t.ntiles);
+    int tile = xw.first;
+    if (tile < xw.end) prefetch(tile);
     const int fr = lane & 15, fg = lane >> 4;
     const int q = fr >> 2, pp4 = fr & 3;
     // group gi of this wave: g = slice + gi * NS -> Cin block g / 3, tap column g % 3; LDS byte offset of its row-0 fragment
@@ -457,7 +459,7 @@ __global__ __launch_bounds__(512) void wgrad_tile_rr_kernel(const XmcConvDesc d,
     const unsigned char* bfrag = xp + (size_t)(4 * fg + q) * XS + (4 * pp4) * 2;
     const unsigned char *afr = afrag, *bfr = bfrag;
 
-    for (; tile < t.ntiles; tile += gridDim.x) {
+    for (; tile < xw.end; tile += xw.step) {
         __syncthreads();                                      // previous tile's reads are done
 #pragma unroll
         for (int it = 0; it < YIT; ++it) {
@@ -481,7 +483,7 @@ __global__ __launch_bounds__(512) void wgrad_tile_rr_kernel(const XmcConvDesc d,
             if ((xin >> it) & 1) *reinterpret_cast<u32x4*>(xp + ((tid + it * NT) / XCH) * XS + xch * 16) = v;
         }
         __syncthreads();
-        if (tile + (int)gridDim.x < t.ntiles) prefetch(tile + gridDim.x);
+        if (tile + xw.step < xw.end) prefetch(tile + xw.step);
         {
             int zq = 0;
             asm volatile("" : "+v"(zq));
@@ -564,7 +566,7 @@ int launch_wt_rr(const XmcConvDesc& d, float* dwp, float* dbias, const WTCfg& t,
     int gx = 256 / (ny * nz);
     if (gx < 1) gx = 1;
     if (gx > t.ntiles) gx = t.ntiles;
-    hipLaunchKernelGGL((wgrad_tile_rr_kernel<NCO, NCI, NCG>), dim3(gx, ny, nz), dim3(512), lds, st, d, dwp, dbias, t);
+    hipLaunchKernelGGL((wgrad_tile_rr_kernel<NCO, NCI, NCG>), dim3(xmc_ab_grid(gx), ny, nz), dim3(512), lds, st, d, dwp, dbias, t);
     xmc_note_kernel("wgrad_tile_rr_kernel<%d, %d, %d>", NCO, NCI, NCG);
     XMC_LAUNCH_CHECK();
     return 0;
@@ -584,7 +586,7 @@ int launch_wt(const XmcConvDesc& d, float* dwp, float* dbias, const WTCfg& t, hi
     int gx = 256 * per_cu / (ny * nz);
     if (gx < 1) gx = 1;
     if (gx > t.ntiles) gx = t.ntiles;
-    hipLaunchKernelGGL((wgrad_tile_kernel<NCO, NCI, NT, SA, KT, CBW, DIAG, T16>), dim3(gx, ny, nz), dim3(NT), lds, st, d, dwp, dbias, t);
+    hipLaunchKernelGGL((wgrad_tile_kernel<NCO, NCI, NT, SA, KT, CBW, DIAG, T16>), dim3(xmc_ab_grid(gx), ny, nz), dim3(NT), lds, st, d, dwp, dbias, t);
     xmc_note_kernel(T16 ? "wgrad_tile_kernel<%d, %d, %d, %d, %d, %d, false, true>" : DIAG ? "wgrad_tile_kernel<%d, %d, %d, %d, %d, %d, true>" : "wgrad_tile_kernel<%d, %d, %d, %d, %d, %d>", NCO, NCI, NT, SA, KT, CBW);
     XMC_LAUNCH_CHECK();
     return 0;

@@ -117,8 +117,9 @@ __global__ __launch_bounds__(512) void wgrad_up_kernel(const XmcConvDesc d, floa
 
     float bsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const bool do_bias = dbias != nullptr && blockIdx.y == 0;
-    int tile = blockIdx.x;
-    if (tile < t.ntiles) prefetch(tile);
+    const XcdWalk xw = xmc_xcd_walk(t.ntiles);
+    int tile = xw.first;
+    if (tile < xw.end) prefetch(tile);
     const int fr = lane & 15, fg = lane >> 4;
     const int q = fr >> 2, pp4 = fr & 3;
     // item j of this wave: Cin block half * 2 + j / 4, shift (u, v) = ((j >> 1) & 1, j & 1): patch pixel of low-res pixel (ay, ax) is
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(512) void wgrad_up_kernel(const XmcConvDesc d, floa
     const unsigned char *afr = afrag, *bfr = bfrag;
     auto itoff = [&](int j) -> int { return (((j >> 1) & 1) * PW + (j & 1)) * XS + (j >> 2) * 32; };
 
-    for (; tile < t.ntiles; tile += gridDim.x) {
+    for (; tile < xw.end; tile += xw.step) {
         __syncthreads();                                      // previous tile's reads are done
 #pragma unroll
         for (int it = 0; it < YIT; ++it) {
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(512) void wgrad_up_kernel(const XmcConvDesc d, floa
             if ((xin >> it) & 1) *reinterpret_cast<u32x4*>(xp + ((tid + it * NT) / XCH) * XS + xch * 16) = v;
         }
         __syncthreads();
-        if (tile + (int)gridDim.x < t.ntiles) prefetch(tile + gridDim.x);
+        if (tile + xw.step < xw.end) prefetch(tile + xw.step);
         {
             int zq = 0;                                       // opaque zero: keeps the fragment addresses out of the tile loop's live set
             asm volatile("" : "+v"(zq));
@@ -235,7 +236,7 @@ int launch_wu(const XmcConvDesc& d, float* dwp, float* dbias, const WUCfg& t, hi
     int gx = 256 / (ny * nz);
     if (gx < 1) gx = 1;
     if (gx > t.ntiles) gx = t.ntiles;
-    hipLaunchKernelGGL((wgrad_up_kernel<NCO, W16>), dim3(gx, ny, nz), dim3(512), lds, st, d, dwp, dbias, t);
+    hipLaunchKernelGGL((wgrad_up_kernel<NCO, W16>), dim3(xmc_ab_grid(gx), ny, nz), dim3(512), lds, st, d, dwp, dbias, t);
     xmc_note_kernel(W16 ? "wgrad_up_kernel<%d, true>" : "wgrad_up_kernel<%d, false>", NCO);
     XMC_LAUNCH_CHECK();
     return 0;

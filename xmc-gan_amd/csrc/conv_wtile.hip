@@ -98,7 +98,8 @@ __global__ __launch_bounds__(64 * CW + 256) void wtile2_kernel(const XmcConvDesc
     }
     // Persistent: this workgroup's tiles are blockIdx.x, + gridDim.x, ...  The K stages of all of them form ONE stream
     // (patch sequence q = (tile, slab), NTAPS stages each).
-    const int mytiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const XcdWalk xw = xmc_xcd_walk(ntiles);      // XCD-aware tile walk (common.h): this workgroup's tiles are xw.first, + xw.step, ... < xw.end
+    const int mytiles = xw.first < xw.end ? (xw.end - xw.first + xw.step - 1) / xw.step : 0;
     const int Q = mytiles * nslab;
     unsigned char* const wring = smem;                           // [3][BN][128]
     unsigned char* const patch0 = smem + 3 * WSTG;               // [2][patch_bytes]
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(64 * CW + 256) void wtile2_kernel(const XmcConvDesc
         unsigned okmask = 0;                      // of the patch held in pv
         auto issue_patch = [&](int q) {           // q is clamped by the caller: always a patch of this workgroup
             const int tk = q / nslab, sl = q - tk * nslab;
-            const int tile = (int)blockIdx.x + tk * (int)gridDim.x;
+            const int tile = xw.first + tk * xw.step;
             const int img = tile / tpi, trem = tile - img * tpi;
             const int a0 = (trem / t.tiles_x) * t.TH, b0 = (trem % t.tiles_x) * t.TW;
             int base;
@@ -471,7 +472,7 @@ __global__ __launch_bounds__(64 * CW + 256) void wtile2_kernel(const XmcConvDesc
                 if (!(WT_ABL & 8)) __builtin_amdgcn_s_barrier();
             }
             if (++sl == nslab) {
-                epilogue((int)blockIdx.x + tk * (int)gridDim.x);
+                epilogue(xw.first + tk * xw.step);
                 sl = 0; ++tk;
             }
         }
@@ -551,6 +552,7 @@ int launch(const XmcConvDesc& d, const WtCfg& t, hipStream_t st) {
     int gx = 256 / (ny * d.nclass);               // one 8-wave workgroup per CU, persistent over its tiles
     if (gx < 1) gx = 1;
     if (gx > ntiles) gx = ntiles;
+    gx = xmc_ab_grid(gx);
     // epilogue option sets of the training step as compile-time instantiations (common.h: kEpi*), eight compute waves only
     static const bool no_epi = xmc_debug_off("no_wtile_epi");
     const int epi = (no_epi || CW != 8) ? -1 : xmc_epi_mask(d);

@@ -114,7 +114,8 @@ __global__ __launch_bounds__(512) void wtile3_kernel(const XmcConvDesc d, const 
         const int sl = tid - 64;
         s_slab[sl] = MODE == 0 ? sl : (((sl / cb) << 8) | (sl % cb));
     }
-    const int mytiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const XcdWalk xw = xmc_xcd_walk(ntiles);      // XCD-aware tile walk (common.h): this workgroup's tiles are xw.first, + xw.step, ... < xw.end
+    const int mytiles = xw.first < xw.end ? (xw.end - xw.first + xw.step - 1) / xw.step : 0;
     const int Q = mytiles * nslab;               // patches (tile, slab) of this workgroup, one stream
     __syncthreads();
     if (mytiles <= 0) return;
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(512) void wtile3_kernel(const XmcConvDesc d, const 
     unsigned pborder = 0;
     auto patch_setup = [&](int q) {
         const int tk = q / nslab, sl = q - tk * nslab;
-        const int tile = (int)blockIdx.x + tk * (int)gridDim.x;
+        const int tile = xw.first + tk * xw.step;
         const int timg = tile / tpi, trem = tile - timg * tpi, img = timg * t.ipt;
         const int a0 = (trem / t.tiles_x) * t.TH, b0 = (trem % t.tiles_x) * t.TW;
         if (MODE == 0) {
@@ -510,7 +511,7 @@ __global__ __launch_bounds__(512) void wtile3_kernel(const XmcConvDesc d, const 
         // end of a tile: the epilogue takes the place of (the start of) this wave's next LOAD phase, i.e. it runs beside the SIMD
         // partner's MFMA phase
         if (sl == nslab - 1) {
-            epilogue((int)blockIdx.x + tk * (int)gridDim.x);
+            epilogue(xw.first + tk * xw.step);
             ++tk;
         }
         sl = sl1;
@@ -602,6 +603,7 @@ int launch3(const XmcConvDesc& d, const W3Cfg& t, hipStream_t st) {
     int gx = 256 / (ny * d.nclass);               // one 8-wave workgroup per CU, persistent over its tiles
     if (gx < 1) gx = 1;
     if (gx > ntiles) gx = ntiles;
+    gx = xmc_ab_grid(gx);
     // epilogue option sets of the training step as compile-time instantiations (common.h: kEpi*)
     static const bool no_epi = xmc_debug_off("no_wtile_epi");
     const int epi = no_epi ? -1 : xmc_epi_mask(d);

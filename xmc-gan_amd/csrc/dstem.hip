@@ -115,14 +115,15 @@ __global__ __launch_bounds__(512, 4) void dstem_fwd_kernel(const u32x4* __restri
     const float sl = cq < 2 ? slope : 1.f;
     const float* bp = bias + cq * 32 + g * 8;
     const f32x4 b0v = *reinterpret_cast<const f32x4*>(bp), b1v = *reinterpret_cast<const f32x4*>(bp + 4);
-    int tile = blockIdx.x, buf = 0;
-    if (tile < ntiles) prefetch(tile);
-    for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
+    const XcdWalk xw = xmc_xcd_walk(ntiles);
+    int tile = xw.first, buf = 0;
+    if (tile < xw.end) prefetch(tile);
+    for (; tile < xw.end; tile += xw.step, buf ^= 1) {
 #pragma unroll
         for (int it = 0; it < 2; ++it)
             if (tid + it * 512 < PUNITS) patch[buf][tid + it * 512] = pv[it];
         __syncthreads();
-        if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);
+        if (tile + xw.step < xw.end) prefetch(tile + xw.step);
         f32x4 acc[NBLK][2];
 #pragma unroll
         for (int b = 0; b < NBLK; ++b)
@@ -239,9 +240,10 @@ __global__ __launch_bounds__(512, 4) void dstem_wgrad_kernel(const u32x4* __rest
         const int tq = 4 * j + pp4, ta = tq / 6, tb = tq - 6 * ta;
         boff[j] = ((ta * 2 + (tb & 1)) * PLANE + (tb >> 1) + 4 * fg + q) * 8;
     }
-    int tile = blockIdx.x;
-    if (tile < ntiles) prefetch(tile);
-    for (; tile < ntiles; tile += gridDim.x) {
+    const XcdWalk xw = xmc_xcd_walk(ntiles);
+    int tile = xw.first;
+    if (tile < xw.end) prefetch(tile);
+    for (; tile < xw.end; tile += xw.step) {
         __syncthreads();                                      // previous tile's reads are done
 #pragma unroll
         for (int it = 0; it < YIT; ++it) {
@@ -254,7 +256,7 @@ __global__ __launch_bounds__(512, 4) void dstem_wgrad_kernel(const u32x4* __rest
         for (int it = 0; it < XIT; ++it)
             if (tid + it * 512 < PUNITS) *reinterpret_cast<u32x2*>(xp + xdst[it]) = xv[it];
         __syncthreads();
-        if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);
+        if (tile + xw.step < xw.end) prefetch(tile + xw.step);
         int zq = 0;
         asm volatile("" : "+v"(zq));                          // opaque zero: keeps the fragment addresses out of the tile loop's live set
         const unsigned char* afr = afrag + zq;
@@ -569,9 +571,10 @@ __global__ __launch_bounds__(256) void dstem_dgrad_kernel(const u32x4* __restric
             pv[it] = ok ? src[(((size_t)n * OH + sy) * OW + sx) * 8 + (ch & 7)] : u32x4{0, 0, 0, 0};
         }
     };
-    int tile = blockIdx.x;
-    if (tile < ntiles) prefetch(tile);
-    for (; tile < ntiles; tile += gridDim.x) {
+    const XcdWalk xw = xmc_xcd_walk(ntiles);
+    int tile = xw.first;
+    if (tile < xw.end) prefetch(tile);
+    for (; tile < xw.end; tile += xw.step) {
         __syncthreads();
 #pragma unroll
         for (int it = 0; it < MAXU; ++it) {
@@ -579,7 +582,7 @@ __global__ __launch_bounds__(256) void dstem_dgrad_kernel(const u32x4* __restric
             if (id < NUN) *reinterpret_cast<u32x4*>(smem + (id >> 4) * DG_PSTR + (id & 15) * 16) = pv[it];
         }
         __syncthreads();
-        if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);
+        if (tile + xw.step < xw.end) prefetch(tile + xw.step);
         const int n = tile / (tiles_y * tiles_x), tr = tile - n * (tiles_y * tiles_x);
         const int y0 = (tr / tiles_x) * DG_H, x0 = (tr % tiles_x) * DG_W;
 #pragma unroll
@@ -871,11 +874,11 @@ extern "C" int xmc_dstem_fwd(const void* img, const void* wfrag, const float* bi
     const int ntiles = N * (H / 8) * (W / 64);
     const int grid = ntiles < 512 ? ntiles : 512;
     if (sc)
-        hipLaunchKernelGGL(dstem_fwd_kernel<false>, dim3(grid), dim3(512), 0, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const u32x4*>(img),
+        hipLaunchKernelGGL(dstem_fwd_kernel<false>, dim3(xmc_ab_grid(grid)), dim3(512), 0, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const u32x4*>(img),
                            reinterpret_cast<const u32x4*>(wfrag), bias, reinterpret_cast<bf16x8*>(h1), reinterpret_cast<bf16x8*>(sc), N, H, W, slope,
                            ntiles);
     else
-        hipLaunchKernelGGL(dstem_fwd_kernel<true>, dim3(grid), dim3(512), 0, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const u32x4*>(img),
+        hipLaunchKernelGGL(dstem_fwd_kernel<true>, dim3(xmc_ab_grid(grid)), dim3(512), 0, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const u32x4*>(img),
                            reinterpret_cast<const u32x4*>(wfrag), bias, reinterpret_cast<bf16x8*>(h1), reinterpret_cast<bf16x8*>(sc), N, H, W, slope,
                            ntiles);
     xmc_note_kernel("dstem_fwd_kernel");
@@ -941,7 +944,7 @@ extern "C" int xmc_dstem_dgrad(const void* dh1, const void* dsc, const float* ws
     hipLaunchKernelGGL(dstem_pack_t_kernel, dim3(9), dim3(256), 0, st, wsets, reinterpret_cast<bf16x8*>(frag_scratch));
     const int ntiles = N * (H / 2 / DG_H) * (W / 2 / DG_W);
     const int grid = ntiles < 512 ? ntiles : 512;
-    hipLaunchKernelGGL(dstem_dgrad_kernel, dim3(grid), dim3(256), 0, st, reinterpret_cast<const u32x4*>(dh1), reinterpret_cast<const u32x4*>(dsc),
+    hipLaunchKernelGGL(dstem_dgrad_kernel, dim3(xmc_ab_grid(grid)), dim3(256), 0, st, reinterpret_cast<const u32x4*>(dh1), reinterpret_cast<const u32x4*>(dsc),
                        reinterpret_cast<const u32x4*>(frag_scratch), reinterpret_cast<bf16x8*>(dimg), N, H, W, ntiles);
     xmc_note_kernel("dstem_dgrad_kernel");
     for (int phase = 0; phase < 2; ++phase) {
@@ -961,7 +964,7 @@ extern "C" int xmc_dstem_wgrad(const void* img, const void* dh1, const void* dsc
     const int grid = ntiles < 512 ? ntiles : 512;
     const size_t lds = (size_t)kWgTR * 32 * (128 * 2 + 32) + (size_t)(2 * kWgTR + 4) * 2 * 48 * 8;
     XMC_ALLOW_BIG_LDS(dstem_wgrad_kernel);
-    hipLaunchKernelGGL(dstem_wgrad_kernel, dim3(grid), dim3(512), lds, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const u32x4*>(img),
+    hipLaunchKernelGGL(dstem_wgrad_kernel, dim3(xmc_ab_grid(grid)), dim3(512), lds, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const u32x4*>(img),
                        reinterpret_cast<const u32x4*>(dh1), reinterpret_cast<const u32x4*>(dsc), dw, dbias, N, H, W, skip_border, ntiles);
     xmc_note_kernel("dstem_wgrad_kernel");
     XMC_LAUNCH_CHECK();
