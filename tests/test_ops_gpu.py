@@ -1310,6 +1310,73 @@ def test_composed_stem_block_equals_conv_img_plus_block(mode, N, S):
         assert e_ref < (3e-2 if mode == "bf16" else 4e-3) or e_ref < 1.5 * e_old + 1e-3, (n_, e_ref, e_old)
 
 
+@pytest.mark.parametrize("mode,N,S", [("f16", 3, 64), ("bf16", 2, 128)])
+def test_composed_stem_block_second_order_equals_the_reference_double_backward(mode, N, S):
+    """ops.DStemBwdFn: the MA-GP pattern on the composed stem block -- d(out . r)/d(image) with create_graph, a penalty on that
+    gradient, and ITS gradients with respect to every parameter (train_gan.py:231-252) -- against autograd's double backward of
+    conv_img + the block in f32 on the CPU, and against the un-composed second-order form (conv_img + ops.ResDFn) on the same inputs.
+    The penalty is a plain sum of squares here (the sixth power of the reference amplifies rounding sixfold and is tested end to end)."""
+    ops.set_precision(mode)
+    dt = ops.act_dtype()
+    from xmc_gan.model.df_gan import resD
+    from xmc_gan.model.modules import HipConv2d
+    torch.manual_seed(7)
+    conv_img = HipConv2d(3, 32, 3, 1, 1).to(DEV)
+    blk = resD(32, 64, True).to(DEV)
+    with torch.no_grad():
+        blk.gamma.fill_(0.6)
+        conv_img.bias.normal_(0, 0.1)
+        blk.conv_s.bias.normal_(0, 0.1)
+    g = torch.Generator().manual_seed(N + S)
+    x = rt(torch.rand(N, 3, S, S, generator=g) * 2 - 1, mode)
+    r = rt(torch.randn(N, 64, S // 2, S // 2, generator=g), mode)
+    params = [conv_img.weight, conv_img.bias, blk.conv_r[0].weight, blk.conv_r[2].weight, blk.conv_s.weight, blk.conv_s.bias, blk.gamma]
+    r0, r2, s_ = blk.conv_r[0], blk.conv_r[2], blk.conv_s
+
+    def penalty_grads(form):
+        for p_ in params:
+            p_.grad = None
+        ops.new_iteration(DEV)
+        xin = to_nhwc(x, 8, dt).requires_grad_()
+        with ops.second_order():
+            if form == "composed":
+                out, _ = ops.DStemBlockFn.apply(xin, conv_img.weight, conv_img.bias, r0.weight, r2.weight, s_.weight, s_.bias, blk.gamma,
+                                                conv_img.geom, r0.geom, r2.geom, s_.geom, True)
+            else:
+                ci, cip = conv_img(xin, want_pool=True)
+                out, _ = blk(ci, xp_hint=cip, want_pool=True)
+            with ops.no_wgrad():
+                gx, = torch.autograd.grad((out.float() * to_nhwc(r, 64, torch.float32)).sum(), xin, create_graph=True)
+        pen = (gx.float()[..., :3] ** 2).sum()
+        pen.backward()
+        return [None if p_.grad is None else p_.grad.detach().float().cpu().clone() for p_ in params], from_nhwc(gx.detach(), 3), pen.item()
+
+    g_n, gx_n, pen_n = penalty_grads("composed")
+    assert L.load().xmc_last_kernel().decode() != "", "no kernel ran"
+    g_o, gx_o, pen_o = penalty_grads("uncomposed")
+    P = [p_.detach().float().cpu().clone().requires_grad_() for p_ in params]
+    xr = x.clone().requires_grad_()
+    ci_r = F.conv2d(xr, P[0], P[1], 1, 1)
+    br = F.leaky_relu(F.conv2d(F.leaky_relu(F.conv2d(ci_r, P[2], None, 2, 1), 0.2), P[3], None, 1, 1), 0.2)
+    out_r = F.conv2d(F.avg_pool2d(ci_r, 2), P[4], P[5]) + P[6] * br
+    gx_r, = torch.autograd.grad((out_r * r).sum(), xr, create_graph=True)
+    pen_r = (gx_r ** 2).sum()
+    pen_r.backward()
+    tl = 3e-2 if mode == "bf16" else 4e-3
+    ex_n, ex_o = rel_l2(gx_n, gx_r.detach()), rel_l2(gx_o, gx_r.detach())
+    print(f"image gradient: composed vs f32 {ex_n:.2e}   conv_img + ResDFn vs f32 {ex_o:.2e};  penalty {pen_n:.5g} / {pen_o:.5g} / f32 {pen_r.item():.5g}")
+    assert (ex_n < tl or ex_n < 1.5 * ex_o + 1e-3) and abs(pen_n - pen_r.item()) < 2 * tl * pen_r.item(), (ex_n, ex_o, pen_n, pen_r.item())
+    names = ["conv_img.weight", "conv_img.bias", "conv_r.0.weight", "conv_r.2.weight", "conv_s.weight", "conv_s.bias", "gamma"]
+    for n_, a, b, c in zip(names, g_n, g_o, P):
+        if n_.endswith(".bias"):          # dx carries no bias term: zero (not None) gradients, as the reference's autograd hands out
+            assert a is not None and float(a.abs().max()) == 0.0 and (c.grad is None or float(c.grad.abs().max()) == 0.0), n_
+            continue
+        e_ref, e_old = rel_l2(a, c.grad), rel_l2(b, c.grad)
+        print(f"{n_:18s} composed vs f32 {e_ref:.2e}   conv_img + ResDFn vs f32 {e_old:.2e}")
+        assert e_ref < 2 * tl or e_ref < 1.5 * e_old + 1e-3, (n_, e_ref, e_old)
+    ops.set_precision("bf16")
+
+
 def rel_l2(a, b):
     return ((a - b).norm() / b.norm().clamp_min(1e-12)).item()
 

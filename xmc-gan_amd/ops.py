@@ -1770,7 +1770,6 @@ class DStemBlockFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xin, w_img, b_img, w0, w2, ws, bs, gamma, g_img, g0, g2, gs, want_pool=False):
-        assert not _second_order(), "the composed stem has no second-order form: NetD.forward routes MA-GP passes to ResDFn"
         xin = xin.contiguous()
         dt = xin.dtype
         N, H, W, _ = xin.shape
@@ -1781,7 +1780,10 @@ class DStemBlockFn(torch.autograd.Function):
         pool_ok = want_pool and H % 4 == 0 and W % 4 == 0
         # the shortcut (0.54 GB per 256 images, written here and read once by the block end) is recomputed from the image inside the
         # block-end kernel where that kernel takes the shape: 16 more MFMAs per wave and tile on an 18 x 66 pixel image patch
-        fuse_sc = pool_ok and OH % 8 == 0 and OW % 32 == 0 and "no_scimg" not in _DEBUG_DISPATCH      # (its two epilogue sets write the pooled output)
+        # MA-GP (ops.second_order()): the backward of this node is differentiated again (DStemBwdFn), whose linearised forward needs the
+        # residual branch's VALUES as its LeakyReLU' mask operand -- kept instead of the sign bits, with the shortcut as a tensor
+        so2 = _second_order()
+        fuse_sc = pool_ok and OH % 8 == 0 and OW % 32 == 0 and not so2 and "no_scimg" not in _DEBUG_DISPATCH      # (its two epilogue sets write the pooled output)
         h1, sc = _dstem_fwd_raw(xin, wsets, bias, want_sc=not fuse_sc)
         _dstem_border_fwd_raw(xin, wsets, bias, D, DB, h1)          # conv_r[0]'s zero padding of conv_img's output: 3 % of the pixels
         assert pool_ok == (want_pool and res_pool_ok(h1, g2))
@@ -1791,10 +1793,11 @@ class DStemBlockFn(torch.autograd.Function):
             if r is None:
                 raise RuntimeError("xmc_conv_ptile_scimg declined a shape DStemBlockFn expects it to take")
         else:
-            r = _conv_fwd_raw(h1, w2, None, g2, L.ACT_LRELU, dt, res=sc, alpha=al, want_sign=keep, want_pool=pool_ok, round_act=True)
+            r = _conv_fwd_raw(h1, w2, None, g2, L.ACT_LRELU, dt, res=sc, alpha=al, want_sign=keep and not so2, want2=keep and so2,
+                              want_pool=pool_ok, round_act=True)
         r = r if isinstance(r, tuple) else (r,)
         out = r[0]
-        bits = r[1] if keep else None
+        bits = r[1] if keep else None             # sign bytes, or (second order) the branch itself
         outp = r[-1] if pool_ok else None
         ctx.geoms = (g_img, g0, g2, gs)
         ctx.has_bs = bs is not None
@@ -1809,11 +1812,25 @@ class DStemBlockFn(torch.autograd.Function):
         return out
 
     @staticmethod
-    @torch.autograd.function.once_differentiable
     def backward(ctx, dout, _doutp=None):
         nin = 13
         if dout is None:
             return (None,) * nin
+        xin, h1, bits, w_img, b_img, w0, w2, ws, bs, gamma, wsets, D = ctx.saved_tensors
+        if bits is not None and bits.dtype != torch.uint8:
+            # second-order form: the first-order backward as a node of its own
+            need = tuple(bool(v) for v in ctx.needs_input_grad[:8])
+            outs = DStemBwdFn.apply(dout, xin, h1, bits, w_img, b_img, w0, w2, ws, bs, gamma, ctx.geoms, need, _skip_wgrad())
+            return tuple(outs) + (None,) * 5
+        if torch.is_grad_enabled():
+            raise RuntimeError("DStemBlockFn: this block kept only the sign bits of its residual branch; wrap the forward in "
+                               "ops.second_order() to differentiate its backward (the MA-GP pattern)")
+        with torch.no_grad():
+            return DStemBlockFn._backward_bits(ctx, dout)
+
+    @staticmethod
+    def _backward_bits(ctx, dout):
+        nin = 13
         xin, h1, bits, w_img, b_img, w0, w2, ws, bs, gamma, wsets, D = ctx.saved_tensors
         g_img, g0, g2, gs = ctx.geoms
         dt = xin.dtype
@@ -1851,6 +1868,96 @@ class DStemBlockFn(torch.autograd.Function):
         dwi, dw0, dws = dwi.view(w_img.shape), dw0.view(w0.shape), dws.view(ws.shape)
         return (dx, dwi.to(w_img.dtype), dbi.to(b_img.dtype), dw0.to(w0.dtype), dw2, dws.to(ws.dtype),
                 None if dbs is None else dbs.to(bs.dtype), dgamma) + (None,) * 5
+
+
+class DStemBwdFn(torch.autograd.Function):
+    """First-order backward of DStemBlockFn as a node of its own (MA-GP: the penalty is a function of this node's dx; ResDBwdFn is the
+    same idea for the later blocks).  With A = the composed residual-branch stem (6x6 stride 2 + border corrections), B = the composed
+    shortcut, C2 = conv_r[2], m1 = LeakyReLU'(h1), m2 = LeakyReLU'(branch):
+        forward:   gr = gamma m2 * dout,  gh = m1 * C2^T gr,  dx = A^T gh + B^T dout          (xmc_dstem_dgrad + border)
+                   parameter gradients as in DStemBlockFn (tables from xmc_dstem_wgrad, through the composition's adjoint)
+        backward for g = dL/d(dx) -- the linearised forward of the block applied to g, on the SAME stem kernels:
+                   A g, B g   = xmc_dstem_fwd / _border_fwd on g with zero biases and slope 1
+                   v = m1 * A g;  d(dout) = B g + gamma m2 * C2 v;  d(gamma) = <m2 * dout, C2 v>;  d(w2) = wgrad(v, gr)
+                   d(tables) = xmc_dstem_wgrad(image := g, gh, dout) with the bias entries dropped (dx has no bias term), then the
+                   composition's adjoint to conv_img / conv_r[0] / conv_s.
+    Only d(dx) is differentiated again."""
+
+    @staticmethod
+    def forward(ctx, dout, xin, h1, res, w_img, b_img, w0, w2, ws, bs, gamma, geoms, need, skip_w):
+        g_img, g0, g2, gs = geoms
+        ctx.set_materialize_grads(False)
+        ctx.dout_dtype = dout.dtype
+        dt = xin.dtype
+        N, H, W, _ = xin.shape
+        OH, OW = H // 2, W // 2
+        dout = dout.contiguous()
+        if dout.dtype != dt:
+            dout = dout.to(dt)
+        al = gamma.detach().reshape(-1).float()
+        dgam = _zeros_f32_out(1, xin.device)
+        wsets, bias, D, DB = _dstem_compose_raw(w_img, b_img, w0, ws, bs)
+        gr = torch.empty_like(res)
+        L.call("xmc_scale_mask_dot", _p(dout), _p(res), _p(al), _p(gr), _p(dgam), res.numel(), _code(dt), _st())
+        dw2 = _conv_wgrad_raw(h1, gr, g2).view(w2.shape) if (need[4] and not skip_w) else None
+        gh = _conv_dgrad_raw(gr, w2, g2, (OH, OW), dt, mask=h1)                          # includes LeakyReLU'(h1)
+        dx = _dstem_dgrad_raw(gh, dout, wsets, D, H, W) if need[0] else None
+        dwi = dbi = dw0 = dws = dbs = None
+        if not skip_w and any(need[1:4] + need[5:7]):
+            tabs = _dstem_wgrad_raw(xin, gh, dout)
+            dwi, dbi, dw0, dws, dbs = _dstem_compose_bwd_raw(w_img, b_img, w0, ws, bs, *tabs)
+            dwi, dw0, dws = dwi.view(w_img.shape).to(w_img.dtype), dw0.view(w0.shape).to(w0.dtype), dws.view(ws.shape).to(ws.dtype)
+            dbi = dbi.to(b_img.dtype)
+            dbs = None if dbs is None else dbs.to(bs.dtype)
+        dgamma = dgam.reshape(gamma.shape).to(gamma.dtype) if need[7] else None
+        ctx.geoms = geoms
+        ctx.save_for_backward(dout, h1, res, w_img, b_img, w0, w2, ws, bs, gamma, gr, gh, wsets, D)
+        return dx, dwi, dbi, dw0, dw2, dws, dbs, dgamma
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g, *g_params):
+        if any(t is not None for t in g_params):
+            raise NotImplementedError("DStemBwdFn: only d(dx) is differentiated again (the MA-GP penalty)")
+        nin = 14
+        if g is None:
+            return (None,) * nin
+        dout, h1, res, w_img, b_img, w0, w2, ws, bs, gamma, gr, gh, wsets, D = ctx.saved_tensors
+        g_img, g0, g2, gs = ctx.geoms
+        dt = h1.dtype
+        g = g.contiguous()
+        if g.dtype != dt:
+            g = g.to(dt)
+        skip_w = _skip_wgrad()
+        al = gamma.detach().reshape(-1).float()
+        zb = torch.zeros(128, dtype=torch.float32, device=g.device)
+        zdb = torch.zeros(64 * 8, dtype=torch.float32, device=g.device)
+        ag, bg = _dstem_fwd_raw(g, wsets, zb, slope=1.0)                                 # A g (interior form), B g
+        _dstem_border_fwd_raw(g, wsets, zb, D, zdb, ag, slope=1.0)                      # ... border pixels of A g
+        v = torch.empty_like(ag)
+        L.call("xmc_lrelu_mask", _p(ag), _p(h1), _p(v), ag.numel(), 0.2, _code(dt), _st())      # m1 * A g
+        ddout, c2 = _conv_fwd_raw(v, w2, None, g2, L.ACT_NONE, dt, res=bg, alpha=al, mask=res, want2=True)      # c2 = C2 v
+        dgamma = None
+        if ctx.needs_input_grad[10]:
+            u = torch.empty_like(c2)
+            L.call("xmc_lrelu_mask", _p(c2), _p(res), _p(u), c2.numel(), 0.2, _code(dt), _st())
+            dg = _zeros_f32_out(1, g.device)
+            L.call("xmc_dot", _p(dout), _p(u), _p(dg), u.numel(), _code(dt), _st())
+            dgamma = dg.reshape(gamma.shape).to(gamma.dtype)
+        dwi = dbi = dw0 = dw2 = dws = dbs = None
+        if not skip_w:
+            if ctx.needs_input_grad[7]:
+                dw2 = _conv_wgrad_raw(v, gr, g2).view(w2.shape)
+            if any(ctx.needs_input_grad[4:7]) or any(ctx.needs_input_grad[8:10]):
+                dW, dB, dD, dDB = _dstem_wgrad_raw(g, gh, dout)
+                dB.zero_()
+                dDB.zero_()                     # dx = A^T gh + B^T dout carries no bias term
+                dwi, dbi, dw0, dws, dbs = _dstem_compose_bwd_raw(w_img, b_img, w0, ws, bs, dW, dB, dD, dDB)
+                dwi, dw0, dws = dwi.view(w_img.shape).to(w_img.dtype), dw0.view(w0.shape).to(w0.dtype), dws.view(ws.shape).to(ws.dtype)
+                dbi = dbi.to(b_img.dtype)
+                dbs = None if dbs is None else dbs.to(bs.dtype)
+        return (ddout.to(ctx.dout_dtype) if ctx.needs_input_grad[0] else None, None, None, None, dwi, dbi, dw0, dw2, dws, dbs, dgamma,
+                None, None, None)
 
 
 class ResDBwdFn(torch.autograd.Function):

@@ -152,9 +152,10 @@ class NetD(nn.Module):
             b0 = self.downblocks[0]
             first = 0
             # conv_img + the first block on the composed stem (ops.DStemBlockFn: the image straight to the block's first activation and
-            # to its shortcut; conv_img's output never exists) wherever no second-order pass follows (MA-GP differentiates the
-            # backward of this forward: conv_img + ResDFn there)
-            if (ops.fused_blocks() and not self.conv_img.spec_norm and not ops.second_order_active() and b0.downsample
+            # to its shortcut; conv_img's output never exists).  Under MA-GP (the backward of this forward is differentiated again)
+            # the node keeps the branch values and its backward is ops.DStemBwdFn, on the same stem kernels
+            if (ops.fused_blocks() and not self.conv_img.spec_norm and b0.downsample
+                    and not (ops.second_order_active() and ops.debug_switch("no_dstem2"))
                     and ops.dstem_eligible(xin, self.conv_img.out_channels, b0.learned_shortcut, b0.conv_r[0].out_channels)):
                 r0, r2, s_ = b0.conv_r[0], b0.conv_r[2], b0.conv_s
                 out, pooled = ops.DStemBlockFn.apply(xin, self.conv_img.weight, self.conv_img.bias, r0.weight, r2.weight, s_.weight, s_.bias,
