@@ -878,8 +878,8 @@ def _dstem_compose_q(P):
 
 def dstem_applies(h: Hyper, x, second_order=False):
     """where the engine takes the composed stem: 16-bit modes at the width it is built for (ndf = 32), images that tile, no
-    spectral norm, no second-order pass (ops.dstem_eligible / NetD.forward)"""
-    return h.nch == 32 and not h.spec_norm and not second_order and x.shape[2] % 16 == 0 and x.shape[3] % 64 == 0
+    spectral norm (ops.dstem_eligible / NetD.forward); since round 4 also in the second-order pass (ops.DStemBwdFn)"""
+    return h.nch == 32 and not h.spec_norm and x.shape[2] % 16 == 0 and x.shape[3] % 64 == 0
 
 
 def _netd_forward_q(P, h: Hyper, x, a, second_order=False):
