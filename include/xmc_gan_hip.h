@@ -35,8 +35,9 @@ extern "C" {
  * 7: xmc_dstem_* (the discriminator's stem composed into one convolution from the image).
  * 8: XmcConvDesc.mask_bits, xmc_conv_ptile_bits / xmc_conv_wgrad_bits (the sign mask applied in the consumers' staging).
  * 9: XmcConvDesc.sc_img / sc_frag / sc_bias, xmc_conv_ptile_scimg, xmc_dstem_pack_sc (the stem block's shortcut recomputed from the image in
- *    its block-end kernel); xmc_dstem_fwd accepts sc == NULL. */
-#define XMC_ABI_VERSION 9
+ *    its block-end kernel); xmc_dstem_fwd accepts sc == NULL.
+ * 10: xmc_set_fixed_order (repeatable reductions, test mode). */
+#define XMC_ABI_VERSION 10
 
 /* XMC_BF16 names the 16-bit storage / MFMA-operand format THIS BUILD of the library was compiled for: bf16 in
  * libxmc_gan_hip.so, IEEE half in libxmc_gan_hip_f16.so (same sources, same entry points; xmc_half_format()). */
@@ -142,6 +143,9 @@ int xmc_half_format(void);
 /* Name (template instantiation, as rocprof prints it) of the convolution kernel the calling thread dispatched last;
  * "" before the first one.  Measurement aid for bench.py's roofline; not part of the reference's surface. */
 const char* xmc_last_kernel(void);
+/* test mode: the reductions that feed activations (GroupNorm statistics, the attention query gradient) run with one workgroup per
+ * reduction target, i.e. in a fixed summation order; returns the previous setting (ABI 10) */
+int xmc_set_fixed_order(int on);
 
 /* forward / dgrad implicit GEMM on MFMA (bf16: v_mfma_f32_16x16x32_bf16; f32: v_mfma_f32_16x16x4_f32) */
 int xmc_conv_igemm(const XmcConvDesc* d, void* stream);

@@ -122,7 +122,11 @@ def test_train_iteration_parity(yml, over, batch, steps, mode):
             b["sent_embs"][1] = b["sent_embs"][0] + 0.05 * b["sent_embs"][1]
             b["sent_embs"][4] = b["sent_embs"][3] + 0.05 * b["sent_embs"][4]
     _, _, o_outs = run_oracle_steps(h, PG, PD, batches, eps=PARITY_EPS)
-    netG, netD, p_outs, tapG, tapD = run_product_steps(h, PG, PD, batches, eps=PARITY_EPS)
+    # the attention-modulation generators run in the fixed-order test mode (ops.fixed_order: GroupNorm statistics and the attention
+    # query gradient summed by ONE workgroup per target), so their bars below describe the kernels, not the order of f32 atomics:
+    # tests/diag/fixed_order_probe.py, 128 px: run-to-run spread of the bf16 gradients 1.9 (!) -> 4e-2, fp32 1e-5 either way
+    with (ops.fixed_order() if h.gen != "DF_GEN" else contextlib.nullcontext()):
+        netG, netD, p_outs, tapG, tapD = run_product_steps(h, PG, PD, batches, eps=PARITY_EPS)
     if mode == "bf16" and h.gen == "DF_GEN" and not h.spec_norm:
         # kernel error proper: first iteration against the oracle that rounds where the engine rounds
         _, _, q_outs = run_oracle_steps(h, PG, PD, batches[:1], eps=PARITY_EPS, quant=True)
@@ -148,18 +152,14 @@ def test_train_iteration_parity(yml, over, batch, steps, mode):
     loose = None
     agg_g = 1.0
     if mode == "fp32" and h.gen != "DF_GEN" and h.img_size >= 128:
-        # the same cancelling sums (below) in f32: at 16 384 regions the order of the f32 atomics alone moves these tensors between
-        # 1.4e-3 and 5.2e-3 from run to run (two driver-box runs of this case); x4 on their per-tensor bar, aggregate unchanged
-        # (and what hangs off the pooled context: reasoner, value projection, modulation heads).  The tensors UPSTREAM of the
-        # attention logits (query / key projections and their GroupNorms: the bracket described below) moved up to 2.1e-2 on a
-        # third box: x10 for those four
+        # the same cancelling sums (below) in f32 at 16 384 regions.  Round 4, with the reductions in fixed order: the product repeats
+        # itself to 1e-5 per tensor (it did before as well -- the spread rounds 2-3 blamed was between BOXES running different tile
+        # counts), and sits at a FIXED distance from the oracle, which sums the same cancelling brackets in another order: tensors
+        # upstream of the attention logits (query / key projections and their GroupNorms) 1.3e-2 .. 2.1e-2, the rest of the concept
+        # stages <= 1.4e-2, everything as one vector 3.1e-3 (fixed_order_probe.py).  x6 / x3 per tensor, x2 on the vector
         upstream = lambda n: "concept_sampler" in n and n.split(".")[-2] in ("query_gconv", "key_gconv", "gn1", "gn2")
-        # (fourth box: upblocks.5.conv_out1.weight 5.5e-3 against 5e-3 -- every tensor of a block with a concept stage sees the
-        # same run-to-run spread, so the x4 covers the generator's blocks as a whole; the aggregate bound is what stays tight)
-        loose = (lambda n: n.startswith("upblocks.") or ".concept" in n, lambda n: 10.0 if upstream(n) else 4.0)
-        # all G tensors as one vector: 3.1e-3 on three consecutive runs of one box, carried by those four tensor kinds (their norms are
-        # not small); x2.5 on the 2e-3 bar for this case only
-        agg_g = 2.5
+        loose = (lambda n: n.startswith("upblocks.") or ".concept" in n, lambda n: 6.0 if upstream(n) else 3.0)
+        agg_g = 2.0
     if mode == "bf16" and h.gen != "DF_GEN":
         # Parameters upstream of the region-attention LOGITS (query / key projections and their GroupNorms).  Their gradient is
         # sum_p a_p (<dctx, x_p> - <dctx, ctx>) k_p over up to 16 384 regions: with the synthetic weights the attention is close
@@ -175,12 +175,12 @@ def test_train_iteration_parity(yml, over, batch, steps, mode):
         # 128 px against 1.4e-3 in fp32 mode on the same kernels) -- guard against gross errors only, like the tensors above; the
         # WEIGHTS of those two convolutions see the same gradient map (5.04e-1 against the 0.5 bar on one box) and join them.
         loose = (lambda n: ("concept_sampler" in n and n.split(".")[-2] in ("query_gconv", "key_gconv", "gn1", "gn2"))
-                 or (h.img_size >= 128 and (".concept" in n or ".conv_out1." in n or ".conv_out2." in n or n.endswith(".c_sc.bias"))), 6.0)
+                 or (h.img_size >= 128 and (".concept" in n or ".conv_out1." in n or ".conv_out2." in n or n.endswith(".c_sc.bias"))), 4.0)
         if h.img_size >= 128:
-            # ... and with those tensors at signal-to-noise ~1 the G gradients as ONE vector sit at 0.25-0.42 from the f32 oracle
-            # from run to run (bar 0.3): x2 for this case.  The kernels' own accuracy at this size is what the fp32 mode of the same
-            # case and the quantisation-aware comparison above assert.
-            agg_g = 2.0
+            # ... and with those tensors at signal-to-noise ~1 the G gradients as ONE vector sat at 0.25-0.42 from the f32 oracle
+            # from run to run; in the fixed-order mode the figure repeats (0.27 on the probe's inputs): x1.5 instead of x2.  The
+            # kernels' own accuracy at this size is what the fp32 mode of the same case asserts.
+            agg_g = 1.5
     for s in range(steps):
         # Step 0 is the strict kernel-accuracy check (identical weights on both sides).  Later steps start from weights
         # that differ in the last bits (f32 atomics order in the weight-gradient kernels is not deterministic), and the

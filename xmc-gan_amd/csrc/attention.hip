@@ -415,6 +415,7 @@ extern "C" int xmc_groupnorm_fwd(const void* x, const float* w, const float* b, 
     // 64 pixels per thread lane of the statistics pass: with 16, a 128x128x128 map had 4096 workgroups per launch ending in 1 M
     // atomics on 16 k addresses and read at 2.0 TB/s (sums) / 3.0 (backward sums); 64: whole forward 272 -> 202 us
     int bx = (HW + groups * 64 - 1) / (groups * 64); if (bx < 1) bx = 1;
+    if (xmc_fixed_order()) bx = 1;                   // one workgroup per image: each (image, channel) sum is formed in one order
     int ppb = (HW + bx - 1) / bx;
     hipError_t e = hipMemsetAsync(ws, 0, (size_t)N * C * 2 * 4, ST(s));
     if (e != hipSuccess) return -(1000 + (int)e);
@@ -436,6 +437,7 @@ extern "C" int xmc_groupnorm_bwd(const void* x, const void* dy, const float* w, 
     // 64 pixels per thread lane of the statistics pass: with 16, a 128x128x128 map had 4096 workgroups per launch ending in 1 M
     // atomics on 16 k addresses and read at 2.0 TB/s (sums) / 3.0 (backward sums); 64: whole forward 272 -> 202 us
     int bx = (HW + groups * 64 - 1) / (groups * 64); if (bx < 1) bx = 1;
+    if (xmc_fixed_order()) bx = 1;                   // one workgroup per image: each (image, channel) sum is formed in one order
     int ppb = (HW + bx - 1) / bx;
     hipError_t e = hipMemsetAsync(ws, 0, (size_t)N * C * 2 * 4, ST(s));
     if (e != hipSuccess) return -(1000 + (int)e);
@@ -474,7 +476,9 @@ extern "C" int xmc_attn_pool_bwd_acc(const void* key, const float* q, const void
     if (!key || !q || !x || !stats || !ctx || !dctx || !dq || !dkey || !dx || N < 1 || HW < 1) return XMC_EINVAL;
     if (pk != AP_PK || px != AP_PX || ncon != AP_CON) return XMC_ESHAPE;
     if (hipMemsetAsync(dq, 0, sizeof(float) * (size_t)N * AP_CON * AP_PK, ST(s)) != hipSuccess) return XMC_EINVAL;
-    const int ppc = ap_pixels_per_chunk(N, HW), chunks = (HW + ppc - 1) / ppc;
+    int ppc = ap_pixels_per_chunk(N, HW);
+    if (xmc_fixed_order()) ppc = (HW + AP_SLOTS - 1) / AP_SLOTS * AP_SLOTS;      // one run per image: dq gets one addition per element
+    const int chunks = (HW + ppc - 1) / ppc;
     dim3 grid(chunks, N);
     if (dtype == XMC_BF16) hipLaunchKernelGGL((attn_pool_bwd_kernel<XMC_BF16>), grid, dim3(NT), 0, ST(s), key, q, x, stats, ctx, dctx, dq, dkey, dx, dx_in, HW, scale, ppc);
     else if (dtype == XMC_F32) hipLaunchKernelGGL((attn_pool_bwd_kernel<XMC_F32>), grid, dim3(NT), 0, ST(s), key, q, x, stats, ctx, dctx, dq, dkey, dx, dx_in, HW, scale, ppc);

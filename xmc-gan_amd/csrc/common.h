@@ -39,6 +39,8 @@ void xmc_note_kernel(const char* fmt, ...);
 void xmc_note_generic_epi(const char* kernel, int mask);
 // true when `token` is listed in the XMC_DEBUG_DISPATCH environment variable (kernel A/B experiments; unset in production)
 bool xmc_debug_off(const char* token);
+// true in the fixed-order test mode (xmc_set_fixed_order): one workgroup per reduction target in the reductions that feed activations
+bool xmc_fixed_order();
 
 // HIP errors are reported as -(1000 + code): positive 1 is taken by "not this kernel's case" in the *_try dispatch chain
 // (hipErrorInvalidValue == 1 once made a stale error look like "not eligible", and the next kernel in the chain ran as well).

@@ -851,6 +851,13 @@ void xmc_note_generic_epi(const char* kernel, int mask) {
 
 // One debugging switch for the kernel dispatchers: XMC_DEBUG_DISPATCH="tok1,tok2,..." disables the named specialised kernels
 // (the dispatcher then falls through to the next, more general one).  Unset in production: every call returns false.
+// Fixed-order reductions (test mode, xmc_set_fixed_order): the reductions whose results feed ACTIVATIONS -- the GroupNorm statistics and
+// the attention logits' query gradient -- run with ONE workgroup per reduction target, so every f32 sum is formed in one order and an
+// iteration is repeatable bit for bit up to the parameter-gradient atomics (which feed nothing inside the iteration).
+static int g_fixed_order = 0;
+extern "C" int xmc_set_fixed_order(int on) { const int was = g_fixed_order; g_fixed_order = on ? 1 : 0; return was; }
+bool xmc_fixed_order() { return g_fixed_order != 0; }
+
 bool xmc_debug_off(const char* token) {
     static const char* env = getenv("XMC_DEBUG_DISPATCH");
     if (!env || !*env) return false;

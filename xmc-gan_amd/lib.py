@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("XMC_LIB_PATH", os.path.join(HERE, "libxmc_gan_hip.so"))   # override: kernel experiments
 LIB_PATH_F16 = os.environ.get("XMC_LIB_PATH_F16", os.path.join(HERE, "libxmc_gan_hip_f16.so"))
-ABI_VERSION = 9          # include/xmc_gan_hip.h XMC_ABI_VERSION; the ctypes structures below mirror that version
+ABI_VERSION = 10          # include/xmc_gan_hip.h XMC_ABI_VERSION; the ctypes structures below mirror that version
 
 # BF16 is the dtype code of "the 16-bit storage format of the loaded build": bf16 in libxmc_gan_hip.so, IEEE half in
 # libxmc_gan_hip_f16.so (the same sources compiled with -DXMC_H16_IS_F16; `use_variant`)
@@ -55,6 +55,7 @@ _SIGS = {
     "xmc_abi_version": [],
     "xmc_half_format": [],
     "xmc_last_kernel": [],
+    "xmc_set_fixed_order": [i32],
     "xmc_conv_igemm": [C.POINTER(ConvDesc), vp],
     "xmc_conv_wgrad": [C.POINTER(ConvDesc), vp, vp],
     "xmc_conv_wgrad_bias": [C.POINTER(ConvDesc), vp, vp, vp],

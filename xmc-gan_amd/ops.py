@@ -1745,6 +1745,21 @@ class ResDFn(torch.autograd.Function):
         return tuple(outs) + (None, None, None, None, None)
 
 
+class fixed_order:
+    """Context manager: the reductions that feed activations (GroupNorm statistics, the attention query gradient) in a fixed summation
+    order (xmc_set_fixed_order: one workgroup per reduction target).  A test mode -- it costs those launches their parallelism -- that
+    makes an iteration of the attention-modulation generators repeatable, so that their gradient tests need not budget for run-to-run
+    spread."""
+
+    def __enter__(self):
+        self.was = L.load().xmc_set_fixed_order(1)
+        return self
+
+    def __exit__(self, *a):
+        L.load().xmc_set_fixed_order(self.was)
+        return False
+
+
 def debug_switch(token):
     """True when `token` is listed in XMC_DEBUG_DISPATCH (A/B experiments; unset in production)"""
     return token in _DEBUG_DISPATCH
