@@ -12,6 +12,7 @@ bf16 mode (the benched mode: bf16 activations + packed conv weights, f32 accumul
   * against the plain f32 oracle, which measures the format itself: losses within 5e-2 (measured <= 2.6e-2), all gradient
     tensors of a backward as one vector within 0.3 (measured <= 0.21), single tensors within 0.5.  These figures are the stated
     cost of bf16 storage, not a kernel tolerance."""
+import contextlib
 import copy
 
 import pytest
