@@ -37,7 +37,8 @@ CARD, PW, SD = 16, 8, 4  # cardinality, bottleneck width p, state dim p' (df_con
 # gradient values where it writes a gradient tensor, convolution weights where it packs them (straight-through for the weight
 # gradient, which the engine accumulates in f32) -- and keeps all arithmetic in f32.  What then remains between this oracle and
 # the engine is summation order, i.e. kernel error proper, which separates it from the error of the number format.
-# Covers DF_GEN + DF_DISC (the benched path); the mode is off unless a test turns it on, the goldens never see it.
+# Covers DF_GEN + DF_DISC (the benched path) and, since round 4, the attention-modulation generators (CONCEPT_IN / CONCEPT_OUT_DF_GEN); the
+# mode is off unless a test turns it on, the goldens never see it.
 _QUANT = False
 _QSKIP = frozenset()      # storage sites that stay f32 although the mode is on (the per-site ladder, tests/diag/quant_ladder.py)
 _QGRAD = True             # round the gradient that flows back through a storage site as well
@@ -50,7 +51,11 @@ _QGRAD = True             # round the gradient that flows back through a storage
 #   d.last the LAST block sum (the [B,16*NCH,4,4] feature map COND_DNET reads): a site of its own only when it is skipped -- the
 #          engine's "f32 head" option keeps that map, the condition, joint_conv.0's output and the head's weights in f32
 QUANT_SITES = ("d.img", "d.conv_img", "d.r0", "d.r2", "d.pool", "d.sc", "d.sum", "d.last", "d.w", "h.c", "h.m", "h.w",
-               "g.stem", "g.aff", "g.c1", "g.c2", "g.sc", "g.sum", "g.act", "g.img", "g.w")
+               "g.stem", "g.aff", "g.c1", "g.c2", "g.sc", "g.sum", "g.act", "g.img", "g.w",
+               "g.c.split", "g.c.trans", "g.c.trunk", "g.c.key", "g.c.keyn", "g.c.mod", "g.c.out1", "g.c.out2")
+#   g.c.*  the attention-modulation generators (round 4): split_conv / trans_gconv outputs, the trunk after GroupNorm + LeakyReLU, the
+#          key projection and its GroupNorm, the modulated map of a concept stage, conv_out1 / conv_out2 outputs.  Everything per (sample,
+#          concept) -- queries, attention statistics, pooled contexts, the heads' gamma / beta -- is f32 in the engine
 
 
 class quant:
@@ -611,6 +616,9 @@ def _gn(P, p, x, groups):
     return F.group_norm(x, groups, P[f"{p}.weight"], P[f"{p}.bias"])
 
 
+q_ = q          # (the samplers below name their query `q`)
+
+
 def _cond_sampler(P, p, x, sent, normalize):
     """CondConceptSampler.forward (df_concept_gan.py:273-302): sentence query, region keys,
     softmax over H*W per (sample, concept), attention-weighted sum of x, grouped value proj."""
@@ -620,9 +628,9 @@ def _cond_sampler(P, p, x, sent, normalize):
     if normalize:
         q = _gn(P, f"{p}.gn1", q, CARD)
     q = q.view(B, CARD, -1, 1)
-    k = F.conv2d(x, P[f"{p}.key_gconv.weight"], groups=CARD)
+    k = q_(F.conv2d(x, qw(P[f"{p}.key_gconv.weight"], "g.w"), groups=CARD), "g.c.key")
     if normalize:
-        k = _gn(P, f"{p}.gn2", k, CARD)
+        k = q_(_gn(P, f"{p}.gn2", k, CARD), "g.c.keyn")
     k = k.view(B, CARD, -1, H * W)
     attn = torch.softmax(torch.matmul(q.transpose(2, 3), k), dim=3)          # [B,C,1,HW]
     ctx = torch.matmul(attn, x.view(B, CARD, -1, H * W).transpose(2, 3))      # [B,C,1,p]
@@ -637,9 +645,9 @@ def _self_sampler(P, p, x, normalize):
     if normalize:
         q = _gn(P, f"{p}.gn1", q, CARD)
     q = q.view(B, CARD, 1, -1)
-    k = F.conv2d(x, P[f"{p}.key_gconv.weight"], groups=CARD)
+    k = q_(F.conv2d(x, qw(P[f"{p}.key_gconv.weight"], "g.w"), groups=CARD), "g.c.key")
     if normalize:
-        k = _gn(P, f"{p}.gn2", k, CARD)
+        k = q_(_gn(P, f"{p}.gn2", k, CARD), "g.c.keyn")
     k = k.view(B, CARD, -1, H * W)
     attn = torch.matmul(q, k).view(B, CARD, -1) * P[f"{p}.norm"]
     attn = torch.softmax(attn, dim=2).view(B, CARD, 1, H * W)
@@ -663,11 +671,11 @@ def _mod_mlp(P, p, cond):
 def _concept_block(P, p, x, sent, h: Hyper, kind):
     """InConceptBlock.residual (df_concept_gan.py:213-253) / OutConceptBlock.residual (481-531)."""
     B = x.size(0)
-    e = F.leaky_relu(F.conv2d(x, P[f"{p}.split_conv.weight"]), LRELU)
-    e = F.conv2d(e, P[f"{p}.trans_gconv.weight"], None, 1, 1, 1, CARD)
+    e = q(F.leaky_relu(F.conv2d(x, qw(P[f"{p}.split_conv.weight"], "g.w")), LRELU), "g.c.split")
+    e = q(F.conv2d(e, qw(P[f"{p}.trans_gconv.weight"], "g.w"), None, 1, 1, 1, CARD), "g.c.trans")
     if h.normalize:
         e = _gn(P, f"{p}.gn", e, CARD)
-    e = F.leaky_relu(e, LRELU)
+    e = q(F.leaky_relu(e, LRELU), "g.c.trunk")
     gc = sent.view(B, 1, -1).repeat(1, CARD, 1)
     out = e
     for j in (1, 2):
@@ -683,7 +691,7 @@ def _concept_block(P, p, x, sent, h: Hyper, kind):
         cond = torch.cat([gc, ctx], dim=2).reshape(B, -1, 1, 1)
         gamma = _mod_mlp(P, f"{p}.gamma{j}_gconv", cond)
         beta = _mod_mlp(P, f"{p}.beta{j}_gconv", cond)
-        out = F.leaky_relu(gamma * out + beta, LRELU)
+        out = q(F.leaky_relu(gamma * out + beta, LRELU), "g.c.mod")
     return out
 
 
@@ -691,11 +699,11 @@ def _concept_g_block(P, p, x, sent, h: Hyper, kind, upsample):
     """ICAttnG_Block (df_concept_gan.py:133-156) / OCAG_Block (395-418)."""
     pad = 1 if kind == "in" else 0
     r = _concept_block(P, f"{p}.concept1", x, sent, h, kind)
-    r = F.leaky_relu(F.conv2d(r, P[f"{p}.conv_out1.weight"], P[f"{p}.conv_out1.bias"], 1, pad), LRELU)
+    r = q(F.leaky_relu(F.conv2d(r, qw(P[f"{p}.conv_out1.weight"], "g.w"), P[f"{p}.conv_out1.bias"], 1, pad), LRELU), "g.c.out1")
     r = _concept_block(P, f"{p}.concept2", r, sent, h, kind)
-    r = F.conv2d(r, P[f"{p}.conv_out2.weight"], P[f"{p}.conv_out2.bias"], 1, pad)
-    sc = F.conv2d(x, P[f"{p}.c_sc.weight"], P[f"{p}.c_sc.bias"]) if f"{p}.c_sc.weight" in P else x
-    out = P[f"{p}.gamma"] * r + sc
+    r = q(F.conv2d(r, qw(P[f"{p}.conv_out2.weight"], "g.w"), P[f"{p}.conv_out2.bias"], 1, pad), "g.c.out2")
+    sc = q(F.conv2d(x, qw(P[f"{p}.c_sc.weight"], "g.w"), P[f"{p}.c_sc.bias"]), "g.sc") if f"{p}.c_sc.weight" in P else x
+    out = q(P[f"{p}.gamma"] * r + sc, "g.sum")
     if upsample:
         out = F.interpolate(out, scale_factor=2)
     return out

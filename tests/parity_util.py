@@ -151,3 +151,89 @@ def compare_grads(tap_rec, oracle_grads, rtol, name="", floor=1e-5, agg_rtol=Non
         agg = (num2 / max(den2, 1e-300)) ** 0.5
         assert agg <= agg_rtol, f"{name}aggregate gradient error {agg:.3e} > {agg_rtol}"
     return worst
+
+
+def concept_quant_walk(kind, over=None, batch=3):
+    """Teacher-forced walk over the storage points of an attention-modulation generator (kind "in" / "out") in the engine's CURRENT
+    16-bit mode: every stage of the product reads the quantisation-aware ORACLE's (already rounded) input of that stage and its output is
+    compared with the oracle's value at the same point.  Returns [(block, site, bit-equal fraction, relative L2 error)]; the
+    key projection and its GroupNorm live inside the stage node and are covered through the stage output."""
+    import xmc_ref as X
+    from xmc_gan_amd import ops
+    from xmc_gan_amd.lib import ACT_LRELU
+    yml = {"in": "concept_in_df_gan_damsm_nomagp.yml", "out": "concept_out_df_gan_sbert_damsm_nomagp.yml"}[kind]
+    cfg, h = setup_cfg(yml, **(over or {"TRAIN.NCH": 8}))
+    PG, PD = X.synth_params(X.gen_shapes(h), 5), X.synth_params(X.netd_shapes(h), 6)
+    b = X.synth_batch(h, batch, seed=200, words_len=cfg.TEXT.MAX_LENGTH)
+    netG, _, _, _ = build_product(h, PG, PD)
+    fmt = torch.bfloat16 if ops.precision() == "bf16" else torch.float16
+    log, q0_, q1_ = [], X.q, X.q_
+
+    def rec_q(x, site=None):
+        y = q0_(x, site)
+        log.append((site, y.detach()))
+        return y
+
+    X.q = X.q_ = rec_q
+    try:
+        with torch.no_grad(), X.quant(True, fmt=fmt):
+            X.gen_forward(PG, h, b["noise"], b["sent_embs"])
+    finally:
+        X.q, X.q_ = q0_, q1_
+
+    def nhwc(t):
+        return t.permute(0, 2, 3, 1).contiguous().to(DEV, fmt)
+
+    rows = []
+
+    def cmp(blk_i, what, got_nhwc, want):
+        got = got_nhwc.permute(0, 3, 1, 2).float().cpu()[:, : want.size(1)]
+        rows.append((blk_i, what, (got == want).float().mean().item(), float((got - want).norm() / want.norm())))
+
+    sent = netG.proj_sent(b["sent_embs"].to(DEV)).float()
+    it = iter(log)
+    site, cur = next(it)
+    assert site == "g.stem", site
+    cur = cur.view(cur.size(0), 8 * h.nch, 4, 4)
+    with torch.no_grad():
+        for i, blk in enumerate(netG.upblocks):
+            xin = cur
+            for cname in ("concept1", "concept2"):
+                cb = getattr(blk, cname)
+                site, want = next(it); assert site == "g.c.split", site
+                cmp(i, cname + ".split_conv", cb.split_conv(nhwc(cur), act=ACT_LRELU), want); cur = want
+                site, want = next(it); assert site == "g.c.trans", site
+                cmp(i, cname + ".trans_gconv", cb.trans_gconv(nhwc(cur)), want); cur = want
+                site, want = next(it); assert site == "g.c.trunk", site
+                cmp(i, cname + ".trunk", ops.groupnorm(nhwc(cur), cb.gn.weight, cb.gn.bias, cb.cardinality, slope=0.2) if cb.normalize
+                    else ops.lrelu(nhwc(cur)), want); cur = want
+                for j in (1, 2):
+                    samp, reas = getattr(cb, f"concept_sampler{j}"), getattr(cb, f"concept_reasoner{j}")
+                    gm, bm = getattr(cb, f"gamma{j}_gconv"), getattr(cb, f"beta{j}_gconv")
+                    site, _ = next(it); assert site == "g.c.key", site
+                    if cb.normalize:
+                        site, _ = next(it); assert site == "g.c.keyn", site
+                    site, want = next(it); assert site == "g.c.mod", site
+                    x = nhwc(cur)
+                    hp = (samp.value_gconv.weight, reas.proj_edge.weight, gm[0].weight, gm[0].bias, gm[2].weight, gm[2].bias,
+                          bm[0].weight, bm[0].bias, bm[2].weight, bm[2].bias)
+                    gn1 = (samp.gn1.weight, samp.gn1.bias) if samp.normalize else (None, None)
+                    if kind == "in":
+                        y = samp.stage(x, ops.concept_query(sent, samp.query_gconv.weight, *gn1), 1.0, sent, hp)
+                    else:
+                        qv = ops.concept_gquery(ops.global_avgpool(x).view(x.size(0), -1), samp.query_gconv.weight, *gn1)
+                        y = samp.stage(x, qv, samp._scale, sent, hp + (getattr(cb, f"sent_linear{j}").weight,))
+                    cmp(i, f"{cname}.stage{j}", y, want); cur = want
+                site, want = next(it); assert site in ("g.c.out1", "g.c.out2"), site
+                conv = blk.conv_out1 if cname == "concept1" else blk.conv_out2
+                cmp(i, cname + "->" + site[4:], conv(nhwc(cur), act=ACT_LRELU) if cname == "concept1" else conv(nhwc(cur)), want); cur = want
+            r2 = cur
+            if blk.learnable_sc:
+                site, sc = next(it); assert site == "g.sc", site
+                cmp(i, "c_sc", blk.c_sc(nhwc(xin)), sc)
+            else:
+                sc = xin
+            site, want = next(it); assert site == "g.sum", site
+            cmp(i, "sum", ops.axpby(nhwc(sc), nhwc(r2), blk.gamma), want)
+            cur = torch.nn.functional.interpolate(want, scale_factor=2) if blk.upsample else want
+    return rows

@@ -156,3 +156,38 @@ def test_train_step_matches_reference_loop(name):
     if "g_buf_names" in fx.files:                 # BatchNorm generators: running statistics after the loop
         for j, n in enumerate(fx["g_buf_names"]):
             _close(stats(PG[str(n)]), fx["g_buf_final"][j], rtol=5e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize("gen", ["DF_GEN", "CONCEPT_IN_DF_GEN", "CONCEPT_OUT_DF_GEN"])
+def test_rounding_mode_is_off_by_default_and_visits_every_site(gen):
+    """`X.quant` (the oracle's 16-bit storage mode, used only by the GPU parity tests): off, a forward is the plain f32 restatement the
+    goldens pin; on, every rounding site tagged for the generator family is reached and each value it returns is a bf16 number."""
+    h = X.Hyper(img_size=64, nch=8, gen=gen)
+    PG = X.synth_params(X.gen_shapes(h), 5)
+    b = X.synth_batch(h, 2, seed=1)
+    seen, q0 = {}, X.q
+
+    def rec(x, site=None):
+        y = q0(x, site)
+        seen.setdefault(site, []).append(y.detach())
+        return y
+
+    with torch.no_grad():
+        plain = X.gen_forward(PG, h, b["noise"], b["sent_embs"])
+        X.q = X.q_ = rec
+        try:
+            again = X.gen_forward(PG, h, b["noise"], b["sent_embs"])           # hooks in place, mode off: identity
+            assert torch.equal(plain, again)
+            seen.clear()
+            with X.quant(True):
+                rounded = X.gen_forward(PG, h, b["noise"], b["sent_embs"])
+        finally:
+            X.q = X.q_ = q0
+    assert not torch.equal(plain, rounded) and (plain - rounded).abs().mean() < 2e-2
+    # (DF_GEN's restatement folds the tail LeakyReLU into the last block's stored tensor, as the engine does: no g.act there)
+    want = {"g.stem", "g.sum", "g.img"} | ({"g.aff", "g.c1", "g.c2", "g.sc"} if gen == "DF_GEN" else
+                                            {s for s in X.QUANT_SITES if s.startswith("g.c.")} | {"g.sc", "g.act"})
+    assert want <= set(seen), want - set(seen)
+    for site, vals in seen.items():
+        for v in vals:
+            assert torch.equal(v, v.to(torch.bfloat16).float()), site
