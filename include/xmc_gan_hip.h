@@ -36,8 +36,9 @@ extern "C" {
  * 8: XmcConvDesc.mask_bits, xmc_conv_ptile_bits / xmc_conv_wgrad_bits (the sign mask applied in the consumers' staging).
  * 9: XmcConvDesc.sc_img / sc_frag / sc_bias, xmc_conv_ptile_scimg, xmc_dstem_pack_sc (the stem block's shortcut recomputed from the image in
  *    its block-end kernel); xmc_dstem_fwd accepts sc == NULL.
- * 10: xmc_set_fixed_order (repeatable reductions, test mode). */
-#define XMC_ABI_VERSION 10
+ * 10: xmc_set_fixed_order (repeatable reductions, test mode).
+ * 11: xmc_set_prezeroed (the caller hands over zero-filled accumulators; the library skips its own memsets). */
+#define XMC_ABI_VERSION 11
 
 /* XMC_BF16 names the 16-bit storage / MFMA-operand format THIS BUILD of the library was compiled for: bf16 in
  * libxmc_gan_hip.so, IEEE half in libxmc_gan_hip_f16.so (same sources, same entry points; xmc_half_format()). */
@@ -146,6 +147,12 @@ const char* xmc_last_kernel(void);
 /* test mode: the reductions that feed activations (GroupNorm statistics, the attention query gradient) run with one workgroup per
  * reduction target, i.e. in a fixed summation order; returns the previous setting (ABI 10) */
 int xmc_set_fixed_order(int on);
+/* Accumulators the entry points below document as "zeroed here" -- xmc_groupnorm_fwd / _bwd `ws`, xmc_attn_pool_bwd_acc `dq`,
+ * xmc_global_avgpool's f32 `y` on maps of >= 256 pixels -- are cleared with a hipMemsetAsync of their own, one more launch per call
+ * (~100 per iteration of an attention-modulation generator).  on = 1: the caller promises they arrive ALREADY ZERO (the Python host
+ * carves them from an arena it clears once per iteration) and the library skips those memsets.  Returns the previous setting; process-wide,
+ * off by default (ABI 11) */
+int xmc_set_prezeroed(int on);
 
 /* forward / dgrad implicit GEMM on MFMA (bf16: v_mfma_f32_16x16x32_bf16; f32: v_mfma_f32_16x16x4_f32) */
 int xmc_conv_igemm(const XmcConvDesc* d, void* stream);

@@ -29,7 +29,7 @@ def test_library_loads_and_exports_every_declared_symbol(variant):
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/xmc_gan_hip.h but not exported"
     assert set(L.EXPORTS) == declared
-    assert lib.xmc_abi_version() == L.ABI_VERSION == 10
+    assert lib.xmc_abi_version() == L.ABI_VERSION == 11
     assert lib.xmc_adam_step_scaled(None, 1, None, 1, 0.0, 0.0, 0.0, 0.0, None, None, 7, 2.0, 0.5, 1, None) == -1
     # argument validation happens before any launch, so it is safe without a GPU
     d = L.ConvDesc()

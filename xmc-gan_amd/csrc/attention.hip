@@ -417,7 +417,7 @@ extern "C" int xmc_groupnorm_fwd(const void* x, const float* w, const float* b, 
     int bx = (HW + groups * 64 - 1) / (groups * 64); if (bx < 1) bx = 1;
     if (xmc_fixed_order()) bx = 1;                   // one workgroup per image: each (image, channel) sum is formed in one order
     int ppb = (HW + bx - 1) / bx;
-    hipError_t e = hipMemsetAsync(ws, 0, (size_t)N * C * 2 * 4, ST(s));
+    hipError_t e = xmc_zero_acc(ws, (size_t)N * C * 2 * 4, ST(s));
     if (e != hipSuccess) return -(1000 + (int)e);
     const int blocks = gn_apply_blocks(N, HW, C8);
     if (dtype == XMC_BF16) {
@@ -439,7 +439,7 @@ extern "C" int xmc_groupnorm_bwd(const void* x, const void* dy, const float* w, 
     int bx = (HW + groups * 64 - 1) / (groups * 64); if (bx < 1) bx = 1;
     if (xmc_fixed_order()) bx = 1;                   // one workgroup per image: each (image, channel) sum is formed in one order
     int ppb = (HW + bx - 1) / bx;
-    hipError_t e = hipMemsetAsync(ws, 0, (size_t)N * C * 2 * 4, ST(s));
+    hipError_t e = xmc_zero_acc(ws, (size_t)N * C * 2 * 4, ST(s));
     if (e != hipSuccess) return -(1000 + (int)e);
     const int blocks = gn_apply_blocks(N, HW, C8);   // grid.y = N images + one slice of blocks for the parameter gradients
     if (dtype == XMC_BF16) {
@@ -475,7 +475,7 @@ extern "C" int xmc_attn_pool_bwd_acc(const void* key, const float* q, const void
                                      int pk, int px, float scale, int dtype, void* s) {
     if (!key || !q || !x || !stats || !ctx || !dctx || !dq || !dkey || !dx || N < 1 || HW < 1) return XMC_EINVAL;
     if (pk != AP_PK || px != AP_PX || ncon != AP_CON) return XMC_ESHAPE;
-    if (hipMemsetAsync(dq, 0, sizeof(float) * (size_t)N * AP_CON * AP_PK, ST(s)) != hipSuccess) return XMC_EINVAL;
+    if (xmc_zero_acc(dq, sizeof(float) * (size_t)N * AP_CON * AP_PK, ST(s)) != hipSuccess) return XMC_EINVAL;
     int ppc = ap_pixels_per_chunk(N, HW);
     if (xmc_fixed_order()) ppc = (HW + AP_SLOTS - 1) / AP_SLOTS * AP_SLOTS;      // one run per image: dq gets one addition per element
     const int chunks = (HW + ppc - 1) / ppc;

@@ -41,6 +41,7 @@ void xmc_note_generic_epi(const char* kernel, int mask);
 bool xmc_debug_off(const char* token);
 // true in the fixed-order test mode (xmc_set_fixed_order): one workgroup per reduction target in the reductions that feed activations
 bool xmc_fixed_order();
+hipError_t xmc_zero_acc(void* p, size_t bytes, hipStream_t st);      // memset unless the caller promised zeros (xmc_set_prezeroed)
 
 // HIP errors are reported as -(1000 + code): positive 1 is taken by "not this kernel's case" in the *_try dispatch chain
 // (hipErrorInvalidValue == 1 once made a stale error look like "not eligible", and the next kernel in the chain ran as well).

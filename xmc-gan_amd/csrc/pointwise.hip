@@ -857,6 +857,10 @@ void xmc_note_generic_epi(const char* kernel, int mask) {
 static int g_fixed_order = 0;
 extern "C" int xmc_set_fixed_order(int on) { const int was = g_fixed_order; g_fixed_order = on ? 1 : 0; return was; }
 bool xmc_fixed_order() { return g_fixed_order != 0; }
+// the caller's promise that "zeroed here" accumulators arrive zero (include/xmc_gan_hip.h): xmc_zero_acc is the one place that memsets them
+static int g_prezeroed = 0;
+extern "C" int xmc_set_prezeroed(int on) { const int was = g_prezeroed; g_prezeroed = on ? 1 : 0; return was; }
+hipError_t xmc_zero_acc(void* p, size_t bytes, hipStream_t st) { return g_prezeroed ? hipSuccess : hipMemsetAsync(p, 0, bytes, st); }
 
 bool xmc_debug_off(const char* token) {
     static const char* env = getenv("XMC_DEBUG_DISPATCH");
@@ -970,7 +974,7 @@ extern "C" int xmc_global_avgpool(const void* x, void* y, int N, int HW, int C, 
         int64_t ppb = ((int64_t)N * HW + 2047) / 2048;          // ~2048 workgroups over the batch, >= 4 pixels per lane
         if (ppb < 4 * groups) ppb = 4 * groups;
         const int bx = (int)((HW + ppb - 1) / ppb);
-        if (hipMemsetAsync(y, 0, sizeof(float) * (size_t)N * C, ST(s)) != hipSuccess) return XMC_EINVAL;
+        if (xmc_zero_acc(y, sizeof(float) * (size_t)N * C, ST(s)) != hipSuccess) return XMC_EINVAL;
         if (dtype == XMC_BF16) hipLaunchKernelGGL((gap_big_kernel<XMC_BF16>), dim3(bx, N), dim3(NT), 0, ST(s), x, (float*)y, HW, C8, (int)ppb);
         else hipLaunchKernelGGL((gap_big_kernel<XMC_F32>), dim3(bx, N), dim3(NT), 0, ST(s), x, (float*)y, HW, C8, (int)ppb);
         XMC_LAUNCH_CHECK();

@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("XMC_LIB_PATH", os.path.join(HERE, "libxmc_gan_hip.so"))   # override: kernel experiments
 LIB_PATH_F16 = os.environ.get("XMC_LIB_PATH_F16", os.path.join(HERE, "libxmc_gan_hip_f16.so"))
-ABI_VERSION = 10          # include/xmc_gan_hip.h XMC_ABI_VERSION; the ctypes structures below mirror that version
+ABI_VERSION = 11          # include/xmc_gan_hip.h XMC_ABI_VERSION; the ctypes structures below mirror that version
 
 # BF16 is the dtype code of "the 16-bit storage format of the loaded build": bf16 in libxmc_gan_hip.so, IEEE half in
 # libxmc_gan_hip_f16.so (the same sources compiled with -DXMC_H16_IS_F16; `use_variant`)
@@ -56,6 +56,7 @@ _SIGS = {
     "xmc_half_format": [],
     "xmc_last_kernel": [],
     "xmc_set_fixed_order": [i32],
+    "xmc_set_prezeroed": [i32],
     "xmc_conv_igemm": [C.POINTER(ConvDesc), vp],
     "xmc_conv_wgrad": [C.POINTER(ConvDesc), vp, vp],
     "xmc_conv_wgrad_bias": [C.POINTER(ConvDesc), vp, vp, vp],
@@ -181,6 +182,8 @@ def load(v=None):
         raise RuntimeError(f"{path}: ABI version {lib.xmc_abi_version()}, this binding needs {ABI_VERSION} (stale build?)")
     if lib.xmc_half_format() != (0 if v == "bf16" else 1):
         raise RuntimeError(f"{path} was not built for the {v} storage format")
+    # ops.py hands every accumulator the header documents as "zeroed here" over as a slice of its once-per-iteration zero arena
+    lib.xmc_set_prezeroed(1)
     _libs[v] = lib
     return lib
 

@@ -693,10 +693,12 @@ class _EscapeBlocks:
     GRANULE, MIN_BLOCK = 64, 1 << 14
 
     def __init__(self):
-        self.buf, self.off = {}, {}
+        self.buf, self.off, self.need, self.last = {}, {}, {}, {}
 
     def new_iteration(self, device):
-        self.buf.pop((device.type, device.index), None)          # owners of its slices keep the storage alive
+        key = (device.type, device.index)
+        self.buf.pop(key, None)                                  # owners of its slices keep the storage alive
+        self.last[key], self.need[key] = self.need.get(key, 0), 0
 
     def zeros(self, shape, device):
         key = (device.type, device.index)
@@ -704,9 +706,13 @@ class _EscapeBlocks:
         for s_ in shape:
             n *= s_
         n4 = (n + self.GRANULE - 1) // self.GRANULE * self.GRANULE
+        self.need[key] = self.need.get(key, 0) + n4
         buf, off = self.buf.get(key), self.off.get(key, 0)
         if buf is None or off + n4 > buf.numel():
-            buf = self.buf[key] = torch.zeros(max(self.MIN_BLOCK, n4), dtype=torch.float32, device=device)
+            # a fresh block sized by what the previous iteration asked for in total (the attention-modulation generators' head
+            # gradients are 100-300 KB each: with 64 KB blocks every one of their 48 requests was a block, i.e. a fill launch, of its own)
+            want = max(self.MIN_BLOCK, n4, self.last.get(key, 0) - self.need[key] + n4)
+            buf = self.buf[key] = torch.zeros(want, dtype=torch.float32, device=device)
             off = 0
         self.off[key] = off + n4
         return buf[off:off + n].view(shape)
@@ -2153,7 +2159,8 @@ class GapFn(torch.autograd.Function):
     def forward(ctx, x, out_dtype):
         x = x.contiguous()
         N, H, W, Cc = x.shape
-        y = torch.empty((N, Cc), dtype=out_dtype, device=x.device)
+        # (an f32 result is accumulated with atomics on big maps: handed over zero-filled, lib.load() has told the library so)
+        y = _zeros_f32_out((N, Cc), x.device) if out_dtype == torch.float32 else torch.empty((N, Cc), dtype=out_dtype, device=x.device)
         L.call("xmc_global_avgpool", _p(x), _p(y), N, H * W, Cc, _code(x.dtype), _code(out_dtype), _st())
         ctx.hw, ctx.dtype = (H, W), x.dtype
         return y
@@ -2278,7 +2285,7 @@ def _gn_fwd_raw(x, wf, bf, groups, slope, eps):
     N, H, W, Cc = x.shape
     y = torch.empty_like(x)
     stats = torch.empty((N, groups, 2), dtype=torch.float32, device=x.device)
-    ws = torch.empty((N, Cc, 2), dtype=torch.float32, device=x.device)
+    ws = _zeros_f32((N, Cc, 2), x.device)          # accumulators arrive zero (xmc_set_prezeroed): no memset launch per call
     L.call("xmc_groupnorm_fwd", _p(x), _p(wf), _p(bf), _p(y), _p(stats), _p(ws), N, H * W, Cc, groups, float(eps),
            float(slope), _code(x.dtype), _st())
     return y, stats
@@ -2288,7 +2295,7 @@ def _gn_bwd_raw(x, dy, wf, bf, stats, groups, slope):
     N, H, W, Cc = x.shape
     dx = torch.empty_like(x)
     dw, db = torch.empty_like(wf), torch.empty_like(bf)
-    ws = torch.empty(N * Cc * 2 + N * groups * 2, dtype=torch.float32, device=x.device)
+    ws = _zeros_f32(N * Cc * 2 + N * groups * 2, x.device)
     L.call("xmc_groupnorm_bwd", _p(x), _p(dy), _p(wf), _p(bf), _p(stats), _p(dx), _p(dw), _p(db), _p(ws), N, H * W, Cc,
            groups, float(slope), _code(x.dtype), _st())
     return dx, dw, db
@@ -2361,7 +2368,7 @@ class BatchNormTrainFn(torch.autograd.Function):
         wf, bf = w.detach().float().contiguous(), b.detach().float().contiguous()
         y = torch.empty_like(x)
         stats = torch.empty((1, Cc, 2), dtype=torch.float32, device=x.device)
-        ws = torch.empty((1, Cc, 2), dtype=torch.float32, device=x.device)
+        ws = _zeros_f32((1, Cc, 2), x.device)
         L.call("xmc_groupnorm_fwd", _p(x), _p(wf), _p(bf), _p(y), _p(stats), _p(ws), 1, N * H * W, Cc, Cc, float(eps), -1.0,
                _code(x.dtype), _st())
         ctx.save_for_backward(x, wf, bf, stats)
@@ -2377,7 +2384,7 @@ class BatchNormTrainFn(torch.autograd.Function):
         N, H, W, Cc = x.shape
         dx = torch.empty_like(x)
         dw, db = torch.empty_like(wf), torch.empty_like(bf)
-        ws = torch.empty(Cc * 2 + Cc * 2, dtype=torch.float32, device=x.device)
+        ws = _zeros_f32(Cc * 2 + Cc * 2, x.device)
         L.call("xmc_groupnorm_bwd", _p(x), _p(dy), _p(wf), _p(bf), _p(stats), _p(dx), _p(dw), _p(db), _p(ws), 1, N * H * W, Cc,
                Cc, -1.0, _code(x.dtype), _st())
         return dx, dw, db, None
@@ -2402,7 +2409,7 @@ def _attn_bwd_raw(key, q, x, stats, out, dctx, ncon, scale, dx_acc=None):
     """``dx_acc``: another gradient of x; the kernel adds it on the way out and the sum is written IN PLACE into it."""
     N, H, W, CK = key.shape
     pk, px = CK // ncon, x.shape[3] // ncon
-    dq = torch.empty_like(q)
+    dq = _zeros_f32_out(tuple(q.shape), q.device)
     dkey = torch.empty_like(key)
     dx = torch.empty_like(x) if dx_acc is None else dx_acc
     assert dx.shape == x.shape and dx.dtype == x.dtype and dx.is_contiguous()
