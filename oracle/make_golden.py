@@ -37,13 +37,32 @@ def stats(t):
     return np.array([f.sum().item(), f.abs().sum().item(), f[0].item(), f[n // 2].item(), f[-1].item()])
 
 
+def repaired_word_in_netg(cfg, M):
+    """The reference's concept_gan.InNetG with the two run-time patches that make it runnable (oracle/xmc_ref.py
+    word_in_netg_forward states them): every word-region sampler is re-created BY THE REFERENCE'S OWN CLASS with cond_dim = NEF --
+    the channel count the forward feeds it (concept_gan.py:570-573) instead of noise_dim + nef (137, 183) -- and every InConceptBlock
+    gets the `upsample` attribute its forward reads (222) from the enclosing block.  Everything else that runs is upstream code."""
+    cg = M.concept_gan
+    net = cg.InNetG(cfg)
+    for blk in net.upblocks:
+        if isinstance(blk, cg.ICAttnResBlockUp):
+            cb = blk.concept1
+            cb.upsample = blk.upsample
+            for j in (1, 2):
+                setattr(cb, f"concept_sampler{j}", cg.CondConceptSampler(
+                    cardinality=cb.cardinality, bottleneck_width=8, state_dim=4, cond_dim=cfg.TRAIN.NEF, normalize=cb.normalize))
+    return net
+
+
 def build_ref(cfg, M, seed):
     """Reference models with deterministic synthetic parameters (strict load pins keys+shapes)."""
     h = X.Hyper.from_cfg(cfg)
     gen_cls = {"DF_GEN": M.df_gan.NetG, "CONCEPT_IN_DF_GEN": M.df_concept_gan.InNetG,
                "CONCEPT_OUT_DF_GEN": M.df_concept_gan.OutNetG,
                # un-wired upstream (its registry entry is commented out, train_gan.py:31,44): the class itself is importable
-               "CONCEPT_OUTATTN_GEN": M.concept_gan.OutNetG}[cfg.GEN.ENCODER_NAME]
+               "CONCEPT_OUTATTN_GEN": M.concept_gan.OutNetG,
+               # broken upstream; runs with two patches applied to the reference's objects
+               "CONCEPT_INATTN_GEN": lambda c: repaired_word_in_netg(c, M)}[cfg.GEN.ENCODER_NAME]
     netG = gen_cls(cfg)
     netD = M.df_gan.NetD(cfg, is_disc=True)
     PG = X.synth_params(X.gen_shapes(h), seed)
@@ -286,6 +305,11 @@ def main():
     golden_forward("wordg64_nch8", "df_gan_damsm_nomagp.yml", 3, 51, a.out, **WG)
     golden_forward("wordg128_nonorm", "df_gan_sbert_damsm_nomagp.yml", 2, 52, a.out, **{"IMG.SIZE": 128, "GEN.NORMALIZE": False, **WG})
     golden_step("wordg64", "df_gan_damsm_nomagp.yml", 4, 2, 53, a.out, **WG)
+    # the word-REGION attention generator concept_gan.InNetG, repaired: repaired_word_in_netg above
+    WI = {"GEN.ENCODER_NAME": "CONCEPT_INATTN_GEN", **N8}
+    golden_forward("wordin64_nch8", "df_gan_damsm_nomagp.yml", 3, 61, a.out, **WI)
+    golden_forward("wordin128_nonorm", "df_gan_sbert_damsm_nomagp.yml", 2, 62, a.out, **{"IMG.SIZE": 128, "GEN.NORMALIZE": False, **WI})
+    golden_step("wordin64", "df_gan_damsm_nomagp.yml", 4, 2, 63, a.out, **WI)
     # frozen text front end: embedding + bidirectional LSTM over packed captions
     golden_rnn_encoder("enc_damsm", "df_gan_damsm.yml", 6, 41, a.out)
     golden_rnn_encoder("enc_len12", "df_gan_damsm.yml", 5, 42, a.out, **{"TEXT.MAX_LENGTH": 12, "TEXT.VOCA_SIZE": 500})

@@ -412,9 +412,47 @@ def word_netg_shapes(h: Hyper):
     return s
 
 
+def word_in_netg_shapes(h: Hyper):
+    """state_dict of the REPAIRED concept_gan.InNetG (concept_gan.py:67-103): stem and the two ResBlockUp as OutNetG's, then
+    ICAttnResBlockUp (123-165) with the word-region InConceptBlock (168-191).  Repair 1 (see `word_in_netg_forward`): the samplers'
+    key projection is a grouped Conv1d over `nef` word channels per concept -- upstream builds it for noise_dim + nef (183,185,527) and
+    feeds it nef (570-573), which raises; this is the only key whose shape differs from what upstream's constructor registers."""
+    a = word_gen_arch(h.img_size, h.nch)
+    gc = h.noise_dim + h.nef
+    gw, sw = CARD * PW, CARD * SD
+    full = word_netg_shapes(h)
+    s = {k: v for k, v in full.items() if k.startswith(("proj_", "upblocks.0.", "upblocks.1."))}
+    for i in range(2, a["depth"]):
+        p, ci, co = f"upblocks.{i}", a["in_channels"][i], a["out_channels"][i]
+        q = f"{p}.concept1"
+        s[f"{q}.split_conv.weight"] = (gw, ci, 1, 1)
+        s[f"{q}.trans_gconv.weight"] = (gw, PW, 3, 3)
+        if h.normalize:
+            s[f"{q}.gn.weight"] = (gw,); s[f"{q}.gn.bias"] = (gw,)
+        for j in (1, 2):
+            s[f"{q}.concept_sampler{j}.query_gconv.weight"] = (sw, PW, 1, 1)
+            s[f"{q}.concept_sampler{j}.key_gconv.weight"] = (sw, h.nef, 1)                 # repair 1: nef, not noise_dim + nef
+            if h.normalize:
+                for g_ in ("gn1", "gn2"):
+                    s[f"{q}.concept_sampler{j}.{g_}.weight"] = (sw,); s[f"{q}.concept_sampler{j}.{g_}.bias"] = (sw,)
+            s[f"{q}.concept_reasoner{j}.proj_edge.weight"] = (CARD, SD)
+            if h.normalize:
+                _bn_shapes(s, f"{q}.concept_reasoner{j}.bn", CARD)
+        for j in (1, 2):            # (registration order upstream: both samplers / reasoners first, then the four heads, 188-191)
+            for nm in ("gamma", "beta"):
+                s[f"{q}.{nm}{j}_gconv.weight"] = (gw, gc + SD, 1, 1); s[f"{q}.{nm}{j}_gconv.bias"] = (gw,)
+        s[f"{p}.conv_out1.weight"] = (co, gw, 1, 1); s[f"{p}.conv_out1.bias"] = (co,)
+        if ci != co:
+            s[f"{p}.c_sc.weight"] = (co, ci, 1, 1); s[f"{p}.c_sc.bias"] = (co,)
+    s["conv_out.1.weight"] = full["conv_out.1.weight"]; s["conv_out.1.bias"] = full["conv_out.1.bias"]
+    return s
+
+
 def gen_shapes(h: Hyper):
     if h.gen == "CONCEPT_OUTATTN_GEN":
         return word_netg_shapes(h)
+    if h.gen == "CONCEPT_INATTN_GEN":
+        return word_in_netg_shapes(h)
     return netg_shapes(h) if h.gen == "DF_GEN" else concept_netg_shapes(h)
 
 
@@ -822,9 +860,81 @@ def word_netg_forward(P, h: Hyper, noise, sent_embs, words_embs=None, mask=None,
     return _tail(P, out)
 
 
+def _word_region_sampler(P, p, x, words, mask, normalize):
+    """concept_gan.CondConceptSampler.forward + get_context_embs (532-580): every REGION queries the caption words.  query =
+    grouped 1x1 of the map [-> GroupNorm], key = grouped Conv1d of the words repeated per concept [-> GroupNorm over (p', T), padded
+    positions included, as upstream]; both L2-normalised over p'; cosine scores [B,C,HW,T], padded words -> -inf, softmax over T,
+    attention-weighted sum of the normalised keys, MEAN over the regions -> [B, C*p', 1, 1]."""
+    B, _, H, W = x.shape
+    T = words.size(-1)
+    qy = F.conv2d(x, P[f"{p}.query_gconv.weight"], groups=CARD)
+    if normalize:
+        qy = _gn(P, f"{p}.gn1", qy, CARD)
+    qy = F.normalize(qy.view(B, CARD, -1, H * W), p=2, dim=2)
+    k = F.conv1d(words.view(B, 1, -1, T).repeat(1, CARD, 1, 1).view(B, -1, T), P[f"{p}.key_gconv.weight"], groups=CARD)
+    if normalize:
+        k = _gn(P, f"{p}.gn2", k, CARD)
+    k = F.normalize(k.view(B, CARD, -1, T), p=2, dim=2)
+    sim = torch.matmul(qy.transpose(2, 3), k).masked_fill(mask.view(B, 1, 1, T), float("-inf"))
+    ctx = torch.matmul(torch.softmax(sim, dim=3), k.transpose(2, 3)).mean(dim=2)                   # [B,C,p']
+    return ctx.reshape(B, -1, 1, 1)
+
+
+def _word_in_concept_block(P, p, x, gcond, words, mask, h: Hyper, upsample, train):
+    """concept_gan.InConceptBlock.forward (193-240) with repair 2: `self.upsample`, read at 222 and never assigned by the constructor
+    (170-191), is the enclosing ICAttnResBlockUp's flag -- the value its shortcut (148-149) needs the residual to agree with."""
+    B = x.size(0)
+    e = F.relu(F.conv2d(x, P[f"{p}.split_conv.weight"]))
+    e = F.conv2d(e, P[f"{p}.trans_gconv.weight"], None, 1, 1, 1, CARD)
+    if h.normalize:
+        e = _gn(P, f"{p}.gn", e, CARD)
+    out = F.relu(e)
+    gc = gcond.view(B, 1, -1).repeat(1, CARD, 1)
+    for j in (1, 2):
+        ctx = _word_region_sampler(P, f"{p}.concept_sampler{j}", out, words, mask, h.normalize)
+        ctx = _word_reasoner(P, f"{p}.concept_reasoner{j}", ctx, h.normalize, train).view(B, CARD, -1)
+        cond = torch.cat([gc, ctx], dim=2).reshape(B, -1, 1, 1)
+        gamma = F.conv2d(cond, P[f"{p}.gamma{j}_gconv.weight"], P[f"{p}.gamma{j}_gconv.bias"], groups=CARD)
+        beta = F.conv2d(cond, P[f"{p}.beta{j}_gconv.weight"], P[f"{p}.beta{j}_gconv.bias"], groups=CARD)
+        out = F.relu(gamma * out + beta)
+        if j == 1 and upsample:
+            out = F.interpolate(out, scale_factor=2)
+    return out
+
+
+def word_in_netg_forward(P, h: Hyper, noise, sent_embs, words_embs=None, mask=None, train=True, **_):
+    """concept_gan.InNetG.forward (105-121), REPAIRED.  Upstream's class cannot run: (1) CondConceptSampler.key_gconv is
+    built with cond_dim = noise_dim + nef input channels per concept (137, 183, 527) but receives the projected words, nef channels
+    (570-573) -> RuntimeError; (2) InConceptBlock.forward reads self.upsample (222), which no constructor sets -> AttributeError.
+    The repair changes exactly those two things -- key_gconv takes nef channels (what it is fed), the block inherits its parent's
+    upsample flag (what the parent's shortcut assumes) -- and nothing else; `oracle/make_golden.py` applies the same two patches to
+    the reference's own objects at run time, so fwd_wordin* / step_wordin* pin this restatement against upstream's code for every
+    other line."""
+    a = word_gen_arch(h.img_size, h.nch)
+    sent = F.linear(sent_embs, P["proj_sent.weight"], P["proj_sent.bias"])
+    words = F.conv1d(words_embs, P["proj_word.weight"], P["proj_word.bias"])
+    gcond = torch.cat([noise, sent], dim=1)
+    out = F.linear(gcond, P["proj_cond.weight"], P["proj_cond.bias"]).view(noise.size(0), -1, 4, 4)
+    for i in range(a["depth"]):
+        p = f"upblocks.{i}"
+        if i < 2:
+            out = _res_block_up(P, p, out, gcond, h, train)
+            continue
+        up = a["upsample"][i]
+        r = _word_in_concept_block(P, f"{p}.concept1", out, gcond, words, mask, h, up, train)
+        r = F.conv2d(r, P[f"{p}.conv_out1.weight"], P[f"{p}.conv_out1.bias"])
+        sc = F.interpolate(out, scale_factor=2) if up else out
+        if f"{p}.c_sc.weight" in P:
+            sc = F.conv2d(sc, P[f"{p}.c_sc.weight"], P[f"{p}.c_sc.bias"])
+        out = r + sc
+    return _tail(P, out)
+
+
 def gen_forward(P, h: Hyper, noise, sent_embs, **kw):
     if h.gen == "CONCEPT_OUTATTN_GEN":
         return word_netg_forward(P, h, noise, sent_embs, **kw)
+    if h.gen == "CONCEPT_INATTN_GEN":
+        return word_in_netg_forward(P, h, noise, sent_embs, **kw)
     f = netg_forward if h.gen == "DF_GEN" else concept_netg_forward
     return f(P, h, noise, sent_embs, **kw)
 
