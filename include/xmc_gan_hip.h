@@ -37,7 +37,8 @@ extern "C" {
  * 9: XmcConvDesc.sc_img / sc_frag / sc_bias, xmc_conv_ptile_scimg, xmc_dstem_pack_sc (the stem block's shortcut recomputed from the image in
  *    its block-end kernel); xmc_dstem_fwd accepts sc == NULL.
  * 10: xmc_set_fixed_order (repeatable reductions, test mode).
- * 11: xmc_set_prezeroed (the caller hands over zero-filled accumulators; the library skips its own memsets). */
+ * 11: xmc_set_prezeroed (the caller hands over zero-filled accumulators; the library skips its own memsets);
+ *     xmc_word_pool_fwd / _bwd (word-region attention of the repaired concept_gan.InNetG). */
 #define XMC_ABI_VERSION 11
 
 /* XMC_BF16 names the 16-bit storage / MFMA-operand format THIS BUILD of the library was compiled for: bf16 in
@@ -148,7 +149,8 @@ const char* xmc_last_kernel(void);
  * reduction target, i.e. in a fixed summation order; returns the previous setting (ABI 10) */
 int xmc_set_fixed_order(int on);
 /* Accumulators the entry points below document as "zeroed here" -- xmc_groupnorm_fwd / _bwd `ws`, xmc_attn_pool_bwd_acc `dq`,
- * xmc_global_avgpool's f32 `y` on maps of >= 256 pixels -- are cleared with a hipMemsetAsync of their own, one more launch per call
+ * xmc_global_avgpool's f32 `y` on maps of >= 256 pixels,
+ * xmc_word_pool_fwd `ctx` / _bwd `dkh` -- are cleared with a hipMemsetAsync of their own, one more launch per call
  * (~100 per iteration of an attention-modulation generator).  on = 1: the caller promises they arrive ALREADY ZERO (the Python host
  * carves them from an arena it clears once per iteration) and the library skips those memsets.  Returns the previous setting; process-wide,
  * off by default (ABI 11) */
@@ -381,6 +383,18 @@ int xmc_attn_pool_bwd(const void* key, const float* q, const void* x, const floa
 int xmc_attn_pool_bwd_acc(const void* key, const float* q, const void* x, const float* stats, const float* ctx, const float* dctx,
                           float* dq, void* dkey, void* dx, const void* dx_in, int N, int HW, int ncon, int pk, int px, float scale,
                           int dtype, void* stream);
+
+/* Word-region attention pooling of the word-attention generator concept_gan.InNetG (reference model/concept_gan.py
+ * CondConceptSampler.get_context_embs 532-555; the class is repaired here): every region's query attends over the caption's
+ * words.  qmap [N][HW][16*4] (dtype), the grouped 1x1 query projection after its GroupNorm; kh f32 [N][16][T][4], the per-concept word
+ * keys L2-normalised over the 4 state channels by the caller; pad u8 [N][T], 1 = padding word (score -inf); T <= 32.
+ * ctx f32 [N][16][4] = mean over regions of sum_t softmax_t(<q/|q|, kh_t>) kh_t  (accumulated with atomics: zeroed here).
+ * Backward: dq (qmap's layout and dtype) and dkh f32 [N][16][T][4] (zeroed here) from dctx f32 [N][16][4]; the attention is
+ * recomputed, nothing but ctx is kept between the passes (ABI 11). */
+int xmc_word_pool_fwd(const void* qmap, const float* kh, const unsigned char* pad, float* ctx, int N, int HW, int ncon, int pk, int T,
+                      int dtype, void* stream);
+int xmc_word_pool_bwd(const void* qmap, const float* kh, const unsigned char* pad, const float* dctx, void* dq, float* dkh, int N, int HW,
+                      int ncon, int pk, int T, int dtype, void* stream);
 
 /*
  * Contrastive head (cosine_scores + sent_loss/img_loss, train_gan.py:85-139), fused:

@@ -61,6 +61,10 @@ FWD_CASES = [
     ("df_gan_damsm_nomagp.yml", {"TRAIN.NCH": 8, "GEN.ENCODER_NAME": "CONCEPT_OUTATTN_GEN"}, 3),
     ("df_gan_sbert_damsm_nomagp.yml", {"TRAIN.NCH": 8, "GEN.ENCODER_NAME": "CONCEPT_OUTATTN_GEN", "IMG.SIZE": 128,
                                        "GEN.NORMALIZE": False}, 2),
+    # word-REGION attention generator (concept_gan.InNetG, repaired: xmc_gan/model/concept_gan.py docstring)
+    ("df_gan_damsm_nomagp.yml", {"TRAIN.NCH": 8, "GEN.ENCODER_NAME": "CONCEPT_INATTN_GEN"}, 3),
+    ("df_gan_sbert_damsm_nomagp.yml", {"TRAIN.NCH": 8, "GEN.ENCODER_NAME": "CONCEPT_INATTN_GEN", "IMG.SIZE": 128,
+                                       "GEN.NORMALIZE": False}, 2),
 ]
 
 
@@ -108,6 +112,7 @@ STEP_CASES = [
     ("concept_out_df_gan_sbert_damsm_nomagp.yml", {"TRAIN.NCH": 8}, 3, 1),               # self-attention G, E=768
     ("concept_in_df_gan_sbert_n2_damsm.yml", {"TRAIN.NCH": 8}, 3, 2),                    # N_CRITIC=2 + MA-GP
     ("df_gan_damsm_nomagp.yml", {"TRAIN.NCH": 8, "GEN.ENCODER_NAME": "CONCEPT_OUTATTN_GEN"}, 4, 2),   # word-attention G (BatchNorm)
+    ("df_gan_damsm_nomagp.yml", {"TRAIN.NCH": 8, "GEN.ENCODER_NAME": "CONCEPT_INATTN_GEN"}, 4, 2),    # word-region attention G (repaired)
     # DISC.SPEC_NORM: every discriminator layer wrapped in the legacy spectral_norm hook (modules.py:16-17,31-32)
     ("df_gan_damsm_nomagp.yml", {"TRAIN.NCH": 8, "DISC.SPEC_NORM": True}, 4, 2),
     ("df_gan_damsm.yml", {"TRAIN.NCH": 8, "DISC.SPEC_NORM": True}, 4, 1),                # ... under the MA-GP double backward
@@ -205,7 +210,7 @@ def test_train_iteration_parity(yml, over, batch, steps, mode):
         # at step 1 with everything at 1e-6 on a rerun).  Later steps therefore only verify the phase ordering, whose
         # violations are O(1) errors.
         k = 1.0 if s == 0 else 20.0
-        if over.get("GEN.ENCODER_NAME") == "CONCEPT_OUTATTN_GEN" and mode == "fp32":
+        if over.get("GEN.ENCODER_NAME") in ("CONCEPT_OUTATTN_GEN", "CONCEPT_INATTN_GEN") and mode == "fp32":
             # ReLU (not LeakyReLU) everywhere + batch statistics over 4 samples: this generator sits on kinks.  Evaluated in
             # f64, the same restatement differs from its own f32 CPU run by up to 3.7e-2 in a gradient tensor (8 seeds, linear
             # loss, no discriminator involved; the HIP path stayed within 2.6e-4 of f64 in all 8), and a whole iteration
@@ -504,15 +509,16 @@ def test_word_attention_generator_batchnorm_state_and_eval_mode(mode):
     assert mean_abs_err(fake_e, fake_o) < (2e-2 if mode == "fp32" else 8e-2), mean_abs_err(fake_e, fake_o)
 
 
-def test_word_attention_generator_gradients_match_f64_evaluation():
-    """concept_gan.OutNetG alone under a loss that is linear in the image (no discriminator, so no kinks outside the
+@pytest.mark.parametrize("gen", ["CONCEPT_OUTATTN_GEN", "CONCEPT_INATTN_GEN"])
+def test_word_attention_generator_gradients_match_f64_evaluation(gen):
+    """concept_gan.OutNetG / the repaired InNetG alone under a loss that is linear in the image (no discriminator, so no kinks outside the
     generator): every parameter gradient of the HIP path (fp32 mode) against the oracle restatement evaluated in float64,
     the limit both f32 implementations approximate.  Measured <= 2.6e-4 over 8 seeds in one process and up to 2.3e-3 across
     runs (f32 atomics order; the softmax over 4096 pixels in the last block's sampler is the sensitive spot), against up to
     3.7e-2 for the f32 CPU evaluation of the same restatement; bar 1e-2 relative L2 per tensor
     (tensors below 1e-5 of the largest gradient norm are compared on that scale)."""
     ops.set_precision("fp32")
-    cfg, h = setup_cfg("df_gan_damsm_nomagp.yml", **{"TRAIN.NCH": 8, "GEN.ENCODER_NAME": "CONCEPT_OUTATTN_GEN"})
+    cfg, h = setup_cfg("df_gan_damsm_nomagp.yml", **{"TRAIN.NCH": 8, "GEN.ENCODER_NAME": gen})
     for seed in (0, 3):
         PG, PD = X.synth_params(X.gen_shapes(h), 5 + seed), X.synth_params(X.netd_shapes(h), 6)
         b = X.synth_batch(h, 4, seed=200 + seed, words_len=cfg.TEXT.MAX_LENGTH)

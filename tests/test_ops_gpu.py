@@ -844,6 +844,43 @@ def test_region_attention_pooling(N, H, W, mode):
 
 
 @pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("N,H,W,T", [(3, 16, 16, 18), (2, 10, 7, 5), (16, 32, 32, 18), (1, 128, 128, 24), (2, 8, 8, 32), (2, 4, 4, 16)])
+def test_word_region_attention_pooling(N, H, W, T, mode):
+    """ops.word_region_pool (the repaired concept_gan.InNetG's CondConceptSampler.get_context_embs, concept_gan.py:532-555): per
+    (sample, concept, REGION) cosine scores against the word keys, padded words at -inf, softmax over the words, attention-weighted key
+    sum, mean over regions -- forward and the gradients w.r.t. the query map and the keys against an f64 evaluation of the reference's
+    formula on the CPU.  Sizes: one run per image, ragged runs (70 regions), several runs per image, the three compile-time word
+    capacities (16 / 24 / 32), captions padded to different lengths."""
+    ops.set_precision(mode)
+    dt = ops.act_dtype()
+    g = torch.Generator().manual_seed(N * 1000 + H + T)
+    ncon, pk = 16, 4
+    qmap = rt(torch.randn(N, H, W, ncon * pk, generator=g) * 1.5, mode)
+    kh = torch.nn.functional.normalize(torch.randn(N, ncon, T, pk, generator=g), dim=3)
+    lens = torch.randint(1, T + 1, (N,), generator=g)
+    lens[0] = T
+    pad = torch.arange(T)[None, :] >= lens[:, None]
+    R = torch.randn(N, ncon, pk, generator=g)
+    qd, kd = qmap.double().requires_grad_(), kh.double().requires_grad_()
+    # the reference's formula: img [N,C,p',HW] and words [N,C,p',T] normalised over p', sim [N,C,HW,T], masked softmax over T
+    qn = torch.nn.functional.normalize(qd.view(N, H * W, ncon, pk).permute(0, 2, 3, 1), p=2, dim=2)
+    kn = kd.permute(0, 1, 3, 2)
+    sim = torch.matmul(qn.transpose(2, 3), kn).masked_fill(pad.view(N, 1, 1, T), float("-inf"))
+    ctx_ref = torch.matmul(torch.softmax(sim, dim=3), kn.transpose(2, 3)).mean(dim=2)
+    (ctx_ref * R.double()).sum().backward()
+    qp, kp = qmap.to(DEV, dt).requires_grad_(), kh.to(DEV).requires_grad_()
+    ctx = ops.word_region_pool(qp, kp, pad.to(DEV))
+    assert ctx.shape == (N, ncon, pk) and ctx.dtype == torch.float32
+    (ctx * R.to(DEV)).sum().backward()
+    rel = lambda u, v: ((u.detach().double().cpu() - v).norm() / v.norm().clamp_min(1e-30)).item()
+    assert rel(ctx, ctx_ref.detach()) < 1e-5, rel(ctx, ctx_ref.detach())
+    assert rel(kp.grad, kd.grad) < 1e-4, rel(kp.grad, kd.grad)
+    assert (kp.grad.cpu()[pad[:, None, :, None].expand_as(kh)] == 0).all()          # a padding word's key receives nothing
+    # the query gradient is stored in the activation format: 1e-2 in the 16-bit modes
+    assert rel(qp.grad, qd.grad) < (1e-5 if mode == "fp32" else 1e-2), rel(qp.grad, qd.grad)
+
+
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("N,H,W,C", [(3, 16, 16, 128), (2, 100, 7, 64), (64, 32, 32, 128), (1, 128, 128, 128), (2, 20, 20, 8)])
 def test_global_avgpool_large_maps(N, H, W, C, mode):
     """F.adaptive_avg_pool2d(x, 1) on the maps the concept samplers pool (df_concept_gan.py:557): the many-workgroup kernel

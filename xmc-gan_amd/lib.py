@@ -111,6 +111,8 @@ _SIGS = {
     "xmc_attn_pool_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp],
     "xmc_attn_pool_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp],
     "xmc_attn_pool_bwd_acc": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp],
+    "xmc_word_pool_fwd": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "xmc_word_pool_bwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "xmc_contrastive_ws_bytes": [i32, i32],
     "xmc_contrastive_fwd": [vp, vp, vp, vp, i32, i32, vp, vp, vp],
     "xmc_contrastive_bwd": [vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp],

@@ -2418,6 +2418,44 @@ def _attn_bwd_raw(key, q, x, stats, out, dctx, ncon, scale, dx_acc=None):
     return dkey, dq, dx
 
 
+class WordRegionPoolFn(torch.autograd.Function):
+    """Word-region attention of the repaired concept_gan.InNetG (concept_gan.py:532-555): qmap NHWC [B,H,W,64] (the query projection of
+    the map), kh f32 [B,16,T,4] (per-concept word keys, L2-normalised over the last axis), pad bool [B,T] (True = padding) ->
+    ctx f32 [B,16,4], the mean over the regions of each region's attention-weighted key sum.  One pass forward, one backward
+    (csrc/word_attention.hip); the [B,16,HW,T] attention tensor of the reference is never formed."""
+
+    @staticmethod
+    def forward(ctx, qmap, kh, pad):
+        qmap, kh = qmap.contiguous(), kh.contiguous().float()
+        _need_cuda(qmap, kh)
+        B, H, W, Cq = qmap.shape
+        T = kh.shape[2]
+        assert Cq == 64 and kh.shape == (B, 16, T, 4) and pad.shape == (B, T), (qmap.shape, kh.shape, pad.shape)
+        padu = pad.to(torch.uint8).contiguous()
+        out = _zeros_f32_out((B, 16, 4), qmap.device)
+        L.call("xmc_word_pool_fwd", _p(qmap), _p(kh), _p(padu), _p(out), B, H * W, 16, 4, T, _code(qmap.dtype), _st())
+        ctx.save_for_backward(qmap, kh, padu)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dctx):
+        qmap, kh, padu = ctx.saved_tensors
+        B, H, W, _ = qmap.shape
+        T = kh.shape[2]
+        dq = torch.empty_like(qmap)
+        dkh = _zeros_f32_out((B, 16, T, 4), qmap.device)
+        # (the query map's gradient is an activation gradient: in the half mode it carries the backward's loss scale like every
+        # other one, and dctx arrives scaled already)
+        L.call("xmc_word_pool_bwd", _p(qmap), _p(kh), _p(padu), _p(dctx.contiguous().float()), _p(dq), _p(dkh), B, H * W, 16, 4, T,
+               _code(qmap.dtype), _st())
+        return dq, dkh, None
+
+
+def word_region_pool(qmap, kh, pad):
+    return WordRegionPoolFn.apply(qmap, kh, pad)
+
+
 class AttnPoolFn(torch.autograd.Function):
     """Region attention of the concept samplers (df_concept_gan.py:293-299, 570-578): per (sample, concept) softmax over
     H*W of scale*<q, key>, then the attention-weighted sum of x.  key [N,H,W,ncon*pk], x [N,H,W,ncon*px], q f32 [N,ncon,pk]
