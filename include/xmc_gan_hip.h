@@ -38,7 +38,8 @@ extern "C" {
  *    its block-end kernel); xmc_dstem_fwd accepts sc == NULL.
  * 10: xmc_set_fixed_order (repeatable reductions, test mode).
  * 11: xmc_set_prezeroed (the caller hands over zero-filled accumulators; the library skips its own memsets);
- *     xmc_word_pool_fwd / _bwd (word-region attention of the repaired concept_gan.InNetG). */
+ *     xmc_word_pool_fwd / _bwd (word-region attention of the repaired concept_gan.InNetG);
+ *     XmcConvDesc.splitk_ws / splitk_ws_bytes, xmc_conv_splitk_ws_bytes (split-K for the layers on 4x4 / 8x8 maps). */
 #define XMC_ABI_VERSION 11
 
 /* XMC_BF16 names the 16-bit storage / MFMA-operand format THIS BUILD of the library was compiled for: bf16 in
@@ -137,6 +138,14 @@ typedef struct XmcConvDesc {
     const void* sc_img;
     const void* sc_frag;
     const float* sc_bias;
+    /* splitk_ws / splitk_ws_bytes (ABI 11; honoured by the generic implicit-GEMM kernel only): scratch for a split-K launch.  The
+     *             layers on 4x4 / 8x8 maps have K = 2304-8192 against M = 4096-16384 output pixels: 128-256 tiles, one workgroup per
+     *             CU walking all of K alone, every K step an exposed memory round trip (100-400 TF/s).  With this scratch the kernel
+     *             cuts K into S <= 8 ranges (S x the workgroups), each writes its f32 partial tile here ([S][class][M][CDw]) and a
+     *             finishing pass sums the S partials IN ORDER and runs the ordinary epilogue -- deterministic, no atomics.
+     *             xmc_conv_splitk_ws_bytes(d) says how much the descriptor wants (0: it would not split); NULL / too small = no split */
+    void* splitk_ws;
+    int64_t splitk_ws_bytes;
 } XmcConvDesc;
 
 int xmc_abi_version(void);
@@ -155,6 +164,9 @@ int xmc_set_fixed_order(int on);
  * carves them from an arena it clears once per iteration) and the library skips those memsets.  Returns the previous setting; process-wide,
  * off by default (ABI 11) */
 int xmc_set_prezeroed(int on);
+
+/* bytes of XmcConvDesc.splitk_ws this descriptor would use (0 = the launch would not be split); fill the descriptor first (ABI 11) */
+int64_t xmc_conv_splitk_ws_bytes(const XmcConvDesc* d);
 
 /* forward / dgrad implicit GEMM on MFMA (bf16: v_mfma_f32_16x16x32_bf16; f32: v_mfma_f32_16x16x4_f32) */
 int xmc_conv_igemm(const XmcConvDesc* d, void* stream);

@@ -60,7 +60,37 @@ struct IgemmLds {                                    // LDS plan shared by the k
     static constexpr bool DYNAMIC = SMEM_U * 16 + 4 * XMC_MAX_TAPS > 64 * 1024;      // beyond the static-LDS limit
 };
 
-template <int DT, int BM, int BN, int WM, int WN, int KSUB>
+// One output item of the epilogue -- 8 channels `ch..ch+7` of output row m (class cls) -- from its f32 sums: bias, activation,
+// residual index, shared tail.  Used by the kernel's own epilogue and by the split-K finishing pass.
+template <int ODT>
+__device__ __forceinline__ void igemm_epi_item(const XmcConvDesc& d, int cls, int m, int ch, float (&v)[8], float alpha, float* dacc) {
+    const int MHW = d.MH * d.MW;
+    const int n = m / MHW, rem = m - n * MHW;
+    const int a = rem / d.MW, b = rem - a * d.MW;
+    const int dph = d.dph[cls], dpw = d.dpw[cls];
+    const size_t pix = ((size_t)n * d.DH + a * d.DA + dph) * d.DW + b * d.DA + dpw;
+    const size_t idx8 = (pix * d.CD + ch) >> 3;
+    if (d.bias) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] += d.bias[ch + k];
+    }
+    if (d.act == XMC_ACT_LRELU) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = lrelu_f(v[k]);
+    } else if (d.act == XMC_ACT_RELU) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+    } else if (d.act == XMC_ACT_TANH) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = tanhf(v[k]);
+    }
+    const size_t ridx8 = res_index8(d, idx8, n, a * d.DA + dph, b * d.DA + dpw, a, b, ch >> 3);
+    epilogue_tail<ODT>(d, idx8, ridx8, v, alpha, dacc);
+}
+
+// SK: split-K (XmcConvDesc.splitk_ws): blockIdx.y = K range `ks` of gridDim.y; the tile's f32 partial sums go to
+// ws[ks][cls][m][CDw] and igemm_splitk_finish_kernel runs the epilogue.
+template <int DT, int BM, int BN, int WM, int WN, int KSUB, bool SK = false>
 __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const XmcConvDesc d) {
     constexpr int NT = 64 * WM * WN;                 // 4 waves, or 8 for the 256x256 tile
     static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves");
@@ -122,7 +152,11 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const XmcConvDesc d
     const u32x4* __restrict__ src16 = reinterpret_cast<const u32x4*>(d.src);
     const u32x4* __restrict__ w16 = reinterpret_cast<const u32x4*>(d.wpk);
 
-    int tap = c / upt, cu = c % upt;                 // unit index u = sub*4 + c  ->  (tap, cu)
+    // the K steps of this workgroup: all of them, or range blockIdx.y of gridDim.y
+    const int s_begin = SK ? (int)((int64_t)nstep * blockIdx.y / gridDim.y) : 0;
+    const int s_end = SK ? (int)((int64_t)nstep * (blockIdx.y + 1) / gridDim.y) : nstep;
+    const int u0 = s_begin * KSUB * 4 + c;           // unit index u = sub*4 + c  ->  (tap, cu)
+    int tap = u0 / upt, cu = u0 % upt;
     u32x4 ra[KSUB][AL], rb[KSUB][BL];
 
     auto load_step = [&](int step) {
@@ -178,12 +212,12 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const XmcConvDesc d
 
     const int fr = lane & 15, fc = lane >> 4;        // fragment row / 16-byte chunk
     constexpr bool pin_reads = XMC_IGEMM_PIN;
-    load_step(0);
+    load_step(s_begin);
     store_step(0);
     __syncthreads();
-    for (int step = 0; step < nstep; ++step) {
-        const int buf = step & 1;
-        const bool more = step + 1 < nstep;
+    for (int step = s_begin; step < s_end; ++step) {
+        const int buf = (step - s_begin) & 1;
+        const bool more = step + 1 < s_end;
         if (more) load_step(step + 1);
         const u32x4* la = smem + buf * (KSUB * (BM + BN) * 4);
         const u32x4* lb = la + KSUB * BM * 4;
@@ -220,7 +254,6 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const XmcConvDesc d
     const float alpha = d.alpha_dev ? *d.alpha_dev : 1.f;
     float dacc = 0.f;
     constexpr int CPR = BN / 8;                      // 8-channel chunks per tile row
-    const int dph = d.dph[cls], dpw = d.dpw[cls];
     for (int half = 0; half < BM / EP_ROWS; ++half) {
         if (half) __syncthreads();
 #pragma unroll
@@ -238,39 +271,105 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const XmcConvDesc d
         for (int id = tid; id < EP_ROWS * CPR; id += NT) {
             int row = id / CPR, cc = id - row * CPR;
             int m = m0 + half * EP_ROWS + row, ch = n0 + cc * 8;
-            if (m >= M || ch >= d.CD) continue;
-            int n = m / MHW, rem = m - n * MHW;
-            int a = rem / d.MW, b = rem - a * d.MW;
-            size_t pix = ((size_t)n * d.DH + a * d.DA + dph) * d.DW + b * d.DA + dpw;
-            size_t idx8 = (pix * d.CD + ch) >> 3;
-            float v[8];
+            if (m >= M) continue;
             const f32x4 e0 = *reinterpret_cast<const f32x4*>(&ep[row * EP_LD + cc * 8]);
             const f32x4 e1 = *reinterpret_cast<const f32x4*>(&ep[row * EP_LD + cc * 8 + 4]);
+            if (SK) {                                // the raw partial sums of this K range
+                f32x4* w = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(d.splitk_ws) +
+                                                    (((size_t)blockIdx.y * gridDim.z + cls) * M + m) * d.CDw + ch);
+                w[0] = e0; w[1] = e1;
+                continue;
+            }
+            if (ch >= d.CD) continue;
+            float v[8];
 #pragma unroll
             for (int k = 0; k < 4; ++k) { v[k] = e0[k]; v[4 + k] = e1[k]; }
-            if (d.bias) {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] += d.bias[ch + k];
-            }
-            if (d.act == XMC_ACT_LRELU) {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] = lrelu_f(v[k]);
-            } else if (d.act == XMC_ACT_RELU) {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
-            } else if (d.act == XMC_ACT_TANH) {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] = tanhf(v[k]);
-            }
-            const size_t ridx8 = res_index8(d, idx8, n, a * d.DA + dph, b * d.DA + dpw, a, b, ch >> 3);
-            if (d.out_dtype == XMC_BF16) epilogue_tail<XMC_BF16>(d, idx8, ridx8, v, alpha, &dacc);
-            else epilogue_tail<XMC_F32>(d, idx8, ridx8, v, alpha, &dacc);
+            if (d.out_dtype == XMC_BF16) igemm_epi_item<XMC_BF16>(d, cls, m, ch, v, alpha, &dacc);
+            else igemm_epi_item<XMC_F32>(d, cls, m, ch, v, alpha, &dacc);
         }
     }
+    if (SK) return;
     if (d.dot) {                                     // one atomic per wave: the d(gamma) dot product of XmcConvDesc.dot
         dacc = wave_sum(dacc);
         if (lane == 0) atomicAdd(d.dot, dacc);
     }
+}
+
+// split-K finishing pass: out item (m, 8 channels) = epilogue(sum over the S partial tiles, in order)
+constexpr int SK_FIN_ITEMS = 4;
+__global__ __launch_bounds__(256) void igemm_splitk_finish_kernel(const XmcConvDesc d, int S) {
+    const int cls = blockIdx.z;
+    const int M = d.N * d.MH * d.MW, C8 = d.CD / 8;
+    const float alpha = d.alpha_dev ? *d.alpha_dev : 1.f;
+    float dacc = 0.f;
+    // SK_FIN_ITEMS items per thread: the d(gamma) dot of XmcConvDesc.dot costs one atomic per WORKGROUP on a single address, and with
+    // one item per thread (8192 waves at batch 512) those serialised read-modify-writes took longer than the GEMM itself
+    for (int it = 0; it < SK_FIN_ITEMS; ++it) {
+        const int64_t id = ((int64_t)blockIdx.x * SK_FIN_ITEMS + it) * 256 + threadIdx.x;
+        if (id >= (int64_t)M * C8) break;
+        const int m = (int)(id / C8), ch = (int)(id - (int64_t)m * C8) * 8;
+        const float* w = reinterpret_cast<const float*>(d.splitk_ws) + ((size_t)cls * M + m) * d.CDw + ch;
+        const size_t stride = (size_t)gridDim.z * M * d.CDw;
+        float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int s = 0; s < S; ++s) {
+            const f32x4 e0 = *reinterpret_cast<const f32x4*>(w + s * stride), e1 = *reinterpret_cast<const f32x4*>(w + s * stride + 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { v[k] += e0[k]; v[4 + k] += e1[k]; }
+        }
+        if (d.out_dtype == XMC_BF16) igemm_epi_item<XMC_BF16>(d, cls, m, ch, v, alpha, &dacc);
+        else igemm_epi_item<XMC_F32>(d, cls, m, ch, v, alpha, &dacc);
+    }
+    if (d.dot) {
+        __shared__ float sdot[4];
+        dacc = wave_sum(dacc);
+        if ((threadIdx.x & 63) == 0) sdot[threadIdx.x >> 6] = dacc;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(d.dot, sdot[0] + sdot[1] + sdot[2] + sdot[3]);
+    }
+}
+
+// K ranges of a split launch: 0 = this descriptor is not split.  16-bit operands, few output pixels and a deep K (the layers on 4x4 / 8x8
+// maps).  Tile: 256x256 (8 waves; half the L2 -> LDS bytes per MAC of the 128x128 tile) when the weights allow it, with S bringing the
+// launch to one workgroup per CU; else 128x128 with ~4 workgroups per CU.  Every range keeps >= 4 K steps.
+struct SkPlan { int S, big; };
+static SkPlan splitk_plan(const XmcConvDesc& d) {
+    static const bool off = xmc_debug_off("no_igemm_splitk"), no_big = xmc_debug_off("no_igemm_splitk256");
+    SkPlan p = {0, 0};
+    if (off || d.dtype != XMC_BF16 || d.CDw % 128 != 0) return p;
+    const int64_t M = (int64_t)d.N * d.MH * d.MW, K = (int64_t)d.ntaps * d.CS;
+    // measured per layer of the benched step (tests/diag: XMC_PROF_SHAPES): K >= 4096 in one class gains 20-40 % (8x8 -> 4x4 k4s2 and
+    // the 3x3 on 4x4 maps at 512 channels, the fused-upsample data gradients at 256); K = 2304 (256 channels, 36 steps) and the
+    // four-class stride-2 data gradients do not
+    if (M > 16384 || K < 4096 || d.nclass != 1) return p;
+    p.big = (d.CDw % 256 == 0 && !no_big) ? 1 : 0;
+    const int B = p.big ? 256 : 128;
+    const int64_t tiles = (M + B - 1) / B * (d.CDw / B) * d.nclass;
+    const int nstep = (int)((K * 2 / 16 + 3) / 4 + 1) / 2;              // KSUB = 2 in both forms
+    int S = (int)((p.big ? 256 : 1024) / tiles);
+    if (S > 8) S = 8;
+    if (S > nstep / 4) S = nstep / 4;
+    p.S = S >= 2 ? S : 0;
+    return p;
+}
+static int64_t splitk_bytes(const XmcConvDesc& d, int S) { return (int64_t)S * d.nclass * d.N * d.MH * d.MW * d.CDw * 4; }
+
+template <int BM, int BN, int WM, int WN>
+int launch_splitk(const XmcConvDesc& d, int S, hipStream_t st) {
+    const int64_t M = (int64_t)d.N * d.MH * d.MW;
+    dim3 grid((unsigned)(((M + BM - 1) / BM) * (d.CDw / BN)), (unsigned)S, (unsigned)d.nclass);
+    using Lds = IgemmLds<BM, BN, 2>;
+    size_t dyn = 0;
+    if (Lds::DYNAMIC) {
+        dyn = (size_t)Lds::SMEM_U * 16;
+        XMC_ALLOW_BIG_LDS((igemm_kernel<XMC_BF16, BM, BN, WM, WN, 2, true>));
+    }
+    hipLaunchKernelGGL((igemm_kernel<XMC_BF16, BM, BN, WM, WN, 2, true>), grid, dim3(64 * WM * WN), dyn, st, d);
+    xmc_note_kernel("igemm_kernel<%d, %d, %d, %d, %d, %d, splitk>", XMC_BF16, BM, BN, WM, WN, 2);
+    XMC_LAUNCH_CHECK();
+    const int64_t items = M * (d.CD / 8);
+    hipLaunchKernelGGL(igemm_splitk_finish_kernel, dim3((unsigned)((items + 256 * SK_FIN_ITEMS - 1) / (256 * SK_FIN_ITEMS)), 1, (unsigned)d.nclass), dim3(256), 0, st, d, S);
+    XMC_LAUNCH_CHECK();
+    return 0;
 }
 
 template <int DT, int BM, int BN, int WM, int WN, int KSUB>
@@ -296,6 +395,11 @@ int dispatch(const XmcConvDesc& d, hipStream_t st) {
     // chip and each walks all of K alone; 32-wide tiles give 4x the workgroups and a 4x shorter critical path
     static const bool no_small = xmc_debug_off("no_small_m");
     if (!no_small && (int64_t)d.N * d.MH * d.MW <= 1024) return launch<DT, 128, 32, 4, 1, 2>(d, st);
+    if (DT == XMC_BF16 && d.splitk_ws) {             // few output pixels, deep K: K cut into ranges (XmcConvDesc.splitk_ws)
+        const SkPlan sp = splitk_plan(d);
+        if (sp.S && d.splitk_ws_bytes >= splitk_bytes(d, sp.S))
+            return sp.big ? launch_splitk<256, 256, 2, 4>(d, sp.S, st) : launch_splitk<128, 128, 2, 2>(d, sp.S, st);
+    }
     if (d.CDw % 128 == 0) {
         const int64_t M = (int64_t)d.N * d.MH * d.MW;
         if (variant == 1) return launch<DT, 128, 128, 2, 2, 2>(d, st);
@@ -346,6 +450,12 @@ int xmc_conv_ptile_pool_try(const XmcConvDesc* d, void* stream);                
 int xmc_conv_ptile_slab128_try(const XmcConvDesc* d, void* stream);                   // conv_tile.hip
 int xmc_conv_group_try(const XmcConvDesc* d, void* stream);                           // conv_group.hip
 int xmc_conv_thin_out_try(const XmcConvDesc* d, void* stream);                        // conv_thin.hip
+
+extern "C" int64_t xmc_conv_splitk_ws_bytes(const XmcConvDesc* d) {
+    if (!d) return 0;
+    const SkPlan sp = splitk_plan(*d);
+    return sp.S ? splitk_bytes(*d, sp.S) : 0;
+}
 
 extern "C" int xmc_conv_igemm(const XmcConvDesc* d, void* stream) {
     if (!d || !d->src || !d->wpk || !d->dst) return XMC_EINVAL;

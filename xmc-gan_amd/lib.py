@@ -31,7 +31,8 @@ class ConvDesc(C.Structure):
                 ("wi", (C.c_int8 * MAX_TAPS) * MAX_CLASSES),
                 ("dph", C.c_int8 * MAX_CLASSES), ("dpw", C.c_int8 * MAX_CLASSES),
                 ("mask", vp), ("res_scale", f32), ("res_mode", i32), ("dst2", vp), ("dst_pool", vp), ("round_act", i32), ("groups", i32),
-                ("post_act", i32), ("pool_scale", f32), ("sign_bits", vp), ("dot", vp), ("mask_bits", vp), ("sc_img", vp), ("sc_frag", vp), ("sc_bias", vp)]
+                ("post_act", i32), ("pool_scale", f32), ("sign_bits", vp), ("dot", vp), ("mask_bits", vp), ("sc_img", vp), ("sc_frag", vp), ("sc_bias", vp),
+                ("splitk_ws", vp), ("splitk_ws_bytes", C.c_int64)]
 
 
 # XmcGemmProblem as a numpy record (filled vectorised on the host, handed to xmc_gemm_group by pointer)
@@ -57,6 +58,7 @@ _SIGS = {
     "xmc_last_kernel": [],
     "xmc_set_fixed_order": [i32],
     "xmc_set_prezeroed": [i32],
+    "xmc_conv_splitk_ws_bytes": [vp],
     "xmc_conv_igemm": [C.POINTER(ConvDesc), vp],
     "xmc_conv_wgrad": [C.POINTER(ConvDesc), vp, vp],
     "xmc_conv_wgrad_bias": [C.POINTER(ConvDesc), vp, vp, vp],
@@ -142,7 +144,7 @@ _SIGS = {
     "xmc_dstem_border_wgrad": [vp, vp, vp, vp, i32, i32, i32, vp],
     "xmc_dstem_dgrad": [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
 }
-_RESTYPE = {"xmc_contrastive_ws_bytes": i64, "xmc_attn_pool_ws_floats": i64, "xmc_last_kernel": C.c_char_p}
+_RESTYPE = {"xmc_contrastive_ws_bytes": i64, "xmc_conv_splitk_ws_bytes": i64, "xmc_attn_pool_ws_floats": i64, "xmc_last_kernel": C.c_char_p}
 EXPORTS = tuple(_SIGS)
 
 _libs = {}               # variant -> loaded library

@@ -255,6 +255,17 @@ class ConvGeom:
         return self._perm_dev
 
 
+def _igemm(d, what):
+    """xmc_conv_igemm, handing over the split-K scratch the descriptor asks for (the layers on 4x4 / 8x8 maps: XmcConvDesc.splitk_ws).
+    The scratch is a plain caching-allocator block: stream order keeps it alive until the two launches that use it have run."""
+    lib = L.load()
+    nb = lib.xmc_conv_splitk_ws_bytes(C.byref(d))
+    if nb > 0:
+        ws = torch.empty(nb, dtype=torch.uint8, device=torch.cuda.current_device())
+        d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), nb
+    L.check(lib.xmc_conv_igemm(C.byref(d), _st()), what)
+
+
 def _fill_taps(d, cls, taps):
     for t, (dh, dw, wi) in enumerate(taps):
         d.dh[cls][t] = dh
@@ -429,7 +440,7 @@ def _upconv_fwd_raw(x, w, bias, geom, act, out_dtype):
             d.dph[cls], d.dpw[cls] = i, j
     with prof.launch("igemm_kernel (conv fwd+dgrad, MFMA implicit GEMM)", 2.0 * N * 4 * H * W * geom.cout * geom.cin * 9,
                      f"upconv-fwd {x.dtype} N{N} {2 * H}x{2 * W} {geom.cin}->{geom.cout} k3s1", _nbytes(x, wpk, y)):
-        L.check(L.load().xmc_conv_igemm(C.byref(d), _st()), "xmc_conv_igemm(upconv fwd)")
+        _igemm(d, "xmc_conv_igemm(upconv fwd)")
     return y
 
 
@@ -460,7 +471,7 @@ def _upconv_dgrad_raw(dy, w, geom, in_dtype):
     _fill_taps(d, 0, taps)
     with prof.launch("igemm_kernel (conv fwd+dgrad, MFMA implicit GEMM)", 2.0 * N * OH * OW * geom.cout * geom.cin * 9,
                      f"upconv-dgrad {dy.dtype} N{N} {OH}x{OW} {geom.cin}->{geom.cout} k3s1", _nbytes(dy, wpk, dx)):
-        L.check(L.load().xmc_conv_igemm(C.byref(d), _st()), "xmc_conv_igemm(upconv dgrad)")
+        _igemm(d, "xmc_conv_igemm(upconv dgrad)")
     return dx
 
 
@@ -534,7 +545,7 @@ def _conv_fwd_raw(x, w, bias, geom, act, out_dtype, res=None, alpha=None, up=Fal
         return y if len(outs) == 1 else tuple(outs)
     with prof.launch("igemm_kernel (conv fwd+dgrad, MFMA implicit GEMM)", 2.0 * N * OH * OW * geom.cout * geom.cin * geom.k * geom.k,
                      f"fwd {x.dtype} N{N} {H}x{W} {geom.cin}->{geom.cout} k{geom.k}s{geom.s}", _nbytes(x, wpk, res, mask, *outs)):
-        L.check(L.load().xmc_conv_igemm(C.byref(d), _st()), "xmc_conv_igemm(fwd)")
+        _igemm(d, "xmc_conv_igemm(fwd)")
     return y if len(outs) == 1 else tuple(outs)
 
 
@@ -621,7 +632,7 @@ def _conv_dgrad_raw(dy, w, geom, in_hw, in_dtype, mask=None, res=None, res_rows=
                          f"dgrad+srcmask {dy.dtype} N{N} {H}x{W} {geom.cin}->{geom.cout} k1s1", _nbytes(dy, wpk, dx, dym)):
             rc = L.load().xmc_conv_pw1x1_masked_src(C.byref(d), _p(src_bits), _p(dym), 0.2, _st())
             if rc == 1:
-                L.check(L.load().xmc_conv_igemm(C.byref(d), _st()), "xmc_conv_igemm(dgrad)")
+                _igemm(d, "xmc_conv_igemm(dgrad)")
                 L.call("xmc_signmask_apply", _p(dy), _p(src_bits), _p(dym), dy.numel(), 0.2, _code(dy.dtype), _st())
             else:
                 L.check(rc, "xmc_conv_pw1x1_masked_src")
@@ -638,7 +649,7 @@ def _conv_dgrad_raw(dy, w, geom, in_hw, in_dtype, mask=None, res=None, res_rows=
         d.mask_bits, d.src = None, staged.materialised().data_ptr()
     with prof.launch("igemm_kernel (conv fwd+dgrad, MFMA implicit GEMM)", 2.0 * N * OH * OW * geom.cout * geom.cin * geom.k * geom.k,
                      f"dgrad {dy.dtype} N{N} {H}x{W} {geom.cin}->{geom.cout} k{geom.k}s{geom.s}", _nbytes(dy, wpk, dx, mask, res, dxp)):
-        L.check(L.load().xmc_conv_igemm(C.byref(d), _st()), "xmc_conv_igemm(dgrad)")
+        _igemm(d, "xmc_conv_igemm(dgrad)")
     return (dx, dxp) if want_sumpool else dx
 
 
