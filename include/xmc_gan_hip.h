@@ -141,7 +141,7 @@ typedef struct XmcConvDesc {
     /* splitk_ws / splitk_ws_bytes (ABI 11; honoured by the generic implicit-GEMM kernel only): scratch for a split-K launch.  The
      *             layers on 4x4 / 8x8 maps have K = 2304-8192 against M = 4096-16384 output pixels: 128-256 tiles, one workgroup per
      *             CU walking all of K alone, every K step an exposed memory round trip (100-400 TF/s).  With this scratch the kernel
-     *             cuts K into S <= 8 ranges (S x the workgroups), each writes its f32 partial tile here ([S][class][M][CDw]) and a
+     *             cuts K into S <= 16 ranges (S x the workgroups), each writes its f32 partial tile here ([S][class][M][CDw]) and a
      *             finishing pass sums the S partials IN ORDER and runs the ordinary epilogue -- deterministic, no atomics.
      *             xmc_conv_splitk_ws_bytes(d) says how much the descriptor wants (0: it would not split); NULL / too small = no split */
     void* splitk_ws;

@@ -335,18 +335,19 @@ struct SkPlan { int S, big; };
 static SkPlan splitk_plan(const XmcConvDesc& d) {
     static const bool off = xmc_debug_off("no_igemm_splitk"), no_big = xmc_debug_off("no_igemm_splitk256");
     SkPlan p = {0, 0};
-    if (off || d.dtype != XMC_BF16 || d.CDw % 128 != 0) return p;
+    if (off || d.dtype != XMC_BF16 || d.CDw % 64 != 0) return p;
     const int64_t M = (int64_t)d.N * d.MH * d.MW, K = (int64_t)d.ntaps * d.CS;
     // measured per layer of the benched step (tests/diag: XMC_PROF_SHAPES): K >= 4096 in one class gains 20-40 % (8x8 -> 4x4 k4s2 and
     // the 3x3 on 4x4 maps at 512 channels, the fused-upsample data gradients at 256); K = 2304 (256 channels, 36 steps) and the
     // four-class stride-2 data gradients do not
     if (M > 16384 || K < 4096 || d.nclass != 1) return p;
-    p.big = (d.CDw % 256 == 0 && !no_big) ? 1 : 0;
-    const int B = p.big ? 256 : 128;
-    const int64_t tiles = (M + B - 1) / B * (d.CDw / B) * d.nclass;
-    const int nstep = (int)((K * 2 / 16 + 3) / 4 + 1) / 2;              // KSUB = 2 in both forms
-    int S = (int)((p.big ? 256 : 1024) / tiles);
-    if (S > 8) S = 8;
+    // big: 1 = 256x256 tiles (8 waves), 0 = 128x128, 2 = 128x64 (the logit head's joint convolution, 768 -> 64: 32-96 tiles of 54 steps)
+    p.big = (d.CDw % 256 == 0 && !no_big) ? 1 : (d.CDw % 128 == 0 ? 0 : 2);
+    const int BMp = p.big == 1 ? 256 : 128, BNp = p.big == 1 ? 256 : (p.big == 0 ? 128 : 64);
+    const int64_t tiles = (M + BMp - 1) / BMp * (d.CDw / BNp) * d.nclass;
+    const int nstep = (int)((K * 2 / 16 + 3) / 4 + 1) / 2;              // KSUB = 2 in every form
+    int S = (int)((p.big == 1 ? 256 : 1024) / tiles);
+    if (S > (p.big == 2 ? 16 : 8)) S = p.big == 2 ? 16 : 8;
     if (S > nstep / 4) S = nstep / 4;
     p.S = S >= 2 ? S : 0;
     return p;
@@ -398,7 +399,8 @@ int dispatch(const XmcConvDesc& d, hipStream_t st) {
     if (DT == XMC_BF16 && d.splitk_ws) {             // few output pixels, deep K: K cut into ranges (XmcConvDesc.splitk_ws)
         const SkPlan sp = splitk_plan(d);
         if (sp.S && d.splitk_ws_bytes >= splitk_bytes(d, sp.S))
-            return sp.big ? launch_splitk<256, 256, 2, 4>(d, sp.S, st) : launch_splitk<128, 128, 2, 2>(d, sp.S, st);
+            return sp.big == 1 ? launch_splitk<256, 256, 2, 4>(d, sp.S, st) : sp.big == 0 ? launch_splitk<128, 128, 2, 2>(d, sp.S, st)
+                                                                                             : launch_splitk<128, 64, 4, 1>(d, sp.S, st);
     }
     if (d.CDw % 128 == 0) {
         const int64_t M = (int64_t)d.N * d.MH * d.MW;
