@@ -24,7 +24,8 @@ constexpr int WR_BCO = 128, WR_KP = 64, WR_NT = 512;      // BCI (ci block) is a
 constexpr int WR_LD = 128 + 16;                   // dy tile row stride in elements: 72 dwords, rows 0..7 land 8 banks apart
 // x tile row stride: consecutive K pixels are SA rows apart, and the 32 lanes one tr16 read serves together (pixels
 // 0..7) must land on 8 distinct bank octets: SA == 1: 72 dwords; SA == 2: 68 dwords (2 rows = 136 = 8 mod 64)
-template <int SA> struct XLd { static constexpr int v = SA == 1 ? 128 + 16 : 128 + 8; };
+// (a 64-channel ci block keeps rows of 64 + 16 / 64 + 8 elements: 40 / 36 dwords, the same octet spread)
+template <int SA, int BCI> struct XLd { static constexpr int v = SA == 1 ? BCI + 16 : BCI + 8; };
 
 struct RowCfg {
     int seg, nseg, xseg, xrows;                   // segment length, segments per K step, x rows per segment / per step
@@ -32,13 +33,18 @@ struct RowCfg {
     int lds_bytes;
 };
 
+// The 64-channel ci block (resD block 1's 4x4 stride-2 layer, Cin = 64) has half the MFMAs per staged dy tile and runs at 660 TF/s
+// against the 128-wide form's 980, its K steps waiting on the L2 -> LDS path (HBM traffic is ideal: the four kernel rows' re-reads hit
+// L2).  Round 4 tried two workgroups per CU for it (74 KB of LDS each with the narrow rows): the 128-register cap that needs spills 25
+// registers in the K loop, 0.83 -> 1.01 ms.  Measured and not kept; the narrow rows and the packed staging stayed.
 template <int KW, int SA, int WR_BCI>
 __global__ __launch_bounds__(WR_NT) void wgrad_row_kernel(const XmcConvDesc d, const RowCfg t, float* __restrict__ dwp,
                                                           float* __restrict__ dbias, int pix_per_block) {
-    constexpr int NT = WR_NT, KP = WR_KP, LD = WR_LD, LDX = XLd<SA>::v;
+    constexpr int NT = WR_NT, KP = WR_KP, LD = WR_LD, LDX = XLd<SA, WR_BCI>::v;
     constexpr int TM = 4, TN = WR_BCI / 64;       // 16x16 tiles per wave: 64 co x 32 ci (x 16 ci for the 64-wide ci block)
     constexpr int XCH = WR_BCI / 8;               // 16-byte chunks per x pixel row
-    constexpr int XIT = ((SA * 63 + KW) * 16 + NT - 1) / NT + 1;      // x chunks per thread per step (upper bound over seg)
+    constexpr int XRP = NT / XCH;                 // x rows staged per pass: XCH threads per row (every thread loads, also for 64 channels)
+    constexpr int XIT = ((SA * 63 + KW) + XRP - 1) / XRP + 1;         // x chunks per thread per step (upper bound over seg)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int s_seg[2][16];                  // per (step parity, segment): source pixel index of (n, row, col 0) or -1
 
@@ -72,10 +78,11 @@ __global__ __launch_bounds__(WR_NT) void wgrad_row_kernel(const XmcConvDesc d, c
     }
     // staging coordinates
     const int dch = tid & 15, drow0 = tid >> 4;   // dy: 16 chunks per pixel row, rows drow0 and drow0 + 32
-    int xs[XIT], xj[XIT];                         // x: LDS row r = tid/16 + 32*it -> segment, position in segment
+    const int xch = tid % XCH, xr0 = tid / XCH;
+    int xs[XIT], xj[XIT];                         // x: LDS row r = tid/XCH + XRP*it -> segment, position in segment
 #pragma unroll
     for (int it = 0; it < XIT; ++it) {
-        const int r = (tid >> 4) + 32 * it;
+        const int r = xr0 + XRP * it;
         xs[it] = r < t.xrows ? r / t.xseg : -1;
         xj[it] = r - (r / t.xseg) * t.xseg;
     }
@@ -95,11 +102,11 @@ __global__ __launch_bounds__(WR_NT) void wgrad_row_kernel(const XmcConvDesc d, c
 #pragma unroll
         for (int it = 0; it < XIT; ++it) {
             u32x4 v = {0, 0, 0, 0};
-            if (xs[it] >= 0 && dch < XCH) {
+            if (xs[it] >= 0) {
                 const int base = s_seg[par][xs[it]];
                 const int col = (t.nseg == 1 ? b0 : 0) * SA + xj[it] - t.pad;
                 if (base >= 0 && (unsigned)col < (unsigned)(d.SW << d.src_shift))
-                    v = x16[(size_t)(base + (col >> d.src_shift)) * cs_ch + (ci0 >> 3) + dch];
+                    v = x16[(size_t)(base + (col >> d.src_shift)) * cs_ch + (ci0 >> 3) + xch];
             }
             ri[it] = v;
         }
@@ -118,7 +125,7 @@ __global__ __launch_bounds__(WR_NT) void wgrad_row_kernel(const XmcConvDesc d, c
         }
 #pragma unroll
         for (int it = 0; it < XIT; ++it)
-            if (xs[it] >= 0 && dch < XCH) *reinterpret_cast<u32x4*>(sx + (((tid >> 4) + 32 * it) * LDX + dch * 8) * 2) = ri[it];
+            if (xs[it] >= 0) *reinterpret_cast<u32x4*>(sx + ((xr0 + XRP * it) * LDX + xch * 8) * 2) = ri[it];
     };
 
     f32x4 acc[KW][TM][TN];
@@ -257,7 +264,8 @@ int xmc_conv_wgrad_row_try(const XmcConvDesc* d, float* dwp, float* dbias, void*
     t.xseg = sa * (t.seg - 1) + kw;
     t.xrows = t.nseg * t.xseg;
     t.pad = pad;
-    t.lds_bytes = 2 * (WR_KP * WR_LD + t.xrows * (sa == 1 ? XLd<1>::v : XLd<2>::v)) * 2;
+    const int bci = d->CS == 64 ? 64 : 128;
+    t.lds_bytes = 2 * (WR_KP * WR_LD + t.xrows * (sa == 1 ? bci + 16 : bci + 8)) * 2;
     if (t.lds_bytes > XMC_MAX_DYN_LDS) return 1;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (d->CS == 64) return kw == 3 ? launch_row<3, 1, 64>(*d, t, dwp, dbias, st) : launch_row<4, 2, 64>(*d, t, dwp, dbias, st);
