@@ -342,10 +342,14 @@ static SkPlan splitk_plan(const XmcConvDesc& d) {
     // four-class stride-2 data gradients do not
     if (M > 16384 || K < 4096 || d.nclass != 1) return p;
     // big: 1 = 256x256 tiles (8 waves), 0 = 128x128, 2 = 128x64 (the logit head's joint convolution, 768 -> 64: 32-96 tiles of 54 steps)
+    const int nstep = (int)((K * 2 / 16 + 3) / 4 + 1) / 2;              // KSUB = 2 in every form
     p.big = (d.CDw % 256 == 0 && !no_big) ? 1 : (d.CDw % 128 == 0 ? 0 : 2);
+    if (p.big == 1) {                             // ... unless even 8 ranges of 256x256 tiles leave a quarter of the CUs idle (batch 64)
+        const int64_t t256 = (M + 255) / 256 * (d.CDw / 256);
+        if (t256 * (nstep / 4 < 8 ? nstep / 4 : 8) < 192) p.big = 0;
+    }
     const int BMp = p.big == 1 ? 256 : 128, BNp = p.big == 1 ? 256 : (p.big == 0 ? 128 : 64);
     const int64_t tiles = (M + BMp - 1) / BMp * (d.CDw / BNp) * d.nclass;
-    const int nstep = (int)((K * 2 / 16 + 3) / 4 + 1) / 2;              // KSUB = 2 in every form
     int S = (int)((p.big == 1 ? 256 : 1024) / tiles);
     if (S > (p.big == 2 ? 16 : 8)) S = p.big == 2 ? 16 : 8;
     if (S > nstep / 4) S = nstep / 4;
@@ -395,13 +399,13 @@ int dispatch(const XmcConvDesc& d, hipStream_t st) {
     // batch-sized GEMMs (the conditioning MLPs: M = batch, K = N = 256): a 128-wide N tile leaves 4 workgroups on the
     // chip and each walks all of K alone; 32-wide tiles give 4x the workgroups and a 4x shorter critical path
     static const bool no_small = xmc_debug_off("no_small_m");
-    if (!no_small && (int64_t)d.N * d.MH * d.MW <= 1024) return launch<DT, 128, 32, 4, 1, 2>(d, st);
     if (DT == XMC_BF16 && d.splitk_ws) {             // few output pixels, deep K: K cut into ranges (XmcConvDesc.splitk_ws)
         const SkPlan sp = splitk_plan(d);
         if (sp.S && d.splitk_ws_bytes >= splitk_bytes(d, sp.S))
             return sp.big == 1 ? launch_splitk<256, 256, 2, 4>(d, sp.S, st) : sp.big == 0 ? launch_splitk<128, 128, 2, 2>(d, sp.S, st)
                                                                                              : launch_splitk<128, 64, 4, 1>(d, sp.S, st);
     }
+    if (!no_small && (int64_t)d.N * d.MH * d.MW <= 1024) return launch<DT, 128, 32, 4, 1, 2>(d, st);
     if (d.CDw % 128 == 0) {
         const int64_t M = (int64_t)d.N * d.MH * d.MW;
         if (variant == 1) return launch<DT, 128, 128, 2, 2, 2>(d, st);
