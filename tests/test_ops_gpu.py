@@ -843,7 +843,7 @@ def test_region_attention_pooling(N, H, W, mode):
     assert rel(kp.grad, kd.grad) < t and rel(xp.grad, xd.grad) < t and rel(qp.grad, qd.grad) < 1e-4 + t
 
 
-@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("mode", MODES + ["f16"])
 @pytest.mark.parametrize("N,H,W,T", [(3, 16, 16, 18), (2, 10, 7, 5), (16, 32, 32, 18), (1, 128, 128, 24), (2, 8, 8, 32), (2, 4, 4, 16)])
 def test_word_region_attention_pooling(N, H, W, T, mode):
     """ops.word_region_pool (the repaired concept_gan.InNetG's CondConceptSampler.get_context_embs, concept_gan.py:532-555): per
