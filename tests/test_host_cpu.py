@@ -373,3 +373,20 @@ def test_image_grid_and_scalar_log(tmp_path):
     log.close()
     rows = [json.loads(line) for line in open(tmp_path / "scalars.jsonl")]
     assert rows == [{"tag": "Loss_D", "value": 1.5, "step": 3}, {"tag": "FID", "value": 42.0, "step": 3}]
+
+
+def test_integration_doc_stub_mirrors_the_descriptor():
+    """INTEGRATION.md shows a maintainer the ctypes mirror of XmcConvDesc: the struct in that code block must be the real one, field for
+    field (the library reads every field; a stub that stops short hands it stack garbage as option pointers)."""
+    import ctypes as C
+    import re
+    from xmc_gan_amd import lib as L
+    txt = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "INTEGRATION.md")).read()
+    m = re.search(r"(class XmcConvDesc\(C\.Structure\):.*?)\nassert C\.sizeof\(XmcConvDesc\) == (\d+)", txt, re.S)
+    assert m, "the XmcConvDesc stub is gone from INTEGRATION.md"
+    ns = {"C": C}
+    exec(m.group(1), ns)
+    doc = ns["XmcConvDesc"]
+    assert int(m.group(2)) == C.sizeof(doc) == C.sizeof(L.ConvDesc)
+    assert [(n, C.sizeof(t)) for n, t in doc._fields_] == [(n, C.sizeof(t)) for n, t in L.ConvDesc._fields_]
+    assert f"xmc_abi_version() == {L.ABI_VERSION}" in txt
