@@ -1436,3 +1436,29 @@ def test_stem_composition_launches_equal_the_torch_statement():
     have = ops._dstem_compose_bwd_raw(*leaves, *douts)
     for name, a, b in zip(("conv_img.weight", "conv_img.bias", "conv_r.0.weight", "conv_s.weight", "conv_s.bias"), have, want):
         assert rel_l2(a.reshape(b.shape), b) < 1e-5, (name, rel_l2(a.reshape(b.shape), b))
+
+
+def test_integration_doc_snippet_runs_as_written():
+    """The ctypes example of INTEGRATION.md (load the library, mirror XmcConvDesc, pack a weight, run a 3x3 convolution through the C ABI
+    with nothing of this package imported) executed verbatim against F.conv2d."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    txt = open(os.path.join(root, "INTEGRATION.md")).read()
+    m = re.search(r"```python\n(import ctypes as C, torch\n.*?)```", txt, re.S)
+    assert m, "the ctypes example is gone from INTEGRATION.md"
+    ns = {}
+    cwd = os.getcwd()
+    os.chdir(root)                                  # the example opens the library by its in-tree relative path
+    try:
+        exec(m.group(1), ns)
+    finally:
+        os.chdir(cwd)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 16, 16, 32, generator=g).to(DEV, torch.bfloat16)
+    w = (torch.randn(24, 32, 3, 3, generator=g) * 0.1).to(DEV)
+    b = torch.randn(24, generator=g).to(DEV)
+    y = ns["conv3x3"](x, w, b)
+    ref = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), w.to(torch.bfloat16).float(), b, padding=1).permute(0, 2, 3, 1)
+    assert y.shape == (2, 16, 16, 24) and y.dtype == torch.bfloat16
+    assert ((y.float() - ref).norm() / ref.norm()).item() < 5e-3
