@@ -390,3 +390,22 @@ def test_integration_doc_stub_mirrors_the_descriptor():
     assert int(m.group(2)) == C.sizeof(doc) == C.sizeof(L.ConvDesc)
     assert [(n, C.sizeof(t)) for n, t in doc._fields_] == [(n, C.sizeof(t)) for n, t in L.ConvDesc._fields_]
     assert f"xmc_abi_version() == {L.ABI_VERSION}" in txt
+
+
+def test_public_header_is_plain_c(tmp_path):
+    """include/xmc_gan_hip.h is the drop-in boundary: it must compile as C99 (and as C++) on its own, and a C translation unit must see the
+    struct size the Python binding mirrors."""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    from xmc_gan_amd import lib as L
+    hdr = os.path.join(ROOT, "include", "xmc_gan_hip.h")
+    subprocess.run(["gcc", "-x", "c", "-std=c99", "-fsyntax-only", "-Wall", "-Werror", hdr], check=True)
+    subprocess.run(["g++", "-x", "c++", "-fsyntax-only", hdr], check=True)
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include "xmc_gan_hip.h"\nint main(void) { printf("%zu %d\\n", sizeof(XmcConvDesc), XMC_ABI_VERSION); return 0; }\n')
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    size, abi = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    assert int(size) == ctypes.sizeof(L.ConvDesc) and int(abi) == L.ABI_VERSION
