@@ -369,7 +369,7 @@ int launch_splitk(const XmcConvDesc& d, int S, hipStream_t st) {
         XMC_ALLOW_BIG_LDS((igemm_kernel<XMC_BF16, BM, BN, WM, WN, 2, true>));
     }
     hipLaunchKernelGGL((igemm_kernel<XMC_BF16, BM, BN, WM, WN, 2, true>), grid, dim3(64 * WM * WN), dyn, st, d);
-    xmc_note_kernel("igemm_kernel<%d, %d, %d, %d, %d, %d, splitk>", XMC_BF16, BM, BN, WM, WN, 2);
+    xmc_note_kernel("igemm_kernel<%d, %d, %d, %d, %d, %d, true>", XMC_BF16, BM, BN, WM, WN, 2);     // (SK = true: the name rocprof prints)
     XMC_LAUNCH_CHECK();
     const int64_t items = M * (d.CD / 8);
     hipLaunchKernelGGL(igemm_splitk_finish_kernel, dim3((unsigned)((items + 256 * SK_FIN_ITEMS - 1) / (256 * SK_FIN_ITEMS)), 1, (unsigned)d.nclass), dim3(256), 0, st, d, S);
