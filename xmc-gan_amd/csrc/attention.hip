@@ -9,6 +9,7 @@
 namespace {
 constexpr int NT = 256;
 constexpr int UN = 4;      // vectors per operand in flight per thread (pointwise.hip: 4.7 -> 5.6 TB/s on flat passes)
+constexpr int GN_MAXG = 8 * NT;        // GroupNorm groups per image: at most one per channel, and C / 8 <= NT
 // a 16/32-byte vector kept as loaded until it is used
 template <int DT> struct Raw8;
 template <> struct Raw8<XMC_BF16> {
@@ -127,17 +128,25 @@ __global__ void gn_apply_kernel(const void* x, const float* sums, float* stats, 
     const int C = C8 * 8, G = C / cpg, n = blockIdx.y;
     const int stride = gridDim.x * blockDim.x;               // a multiple of C8 (host)
     const int i0 = blockIdx.x * blockDim.x + threadIdx.x, cc = i0 % C8;
-    float sc[8], sh[8];
+    // The (mean, rstd) of the image's G groups are formed ONCE per workgroup, one thread per group, and shared through LDS.  (Every thread
+    // used to sum its own groups' 2 cpg sums for each of its 8 channels: 128 dependent scalar loads in front of ~32 vector accesses of
+    // real work -- the pass ran at 2.6 TB/s inside the 128 px iteration where the plain affine pass reaches 4.2.)
+    __shared__ float s_mean[GN_MAXG], s_rstd[GN_MAXG];
     const float m = (float)HW * cpg;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const int c = cc * 8 + k, grp = c / cpg;
+    for (int grp = threadIdx.x; grp < G; grp += blockDim.x) {
         float s1 = 0.f, s2 = 0.f;
         for (int q = grp * cpg; q < (grp + 1) * cpg; ++q) { s1 += sums[((size_t)n * C + q) * 2]; s2 += sums[((size_t)n * C + q) * 2 + 1]; }
         const float mean = s1 / m, rstd = rsqrtf(fmaxf(s2 / m - mean * mean, 0.f) + eps);
-        sc[k] = rstd * w[c];
-        sh[k] = b[c] - mean * sc[k];
-        if (blockIdx.x == 0 && i0 < C8 && c == grp * cpg) { stats[((size_t)n * G + grp) * 2] = mean; stats[((size_t)n * G + grp) * 2 + 1] = rstd; }
+        s_mean[grp] = mean; s_rstd[grp] = rstd;
+        if (blockIdx.x == 0) { stats[((size_t)n * G + grp) * 2] = mean; stats[((size_t)n * G + grp) * 2 + 1] = rstd; }
+    }
+    __syncthreads();
+    float sc[8], sh[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int c = cc * 8 + k, grp = c / cpg;
+        sc[k] = s_rstd[grp] * w[c];
+        sh[k] = b[c] - s_mean[grp] * sc[k];
     }
     const int total = HW * C8;
     for (int ib = i0; ib < total; ib += stride * UN) {
@@ -181,6 +190,14 @@ __global__ void gn_bwd_apply_kernel(const void* x, const void* dy, const float* 
     const int stride = gridDim.x * blockDim.x;
     const int i0 = blockIdx.x * blockDim.x + threadIdx.x, cc = i0 % C8;
     const float inv_m = 1.f / ((float)HW * cpg);
+    // the groups' A_g, B_g once per workgroup through LDS (as in gn_apply_kernel: it was 3 cpg loads per channel and thread)
+    __shared__ float s_A[GN_MAXG], s_B[GN_MAXG];
+    for (int grp = threadIdx.x; grp < G; grp += blockDim.x) {
+        float a = 0.f, bq = 0.f;
+        for (int q = grp * cpg; q < (grp + 1) * cpg; ++q) { a += w[q] * sums2[((size_t)n * C + q) * 2]; bq += w[q] * sums2[((size_t)n * C + q) * 2 + 1]; }
+        s_A[grp] = a * inv_m; s_B[grp] = bq * inv_m;
+    }
+    __syncthreads();
     float mean[8], rstd[8], wv[8], bv[8], A[8], B[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -188,9 +205,7 @@ __global__ void gn_bwd_apply_kernel(const void* x, const void* dy, const float* 
         mean[k] = stats[((size_t)n * G + grp) * 2];
         rstd[k] = stats[((size_t)n * G + grp) * 2 + 1];
         wv[k] = w[c]; bv[k] = b[c];
-        float a = 0.f, bq = 0.f;
-        for (int q = grp * cpg; q < (grp + 1) * cpg; ++q) { a += w[q] * sums2[((size_t)n * C + q) * 2]; bq += w[q] * sums2[((size_t)n * C + q) * 2 + 1]; }
-        A[k] = a * inv_m; B[k] = bq * inv_m;
+        A[k] = s_A[grp]; B[k] = s_B[grp];
     }
     const int total = HW * C8;
     for (int ib = i0; ib < total; ib += stride * UN) {
