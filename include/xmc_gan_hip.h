@@ -39,7 +39,8 @@ extern "C" {
  * 10: xmc_set_fixed_order (repeatable reductions, test mode).
  * 11: xmc_set_prezeroed (the caller hands over zero-filled accumulators; the library skips its own memsets);
  *     xmc_word_pool_fwd / _bwd (word-region attention of the repaired concept_gan.InNetG);
- *     XmcConvDesc.splitk_ws / splitk_ws_bytes, xmc_conv_splitk_ws_bytes (split-K for the layers on 4x4 / 8x8 maps). */
+ *     XmcConvDesc.splitk_ws / splitk_ws_bytes, xmc_conv_splitk_ws_bytes (split-K for the layers on 4x4 / 8x8 maps);
+ *     xmc_concept_query_fwd_multi / _bwd_multi (every sampler stage's sentence query in one launch). */
 #define XMC_ABI_VERSION 11
 
 /* XMC_BF16 names the 16-bit storage / MFMA-operand format THIS BUILD of the library was compiled for: bf16 in
@@ -491,6 +492,14 @@ int xmc_concept_query_fwd(const float* sent, const float* Wq, const float* gnw, 
                           int B, int E, float eps, void* stream);
 int xmc_concept_query_bwd(const float* sent, const float* Wq, const float* gnw, const float* qraw, const float* dq, float* dsent,
                           float* dWq, float* dgnw, float* dgnb, float* scratch, int B, int E, float eps, void* stream);
+/* The sentence queries of ALL sampler stages of a generator at once (they depend on nothing but the sentence vector; S <= 32): Wq / gnw / gnb
+ * are HOST arrays of S device pointers ([64][E], [64], [64]; gnw[s] = gnb[s] = NULL: no GroupNorm); q, qraw f32 [S][B][64].
+ * Backward: dq [S][B][64] -> dsent [B][E] (written: summed over the stages), dWq f32 [S][64][E] (written), dgn f32 [S][2][64] = (d gnw, d gnb)
+ * (accumulated: zeroed by the caller), scratch f32 [B][S*64].  One launch forward, two backward, instead of one / two per stage (ABI 11) */
+int xmc_concept_query_fwd_multi(const float* sent, const float* const* Wq, const float* const* gnw, const float* const* gnb, int S, float* q,
+                                float* qraw, int B, int E, float eps, void* stream);
+int xmc_concept_query_bwd_multi(const float* sent, const float* const* Wq, const float* const* gnw, int S, const float* qraw, const float* dq,
+                                float* dsent, float* dWq, float* dgn, float* scratch, int B, int E, float eps, void* stream);
 int xmc_concept_gquery_fwd(const float* q0, const float* Wq, const float* gnw, const float* gnb, float* q, float* qraw, int B,
                            float eps, void* stream);
 int xmc_concept_gquery_bwd(const float* q0, const float* Wq, const float* gnw, const float* qraw, const float* dq, float* dq0,

@@ -67,8 +67,9 @@ __device__ __forceinline__ float rows_dot64(const float* __restrict__ W, int ld,
 // ------------------------------------------------------------------------------------------------ batch products of a backward
 // D [B, R] (d pre-activation), X [B, C] (the sentence vectors); rows [k*Rp, (k+1)*Rp) of D belong to weight W[k] [Rp, ldw].
 // blocks [0, R/2): dW rows 2*blk, 2*blk+1 (written: columns [0, C));   blocks [R/2, R/2+B): dX[b, :] (written)
+constexpr int QMAX = 32;                // weights per batch product / sampler stages per hoisted query launch (XMC_CONCEPT_QUERY_MAX)
 struct OuterArgs {
-    const float* D; const float* X; const float* W[2]; float* dW[2]; float* dX;
+    const float* D; const float* X; const float* W[QMAX]; float* dW[QMAX]; float* dX;
     int B, R, Rp, C, ldw, acc_dx;       // acc_dx: dX += instead of =
 };
 __global__ __launch_bounds__(256) void concept_outer_kernel(OuterArgs a) {
@@ -142,6 +143,48 @@ __global__ __launch_bounds__(64) void concept_query_bwd_kernel(const float* __re
         g = rstd * (gh - s1 - xh * s2);
     }
     dx[(size_t)b * 64 + c] = g;
+}
+
+// The sentence queries of EVERY sampler stage of a generator in one launch (they depend on nothing but the sentence vector:
+// xmc_concept_query_fwd_multi): blockIdx.y = stage s, weights through a pointer table in the kernel arguments, q / qraw [S][B][64].
+struct QueryTab { const float* Wq[QMAX]; const float* gnw[QMAX]; const float* gnb[QMAX]; };
+__global__ __launch_bounds__(64) void concept_query_fwd_multi_kernel(const float* __restrict__ sent, const QueryTab T, float* __restrict__ q,
+                                                                    float* __restrict__ qraw, int B, int E, float eps) {
+    __shared__ __attribute__((aligned(16))) float s_sent[1024];
+    const int b = blockIdx.x, s = blockIdx.y, c = threadIdx.x;
+    for (int i = c; i < E; i += 64) s_sent[i] = sent[(size_t)b * E + i];
+    __syncthreads();
+    float x = rows_dot64(T.Wq[s], E, s_sent, E, c);
+    const size_t o = ((size_t)s * B + b) * 64 + c;
+    qraw[o] = x;
+    if (T.gnw[s]) {
+        float m = x + xmc_xor1(x); m += xmc_xor2(m); m *= 0.25f;
+        const float dx = x - m;
+        float v = dx * dx; v += xmc_xor1(v); v += xmc_xor2(v); v *= 0.25f;
+        x = dx * rsqrtf(v + eps) * T.gnw[s][c] + T.gnb[s][c];
+    }
+    q[o] = x;
+}
+// dq [S][B][64] -> dx [B][S*64] (row layout of the ONE batch product that follows); dgn [S][2][64] atomically accumulated
+__global__ __launch_bounds__(64) void concept_query_bwd_multi_kernel(const QueryTab T, const float* __restrict__ qraw, const float* __restrict__ dq,
+                                                                    float* __restrict__ dx, float* __restrict__ dgn, int B, int S, float eps) {
+    const int b = blockIdx.x, s = blockIdx.y, c = threadIdx.x;
+    const size_t o = ((size_t)s * B + b) * 64 + c;
+    const float x = qraw[o];
+    float g = dq[o];
+    if (T.gnw[s]) {
+        float m = x + xmc_xor1(x); m += xmc_xor2(m); m *= 0.25f;
+        const float dxm = x - m;
+        float v = dxm * dxm; v += xmc_xor1(v); v += xmc_xor2(v); v *= 0.25f;
+        const float rstd = rsqrtf(v + eps), xh = dxm * rstd;
+        atomicAdd(&dgn[(s * 2 + 0) * 64 + c], g * xh);
+        atomicAdd(&dgn[(s * 2 + 1) * 64 + c], g);
+        const float gh = g * T.gnw[s][c];
+        float s1 = gh + xmc_xor1(gh); s1 += xmc_xor2(s1); s1 *= 0.25f;
+        float s2 = gh * xh; s2 += xmc_xor1(s2); s2 += xmc_xor2(s2); s2 *= 0.25f;
+        g = rstd * (gh - s1 - xh * s2);
+    }
+    dx[(size_t)b * S * 64 + s * 64 + c] = g;
 }
 
 // query of the self-attention sampler: q0 [B, CARD*PWD] (global average of x), Wq [CARD*SD, PWD] grouped 1x1 (555-569)
@@ -461,6 +504,38 @@ extern "C" int xmc_concept_query_bwd(const float* sent, const float* Wq, const f
     OuterArgs a;
     a.D = scratch; a.X = sent; a.W[0] = Wq; a.W[1] = nullptr; a.dW[0] = dWq; a.dW[1] = nullptr; a.dX = dsent;
     a.B = B; a.R = 64; a.Rp = 64; a.C = E; a.ldw = E; a.acc_dx = 0;
+    hipLaunchKernelGGL(concept_outer_kernel, dim3(a.R / 2 + B), dim3(256), 0, ST(stream), a);
+    XMC_LAUNCH_CHECK();
+    return 0;
+}
+
+// all S <= 32 sampler stages at once.  Wq / gnw / gnb: host arrays of S device pointers ([64][E], [64], [64]; gnw[s] and gnb[s] both NULL =
+// no GroupNorm); q, qraw f32 [S][B][64].  Backward: dq [S][B][64] -> dsent [B][E] (written: the sum over the stages), dWq f32 [S][64][E]
+// (written), dgn f32 [S][2][64] = (d gnw, d gnb) (accumulated: zeroed by the caller), scratch f32 [B][S*64].
+extern "C" int xmc_concept_query_fwd_multi(const float* sent, const float* const* Wq, const float* const* gnw, const float* const* gnb, int S,
+                                           float* q, float* qraw, int B, int E, float eps, void* stream) {
+    if (!sent || !Wq || !gnw || !gnb || !q || !qraw || S < 1 || S > QMAX || B < 1 || E < 1 || E > 1024) return XMC_EINVAL;
+    QueryTab T;
+    for (int s = 0; s < QMAX; ++s) {
+        T.Wq[s] = s < S ? Wq[s] : nullptr; T.gnw[s] = s < S ? gnw[s] : nullptr; T.gnb[s] = s < S ? gnb[s] : nullptr;
+        if (s < S && (!Wq[s] || (gnw[s] == nullptr) != (gnb[s] == nullptr))) return XMC_EINVAL;
+    }
+    hipLaunchKernelGGL(concept_query_fwd_multi_kernel, dim3(B, S), dim3(64), 0, ST(stream), sent, T, q, qraw, B, E, eps);
+    XMC_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int xmc_concept_query_bwd_multi(const float* sent, const float* const* Wq, const float* const* gnw, int S, const float* qraw,
+                                           const float* dq, float* dsent, float* dWq, float* dgn, float* scratch, int B, int E, float eps,
+                                           void* stream) {
+    if (!sent || !Wq || !gnw || !qraw || !dq || !dsent || !dWq || !dgn || !scratch || S < 1 || S > QMAX || B < 1 || E < 1) return XMC_EINVAL;
+    QueryTab T;
+    for (int s = 0; s < QMAX; ++s) { T.Wq[s] = s < S ? Wq[s] : nullptr; T.gnw[s] = s < S ? gnw[s] : nullptr; T.gnb[s] = nullptr; }
+    hipLaunchKernelGGL(concept_query_bwd_multi_kernel, dim3(B, S), dim3(64), 0, ST(stream), T, qraw, dq, scratch, dgn, B, S, eps);
+    XMC_LAUNCH_CHECK();
+    OuterArgs a;
+    for (int s = 0; s < QMAX; ++s) { a.W[s] = s < S ? Wq[s] : nullptr; a.dW[s] = s < S ? dWq + (size_t)s * 64 * E : nullptr; }
+    a.D = scratch; a.X = sent; a.dX = dsent;
+    a.B = B; a.R = S * 64; a.Rp = 64; a.C = E; a.ldw = E; a.acc_dx = 0;
     hipLaunchKernelGGL(concept_outer_kernel, dim3(a.R / 2 + B), dim3(256), 0, ST(stream), a);
     XMC_LAUNCH_CHECK();
     return 0;

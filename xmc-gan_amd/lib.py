@@ -124,6 +124,8 @@ _SIGS = {
     "xmc_cast": [vp, vp, i64, i32, i32, vp],
     "xmc_concept_query_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, f32, vp],
     "xmc_concept_query_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp],
+    "xmc_concept_query_fwd_multi": [vp, vp, vp, vp, i32, vp, vp, i32, i32, f32, vp],
+    "xmc_concept_query_bwd_multi": [vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp],
     "xmc_concept_gquery_fwd": [vp, vp, vp, vp, vp, vp, i32, f32, vp],
     "xmc_concept_gquery_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, f32, vp],
     "xmc_concept_head_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, vp],

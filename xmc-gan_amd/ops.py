@@ -2574,6 +2574,63 @@ class ConceptQueryFn(torch.autograd.Function):
         return dsent, dw.view(ctx.wshape), dgw, dgb, None
 
 
+class ConceptQueryAllFn(torch.autograd.Function):
+    """ConceptQueryFn for EVERY sampler stage of a generator at once: the sentence queries depend on nothing but the sentence vector, so the
+    24-28 per-stage launches (and, backward, as many pairs of launches) are one (two).  apply(sent, eps, wq_0, gnw_0, gnb_0, wq_1, ...) ->
+    (q_0, q_1, ...) each f32 [B,16,4] (gnw_s / gnb_s None: no GroupNorm)."""
+
+    @staticmethod
+    def _tabs(ws, gws, gbs=None):
+        mk = lambda ts: (C.c_void_p * len(ts))(*[None if t is None else t.data_ptr() for t in ts])
+        return (mk(ws), mk(gws)) + ((mk(gbs),) if gbs is not None else ())
+
+    @staticmethod
+    def forward(ctx, sent, eps, *params):
+        sent = sent.contiguous().float()
+        S = len(params) // 3
+        assert 1 <= S <= 32 and len(params) == 3 * S
+        B, E = sent.shape
+        ws = [params[3 * s].detach().contiguous().float().view(64, E) for s in range(S)]
+        gws = [None if params[3 * s + 1] is None else params[3 * s + 1].detach().contiguous().float() for s in range(S)]
+        gbs = [None if params[3 * s + 2] is None else params[3 * s + 2].detach().contiguous().float() for s in range(S)]
+        _need_cuda(sent, *ws)
+        q = torch.empty(S, B, 64, dtype=torch.float32, device=sent.device)
+        qraw = torch.empty_like(q)
+        tw, tg, tb = ConceptQueryAllFn._tabs(ws, gws, gbs)
+        L.call("xmc_concept_query_fwd_multi", _p(sent), tw, tg, tb, S, _p(q), _p(qraw), B, E, float(eps), _st())
+        ctx.eps, ctx.S, ctx.wshapes, ctx.has_gn = float(eps), S, [tuple(params[3 * s].shape) for s in range(S)], [g is not None for g in gws]
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(sent, qraw, *ws, *[g for g in gws if g is not None])
+        return tuple(q[s].view(B, 16, 4) for s in range(S))
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, *dqs):
+        sent, qraw, *rest = ctx.saved_tensors
+        S = ctx.S
+        ws, gl = rest[:S], list(rest[S:])
+        gws = [gl.pop(0) if h else None for h in ctx.has_gn]
+        B, E = sent.shape
+        dq = torch.stack([torch.zeros(B, 64, dtype=torch.float32, device=sent.device) if d is None else d.reshape(B, 64).float() for d in dqs])
+        dsent = torch.empty_like(sent)
+        flat = _zeros_f32_out(S * 64 * E + S * 128, sent.device)
+        dw, dgn = flat[:S * 64 * E].view(S, 64, E), flat[S * 64 * E:].view(S, 2, 64)
+        scratch = torch.empty(B, S * 64, dtype=torch.float32, device=sent.device)
+        tw, tg = ConceptQueryAllFn._tabs(ws, gws)
+        L.call("xmc_concept_query_bwd_multi", _p(sent), tw, tg, S, _p(qraw), _p(dq.contiguous()), _p(dsent), _p(dw), _p(dgn), _p(scratch),
+               B, E, ctx.eps, _st())
+        out = [dsent, None]
+        for s in range(S):
+            out += [dw[s].view(ctx.wshapes[s]), dgn[s, 0] if ctx.has_gn[s] else None, dgn[s, 1] if ctx.has_gn[s] else None]
+        return tuple(out)
+
+
+def concept_query_all(sent, stages, eps=1e-5):
+    """stages: [(wq, gnw | None, gnb | None), ...] in any order -> the list of their queries"""
+    flat = [t for st in stages for t in st]
+    return list(ConceptQueryAllFn.apply(sent, eps, *flat))
+
+
 class ConceptGQueryFn(torch.autograd.Function):
     """Query of the self-attention sampler (df_concept_gan.py:555-569): grouped 1x1 (8 -> 4 per concept) on the globally
     averaged block input + GroupNorm over each concept's 4 values.  q0 f32 [B,128], wq [64,8,1,1] -> q f32 [B,16,4]."""

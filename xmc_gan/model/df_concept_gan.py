@@ -170,8 +170,11 @@ class InConceptBlock(_ConceptBlockBase):
             # per-sample concept algebra in two kernels per stage (csrc/concept.hip) around the region attention:
             #   sentence query + GroupNorm                                   (273-286)
             #   value projection, ConceptReasoner, gamma / beta grouped MLPs (238-253, 291-326)
-            q = ops.concept_query(sent, samp.query_gconv.weight, samp.gn1.weight if samp.normalize else None,
-                                  samp.gn1.bias if samp.normalize else None)
+            # (the generator's forward has usually computed every stage's query in one launch already: _ConceptNetG.forward)
+            q = samp.__dict__.pop("_q_hoisted", None)
+            if q is None:
+                q = ops.concept_query(sent, samp.query_gconv.weight, samp.gn1.weight if samp.normalize else None,
+                                      samp.gn1.bias if samp.normalize else None)
             out = samp.stage(out, q, 1.0, sent, (
                 samp.value_gconv.weight, reas.proj_edge.weight,
                 gm[0].weight, gm[0].bias, gm[2].weight, gm[2].bias, bm[0].weight, bm[0].bias, bm[2].weight, bm[2].bias))
@@ -271,9 +274,23 @@ class _ConceptNetG(_DFNetG):
     def forward(self, noise, sent_embs, return_nhwc=False, nhwc_dst=None, **kwargs):
         sent_embs = self.proj_sent(sent_embs.float())
         out = self.stem(noise)
+        self._hoist_queries(sent_embs)
         for gblock in self.upblocks:
             out = gblock(out, sent_embs)
         return self.tail(out, False, return_nhwc, nhwc_dst)
+
+    def _hoist_queries(self, sent):
+        """The sentence queries of all CondConceptSampler stages (df_concept_gan.py:273-286) depend on nothing but the sentence vector: one
+        launch for all of them (ops.concept_query_all; backward: one GroupNorm-backward launch and one batch product instead of a pair per
+        stage), handed to the stages through a one-shot attribute."""
+        samplers = [s_ for m in self.modules() if isinstance(m, InConceptBlock) for s_ in (m.concept_sampler1, m.concept_sampler2)]
+        if not samplers or len(samplers) > 32 or not sent.is_cuda or ops.debug_switch("no_query_hoist"):
+            return
+        sent = sent.float()
+        qs = ops.concept_query_all(sent, [(s_.query_gconv.weight, s_.gn1.weight if s_.normalize else None,
+                                           s_.gn1.bias if s_.normalize else None) for s_ in samplers])
+        for s_, q in zip(samplers, qs):
+            s_.__dict__["_q_hoisted"] = q
 
 
 class InNetG(_ConceptNetG):
