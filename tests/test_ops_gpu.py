@@ -1438,6 +1438,43 @@ def test_stem_composition_launches_equal_the_torch_statement():
         assert rel_l2(a.reshape(b.shape), b) < 1e-5, (name, rel_l2(a.reshape(b.shape), b))
 
 
+@pytest.mark.parametrize("norm", [True, False])
+def test_hoisted_sentence_queries_equal_the_per_stage_ones(norm):
+    """ops.concept_query_all (every CondConceptSampler stage's sentence query in one launch, df_concept_gan.py:273-286) against the
+    per-stage operator: values bit-equal; gradients of the sentence vector (the SUM over the stages), of every stage's projection and of
+    its GroupNorm parameters to f32 summation order.  One stage is left without a consumer (no gradient reaches it)."""
+    g = torch.Generator().manual_seed(7)
+    B, E, S = 5, 256, 7
+    sent = torch.randn(B, E, generator=g).to(DEV)
+    stages = [(torch.nn.Parameter((torch.randn(64, E, 1, 1, generator=g) * 0.1).to(DEV)),
+               torch.nn.Parameter((1 + 0.1 * torch.randn(64, generator=g)).to(DEV)) if norm else None,
+               torch.nn.Parameter((0.1 * torch.randn(64, generator=g)).to(DEV)) if norm else None) for _ in range(S)]
+    R = [torch.randn(B, 16, 4, generator=g).to(DEV) for _ in range(S)]
+    s1 = sent.clone().requires_grad_()
+    qs = ops.concept_query_all(s1, stages)
+    sum((q * r).sum() for q, r in list(zip(qs, R))[:-1]).backward()          # the last stage's query is not used
+    got = [(s1.grad.clone(),)] + [tuple(None if p is None or p.grad is None else p.grad.clone() for p in st) for st in stages]
+    for st in stages:
+        for p in st:
+            if p is not None:
+                p.grad = None
+    s2 = sent.clone().requires_grad_()
+    ref_q = [ops.concept_query(s2, *st) for st in stages]
+    sum((q * r).sum() for q, r in list(zip(ref_q, R))[:-1]).backward()
+    for a, b in zip(qs, ref_q):
+        assert torch.equal(a, b)
+    rel = lambda u, v: ((u - v).norm() / v.norm().clamp_min(1e-30)).item()
+    assert rel(got[0][0], s2.grad) < 1e-5
+    for s_, st in enumerate(stages):
+        for k, p in enumerate(st):
+            if p is None:
+                continue
+            if s_ == S - 1:
+                assert p.grad is None and (got[1 + s_][k] is None or float(got[1 + s_][k].abs().max()) == 0.0)
+            else:
+                assert rel(got[1 + s_][k], p.grad) < 1e-5, (s_, k)
+
+
 def test_integration_doc_snippet_runs_as_written():
     """The ctypes example of INTEGRATION.md (load the library, mirror XmcConvDesc, pack a weight, run a 3x3 convolution through the C ABI
     with nothing of this package imported) executed verbatim against F.conv2d."""
