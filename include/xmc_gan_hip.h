@@ -506,6 +506,10 @@ int xmc_concept_gquery_bwd(const float* q0, const float* Wq, const float* gnw, c
                            float* dWq, float* dgnw, float* dgnb, int B, float eps, void* stream);
 int xmc_concept_head_fwd(const float* ctx, const float* sent, const float* const* params, float* gamma, float* beta, float* hid,
                          int B, int E, void* stream);
+/* the same with the sentence part of layer 1 computed ahead (for every stage of a generator at once, e.g. by xmc_gemm_group: it depends on
+ * nothing but the sentence vector): a_pre f32 [2][B][128], a_pre[t][b][row] = sum_{i < E} W1_t[row][i] * sent[b][i] (ABI 11) */
+int xmc_concept_head_fwd_pre(const float* ctx, const float* sent, const float* const* params, const float* a_pre, float* gamma, float* beta,
+                             float* hid, int B, int E, void* stream);
 int xmc_concept_head_bwd(const float* ctx, const float* sent, const float* hid, const float* const* params, const float* dgamma,
                          const float* dbeta, float* dctx, float* dsent, float* const* grads, float* scratch, int B, int E,
                          void* stream);

@@ -333,9 +333,11 @@ __device__ __forceinline__ void context_forward(HeadState& S, const HeadParams& 
 }
 
 // ctx [B,CARD,PWD], sent [B,E] -> gamma, beta [B, CARD*PWD], hid [B, 2*HID] (layer-1 pre-activations, kept for the backward)
+// a_pre (optional) f32 [2][B][HID]: the sentence part of layer 1, W1[t][:, :E] . sent, computed ahead for every stage of the generator in one
+// grouped GEMM (it depends on nothing but the sentence vector; xmc_concept_head_fwd_pre) -- the kernel then skips its 256 rows x E dot
 __global__ __launch_bounds__(256) void concept_head_fwd_kernel(const float* __restrict__ ctx, const float* __restrict__ sent,
                                                               HeadParams P, float* __restrict__ gamma, float* __restrict__ beta,
-                                                              float* __restrict__ hid, int E) {
+                                                              float* __restrict__ hid, int E, const float* __restrict__ a_pre, int B) {
     __shared__ HeadState S;
     __shared__ __attribute__((aligned(16))) float s_sent[1024];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -344,7 +346,7 @@ __global__ __launch_bounds__(256) void concept_head_fwd_kernel(const float* __re
     __syncthreads();
     // thread tid owns layer-1 unit (t, row) = (tid >> 7, tid & 127), row = g*8 + o
     const int t = wave >> 1, row = (wave & 1) * 64 + lane, ld = E + SD;
-    float a = rows_dot64(P.W1[t] + (size_t)(wave & 1) * 64 * ld, ld, s_sent, E, lane) + P.b1[t][row];
+    float a = (a_pre ? a_pre[((size_t)t * B + b) * HID + row] : rows_dot64(P.W1[t] + (size_t)(wave & 1) * 64 * ld, ld, s_sent, E, lane)) + P.b1[t][row];
     reasoner_forward(S, P, tid);
     context_forward<4>(S, P, s_sent, E, tid);
     {
@@ -570,7 +572,16 @@ extern "C" int xmc_concept_head_fwd(const float* ctx, const float* sent, const f
                                     float* hid, int B, int E, void* stream) {
     HeadParams P;
     if (!ctx || !sent || !params || !gamma || !beta || !hid || B < 1 || E < 1 || E > 1024 || !head_params(params, P)) return XMC_EINVAL;
-    hipLaunchKernelGGL(concept_head_fwd_kernel, dim3(B), dim3(256), 0, ST(stream), ctx, sent, P, gamma, beta, hid, E);
+    hipLaunchKernelGGL(concept_head_fwd_kernel, dim3(B), dim3(256), 0, ST(stream), ctx, sent, P, gamma, beta, hid, E, (const float*)nullptr, B);
+    XMC_LAUNCH_CHECK();
+    return 0;
+}
+// the same with the sentence part of layer 1 handed in: a_pre f32 [2][B][128], a_pre[t][b][row] = sum_i W1_t[row][i] sent[b][i] (i < E)
+extern "C" int xmc_concept_head_fwd_pre(const float* ctx, const float* sent, const float* const* params, const float* a_pre, float* gamma,
+                                        float* beta, float* hid, int B, int E, void* stream) {
+    HeadParams P;
+    if (!ctx || !sent || !params || !a_pre || !gamma || !beta || !hid || B < 1 || E < 1 || E > 1024 || !head_params(params, P)) return XMC_EINVAL;
+    hipLaunchKernelGGL(concept_head_fwd_kernel, dim3(B), dim3(256), 0, ST(stream), ctx, sent, P, gamma, beta, hid, E, a_pre, B);
     XMC_LAUNCH_CHECK();
     return 0;
 }

@@ -2664,14 +2664,39 @@ class ConceptGQueryFn(torch.autograd.Function):
         return dq0, dw.view(ctx.wshape), dgw, dgb, None
 
 
-def _head_fwd_raw(pooled, sent, ps):
+def _head_fwd_raw(pooled, sent, ps, a_pre=None):
+    """``a_pre`` f32 [2,B,128]: the sentence part of the two MLPs' first layer, computed ahead (head_sentence_products)"""
     B, E = sent.shape
     tab = (C.c_void_p * 11)(*[p_.data_ptr() for p_ in ps])          # tab[10] stays NULL without sent_linear
     gamma = torch.empty(B, 128, dtype=torch.float32, device=sent.device)
     beta = torch.empty_like(gamma)
     hid = torch.empty(B, 256, dtype=torch.float32, device=sent.device)
-    L.call("xmc_concept_head_fwd", _p(pooled), _p(sent), tab, _p(gamma), _p(beta), _p(hid), B, E, _st())
+    if a_pre is not None:
+        assert a_pre.dtype == torch.float32 and tuple(a_pre.shape) == (2, B, 128) and a_pre.is_contiguous()
+        L.call("xmc_concept_head_fwd_pre", _p(pooled), _p(sent), tab, _p(a_pre), _p(gamma), _p(beta), _p(hid), B, E, _st())
+    else:
+        L.call("xmc_concept_head_fwd", _p(pooled), _p(sent), tab, _p(gamma), _p(beta), _p(hid), B, E, _st())
     return gamma, beta, hid
+
+
+def head_sentence_products(sent, w1s):
+    """The sentence part of layer 1 of the gamma / beta heads for MANY stages at once (df_concept_gan.py:238-253: the heads' grouped 1x1
+    over [sentence ; concept state], whose sentence columns see the same vector in every stage): w1s = [(W1_gamma, W1_beta), ...] with
+    W1 [128, E + 4(, 1, 1)] -> f32 [S, 2, B, 128], entry [s, t] = sent @ W1_t[:, :E].T, ONE grouped GEMM launch per 32 problems.  No
+    autograd: a stage's backward forms its sentence and weight gradients from the saved sentence vector itself."""
+    sent = sent.detach().contiguous().float()
+    B, E = sent.shape
+    S = len(w1s)
+    out = torch.empty(S, 2, B, 128, dtype=torch.float32, device=sent.device)
+    t = np.zeros(2 * S, dtype=L.GEMM_PROBLEM)
+    ws = [w.detach() for pair in w1s for w in pair]
+    assert all(w.is_contiguous() and w.dtype == torch.float32 and w.numel() == 128 * (E + 4) for w in ws)
+    t["A"], t["B"] = sent.data_ptr(), np.array([w.data_ptr() for w in ws], dtype=np.uint64)
+    t["C"] = (out.data_ptr() + np.arange(2 * S, dtype=np.int64) * (B * 128 * 4)).astype(np.uint64)
+    t["M"], t["N"], t["K"] = B, 128, E
+    t["sa_i"], t["sa_r"], t["sb_j"], t["sb_r"] = E, 1, E + 4, 1
+    _gemm_group(t)
+    return out
 
 
 def _head_bwd_raw(pooled, sent, hid, ps, dgamma, dbeta):
@@ -2729,7 +2754,7 @@ class ConceptStageFn(torch.autograd.Function):
     the key projection's data gradient takes that buffer as its residual: no add pass, no framework kernel in the stage."""
 
     @staticmethod
-    def forward(ctx, x, q, sent, wk, gnw, gnb, geom, ncon, scale, eps, *params):
+    def forward(ctx, x, q, sent, wk, gnw, gnb, geom, ncon, scale, eps, a_pre, *params):
         x = x.contiguous()
         q, sent = q.contiguous().float(), sent.contiguous().float()
         _need_cuda(x, q, sent)
@@ -2743,7 +2768,7 @@ class ConceptStageFn(torch.autograd.Function):
             keyn = key
         pooled, astats = _attn_fwd_raw(keyn, q, x, ncon, scale)
         ps = [p_.detach().contiguous().float() for p_ in params]
-        gamma, beta, hid = _head_fwd_raw(pooled, sent, ps)
+        gamma, beta, hid = _head_fwd_raw(pooled, sent, ps, a_pre)
         y = _affine_fwd_raw(x, [gamma, beta], 0.2)
         ctx.geom, ctx.ncon, ctx.scale, ctx.gn = geom, ncon, scale, gn
         ctx.shapes = [tuple(p_.shape) for p_ in params]
@@ -2767,12 +2792,12 @@ class ConceptStageFn(torch.autograd.Function):
         dwk = None
         if ctx.needs_input_grad[3] and not _skip_wgrad():
             dwk = _conv_wgrad_raw(x, dkey, geom).view(wk.shape)
-        return (dxt, dq.view(q.shape), dsent, dwk, dgw, dgb, None, None, None, None) + \
+        return (dxt, dq.view(q.shape), dsent, dwk, dgw, dgb, None, None, None, None, None) + \
             tuple(g_.view(sh) for g_, sh in zip(grads, ctx.shapes))
 
 
-def concept_stage(x, q, sent, wk, gnw, gnb, geom, ncon, scale, head_params, eps=1e-5):
-    return ConceptStageFn.apply(x, q, sent, wk, gnw, gnb, geom, ncon, scale, eps, *head_params)
+def concept_stage(x, q, sent, wk, gnw, gnb, geom, ncon, scale, head_params, eps=1e-5, a_pre=None):
+    return ConceptStageFn.apply(x, q, sent, wk, gnw, gnb, geom, ncon, scale, eps, a_pre, *head_params)
 
 
 def concept_gquery(q0, wq, gnw=None, gnb=None, eps=1e-5):

@@ -88,10 +88,11 @@ class _SamplerBase(nn.Module):
 
     def stage(self, x, q, scale, sent, head_params):
         """key projection [+ GroupNorm], region attention, concept head and the channel modulation lrelu(gamma * x + beta) as one
-        autograd node (ops.ConceptStageFn): x [B,H,W,128], q [B,16,4] f32 (already normalised) -> [B,H,W,128]."""
+        autograd node (ops.ConceptStageFn): x [B,H,W,128], q [B,16,4] f32 (already normalised) -> [B,H,W,128].
+        (the heads' sentence products have usually been computed for all stages at once: _ConceptNetG._hoist)"""
         return ops.concept_stage(x, q, sent, self.key_gconv.weight, self.gn2.weight if self.normalize else None,
                                  self.gn2.bias if self.normalize else None, self.key_gconv.geom, self.cardinality, scale,
-                                 head_params, eps=self.gn2.eps if self.normalize else 1e-5)
+                                 head_params, eps=self.gn2.eps if self.normalize else 1e-5, a_pre=self.__dict__.pop("_a_hoisted", None))
 
     def _attend(self, x, q, scale):
         """x [B,H,W,128], q [B,16,4] f32 -> value-projected context [B,16,4]."""
@@ -274,19 +275,28 @@ class _ConceptNetG(_DFNetG):
     def forward(self, noise, sent_embs, return_nhwc=False, nhwc_dst=None, **kwargs):
         sent_embs = self.proj_sent(sent_embs.float())
         out = self.stem(noise)
-        self._hoist_queries(sent_embs)
+        self._hoist(sent_embs)
         for gblock in self.upblocks:
             out = gblock(out, sent_embs)
         return self.tail(out, False, return_nhwc, nhwc_dst)
 
-    def _hoist_queries(self, sent):
-        """The sentence queries of all CondConceptSampler stages (df_concept_gan.py:273-286) depend on nothing but the sentence vector: one
-        launch for all of them (ops.concept_query_all; backward: one GroupNorm-backward launch and one batch product instead of a pair per
-        stage), handed to the stages through a one-shot attribute."""
-        samplers = [s_ for m in self.modules() if isinstance(m, InConceptBlock) for s_ in (m.concept_sampler1, m.concept_sampler2)]
-        if not samplers or len(samplers) > 32 or not sent.is_cuda or ops.debug_switch("no_query_hoist"):
+    def _hoist(self, sent):
+        """What every sampler stage computes from the sentence vector ALONE, once for the whole generator, handed to the stages through
+        one-shot attributes: the sentence part of the gamma / beta heads' first layer (df_concept_gan.py:238-253; one grouped GEMM instead of
+        a 256-row dot per sample in each of the 24-28 head launches) and, for the sentence-attention kind, the queries of all
+        CondConceptSampler stages (273-286; ops.concept_query_all: one launch, backward one GroupNorm-backward launch and ONE batch product)."""
+        if not sent.is_cuda:
             return
         sent = sent.float()
+        blocks = [m for m in self.modules() if isinstance(m, (InConceptBlock, OutConceptBlock))]
+        if blocks and not ops.debug_switch("no_head_hoist"):
+            stages = [(m.concept_sampler1, m.gamma1_gconv, m.beta1_gconv) for m in blocks] + [(m.concept_sampler2, m.gamma2_gconv, m.beta2_gconv) for m in blocks]
+            A = ops.head_sentence_products(sent, [(gm[0].weight, bm[0].weight) for _, gm, bm in stages])
+            for k, (s_, _, _) in enumerate(stages):
+                s_.__dict__["_a_hoisted"] = A[k]
+        samplers = [s_ for m in blocks if isinstance(m, InConceptBlock) for s_ in (m.concept_sampler1, m.concept_sampler2)]
+        if not samplers or len(samplers) > 32 or ops.debug_switch("no_query_hoist"):
+            return
         qs = ops.concept_query_all(sent, [(s_.query_gconv.weight, s_.gn1.weight if s_.normalize else None,
                                            s_.gn1.bias if s_.normalize else None) for s_ in samplers])
         for s_, q in zip(samplers, qs):
