@@ -513,6 +513,15 @@ int xmc_concept_head_fwd_pre(const float* ctx, const float* sent, const float* c
 int xmc_concept_head_bwd(const float* ctx, const float* sent, const float* hid, const float* const* params, const float* dgamma,
                          const float* dbeta, float* dctx, float* dsent, float* const* grads, float* scratch, int B, int E,
                          void* stream);
+/* the same WITHOUT the batch products of layer 1's sentence columns (dW1[:, :E], and dsent's share of them): scratch[:, :256] = d of the
+ * layer-1 pre-activations ([B][2*128]) is what the caller collects from every stage and hands to ONE xmc_concept_outer_multi.  grads'
+ * W1 entries still receive the concept-state columns and must be zeroed; dsent is written only when params[10] (sent_linear) is set (ABI 11) */
+int xmc_concept_head_bwd_pre(const float* ctx, const float* sent, const float* hid, const float* const* params, const float* dgamma,
+                             const float* dbeta, float* dctx, float* dsent, float* const* grads, float* scratch, int B, int E, void* stream);
+/* D [B][nW*Rp] x X [B][C]:  dW[k][r][c] = sum_b D[b][k*Rp + r] * X[b][c] for c < C (written; row pitch ldw >= C, other columns untouched),
+ * dX[b][c] = sum_{k,r} D[b][k*Rp + r] * W[k][r][c] (written).  W / dW: HOST arrays of nW <= 64 device pointers; Rp even (ABI 11) */
+int xmc_concept_outer_multi(const float* D, const float* X, const float* const* W, float* const* dW, int nW, int Rp, float* dX, int B, int C,
+                            int ldw, void* stream);
 
 /* ---- the discriminator's stem as one convolution from the image (csrc/dstem.hip) -------------------------------------------------
  * conv_img (df_gan.py:114,127) feeds the first resD block without an activation, so conv_r[0] o conv_img is a 6x6 stride-2 pad-2

@@ -167,7 +167,10 @@ def test_generator_full_batch_equals_slices(yml, size, batch, nsl, mode):
     # every logit alike and has NO gradient) to a floor of the largest tensor norm, as compare_grads does
     big = max(acc[n].norm().item() for n in acc)
     fl = 1e-4 if mode == "fp32" else 2e-2
-    errs = {n: ((gw[n] - acc[n]).norm() / max(acc[n].norm().item(), fl * big)).item() for n in gw}
+    # (parameters with <= 4 elements -- the block gammas: <dout, residual>, one cancelling sum over every pixel -- on the scale of the largest
+    # such gradient, as parity_util.compare_grads does: one of them near zero otherwise turns f32 summation order into 2e-3 .. 8e-3 run to run)
+    small = max([acc[n].abs().max().item() for n in acc if acc[n].numel() <= 4] + [0.0])
+    errs = {n: ((gw[n] - acc[n]).norm() / max(acc[n].norm().item(), fl * big, small if acc[n].numel() <= 4 else 0.0)).item() for n in gw}
     worst = max(errs, key=errs.get)
     tot = rel_err(torch.cat([gw[n].flatten() for n in gw]), torch.cat([acc[n].flatten() for n in gw]))
     print(f"\n[G {yml} {size}px b{batch} {mode}] image {worst_img:.1e}; weight gradients full vs sum of {nsl} slices: worst {errs[worst]:.1e} "

@@ -67,7 +67,7 @@ __device__ __forceinline__ float rows_dot64(const float* __restrict__ W, int ld,
 // ------------------------------------------------------------------------------------------------ batch products of a backward
 // D [B, R] (d pre-activation), X [B, C] (the sentence vectors); rows [k*Rp, (k+1)*Rp) of D belong to weight W[k] [Rp, ldw].
 // blocks [0, R/2): dW rows 2*blk, 2*blk+1 (written: columns [0, C));   blocks [R/2, R/2+B): dX[b, :] (written)
-constexpr int QMAX = 32;                // weights per batch product / sampler stages per hoisted query launch (XMC_CONCEPT_QUERY_MAX)
+constexpr int QMAX = 64;                // weights per batch product; sampler stages per hoisted query launch: QMAX / 2
 struct OuterArgs {
     const float* D; const float* X; const float* W[QMAX]; float* dW[QMAX]; float* dX;
     int B, R, Rp, C, ldw, acc_dx;       // acc_dx: dX += instead of =
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(64) void concept_query_bwd_kernel(const float* __re
 
 // The sentence queries of EVERY sampler stage of a generator in one launch (they depend on nothing but the sentence vector:
 // xmc_concept_query_fwd_multi): blockIdx.y = stage s, weights through a pointer table in the kernel arguments, q / qraw [S][B][64].
-struct QueryTab { const float* Wq[QMAX]; const float* gnw[QMAX]; const float* gnb[QMAX]; };
+struct QueryTab { const float* Wq[32]; const float* gnw[32]; const float* gnb[32]; };
 __global__ __launch_bounds__(64) void concept_query_fwd_multi_kernel(const float* __restrict__ sent, const QueryTab T, float* __restrict__ q,
                                                                     float* __restrict__ qraw, int B, int E, float eps) {
     __shared__ __attribute__((aligned(16))) float s_sent[1024];
@@ -516,9 +516,9 @@ extern "C" int xmc_concept_query_bwd(const float* sent, const float* Wq, const f
 // (written), dgn f32 [S][2][64] = (d gnw, d gnb) (accumulated: zeroed by the caller), scratch f32 [B][S*64].
 extern "C" int xmc_concept_query_fwd_multi(const float* sent, const float* const* Wq, const float* const* gnw, const float* const* gnb, int S,
                                            float* q, float* qraw, int B, int E, float eps, void* stream) {
-    if (!sent || !Wq || !gnw || !gnb || !q || !qraw || S < 1 || S > QMAX || B < 1 || E < 1 || E > 1024) return XMC_EINVAL;
+    if (!sent || !Wq || !gnw || !gnb || !q || !qraw || S < 1 || S > 32 || B < 1 || E < 1 || E > 1024) return XMC_EINVAL;
     QueryTab T;
-    for (int s = 0; s < QMAX; ++s) {
+    for (int s = 0; s < 32; ++s) {
         T.Wq[s] = s < S ? Wq[s] : nullptr; T.gnw[s] = s < S ? gnw[s] : nullptr; T.gnb[s] = s < S ? gnb[s] : nullptr;
         if (s < S && (!Wq[s] || (gnw[s] == nullptr) != (gnb[s] == nullptr))) return XMC_EINVAL;
     }
@@ -529,9 +529,9 @@ extern "C" int xmc_concept_query_fwd_multi(const float* sent, const float* const
 extern "C" int xmc_concept_query_bwd_multi(const float* sent, const float* const* Wq, const float* const* gnw, int S, const float* qraw,
                                            const float* dq, float* dsent, float* dWq, float* dgn, float* scratch, int B, int E, float eps,
                                            void* stream) {
-    if (!sent || !Wq || !gnw || !qraw || !dq || !dsent || !dWq || !dgn || !scratch || S < 1 || S > QMAX || B < 1 || E < 1) return XMC_EINVAL;
+    if (!sent || !Wq || !gnw || !qraw || !dq || !dsent || !dWq || !dgn || !scratch || S < 1 || S > 32 || B < 1 || E < 1) return XMC_EINVAL;
     QueryTab T;
-    for (int s = 0; s < QMAX; ++s) { T.Wq[s] = s < S ? Wq[s] : nullptr; T.gnw[s] = s < S ? gnw[s] : nullptr; T.gnb[s] = nullptr; }
+    for (int s = 0; s < 32; ++s) { T.Wq[s] = s < S ? Wq[s] : nullptr; T.gnw[s] = s < S ? gnw[s] : nullptr; T.gnb[s] = nullptr; }
     hipLaunchKernelGGL(concept_query_bwd_multi_kernel, dim3(B, S), dim3(64), 0, ST(stream), T, qraw, dq, scratch, dgn, B, S, eps);
     XMC_LAUNCH_CHECK();
     OuterArgs a;
@@ -585,9 +585,35 @@ extern "C" int xmc_concept_head_fwd_pre(const float* ctx, const float* sent, con
     XMC_LAUNCH_CHECK();
     return 0;
 }
+static int head_bwd_go(const float* ctx, const float* sent, const float* hid, const float* const* params, const float* dgamma,
+                       const float* dbeta, float* dctx, float* dsent, float* const* grads, float* scratch, int B, int E, void* stream, bool defer);
 extern "C" int xmc_concept_head_bwd(const float* ctx, const float* sent, const float* hid, const float* const* params,
                                     const float* dgamma, const float* dbeta, float* dctx, float* dsent, float* const* grads,
                                     float* scratch, int B, int E, void* stream) {
+    return head_bwd_go(ctx, sent, hid, params, dgamma, dbeta, dctx, dsent, grads, scratch, B, E, stream, false);
+}
+// the same WITHOUT the batch products of layer 1's sentence columns (dW1[:, :E] and its share of dsent): scratch[:, :256] = d of the layer-1
+// pre-activations is the result the caller collects from every stage and hands to ONE xmc_concept_outer_multi.  dsent is written only for
+// the self-attention kind (its sent_linear term), and not read.
+extern "C" int xmc_concept_head_bwd_pre(const float* ctx, const float* sent, const float* hid, const float* const* params,
+                                        const float* dgamma, const float* dbeta, float* dctx, float* dsent, float* const* grads,
+                                        float* scratch, int B, int E, void* stream) {
+    return head_bwd_go(ctx, sent, hid, params, dgamma, dbeta, dctx, dsent, grads, scratch, B, E, stream, true);
+}
+// D [B][nW * Rp] x X [B][C]: dW[k][r][c < C] = sum_b D[b][k Rp + r] X[b][c] (written, row pitch ldw), dX[b][c] = sum_k,r D[b][k Rp + r] W[k][r][c]
+// (written); nW <= 64.  The batch products of every stage's heads in one launch.
+extern "C" int xmc_concept_outer_multi(const float* D, const float* X, const float* const* W, float* const* dW, int nW, int Rp, float* dX,
+                                       int B, int C, int ldw, void* stream) {
+    if (!D || !X || !W || !dW || !dX || nW < 1 || nW > QMAX || Rp < 2 || (Rp & 1) || B < 1 || C < 1 || ldw < C) return XMC_EINVAL;
+    OuterArgs a;
+    for (int k = 0; k < QMAX; ++k) { a.W[k] = k < nW ? W[k] : nullptr; a.dW[k] = k < nW ? dW[k] : nullptr; if (k < nW && (!W[k] || !dW[k])) return XMC_EINVAL; }
+    a.D = D; a.X = X; a.dX = dX; a.B = B; a.R = nW * Rp; a.Rp = Rp; a.C = C; a.ldw = ldw; a.acc_dx = 0;
+    hipLaunchKernelGGL(concept_outer_kernel, dim3(a.R / 2 + B), dim3(256), 0, ST(stream), a);
+    XMC_LAUNCH_CHECK();
+    return 0;
+}
+static int head_bwd_go(const float* ctx, const float* sent, const float* hid, const float* const* params, const float* dgamma,
+                       const float* dbeta, float* dctx, float* dsent, float* const* grads, float* scratch, int B, int E, void* stream, bool defer) {
     HeadParams P;
     if (!ctx || !sent || !hid || !params || !dgamma || !dbeta || !dctx || !dsent || !grads || !scratch || B < 1 || E < 1 || E > 1024 ||
         !head_params(params, P))
@@ -604,11 +630,13 @@ extern "C" int xmc_concept_head_bwd(const float* ctx, const float* sent, const f
     OuterArgs a;
     a.D = scratch; a.X = sent; a.W[0] = P.W1[0]; a.W[1] = P.W1[1]; a.dW[0] = G.W1[0]; a.dW[1] = G.W1[1]; a.dX = dsent;
     a.B = B; a.R = 2 * HID; a.Rp = HID; a.C = E; a.ldw = E + SD; a.acc_dx = 0;
-    hipLaunchKernelGGL(concept_outer_kernel, dim3(a.R / 2 + B), dim3(256), 0, ST(stream), a);
-    XMC_LAUNCH_CHECK();
-    if (P.Ws) {                                       // dWs = ds^T sent;  dsent += ds Ws
+    if (!defer) {
+        hipLaunchKernelGGL(concept_outer_kernel, dim3(a.R / 2 + B), dim3(256), 0, ST(stream), a);
+        XMC_LAUNCH_CHECK();
+    }
+    if (P.Ws) {                                       // dWs = ds^T sent;  dsent += ds Ws  (deferred: dsent = ds Ws)
         a.D = ds; a.W[0] = P.Ws; a.W[1] = nullptr; a.dW[0] = grads[10]; a.dW[1] = nullptr;
-        a.R = SD; a.Rp = SD; a.ldw = E; a.acc_dx = 1;
+        a.R = SD; a.Rp = SD; a.ldw = E; a.acc_dx = defer ? 0 : 1;
         hipLaunchKernelGGL(concept_outer_kernel, dim3(a.R / 2 + B), dim3(256), 0, ST(stream), a);
         XMC_LAUNCH_CHECK();
     }

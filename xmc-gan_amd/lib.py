@@ -130,6 +130,8 @@ _SIGS = {
     "xmc_concept_gquery_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, f32, vp],
     "xmc_concept_head_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, vp],
     "xmc_concept_head_fwd_pre": [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
+    "xmc_concept_head_bwd_pre": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
+    "xmc_concept_outer_multi": [vp, vp, vp, vp, i32, i32, vp, i32, i32, i32, vp],
     "xmc_concept_head_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
     "xmc_rows_sumsq": [vp, vp, i32, i64, vp],
     "xmc_gp_finish": [vp, i32, vp, vp, f32, vp],

@@ -2679,27 +2679,75 @@ def _head_fwd_raw(pooled, sent, ps, a_pre=None):
     return gamma, beta, hid
 
 
+class _HeadHoist:
+    """What the stage nodes and HeadSentProductsFn share during one backward: the heads' layer-1 weight gradients of ALL stages, f32
+    [S, 2, 128, E + 4], zero-filled.  A stage's backward accumulates its concept-state columns and nothing else into its slice; the
+    hoisted node, which autograd runs after every stage that used its outputs, writes the sentence columns and hands the slices out as the
+    gradients of the W1 parameters -- so neither side's contribution goes through a framework add."""
+
+    def __init__(self, S, E, device):
+        self.S, self.E, self.device, self.dw1 = S, E, device, None
+
+    def grads(self):
+        if self.dw1 is None:
+            self.dw1 = _zeros_f32_out((self.S, 2, 128, self.E + 4), self.device)
+        return self.dw1
+
+
+class HeadSentProductsFn(torch.autograd.Function):
+    """The sentence part of layer 1 of the gamma / beta heads for EVERY stage of a generator at once (df_concept_gan.py:238-253: the heads'
+    grouped 1x1 over [sentence ; concept state], whose sentence columns see the same vector in every stage).
+    apply(hoist, sent, W1_gamma_0, W1_beta_0, W1_gamma_1, ...) -> (A_0, A_1, ...), A_s f32 [2, B, 128] = sent @ W1_t[:, :E].T: one grouped
+    GEMM forward; backward ONE batch product over all stages (xmc_concept_outer_multi) from the d(pre-activation) every stage's node returns
+    as the gradient of its A_s, instead of one per stage."""
+
+    @staticmethod
+    def forward(ctx, hoist, sent, *w1):
+        sent = sent.contiguous().float()
+        B, E = sent.shape
+        S = len(w1) // 2
+        ws = [w.detach() for w in w1]
+        assert len(w1) == 2 * S and all(w.is_contiguous() and w.dtype == torch.float32 and w.numel() == 128 * (E + 4) for w in ws)
+        _need_cuda(sent, *ws)
+        out = torch.empty(S, 2, B, 128, dtype=torch.float32, device=sent.device)
+        t = np.zeros(2 * S, dtype=L.GEMM_PROBLEM)
+        t["A"], t["B"] = sent.data_ptr(), np.array([w.data_ptr() for w in ws], dtype=np.uint64)
+        t["C"] = (out.data_ptr() + np.arange(2 * S, dtype=np.int64) * (B * 128 * 4)).astype(np.uint64)
+        t["M"], t["N"], t["K"] = B, 128, E
+        t["sa_i"], t["sa_r"], t["sb_j"], t["sb_r"] = E, 1, E + 4, 1
+        _gemm_group(t)
+        ctx.hoist, ctx.shapes = hoist, [tuple(w.shape) for w in w1]
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(sent, *ws)
+        return tuple(out[s] for s in range(S))
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, *dA):
+        sent, *ws = ctx.saved_tensors
+        B, E = sent.shape
+        S = len(ws) // 2
+        # stage s hands back d A_s as a [2, B, 128] view of its [B, 256] d(pre-activation): row layout [B][S * 256] for the batch product
+        D = torch.cat([torch.zeros(B, 256, dtype=torch.float32, device=sent.device) if g is None else g.permute(1, 0, 2).reshape(B, 256)
+                       for g in dA], dim=1).contiguous()
+        dw1 = ctx.hoist.grads()
+        ctx.hoist.dw1 = None                      # the next backward starts from a fresh zero buffer
+        dsent = torch.empty_like(sent)
+        mk = lambda ptrs: (C.c_void_p * len(ptrs))(*ptrs)
+        L.call("xmc_concept_outer_multi", _p(D), _p(sent), mk([w.data_ptr() for w in ws]),
+               mk([dw1[k // 2, k % 2].data_ptr() for k in range(2 * S)]), 2 * S, 128, _p(dsent), B, E, E + 4, _st())
+        return (None, dsent) + tuple(dw1[k // 2, k % 2].view(ctx.shapes[k]) for k in range(2 * S))
+
+
 def head_sentence_products(sent, w1s):
-    """The sentence part of layer 1 of the gamma / beta heads for MANY stages at once (df_concept_gan.py:238-253: the heads' grouped 1x1
-    over [sentence ; concept state], whose sentence columns see the same vector in every stage): w1s = [(W1_gamma, W1_beta), ...] with
-    W1 [128, E + 4(, 1, 1)] -> f32 [S, 2, B, 128], entry [s, t] = sent @ W1_t[:, :E].T, ONE grouped GEMM launch per 32 problems.  No
-    autograd: a stage's backward forms its sentence and weight gradients from the saved sentence vector itself."""
-    sent = sent.detach().contiguous().float()
-    B, E = sent.shape
-    S = len(w1s)
-    out = torch.empty(S, 2, B, 128, dtype=torch.float32, device=sent.device)
-    t = np.zeros(2 * S, dtype=L.GEMM_PROBLEM)
-    ws = [w.detach() for pair in w1s for w in pair]
-    assert all(w.is_contiguous() and w.dtype == torch.float32 and w.numel() == 128 * (E + 4) for w in ws)
-    t["A"], t["B"] = sent.data_ptr(), np.array([w.data_ptr() for w in ws], dtype=np.uint64)
-    t["C"] = (out.data_ptr() + np.arange(2 * S, dtype=np.int64) * (B * 128 * 4)).astype(np.uint64)
-    t["M"], t["N"], t["K"] = B, 128, E
-    t["sa_i"], t["sa_r"], t["sb_j"], t["sb_r"] = E, 1, E + 4, 1
-    _gemm_group(t)
-    return out
+    """w1s = [(W1_gamma, W1_beta), ...] -> ([A_s f32 [2,B,128]], hoist): see HeadSentProductsFn / _HeadHoist"""
+    hoist = _HeadHoist(len(w1s), sent.shape[1], sent.device)
+    return list(HeadSentProductsFn.apply(hoist, sent, *[w for pair in w1s for w in pair])), hoist
 
 
-def _head_bwd_raw(pooled, sent, hid, ps, dgamma, dbeta):
+def _head_bwd_raw(pooled, sent, hid, ps, dgamma, dbeta, hoist=None):
+    """``hoist`` = (_HeadHoist, stage index): the batch products of layer 1's sentence columns are left to HeadSentProductsFn.backward;
+    returns (dpooled, dsent | None, grads with None for the two W1 tensors, d(pre-activation) [B,256])."""
     B, E = sent.shape
     dpooled, dsent = torch.empty_like(pooled), torch.empty_like(sent)
     sizes = [(p_.numel() + 3) // 4 * 4 for p_ in ps]                      # 16-byte aligned slices of ONE zero-filled buffer
@@ -2709,8 +2757,17 @@ def _head_bwd_raw(pooled, sent, hid, ps, dgamma, dbeta):
         grads.append(flat[off:off + p_.numel()].view(p_.shape))
         off += n_
     tab = (C.c_void_p * 11)(*[p_.data_ptr() for p_ in ps])
-    gtab = (C.c_void_p * 11)(*[g_.data_ptr() for g_ in grads])
     scratch = torch.empty(B, 260, dtype=torch.float32, device=sent.device)
+    if hoist is not None:
+        H, k = hoist
+        own = [g_.data_ptr() for g_ in grads]
+        own[2], own[6] = H.grads()[k, 0].data_ptr(), H.grads()[k, 1].data_ptr()       # the stage's concept-state columns land in the shared buffer
+        L.call("xmc_concept_head_bwd_pre", _p(pooled), _p(sent), _p(hid), tab, _p(dgamma), _p(dbeta), _p(dpooled), _p(dsent),
+               (C.c_void_p * 11)(*own), _p(scratch), B, E, _st())
+        grads[2] = grads[6] = None
+        # (scratch holds d(pre-activation) as [B][256] followed by the [B][4] of the sent_linear term: not a [B, 260] matrix)
+        return dpooled, (dsent if len(ps) > 10 else None), grads, scratch.view(-1)[:B * 256].view(B, 256)
+    gtab = (C.c_void_p * 11)(*[g_.data_ptr() for g_ in grads])
     L.call("xmc_concept_head_bwd", _p(pooled), _p(sent), _p(hid), tab, _p(dgamma), _p(dbeta), _p(dpooled), _p(dsent), gtab,
            _p(scratch), B, E, _st())
     return dpooled, dsent, grads
@@ -2754,7 +2811,7 @@ class ConceptStageFn(torch.autograd.Function):
     the key projection's data gradient takes that buffer as its residual: no add pass, no framework kernel in the stage."""
 
     @staticmethod
-    def forward(ctx, x, q, sent, wk, gnw, gnb, geom, ncon, scale, eps, a_pre, *params):
+    def forward(ctx, x, q, sent, wk, gnw, gnb, geom, ncon, scale, eps, a_pre, hoist, *params):
         x = x.contiguous()
         q, sent = q.contiguous().float(), sent.contiguous().float()
         _need_cuda(x, q, sent)
@@ -2771,6 +2828,7 @@ class ConceptStageFn(torch.autograd.Function):
         gamma, beta, hid = _head_fwd_raw(pooled, sent, ps, a_pre)
         y = _affine_fwd_raw(x, [gamma, beta], 0.2)
         ctx.geom, ctx.ncon, ctx.scale, ctx.gn = geom, ncon, scale, gn
+        ctx.hoist = hoist if a_pre is not None else None
         ctx.shapes = [tuple(p_.shape) for p_ in params]
         ctx.save_for_backward(x, q, sent, wk, key if gn else None, keyn, gwf, gbf, gstats, astats, pooled, hid, gamma, beta, *ps)
         return y
@@ -2781,7 +2839,12 @@ class ConceptStageFn(torch.autograd.Function):
         x, q, sent, wk, key, keyn, gwf, gbf, gstats, astats, pooled, hid, gamma, beta, *ps = ctx.saved_tensors
         geom = ctx.geom
         dx, red = _affine_bwd_raw(x, dy.contiguous(), [gamma, beta], 0.2)
-        dpooled, dsent, grads = _head_bwd_raw(pooled, sent, hid, ps, red[0], red[1])
+        da_pre = None
+        if ctx.hoist is not None:
+            dpooled, dsent, grads, da = _head_bwd_raw(pooled, sent, hid, ps, red[0], red[1], hoist=ctx.hoist)
+            da_pre = da.view(da.shape[0], 2, 128).permute(1, 0, 2)            # d A_s = d(pre-activation), in A_s's [2, B, 128] indexing
+        else:
+            dpooled, dsent, grads = _head_bwd_raw(pooled, sent, hid, ps, red[0], red[1])
         dkeyn, dq, dx = _attn_bwd_raw(keyn, q, x, astats, pooled, dpooled, ctx.ncon, ctx.scale, dx_acc=dx)
         dgw = dgb = None
         if ctx.gn:
@@ -2792,12 +2855,13 @@ class ConceptStageFn(torch.autograd.Function):
         dwk = None
         if ctx.needs_input_grad[3] and not _skip_wgrad():
             dwk = _conv_wgrad_raw(x, dkey, geom).view(wk.shape)
-        return (dxt, dq.view(q.shape), dsent, dwk, dgw, dgb, None, None, None, None, None) + \
-            tuple(g_.view(sh) for g_, sh in zip(grads, ctx.shapes))
+        return (dxt, dq.view(q.shape), dsent, dwk, dgw, dgb, None, None, None, None, da_pre, None) + \
+            tuple(None if g_ is None else g_.view(sh) for g_, sh in zip(grads, ctx.shapes))
 
 
-def concept_stage(x, q, sent, wk, gnw, gnb, geom, ncon, scale, head_params, eps=1e-5, a_pre=None):
-    return ConceptStageFn.apply(x, q, sent, wk, gnw, gnb, geom, ncon, scale, eps, a_pre, *head_params)
+def concept_stage(x, q, sent, wk, gnw, gnb, geom, ncon, scale, head_params, eps=1e-5, a_pre=None, hoist=None):
+    """``a_pre`` / ``hoist`` = (A_s, (_HeadHoist, s)) from head_sentence_products: layer 1's sentence products, computed for all stages at once"""
+    return ConceptStageFn.apply(x, q, sent, wk, gnw, gnb, geom, ncon, scale, eps, a_pre, hoist, *head_params)
 
 
 def concept_gquery(q0, wq, gnw=None, gnb=None, eps=1e-5):

@@ -92,7 +92,7 @@ class _SamplerBase(nn.Module):
         (the heads' sentence products have usually been computed for all stages at once: _ConceptNetG._hoist)"""
         return ops.concept_stage(x, q, sent, self.key_gconv.weight, self.gn2.weight if self.normalize else None,
                                  self.gn2.bias if self.normalize else None, self.key_gconv.geom, self.cardinality, scale,
-                                 head_params, eps=self.gn2.eps if self.normalize else 1e-5, a_pre=self.__dict__.pop("_a_hoisted", None))
+                                 head_params, eps=self.gn2.eps if self.normalize else 1e-5, **self.__dict__.pop("_a_hoisted", {}))
 
     def _attend(self, x, q, scale):
         """x [B,H,W,128], q [B,16,4] f32 -> value-projected context [B,16,4]."""
@@ -291,9 +291,9 @@ class _ConceptNetG(_DFNetG):
         blocks = [m for m in self.modules() if isinstance(m, (InConceptBlock, OutConceptBlock))]
         if blocks and not ops.debug_switch("no_head_hoist"):
             stages = [(m.concept_sampler1, m.gamma1_gconv, m.beta1_gconv) for m in blocks] + [(m.concept_sampler2, m.gamma2_gconv, m.beta2_gconv) for m in blocks]
-            A = ops.head_sentence_products(sent, [(gm[0].weight, bm[0].weight) for _, gm, bm in stages])
+            A, hoist = ops.head_sentence_products(sent, [(gm[0].weight, bm[0].weight) for _, gm, bm in stages])
             for k, (s_, _, _) in enumerate(stages):
-                s_.__dict__["_a_hoisted"] = A[k]
+                s_.__dict__["_a_hoisted"] = dict(a_pre=A[k], hoist=(hoist, k))
         samplers = [s_ for m in blocks if isinstance(m, InConceptBlock) for s_ in (m.concept_sampler1, m.concept_sampler2)]
         if not samplers or len(samplers) > 32 or ops.debug_switch("no_query_hoist"):
             return
