@@ -160,7 +160,7 @@ const char* xmc_last_kernel(void);
 int xmc_set_fixed_order(int on);
 /* Accumulators the entry points below document as "zeroed here" -- xmc_groupnorm_fwd / _bwd `ws`, xmc_attn_pool_bwd_acc `dq`,
  * xmc_global_avgpool's f32 `y` on maps of >= 256 pixels,
- * xmc_word_pool_fwd `ctx` / _bwd `dkh` -- are cleared with a hipMemsetAsync of their own, one more launch per call
+ * xmc_word_pool_fwd `ctx` / _bwd `dkh`, xmc_concept_query_bwd_multi `dsent`, xmc_concept_outer_multi `dX` -- are cleared with a hipMemsetAsync of their own, one more launch per call
  * (~100 per iteration of an attention-modulation generator).  on = 1: the caller promises they arrive ALREADY ZERO (the Python host
  * carves them from an arena it clears once per iteration) and the library skips those memsets.  Returns the previous setting; process-wide,
  * off by default (ABI 11) */
@@ -494,7 +494,7 @@ int xmc_concept_query_bwd(const float* sent, const float* Wq, const float* gnw, 
                           float* dWq, float* dgnw, float* dgnb, float* scratch, int B, int E, float eps, void* stream);
 /* The sentence queries of ALL sampler stages of a generator at once (they depend on nothing but the sentence vector; S <= 32): Wq / gnw / gnb
  * are HOST arrays of S device pointers ([64][E], [64], [64]; gnw[s] = gnb[s] = NULL: no GroupNorm); q, qraw f32 [S][B][64].
- * Backward: dq [S][B][64] -> dsent [B][E] (written: summed over the stages), dWq f32 [S][64][E] (written), dgn f32 [S][2][64] = (d gnw, d gnb)
+ * Backward: dq [S][B][64] -> dsent [B][E] (summed over the stages with atomics: zeroed here, xmc_set_prezeroed), dWq f32 [S][64][E] (written), dgn f32 [S][2][64] = (d gnw, d gnb)
  * (accumulated: zeroed by the caller), scratch f32 [B][S*64].  One launch forward, two backward, instead of one / two per stage (ABI 11) */
 int xmc_concept_query_fwd_multi(const float* sent, const float* const* Wq, const float* const* gnw, const float* const* gnb, int S, float* q,
                                 float* qraw, int B, int E, float eps, void* stream);
@@ -519,7 +519,8 @@ int xmc_concept_head_bwd(const float* ctx, const float* sent, const float* hid, 
 int xmc_concept_head_bwd_pre(const float* ctx, const float* sent, const float* hid, const float* const* params, const float* dgamma,
                              const float* dbeta, float* dctx, float* dsent, float* const* grads, float* scratch, int B, int E, void* stream);
 /* D [B][nW*Rp] x X [B][C]:  dW[k][r][c] = sum_b D[b][k*Rp + r] * X[b][c] for c < C (written; row pitch ldw >= C, other columns untouched),
- * dX[b][c] = sum_{k,r} D[b][k*Rp + r] * W[k][r][c] (written).  W / dW: HOST arrays of nW <= 64 device pointers; Rp even (ABI 11) */
+ * dX[b][c] = sum_{k,r} D[b][k*Rp + r] * W[k][r][c] (accumulated with atomics: zeroed here, xmc_set_prezeroed).  W / dW: HOST arrays of
+ * nW <= 64 device pointers; Rp even (ABI 11) */
 int xmc_concept_outer_multi(const float* D, const float* X, const float* const* W, float* const* dW, int nW, int Rp, float* dX, int B, int C,
                             int ldw, void* stream);
 

@@ -71,6 +71,8 @@ constexpr int QMAX = 64;                // weights per batch product; sampler st
 struct OuterArgs {
     const float* D; const float* X; const float* W[QMAX]; float* dW[QMAX]; float* dX;
     int B, R, Rp, C, ldw, acc_dx;       // acc_dx: dX += instead of =
+    int kchunk;                         // 0: one workgroup per sample walks all R rows for dX;  > 0: one per (sample, kchunk weights), added
+                                        // atomically into a dX the caller zeroed (the all-stages launches: 6 144 rows per sample)
 };
 __global__ __launch_bounds__(256) void concept_outer_kernel(OuterArgs a) {
     const int blk = blockIdx.x;
@@ -85,6 +87,20 @@ __global__ __launch_bounds__(256) void concept_outer_kernel(OuterArgs a) {
             }
             a.dW[k][(size_t)rr * a.ldw + c] = s0;
             a.dW[k][(size_t)(rr + 1) * a.ldw + c] = s1;
+        }
+    } else if (a.kchunk > 0) {
+        const int nch = (a.R / a.Rp + a.kchunk - 1) / a.kchunk;
+        const int b = (blk - a.R / 2) / nch, k0 = ((blk - a.R / 2) % nch) * a.kchunk;
+        const int k1 = k0 + a.kchunk < a.R / a.Rp ? k0 + a.kchunk : a.R / a.Rp;
+        for (int c = threadIdx.x; c < a.C; c += 256) {
+            float s = 0.f;
+            for (int k = k0; k < k1; ++k) {
+                const float* w = a.W[k];
+                const float* dd = a.D + (size_t)b * a.R + k * a.Rp;
+#pragma unroll 8
+                for (int r = 0; r < a.Rp; ++r) s += dd[r] * w[(size_t)r * a.ldw + c];
+            }
+            atomicAdd(&a.dX[(size_t)b * a.C + c], s);
         }
     } else {
         const int b = blk - a.R / 2;
@@ -505,7 +521,7 @@ extern "C" int xmc_concept_query_bwd(const float* sent, const float* Wq, const f
     XMC_LAUNCH_CHECK();
     OuterArgs a;
     a.D = scratch; a.X = sent; a.W[0] = Wq; a.W[1] = nullptr; a.dW[0] = dWq; a.dW[1] = nullptr; a.dX = dsent;
-    a.B = B; a.R = 64; a.Rp = 64; a.C = E; a.ldw = E; a.acc_dx = 0;
+    a.B = B; a.R = 64; a.Rp = 64; a.C = E; a.ldw = E; a.acc_dx = 0; a.kchunk = 0;
     hipLaunchKernelGGL(concept_outer_kernel, dim3(a.R / 2 + B), dim3(256), 0, ST(stream), a);
     XMC_LAUNCH_CHECK();
     return 0;
@@ -537,8 +553,9 @@ extern "C" int xmc_concept_query_bwd_multi(const float* sent, const float* const
     OuterArgs a;
     for (int s = 0; s < QMAX; ++s) { a.W[s] = s < S ? Wq[s] : nullptr; a.dW[s] = s < S ? dWq + (size_t)s * 64 * E : nullptr; }
     a.D = scratch; a.X = sent; a.dX = dsent;
-    a.B = B; a.R = S * 64; a.Rp = 64; a.C = E; a.ldw = E; a.acc_dx = 0;
-    hipLaunchKernelGGL(concept_outer_kernel, dim3(a.R / 2 + B), dim3(256), 0, ST(stream), a);
+    a.B = B; a.R = S * 64; a.Rp = 64; a.C = E; a.ldw = E; a.acc_dx = 0; a.kchunk = 8;        // dsent: zeroed by the caller, added atomically
+    if (xmc_zero_acc(dsent, sizeof(float) * (size_t)B * E, ST(stream)) != hipSuccess) return XMC_EINVAL;
+    hipLaunchKernelGGL(concept_outer_kernel, dim3(a.R / 2 + B * ((S + 7) / 8)), dim3(256), 0, ST(stream), a);
     XMC_LAUNCH_CHECK();
     return 0;
 }
@@ -607,8 +624,9 @@ extern "C" int xmc_concept_outer_multi(const float* D, const float* X, const flo
     if (!D || !X || !W || !dW || !dX || nW < 1 || nW > QMAX || Rp < 2 || (Rp & 1) || B < 1 || C < 1 || ldw < C) return XMC_EINVAL;
     OuterArgs a;
     for (int k = 0; k < QMAX; ++k) { a.W[k] = k < nW ? W[k] : nullptr; a.dW[k] = k < nW ? dW[k] : nullptr; if (k < nW && (!W[k] || !dW[k])) return XMC_EINVAL; }
-    a.D = D; a.X = X; a.dX = dX; a.B = B; a.R = nW * Rp; a.Rp = Rp; a.C = C; a.ldw = ldw; a.acc_dx = 0;
-    hipLaunchKernelGGL(concept_outer_kernel, dim3(a.R / 2 + B), dim3(256), 0, ST(stream), a);
+    a.D = D; a.X = X; a.dX = dX; a.B = B; a.R = nW * Rp; a.Rp = Rp; a.C = C; a.ldw = ldw; a.acc_dx = 0; a.kchunk = 4;
+    if (xmc_zero_acc(dX, sizeof(float) * (size_t)B * C, ST(stream)) != hipSuccess) return XMC_EINVAL;
+    hipLaunchKernelGGL(concept_outer_kernel, dim3(a.R / 2 + B * ((nW + 3) / 4)), dim3(256), 0, ST(stream), a);
     XMC_LAUNCH_CHECK();
     return 0;
 }
@@ -629,7 +647,7 @@ static int head_bwd_go(const float* ctx, const float* sent, const float* hid, co
     XMC_LAUNCH_CHECK();
     OuterArgs a;
     a.D = scratch; a.X = sent; a.W[0] = P.W1[0]; a.W[1] = P.W1[1]; a.dW[0] = G.W1[0]; a.dW[1] = G.W1[1]; a.dX = dsent;
-    a.B = B; a.R = 2 * HID; a.Rp = HID; a.C = E; a.ldw = E + SD; a.acc_dx = 0;
+    a.B = B; a.R = 2 * HID; a.Rp = HID; a.C = E; a.ldw = E + SD; a.acc_dx = 0; a.kchunk = 0;
     if (!defer) {
         hipLaunchKernelGGL(concept_outer_kernel, dim3(a.R / 2 + B), dim3(256), 0, ST(stream), a);
         XMC_LAUNCH_CHECK();

@@ -2612,7 +2612,7 @@ class ConceptQueryAllFn(torch.autograd.Function):
         gws = [gl.pop(0) if h else None for h in ctx.has_gn]
         B, E = sent.shape
         dq = torch.stack([torch.zeros(B, 64, dtype=torch.float32, device=sent.device) if d is None else d.reshape(B, 64).float() for d in dqs])
-        dsent = torch.empty_like(sent)
+        dsent = _zeros_f32_out(tuple(sent.shape), sent.device)          # accumulated with atomics (arrives zero: xmc_set_prezeroed)
         flat = _zeros_f32_out(S * 64 * E + S * 128, sent.device)
         dw, dgn = flat[:S * 64 * E].view(S, 64, E), flat[S * 64 * E:].view(S, 2, 64)
         scratch = torch.empty(B, S * 64, dtype=torch.float32, device=sent.device)
@@ -2732,7 +2732,7 @@ class HeadSentProductsFn(torch.autograd.Function):
                        for g in dA], dim=1).contiguous()
         dw1 = ctx.hoist.grads()
         ctx.hoist.dw1 = None                      # the next backward starts from a fresh zero buffer
-        dsent = torch.empty_like(sent)
+        dsent = _zeros_f32_out(tuple(sent.shape), sent.device)          # accumulated with atomics (arrives zero: xmc_set_prezeroed)
         mk = lambda ptrs: (C.c_void_p * len(ptrs))(*ptrs)
         L.call("xmc_concept_outer_multi", _p(D), _p(sent), mk([w.data_ptr() for w in ws]),
                mk([dw1[k // 2, k % 2].data_ptr() for k in range(2 * S)]), 2 * S, 128, _p(dsent), B, E, E + 4, _st())
