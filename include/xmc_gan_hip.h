@@ -40,7 +40,8 @@ extern "C" {
  * 11: xmc_set_prezeroed (the caller hands over zero-filled accumulators; the library skips its own memsets);
  *     xmc_word_pool_fwd / _bwd (word-region attention of the repaired concept_gan.InNetG);
  *     XmcConvDesc.splitk_ws / splitk_ws_bytes, xmc_conv_splitk_ws_bytes (split-K for the layers on 4x4 / 8x8 maps);
- *     xmc_concept_query_fwd_multi / _bwd_multi (every sampler stage's sentence query in one launch). */
+ *     xmc_concept_query_fwd_multi / _bwd_multi (every sampler stage's sentence query in one launch);
+ *     xmc_concept_head_fwd_pre / _bwd_pre, xmc_concept_outer_multi (the heads' sentence products of all stages as one GEMM / one batch product). */
 #define XMC_ABI_VERSION 11
 
 /* XMC_BF16 names the 16-bit storage / MFMA-operand format THIS BUILD of the library was compiled for: bf16 in
