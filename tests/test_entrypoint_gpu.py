@@ -61,12 +61,14 @@ def test_synthetic_run_uses_the_hip_rnn_encoder(tmp_path):
     _finite(last)
 
 
-@pytest.mark.parametrize("gen", ["CONCEPT_OUTATTN_GEN", "CONCEPT_INATTN_GEN"])
+@pytest.mark.parametrize("gen", ["CONCEPT_OUTATTN_GEN", "CONCEPT_INATTN_GEN", "CONCEPT_IN_DF_GEN", "CONCEPT_OUT_DF_GEN"])
 @pytest.mark.parametrize("precision", ["bf16", "f16"])
 def test_word_attention_generators_from_the_entry_point(tmp_path, gen, precision):
     """The word-attention generators consume what the reference's loop hands every generator -- the RNN_ENCODER's per-word embeddings
     and padding mask (train_gan.py:160-170, 197) -- selected by GEN.ENCODER_NAME like any other (the names upstream left commented out,
-    train_gan.py:31,44; InNetG is the documented repair): captions of different lengths, 64 px, both 16-bit modes, two iterations."""
+    train_gan.py:31,44; InNetG is the documented repair): captions of different lengths, 64 px, both 16-bit modes, two iterations.  The two
+    attention-modulation generators ride along: their hoisted sentence products (one launch for all stages) under the real loop, graph capture
+    and the half mode's loss scale."""
     import xmc_gan.train_gan as tg
     yml = _mini_yml(tmp_path, **{"ENCODER_NAME: DF_GEN": f"ENCODER_NAME: {gen}"})
     last = tg.main(["--cfg", yml, "--synthetic", "2", "--max_epoch", "1", "--precision", precision, "--output_dir", str(tmp_path / "run")])
