@@ -62,25 +62,39 @@ class quant:
     """context manager / switch: `with X.quant(True): ...`.  ``skip``: site tags (prefix match, e.g. "d." or "g.w") that keep
     f32 storage; ``grad=False``: forward values are rounded, gradients pass through unrounded."""
 
-    def __init__(self, on=True, skip=(), grad=True, fmt=torch.bfloat16, grad_scale=None):
-        """``grad_scale``: the factor the engine's backward passes run at in this format (ops.loss_scale(): 4096 for IEEE half, whose
+    def __init__(self, on=True, skip=(), grad=True, fmt=torch.bfloat16, grad_scale=None, only=None):
+        """``only`` (round 5, the per-layer ladder): round NOTHING but these sites; an entry "site@layer" (e.g. "d.w@b3.s", "d.sum@b2")
+        names one layer of a discriminator site -- `skip` takes such entries too (that layer alone keeps f32).
+        ``grad_scale``: the factor the engine's backward passes run at in this format (ops.loss_scale(): 4096 for IEEE half, whose
         5 exponent bits would otherwise put 1/B-sized gradients among the denormals; 1 for bf16) -- a gradient tensor is rounded as
         round(g * scale) / scale, which is what the engine stores and later divides out."""
         self.on, self.skip, self.grad, self.fmt = bool(on), tuple(skip), bool(grad), fmt
+        self.only = None if only is None else tuple(only)
         self.gscale = float(grad_scale) if grad_scale is not None else (4096.0 if fmt == torch.float16 else 1.0)
 
     def __enter__(self):
-        global _QUANT, _QSKIP, _QGRAD, _QFMT, _QGSCALE
-        self.prev = (_QUANT, _QSKIP, _QGRAD, _QFMT, _QGSCALE)
+        global _QUANT, _QSKIP, _QGRAD, _QFMT, _QGSCALE, _QLAYER
+        self.prev = (_QUANT, _QSKIP, _QGRAD, _QFMT, _QGSCALE, _QLAYER)
         _QUANT, _QGRAD, _QFMT, _QGSCALE = self.on, self.grad, self.fmt, self.gscale
-        _QSKIP = frozenset(t for t in QUANT_SITES if any(t.startswith(p_) for p_ in self.skip))
+        whole = tuple(p_ for p_ in self.skip if "@" not in p_)
+        _QSKIP = frozenset(t for t in QUANT_SITES if any(t.startswith(p_) for p_ in whole))
+        _QLAYER = {p_: False for p_ in self.skip if "@" in p_}                 # "site@layer" -> rounded?
+        if self.only is not None:
+            whole = tuple(p_ for p_ in self.only if "@" not in p_)
+            per_layer = {p_.split("@")[0] for p_ in self.only if "@" in p_}
+            # ("d.conv_img" / "d.last" in _QSKIP also switch the composed stem off / split the last block sum off: not meant here)
+            _QSKIP = frozenset(t for t in QUANT_SITES if not any(t.startswith(p_) for p_ in whole) and t not in per_layer
+                               and t not in ("d.conv_img", "d.last"))
+            _QLAYER = {p_: True for p_ in self.only if "@" in p_}
+            _QLAYER.update({t + "@*": False for t in per_layer})                 # the site's other layers: f32
         return self
 
     def __exit__(self, *a):
-        global _QUANT, _QSKIP, _QGRAD, _QFMT, _QGSCALE
-        _QUANT, _QSKIP, _QGRAD, _QFMT, _QGSCALE = self.prev
+        global _QUANT, _QSKIP, _QGRAD, _QFMT, _QGSCALE, _QLAYER
+        _QUANT, _QSKIP, _QGRAD, _QFMT, _QGSCALE, _QLAYER = self.prev
 
 
+_QLAYER = {}               # per-layer overrides of the ladder: "site@layer" -> rounded?  ("site@*": the site's default)
 _QFMT = torch.bfloat16     # the 16-bit storage format the mode rounds to (torch.float16: the what-if rung of the ladder)
 _QGSCALE = 1.0             # loss scale of the backward passes (see quant.__init__)
 
@@ -139,12 +153,20 @@ class _QBranchTimesGamma(torch.autograd.Function):
         return gamma * sg, (g * r).sum().reshape(gamma.shape)
 
 
-def q(x, site=None):
-    return _QAct.apply(x) if (_QUANT and site not in _QSKIP) else x
+def _rounded(site, layer):
+    if not _QUANT or site in _QSKIP:
+        return False
+    if _QLAYER and layer is not None:
+        return _QLAYER.get(f"{site}@{layer}", _QLAYER.get(site + "@*", True))
+    return _QLAYER.get(site + "@*", True) if _QLAYER else True
 
 
-def qw(w, site=None):
-    return _QWeight.apply(w) if (_QUANT and site not in _QSKIP) else w
+def q(x, site=None, layer=None):
+    return _QAct.apply(x) if _rounded(site, layer) else x
+
+
+def qw(w, site=None, layer=None):
+    return _QWeight.apply(w) if _rounded(site, layer) else w
 
 
 # ----------------------------------------------------------------------------------------
@@ -1016,29 +1038,29 @@ def _netd_forward_q(P, h: Hyper, x, a, second_order=False):
         wa, ba, wb, bb = _dstem_compose_q(P)
         ci = F.conv2d(xq, P["conv_img.weight"], P["conv_img.bias"], 1, 1)                       # f32, never stored: border pixels only
         r_exact = F.conv2d(ci, P["downblocks.0.conv_r.0.weight"], None, 2, 1)
-        r_comp = F.conv2d(xq, qw(wa, "d.w"), ba, 2, 2)
+        r_comp = F.conv2d(xq, qw(wa, "d.w", "b0.r0"), ba, 2, 2)
         m = torch.zeros_like(r_comp[:1, :1])
         m[:, :, 1:-1, 1:-1] = 1.0
-        r0 = q(F.leaky_relu(m * r_comp + (1.0 - m) * r_exact, LRELU), "d.r0")
-        s0 = q(F.conv2d(xq, qw(wb, "d.w"), bb, 2, 1), "d.sc")
+        r0 = q(F.leaky_relu(m * r_comp + (1.0 - m) * r_exact, LRELU), "d.r0", "b0")
+        s0 = q(F.conv2d(xq, qw(wb, "d.w", "b0.s"), bb, 2, 1), "d.sc", "b0")
         out = None
     else:
-        out = q(F.conv2d(xq, qw(sn_weight(P, "conv_img.weight"), "d.w"), P["conv_img.bias"], 1, 1), "d.conv_img")
+        out = q(F.conv2d(xq, qw(sn_weight(P, "conv_img.weight"), "d.w", "img"), P["conv_img.bias"], 1, 1), "d.conv_img")
     for i in range(1, a["depth"]):
-        p = f"downblocks.{i - 1}"
+        p, L = f"downblocks.{i - 1}", f"b{i - 1}"              # L: the layer tag of the per-layer ladder ("d.w@b3.s", "d.sum@b3")
         if stem and i == 1:
             r, s = r0, s0
         else:
-            r = q(F.leaky_relu(F.conv2d(out, qw(sn_weight(P, f"{p}.conv_r.0.weight"), "d.w"), None, 2, 1), LRELU), "d.r0")
-            s = q(F.avg_pool2d(out, 2), "d.pool")
+            r = q(F.leaky_relu(F.conv2d(out, qw(sn_weight(P, f"{p}.conv_r.0.weight"), "d.w", L + ".r0"), None, 2, 1), LRELU), "d.r0", L)
+            s = q(F.avg_pool2d(out, 2), "d.pool", L)
             if a["cin"][i] != a["cout"][i]:
-                s = q(F.conv2d(s, qw(sn_weight(P, f"{p}.conv_s.weight"), "d.w"), P[f"{p}.conv_s.bias"]), "d.sc")
-        z = F.conv2d(r, qw(sn_weight(P, f"{p}.conv_r.2.weight"), "d.w"), None, 1, 1)
+                s = q(F.conv2d(s, qw(sn_weight(P, f"{p}.conv_s.weight"), "d.w", L + ".s"), P[f"{p}.conv_s.bias"]), "d.sc", L)
+        z = F.conv2d(r, qw(sn_weight(P, f"{p}.conv_r.2.weight"), "d.w", L + ".r2"), None, 1, 1)
         site = "d.last" if (i == a["depth"] - 1 and "d.last" in _QSKIP) else "d.sum"
-        if second_order or "d.r2" in _QSKIP:
-            out = q(s + P[f"{p}.gamma"] * q(F.leaky_relu(z, LRELU), "d.r2"), site)
+        if second_order or not _rounded("d.r2", L):
+            out = q(s + P[f"{p}.gamma"] * q(F.leaky_relu(z, LRELU), "d.r2", L), site, L)
         else:
-            out = q(s + _QBranchTimesGamma.apply(z, P[f"{p}.gamma"]), site)
+            out = q(s + _QBranchTimesGamma.apply(z, P[f"{p}.gamma"]), site, L)
     return out
 
 
@@ -1053,8 +1075,8 @@ def cond_dnet(P, h: Hyper, feat, sent_embs):
         sent_embs = F.linear(sent_embs, sn_weight(P, "COND_DNET.proj_match.weight"), P["COND_DNET.proj_match.bias"])
     c = q(sent_embs, "h.c").view(B, -1, 1, 1).repeat(1, 1, 4, 4)        # engine: the condition joins the bf16 feature map
     hc = torch.cat((feat, c), 1)
-    m = q(F.leaky_relu(F.conv2d(hc, qw(sn_weight(P, "COND_DNET.joint_conv.0.weight"), "h.w"), None, 1, 1), LRELU), "h.m")
-    m = F.conv2d(m, qw(sn_weight(P, "COND_DNET.joint_conv.2.weight"), "h.w"))         # the logit itself leaves the engine in f32
+    m = q(F.leaky_relu(F.conv2d(hc, qw(sn_weight(P, "COND_DNET.joint_conv.0.weight"), "h.w", "j0"), None, 1, 1), LRELU), "h.m")
+    m = F.conv2d(m, qw(sn_weight(P, "COND_DNET.joint_conv.2.weight"), "h.w", "j2"))         # the logit itself leaves the engine in f32
     return [m, out, sent_embs]
 
 
