@@ -18,6 +18,9 @@ carrying, besides the throughput:
                 with the 64x64 figure of rounds 1-3 beside it (`at_64px`)
   alt_precision the same workload timed (with its own `roofline`) and parity-checked in the IEEE-half mode: the same kernels
                 compiled for the 11-bit format, same MFMA rate, dynamic loss scale
+  entrypoint    the same workload through the PRODUCT's entry point -- `xmc_gan/train_gan.py --cfg ... --synthetic N` (a child
+                process): main() builds the models and the text encoder, train() feeds loader batches (host tensors, uploaded on a side
+                stream) to the hipGraph replay it builds by default; images/s as train() itself reports it, beside `value`
   step_ms       median / min / max of the timed steps (`value` and `ms_per_step` are the contract's total over the K steps)
   dist          backend / world size / RCCL version the collectives ran on (`--force_dp`: the data-parallel path with its
                 graph seams and RCCL calls exercised at world size 1)
@@ -77,6 +80,7 @@ def parse():
     ap.add_argument("--spec_norm", action="store_true", help="variant: DISC.SPEC_NORM=True (off in the headline cfg)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_roofline", action="store_true")
+    ap.add_argument("--no_entrypoint", action="store_true")
     a = ap.parse_args()
     w = WORKLOADS[a.workload]
     a.imsize = w["imsize"] if a.imsize is None else a.imsize
@@ -215,7 +219,7 @@ def alt_precision_leg(a):
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(a.steps), "--warmup", str(a.warmup),
            "--imsize", str(a.imsize), "--batch", str(a.batch), "--cfg", a.cfg, "--precision", "f16", "--no_cpu_baseline",
-           "--no_parity", "--no_alt_precision"]
+           "--no_parity", "--no_alt_precision", "--no_entrypoint"]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
@@ -230,6 +234,30 @@ def alt_precision_leg(a):
                                                    "traffic")} if roof else None,
                 note="same kernels compiled for IEEE half (libxmc_gan_hip_f16.so): f16 MFMA = the bf16 rate; dynamic loss scale "
                      "with a found-inf skip inside the Adam kernel (initial 4096)")
+
+
+def entrypoint_leg(a):
+    """`python xmc_gan/train_gan.py --cfg <cfg> --synthetic N --bs B --imsize S --max_epoch 1` in a child process; train()'s own
+    throughput report (from its fifth iteration to the end of the epoch, device-synchronised at both ends)."""
+    import subprocess
+    import tempfile
+    n = 5 + max(a.steps, 20)
+    with tempfile.TemporaryDirectory() as tmp:
+        code = ("import json, sys; sys.path.insert(0, %r); import xmc_gan.train_gan as tg; "
+                "last = tg.main(%r); print('ENTRYPOINT ' + json.dumps(last.get('throughput')))") % (
+            ROOT, ["--cfg", os.path.join(ROOT, "xmc_gan", "cfg", a.cfg), "--synthetic", str(n), "--bs", str(a.batch), "--imsize", str(a.imsize),
+                   "--max_epoch", "1", "--precision", a.precision, "--output_dir", os.path.join(tmp, "run")])
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+        r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("ENTRYPOINT ")]
+    if r.returncode != 0 or not line:
+        return dict(error=(r.stderr or r.stdout)[-400:])
+    thr = json.loads(line[-1][len("ENTRYPOINT "):]) or {}
+    return dict(command=f"python xmc_gan/train_gan.py --cfg xmc_gan/cfg/{a.cfg} --synthetic {n} --bs {a.batch} --imsize {a.imsize} --max_epoch 1 "
+                        f"--precision {a.precision}", images_per_s=thr.get("images_per_s"), ms_per_step=thr.get("ms_per_step"),
+                steps=thr.get("steps"), hipgraph=thr.get("hipgraph"),
+                note="loader batches are host tensors (pinned, uploaded on a side stream while the previous iteration runs); includes the "
+                     "text encoder's forward and the CPU-side noise draw of every iteration (train_gan.py:160-170,197)")
 
 
 def self_launch(n):
@@ -454,6 +482,10 @@ def main():
     if rank == 0 and world == 1 and not a.force_dp:
         if not a.no_alt_precision and a.precision == "bf16" and not a.gen and not a.spec_norm:
             out["alt_precision"] = alt_precision_leg(a)
+        if not a.no_entrypoint and not a.gen and not a.spec_norm:
+            out["entrypoint"] = entrypoint_leg(a)
+            if out["entrypoint"].get("images_per_s"):
+                out["entrypoint"]["frac_of_value"] = round(out["entrypoint"]["images_per_s"] / out["value"], 4)
         if not a.no_parity and not a.gen and not a.spec_norm:
             out["parity"] = parity_legs(a.precision, a.cfg, a.imsize)
             if "alt_precision" in out:

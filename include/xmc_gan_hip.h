@@ -41,8 +41,10 @@ extern "C" {
  *     xmc_word_pool_fwd / _bwd (word-region attention of the repaired concept_gan.InNetG);
  *     XmcConvDesc.splitk_ws / splitk_ws_bytes, xmc_conv_splitk_ws_bytes (split-K for the layers on 4x4 / 8x8 maps);
  *     xmc_concept_query_fwd_multi / _bwd_multi (every sampler stage's sentence query in one launch);
- *     xmc_concept_head_fwd_pre / _bwd_pre, xmc_concept_outer_multi (the heads' sentence products of all stages as one GEMM / one batch product). */
-#define XMC_ABI_VERSION 11
+ *     xmc_concept_head_fwd_pre / _bwd_pre, xmc_concept_outer_multi (the heads' sentence products of all stages as one GEMM / one batch product).
+ * 12: XmcConvDesc.wpk_lo, XmcPackJob.lo, xmc_conv_pw1x1_split (a learned shortcut's 1x1 convolution on weights held as a 16-bit
+ *     hi + lo pair: the precise trunk of the IEEE-half mode). */
+#define XMC_ABI_VERSION 12
 
 /* XMC_BF16 names the 16-bit storage / MFMA-operand format THIS BUILD of the library was compiled for: bf16 in
  * libxmc_gan_hip.so, IEEE half in libxmc_gan_hip_f16.so (same sources, same entry points; xmc_half_format()). */
@@ -148,6 +150,11 @@ typedef struct XmcConvDesc {
      *             xmc_conv_splitk_ws_bytes(d) says how much the descriptor wants (0: it would not split); NULL / too small = no split */
     void* splitk_ws;
     int64_t splitk_ws_bytes;
+    /* wpk_lo (ABI 12; honoured by xmc_conv_pw1x1_split ONLY -- every other entry rejects a descriptor that sets it): a second packed
+     *             weight tensor in wpk's layout holding round16(w - round16(w)), the part of the f32 parameter the 16-bit copy lost
+     *             (xmc_pack_weight_multi with XmcPackJob.lo).  The kernel issues two MFMAs per K step into one f32 accumulator:
+     *             weights at ~20 significant bits for twice the matrix work of a launch that is bound by its HBM stream. */
+    const void* wpk_lo;
 } XmcConvDesc;
 
 int xmc_abi_version(void);
@@ -204,6 +211,7 @@ typedef struct XmcPackJob {
     void* wpk;
     const int32_t* row_perm;
     int32_t Co, Ci, KHW, rows_pad, cols_pad, transpose, dtype, groups, upconv;
+    int32_t lo;             /* ABI 12: 1 = pack round16(w - round16(w)) (XmcConvDesc.wpk_lo) instead of round16(w); 16-bit dtype only */
 } XmcPackJob;
 int xmc_pack_weight_multi(const XmcPackJob* jobs /* host array */, int njobs, void* stream);
 /* Fused nearest-x2 upsample + 3x3 conv (F.interpolate(scale_factor=2) at df_gan.py:202 followed by the next block's c1, 187):
@@ -245,6 +253,10 @@ int xmc_signmask_apply(const void* dy, const void* bits, void* dx, int64_t n, fl
  * XmcConvDesc.sign_bits layout of the source tensor -- the backward of a block reads `dout` once for both.  Returns 1 (nothing
  * launched) when the shape is not one the streaming kernels take; the caller then uses xmc_conv_igemm + xmc_signmask_apply.  (ABI 5) */
 int xmc_conv_pw1x1_masked_src(const XmcConvDesc* d, const void* src_bits, void* src_masked, float slope, void* stream);
+/* The 1x1 convolution of `d` on the streaming kernels with its weights as the pair (d->wpk, d->wpk_lo) (XmcConvDesc.wpk_lo; the
+ * discriminator's learned shortcuts conv_s, df_gan.py:280,286-291, in the IEEE-half mode).  Returns 1 and launches nothing when the
+ * shape is not one of theirs (Cin 64 -> Cout 128 from registers, Cin 128 / 256 from LDS, >= 16 k pixels). */
+int xmc_conv_pw1x1_split(const XmcConvDesc* d, void* stream);
 /* The same masked operand WITHOUT writing it: the data gradient (weights-resident kernel, Cin / Cout <= 64, unit stride) and the 3x3
  * weight gradient (row-reuse kernel, W % 32 == 0, H % 8 == 0) apply d->mask_bits while they stage the gradient operand.  Return 1
  * when the shape is not theirs (the caller then runs xmc_signmask_apply and the plain entry), 0 on success, < 0 on error. */

@@ -62,20 +62,26 @@ class quant:
     """context manager / switch: `with X.quant(True): ...`.  ``skip``: site tags (prefix match, e.g. "d." or "g.w") that keep
     f32 storage; ``grad=False``: forward values are rounded, gradients pass through unrounded."""
 
-    def __init__(self, on=True, skip=(), grad=True, fmt=torch.bfloat16, grad_scale=None, only=None):
-        """``only`` (round 5, the per-layer ladder): round NOTHING but these sites; an entry "site@layer" (e.g. "d.w@b3.s", "d.sum@b2")
+    def __init__(self, on=True, skip=(), grad=True, fmt=torch.bfloat16, grad_scale=None, only=None, precise=None):
+        """``precise`` (round 5; default: on for IEEE half, off for bf16 -- the engine's defaults, ops.precise_trunk): the discriminator's
+        PRECISE TRUNK.  Outside the pass whose backward is differentiated again: the learned shortcuts' weights exact (a 16-bit hi + lo
+        pair or exact-f32 MFMA in the engine; the composed stem's shortcut stays rounded); on maps of <= 8x8 pixels the shortcut, the
+        block sum (its branch unrounded, f32 destination) and the pooled by-product stay f32 -- the next block's conv_r[0] reads the
+        rounded sum --; COND_DNET runs in f32 on the f32 map of the last block.  Gradients are rounded where they were.
+        ``only`` (round 5, the per-layer ladder): round NOTHING but these sites; an entry "site@layer" (e.g. "d.w@b3.s", "d.sum@b2")
         names one layer of a discriminator site -- `skip` takes such entries too (that layer alone keeps f32).
         ``grad_scale``: the factor the engine's backward passes run at in this format (ops.loss_scale(): 4096 for IEEE half, whose
         5 exponent bits would otherwise put 1/B-sized gradients among the denormals; 1 for bf16) -- a gradient tensor is rounded as
         round(g * scale) / scale, which is what the engine stores and later divides out."""
         self.on, self.skip, self.grad, self.fmt = bool(on), tuple(skip), bool(grad), fmt
         self.only = None if only is None else tuple(only)
+        self.precise = (fmt == torch.float16) if precise is None else bool(precise)
         self.gscale = float(grad_scale) if grad_scale is not None else (4096.0 if fmt == torch.float16 else 1.0)
 
     def __enter__(self):
-        global _QUANT, _QSKIP, _QGRAD, _QFMT, _QGSCALE, _QLAYER
-        self.prev = (_QUANT, _QSKIP, _QGRAD, _QFMT, _QGSCALE, _QLAYER)
-        _QUANT, _QGRAD, _QFMT, _QGSCALE = self.on, self.grad, self.fmt, self.gscale
+        global _QUANT, _QSKIP, _QGRAD, _QFMT, _QGSCALE, _QLAYER, _QPRECISE
+        self.prev = (_QUANT, _QSKIP, _QGRAD, _QFMT, _QGSCALE, _QLAYER, _QPRECISE)
+        _QUANT, _QGRAD, _QFMT, _QGSCALE, _QPRECISE = self.on, self.grad, self.fmt, self.gscale, self.precise and self.on
         whole = tuple(p_ for p_ in self.skip if "@" not in p_)
         _QSKIP = frozenset(t for t in QUANT_SITES if any(t.startswith(p_) for p_ in whole))
         _QLAYER = {p_: False for p_ in self.skip if "@" in p_}                 # "site@layer" -> rounded?
@@ -90,10 +96,11 @@ class quant:
         return self
 
     def __exit__(self, *a):
-        global _QUANT, _QSKIP, _QGRAD, _QFMT, _QGSCALE, _QLAYER
-        _QUANT, _QSKIP, _QGRAD, _QFMT, _QGSCALE, _QLAYER = self.prev
+        global _QUANT, _QSKIP, _QGRAD, _QFMT, _QGSCALE, _QLAYER, _QPRECISE
+        _QUANT, _QSKIP, _QGRAD, _QFMT, _QGSCALE, _QLAYER, _QPRECISE = self.prev
 
 
+_QPRECISE = False          # the discriminator's precise trunk (quant.__init__)
 _QLAYER = {}               # per-layer overrides of the ladder: "site@layer" -> rounded?  ("site@*": the site's default)
 _QFMT = torch.bfloat16     # the 16-bit storage format the mode rounds to (torch.float16: the what-if rung of the ladder)
 _QGSCALE = 1.0             # loss scale of the backward passes (see quant.__init__)
@@ -120,6 +127,18 @@ class _QAct(torch.autograd.Function):
         return _bf16g(g) if _QGRAD else g
 
 
+class _QGradOnly(torch.autograd.Function):
+    """a tensor the engine keeps in f32 whose GRADIENT it stores in the 16-bit format (the precise trunk: forward exact)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _bf16g(g) if _QGRAD else g
+
+
 class _QWeight(torch.autograd.Function):
     """a packed convolution weight: rounded for the forward / data-gradient kernels, f32 weight gradient passed through"""
 
@@ -139,8 +158,10 @@ class _QBranchTimesGamma(torch.autograd.Function):
     follows -- so the gradient handed to the convolution is gamma * round(s * dout), not round(gamma * dout) * s."""
 
     @staticmethod
-    def forward(ctx, z, gamma):
-        r = _bf16(F.leaky_relu(z, LRELU))
+    def forward(ctx, z, gamma, round_fwd=True):
+        r = F.leaky_relu(z, LRELU)
+        if round_fwd:                  # (False: the precise trunk's f32 block sum takes the branch from the accumulators)
+            r = _bf16(r)
         ctx.save_for_backward(z, gamma, r)
         return gamma * r
 
@@ -150,7 +171,7 @@ class _QBranchTimesGamma(torch.autograd.Function):
         sg = torch.where(z > 0, g, LRELU * g)
         if _QGRAD:
             sg = _bf16g(sg)
-        return gamma * sg, (g * r).sum().reshape(gamma.shape)
+        return gamma * sg, (g * r).sum().reshape(gamma.shape), None
 
 
 def _rounded(site, layer):
@@ -161,8 +182,10 @@ def _rounded(site, layer):
     return _QLAYER.get(site + "@*", True) if _QLAYER else True
 
 
-def q(x, site=None, layer=None):
-    return _QAct.apply(x) if _rounded(site, layer) else x
+def q(x, site=None, layer=None, grad_only=False):
+    if not _rounded(site, layer):
+        return x
+    return _QGradOnly.apply(x) if grad_only else _QAct.apply(x)
 
 
 def qw(w, site=None, layer=None):
@@ -1046,25 +1069,36 @@ def _netd_forward_q(P, h: Hyper, x, a, second_order=False):
         out = None
     else:
         out = q(F.conv2d(xq, qw(sn_weight(P, "conv_img.weight"), "d.w", "img"), P["conv_img.bias"], 1, 1), "d.conv_img")
+    precise = _QPRECISE and not second_order
+    trunk = None                       # precise trunk: the previous block's f32 sum (its pooled by-product is not rounded)
     for i in range(1, a["depth"]):
         p, L = f"downblocks.{i - 1}", f"b{i - 1}"              # L: the layer tag of the per-layer ladder ("d.w@b3.s", "d.sum@b3")
+        last = i == a["depth"] - 1
         if stem and i == 1:
             r, s = r0, s0
+            small = False
         else:
+            small = precise and out.shape[2] // 2 <= 8         # the block's maps: <= 8x8 pixels
             r = q(F.leaky_relu(F.conv2d(out, qw(sn_weight(P, f"{p}.conv_r.0.weight"), "d.w", L + ".r0"), None, 2, 1), LRELU), "d.r0", L)
-            s = q(F.avg_pool2d(out, 2), "d.pool", L)
+            s = q(F.avg_pool2d(out, 2), "d.pool", L) if trunk is None else q(F.avg_pool2d(trunk, 2), "d.pool", L, grad_only=True)
             if a["cin"][i] != a["cout"][i]:
-                s = q(F.conv2d(s, qw(sn_weight(P, f"{p}.conv_s.weight"), "d.w", L + ".s"), P[f"{p}.conv_s.bias"]), "d.sc", L)
+                ws = sn_weight(P, f"{p}.conv_s.weight")
+                s = q(F.conv2d(s, ws if precise else qw(ws, "d.w", L + ".s"), P[f"{p}.conv_s.bias"]), "d.sc", L, grad_only=small)
         z = F.conv2d(r, qw(sn_weight(P, f"{p}.conv_r.2.weight"), "d.w", L + ".r2"), None, 1, 1)
-        site = "d.last" if (i == a["depth"] - 1 and "d.last" in _QSKIP) else "d.sum"
+        site = "d.last" if (last and "d.last" in _QSKIP) else "d.sum"
         if second_order or not _rounded("d.r2", L):
             out = q(s + P[f"{p}.gamma"] * q(F.leaky_relu(z, LRELU), "d.r2", L), site, L)
+            trunk = None
+        elif small:
+            trunk = q(s + _QBranchTimesGamma.apply(z, P[f"{p}.gamma"], False), site, L, grad_only=True)
+            out = trunk if last else _bf16(trunk.detach()) + (trunk - trunk.detach())      # conv_r[0] of the next block reads the rounded sum
         else:
             out = q(s + _QBranchTimesGamma.apply(z, P[f"{p}.gamma"]), site, L)
+            trunk = None
     return out
 
 
-def cond_dnet(P, h: Hyper, feat, sent_embs):
+def cond_dnet(P, h: Hyper, feat, sent_embs, second_order=False):
     """D_GET_LOGITS.forward (df_gan.py:162-176) -> [logit[B,1,1,1], img_emb, txt_emb]."""
     B = feat.size(0)
     out = F.avg_pool2d(feat, 4).view(B, -1)
@@ -1073,6 +1107,10 @@ def cond_dnet(P, h: Hyper, feat, sent_embs):
         out = F.linear(out, sn_weight(P, "COND_DNET.proj_match.weight"), P["COND_DNET.proj_match.bias"])
     elif has_proj:
         sent_embs = F.linear(sent_embs, sn_weight(P, "COND_DNET.proj_match.weight"), P["COND_DNET.proj_match.bias"])
+    if _QPRECISE and not second_order:      # precise trunk: the last block handed over an f32 map and COND_DNET runs in f32 (not in the MA-GP pass)
+        c = sent_embs.view(B, -1, 1, 1).repeat(1, 1, 4, 4)
+        m = F.leaky_relu(F.conv2d(torch.cat((feat, c), 1), sn_weight(P, "COND_DNET.joint_conv.0.weight"), None, 1, 1), LRELU)
+        return [F.conv2d(m, sn_weight(P, "COND_DNET.joint_conv.2.weight")), out, sent_embs]
     c = q(sent_embs, "h.c").view(B, -1, 1, 1).repeat(1, 1, 4, 4)        # engine: the condition joins the bf16 feature map
     hc = torch.cat((feat, c), 1)
     m = q(F.leaky_relu(F.conv2d(hc, qw(sn_weight(P, "COND_DNET.joint_conv.0.weight"), "h.w", "j0"), None, 1, 1), LRELU), "h.m")
@@ -1293,7 +1331,7 @@ def train_step(PG, PD, optG: AdamState, optD: AdamState, h: Hyper, batch, it_cou
         D = _leaves(PD)
         xi = imgs.detach().clone().requires_grad_()
         si = psent.detach().clone().requires_grad_()
-        o = cond_dnet(D, h, netd_forward(D, h, xi, second_order=True), si)
+        o = cond_dnet(D, h, netd_forward(D, h, xi, second_order=True), si, second_order=True)
         g0, g1 = torch.autograd.grad(o[0], (xi, si), torch.ones_like(o[0]), create_graph=True)
         gcat = torch.cat((g0.reshape(B, -1), g1.reshape(B, -1)), dim=1)
         gp = (gcat.pow(2).sum(1).sqrt() ** 6).mean()

@@ -1,4 +1,4 @@
-run() { python bench.py --steps 10 --warmup 3 --no_cpu_baseline --no_roofline --no_parity --no_alt_precision "$@" 2>/dev/null | python -c "import sys,json; j=json.loads(sys.stdin.read()); print('$*', '|', j['value'], 'img/s', j['ms_per_step'], 'ms', j.get('step_algorithmic_tflops'))"; }
+run() { python bench.py --steps 10 --warmup 3 --no_cpu_baseline --no_roofline --no_parity --no_alt_precision --no_entrypoint "$@" 2>/dev/null | python -c "import sys,json; j=json.loads(sys.stdin.read()); print('$*', '|', j['value'], 'img/s', j['ms_per_step'], 'ms', j.get('step_algorithmic_tflops'))"; }
 run
 run --cfg df_gan_damsm.yml
 run --spec_norm

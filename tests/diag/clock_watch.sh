@@ -1,7 +1,7 @@
 #!/bin/bash
 # samples the card's clock / power while the headline step runs: tests/diag/clock_watch.sh  (writes gpurun_out/clock/)
 mkdir -p gpurun_out/clock
-python bench.py --steps 500 --warmup 5 --no_parity --no_alt_precision --no_cpu_baseline --no_roofline > gpurun_out/clock/bench.log 2>&1 &
+python bench.py --steps 500 --warmup 5 --no_parity --no_alt_precision --no_entrypoint --no_cpu_baseline --no_roofline > gpurun_out/clock/bench.log 2>&1 &
 bp=$!
 sleep 6
 for i in $(seq 1 80); do

@@ -1,4 +1,8 @@
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" && O=gpurun_out/r04prof/pmc_dstem && mkdir -p $O
+set -e
+cd /tmp && export TMPDIR=/tmp
+cd "${GRAFT_REPO_ROOT:?}"
+O=gpurun_out/r04prof/pmc_dstem
+mkdir -p "$O"
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS --kernel-trace -f csv -d $O/a -- python tests/diag/dstem_time.py > /dev/null 2> $O/err.txt
 python - <<'PY'
 import csv,glob,collections

@@ -46,7 +46,7 @@ def main():
     learned = [f"b{i}" for i in range(depth) if X.disc_arch(h.img_size, h.nch)["cin"][i + 1] != X.disc_arch(h.img_size, h.nch)["cout"][i + 1]]
     trunk_w = [f"d.w@{b}.s" for b in learned] + ["h.w"]
     trunk_a = ["d.img", "d.pool", "d.sc", "d.sum", "h.c"]
-    rungs = [("ALL sites rounded (the mode as it is)", dict(skip=())),
+    rungs = [("ALL sites rounded (the f16 mode of rounds 3-4)", dict(skip=())),
              ("all WEIGHTS rounded, activations f32", dict(only=("d.w", "h.w"))),
              ("all ACTIVATIONS rounded, weights f32", dict(skip=("d.w", "h.w", "g.w"))),
              ("trunk only rounded (image, pool, conv_s, block sums, conv_s weights, head)", dict(only=tuple(trunk_w + trunk_a + ["h.m"]))),
@@ -63,6 +63,7 @@ def main():
         plan += [f"d.sc@b{i}", f"d.sum@b{i}"] + ([f"d.pool@b{i + 1}"] if i + 1 < depth else [])
     rungs.append(("PLAN: f32 head, hi+lo conv_s weights (b1..), f32 trunk on maps <= 8x8", dict(skip=tuple(plan))))
     rungs.append(("PLAN + b0's composed shortcut weights exact", dict(skip=tuple(plan + ["d.w@b0.s"]))))
+    rungs.append(("BUILT: the rounding oracle's precise-trunk mode (= the engine's f16 mode since round 5)", dict(precise=True)))
     rungs += [(f"only image rounded", dict(only=("d.img",)))]
     for b in blocks:
         for site, tag in (("d.w", f"{b}.r0"), ("d.w", f"{b}.r2"), ("d.w", f"{b}.s"), ("d.r0", b), ("d.r2", b), ("d.pool", b), ("d.sc", b), ("d.sum", b)):
@@ -87,7 +88,7 @@ def main():
             ps = F_proj(PG, h, b["sent_embs"])
             ref = [X.cond_dnet(PD, h, X.netd_forward(PD, h, im), ps)[0].flatten() for im in (b["imgs"], fake)]
             for name, kw in rungs:
-                with X.quant(True, fmt=fmt, **kw):
+                with X.quant(True, fmt=fmt, **{"precise": False, **kw}):
                     o = [X.cond_dnet(PD, h, X.netd_forward(PD, h, im), ps)[0].flatten() for im in (b["imgs"], fake)]
                 res[name].append(tuple(float((x - y).norm() / y.norm()) for x, y in zip(o, ref)))
         print(f"# seed {s} done", file=sys.stderr, flush=True)

@@ -62,9 +62,9 @@ def one_step(h, PG, PD, batch, skip=None):
     if skip is None:
         return X.train_step(PG, PD, oG, oD, h, batch)
     if skip == "f16":
-        with X.quant(True, fmt=torch.float16):
+        with X.quant(True, fmt=torch.float16, precise=False):
             return X.train_step(PG, PD, oG, oD, h, batch)
-    with X.quant(True, skip=skip, fmt=FMT):
+    with X.quant(True, skip=skip, fmt=FMT, precise=False):      # (the rungs describe the modes WITHOUT the precise trunk of round 5)
         return X.train_step(PG, PD, oG, oD, h, batch)
 
 

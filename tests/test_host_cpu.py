@@ -29,13 +29,13 @@ def test_library_loads_and_exports_every_declared_symbol(variant):
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/xmc_gan_hip.h but not exported"
     assert set(L.EXPORTS) == declared
-    assert lib.xmc_abi_version() == L.ABI_VERSION == 11
+    assert lib.xmc_abi_version() == L.ABI_VERSION == 12
     assert lib.xmc_adam_step_scaled(None, 1, None, 1, 0.0, 0.0, 0.0, 0.0, None, None, 7, 2.0, 0.5, 1, None) == -1
     # argument validation happens before any launch, so it is safe without a GPU
     d = L.ConvDesc()
     assert lib.xmc_conv_igemm(ctypes.byref(d), None) == -1
     assert lib.xmc_conv_wgrad(ctypes.byref(d), None, None) == -1
-    assert ctypes.sizeof(L.ConvDesc) == 432 and ctypes.sizeof(L.AdamEntry) == 48 and ctypes.sizeof(L.PackJob) == 64   # = the C structs
+    assert ctypes.sizeof(L.ConvDesc) == 440 and ctypes.sizeof(L.AdamEntry) == 48 and ctypes.sizeof(L.PackJob) == 64   # = the C structs
     # the entry points added for the callers either side of the step reject bad arguments the same way (nothing launched)
     import numpy as np
     assert np.dtype(L.GEMM_PROBLEM).itemsize == 88                    # sizeof(XmcGemmProblem)
@@ -49,6 +49,7 @@ def test_library_loads_and_exports_every_declared_symbol(variant):
     assert lib.xmc_gru_bidir(one, one, one, one, one, one, 4, 20, 64, None) == -1
     assert lib.xmc_signmask_apply(one, None, one, 64, 0.2, 0, None) == -1 and lib.xmc_signmask_apply(one, one, one, 12, 0.2, 0, None) == -2
     assert lib.xmc_conv_pw1x1_masked_src(ctypes.byref(L.ConvDesc()), one, one, 0.2, None) == -1      # null tensors in the descriptor
+    assert lib.xmc_conv_pw1x1_split(ctypes.byref(L.ConvDesc()), None) == -1
     assert lib.xmc_spectral_sigma(None, one, one, one, one, None, 8, 8, 1, 1e-12, None) == -1
     assert lib.xmc_spectral_bwd(one, one, one, one, one, one, None, 8, 8, None) == -1
     assert lib.xmc_affine2_act_fwd(one, one, one, None, None, one, 1, 16, 12, 0.0, 0, None) == -2   # channels % 8

@@ -681,6 +681,40 @@ def test_shortcut_data_gradient_writes_the_masked_gradient_as_a_by_product(N, H,
     assert torch.equal(dx, dx_ref)
 
 
+@pytest.mark.parametrize("mode", ["f16", "bf16"])
+@pytest.mark.parametrize("N,H,cin,cout,kernel", [(16, 32, 64, 128, "pw1x1_kernel<2, 8, false, true>"), (16, 32, 128, 256, "pw1x1w_kernel<4, false, true>"),
+                                                 (64, 16, 256, 512, "pw1x1w_kernel<8, false, true>"), (8, 16, 64, 128, "igemm"), (4, 32, 8, 16, "igemm")])
+def test_learned_shortcut_on_a_weight_pair(N, H, cin, cout, kernel, mode):
+    """xmc_conv_pw1x1_split (ABI 12, XmcConvDesc.wpk_lo): conv_s with its f32 weights as the 16-bit pair round16(w) + round16(w - round16(w)).
+    A weight's rounding error is the SAME for every pixel, so it survives a mean over pixels, where the rounding of the stored
+    16-bit outputs averages out: per output channel, |mean over pixels of (y - y_exact)| / rms(y_exact) is ~2^-9 (bf16) / 2^-12
+    (f16) x |mean x| / rms x with plain weights and at the noise floor of the output rounding with the pair.  Shapes: the three
+    streaming instantiations, and two the streaming kernels decline (few pixels / narrow layers: exact-f32 MFMA on the widened
+    input).  The half build must not flush the pair's low half (subnormal for |w| < 0.12): the f16 bar would fail by 30x."""
+    ops.set_precision(mode)
+    dt = ops.act_dtype()
+    g = torch.Generator().manual_seed(N + cin)
+    x = (torch.randn(N, H, H, cin, generator=g).abs() + 0.25).to(dt)           # a non-zero mean per channel
+    w = (torch.randn(cout, cin, 1, 1, generator=g) * math.sqrt(2.0 / cin))
+    b = torch.randn(cout, generator=g) * 0.1
+    gs = ops.ConvGeom(cin, cout, 1, 1, 0)
+    wd, bd = torch.nn.Parameter(w.to(DEV)), b.to(DEV)
+    y = ops._conv1x1_pair_raw(x.to(DEV), wd, bd, gs, dt)
+    kn = L.load().xmc_last_kernel().decode()
+    y_plain = ops._conv_fwd_raw(x.to(DEV), wd, bd, gs, L.ACT_NONE, dt)
+    ref = (x.double().reshape(-1, cin) @ w.double().reshape(cout, cin).t() + b.double())
+    rms = ref.pow(2).mean(0).sqrt()
+    bias_of = lambda t: ((t.double().cpu().reshape(-1, cout) - ref).mean(0).abs() / rms).max().item()
+    e_pair, e_plain = bias_of(y), bias_of(y_plain)
+    ulp = 2.0 ** -12 if mode == "f16" else 2.0 ** -9
+    floor = ulp / math.sqrt(N * H * H) * 4
+    print(f"\n[{mode} {cin}->{cout} N{N} {H}x{H}] {kn}: coherent error pair {e_pair:.2e}, plain weights {e_plain:.2e} (noise floor ~{floor:.1e})")
+    assert kernel in kn, kn
+    assert e_pair <= max(3 * floor, ulp / 30), (e_pair, e_plain)
+    assert rel_l2(y.float().cpu(), ref.float().reshape(y.shape)) <= 1.2 * ulp        # element-wise: the rounding of the stored output
+    ops.set_precision("bf16")
+
+
 @pytest.mark.parametrize("mode", ["bf16", "f16"])
 @pytest.mark.parametrize("N,H,W,cin,cout,fused", [(3, 32, 64, 64, 64, True), (2, 128, 128, 64, 64, True), (5, 16, 32, 32, 64, True),
                                                   (2, 16, 16, 128, 128, False), (2, 24, 24, 64, 64, False)])

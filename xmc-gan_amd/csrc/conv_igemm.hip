@@ -482,6 +482,7 @@ extern "C" int xmc_conv_igemm(const XmcConvDesc* d, void* stream) {
     if (d->dot && !d->mask) return XMC_EINVAL;                  // the dot is <value before alpha, mask tensor>
     if (d->mask_bits) return XMC_EINVAL;                        // only xmc_conv_ptile_bits / xmc_conv_wgrad_bits apply it
     if (d->sc_img) return XMC_EINVAL;                           // only xmc_conv_ptile_scimg recomputes the residual
+    if (d->wpk_lo) return XMC_EINVAL;                           // only xmc_conv_pw1x1_split multiplies a weight pair
     if (d->res_mode < 0 || d->res_mode > 2 || (d->res_mode == 2 && (d->DA != 1 || (d->DH & 1) || (d->DW & 1)))) return XMC_ESHAPE;
     static const bool no_tile = xmc_debug_off("no_tile");
     static const bool no_wt2 = xmc_debug_off("no_wtile_v2");

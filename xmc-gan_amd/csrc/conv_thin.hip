@@ -190,7 +190,9 @@ __device__ __forceinline__ u32x4 mask_unit(u32x4 v, unsigned bits, float slope) 
     return __builtin_bit_cast(u32x4, h);
 }
 
-template <int KS, int TN, bool MASKED = false>                     // KS = Cin / 32 K-steps, TN = Cout(padded) / 16 row blocks
+// SPLIT (round 5, XmcConvDesc.wpk_lo): the weights are the pair hi + lo = round16(w) + round16(w - round16(w)); a second register
+// set and a second MFMA per K step into the same accumulator (the launch is bound by its HBM stream, not by its matrix work).
+template <int KS, int TN, bool MASKED = false, bool SPLIT = false>   // KS = Cin / 32 K-steps, TN = Cout(padded) / 16 row blocks
 __global__ __launch_bounds__(256) void pw1x1_kernel(const XmcConvDesc d, int ngroups, const unsigned char* __restrict__ sbits, u32x4* __restrict__ smasked,
                                                     float mslope) {
     const int lane = threadIdx.x & 63, fr = lane & 15, fc = lane >> 4;
@@ -198,12 +200,15 @@ __global__ __launch_bounds__(256) void pw1x1_kernel(const XmcConvDesc d, int ngr
     const u32x4* __restrict__ src16 = reinterpret_cast<const u32x4*>(d.src);
     const u32x4* __restrict__ w16 = reinterpret_cast<const u32x4*>(d.wpk);
     bf16x8* __restrict__ dst8 = reinterpret_cast<bf16x8*>(d.dst);
-    u32x4 wf[KS][TN];
+    u32x4 wf[KS][TN], wl[SPLIT ? KS : 1][SPLIT ? TN : 1];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int lrow = (j >> 1) * 32 + (fr >> 2) * 8 + (j & 1) * 4 + (fr & 3);      // see conv_tile.hip: 64-byte stores per pixel
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) wf[ks][j] = w16[((size_t)d.wi[0][0] * d.CDw + lrow) * cs_units + ks * 4 + fc];
+        for (int ks = 0; ks < KS; ++ks) {
+            wf[ks][j] = w16[((size_t)d.wi[0][0] * d.CDw + lrow) * cs_units + ks * 4 + fc];
+            if (SPLIT) wl[ks][j] = reinterpret_cast<const u32x4*>(d.wpk_lo)[((size_t)d.wi[0][0] * d.CDw + lrow) * cs_units + ks * 4 + fc];
+        }
     }
     float bias8[TN / 2][8];
 #pragma unroll
@@ -241,8 +246,10 @@ __global__ __launch_bounds__(256) void pw1x1_kernel(const XmcConvDesc d, int ngr
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
+                for (int j = 0; j < TN; ++j) {
+                    if (SPLIT) acc[j] = XMC_MFMA_16x16x32(__builtin_bit_cast(bf16x8, wl[ks][j]), __builtin_bit_cast(bf16x8, pf[r][ks]), acc[j], 0, 0, 0);
                     acc[j] = XMC_MFMA_16x16x32(__builtin_bit_cast(bf16x8, wf[ks][j]), __builtin_bit_cast(bf16x8, pf[r][ks]), acc[j], 0, 0, 0);
+                }
             const size_t pix = (size_t)(g0 + r) * 16 + fr;
 #pragma unroll
             for (int u = 0; u < TN / 2; ++u) {
@@ -264,6 +271,17 @@ template <int KS, int TN>
 int launch_pw(const XmcConvDesc& d, int ngroups, hipStream_t st, const unsigned char* sbits, void* smasked, float mslope) {
     int nb = (ngroups + 4 * 4 - 1) / (4 * 4);           // 4 waves per block, 4 groups per wave and iteration
     if (nb > 256 * 8) nb = 256 * 8;
+    if (d.wpk_lo) {                                     // the pair form: 64 -> 128 channels (the first learned shortcut after the stem), forward
+        if constexpr (KS == 2 && TN == 8) {
+            if (smasked) return 1;
+            hipLaunchKernelGGL((pw1x1_kernel<KS, TN, false, true>), dim3(nb), dim3(256), 0, st, d, ngroups, nullptr, nullptr, 0.f);
+            xmc_note_kernel("pw1x1_kernel<%d, %d, false, true>", KS, TN);
+            XMC_LAUNCH_CHECK();
+            return 0;
+        } else {
+            return 1;
+        }
+    }
     if (smasked) hipLaunchKernelGGL((pw1x1_kernel<KS, TN, true>), dim3(nb), dim3(256), 0, st, d, ngroups, sbits, (u32x4*)smasked, mslope);
     else hipLaunchKernelGGL((pw1x1_kernel<KS, TN, false>), dim3(nb), dim3(256), 0, st, d, ngroups, nullptr, nullptr, 0.f);
     xmc_note_kernel(smasked ? "pw1x1_kernel<%d, %d, true>" : "pw1x1_kernel<%d, %d>", KS, TN);
@@ -278,11 +296,11 @@ int launch_pw(const XmcConvDesc& d, int ngroups, hipStream_t st, const unsigned 
 // wave, each weight fragment read once per 64 pixels, 64-byte-per-pixel stores.  8 waves per workgroup (2 per SIMD) share the
 // slice.  85-170 FLOP/byte: an HBM stream (the gather kernel ran these at 1.7-2.6 TB/s: two K steps of prologue and an LDS
 // transposition of the result per 256x256 tile).
-template <int KS, bool MASKED = false>        // KS = Cin / 32 K-steps (4 or 8); MASKED: see pw1x1_kernel (the first column slice writes it)
+template <int KS, bool MASKED = false, bool SPLIT = false>   // KS = Cin / 32 K-steps (4 or 8); MASKED: see pw1x1_kernel (the first column slice writes it)
 __global__ __launch_bounds__(512) void pw1x1w_kernel(const XmcConvDesc d, int ngroups, int ncols, const unsigned char* __restrict__ sbits,
                                                      u32x4* __restrict__ smasked, float mslope) {
     extern __shared__ __attribute__((aligned(16))) unsigned char wlds[];
-    constexpr int RSTR = KS * 64 + 16;         // bytes per weight row
+    constexpr int RSTR = KS * 64 * (SPLIT ? 2 : 1) + 16;         // bytes per weight row (SPLIT: the row's hi half, then its lo half)
     const int tid = threadIdx.x, lane = tid & 63, fr = lane & 15, fc = lane >> 4;
     const int cs_units = d.CS >> 3, cd8 = d.CD >> 3;
     const int c0 = blockIdx.y * ncols;         // first output channel of this workgroup's slice
@@ -296,6 +314,8 @@ __global__ __launch_bounds__(512) void pw1x1w_kernel(const XmcConvDesc d, int ng
         const int j = row >> 4, r = row & 15;
         const int lrow = (j >> 1) * 32 + (r >> 2) * 8 + (j & 1) * 4 + (r & 3);
         *reinterpret_cast<u32x4*>(wlds + row * RSTR + ch * 16) = w16[((size_t)d.wi[0][0] * d.CDw + c0 + lrow) * cs_units + ch];
+        if (SPLIT) *reinterpret_cast<u32x4*>(wlds + row * RSTR + KS * 64 + ch * 16) =
+                reinterpret_cast<const u32x4*>(d.wpk_lo)[((size_t)d.wi[0][0] * d.CDw + c0 + lrow) * cs_units + ch];
     }
     __syncthreads();
     const float slope = d.act == XMC_ACT_LRELU ? XMC_LRELU : 1.f;
@@ -329,6 +349,14 @@ __global__ __launch_bounds__(512) void pw1x1w_kernel(const XmcConvDesc d, int ng
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const bf16x8 wa = *reinterpret_cast<const bf16x8*>(wr + ks * 64), wb = *reinterpret_cast<const bf16x8*>(wr + 16 * RSTR + ks * 64);
+                if (SPLIT) {
+                    const bf16x8 la = *reinterpret_cast<const bf16x8*>(wr + KS * 64 + ks * 64), lb = *reinterpret_cast<const bf16x8*>(wr + 16 * RSTR + KS * 64 + ks * 64);
+#pragma unroll
+                    for (int r = 0; r < UNR; ++r) {
+                        acc[r][0] = XMC_MFMA_16x16x32(la, __builtin_bit_cast(bf16x8, pf[r][ks]), acc[r][0], 0, 0, 0);
+                        acc[r][1] = XMC_MFMA_16x16x32(lb, __builtin_bit_cast(bf16x8, pf[r][ks]), acc[r][1], 0, 0, 0);
+                    }
+                }
 #pragma unroll
                 for (int r = 0; r < UNR; ++r) {
                     acc[r][0] = XMC_MFMA_16x16x32(wa, __builtin_bit_cast(bf16x8, pf[r][ks]), acc[r][0], 0, 0, 0);
@@ -359,7 +387,9 @@ __global__ __launch_bounds__(512) void pw1x1w_kernel(const XmcConvDesc d, int ng
 template <int KS>
 int launch_pww(const XmcConvDesc& d, int ngroups, hipStream_t st, const unsigned char* sbits, void* smasked, float mslope) {
     // the column slice of a workgroup: as many 32-channel units as fit in LDS, dividing CDw evenly (256 x 512: two slices of 135 KB)
-    constexpr int RSTR = KS * 64 + 16;
+    const bool split = d.wpk_lo != nullptr;
+    if (split && smasked) return 1;
+    const int RSTR = KS * 64 * (split ? 2 : 1) + 16;
     int ny = 1;
     while ((size_t)(d.CDw / ny) * RSTR > XMC_MAX_DYN_LDS || d.CDw % ny != 0 || (d.CDw / ny) % 32 != 0) {
         if (++ny > d.CDw / 32) return 1;
@@ -369,6 +399,13 @@ int launch_pww(const XmcConvDesc& d, int ngroups, hipStream_t st, const unsigned
     int nb = (ngroups + 8 * 4 - 1) / (8 * 4);           // 8 waves per block, 4 groups per wave and iteration
     if (nb > 256 / ny) nb = 256 / ny;                   // one workgroup per CU (the slice is staged once per workgroup)
     if (nb < 1) nb = 1;
+    if (split) {
+        XMC_ALLOW_BIG_LDS((pw1x1w_kernel<KS, false, true>));
+        hipLaunchKernelGGL((pw1x1w_kernel<KS, false, true>), dim3(nb, ny), dim3(512), lds, st, d, ngroups, ncols, nullptr, nullptr, 0.f);
+        xmc_note_kernel("pw1x1w_kernel<%d, false, true>", KS);
+        XMC_LAUNCH_CHECK();
+        return 0;
+    }
     if (smasked) {
         XMC_ALLOW_BIG_LDS((pw1x1w_kernel<KS, true>));
         hipLaunchKernelGGL((pw1x1w_kernel<KS, true>), dim3(nb, ny), dim3(512), lds, st, d, ngroups, ncols, sbits, (u32x4*)smasked, mslope);
@@ -556,7 +593,17 @@ static int pw1x1_go(const XmcConvDesc* d, void* stream, const unsigned char* sbi
     return 1;
 }
 
-int xmc_conv_pw1x1_try(const XmcConvDesc* d, void* stream) { return pw1x1_go(d, stream, nullptr, nullptr, 0.f); }
+int xmc_conv_pw1x1_try(const XmcConvDesc* d, void* stream) { return d->wpk_lo ? 1 : pw1x1_go(d, stream, nullptr, nullptr, 0.f); }
+
+// The same kernels on a weight PAIR (XmcConvDesc.wpk_lo, ABI 12): two MFMAs per K step.  1 = not one of their shapes.
+extern "C" int xmc_conv_pw1x1_split(const XmcConvDesc* d, void* stream) {
+    if (!d || !d->src || !d->wpk || !d->wpk_lo || !d->dst) return XMC_EINVAL;
+    if (d->ntaps != 1 || d->CS % 8 != 0 || d->CD % 8 != 0 || d->CDw % 32 != 0 || d->CDw < d->CD || d->N < 1 || d->MH < 1 || d->MW < 1) return XMC_ESHAPE;
+    if (d->mask_bits || d->sc_img) return XMC_EINVAL;
+    static const bool off = xmc_debug_off("no_pw1x1_split");
+    if (off) return 1;
+    return pw1x1_go(d, stream, nullptr, nullptr, 0.f);
+}
 
 // The 1x1 convolution of `d` on the streaming kernels only, with the masked copy of its SOURCE as a by-product (see mask_unit):
 // src_masked[unit] = src[unit] x LeakyReLU'(bit) from one sign byte per 8-channel unit (XmcConvDesc.sign_bits layout of the source

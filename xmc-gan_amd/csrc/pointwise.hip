@@ -597,8 +597,8 @@ __global__ void pack_upconv_kernel(const float* w, void* wpk, int Co, int Ci, in
 constexpr int PM_CHUNK = 2048;
 struct PackJobs { XmcPackJob j[XMC_PACK_MULTI_MAX]; int32_t first[XMC_PACK_MULTI_MAX + 1]; int32_t njobs; };
 template <int DT>
-__device__ __forceinline__ void pack_store(void* p, int64_t i, float v) {
-    if (DT == XMC_BF16) reinterpret_cast<xmc_h16*>(p)[i] = (xmc_h16)v;
+__device__ __forceinline__ void pack_store(void* p, int64_t i, float v, bool lo = false) {
+    if (DT == XMC_BF16) reinterpret_cast<xmc_h16*>(p)[i] = lo ? (xmc_h16)(v - (float)(xmc_h16)v) : (xmc_h16)v;      // XmcPackJob.lo
     else reinterpret_cast<float*>(p)[i] = v;
 }
 template <int DT>
@@ -633,7 +633,7 @@ __device__ __forceinline__ void pack_position(const XmcPackJob& job, int pos) {
         if (job.groups == 1) src = job.w + ((int64_t)sco * job.Ci + ci) * job.KHW;
         else if (sco / cog == ci / cig) src = job.w + ((int64_t)sco * cig + ci % cig) * job.KHW;
     }
-    for (int t = 0; t < job.KHW; ++t) pack_store<DT>(job.wpk, t * plane + pos, src ? src[t] : 0.f);
+    for (int t = 0; t < job.KHW; ++t) pack_store<DT>(job.wpk, t * plane + pos, src ? src[t] : 0.f, job.lo != 0);
 }
 __global__ __launch_bounds__(256) void pack_multi_kernel(const PackJobs J) {
     int jb = 0;

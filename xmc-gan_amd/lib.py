@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("XMC_LIB_PATH", os.path.join(HERE, "libxmc_gan_hip.so"))   # override: kernel experiments
 LIB_PATH_F16 = os.environ.get("XMC_LIB_PATH_F16", os.path.join(HERE, "libxmc_gan_hip_f16.so"))
-ABI_VERSION = 11          # include/xmc_gan_hip.h XMC_ABI_VERSION; the ctypes structures below mirror that version
+ABI_VERSION = 12          # include/xmc_gan_hip.h XMC_ABI_VERSION; the ctypes structures below mirror that version
 
 # BF16 is the dtype code of "the 16-bit storage format of the loaded build": bf16 in libxmc_gan_hip.so, IEEE half in
 # libxmc_gan_hip_f16.so (the same sources compiled with -DXMC_H16_IS_F16; `use_variant`)
@@ -32,7 +32,7 @@ class ConvDesc(C.Structure):
                 ("dph", C.c_int8 * MAX_CLASSES), ("dpw", C.c_int8 * MAX_CLASSES),
                 ("mask", vp), ("res_scale", f32), ("res_mode", i32), ("dst2", vp), ("dst_pool", vp), ("round_act", i32), ("groups", i32),
                 ("post_act", i32), ("pool_scale", f32), ("sign_bits", vp), ("dot", vp), ("mask_bits", vp), ("sc_img", vp), ("sc_frag", vp), ("sc_bias", vp),
-                ("splitk_ws", vp), ("splitk_ws_bytes", C.c_int64)]
+                ("splitk_ws", vp), ("splitk_ws_bytes", C.c_int64), ("wpk_lo", vp)]
 
 
 # XmcGemmProblem as a numpy record (filled vectorised on the host, handed to xmc_gemm_group by pointer)
@@ -44,7 +44,7 @@ GP_BIAS, GP_RELU, GP_MASK, GP_ATOMIC = 1, 2, 4, 8
 
 class PackJob(C.Structure):
     _fields_ = [("w", vp), ("wpk", vp), ("row_perm", vp), ("Co", i32), ("Ci", i32), ("KHW", i32), ("rows_pad", i32),
-                ("cols_pad", i32), ("transpose", i32), ("dtype", i32), ("groups", i32), ("upconv", i32)]
+                ("cols_pad", i32), ("transpose", i32), ("dtype", i32), ("groups", i32), ("upconv", i32), ("lo", i32)]
 
 
 class AdamEntry(C.Structure):
@@ -78,6 +78,7 @@ _SIGS = {
     "xmc_tanh": [vp, vp, i64, i32, vp],
     "xmc_signmask_apply": [vp, vp, vp, i64, f32, i32, vp],
     "xmc_conv_pw1x1_masked_src": [C.POINTER(ConvDesc), vp, vp, f32, vp],
+    "xmc_conv_pw1x1_split": [C.POINTER(ConvDesc), vp],
     "xmc_conv_ptile_bits": [C.POINTER(ConvDesc), vp],
     "xmc_conv_ptile_scimg": [C.POINTER(ConvDesc), vp],
     "xmc_conv_wgrad_bits": [C.POINTER(ConvDesc), vp, vp],

@@ -23,6 +23,7 @@ if PROJ_DIR not in sys.path:
 
 import argparse
 import random
+import time
 
 import numpy as np
 import torch
@@ -65,6 +66,12 @@ def parse_args(argv=None):
     parser.add_argument('--precision', type=str, default=None, choices=['bf16', 'f16', 'fp32'])
     parser.add_argument('--gather_negatives', action='store_true',
                         help='data parallel: all-gather embeddings so the contrastive losses see world*batch negatives')
+    parser.add_argument('--graph', type=int, default=1,
+                        help='1 (default): replay the G+D iteration as hipGraphs (two eager warm-up iterations, then one capture per '
+                             'N_CRITIC phase); 0: launch every kernel from Python (host-bound: ~55 ms per iteration whatever the batch)')
+    parser.add_argument('--log_each_step', type=int, default=0,
+                        help="1: the reference's loss line after EVERY generator step (one host synchronisation per iteration); default: "
+                             'at the first step and every LOG_INTERVAL steps')
     return parser.parse_args(argv)
 
 
@@ -119,8 +126,16 @@ def img_loss(real_imgs, fake_imgs, labels, b_global):
 class StepOptions:
     """Engine-side switches of an iteration (not part of the reference cfg)."""
 
-    def __init__(self, gather_negatives=False):
+    def __init__(self, gather_negatives=False, graph=False, log_each_step=True):
         self.gather_negatives = gather_negatives
+        self.graph = graph                    # train(): replay the iteration as hipGraphs (xmc_gan_amd.graph.GraphedIteration)
+        self.log_each_step = log_each_step    # train(): read the four logged losses back after every generator step
+
+
+def _step(optimizer, scaler):
+    """optimizer.step(), with the dynamic loss scale only where there is one (IEEE-half mode): any torch.optim optimizer works
+    in the bf16 / fp32 modes, as upstream's torch.optim.Adam does"""
+    return optimizer.step(scaler=scaler) if scaler is not None else optimizer.step()
 
 
 def _set_requires_grad(module, flag):
@@ -211,7 +226,7 @@ def gan_iteration(netG, netD, optimizerG, optimizerD, imgs, sent_embs, words_emb
     sc_d = ops.loss_scaler("D", imgs.device)
     (sc_d.scale(errD) if sc_d is not None else errD).backward()
     parallel.allreduce_mean_grads(netD.parameters())
-    optimizerD.step(scaler=sc_d)
+    _step(optimizerD, sc_d)
     out.update(errD=errD.detach(), errD_real=errD_real.detach(), errD_fake=errD_fake.detach())
 
     # ---- matching-aware gradient penalty on real pairs (train_gan.py:231-252)
@@ -242,7 +257,7 @@ def gan_iteration(netG, netD, optimizerG, optimizerD, imgs, sent_embs, words_emb
             if p_.grad is None and name.endswith('.bias') and 'proj_match' not in name and _bias_on_logit_path(netD, name):
                 p_.grad = torch.zeros_like(p_)
         parallel.allreduce_mean_grads(netD.parameters())
-        optimizerD.step(scaler=sc_gp)
+        _step(optimizerD, sc_gp)
         out['d_loss_gp'] = d_loss_gp.detach()
 
     # ---- generator step (train_gan.py:254-291)
@@ -279,10 +294,11 @@ def gan_iteration(netG, netD, optimizerG, optimizerD, imgs, sent_embs, words_emb
         finally:
             _set_requires_grad(netD, True)
         parallel.allreduce_mean_grads(netG.parameters())
-        optimizerG.step(scaler=sc_g)
+        _step(optimizerG, sc_g)
         it_state['i'] = 0
         out.update(errG=errG.detach(), errG_fake=errG_fake.detach())
     out['fake'] = fake.detach()
+    ops.end_iteration(imgs.device)                 # forward-only code between iterations (evaluation, sampling) stays out of the arena
     return out
 
 
@@ -301,19 +317,31 @@ class SyntheticCOCO:
     (dataset.py:64): images uniform in [-1,1] like Normalize(0.5,0.5) output (dataset.py:34-37), captions as WordTextDataset
     pads them (int64 token ids in [1, V), zeros after the length; dataset.py:104-111)."""
 
-    def __init__(self, n_batches, batch_size, img_size, max_len, seed, voca_size=27297):
+    def __init__(self, n_batches, batch_size, img_size, max_len, seed, voca_size=27297, distinct=8):
+        """``distinct``: batches i and i + distinct are the same tensors (generated once, kept in pinned host memory): drawing 50 M
+        uniform numbers per 256 x 256 x 256 batch takes the host ~0.2 s, five times the iteration it feeds."""
         self.n, self.bs, self.size, self.max_len, self.seed, self.voca = n_batches, batch_size, img_size, max_len, seed, voca_size
+        self.distinct = max(1, min(int(distinct), n_batches))
+        self._cache = {}
 
     def __len__(self):
         return self.n
 
-    def __iter__(self):
-        for i in range(self.n):
+    def _batch(self, i):
+        if i not in self._cache:
             g = torch.Generator().manual_seed(self.seed * 100003 + i)
             imgs = torch.rand(self.bs, 3, self.size, self.size, generator=g) * 2 - 1
+            if torch.cuda.is_available():
+                imgs = imgs.pin_memory()
             lens = torch.randint(5, self.max_len + 1, (self.bs,), generator=g)
             caps = torch.randint(1, self.voca, (self.bs, self.max_len), generator=g)
             caps = caps * (torch.arange(self.max_len)[None, :] < lens[:, None])
+            self._cache[i] = (imgs, caps, lens)
+        return self._cache[i]
+
+    def __iter__(self):
+        for i in range(self.n):
+            imgs, caps, lens = self._batch(i % self.distinct)
             yield imgs, [(caps, lens)], [f'syn{i}_{j}' for j in range(self.bs)]
 
 
@@ -336,6 +364,7 @@ class SyntheticTextEncoder(torch.nn.Module):
 
 
 # --------------------------------------------------------------------------------------- epoch loop
+_TIMED_FROM = 4          # train() reports images/s from the end of this step on: two eager warm-ups, the capture(s), one replay
 def _log_epoch_scalars(writer, last, epoch):
     """the per-epoch scalars of the reference (train_gan.py:300-320): the losses of the epoch's last iteration"""
     if writer is None or 'errD' not in last:
@@ -348,25 +377,79 @@ def _log_epoch_scalars(writer, last, epoch):
     writer.flush()
 
 
+class _DeviceBatches:
+    """The loader's batches with the image tensor already on its way to the device: while iteration i runs (a graph replay leaves the
+    host idle), batch i+1 is fetched and uploaded on a side stream from pinned memory, so the 0.2 GB of a 256 x 256 x 256 f32 batch
+    (~5 ms of PCIe time) is off the iteration's critical path.  Yields the loader's tuples with `imgs` on the device."""
+
+    def __init__(self, loader, device):
+        self.loader, self.device = loader, device
+        self.stream = torch.cuda.Stream(device=device) if device.type == 'cuda' else None
+
+    def __len__(self):
+        return len(self.loader)
+
+    def _upload(self, data):
+        imgs, texts_lst, keys = data
+        if self.stream is None or not torch.is_tensor(imgs) or imgs.is_cuda:
+            return (imgs.to(self.device) if torch.is_tensor(imgs) else imgs, texts_lst, keys), imgs, None
+        host = imgs if imgs.is_pinned() else imgs.pin_memory()
+        with torch.cuda.stream(self.stream):
+            dev = host.to(self.device, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        return (dev, texts_lst, keys), host, ev
+
+    def __iter__(self):
+        it = iter(self.loader)
+        try:
+            nxt = self._upload(next(it))
+        except StopIteration:
+            return
+        while nxt is not None:
+            (dev, texts_lst, keys), host, ev = nxt
+            if ev is not None:
+                torch.cuda.current_stream().wait_event(ev)
+                dev.record_stream(torch.cuda.current_stream())
+            yield dev, texts_lst, keys, host
+            try:                       # (after the consumer has launched its iteration: this upload overlaps it)
+                nxt = self._upload(next(it))
+            except StopIteration:
+                nxt = None
+
+
 def train(train_loader, test_loader, state_epoch, text_encoder, netG, netD, optimizerG, optimizerD, logger, model_dir,
           opts=None, img_dir=None, max_steps=None, writer=None):
     """Epoch loop with the reference's signature (train_gan.py:142); returns the last iteration's losses.
 
     With ``img_dir`` (rank 0) it keeps the reference's visual log: ``sents.txt`` and ``imgs.png`` of the first batch (146-160),
     ``fake_samples_<step>.png`` every LOG_INTERVAL steps (298-299), ``fake_samples_epoch_<epoch>.png`` from a fixed noise /
-    caption batch in eval mode after every epoch (322-326); with ``writer`` the per-epoch scalars (300-320)."""
+    caption batch in eval mode after every epoch (322-326); with ``writer`` the per-epoch scalars (300-320).
+
+    ``opts.graph`` (the entry point's default, ``--graph 1``): the loop body runs as hipGraph replays
+    (xmc_gan_amd.graph.GraphedIteration: two eager warm-up iterations, one capture per N_CRITIC phase, collectives as eager
+    seams between graph segments); a batch is copied into the graph's static inputs and the losses stay on the device until they
+    are logged -- at the first step and every LOG_INTERVAL steps unless ``opts.log_each_step``."""
     device = next(netG.parameters()).device
+    opts = opts or StepOptions()
     it_state, last, nsteps = {}, {}, 0
     fixed = None
     visual = img_dir is not None and parallel.rank() == 0
+    graphed, use_graph = None, bool(opts.graph) and device.type == 'cuda'
+    batches = _DeviceBatches(train_loader, device)
+    t_mark, thr = [None, 0], None
+
+    def step_fn(imgs_, sent_, words_, mask_, noise_, st_):
+        return gan_iteration(netG, netD, optimizerG, optimizerD, imgs_, sent_, words_, mask_, noise_, st_, opts)
+
     for epoch in range(state_epoch + 1, cfg.TRAIN.MAX_EPOCH + 1):
         netG.train()
         netD.train()
         sampler = getattr(train_loader, 'sampler', None)
         if isinstance(sampler, torch.utils.data.distributed.DistributedSampler):
             sampler.set_epoch(epoch)             # data parallel: a new permutation (and new per-rank shards) every epoch
-        for step, data in enumerate(train_loader):
-            imgs, texts_lst, keys = data
+        for step, data in enumerate(batches):
+            imgs, texts_lst, keys, imgs_host = data
             caps, cap_lens = texts_lst[0]
             with torch.no_grad():
                 words_embs, sent_embs, mask = text_encoder(caps, cap_lens)
@@ -382,12 +465,31 @@ def train(train_loader, test_loader, state_epoch, text_encoder, netG, netD, opti
                             f.write(f'{sent} \n')
                 fixed = dict(noise=torch.randn(mask.size(0), cfg.TRAIN.NOISE_DIM).to(device), sent=sent_embs.clone(),
                              words=words_embs.clone(), mask=mask.clone())
-                save_image(imgs, f'{img_dir}/imgs.png', normalize=True, scale_each=True)
-            imgs = imgs.to(device, non_blocking=True)
-            noise = torch.randn(mask.size(0), cfg.TRAIN.NOISE_DIM).to(device)        # CPU generator, as upstream (197-198)
-            last = gan_iteration(netG, netD, optimizerG, optimizerD, imgs, sent_embs, words_embs, mask, noise,
-                                 it_state, opts)
-            if 'errG' in last:
+                save_image(imgs_host, f'{img_dir}/imgs.png', normalize=True, scale_each=True)
+            noise = torch.randn(mask.size(0), cfg.TRAIN.NOISE_DIM).to(device, non_blocking=True)   # CPU generator, as upstream (197-198)
+            inputs = (imgs, sent_embs, words_embs, mask, noise)
+            if use_graph and graphed is None:
+                from xmc_gan_amd.graph import GraphedIteration
+                graphed = GraphedIteration(step_fn, inputs, n_critic=cfg.TRAIN.N_CRITIC, warmup=2)
+                graphed.it_state = it_state
+            if graphed is not None and all(s_.shape == t_.shape and s_.dtype == t_.dtype for s_, t_ in zip(graphed.static_in, inputs)):
+                try:
+                    last = dict(graphed(*inputs))
+                except Exception as e:           # noqa: BLE001 -- a capture that failed (an operator that synchronises, memory)
+                    if parallel.world() > 1:
+                        raise                    # the ranks' collectives are out of step: no in-band way to agree on a fallback
+                    logger.info(f'hipGraph capture failed ({type(e).__name__}: {e}); continuing with eager launches')
+                    it_state = dict(graphed.it_state)
+                    graphed.close()
+                    graphed, use_graph = None, False
+                    last = step_fn(*inputs, it_state)
+            else:                                # eager: --graph 0, or a batch of another shape (a loader without drop_last)
+                last = step_fn(*inputs, it_state)
+            first = nsteps == 0
+            if device.type == 'cuda' and t_mark[0] is None and nsteps == _TIMED_FROM + 2 * (cfg.TRAIN.N_CRITIC - 1):
+                torch.cuda.synchronize(device)           # the run's throughput: from the end of step _TIMED_FROM (warm-ups and captures done) ...
+                t_mark[0], t_mark[1] = time.perf_counter(), nsteps + 1
+            if 'errG' in last and (opts.log_each_step or first or (step + 1) % cfg.TRAIN.LOG_INTERVAL == 0):
                 logger.info(f'[{epoch}/{cfg.TRAIN.MAX_EPOCH}][{step + 1}/{len(train_loader)}] '
                             f'Loss_D: {last["errD"].item():.3f} Loss_G: {last["errG"].item():.3f} '
                             f'errD_real: {last["errD_real"].item():.3f} errD_fake: {last["errD_fake"].item():.3f} ')
@@ -395,7 +497,15 @@ def train(train_loader, test_loader, state_epoch, text_encoder, netG, netD, opti
                 save_image(last['fake'], f'{img_dir}/fake_samples_{step + 1:03d}.png', normalize=True, scale_each=True)
             nsteps += 1
             if max_steps is not None and nsteps >= max_steps:
-                return last
+                return _detached(last)
+        if t_mark[0] is not None and nsteps > t_mark[1]:
+            torch.cuda.synchronize(device)               # ... to the end of the epoch (one synchronisation per epoch)
+            dt_, n_ = time.perf_counter() - t_mark[0], nsteps - t_mark[1]
+            thr = dict(steps=n_, seconds=round(dt_, 4), ms_per_step=round(1e3 * dt_ / n_, 3),
+                       images_per_s=round(parallel.world() * cfg.TRAIN.BATCH_SIZE * n_ / dt_, 1), hipgraph=graphed is not None)
+            logger.info(f'throughput: {thr["images_per_s"]} images/s ({thr["ms_per_step"]} ms per iteration over {n_} iterations, '
+                        f'{"hipGraph replay" if graphed is not None else "eager launches"})')
+            t_mark[0], t_mark[1] = time.perf_counter(), nsteps
         if parallel.rank() == 0:
             _log_epoch_scalars(writer, last, epoch)
         # IEEE-half mode: the dynamic loss scales and the optimizer steps the found-inf check skipped so far (one host read per epoch)
@@ -415,11 +525,24 @@ def train(train_loader, test_loader, state_epoch, text_encoder, netG, netD, opti
             torch.save(netD.state_dict(), f'{model_dir}/netD_{epoch:03d}.pth')
             torch.save(optimizerG.state_dict(), f'{model_dir}/optimizerG.pth')
             torch.save(optimizerD.state_dict(), f'{model_dir}/optimizerD.pth')
+            if ops.loss_scaler_state():          # IEEE-half mode: the dynamic loss scales are optimizer state too
+                torch.save(ops.loss_scaler_state(), f'{model_dir}/loss_scale.pth')
             logger.info('Save models')
             if test_loader is not None:
                 eval(loader=test_loader, state_epoch=epoch, text_encoder=text_encoder, netG=netG, logger=logger, num_samples=6000,
                      save_dir=f'{img_dir}/test' if img_dir else None, org_dir=f'{img_dir}/org' if img_dir else None, writer=writer)
+    last = _detached(last)
+    if thr is not None:
+        last['throughput'] = thr
+    if graphed is not None:
+        last['hipgraph'] = True
+        graphed.close()
     return last
+
+
+def _detached(last):
+    """the last iteration's losses as tensors of their own (a graph's static outputs are overwritten by the next replay and freed with it)"""
+    return {k: (v.clone() if torch.is_tensor(v) else v) for k, v in last.items()}
 
 
 @torch.no_grad()
@@ -556,6 +679,8 @@ def main(argv=None):
         netD.load_state_dict(torch.load(f'{model_dir}/netD_{state_epoch:03d}.pth', map_location=device))
         optimizerG.load_state_dict(torch.load(f'{model_dir}/optimizerG.pth', map_location=device))
         optimizerD.load_state_dict(torch.load(f'{model_dir}/optimizerD.pth', map_location=device))
+        if os.path.isfile(f'{model_dir}/loss_scale.pth'):
+            ops.load_loss_scaler_state(torch.load(f'{model_dir}/loss_scale.pth', map_location='cpu'), device)
         logger.info(f'Load models, epoch : {state_epoch}')
     elif cfg.DISC.ENCODER_DIR:
         netD.load_state_dict(torch.load(f'{PROJ_DIR}/{cfg.DISC.ENCODER_DIR}', map_location=device), strict=False)
@@ -563,7 +688,8 @@ def main(argv=None):
     writer = ScalarLog(log_dir, args.log_type, run_name=cfg.CONFIG_NAME) if rank == 0 else None
     last = train(train_loader=train_loader, test_loader=test_loader, state_epoch=state_epoch, text_encoder=text_encoder,
                  netG=netG, netD=netD, optimizerG=optimizerG, optimizerD=optimizerD, logger=logger, model_dir=model_dir,
-                 opts=StepOptions(gather_negatives=args.gather_negatives), img_dir=img_dir if rank == 0 else None, writer=writer)
+                 opts=StepOptions(gather_negatives=args.gather_negatives, graph=bool(args.graph), log_each_step=bool(args.log_each_step)),
+                 img_dir=img_dir if rank == 0 else None, writer=writer)
     if writer is not None:
         writer.close()
     torch.cuda.synchronize()
