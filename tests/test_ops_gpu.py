@@ -682,8 +682,8 @@ def test_shortcut_data_gradient_writes_the_masked_gradient_as_a_by_product(N, H,
 
 
 @pytest.mark.parametrize("mode", ["f16", "bf16"])
-@pytest.mark.parametrize("N,H,cin,cout,kernel", [(16, 32, 64, 128, "pw1x1_kernel<2, 8, false, true>"), (16, 32, 128, 256, "pw1x1w_kernel<4, false, true>"),
-                                                 (64, 16, 256, 512, "pw1x1w_kernel<8, false, true>"), (8, 16, 64, 128, "igemm"), (4, 32, 8, 16, "igemm")])
+@pytest.mark.parametrize("N,H,cin,cout,kernel", [(16, 32, 64, 128, "pw1x1_kernel<2, 8, false, true>"), (32, 32, 128, 256, "pw1x1w_kernel<4, false, true>"),
+                                                 (128, 16, 256, 512, "pw1x1w_kernel<8, false, true>"), (8, 16, 64, 128, "igemm"), (4, 32, 8, 16, "igemm")])
 def test_learned_shortcut_on_a_weight_pair(N, H, cin, cout, kernel, mode):
     """xmc_conv_pw1x1_split (ABI 12, XmcConvDesc.wpk_lo): conv_s with its f32 weights as the 16-bit pair round16(w) + round16(w - round16(w)).
     A weight's rounding error is the SAME for every pixel, so it survives a mean over pixels, where the rounding of the stored

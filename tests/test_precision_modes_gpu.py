@@ -57,9 +57,16 @@ def test_f16_mode_losses_within_1e_3_of_f32_reference(yml, kind):
     # that has just taken the penalty's Adam step.  Rounds 1-3 ran the penalty's INNER backward unscaled (gradients among the
     # subnormals of the format; G-step losses 1.4e-3, bar 3e-3); since round 4 it runs on ops.gp_inner_scale() x ones and the outer
     # backward on its own dynamic scale.
-    dkeys = ("errD_real", "errD_fake", "errD_mismatch", "ds_loss", "errD", "d_loss_gp")
+    dkeys = ("errD_real", "errD_fake", "errD_mismatch", "ds_loss", "errD")
     sel = lambda d_, keys: {k: v for k, v in d_.items() if k in keys}
     wl = compare_losses(sel(p[0], dkeys), sel(o[0], dkeys), 1e-3, 1e-4)
+    if h.magp:
+        # the penalty 2 mean(||d logit / d inputs||^6) is evaluated on the discriminator AFTER its Adam step (beta1 = 0: a weight whose
+        # gradient sits inside rounding noise of zero moves by up to 2 lr the other way: `final D weights: worst element 2 lr from the
+        # oracle's` in tests/diag/precise_magp_probe.py) and raises the norm to the 6th power.  Five seeds on one box, relative error of
+        # the penalty, with / without the precise trunk: 6.6e-3 / 2.2e-3, 3e-6 / 7e-6, 7e-5 / 2.3e-4, 4.6e-4 / 1.8e-3, 4.6e-3 / 4.3e-3 --
+        # seed noise of a few 1e-3 in either mode, i.e. ~1e-3 on the norm itself: the bar is 1.5e-3 on the norm (9e-3 on its 6th power)
+        wl = max(wl, compare_losses(sel(p[0], ("d_loss_gp",)), sel(o[0], ("d_loss_gp",)), 1.5e-3, 1e-4))
     gkeys = ("errG_fake", "gs_loss", "disc_loss", "errG")
     # G-step losses: 1e-3 in the headline configuration (measured 3.4e-4 .. 4.6e-4).  With MA-GP they are evaluated on a discriminator
     # that has taken the PENALTY's Adam step, and that step is sensitive at the last bit: swapping the kernel of ONE layer's data gradient
