@@ -255,7 +255,8 @@ int xmc_signmask_apply(const void* dy, const void* bits, void* dx, int64_t n, fl
 int xmc_conv_pw1x1_masked_src(const XmcConvDesc* d, const void* src_bits, void* src_masked, float slope, void* stream);
 /* The 1x1 convolution of `d` on the streaming kernels with its weights as the pair (d->wpk, d->wpk_lo) (XmcConvDesc.wpk_lo; the
  * discriminator's learned shortcuts conv_s, df_gan.py:280,286-291, in the IEEE-half mode).  Returns 1 and launches nothing when the
- * shape is not one of theirs (Cin 64 -> Cout 128 from registers, Cin 128 / 256 from LDS, >= 16 k pixels). */
+ * shape is not one of theirs (Cin -> Cout 64 -> 128, 128 -> 64, 64 -> 32 from registers, Cin 128 / 256 with Cout >= 128 from LDS;
+ * >= 16 k pixels). */
 int xmc_conv_pw1x1_split(const XmcConvDesc* d, void* stream);
 /* The same masked operand WITHOUT writing it: the data gradient (weights-resident kernel, Cin / Cout <= 64, unit stride) and the 3x3
  * weight gradient (row-reuse kernel, W % 32 == 0, H % 8 == 0) apply d->mask_bits while they stage the gradient operand.  Return 1

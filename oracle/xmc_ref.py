@@ -64,7 +64,8 @@ class quant:
 
     def __init__(self, on=True, skip=(), grad=True, fmt=torch.bfloat16, grad_scale=None, only=None, precise=None):
         """``precise`` (round 5; default: on for IEEE half, off for bf16 -- the engine's defaults, ops.precise_trunk): the discriminator's
-        PRECISE TRUNK.  Outside the pass whose backward is differentiated again: the learned shortcuts' weights exact (a 16-bit hi + lo
+        PRECISE TRUNK.  The generator's learned shortcuts c_sc: weights exact.  The discriminator, outside the pass whose backward is
+        differentiated again: the learned shortcuts' weights exact (a 16-bit hi + lo
         pair or exact-f32 MFMA in the engine; the composed stem's shortcut stays rounded); on maps of <= 8x8 pixels the shortcut, the
         block sum (its branch unrounded, f32 destination) and the pooled by-product stay f32 -- the next block's conv_r[0] reads the
         rounded sum --; COND_DNET runs in f32 on the f32 map of the last block.  Gradients are rounded where they were.
@@ -609,7 +610,7 @@ def _g_block(P, p, x, c, upsample):
     return out
 
 
-def _upconv3x3_q(x_lo, w, b):
+def _upconv3x3_q(x_lo, w, b, L=None):
     """conv3x3(nearest_up2(x_lo), w) + b the way the engine evaluates it: per output parity (i, j) a 2x2-tap convolution on the
     LOW-resolution tensor whose weights are sums of the 3x3 taps that read the same low-resolution pixel, summed in f32 and
     rounded to bf16 once (the same function as the reference's interpolate -> conv; only the weight rounding differs)."""
@@ -624,7 +625,7 @@ def _upconv3x3_q(x_lo, w, b):
                 for tw in (0, 1):
                     (h0, h1), (w0, w1) = rows[i][th], rows[j][tw]
                     taps.append(w[:, :, h0:h1 + 1, w0:w1 + 1].sum(dim=(2, 3)))
-            wc = qw(torch.stack(taps, dim=2).view(w.size(0), C, 2, 2), "g.w")
+            wc = qw(torch.stack(taps, dim=2).view(w.size(0), C, 2, 2), "g.w", None if L is None else L + ".c1")
             xp = F.pad(x_lo, (1 - j, j, 1 - i, i))              # rows a-1..a (i=0) or a..a+1 (i=1), same for columns
             parts.append((i, j, F.conv2d(xp, wc)))
     out = torch.stack([torch.stack([parts[0][2], parts[1][2]], dim=-1), torch.stack([parts[2][2], parts[3][2]], dim=-1)], dim=-3)
@@ -637,16 +638,19 @@ def _g_block_q(P, p, x, c, upsample, x_is_lo=False):
     convolution, after the 1x1 shortcut and after the block sum; `x_is_lo`: x is the previous block's output BEFORE its nearest
     upsample (the engine never writes the upsampled tensor; affines and the 1x1 shortcut commute with it, c1 runs as the fused
     upsample convolution)."""
+    L = "b" + p.split(".")[-1]                  # layer tag of the per-layer ladder ("g.w@b4.sc", "g.sum@b4")
     hdn = F.leaky_relu(_affine(P, f"{p}.affine0", x, c), LRELU)
-    hdn = q(F.leaky_relu(_affine(P, f"{p}.affine1", hdn, c), LRELU), "g.aff")
+    hdn = q(F.leaky_relu(_affine(P, f"{p}.affine1", hdn, c), LRELU), "g.aff", L)
     if x_is_lo:
-        hdn = q(_upconv3x3_q(hdn, P[f"{p}.c1.weight"], P[f"{p}.c1.bias"]), "g.c1")
+        hdn = q(_upconv3x3_q(hdn, P[f"{p}.c1.weight"], P[f"{p}.c1.bias"], L), "g.c1", L)
     else:
-        hdn = q(F.conv2d(hdn, qw(P[f"{p}.c1.weight"], "g.w"), P[f"{p}.c1.bias"], 1, 1), "g.c1")
+        hdn = q(F.conv2d(hdn, qw(P[f"{p}.c1.weight"], "g.w", L + ".c1"), P[f"{p}.c1.bias"], 1, 1), "g.c1", L)
     hdn = F.leaky_relu(_affine(P, f"{p}.affine2", hdn, c), LRELU)
-    hdn = q(F.leaky_relu(_affine(P, f"{p}.affine3", hdn, c), LRELU), "g.aff")
-    res = q(F.conv2d(hdn, qw(P[f"{p}.c2.weight"], "g.w"), P[f"{p}.c2.bias"], 1, 1), "g.c2")
-    sc = q(F.conv2d(x, qw(P[f"{p}.c_sc.weight"], "g.w"), P[f"{p}.c_sc.bias"]), "g.sc") if f"{p}.c_sc.weight" in P else x
+    hdn = q(F.leaky_relu(_affine(P, f"{p}.affine3", hdn, c), LRELU), "g.aff", L)
+    res = q(F.conv2d(hdn, qw(P[f"{p}.c2.weight"], "g.w", L + ".c2"), P[f"{p}.c2.bias"], 1, 1), "g.c2", L)
+    # (precise trunk: the learned shortcut's weights exact -- a hi + lo pair in the engine)
+    sc = q(F.conv2d(x, P[f"{p}.c_sc.weight"] if _QPRECISE else qw(P[f"{p}.c_sc.weight"], "g.w", L + ".sc"), P[f"{p}.c_sc.bias"]), "g.sc", L) \
+        if f"{p}.c_sc.weight" in P else x
     if x_is_lo:
         sc = F.interpolate(sc, scale_factor=2)
     return sc, res            # the caller forms sc + gamma * res (the last block fuses the tail's LeakyReLU into that pass)
@@ -668,7 +672,7 @@ def _tail(P, x, lrelu_done=False):
     """conv_out = LeakyReLU -> Conv3x3(->3) -> Tanh (df_gan.py:84-88)."""
     if not lrelu_done:
         x = q(F.leaky_relu(x, LRELU), "g.act")
-    return q(torch.tanh(F.conv2d(x, qw(P["conv_out.1.weight"], "g.w"), P["conv_out.1.bias"], 1, 1)), "g.img")
+    return q(torch.tanh(F.conv2d(x, qw(P["conv_out.1.weight"], "g.w", "out"), P["conv_out.1.bias"], 1, 1)), "g.img")
 
 
 def netg_forward(P, h: Hyper, noise, sent_embs, **_):
@@ -682,7 +686,7 @@ def netg_forward(P, h: Hyper, noise, sent_embs, **_):
             sc, res = _g_block_q(P, p, out, c, a["upsample"][i], x_is_lo=lo)
             out = sc + P[f"{p}.gamma"] * res
             last = i == a["depth"] - 1 and not a["upsample"][i]
-            out = q(F.leaky_relu(out, LRELU), "g.sum") if last else q(out, "g.sum")
+            out = q(F.leaky_relu(out, LRELU), "g.sum", f"b{i}") if last else q(out, "g.sum", f"b{i}")
             lo = a["upsample"][i]
         if lo:
             out = F.interpolate(out, scale_factor=2)

@@ -167,8 +167,8 @@ def test_rounding_mode_is_off_by_default_and_visits_every_site(gen):
     b = X.synth_batch(h, 2, seed=1)
     seen, q0 = {}, X.q
 
-    def rec(x, site=None):
-        y = q0(x, site)
+    def rec(x, site=None, *a, **k):
+        y = q0(x, site, *a, **k)
         seen.setdefault(site, []).append(y.detach())
         return y
 

@@ -271,8 +271,8 @@ template <int KS, int TN>
 int launch_pw(const XmcConvDesc& d, int ngroups, hipStream_t st, const unsigned char* sbits, void* smasked, float mslope) {
     int nb = (ngroups + 4 * 4 - 1) / (4 * 4);           // 4 waves per block, 4 groups per wave and iteration
     if (nb > 256 * 8) nb = 256 * 8;
-    if (d.wpk_lo) {                                     // the pair form: 64 -> 128 channels (the first learned shortcut after the stem), forward
-        if constexpr (KS == 2 && TN == 8) {
+    if (d.wpk_lo) {      // the pair form, forward: D's 64 -> 128 shortcut, G's 128 -> 64 and 64 -> 32 ones (the wider ones: launch_pww)
+        if constexpr ((KS == 2 && TN == 8) || (KS == 4 && TN == 4) || (KS == 2 && TN == 2)) {
             if (smasked) return 1;
             hipLaunchKernelGGL((pw1x1_kernel<KS, TN, false, true>), dim3(nb), dim3(256), 0, st, d, ngroups, nullptr, nullptr, 0.f);
             xmc_note_kernel("pw1x1_kernel<%d, %d, false, true>", KS, TN);

@@ -1042,9 +1042,10 @@ class ConvFn(torch.autograd.Function):
     197,233-240,273,276,280."""
 
     @staticmethod
-    def forward(ctx, x, w, b, geom, act, out_dtype, want_pool=False, out=None):
+    def forward(ctx, x, w, b, geom, act, out_dtype, want_pool=False, out=None, pair=False):
         """``want_pool``: returns (y, avg_pool2d(y, 2)); the pooled tensor is a by-product for the consumer's shortcut branch
-        (written from the epilogue where the kernel can) and carries no gradient of its own.  ``out``: destination tensor."""
+        (written from the epilogue where the kernel can) and carries no gradient of its own.  ``out``: destination tensor.
+        ``pair``: a 1x1 layer of the precise trunk -- forward on the weights' hi + lo pair (`_conv1x1_pair_raw`), backward as ever."""
         x = x.contiguous()
         # `out` is written behind autograd's back (no version bump): it must be a tensor no earlier node has saved
         assert out is None or out._version == 0, "ConvFn(out=): the destination must be a fresh tensor"
@@ -1057,7 +1058,10 @@ class ConvFn(torch.autograd.Function):
             if bp.numel() < cd_p:
                 bp = torch.nn.functional.pad(bp, (0, cd_p - bp.numel()))
             bp = bp.contiguous()
-        y = _conv_fwd_raw(x, w, bp, geom, act, out_dtype, want_pool=want_pool, out=out)
+        if pair and x.dtype != torch.float32 and act == L.ACT_NONE and not want_pool and out is None:
+            y = _conv1x1_pair_raw(x, w, bp, geom, out_dtype)
+        else:
+            y = _conv_fwd_raw(x, w, bp, geom, act, out_dtype, want_pool=want_pool, out=out)
         yp = None
         if want_pool:
             y, yp = y
@@ -1072,7 +1076,7 @@ class ConvFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, _dyp=None):
         if dy is None:
-            return None, None, None, None, None, None, None, None
+            return None, None, None, None, None, None, None, None, None
         x, w, y = ctx.saved_tensors
         geom = ctx.geom
         dy = dy.contiguous()
@@ -1099,7 +1103,7 @@ class ConvFn(torch.autograd.Function):
                 if geom.row_perm is not None:
                     db = torch.zeros_like(db).index_copy(0, geom.perm_dev(db.device).long(), db)
                 db = db[: geom.cout]
-        return dx, dw, db, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None
 
 
 class ConvDgradFn(torch.autograd.Function):
@@ -1411,8 +1415,8 @@ def g_block_end(h1, mod4, c2w, c2b, geom2, sc_lo, gamma, tail=None, nhwc_dst=Non
     return GBlockEndFn.apply(h1, *mod4, c2w, c2b, geom2, sc_lo, gamma, tail[0], tail[1], tail[2], nhwc_dst)
 
 
-def conv2d(x, w, b, geom, act=L.ACT_NONE, out_dtype=None, want_pool=False, out=None):
-    return ConvFn.apply(x, w, b, geom, act, out_dtype or x.dtype, want_pool, out)
+def conv2d(x, w, b, geom, act=L.ACT_NONE, out_dtype=None, want_pool=False, out=None, pair=False):
+    return ConvFn.apply(x, w, b, geom, act, out_dtype or x.dtype, want_pool, out, pair)
 
 
 def linear(x, w, b, geom, act=L.ACT_NONE, out_dtype=None):

@@ -287,7 +287,9 @@ class G_Block(nn.Module):
         return ops.axpby_up(self.shortcut(xs), self.c2(h), self.gamma, lrelu=out_lrelu)
 
     def shortcut(self, x):
-        return self.c_sc(x) if self.learnable_sc else x
+        # precise trunk (IEEE-half mode, ops.precise_trunk): the image is, to first order in the block gammas, a function of the shortcut
+        # path alone, and a rounding error of c_sc's weights is shared by every sample and pixel -- forward on the weights' hi + lo pair
+        return self.c_sc(x, pair=ops.precise_trunk()) if self.learnable_sc else x
 
     def residual(self, x, c, mod=None):
         m = self.modulation(c) if mod is None else mod

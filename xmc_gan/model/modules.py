@@ -54,9 +54,9 @@ class HipConv2d(nn.Conv2d, _SpectralNorm):
         if self.spec_norm:
             self._sn_setup()
 
-    def forward(self, x, act=None, out_dtype=None, want_pool=False, out=None):
+    def forward(self, x, act=None, out_dtype=None, want_pool=False, out=None, pair=False):
         return ops.conv2d(x, self.effective_weight(), self.bias, self.geom,
-                          self.act if act is None else act, out_dtype, want_pool, out)
+                          self.act if act is None else act, out_dtype, want_pool, out, pair)
 
 
 class HipLinear(nn.Linear, _SpectralNorm):
