@@ -682,6 +682,38 @@ def test_shortcut_data_gradient_writes_the_masked_gradient_as_a_by_product(N, H,
 
 
 @pytest.mark.parametrize("mode", ["f16", "bf16"])
+@pytest.mark.parametrize("rows", [8, 767])
+def test_pair_convolution_reaches_f32_grade_on_the_16_bit_pipeline(rows, mode):
+    """ops.PairConvFn (COND_DNET's joint_conv.0 on the precise trunk, df_gan.py:157,170-174): an f32 [rows,4,4,768] map through the
+    3x3 convolution to 64 channels + LeakyReLU with both operands as 16-bit hi + lo pairs, three launches accumulating in f32.
+    Against an f64 evaluation: 2^-20-grade (the dropped lo x lo product and the f32 accumulation), where one 16-bit launch is
+    2^-12 (f16) / 2^-9 (bf16); gradients are the 16-bit layer's."""
+    ops.set_precision(mode)
+    g = torch.Generator().manual_seed(rows)
+    x = torch.randn(rows, 4, 4, 768, generator=g)
+    w = torch.randn(64, 768, 3, 3, generator=g) * math.sqrt(2.0 / (768 * 9))
+    gs = ops.ConvGeom(768, 64, 3, 1, 1)
+    wd = torch.nn.Parameter(w.to(DEV))
+    xd = x.to(DEV).requires_grad_()
+    y = ops.pair_conv2d(xd, wd, gs, L.ACT_LRELU)
+    ref = F.leaky_relu(F.conv2d(x.double().permute(0, 3, 1, 2), w.double(), None, 1, 1), 0.2).permute(0, 2, 3, 1)
+    e = rel_l2(y.detach().float().cpu(), ref.float())
+    y1 = ops.conv2d(xd.detach().to(ops.act_dtype()), wd, None, gs, L.ACT_LRELU, torch.float32)
+    e1 = rel_l2(y1.float().cpu(), ref.float())
+    print(f"\n[{mode} rows {rows}] pair convolution vs f64: {e:.2e}; one 16-bit launch: {e1:.2e}")
+    assert e <= (3e-6 if mode == "f16" else 4e-5) and e1 >= 20 * e
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy.to(DEV))
+    xr = x.double().permute(0, 3, 1, 2).requires_grad_()
+    wr = w.double().requires_grad_()
+    F.leaky_relu(F.conv2d(xr, wr, None, 1, 1), 0.2).backward(dy.double().permute(0, 3, 1, 2))
+    ulp = 2.0 ** -11 if mode == "f16" else 2.0 ** -8
+    assert rel_l2(xd.grad.float().cpu(), xr.grad.permute(0, 2, 3, 1).float()) <= 2 * ulp
+    assert rel_l2(wd.grad.float().cpu(), wr.grad.float()) <= 2 * ulp
+    ops.set_precision("bf16")
+
+
+@pytest.mark.parametrize("mode", ["f16", "bf16"])
 @pytest.mark.parametrize("N,H,cin,cout,kernel", [(16, 32, 64, 128, "pw1x1_kernel<2, 8, false, true>"), (32, 32, 128, 256, "pw1x1w_kernel<4, false, true>"),
                                                  (128, 16, 256, 512, "pw1x1w_kernel<8, false, true>"), (8, 16, 64, 128, "igemm"), (4, 32, 8, 16, "igemm")])
 def test_learned_shortcut_on_a_weight_pair(N, H, cin, cout, kernel, mode):

@@ -508,7 +508,7 @@ def _upconv_dgrad_raw(dy, w, geom, in_dtype):
 
 
 def _conv_fwd_raw(x, w, bias, geom, act, out_dtype, res=None, alpha=None, up=False, res_mode=0, want2=False, want_pool=False,
-                  round_act=False, mask=None, out=None, post_act=L.ACT_NONE, want_sign=False, sc_img=None):
+                  round_act=False, mask=None, out=None, post_act=L.ACT_NONE, want_sign=False, sc_img=None, w_lo=False):
     """y = act(conv(x, w) + bias) [*alpha] [+ res]; x [N,H,W,Cs]. ``up``: x is read through a fused nearest x2.
     ``res_mode`` 2: res is [N,OH/2,OW/2,C] and read through a nearest x2.  ``want2``: also return act(conv + bias) itself (the
     branch value before alpha / res);  ``want_pool``: also return avg_pool2d(y, 2).  Extras are appended: (y[, y2][, ypool]).
@@ -521,7 +521,7 @@ def _conv_fwd_raw(x, w, bias, geom, act, out_dtype, res=None, alpha=None, up=Fal
     OH, OW = geom.out_hw(Hv, Wv)
     cd_p = pad_to(geom.cout, 8)
     assert CS == chan_pad(geom.cin, x.dtype), (CS, geom.cin)
-    wpk = _packed_cached(w, geom, 0, x.dtype)
+    wpk = _packed_cached(w, geom, 0, x.dtype, lo=w_lo)      # (w_lo: the low half of the weight pair, PairConvFn)
     if out is None:
         y = torch.empty((N, OH, OW, cd_p), dtype=out_dtype, device=x.device)
     else:                          # caller-provided destination
@@ -1104,6 +1104,47 @@ class ConvFn(torch.autograd.Function):
                     db = torch.zeros_like(db).index_copy(0, geom.perm_dev(db.device).long(), db)
                 db = db[: geom.cout]
         return dx, dw, db, None, None, None, None, None, None
+
+
+class PairConvFn(torch.autograd.Function):
+    """y = act(conv2d(x, w)) for an f32 x [N,H,W,C] at f32 GRADE on the 16-bit matrix pipeline (the precise trunk's COND_DNET,
+    df_gan.py:157-159,170-175): both operands as 16-bit pairs, x = xh + xl, w = wh + wl (`_packed_cached(lo=True)`), and the three
+    products that matter, conv(xh, wh) + conv(xl, wh) + conv(xh, wl) (the fourth is 2^-22 of the result), as three launches of the
+    16-bit kernel that accumulate in an f32 destination; the activation runs on the last one (XmcConvDesc.post_act).  Against the
+    exact-f32 MFMA kernel (1/16 of the rate): 0.77 -> ~0.3 ms per iteration for joint_conv.0.  The backward is the 16-bit layer's
+    (xh, wh): gradients keep the bars of the 16-bit modes."""
+
+    @staticmethod
+    def forward(ctx, x, w, geom, act):
+        dt = act_dtype()
+        assert x.dtype == torch.float32 and dt != torch.float32
+        x = x.contiguous()
+        xh = CastFn.apply(x, dt)
+        xl = CastFn.apply(x - xh.float(), dt)
+        y = _conv_fwd_raw(xh, w, None, geom, L.ACT_NONE, torch.float32)
+        y = _conv_fwd_raw(xl, w, None, geom, L.ACT_NONE, torch.float32, res=y)
+        y = _conv_fwd_raw(xh, w, None, geom, L.ACT_NONE, torch.float32, res=y, w_lo=True, post_act=act)
+        ctx.geom, ctx.act = geom, act
+        ctx.save_for_backward(xh, w, y if act != L.ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if dy is None:
+            return None, None, None, None
+        xh, w, y = ctx.saved_tensors
+        geom = ctx.geom
+        dy = dy.contiguous()
+        if ctx.act in (L.ACT_LRELU, L.ACT_RELU):
+            dy = MaskFn.apply(dy, y, 0.2 if ctx.act == L.ACT_LRELU else 0.0)
+        dy = CastFn.apply(dy, xh.dtype)
+        dx = CastFn.apply(ConvDgradFn.apply(dy, w, geom, (xh.shape[1], xh.shape[2]), xh.dtype), torch.float32) if ctx.needs_input_grad[0] else None
+        dw = ConvWgradFn.apply(xh, dy, geom).view(w.shape) if (ctx.needs_input_grad[1] and not _skip_wgrad()) else None
+        return dx, dw, None, None
+
+
+def pair_conv2d(x, w, geom, act=L.ACT_NONE):
+    return PairConvFn.apply(x, w, geom, act)
 
 
 class ConvDgradFn(torch.autograd.Function):

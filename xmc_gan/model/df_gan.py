@@ -212,7 +212,12 @@ class D_GET_LOGITS(nn.Module):
         c = ops.cast(_pad8(sent_embs), xh.dtype)
         c = c.view(B, 1, 1, -1).expand(B, xh.size(1), xh.size(2), c.size(-1))
         h_c_code = torch.cat((xh, c), 3)
-        m = self.joint_conv[0](h_c_code, act=ACT_LRELU)
+        j0 = self.joint_conv[0]
+        if h_c_code.dtype == torch.float32 and ops.act_dtype() != torch.float32 and not j0.spec_norm and j0.bias is None:
+            # precise trunk (the last block handed over an f32 map): f32 grade on the 16-bit matrix pipeline (ops.PairConvFn)
+            m = ops.pair_conv2d(h_c_code, j0.weight, j0.geom, ACT_LRELU)
+        else:
+            m = j0(h_c_code, act=ACT_LRELU)
         m = self.joint_conv[2](m, out_dtype=torch.float32)         # [B,1,1,8] f32, channel 0 is the logit (losses are f32)
         match = as_nchw_view(m[..., :1])
         return [match, out, sent_embs]
