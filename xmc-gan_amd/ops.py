@@ -866,76 +866,9 @@ def _pooled_take(dz):
     return dxp if same else None
 
 
-# ---- weight gradients on a SECOND stream (round 5).  A backward pass is a chain of data gradients -- each needs the one before --
-# with one weight gradient hanging off every link: nothing but the optimizer step reads a weight gradient.  Launched on one stream
-# they sit IN the chain: ~200 of the ~500 dependent launches of an iteration, each with its ramp, its tail of half-empty CUs and the
-# dependency gap in front of it.  With `wgrad_async` on, `_conv_wgrad_raw` (and the stem's table gradients) fork onto a side stream at
-# the point where their operands exist and the iteration joins once per backward (`wgrad_join`, before the gradients are reduced or
-# applied); under hipGraph capture the fork / join become graph edges, i.e. two branches the hardware schedules side by side.
-# Process-wide flags (the autograd engine runs backward nodes on its own threads).  Only where every parameter receives ONE gradient
-# contribution per backward (autograd's accumulation of a second one would read the first on the main stream): train_gan.gan_iteration
-# switches it on for DF_GEN + DF_DISC.
-_WGRAD_ASYNC = [False, False]       # [enabled, side stream holds un-joined work]
-_side_streams = {}
-
-
-class wgrad_async:
-    def __init__(self, on=True):
-        self.on = bool(on) and "no_wgrad_async" not in _DEBUG_DISPATCH
-
-    def __enter__(self):
-        self.prev = _WGRAD_ASYNC[0]
-        _WGRAD_ASYNC[0] = self.on
-        return self
-
-    def __exit__(self, *a):
-        wgrad_join()
-        _WGRAD_ASYNC[0] = self.prev
-        return False
-
-
-def wgrad_join():
-    """the current stream waits for the weight gradients launched on the side stream since the last join"""
-    if _WGRAD_ASYNC[1]:
-        cur = torch.cuda.current_stream()
-        cur.wait_stream(_side_streams[cur.device_index])
-        _WGRAD_ASYNC[1] = False
-
-
-class _on_side_stream:
-    """with-block: its launches go to the side stream, ordered after everything enqueued on the current stream so far"""
-
-    def __init__(self, ok=True):
-        self.on = _WGRAD_ASYNC[0] and ok
-
-    def __enter__(self):
-        if self.on:
-            cur = torch.cuda.current_stream()
-            side = _side_streams.get(cur.device_index)
-            if side is None:
-                side = _side_streams[cur.device_index] = torch.cuda.Stream(device=cur.device)
-            side.wait_stream(cur)
-            self.ctx = torch.cuda.stream(side)
-            self.ctx.__enter__()
-            _WGRAD_ASYNC[1] = True
-        return self
-
-    def __exit__(self, *a):
-        if self.on:
-            self.ctx.__exit__(*a)
-        return False
-
-
 def _conv_wgrad_raw(x, dy, geom, scale=None, up=False, want_bias=False, bias_dot=None, dot=None):
     """gw [Co,Ci,k,k] f32 from x [N,H,W,cs_p], dy [N,OH,OW,cd_p] (and the bias gradient [cd_p] f32 from the same launch).
     ``bias_dot`` (f32 [>= cout]) / ``dot`` (f32 [1]): dot += <bias_dot, unscaled bias gradient> (xmc_unpack_wgrad_bias_dot)."""
-    # (a staged mask may have to be materialised for BOTH of its consumers, the other one on the main stream; a row permutation is
-    # undone by the caller with framework ops on the main stream)
-    with _on_side_stream(not isinstance(dy, _StagedMask) and geom.row_perm is None):
-        return _conv_wgrad_raw_(x, dy, geom, scale, up, want_bias, bias_dot, dot)
-
-
-def _conv_wgrad_raw_(x, dy, geom, scale=None, up=False, want_bias=False, bias_dot=None, dot=None):
     staged = dy if isinstance(dy, _StagedMask) else None        # dy x LeakyReLU'(bits), masked where the kernel stages it
     if staged is not None:
         dy = staged.dy
@@ -2127,9 +2060,8 @@ class DStemBlockFn(torch.autograd.Function):
             return (dx, None, None, None, dw2, None, None, dgamma) + (None,) * 5
         # gradients of the composed weights (every pixel) and of the border corrections (border pixels of h1), then back through the
         # composition to the five parameters
-        with _on_side_stream(all(t.dtype == torch.float32 for t in (w_img, b_img, w0, ws))):
-            tabs = _dstem_wgrad_raw(xin, gh, dout)
-            dwi, dbi, dw0, dws, dbs = _dstem_compose_bwd_raw(w_img, b_img, w0, ws, bs, *tabs)
+        tabs = _dstem_wgrad_raw(xin, gh, dout)
+        dwi, dbi, dw0, dws, dbs = _dstem_compose_bwd_raw(w_img, b_img, w0, ws, bs, *tabs)
         dwi, dw0, dws = dwi.view(w_img.shape), dw0.view(w0.shape), dws.view(ws.shape)
         return (dx, dwi.to(w_img.dtype), dbi.to(b_img.dtype), dw0.to(w0.dtype), dw2, dws.to(ws.dtype),
                 None if dbs is None else dbs.to(bs.dtype), dgamma) + (None,) * 5

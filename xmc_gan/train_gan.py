@@ -150,12 +150,6 @@ def gan_iteration(netG, netD, optimizerG, optimizerD, imgs, sent_embs, words_emb
     Returns a dict of 0-d loss tensors (no host sync).  ``it_state['i']`` carries the N_CRITIC counter.
     """
     opts = opts or StepOptions()
-    # weight gradients on a second stream (ops.wgrad_async): where every parameter receives one gradient contribution per backward
-    with ops.wgrad_async(type(netG) is DF_GEN and type(netD) is DF_DISC and not cfg.DISC.SPEC_NORM and ops.fused_blocks()):
-        return _gan_iteration(netG, netD, optimizerG, optimizerD, imgs, sent_embs, words_embs, mask, noise, it_state, opts)
-
-
-def _gan_iteration(netG, netD, optimizerG, optimizerD, imgs, sent_embs, words_embs, mask, noise, it_state, opts):
     T, E = cfg.TRAIN, cfg.TRAIN.ENCODER_LOSS
     batch_size = mask.size(0)
     ops.new_iteration(imgs.device)                 # one memset for all weight-gradient scratch of this iteration
@@ -231,7 +225,6 @@ def _gan_iteration(netG, netD, optimizerG, optimizerD, imgs, sent_embs, words_em
     # of them is inf / NaN (after the all-reduce, so every rank decides alike).  None in the other modes.
     sc_d = ops.loss_scaler("D", imgs.device)
     (sc_d.scale(errD) if sc_d is not None else errD).backward()
-    ops.wgrad_join()
     parallel.allreduce_mean_grads(netD.parameters())
     _step(optimizerD, sc_d)
     out.update(errD=errD.detach(), errD_real=errD_real.detach(), errD_fake=errD_fake.detach())
@@ -258,7 +251,6 @@ def _gan_iteration(netG, netD, optimizerG, optimizerD, imgs, sent_embs, words_em
         optimizerG.zero_grad()
         sc_gp = ops.loss_scaler("GP", imgs.device)
         (sc_gp.scale(d_loss) if sc_gp is not None else d_loss).backward()
-        ops.wgrad_join()
         # the reference's autograd hands zero (not None) grads to every bias that feeds the logit
         # (their only path is through LeakyReLU'' == 0), which still advances Adam's moments/step.
         for name, p_ in netD.named_parameters():
@@ -299,7 +291,6 @@ def _gan_iteration(netG, netD, optimizerG, optimizerD, imgs, sent_embs, words_em
             netD.zero_grad()
             sc_g = ops.loss_scaler("G", imgs.device)
             (sc_g.scale(errG) if sc_g is not None else errG).backward()
-            ops.wgrad_join()
         finally:
             _set_requires_grad(netD, True)
         parallel.allreduce_mean_grads(netG.parameters())
