@@ -95,11 +95,23 @@ def pmc_traffic_lookup(imsize, batch, cfg_name, precision):
     doubled as MI355X_MICROARCH.md prescribes for gfx950; made by profiles/summarize.py).  Counters cannot be read from
     inside the process, so the figure is None for workloads without a committed summary."""
     import csv
-    path = next((q for q in (os.path.join(ROOT, "profiles", f"r{r:02d}_pmc_hbm_traffic_{imsize}px_b{batch}.csv") for r in (4, 3))
+    path = next((q for q in (os.path.join(ROOT, "profiles", f"r{r:02d}_pmc_hbm_traffic_{imsize}px_b{batch}.csv") for r in (5, 4, 3))
                  if os.path.exists(q)), None)
     if cfg_name != "df_gan_damsm_nomagp.yml" or precision != "bf16" or path is None:
         return None
     rows = list(csv.DictReader(open(path)))
+    # the summary was collected on an earlier build: say so when it names kernels the library no longer contains
+    import re
+    from xmc_gan_amd import lib as L
+    try:
+        blob = open(L.LIB_PATH, "rb").read()
+        names = {m.group(1) for r in rows if "at::" not in r["kernel"] for m in [re.search(r"(?:\(anonymous namespace\)::)?([A-Za-z_][A-Za-z0-9_]*_kernel)\b", r["kernel"])] if m}
+        gone = sorted(n for n in names if n.encode() not in blob)
+        if gone:
+            print(f"[bench] {os.path.basename(path)} names kernels that are not in {os.path.basename(L.LIB_PATH)} any more: {gone}; "
+                  "`roofline.traffic` may be stale (re-collect with profiles/collect_r05.sh)", file=sys.stderr)
+    except OSError:
+        pass
 
     def lookup(kernel):
         # the library reports a kernel without trailing default template arguments; instantiations that differ only in the
@@ -471,7 +483,10 @@ def main():
         out["dist"] = dict(backend=(torch.distributed.get_backend() if dist_on else None), world_size=world,
                            process_group=bool(dist_on), forced_at_world_1=bool(a.force_dp),
                            rccl_version=(".".join(map(str, torch.cuda.nccl.version())) if dist_on and backend == "nccl" else None),
-                           collectives_per_iteration=(graphed.seams_per_iteration() if graphed is not None else None))
+                           collectives_per_iteration=(graphed.seams_per_iteration() if graphed is not None else None),
+                           # host time inside one collective call at replay (RCCL: the enqueue; gloo: the whole exchange), rank 0
+                           seam_host_ms=(round(1e3 * graphed.seam_host_s[0] / graphed.seam_host_s[1], 4)
+                                         if graphed is not None and graphed.seam_host_s[1] else None))
         if not a.no_cpu_baseline and world == 1:       # the CPU leg is timed on rank 0 of the single-GPU run only
             out["cpu_baseline"] = cpu_baseline(cfg, a.cfg, S)
     # free the timed run's networks, graphs and pools before the side legs

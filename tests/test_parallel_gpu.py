@@ -47,3 +47,37 @@ def test_two_gloo_ranks_on_one_card_equal_single_process_references(tmp_path):
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank: this box has fewer than two")
 def test_two_rccl_ranks_equal_single_process_references(tmp_path):
     _rehearse("nccl", 2, tmp_path)
+
+
+def _bench(args, env_extra, timeout=600):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=timeout)
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert r.returncode == 0 and line, (r.stdout[-1500:], r.stderr[-3000:])
+    return json.loads(line[-1])
+
+
+def test_bench_launches_two_ranks_itself_and_reports_the_job():
+    """`python bench.py --gpus 2` without a launcher (the path the driver's N > 1 runs take when it calls the script directly): the
+    script starts its ranks as a child `torch.distributed.run`, one process per GPU; here two gloo ranks share the one card
+    (XMC_DIST_BACKEND=gloo).  The line must describe the JOB: n_gpus 2, global batch 2 x per-GPU batch, the collectives of an
+    iteration as graph seams (D gradients, G gradients: 2; with all-gathered negatives 4 gathers in the D step + 8 in the G step
+    more), their host time, and an aggregate rate of the order of the one-rank rate (two ranks time-share one card)."""
+    common = ["--steps", "6", "--warmup", "2", "--workload", "config2", "--batch", "32", "--no_parity", "--no_alt_precision", "--no_entrypoint",
+              "--no_cpu_baseline", "--no_roofline"]
+    one = _bench(["--gpus", "1"] + common, {})
+    two = _bench(["--gpus", "2"] + common, {"XMC_DIST_BACKEND": "gloo"})
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["config"]["global_batch"] == 64 and two["config"]["parallelism"] == "dp2"
+    d = two["dist"]
+    assert d["backend"] == "gloo" and d["world_size"] == 2 and d["process_group"]
+    assert d["collectives_per_iteration"] == {"g_step": 2}, d
+    assert d["seam_host_ms"] is not None and d["seam_host_ms"] > 0
+    assert one["dist"]["collectives_per_iteration"] in (None, {"g_step": 0})
+    ratio = two["value"] / one["value"]
+    print(f"\n[bench --gpus 2, gloo, one card] {two['value']:.0f} images/s against {one['value']:.0f} on one rank (x{ratio:.2f}); "
+          f"{d['collectives_per_iteration']} collectives per iteration, {d['seam_host_ms']} ms of host time each")
+    assert 0.35 <= ratio <= 1.3, ratio
+    gat = _bench(["--gpus", "2", "--gather_negatives"] + common, {"XMC_DIST_BACKEND": "gloo"})
+    assert gat["config"]["parallelism"] == "dp2+gather" and gat["dist"]["collectives_per_iteration"]["g_step"] > 2, gat["dist"]

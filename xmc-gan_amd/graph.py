@@ -12,6 +12,8 @@ the pool, hence at fixed addresses) eagerly on the same stream, and opens the ne
 calls the recorded collectives in the recorded order: 3-4 graph launches and 2-3 collective calls of host work per iteration
 instead of ~1 k kernel launches, for any number of ranks.
 """
+import time
+
 import torch
 
 from . import ops
@@ -49,6 +51,7 @@ class GraphedIteration:
         self._seq = None
         self._pack_serial = None    # ops' pack-entry counter when the last capture ended
         self._counted = 0           # captures ops counts as alive on our behalf
+        self.seam_host_s = [0.0, 0]  # host time spent inside the collectives' calls at replay [seconds, calls] (bench.py `dist`)
 
     def close(self):
         """drop the graphs; lets ops release the packed-weight buffers it kept alive for their replays"""
@@ -88,9 +91,15 @@ class GraphedIteration:
         self._cur = None
 
     def _seam(self, fn):
+        acc = self.seam_host_s
+
         def eager():                 # replays run outside the autograd context the collective was first issued in
+            t0 = time.perf_counter()
             with torch.no_grad():
-                return fn()
+                out = fn()
+            acc[0] += time.perf_counter() - t0
+            acc[1] += 1
+            return out
         self._end()
         out = eager()
         self._seq.append(eager)
