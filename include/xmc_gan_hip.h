@@ -43,7 +43,9 @@ extern "C" {
  *     xmc_concept_query_fwd_multi / _bwd_multi (every sampler stage's sentence query in one launch);
  *     xmc_concept_head_fwd_pre / _bwd_pre, xmc_concept_outer_multi (the heads' sentence products of all stages as one GEMM / one batch product).
  * 12: XmcConvDesc.wpk_lo, XmcPackJob.lo, xmc_conv_pw1x1_split (a learned shortcut's 1x1 convolution on weights held as a 16-bit
- *     hi + lo pair: the precise trunk of the IEEE-half mode). */
+ *     hi + lo pair: the precise trunk of the IEEE-half mode);
+ *     xmc_gvec_fwd / _bwd, xmc_reasoner_fwd / _bwd, xmc_word_ctx_fwd / _bwd, xmc_word_keys_fwd / _bwd (the per-concept algebra of the
+ *     word-attention generators, model/concept_gan.py). */
 #define XMC_ABI_VERSION 12
 
 /* XMC_BF16 names the 16-bit storage / MFMA-operand format THIS BUILD of the library was compiled for: bf16 in
@@ -411,6 +413,30 @@ int xmc_attn_pool_bwd_acc(const void* key, const float* q, const void* x, const 
                           float* dq, void* dkey, void* dx, const void* dx_in, int N, int HW, int ncon, int pk, int px, float scale,
                           int dtype, void* stream);
 
+/* ---- per-concept algebra of the word-attention generators (model/concept_gan.py; C = 16 concepts, P = 4 state channels, f32) ----
+ * Grouped 1x1 convolution of a per-sample vector: y[b,g,o] = bias[g,o] + sum_{i<Is} W[g,o,i] xs[b,i] + sum_{i<Ig} W[g,o,Is+i] xg[b,g,i],
+ * W [G][O][Is+Ig]: the gamma / beta heads on cat(global condition, context) without the concatenation (concept_gan.py:346-371,404-418),
+ * the samplers' query / value projections (545-580; Is = 0).  bwd: any of dxs / dxg / dW / dbias may be NULL. */
+int xmc_gvec_fwd(const float* xs, const float* xg, const float* W, const float* bias, float* y, int B, int G, int O, int Is, int Ig, void* stream);
+int xmc_gvec_bwd(const float* xs, const float* xg, const float* W, const float* dy, float* dxs, float* dxg, float* dW, float* dbias,
+                 int B, int G, int O, int Is, int Ig, void* stream);
+/* ConceptReasoner (concept_gan.py:632-654) on x [B,16,4]: adj = tanh(x We^T), pre = x + adj x, [BatchNorm1d(16) over (batch, state)], relu.
+ * bn_w NULL: no normalisation.  training: batch statistics, running statistics updated (momentum, unbiased variance); else the running
+ * ones.  y NULL: statistics only (upstream's discarded call, 432).  pre [B,16,4] and stat [32] = (mean, rstd) are kept for the backward. */
+int xmc_reasoner_fwd(const float* x, const float* We, const float* bn_w, const float* bn_b, float* run_mean, float* run_var, int training,
+                     float momentum, float eps, float* y, float* pre, float* stat, int B, void* stream);
+int xmc_reasoner_bwd(const float* x, const float* We, const float* bn_w, const float* bn_b, const float* pre, const float* stat, int batch_stats,
+                     const float* dy, float* dx, float* dWe, float* dbn_w, float* dbn_b, int B, void* stream);
+/* OutConceptBlock.get_context_embs (concept_gan.py:374-394): st [B,16,4] L2-normalised over the CONCEPT axis, w [B,T,4] over the state axis,
+ * cosine scores, masked_fill(pad, -inf), softmax over T (<= 32), ctx = p wd -> [B,16,4]; prob [B,16,T] is kept for the backward.  A caption
+ * of padding only gives NaN, as torch.softmax does. */
+int xmc_word_ctx_fwd(const float* st, const float* w, const unsigned char* pad, float* ctx, float* prob, int B, int T, void* stream);
+int xmc_word_ctx_bwd(const float* st, const float* w, const float* prob, const float* dctx, float* dst, float* dw, int B, int T, void* stream);
+/* CondConceptSampler's keys (concept_gan.py:566-575): kraw [B,T,64] (channel = concept * 4 + state) -> [GroupNorm(16) over (state, word)] ->
+ * L2 normalisation over the state axis -> kh [B,16,T,4]; stat [B,16,2] = (mean, rstd).  dgnw / dgnb [64] are ACCUMULATED (hand over zeros). */
+int xmc_word_keys_fwd(const float* kraw, const float* gnw, const float* gnb, float eps, float* kh, float* stat, int B, int T, void* stream);
+int xmc_word_keys_bwd(const float* kraw, const float* gnw, const float* gnb, const float* stat, const float* dkh, float* dkraw, float* dgnw,
+                      float* dgnb, int B, int T, void* stream);
 /* Word-region attention pooling of the word-attention generator concept_gan.InNetG (reference model/concept_gan.py
  * CondConceptSampler.get_context_embs 532-555; the class is repaired here): every region's query attends over the caption's
  * words.  qmap [N][HW][16*4] (dtype), the grouped 1x1 query projection after its GroupNorm; kh f32 [N][16][T][4], the per-concept word

@@ -1565,3 +1565,138 @@ def test_integration_doc_snippet_runs_as_written():
     ref = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), w.to(torch.bfloat16).float(), b, padding=1).permute(0, 2, 3, 1)
     assert y.shape == (2, 16, 16, 24) and y.dtype == torch.bfloat16
     assert ((y.float() - ref).norm() / ref.norm()).item() < 5e-3
+
+
+# ------------------------------------------------------------------------------------------ per-concept algebra (csrc/concept_word.hip, row a16)
+def _close64(got, ref, tol=2e-5, what=""):
+    got, ref = got.detach().double().cpu(), ref.detach().double()
+    assert torch.equal(torch.isnan(got), torch.isnan(ref)), what
+    m = ~torch.isnan(ref)
+    err = (got[m] - ref[m]).norm() / ref[m].norm().clamp_min(1e-30)
+    assert err <= tol, (what, err.item())
+    return err.item()
+
+
+@pytest.mark.parametrize("B,Is,Ig,O,bias", [(5, 356, 4, 8, True), (64, 0, 8, 4, False), (3, 0, 8, 4, True), (16, 356, 4, 8, False)])
+def test_grouped_vector_convolution(B, Is, Ig, O, bias):
+    """xmc_gvec_fwd / _bwd vs the reference's nn.Conv2d(groups=16) on cat(global condition, context) (concept_gan.py:346-371,404-418) in f64"""
+    G = 16
+    g = torch.Generator().manual_seed(B + Is)
+    xs = torch.randn(B, Is, generator=g, dtype=torch.float64) if Is else None
+    xg = torch.randn(B, G, Ig, generator=g, dtype=torch.float64)
+    W = torch.randn(G * O, Is + Ig, 1, 1, generator=g, dtype=torch.float64) * 0.1
+    bs = torch.randn(G * O, generator=g, dtype=torch.float64) if bias else None
+    leaves = [t.clone().requires_grad_() for t in (xs, xg, W, bs) if t is not None]
+    it = iter(leaves)
+    xs_r = next(it) if xs is not None else None
+    xg_r, W_r = next(it), next(it)
+    bs_r = next(it) if bias else None
+    cond = xg_r if xs_r is None else torch.cat([xs_r.view(B, 1, Is).expand(B, G, Is), xg_r], 2)
+    ref = F.conv2d(cond.reshape(B, G * (Is + Ig), 1, 1), W_r, bs_r, groups=G).view(B, G, O)
+    dy = torch.randn(B, G, O, generator=g, dtype=torch.float64)
+    ref.backward(dy)
+    dev = [None if t is None else t.float().to(DEV).requires_grad_() for t in (xs, xg, W, bs)]
+    out = ops.grouped_vec(dev[0], dev[1], dev[2], dev[3], G)
+    _close64(out, ref, what="forward")
+    out.backward(dy.float().to(DEV))
+    for name, d, r in (("xs", dev[0], xs_r), ("xg", dev[1], xg_r), ("W", dev[2], W_r), ("bias", dev[3], bs_r)):
+        if d is not None:
+            _close64(d.grad, r.grad, what=name)
+
+
+@pytest.mark.parametrize("B", [1, 8, 300])
+@pytest.mark.parametrize("bn_mode", ["none", "train", "eval"])
+def test_concept_reasoner_with_batchnorm1d(B, bn_mode):
+    """xmc_reasoner_fwd / _bwd vs concept_gan.ConceptReasoner (632-654) in f64: tanh adjacency, x + adj x, nn.BatchNorm1d(16) in training
+    (batch statistics + running-statistics update) and in evaluation mode, relu; the whole batch in one launch."""
+    g = torch.Generator().manual_seed(B)
+    x = torch.randn(B, 16, 4, generator=g, dtype=torch.float64)
+    We = torch.randn(16, 4, generator=g, dtype=torch.float64) * 0.5
+    bn64 = torch.nn.BatchNorm1d(16).double()
+    with torch.no_grad():
+        bn64.weight.copy_(torch.rand(16, generator=g, dtype=torch.float64) + 0.5)
+        bn64.bias.copy_(torch.randn(16, generator=g, dtype=torch.float64) * 0.3)
+        bn64.running_mean.copy_(torch.randn(16, generator=g, dtype=torch.float64) * 0.1)
+        bn64.running_var.copy_(torch.rand(16, generator=g, dtype=torch.float64) + 0.5)
+    bn64.train(bn_mode == "train")
+    bn32 = torch.nn.BatchNorm1d(16).to(DEV)
+    bn32.load_state_dict({k: v.float() if v.is_floating_point() else v for k, v in bn64.state_dict().items()})
+    bn32.train(bn_mode == "train")
+    if B == 1 and bn_mode == "train":
+        pytest.skip("nn.BatchNorm1d refuses a single value per channel only when B * L == 1; B = 1 has L = 4 values, but the unbiased "
+                    "variance of the running update is what differs -- covered by B = 8")
+    xr, Wr = x.clone().requires_grad_(), We.clone().requires_grad_()
+    adj = torch.tanh(F.linear(xr, Wr))
+    pre = xr + torch.matmul(adj, xr)
+    ref = F.relu(bn64(pre) if bn_mode != "none" else pre)
+    dy = torch.randn(B, 16, 4, generator=g, dtype=torch.float64)
+    ref.backward(dy)
+    xd, Wd = x.float().to(DEV).requires_grad_(), We.float().to(DEV).requires_grad_()
+    out = ops.reasoner(xd, Wd, bn32 if bn_mode != "none" else None)
+    _close64(out, ref, what="forward")
+    out.backward(dy.float().to(DEV))
+    _close64(xd.grad, xr.grad, 5e-5, "dx")
+    _close64(Wd.grad, Wr.grad, 5e-5, "dWe")
+    if bn_mode != "none":
+        _close64(bn32.weight.grad, bn64.weight.grad, 5e-5, "d bn.weight")
+        _close64(bn32.bias.grad, bn64.bias.grad, 5e-5, "d bn.bias")
+        _close64(bn32.running_mean, bn64.running_mean, what="running_mean")
+        _close64(bn32.running_var, bn64.running_var, what="running_var")
+        assert int(bn32.num_batches_tracked) == int(bn64.num_batches_tracked)
+
+
+@pytest.mark.parametrize("B,T,case", [(6, 20, "ragged"), (4, 1, "single word"), (5, 15, "one caption all padding"), (3, 32, "no padding")])
+def test_masked_word_attention_of_the_concepts(B, T, case):
+    """xmc_word_ctx_fwd / _bwd vs OutConceptBlock.get_context_embs (concept_gan.py:374-394) in f64: states normalised over the CONCEPT
+    axis, words over the state axis, masked_fill(-inf), softmax over T.  Padding words receive exactly zero gradient; a caption of
+    padding only gives NaN in the same places as torch.softmax of an all -inf row; T = 1."""
+    g = torch.Generator().manual_seed(T)
+    st = torch.randn(B, 16, 4, generator=g, dtype=torch.float64)
+    w = torch.randn(B, T, 4, generator=g, dtype=torch.float64)
+    lens = torch.randint(1, T + 1, (B,), generator=g)
+    if case == "no padding":
+        lens[:] = T
+    mask = torch.arange(T)[None, :] >= lens[:, None]
+    if case == "one caption all padding":
+        mask[1, :] = True
+    sr, wr = st.clone().requires_grad_(), w.clone().requires_grad_()
+    sn, wd = F.normalize(sr, p=2, dim=1), F.normalize(wr, p=2, dim=2)
+    sim = torch.matmul(sn, wd.transpose(1, 2)).masked_fill(mask.view(B, 1, -1), float("-inf"))
+    ref = torch.matmul(torch.softmax(sim, dim=2), wd)
+    dy = torch.randn(B, 16, 4, generator=g, dtype=torch.float64)
+    ref.backward(dy)
+    sd, wdv = st.float().to(DEV).requires_grad_(), w.float().to(DEV).requires_grad_()
+    out = ops.word_context(sd, wdv, mask.to(DEV))
+    _close64(out, ref, what="forward")
+    out.backward(dy.float().to(DEV))
+    ok = ~torch.isnan(ref).flatten(1).any(1)                                       # samples whose caption has at least one word
+    _close64(sd.grad[ok.to(DEV)], sr.grad[ok], 5e-5, "d state")
+    _close64(wdv.grad[ok.to(DEV)], wr.grad[ok], 5e-5, "d words")
+    assert (wdv.grad.cpu()[ok][mask[ok]] == 0).all()                               # padding words: exactly zero
+    if case == "one caption all padding":
+        assert torch.isnan(out[1]).all() and not torch.isnan(out[0]).any()
+
+
+@pytest.mark.parametrize("B,T,norm", [(5, 20, True), (2, 1, True), (7, 15, False)])
+def test_word_keys_groupnorm_and_normalisation(B, T, norm):
+    """xmc_word_keys_fwd / _bwd vs CondConceptSampler's key path (concept_gan.py:566-575) in f64: [B,64,T] -> GroupNorm(16, 64) over
+    (state, word) -> L2 normalisation over the state axis -> [B,16,T,4]"""
+    g = torch.Generator().manual_seed(B * T)
+    kraw = torch.randn(B, T, 64, generator=g, dtype=torch.float64)
+    gw, gb = torch.rand(64, generator=g, dtype=torch.float64) + 0.5, torch.randn(64, generator=g, dtype=torch.float64) * 0.2
+    kr, gwr, gbr = kraw.clone().requires_grad_(), gw.clone().requires_grad_(), gb.clone().requires_grad_()
+    k = kr.transpose(1, 2)
+    if norm:
+        k = F.group_norm(k, 16, gwr, gbr, 1e-5)
+    ref = F.normalize(k.reshape(B, 16, 4, T), p=2, dim=2).permute(0, 1, 3, 2)
+    dy = torch.randn(B, 16, T, 4, generator=g, dtype=torch.float64)
+    ref.backward(dy)
+    kd = kraw.float().to(DEV).requires_grad_()
+    gwd, gbd = gw.float().to(DEV).requires_grad_(), gb.float().to(DEV).requires_grad_()
+    out = ops.word_keys(kd, gwd if norm else None, gbd if norm else None, 1e-5)
+    _close64(out, ref, what="forward")
+    out.backward(dy.float().to(DEV))
+    _close64(kd.grad, kr.grad, 1e-4, "d kraw")
+    if norm:
+        _close64(gwd.grad, gwr.grad, 5e-5, "d gn.weight")
+        _close64(gbd.grad, gbr.grad, 5e-5, "d gn.bias")

@@ -116,6 +116,14 @@ _SIGS = {
     "xmc_attn_pool_bwd_acc": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp],
     "xmc_word_pool_fwd": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "xmc_word_pool_bwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "xmc_gvec_fwd": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "xmc_gvec_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "xmc_reasoner_fwd": [vp, vp, vp, vp, vp, vp, i32, f32, f32, vp, vp, vp, i32, vp],
+    "xmc_reasoner_bwd": [vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, i32, vp],
+    "xmc_word_ctx_fwd": [vp, vp, vp, vp, vp, i32, i32, vp],
+    "xmc_word_ctx_bwd": [vp, vp, vp, vp, vp, vp, i32, i32, vp],
+    "xmc_word_keys_fwd": [vp, vp, vp, f32, vp, vp, i32, i32, vp],
+    "xmc_word_keys_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
     "xmc_contrastive_ws_bytes": [i32, i32],
     "xmc_contrastive_fwd": [vp, vp, vp, vp, i32, i32, vp, vp, vp],
     "xmc_contrastive_bwd": [vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp],

@@ -3037,6 +3037,169 @@ def concept_head(pooled, sent, params):
     return ConceptHeadFn.apply(pooled, sent, *params)
 
 
+# ------------------------------------------------------------------------------------------ per-concept algebra of the word-attention generators
+# (csrc/concept_word.hip; model/concept_gan.py).  First-order nodes (the generator path is never differentiated twice).
+def _f32c(t):
+    return None if t is None else t.detach().contiguous().float()
+
+
+class GroupedVecFn(torch.autograd.Function):
+    """y[b,g,o] = bias[g,o] + W[g,o,:Is] . xs[b] + W[g,o,Is:] . xg[b,g]: a grouped 1x1 convolution of a per-sample vector whose
+    groups share the first Is inputs (the gamma / beta heads on cat(global condition, context), concept_gan.py:346-371,404-418;
+    Is = 0: the samplers' query / value projections).  xs [B,Is] or None, xg [B,G,Ig] or None, W [G*O, Is+Ig(,1,1)], bias [G*O] or None."""
+
+    @staticmethod
+    def forward(ctx, xs, xg, W, bias, G):
+        xs_, xg_, W_ = _f32c(xs), _f32c(xg), _f32c(W).view(W.shape[0], -1)
+        B = (xs_ if xs_ is not None else xg_).shape[0]
+        Is, Ig = (0 if xs_ is None else xs_.shape[1]), (0 if xg_ is None else xg_.shape[2])
+        O = W_.shape[0] // G
+        assert W_.shape[1] == Is + Ig and W_.shape[0] == G * O
+        _need_cuda(W_, xs_, xg_)
+        y = torch.empty((B, G, O), dtype=torch.float32, device=W_.device)
+        L.call("xmc_gvec_fwd", _p(xs_), _p(xg_), _p(W_), _p(_f32c(bias)), _p(y), B, G, O, Is, Ig, _st())
+        ctx.dims = (B, G, O, Is, Ig)
+        ctx.wshape = W.shape
+        ctx.save_for_backward(xs_, xg_, W_)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        xs_, xg_, W_ = ctx.saved_tensors
+        B, G, O, Is, Ig = ctx.dims
+        dy = dy.contiguous().float()
+        need = ctx.needs_input_grad
+        dxs = torch.empty_like(xs_) if (need[0] and Is) else None
+        dxg = torch.empty_like(xg_) if (need[1] and Ig) else None
+        dW = torch.empty_like(W_) if need[2] else None
+        db = torch.empty(G * O, dtype=torch.float32, device=dy.device) if need[3] else None
+        L.call("xmc_gvec_bwd", _p(xs_), _p(xg_), _p(W_), _p(dy), _p(dxs), _p(dxg), _p(dW), _p(db), B, G, O, Is, Ig, _st())
+        return dxs, dxg, (None if dW is None else dW.view(ctx.wshape)), db, None
+
+
+def grouped_vec(xs, xg, W, bias, groups):
+    return GroupedVecFn.apply(xs, xg, W, bias, groups)
+
+
+class ReasonerFn(torch.autograd.Function):
+    """concept_gan.ConceptReasoner (632-654): relu(BatchNorm1d(x + tanh(x We^T) x)) on x [B,16,4]; ``bn`` = (weight, bias, running_mean,
+    running_var, training, momentum, eps) or None.  Training mode updates the running statistics in place like nn.BatchNorm1d."""
+
+    @staticmethod
+    def forward(ctx, x, We, bn_w, bn_b, run_mean, run_var, training, momentum, eps):
+        x_, We_ = _f32c(x), _f32c(We)
+        B = x_.shape[0]
+        assert tuple(x_.shape[1:]) == (16, 4) and tuple(We_.shape) == (16, 4)
+        _need_cuda(x_, We_)
+        y, pre = torch.empty_like(x_), torch.empty_like(x_)
+        stat = torch.empty(32, dtype=torch.float32, device=x_.device)
+        L.call("xmc_reasoner_fwd", _p(x_), _p(We_), _p(_f32c(bn_w)), _p(_f32c(bn_b)), _p(run_mean), _p(run_var), int(bool(training)),
+               float(momentum), float(eps), _p(y), _p(pre), _p(stat), B, _st())
+        ctx.batch_stats = bool(training) and bn_w is not None
+        ctx.save_for_backward(x_, We_, _f32c(bn_w), _f32c(bn_b), pre, stat)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        x_, We_, bw, bb, pre, stat = ctx.saved_tensors
+        B = x_.shape[0]
+        dy = dy.contiguous().float()
+        need = ctx.needs_input_grad
+        dx = torch.empty_like(x_) if need[0] else None
+        dWe = torch.empty_like(We_) if need[1] else None
+        dbw = torch.empty(16, dtype=torch.float32, device=dy.device) if (bw is not None and need[2]) else None
+        dbb = torch.empty(16, dtype=torch.float32, device=dy.device) if (bw is not None and need[3]) else None
+        L.call("xmc_reasoner_bwd", _p(x_), _p(We_), _p(bw), _p(bb), _p(pre), _p(stat), int(ctx.batch_stats), _p(dy), _p(dx), _p(dWe), _p(dbw),
+               _p(dbb), B, _st())
+        return dx, dWe, dbw, dbb, None, None, None, None, None
+
+
+def reasoner(x, We, bn=None):
+    if bn is None:
+        return ReasonerFn.apply(x, We, None, None, None, None, False, 0.0, 1e-5)
+    if bn.training:
+        with torch.no_grad():
+            bn.num_batches_tracked += 1
+    return ReasonerFn.apply(x, We, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, bn.momentum, bn.eps)
+
+
+def reasoner_stats_only(x, We, bn):
+    """upstream's discarded reasoner call (concept_gan.py:432): all that survives is the BatchNorm1d running-statistics update"""
+    x_, We_ = _f32c(x), _f32c(We)
+    pre = torch.empty_like(x_)
+    L.call("xmc_reasoner_fwd", _p(x_), _p(We_), _p(_f32c(bn.weight)), _p(_f32c(bn.bias)), _p(bn.running_mean), _p(bn.running_var), 1,
+           float(bn.momentum), float(bn.eps), None, _p(pre), None, x_.shape[0], _st())
+    with torch.no_grad():
+        bn.num_batches_tracked += 1
+
+
+class WordContextFn(torch.autograd.Function):
+    """OutConceptBlock.get_context_embs (concept_gan.py:374-394): state [B,16,4], words [B,T,4], mask [B,T] (True = padding) -> [B,16,4]."""
+
+    @staticmethod
+    def forward(ctx, state, words, mask):
+        st_, w_ = _f32c(state), _f32c(words)
+        B, T = w_.shape[0], w_.shape[1]
+        assert tuple(st_.shape) == (B, 16, 4) and w_.shape[2] == 4
+        _need_cuda(st_, w_)
+        pad = mask.to(torch.uint8).contiguous()
+        out = torch.empty_like(st_)
+        prob = torch.empty((B, 16, T), dtype=torch.float32, device=st_.device)
+        L.call("xmc_word_ctx_fwd", _p(st_), _p(w_), _p(pad), _p(out), _p(prob), B, T, _st())
+        ctx.save_for_backward(st_, w_, prob)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dctx):
+        st_, w_, prob = ctx.saved_tensors
+        B, T = w_.shape[0], w_.shape[1]
+        dctx = dctx.contiguous().float()
+        dst = torch.empty_like(st_) if ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(w_) if ctx.needs_input_grad[1] else None
+        L.call("xmc_word_ctx_bwd", _p(st_), _p(w_), _p(prob), _p(dctx), _p(dst), _p(dw), B, T, _st())
+        return dst, dw, None
+
+
+def word_context(state, words, mask):
+    return WordContextFn.apply(state, words, mask)
+
+
+class WordKeysFn(torch.autograd.Function):
+    """CondConceptSampler's keys (concept_gan.py:566-575): kraw [B,T,64] -> [GroupNorm(16, 64) over (state, word)] -> normalised over the
+    state axis -> [B,16,T,4]."""
+
+    @staticmethod
+    def forward(ctx, kraw, gnw, gnb, eps):
+        k_ = _f32c(kraw)
+        B, T = k_.shape[0], k_.shape[1]
+        assert k_.shape[2] == 64
+        _need_cuda(k_)
+        kh = torch.empty((B, 16, T, 4), dtype=torch.float32, device=k_.device)
+        stat = torch.empty((B, 16, 2), dtype=torch.float32, device=k_.device) if gnw is not None else None
+        L.call("xmc_word_keys_fwd", _p(k_), _p(_f32c(gnw)), _p(_f32c(gnb)), float(eps), _p(kh), _p(stat), B, T, _st())
+        ctx.save_for_backward(k_, _f32c(gnw), _f32c(gnb), stat)
+        return kh
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dkh):
+        k_, gw, gb, stat = ctx.saved_tensors
+        B, T = k_.shape[0], k_.shape[1]
+        dkh = dkh.contiguous().float()
+        dk = torch.empty_like(k_)
+        dgw = _zeros_f32_out(64, k_.device) if (gw is not None and ctx.needs_input_grad[1]) else None
+        dgb = _zeros_f32_out(64, k_.device) if (gw is not None and ctx.needs_input_grad[2]) else None
+        L.call("xmc_word_keys_bwd", _p(k_), _p(gw), _p(gb), _p(stat), _p(dkh), _p(dk), _p(dgw), _p(dgb), B, T, _st())
+        return dk, dgw, dgb, None
+
+
+def word_keys(kraw, gnw=None, gnb=None, eps=1e-5):
+    return WordKeysFn.apply(kraw, gnw, gnb, eps)
+
+
 class GradPenaltyFn(torch.autograd.Function):
     """mean_b ||[g0_b, g1_b, ...]||_2^6 over f32 gradient blocks [B, ...] (train_gan.py:241-247: cat, **2, sum, sqrt, **6,
     mean) in two passes over the data: per-sample sums of squares, then -- in the backward -- one scaled copy per block.

@@ -14,8 +14,9 @@ own objects and the fixtures ``fwd_wordin*`` / ``step_wordin*`` pin the result.
 
 Same constructor/forward signatures and ``state_dict()`` keys (incl. the ``linaer_beta2`` spelling and the BatchNorm
 buffers).  Per-pixel work runs on the HIP kernels (MFMA convolutions incl. the fused upsample+3x3, BatchNorm/GroupNorm,
-region attention, conditional modulation); the per-sample concept algebra on [B,16,<=360] tensors (reasoner, word
-attention over T <= 20 words, grouped 1x1 modulation heads) stays in ATen like in ``df_concept_gan``.
+region attention, conditional modulation) and so does the per-sample concept algebra on [B,16,<=360] tensors (since round 5:
+reasoner with its BatchNorm1d, masked word attention over T <= 32 words, grouped 1x1 modulation heads, the word keys'
+GroupNorm -- csrc/concept_word.hip); what is left to ATen is batch-sized glue (the cat of noise and sentence, reshapes).
 
 Behaviour kept because it changes results (concept_gan.py): the first two blocks receive the whole ``upsample`` list as
 their flag, i.e. both upsample (262); in ``OutConceptBlock`` the second sampler's output is discarded and the second reasoner
@@ -33,7 +34,7 @@ import torch.nn.functional as F
 from xmc_gan_amd import ops
 from xmc_gan_amd.lib import ACT_RELU, ACT_TANH
 
-from .df_concept_gan import ConceptSampler, _GroupedConv, _grouped_vec
+from .df_concept_gan import ConceptSampler, _GroupedConv
 from .df_gan import nhwc_feature_perm
 from .modules import HipConv2d, HipLinear
 
@@ -144,38 +145,31 @@ class ConceptReasoner(nn.Module):
             self.bn = nn.BatchNorm1d(num_features=cardinality)
 
     def forward(self, x, **kwargs):
-        adj = torch.tanh(F.linear(x, self.proj_edge.weight))
-        out = x + torch.matmul(adj, x)
-        if self.normalize:
-            out = self._batchnorm(out)
-        return F.relu(out)
-
-    def _batchnorm(self, x):
-        """nn.BatchNorm1d over [B, C, L] written out with elementwise / reduction ops.  (``self.bn(x)`` dispatches to the
-        vendor BatchNorm on the GPU, whose training-mode result on this 16-samples-per-channel tensor left every generator
-        gradient ~0.5 % away from the f64 evaluation of the same network; this form agrees to 4e-6.)"""
-        bn = self.bn
-        if bn.training:
-            mean = x.mean(dim=(0, 2))
-            var = x.var(dim=(0, 2), unbiased=False)
-            with torch.no_grad():
-                n = x.size(0) * x.size(2)
-                bn.running_mean.mul_(1 - bn.momentum).add_(mean, alpha=bn.momentum)
-                bn.running_var.mul_(1 - bn.momentum).add_(var * (n / max(n - 1, 1)), alpha=bn.momentum)
-                bn.num_batches_tracked += 1
-        else:
-            mean, var = bn.running_mean, bn.running_var
-        scale = bn.weight * torch.rsqrt(var + bn.eps)
-        return (x - mean.view(1, -1, 1)) * scale.view(1, -1, 1) + bn.bias.view(1, -1, 1)
+        """x [B,16,4] f32 -> relu(BatchNorm1d(x + tanh(x We^T) x)): one launch for the whole batch (csrc/concept_word.hip), the running
+        statistics updated in place in training mode like nn.BatchNorm1d (momentum 0.1, unbiased variance)"""
+        return ops.reasoner(x, self.proj_edge.weight, self.bn if self.normalize else None)
 
 
 def _word_context(state, words, mask):
     """state [B,C,p'], words [B,T,p'], mask [B,T] (True = padding) -> attention of every concept over the words
-    (OutConceptBlock.get_context_embs, concept_gan.py:374-394): [B,C,p']."""
-    st = F.normalize(state, p=2, dim=1)                       # over the concept axis, as upstream
-    wd = F.normalize(words, p=2, dim=2)
-    sim = torch.matmul(st, wd.transpose(1, 2)).masked_fill(mask.view(mask.size(0), 1, -1), float('-inf'))
-    return torch.matmul(torch.softmax(sim, dim=2), wd)
+    (OutConceptBlock.get_context_embs, concept_gan.py:374-394): [B,C,p'].  States are L2-normalised over the CONCEPT axis, as upstream."""
+    return ops.word_context(state, words, mask)
+
+
+def _project_words(words_embs, conv1d):
+    """nn.Conv1d(text_dim, n, 1) on words [B,T,text_dim] as one GEMM over the B * T words -> [B,T,n]"""
+    B, T, E = words_embs.shape
+    n = conv1d.out_channels
+    geom = conv1d.__dict__.get("_xmc_geom")
+    if geom is None:
+        geom = conv1d.__dict__["_xmc_geom"] = ops.ConvGeom(E, n, 1, 1, 0)
+    y = ops.linear(words_embs.reshape(B * T, E), conv1d.weight.view(n, E), conv1d.bias, geom, out_dtype=torch.float32)
+    return y[:, :n].reshape(B, T, n)
+
+
+def _head(global_cond, ctx, gconv):
+    """grouped 1x1 head on cat(global condition, context) per concept, without the concatenation -> [B, C * p]"""
+    return ops.grouped_vec(global_cond, ctx, gconv.weight, gconv.bias, gconv.groups).reshape(global_cond.size(0), -1)
 
 
 class OutConceptBlock(nn.Module):
@@ -207,18 +201,14 @@ class OutConceptBlock(nn.Module):
         e = self.trans_gconv(e)
         e = ops.groupnorm(e, self.gn.weight, self.gn.bias, self.cardinality, slope=0.0) if self.normalize else ops.lrelu(e, 0.0)
         st = self.concept_reasoner1(self.concept_sampler1(e))                                    # [B,C,p']
-        ctx = _word_context(st, F.linear(words_embs, self.word_conv1.weight[:, :, 0]), mask)
-        gc = global_cond.view(B, 1, -1).expand(B, self.cardinality, -1)
-        cond = torch.cat([gc, ctx], dim=2)
-        g1 = _grouped_vec(cond, self.gamma1_gconv).reshape(B, -1)
-        b1 = _grouped_vec(cond, self.beta1_gconv).reshape(B, -1)
+        ctx = _word_context(st, _project_words(words_embs, self.word_conv1), mask)
+        g1, b1 = _head(global_cond, ctx, self.gamma1_gconv), _head(global_cond, ctx, self.beta1_gconv)
         if self.normalize and self.concept_reasoner2.training:
-            with torch.no_grad():       # upstream's discarded call (432): only the BatchNorm1d running statistics remain
-                self.concept_reasoner2(ctx)
-        ctx2 = _word_context(ctx, F.linear(words_embs, self.word_conv2.weight[:, :, 0]), mask)
-        cond2 = torch.cat([gc, ctx2], dim=2)
-        g2 = _grouped_vec(cond2, self.gamma2_gconv).reshape(B, -1)
-        b2 = _grouped_vec(cond2, self.beta2_gconv).reshape(B, -1)
+            # upstream's discarded call (432): only the BatchNorm1d running statistics remain
+            r2 = self.concept_reasoner2
+            ops.reasoner_stats_only(ctx, r2.proj_edge.weight, r2.bn)
+        ctx2 = _word_context(ctx, _project_words(words_embs, self.word_conv2), mask)
+        g2, b2 = _head(global_cond, ctx2, self.gamma2_gconv), _head(global_cond, ctx2, self.beta2_gconv)
         # relu(g2 * up(relu(g1*e+b1)) + b2) == up(relu(g2 * relu(g1*e+b1) + b2)): one two-stage pass at low resolution
         return ops.Affine2LreluFn.apply(e, g1, b1, g2, b2, 0.0)
 
@@ -306,11 +296,11 @@ class CondConceptSampler(nn.Module):
         q = self.query_gconv(x)
         if self.normalize:
             q = ops.groupnorm(q, self.gn1.weight, self.gn1.bias, C, eps=self.gn1.eps)
-        # the keys: [B,64,T] -- per-sample algebra on a tensor of a few KB, in ATen like the rest of the concept algebra of this file
-        k = torch.matmul(words_embs, self.key_gconv.weight.view(C * P, E).t()).transpose(1, 2)          # every group sees the same words
-        if self.normalize:
-            k = F.group_norm(k, C, self.gn2.weight, self.gn2.bias, self.gn2.eps)
-        kh = F.normalize(k.reshape(B, C, P, T), p=2, dim=2).permute(0, 1, 3, 2)                          # [B,C,T,p']
+        # the keys: every group sees the same words -- one GEMM over the B * T words, then GroupNorm over (p', T) per concept and the L2
+        # normalisation over p' in one launch (csrc/concept_word.hip) -> [B,C,T,p']
+        kraw = _project_words(words_embs, self.key_gconv)
+        kh = ops.word_keys(kraw, self.gn2.weight if self.normalize else None, self.gn2.bias if self.normalize else None,
+                           self.gn2.eps if self.normalize else 1e-5)
         return ops.word_region_pool(q, kh, mask)
 
 
@@ -340,12 +330,10 @@ class InConceptBlock(nn.Module):
         e = self.split_conv(x, act=ACT_RELU)
         e = self.trans_gconv(e)
         out = ops.groupnorm(e, self.gn.weight, self.gn.bias, self.cardinality, slope=0.0) if self.normalize else ops.lrelu(e, 0.0)
-        gc = global_cond.view(B, 1, -1).expand(B, self.cardinality, -1)
         for samp, reas, gm, bm in ((self.concept_sampler1, self.concept_reasoner1, self.gamma1_gconv, self.beta1_gconv),
                                    (self.concept_sampler2, self.concept_reasoner2, self.gamma2_gconv, self.beta2_gconv)):
             ctx = reas(samp(out, words_embs, mask))                                                # [B,C,p']
-            cond = torch.cat([gc, ctx], dim=2)
-            out = ops.affine_act(out, _grouped_vec(cond, gm).reshape(B, -1), _grouped_vec(cond, bm).reshape(B, -1), 0.0)
+            out = ops.affine_act(out, _head(global_cond, ctx, gm), _head(global_cond, ctx, bm), 0.0)
         return out
 
 

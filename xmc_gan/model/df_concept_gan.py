@@ -95,11 +95,8 @@ class _SamplerBase(nn.Module):
                                  head_params, eps=self.gn2.eps if self.normalize else 1e-5, **self.__dict__.pop("_a_hoisted", {}))
 
     def _attend(self, x, q, scale):
-        """x [B,H,W,128], q [B,16,4] f32 -> value-projected context [B,16,4]."""
-        B = x.size(0)
-        if self.normalize:
-            q = F.group_norm(q.reshape(B, -1), self.cardinality, self.gn1.weight, self.gn1.bias).view(B, self.cardinality, -1)
-        return _grouped_vec(self.pool(x, q, scale), self.value_gconv)
+        """x [B,H,W,128], q [B,16,4] f32 (already normalised) -> value-projected context [B,16,4]."""
+        return ops.grouped_vec(None, self.pool(x, q, scale), self.value_gconv.weight, None, self.cardinality)
 
 
 class CondConceptSampler(_SamplerBase):
@@ -125,9 +122,11 @@ class ConceptSampler(_SamplerBase):
         self._scale = float(state_dim) ** -0.5
 
     def forward(self, x, **kwargs):
-        B = x.size(0)
-        q0 = ops.global_avgpool(x).view(B, self.cardinality, -1)
-        return self._attend(x, _grouped_vec(q0, self.query_gconv), self._scale)
+        # (the un-fused form, used by the word-attention generator: query = grouped 1x1 of the global average [+ GroupNorm] in one
+        # launch, region attention, value projection -- csrc/concept.hip, concept_word.hip)
+        q = ops.concept_gquery(ops.global_avgpool(x), self.query_gconv.weight, self.gn1.weight if self.normalize else None,
+                               self.gn1.bias if self.normalize else None, self.gn1.eps if self.normalize else 1e-5)
+        return self._attend(x, q, self._scale)
 
 
 class _ConceptBlockBase(nn.Module):
