@@ -106,6 +106,7 @@ LOSS_KEYS = ("errD_real", "errD_fake", "errD_mismatch", "ds_loss", "errD", "d_lo
 def compare_losses(prod, orac, rtol, atol, after_gp=1.0):
     """``after_gp``: factor on the bar of the generator-step losses when a gradient-penalty Adam step precedes them (MA-GP on)"""
     worst = 0.0
+    used_l = dict(loss=0.0, loss_name="")
     for k in LOSS_KEYS:
         if k in orac:
             assert k in prod, f"product did not report {k}"
@@ -115,7 +116,11 @@ def compare_losses(prod, orac, rtol, atol, after_gp=1.0):
                 r *= after_gp
             err = abs(p - o) / (abs(o) + atol / r)
             worst = max(worst, err / (6.0 if k == "d_loss_gp" else 1.0))
+            frac = abs(p - o) / (r * abs(o) + atol)
+            if frac > used_l["loss"]:
+                used_l["loss"], used_l["loss_name"] = frac, k
             assert abs(p - o) <= r * abs(o) + atol, f"{k}: product {p} vs oracle {o}"
+    USED.append(("losses", used_l))
     return worst
 
 
@@ -127,6 +132,7 @@ def compare_grads(tap_rec, oracle_grads, rtol, name="", floor=1e-5, agg_rtol=Non
     count in the aggregate)."""
     worst = 0.0
     num2 = den2 = 0.0
+    used = dict(tensor=0.0, tensor_name="", loose=0.0, loose_name="", agg=0.0)     # fraction of each bar this call used (USED, below)
     sc_scale = max([go.abs().max().item() for go in oracle_grads.values() if go is not None and go.numel() <= 4] + [0.0])
     # gradients that are structurally zero (e.g. the bias of the GroupNorm applied to attention KEYS: a per-concept constant
     # added to every score leaves the softmax unchanged) come out as rounding noise on both sides: compare those on the
@@ -145,12 +151,36 @@ def compare_grads(tap_rec, oracle_grads, rtol, name="", floor=1e-5, agg_rtol=Non
         worst = max(worst, err)
         num2 += (gp - go).double().pow(2).sum().item()
         den2 += go.double().pow(2).sum().item()
-        tol = rtol * ((loose[1](n) if callable(loose[1]) else loose[1]) if loose is not None and loose[0](n) else 1.0)
+        is_loose = loose is not None and loose[0](n)
+        tol = rtol * ((loose[1](n) if callable(loose[1]) else loose[1]) if is_loose else 1.0)
+        key = "loose" if is_loose else "tensor"
+        if err / tol > used[key]:
+            used[key], used[key + "_name"] = err / tol, n
         assert err <= tol, f"{name}{n}: rel error {err:.3e} > {tol}"
     if agg_rtol is not None:      # all gradient tensors of this backward taken as one vector
         agg = (num2 / max(den2, 1e-300)) ** 0.5
+        used["agg"] = agg / agg_rtol
         assert agg <= agg_rtol, f"{name}aggregate gradient error {agg:.3e} > {agg_rtol}"
+    USED.append((name.strip(), used))
     return worst
+
+
+# what fraction of its bar every compare_grads / compare_losses call used (the tests print the maxima: a bar is ratcheted to <= 1.5 x
+# the largest measured value, i.e. no call should stay below 0.67 for long without the bar coming down)
+USED = []
+
+
+def used_summary(clear=True):
+    out = {}
+    for name, u in USED:
+        o = out.setdefault(name, dict(tensor=0.0, tensor_name="", loose=0.0, loose_name="", agg=0.0, loss=0.0, loss_name=""))
+        for k in ("tensor", "loose", "loss"):
+            if u.get(k, 0.0) > o[k]:
+                o[k], o[k + "_name"] = u[k], u.get(k + "_name", "")
+        o["agg"] = max(o["agg"], u.get("agg", 0.0))
+    if clear:
+        USED.clear()
+    return out
 
 
 def concept_quant_walk(kind, over=None, batch=3):

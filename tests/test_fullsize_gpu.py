@@ -179,6 +179,6 @@ def test_generator_full_batch_equals_slices(yml, size, batch, nsl, mode):
     # carry a heavily cancelling sum over 16 384 regions (tests/test_models_gpu.py): their f32 run-to-run spread is 1e-3 .. 5e-3
     wbar = (2e-4 if h.gen == "DF_GEN" else 5e-3) if mode == "fp32" else 3e-2        # measured 5e-6 / 5.6e-4 .. 2.4e-3 (run to run: f32 atomics in cancelling sums) / 8e-6
     if mode == "bf16" and h.gen != "DF_GEN":
-        wbar = 0.3          # (measured 0.13; vector 1.6e-2) per tensor: a gross-error guard for those cancelling sums at 8-bit storage; the vector bound is the check
+        wbar = 0.15         # (round 5 ratchet: 0.3 -> 0.15; measured 0.088 .. 0.13 by box, vector 1.5e-2 .. 1.6e-2) per tensor: a gross-error guard for those cancelling sums at 8-bit storage; the vector bound is the check
     assert errs[worst] < wbar, (worst, errs[worst])
-    assert tot < (1e-3 if mode == "fp32" else 3e-2), tot
+    assert tot < (1e-3 if mode == "fp32" else 2.4e-2), tot          # (bf16: 3e-2 -> 2.4e-2, measured 1.6e-2 on config 3, 1.7e-4 on DF_GEN)

@@ -26,7 +26,14 @@ if torch.cuda.is_available():
     from parity_util import (DEV, build_product, compare_grads, compare_losses, concept_quant_walk, mean_abs_err, rel_err,
                              run_oracle_steps, run_product_steps, setup_cfg)
 
-TOL = {"fp32": dict(fwd=1e-3, loss=1e-3, grad=5e-3, latol=1e-4, agg=2e-3), "bf16": dict(fwd=3e-2, loss=5e-2, grad=0.5, latol=1e-2, agg=0.3)}
+# Bars are RATCHETED: every compare_* call reports the fraction of its bar it used (parity_util.USED, printed per case as `[bars ...]`);
+# round 5 set each bar to <= 1.5 x the largest value measured over the cases that share it (profiles/r05_test_bar_usage.txt) and
+# split the bf16 bar by generator family, whose worst cases differ by 2x.
+#   fp32: north_star's own figures (loss 1e-3; gradients 5e-3 per tensor / 2e-3 as one vector: largest used fraction 0.63 / 0.31)
+#   bf16 against the plain f32 oracle = the cost of the format: DF_GEN cases used <= 0.37 / 0.41 / 0.35 of the old (5e-2, 0.5, 0.3);
+#        the attention / word-attention generators 0.91 / 0.73 / 0.70 of it, so those stay
+TOL = {"fp32": dict(fwd=1e-3, loss=1e-3, grad=5e-3, latol=1e-4, agg=2e-3), "bf16": dict(fwd=3e-2, loss=5e-2, grad=0.5, latol=1e-2, agg=0.3),
+       "bf16_df": dict(fwd=3e-2, loss=3e-2, grad=0.3, latol=1e-2, agg=0.16)}
 # bf16 engine vs the quantisation-aware oracle (first iteration, identical weights on both sides)
 # measured on MI355X: losses <= 5.6e-3 (terms near zero: 8e-4 absolute), image 1.4e-4 .. 2.0e-3 mean abs, gradient tensors
 # D <= 4.4e-2, G <= 1.9e-1 (worst single tensor), MA-GP <= 7.7e-2
@@ -166,21 +173,14 @@ def test_train_iteration_parity(yml, over, batch, steps, mode):
         qd = compare_grads(tapD.records[0], q_outs[0]["grads_D"], QTOL_C["grad"], "quant D ", 2e-2, QTOL_C["agg"])
         qg = compare_grads(tapG.records[0], q_outs[0]["grads_G"], 4.0, "quant G ", 2e-2, QTOL_C["agg_g"]) if "grads_G" in q_outs[0] else 0.0
         print(f"\n[bf16 vs quantisation-aware oracle {yml} {over}] loss={ql:.2e} image={qf:.2e} D={qd:.2e} G={qg:.2e}")
-    t = TOL[mode]
+    t = TOL["bf16_df" if (mode == "bf16" and h.gen == "DF_GEN") else mode]
     gi = di = 0
     worst = dict(loss=0.0, D=0.0, GP=0.0, G=0.0)
     fl = 1e-5 if mode == "fp32" else 2e-2      # gradient tensors below this fraction of the largest norm are compared on that scale
     loose = None
     agg_g = 1.0
-    if mode == "fp32" and h.gen != "DF_GEN" and h.img_size >= 128:
-        # the same cancelling sums (below) in f32 at 16 384 regions.  Round 4, with the reductions in fixed order: the product repeats
-        # itself to 1e-5 per tensor (it did before as well -- the spread rounds 2-3 blamed was between BOXES running different tile
-        # counts), and sits at a FIXED distance from the oracle, which sums the same cancelling brackets in another order: tensors
-        # upstream of the attention logits (query / key projections and their GroupNorms) 1.3e-2 .. 2.1e-2, the rest of the concept
-        # stages <= 1.4e-2, everything as one vector 3.1e-3 (fixed_order_probe.py).  x6 / x3 per tensor, x2 on the vector
-        upstream = lambda n: "concept_sampler" in n and n.split(".")[-2] in ("query_gconv", "key_gconv", "gn1", "gn2")
-        loose = (lambda n: n.startswith("upblocks.") or ".concept" in n, lambda n: 6.0 if upstream(n) else 3.0)
-        agg_g = 2.0
+    # (fp32, attention generators at 128 px: rounds 2-4 carried per-tensor factors x6 / x3 and x2 on the vector here; measured in the
+    # fixed-order mode those tensors use 0.09 of the PLAIN bar -- the factors are gone)
     if mode == "bf16" and h.gen != "DF_GEN":
         # Parameters upstream of the region-attention LOGITS (query / key projections and their GroupNorms).  Their gradient is
         # sum_p a_p (<dctx, x_p> - <dctx, ctx>) k_p over up to 16 384 regions: with the synthetic weights the attention is close
@@ -196,12 +196,9 @@ def test_train_iteration_parity(yml, over, batch, steps, mode):
         # 128 px against 1.4e-3 in fp32 mode on the same kernels) -- guard against gross errors only, like the tensors above; the
         # WEIGHTS of those two convolutions see the same gradient map (5.04e-1 against the 0.5 bar on one box) and join them.
         loose = (lambda n: ("concept_sampler" in n and n.split(".")[-2] in ("query_gconv", "key_gconv", "gn1", "gn2"))
-                 or (h.img_size >= 128 and (".concept" in n or ".conv_out1." in n or ".conv_out2." in n or n.endswith(".c_sc.bias"))), 4.0)
-        if h.img_size >= 128:
-            # ... and with those tensors at signal-to-noise ~1 the G gradients as ONE vector sat at 0.25-0.42 from the f32 oracle
-            # from run to run; in the fixed-order mode the figure repeats (0.27 on the probe's inputs): x1.5 instead of x2.  The
-            # kernels' own accuracy at this size is what the fp32 mode of the same case asserts.
-            agg_g = 1.5
+                 or (h.img_size >= 128 and (".concept" in n or ".conv_out1." in n or ".conv_out2." in n or n.endswith(".c_sc.bias"))), 1.5)
+        # (round 5 ratchet: x4 -> x1.5 per tensor -- largest measured 0.25 of the x4 bar, i.e. 1.0 of the plain one -- and the x1.5 on
+        # the one-vector bound is gone: 0.25 of it used.  The kernels' own accuracy at this size is what the fp32 mode of the same case asserts.)
     for s in range(steps):
         # Step 0 is the strict kernel-accuracy check (identical weights on both sides).  Later steps start from weights
         # that differ in the last bits (f32 atomics order in the weight-gradient kernels is not deterministic), and the
@@ -209,7 +206,9 @@ def test_train_iteration_parity(yml, over, batch, steps, mode):
         # within rounding of zero flips and moves a gradient tensor by 1e-2 (observed: MA-GP grads 7.5e-3, G grads 4e-2
         # at step 1 with everything at 1e-6 on a rerun).  Later steps therefore only verify the phase ordering, whose
         # violations are O(1) errors.
-        k = 1.0 if s == 0 else 20.0
+        # (round 5 ratchet: x20 -> x4: later iterations used <= 0.12 of the x20 bar -- except the attention generators in bf16, whose
+        # N_CRITIC = 2 + MA-GP case sits at 0.91 of it (d_loss_gp; errD_real 0.24 against 0.53 after two discriminator updates): x20 stays there)
+        k = 1.0 if s == 0 else (20.0 if (mode == "bf16" and h.gen != "DF_GEN") else 4.0)
         if over.get("GEN.ENCODER_NAME") in ("CONCEPT_OUTATTN_GEN", "CONCEPT_INATTN_GEN") and mode == "fp32":
             # ReLU (not LeakyReLU) everywhere + batch statistics over 4 samples: this generator sits on kinks.  Evaluated in
             # f64, the same restatement differs from its own f32 CPU run by up to 3.7e-2 in a gradient tensor (8 seeds, linear
@@ -217,7 +216,7 @@ def test_train_iteration_parity(yml, over, batch, steps, mode):
             # compared f32-to-f32 landed anywhere between 3e-5 and 1.1e-2 from run to run.  The strict check of this
             # generator is test_word_attention_generator_gradients_match_f64_evaluation; here only the phase ordering
             # (O(1) errors) is guarded.
-            k *= 8.0
+            k *= 2.0                     # (round 5 ratchet: x8 -> x2: <= 0.02 of the old bar used)
         worst["loss"] = max(worst["loss"], compare_losses(p_outs[s], o_outs[s], t["loss"] * k, t["latol"] * k))
         assert mean_abs_err(p_outs[s]["fake"], o_outs[s]["fake"]) < t["fwd"] * k
         worst["D"] = max(worst["D"], compare_grads(tapD.records[di], o_outs[s]["grads_D"], t["grad"] * k, f"step{s} D ", fl, t["agg"] * k)); di += 1
@@ -227,6 +226,10 @@ def test_train_iteration_parity(yml, over, batch, steps, mode):
             worst["G"] = max(worst["G"], compare_grads(tapG.records[gi], o_outs[s]["grads_G"], t["grad"] * k, f"step{s} G ", fl, t["agg"] * k * agg_g, loose)); gi += 1
     assert di == len(tapD.records) and gi == len(tapG.records)
     print(f"\n[parity {mode} {yml} {over}] worst rel err: " + ", ".join(f"{k}={v:.2e}" for k, v in worst.items()))
+    from parity_util import used_summary
+    print(f"[bars {mode} {yml} {over}] fraction of each bar used: " + "; ".join(
+        f"{n}: " + ", ".join(f"{k} {u[k]:.2f}" + (f" ({u[k + '_name']})" if u.get(k + "_name") else "") for k in ("loss", "tensor", "loose", "agg") if u[k] > 0)
+        for n, u in used_summary().items()))
 
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
