@@ -153,7 +153,7 @@ class _QWeight(torch.autograd.Function):
 
 
 class _QBranchTimesGamma(torch.autograd.Function):
-    """gamma * LeakyReLU(z) of a discriminator block as the engine's first-order path stores it (xmc_gan_amd/ops.py ResDFn /
+    """gamma * LeakyReLU(z) of a discriminator block as the engine's first-order path stores it (xmc_gan_amd/ops/_nodes_block.py ResDFn /
     ResDBwdFn): forward, the branch is rounded where it enters the block sum; backward, the engine keeps only the
     branch's SIGN, rounds s * dout (`xmc_signmask_apply`) and applies gamma in f32 in the epilogue of the data gradient that
     follows -- so the gradient handed to the convolution is gamma * round(s * dout), not round(gamma * dout) * s."""

@@ -18,6 +18,15 @@ _, _, o32 = run_oracle_steps(h, PG, PD, batches, eps=1e-3)
 # argv[2]: which phases keep the residual branch VALUES (the pre-sign-bits form): "" none, "d" the D step, "g" the G step, "dg" both
 phases = sys.argv[2] if len(sys.argv) > 2 else ""
 import xmc_gan_amd.optim as _optim
+
+
+def _patch_ops(name, val):       # (ops is a package since round 5: a name lives in the module that defines it and in those that import it)
+    import sys
+    for m in list(sys.modules.values()):
+        if getattr(m, "__name__", "").startswith("xmc_gan_amd.ops") and hasattr(m, name):
+            setattr(m, name, val)
+
+
 _calls = [0]
 _orig_step = _optim.HipAdam.step
 def _step(self, *a, **k):
@@ -28,7 +37,7 @@ _orig_so = ops._second_order
 def _so():
     ph = "d" if _calls[0] == 0 else ("m" if _calls[0] == 1 else "g")
     return _orig_so() or (ph in phases)
-ops._second_order = _so
+_patch_ops("_second_order", _so)
 _, _, p, tapG, tapD = run_product_steps(h, PG, PD, batches, eps=1e-3)
 for name, rec, ref, ref32 in (("D", tapD.records[0], o[0]["grads_D"], o32[0]["grads_D"]), ("G", tapG.records[0], o[0]["grads_G"], o32[0]["grads_G"])):
     rows = sorted(((rel_err(rec[n], ref[n]), rel_err(rec[n], ref32[n]), rel_err(ref[n], ref32[n]), n) for n in ref if n in rec), reverse=True)

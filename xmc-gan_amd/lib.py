@@ -200,7 +200,7 @@ def load(v=None):
         raise RuntimeError(f"{path}: ABI version {lib.xmc_abi_version()}, this binding needs {ABI_VERSION} (stale build?)")
     if lib.xmc_half_format() != (0 if v == "bf16" else 1):
         raise RuntimeError(f"{path} was not built for the {v} storage format")
-    # ops.py hands every accumulator the header documents as "zeroed here" over as a slice of its once-per-iteration zero arena
+    # the ops package hands every accumulator the header documents as "zeroed here" over as a slice of its once-per-iteration zero arena
     lib.xmc_set_prezeroed(1)
     _libs[v] = lib
     return lib
