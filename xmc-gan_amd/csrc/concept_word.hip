@@ -71,169 +71,118 @@ __global__ __launch_bounds__(256) void gvec_bwd_kernel(const float* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------------------------------ reasoner
-// ONE workgroup walks the batch (BatchNorm1d's statistics couple the samples; the whole tensor is B x 64 floats)
-__device__ __forceinline__ void block_sum16(float (&v)[C_], float* s_red /*[4][16]*/, float (&out)[C_]) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int c = 0; c < C_; ++c) {
-        const float s = wave_sum(v[c]);
-        if (lane == 0) s_red[wave * C_ + c] = s;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int c = 0; c < C_; ++c) out[c] = s_red[c] + s_red[C_ + c] + s_red[2 * C_ + c] + s_red[3 * C_ + c];
-    __syncthreads();
+// ONE workgroup walks the batch (BatchNorm1d's statistics couple the samples; the whole tensor is B x 64 floats): a wave per sample,
+// lane = (concept c, state channel k); sums over k are quad DPP adds, sums over c four shuffles, a concept's row of the adjacency is
+// 16 registers.  (A first version gave every THREAD a sample -- 3 x 64 registers of state and the We gradient through LDS atomics on
+// 64 addresses: 2.2 ms per call.)
+__device__ __forceinline__ float rs_k(float v) { v += xmc_xor1(v); v += xmc_xor2(v); return v; }
+__device__ __forceinline__ float rs_c(float v) {
+    v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+    return v;
 }
-
-__device__ __forceinline__ void reason_pre(const float (&x)[CP], const float* __restrict__ s_we, float (&pre)[CP]) {
-#pragma unroll
-    for (int c = 0; c < C_; ++c) {
-        float a[C_];
-#pragma unroll
-        for (int e = 0; e < C_; ++e) {
-            float z = 0.f;
-#pragma unroll
-            for (int k = 0; k < P_; ++k) z += x[c * P_ + k] * s_we[e * P_ + k];
-            a[e] = tanhf(z);
-        }
-#pragma unroll
-        for (int k = 0; k < P_; ++k) {
-            float s = x[c * P_ + k];
-#pragma unroll
-            for (int e = 0; e < C_; ++e) s += a[e] * x[e * P_ + k];
-            pre[c * P_ + k] = s;
-        }
-    }
+// per-channel total over the workgroup of a per-lane partial (already summed over this wave's samples): [c] for every lane
+__device__ __forceinline__ float block_channel_sum(float v, float* s_red /*[4][16]*/) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    v = rs_k(v);
+    if ((lane & 3) == 0) s_red[wave * C_ + (lane >> 2)] = v;
+    __syncthreads();
+    const int c = lane >> 2;
+    const float t = s_red[c] + s_red[C_ + c] + s_red[2 * C_ + c] + s_red[3 * C_ + c];
+    __syncthreads();
+    return t;
 }
 
 __global__ __launch_bounds__(256) void reasoner_fwd_kernel(const float* __restrict__ x, const float* __restrict__ We, const float* __restrict__ bn_w,
                                                            const float* __restrict__ bn_b, float* __restrict__ run_mean, float* __restrict__ run_var,
                                                            int training, float momentum, float eps, float* __restrict__ y, float* __restrict__ pre_out,
                                                            float* __restrict__ stat, int B) {
-    __shared__ float s_we[CP], s_red[4 * C_];
-    const int tid = threadIdx.x;
-    if (tid < CP) s_we[tid] = We[tid];
-    __syncthreads();
-    float sum[C_];
+    __shared__ float s_red[4 * C_];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, k = lane & 3, c = lane >> 2;
+    float we[C_];                                   // We[e][k] for this lane's k
 #pragma unroll
-    for (int c = 0; c < C_; ++c) sum[c] = 0.f;
-    for (int b = tid; b < B; b += 256) {
-        float xv[CP], pre[CP];
+    for (int e = 0; e < C_; ++e) we[e] = We[e * P_ + k];
+    float sum = 0.f;
+    for (int b = wave; b < B; b += 4) {
+        const float xv = x[(size_t)b * CP + lane];
+        float pre = xv;
 #pragma unroll
-        for (int i = 0; i < CP; ++i) xv[i] = x[(size_t)b * CP + i];
-        reason_pre(xv, s_we, pre);
-#pragma unroll
-        for (int i = 0; i < CP; ++i) { pre_out[(size_t)b * CP + i] = pre[i]; sum[i / P_] += pre[i]; }
+        for (int e = 0; e < C_; ++e) {
+            const float a = tanhf(rs_k(xv * we[e]));               // adj[c][e]
+            pre += a * __shfl(xv, e * P_ + k, 64);
+        }
+        pre_out[(size_t)b * CP + lane] = pre;
+        sum += pre;
     }
-    float mean[C_], rstd[C_];
+    float mean = 0.f, rstd = 1.f;
     if (bn_w && training) {
-        float tot[C_], sq[C_];
-        block_sum16(sum, s_red, tot);
         const float n = (float)B * P_;
-#pragma unroll
-        for (int c = 0; c < C_; ++c) { mean[c] = tot[c] / n; sq[c] = 0.f; }
-        for (int b = tid; b < B; b += 256)
-#pragma unroll
-            for (int i = 0; i < CP; ++i) { const float dlt = pre_out[(size_t)b * CP + i] - mean[i / P_]; sq[i / P_] += dlt * dlt; }
-        float var[C_];
-        block_sum16(sq, s_red, var);
-#pragma unroll
-        for (int c = 0; c < C_; ++c) { var[c] /= n; rstd[c] = rsqrtf(var[c] + eps); }
-        if (tid < C_) {
-            float m = 0.f, v = 0.f;
-#pragma unroll
-            for (int c = 0; c < C_; ++c) if (c == tid) { m = mean[c]; v = var[c]; }
-            run_mean[tid] = (1.f - momentum) * run_mean[tid] + momentum * m;
-            run_var[tid] = (1.f - momentum) * run_var[tid] + momentum * v * (n / fmaxf(n - 1.f, 1.f));
+        mean = block_channel_sum(sum, s_red) / n;
+        float sq = 0.f;
+        for (int b = wave; b < B; b += 4) { const float dlt = pre_out[(size_t)b * CP + lane] - mean; sq += dlt * dlt; }
+        const float var = block_channel_sum(sq, s_red) / n;
+        rstd = rsqrtf(var + eps);
+        if (wave == 0 && k == 0) {
+            run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mean;
+            run_var[c] = (1.f - momentum) * run_var[c] + momentum * var * (n / fmaxf(n - 1.f, 1.f));
         }
     } else if (bn_w) {
-#pragma unroll
-        for (int c = 0; c < C_; ++c) { mean[c] = run_mean[c]; rstd[c] = rsqrtf(run_var[c] + eps); }
-    } else {
-#pragma unroll
-        for (int c = 0; c < C_; ++c) { mean[c] = 0.f; rstd[c] = 1.f; }
+        mean = run_mean[c]; rstd = rsqrtf(run_var[c] + eps);
     }
-    if (tid == 0 && stat)
-#pragma unroll
-        for (int c = 0; c < C_; ++c) { stat[c] = mean[c]; stat[C_ + c] = rstd[c]; }
+    if (wave == 0 && k == 0 && stat) { stat[c] = mean; stat[C_ + c] = rstd; }
     if (!y) return;
-    for (int b = tid; b < B; b += 256)
-#pragma unroll
-        for (int i = 0; i < CP; ++i) {
-            const int c = i / P_;
-            float v = (pre_out[(size_t)b * CP + i] - mean[c]) * rstd[c];
-            if (bn_w) v = v * bn_w[c] + bn_b[c];
-            y[(size_t)b * CP + i] = fmaxf(v, 0.f);
-        }
+    const float w = bn_w ? bn_w[c] : 1.f, bb = bn_w ? bn_b[c] : 0.f;
+    for (int b = wave; b < B; b += 4)
+        y[(size_t)b * CP + lane] = fmaxf((pre_out[(size_t)b * CP + lane] - mean) * rstd * w + bb, 0.f);
 }
 
 __global__ __launch_bounds__(256) void reasoner_bwd_kernel(const float* __restrict__ x, const float* __restrict__ We, const float* __restrict__ bn_w,
                                                            const float* __restrict__ bn_b, const float* __restrict__ pre, const float* __restrict__ stat,
                                                            int batch_stats, const float* __restrict__ dy, float* __restrict__ dx, float* __restrict__ dWe,
                                                            float* __restrict__ dbn_w, float* __restrict__ dbn_b, int B) {
-    __shared__ float s_we[CP], s_red[4 * C_], s_dwe[CP];
-    const int tid = threadIdx.x;
-    if (tid < CP) { s_we[tid] = We[tid]; s_dwe[tid] = 0.f; }
-    __syncthreads();
-    float mean[C_], rstd[C_], w[C_], bb[C_];
+    __shared__ float s_red[4 * C_], s_dwe[4 * CP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, k = lane & 3, c = lane >> 2;
+    float we[C_];
 #pragma unroll
-    for (int c = 0; c < C_; ++c) { mean[c] = stat[c]; rstd[c] = stat[C_ + c]; w[c] = bn_w ? bn_w[c] : 1.f; bb[c] = bn_w ? bn_b[c] : 0.f; }
+    for (int e = 0; e < C_; ++e) we[e] = We[e * P_ + k];
+    const float wec = We[lane];                                     // We[c][k]
+    const float mean = stat[c], rstd = stat[C_ + c], w = bn_w ? bn_w[c] : 1.f, bb = bn_w ? bn_b[c] : 0.f;
     // pass 1: sums of g = dy * relu' and of g * xhat per concept (BatchNorm's parameter gradients and its batch-statistics terms)
-    float sg[C_], sgx[C_];
-#pragma unroll
-    for (int c = 0; c < C_; ++c) sg[c] = sgx[c] = 0.f;
-    for (int b = tid; b < B; b += 256)
-#pragma unroll
-        for (int i = 0; i < CP; ++i) {
-            const int c = i / P_;
-            const float xh = (pre[(size_t)b * CP + i] - mean[c]) * rstd[c];
-            const float g = (xh * w[c] + bb[c]) > 0.f ? dy[(size_t)b * CP + i] : 0.f;
-            sg[c] += g; sgx[c] += g * xh;
-        }
-    float tg[C_], tgx[C_];
-    block_sum16(sg, s_red, tg);
-    block_sum16(sgx, s_red, tgx);
-    if (tid < C_ && bn_w) {
-#pragma unroll
-        for (int c = 0; c < C_; ++c) if (c == tid) { if (dbn_w) dbn_w[c] = tgx[c]; if (dbn_b) dbn_b[c] = tg[c]; }
+    float sg = 0.f, sgx = 0.f;
+    for (int b = wave; b < B; b += 4) {
+        const float xh = (pre[(size_t)b * CP + lane] - mean) * rstd;
+        const float g = (xh * w + bb) > 0.f ? dy[(size_t)b * CP + lane] : 0.f;
+        sg += g; sgx += g * xh;
     }
+    const float tg = block_channel_sum(sg, s_red), tgx = block_channel_sum(sgx, s_red);
+    if (wave == 0 && k == 0 && bn_w) { if (dbn_w) dbn_w[c] = tgx; if (dbn_b) dbn_b[c] = tg; }
     const float n = (float)B * P_;
     // pass 2: d pre, then through pre = x + tanh(x We^T) x
-    for (int b = tid; b < B; b += 256) {
-        float xv[CP], dp[CP], dxv[CP];
+    float dwe = 0.f;                                                // d We[c][k], this wave's samples
+    for (int b = wave; b < B; b += 4) {
+        const float xv = x[(size_t)b * CP + lane];
+        const float xh = (pre[(size_t)b * CP + lane] - mean) * rstd;
+        const float g = (xh * w + bb) > 0.f ? dy[(size_t)b * CP + lane] : 0.f;
+        float dp = g * w * rstd;
+        if (batch_stats) dp -= w * rstd * (tg + xh * tgx) / n;
+        float dxv = dp;
 #pragma unroll
-        for (int i = 0; i < CP; ++i) {
-            const int c = i / P_;
-            xv[i] = x[(size_t)b * CP + i];
-            const float xh = (pre[(size_t)b * CP + i] - mean[c]) * rstd[c];
-            const float g = (xh * w[c] + bb[c]) > 0.f ? dy[(size_t)b * CP + i] : 0.f;
-            float d = g * w[c] * rstd[c];
-            if (batch_stats) d -= w[c] * rstd[c] * (tg[c] + xh * tgx[c]) / n;
-            dp[i] = d;
-            dxv[i] = d;
+        for (int e = 0; e < C_; ++e) {
+            const float xe = __shfl(xv, e * P_ + k, 64), dpe = __shfl(dp, e * P_ + k, 64);
+            const float a_ce = tanhf(rs_k(xv * we[e]));                                 // adj[c][e]
+            const float a_ec = tanhf(rs_k(xe * wec));                                   // adj[e][c]
+            dxv += a_ec * dpe;                                                          // pre[e] = ... + adj[e][c] x[c]
+            const float dz = rs_k(dp * xe) * (1.f - a_ce * a_ce);                       // d z[c][e],  z[c][e] = x[c] . We[e]
+            dxv += dz * we[e];
+            const float t = rs_c(dz * xv);                                              // sum_c dz[c][e] x[c][k]: d We[e][k]
+            if (c == e) dwe += t;
         }
-#pragma unroll
-        for (int c = 0; c < C_; ++c) {
-#pragma unroll
-            for (int e = 0; e < C_; ++e) {
-                float z = 0.f, da = 0.f;
-#pragma unroll
-                for (int k = 0; k < P_; ++k) { z += xv[c * P_ + k] * s_we[e * P_ + k]; da += dp[c * P_ + k] * xv[e * P_ + k]; }
-                const float a = tanhf(z), dz = da * (1.f - a * a);
-#pragma unroll
-                for (int k = 0; k < P_; ++k) {
-                    dxv[e * P_ + k] += a * dp[c * P_ + k];              // pre[c] = ... + a[c][e] x[e]
-                    dxv[c * P_ + k] += dz * s_we[e * P_ + k];           // z[c][e] = x[c] . We[e]
-                    if (dWe) atomicAdd(&s_dwe[e * P_ + k], dz * xv[c * P_ + k]);
-                }
-            }
-        }
-        if (dx)
-#pragma unroll
-            for (int i = 0; i < CP; ++i) dx[(size_t)b * CP + i] = dxv[i];
+        if (dx) dx[(size_t)b * CP + lane] = dxv;
     }
-    __syncthreads();
-    if (dWe && tid < CP) dWe[tid] = s_dwe[tid];
+    if (dWe) {
+        s_dwe[wave * CP + lane] = dwe;
+        __syncthreads();
+        if (wave == 0) dWe[lane] = s_dwe[lane] + s_dwe[CP + lane] + s_dwe[2 * CP + lane] + s_dwe[3 * CP + lane];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------- word context
