@@ -106,3 +106,35 @@ def test_real_data_path_and_resume(tmp_path):
     tags = {r["tag"] for r in rows}
     assert {"epoch", "Loss_D", "Loss_G", "errD_real", "errD_fake", "errD_mismatch", "ds_loss", "gs_loss", "disc_loss"} <= tags, tags
     assert max(r["step"] for r in rows) == 53
+
+
+@pytest.mark.parametrize("case", ["headline losses", "MA-GP", "N_CRITIC = 2"])
+def test_entry_point_graph_replay_equals_eager_launches(tmp_path, case):
+    """`train()` behind `main()` replays the iteration as hipGraphs by default (two eager warm-ups, one capture per N_CRITIC phase, then
+    replays with the loader's batches copied into the static inputs).  Six iterations through `main()` with `--graph 1` and with
+    `--graph 0` from the same seed, fp32 mode: same final weights (to the f32 atomics order of the weight-gradient kernels: 1e-5 per
+    tensor) and the same last losses -- for the headline loss set, with the gradient penalty, and with two critic steps per generator step
+    (two captured phases)."""
+    import xmc_gan.train_gan as tg
+    subst = {"MAGP: true": "MAGP: true" if case == "MA-GP" else "MAGP: false"}
+    if case == "N_CRITIC = 2":
+        subst["N_CRITIC: 1"] = "N_CRITIC: 2"
+    yml = _mini_yml(tmp_path, **subst)
+    res = {}
+    for graph in (1, 0):
+        last = tg.main(["--cfg", yml, "--synthetic", "6", "--max_epoch", "1", "--precision", "fp32", "--seed", "11", "--graph", str(graph),
+                        "--output_dir", str(tmp_path / f"run{graph}")])
+        netG, netD = tg.main.last_models
+        res[graph] = (last, {"G." + k: v.detach().float().cpu().clone() for k, v in netG.state_dict().items()} |
+                      {"D." + k: v.detach().float().cpu().clone() for k, v in netD.state_dict().items()})
+    assert res[1][0].get("hipgraph") is True and "hipgraph" not in res[0][0]
+    worst = 0.0
+    for k, a in res[1][1].items():
+        b = res[0][1][k]
+        e = ((a - b).norm() / b.norm().clamp_min(1e-12)).item()
+        worst = max(worst, e)
+        assert e <= 1e-5, (k, e)
+    for k in ("errD", "errG", "errD_real", "errD_fake"):
+        a, b = float(res[1][0][k]), float(res[0][0][k])
+        assert abs(a - b) <= 1e-5 * abs(b) + 1e-6, (k, a, b)
+    print(f"\n[entry point, {case}] graph replay vs eager launches after 6 iterations: worst parameter tensor {worst:.1e}")

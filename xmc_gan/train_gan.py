@@ -698,6 +698,7 @@ def main(argv=None):
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.destroy_process_group()
+    main.last_models = (netG, netD)          # (for callers that drive main() in-process: the tests compare runs by their final weights)
     return last
 
 
