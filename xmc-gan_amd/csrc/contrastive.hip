@@ -358,6 +358,141 @@ __global__ __launch_bounds__(256) void cn_scores_kernel(Cn w, const float* __res
     }
 }
 
+// The same for n >= 1024 on 128 x 128 tiles (one per CU at n = 2048): the 64 x 64 form reads its MFMA fragments straight from L2, 32 KB per tile
+// and K step through the CU's vector-memory path (~22 B/clk: 23 us of the launch at n = 2048); here a K step's operands (128 rows x 32 k x hi, lo
+// of both sides: 32 KB for FOUR times the MACs) are staged through LDS once, double buffered, and every wave reads its fragments from there.
+constexpr int CN_LD2 = 129, CN_SROW = 80;                  // epilogue tile row (floats); staged operand row (bytes: 64 + 16 pad, conflict-free b128 reads)
+__global__ __launch_bounds__(512) void cn_scores128_kernel(Cn w, const float* __restrict__ labels, const float* __restrict__ inv_np, int n, int D) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char cn_smem[];
+    float* const Sl = reinterpret_cast<float*>(cn_smem);                    // [128][129]   (aliases the staging buffers: used after the K loop)
+    float* const El = Sl + 128 * CN_LD2;
+    __shared__ float s_t[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+    const int i0 = blockIdx.y * 128, j0 = blockIdx.x * 128, np = w.np;
+    const int fr = lane & 15, fc = lane >> 4;
+    constexpr int ARR = 128 * CN_SROW;                                       // one staged array: 10 KB
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int lrow = tid >> 2, lch = tid & 3;
+    const cn_h* const src[4] = {w.Ahi + (size_t)(i0 + lrow) * D + lch * 8, w.Alo + (size_t)(i0 + lrow) * D + lch * 8,
+                                w.Bhi + (size_t)(j0 + lrow) * D + lch * 8, w.Blo + (size_t)(j0 + lrow) * D + lch * 8};
+    u32x4 ld[4];
+    auto load_k = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ld[q] = *reinterpret_cast<const u32x4*>(src[q] + k0);
+    };
+    auto store_k = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<u32x4*>(cn_smem + buf * 4 * ARR + q * ARR + lrow * CN_SROW + lch * 16) = ld[q];
+    };
+    load_k(0);
+    store_k(0);
+    __syncthreads();
+    const int nst = D / 32;
+    for (int st = 0; st < nst; ++st) {
+        const int buf = st & 1;
+        if (st + 1 < nst) load_k((st + 1) * 32);
+        const unsigned char* base = cn_smem + buf * 4 * ARR;
+        cn_h8 ah[2], al[2], bh[4], bl[4];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int o = (wr * 32 + a * 16 + fr) * CN_SROW + fc * 16;
+            ah[a] = *reinterpret_cast<const cn_h8*>(base + o);
+            al[a] = *reinterpret_cast<const cn_h8*>(base + ARR + o);
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int o = (wc * 64 + b * 16 + fr) * CN_SROW + fc * 16;
+            bh[b] = *reinterpret_cast<const cn_h8*>(base + 2 * ARR + o);
+            bl[b] = *reinterpret_cast<const cn_h8*>(base + 3 * ARR + o);
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[a], bh[b], acc[a][b], 0, 0, 0);
+                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+            }
+        if (st + 1 < nst) store_k(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Sl[(wr * 32 + a * 16 + fc * 4 + r) * CN_LD2 + wc * 64 + b * 16 + fr] = acc[a][b][r];
+    __syncthreads();
+    // row pass: 4 threads per row, 32 columns each
+    const int row = tid >> 2, cq = (tid & 3) * 32, gi = i0 + row;
+    float esum = 0.f, lsum = 0.f, tsum = 0.f;
+    const float npi = (inv_np && gi < n) ? inv_np[gi] : 1.f;
+#pragma unroll
+    for (int v = 0; v < 8; ++v) {
+        f32x4 sv, lv = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (labels && gi < n) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { const int gj = j0 + cq + v * 4 + c; lv[c] = gj < n ? labels[(size_t)gi * n + gj] : 0.f; }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int col = cq + v * 4 + c, gj = j0 + col;
+            const bool in = gi < n && gj < n;
+            const float s_ = Sl[row * CN_LD2 + col];
+            const float e = in ? __expf(s_ - 1.f) : 0.f;
+            sv[c] = in ? s_ : 0.f;
+            esum += e;
+            float L = lv[c];
+            if (!labels) L = (in && gi == gj) ? 1.f : 0.f;
+            El[row * CN_LD2 + col] = e;
+            if (L != 0.f) {
+                const float npj = inv_np ? inv_np[gj] : 1.f;
+                tsum += L * s_ * (npi + npj);
+                lsum += L;
+            }
+            if (labels) Sl[row * CN_LD2 + col] = L;
+        }
+        *reinterpret_cast<f32x4*>(w.S + (size_t)gi * np + j0 + cq + v * 4) = sv;
+    }
+    esum += __shfl_xor(esum, 1, 64); esum += __shfl_xor(esum, 2, 64);
+    lsum += __shfl_xor(lsum, 1, 64); lsum += __shfl_xor(lsum, 2, 64);
+    if ((tid & 3) == 0 && gi < n) {
+        atomicAdd(&w.rowE[gi], esum);
+        if (labels) atomicAdd(&w.rs[gi], lsum);
+    }
+    tsum = wave_sum(tsum);
+    if (lane == 0) s_t[wave] = tsum;
+    __syncthreads();
+    if (tid == 0) {
+        float t = 0.f;
+        for (int q = 0; q < 8; ++q) t += s_t[q];
+        if (t != 0.f) atomicAdd(w.T, t);
+    }
+    if (tid < 128 && j0 + tid < n) {
+        float e = 0.f, l = 0.f;
+        for (int r = 0; r < 128; ++r) { e += El[r * CN_LD2 + tid]; if (labels) l += Sl[r * CN_LD2 + tid]; }
+        atomicAdd(&w.colE[j0 + tid], e);
+        if (labels) atomicAdd(&w.cs[j0 + tid], l);
+    }
+    if (!labels) {                                  // S^T from the tile's columns (labels given: cn_transpose_kernel)
+        const int jr = tid >> 2, iq = (tid & 3) * 32, gj = j0 + jr;
+#pragma unroll
+        for (int v = 0; v < 8; ++v) {
+            f32x4 tv;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int ir = iq + v * 4 + c;
+                tv[c] = ((i0 + ir) < n && gj < n) ? Sl[ir * CN_LD2 + jr] : 0.f;
+            }
+            *reinterpret_cast<f32x4*>(w.ST + (size_t)gj * np + i0 + iq + v * 4) = tv;
+        }
+    }
+}
+
 // labels given: S^T by a plain tiled transpose of S (the rare B_GLOBAL path; keeps cn_scores' LDS tile free for the labels)
 __global__ __launch_bounds__(256) void cn_transpose_kernel(const float* __restrict__ S, float* __restrict__ ST, int np) {
     __shared__ float tl[64 * CN_LD];
@@ -386,11 +521,14 @@ __global__ __launch_bounds__(256) void cn_finish_kernel(Cn w, const float* __res
 }
 
 constexpr int CN_GLD = 40;                      // halfs per row of the transposed dS tile (80 bytes: 16-byte aligned, staggered banks)
-template <int NB>                               // 16-column blocks of a wave's slice of D: D / 64
+template <int NB, int CB>                       // NB: 16-column blocks of a wave's slice of D (D / 64); CB: output rows per workgroup (32 or 64)
 __global__ __launch_bounds__(256) void cn_grad_kernel(Cn w, const float* __restrict__ labels, const float* __restrict__ inv_np, int has_labels,
                                                       const float* __restrict__ dloss, int n, int D, float* __restrict__ dA, float* __restrict__ dB) {
     // side 0: dB[j] = sum_i dS[i][j] Ah[i]   (M = S,   rows r = i, outputs c = j);   side 1: dA[i] = sum_j dS[i][j] Bh[j]  (M = S^T)
-    const int side = blockIdx.y, c0 = blockIdx.x * 32, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, np = w.np;
+    // (CB = 64 where the accumulators allow it: the other side's transposed half pairs -- 32 KB per step through the vector-memory path,
+    // the bound of this launch -- then feed twice the MFMAs)
+    constexpr int NA = CB / 16, RP = 256 / CB, NQ = 32 / RP;        // A blocks; contraction rows per pass of the tile build; passes
+    const int side = blockIdx.y, c0 = blockIdx.x * CB, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, np = w.np;
     const int RS = gridDim.z, rng = blockIdx.z;                     // this workgroup walks range `rng` of the contraction
     const float* __restrict__ M = side ? w.ST : w.S;
     const cn_h* __restrict__ Xhi = side ? w.BThi : w.AThi;
@@ -399,23 +537,23 @@ __global__ __launch_bounds__(256) void cn_grad_kernel(Cn w, const float* __restr
     const float* __restrict__ Rs = side ? w.cs : w.rs;
     const float* __restrict__ Cl = side ? w.lse_r : w.lse_c;       // per output row c
     const float* __restrict__ Cs = side ? w.rs : w.cs;
-    __shared__ __attribute__((aligned(16))) cn_h Gh[2][32 * CN_GLD], Gl[2][32 * CN_GLD];
+    __shared__ __attribute__((aligned(16))) cn_h Gh[2][CB * CN_GLD], Gl[2][CB * CN_GLD];
     const float g = dloss[0] / (float)n;
     const int fr = lane & 15, fc = lane >> 4;
-    const int ec = tid & 31, er = tid >> 5;                         // element (r = er + 8 q, c = ec) of a 32 x 32 step tile
+    const int ec = tid % CB, er = tid / CB;                         // element (r = er + RP q, c = ec) of a 32 x CB step tile
     const int gc = c0 + ec;
     const float cl = gc < n ? Cl[gc] : 0.f, ccs = has_labels ? (gc < n ? Cs[gc] : 0.f) : 1.f, cnp = (inv_np && gc < n) ? inv_np[gc] : 1.f;
     const int dbase = wave * (D / 4);
-    f32x4 acc[2][NB];
+    f32x4 acc[NA][NB];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < NA; ++a)
 #pragma unroll
         for (int b = 0; b < NB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float mv[4];
+    float mv[NQ];
     cn_h8 xh[NB], xl[NB];
     auto load_step = [&](int r0) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) mv[q] = M[(size_t)(r0 + er + 8 * q) * np + gc];
+        for (int q = 0; q < NQ; ++q) mv[q] = M[(size_t)(r0 + er + RP * q) * np + gc];
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             const size_t o = (size_t)(dbase + b * 16 + fr) * np + r0 + fc * 8;
@@ -427,18 +565,18 @@ __global__ __launch_bounds__(256) void cn_grad_kernel(Cn w, const float* __restr
     load_step(st0 * 32);
     for (int st = st0; st < st1; ++st) {
         const int r0 = st * 32, buf = st & 1;
-        // dS of this thread's four elements, as a half pair, into the TRANSPOSED tile [c][r]
+        // dS of this thread's elements, as a half pair, into the TRANSPOSED tile [c][r]
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int r = er + 8 * q, gr = r0 + r;
+        for (int q = 0; q < NQ; ++q) {
+            const int r = er + RP * q, gr = r0 + r;
             float v = 0.f;
             if (gr < n && gc < n) {
-                const float s = mv[q];
+                const float s_ = mv[q];
                 float L;
                 if (has_labels) L = side ? labels[(size_t)gc * n + gr] : labels[(size_t)gr * n + gc];
                 else L = gr == gc ? 1.f : 0.f;
                 const float rnp = inv_np ? inv_np[gr] : 1.f, rrs = has_labels ? Rs[gr] : 1.f;
-                v = g * (cnp * (__expf(s - cl) * ccs - L) + rnp * (__expf(s - Rl[gr]) * rrs - L));
+                v = g * (cnp * (__expf(s_ - cl) * ccs - L) + rnp * (__expf(s_ - Rl[gr]) * rrs - L));
             }
             const cn_h h = (cn_h)v;
             Gh[buf][ec * CN_GLD + r] = h;
@@ -449,25 +587,22 @@ __global__ __launch_bounds__(256) void cn_grad_kernel(Cn w, const float* __restr
         for (int b = 0; b < NB; ++b) { bh[b] = xh[b]; bl[b] = xl[b]; }
         if (st + 1 < st1) load_step(r0 + 32);                         // next step's loads fly during this step's MFMAs
         __syncthreads();
-        cn_h8 ah[2], al[2];
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            ah[a] = *reinterpret_cast<const cn_h8*>(&Gh[buf][(a * 16 + fr) * CN_GLD + fc * 8]);
-            al[a] = *reinterpret_cast<const cn_h8*>(&Gl[buf][(a * 16 + fr) * CN_GLD + fc * 8]);
-        }
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < NA; ++a) {
+            const cn_h8 ah = *reinterpret_cast<const cn_h8*>(&Gh[buf][(a * 16 + fr) * CN_GLD + fc * 8]);
+            const cn_h8 al = *reinterpret_cast<const cn_h8*>(&Gl[buf][(a * 16 + fr) * CN_GLD + fc * 8]);
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
-                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[a], bh[b], acc[a][b], 0, 0, 0);
-                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[a], bl[b], acc[a][b], 0, 0, 0);
-                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[b], acc[a][b], 0, 0, 0);
+                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[b], acc[a][b], 0, 0, 0);
+                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[b], acc[a][b], 0, 0, 0);
             }
+        }
     }
     // this range's partial sums -> scratch [side][range][c][d] (cn_project_kernel adds them up and projects)
     float* __restrict__ part = w.part + ((size_t)(side * CN_RS + rng) * np) * D;
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < NA; ++a)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int c = c0 + a * 16 + fc * 4 + r;
@@ -529,7 +664,14 @@ extern "C" int xmc_contrastive_fwd(const float* A, const float* B, const float* 
     if (cn_ok(n, D)) {
         Cn c = cn_carve(ws, n, D);
         hipLaunchKernelGGL(cn_prepare_kernel, dim3(c.np / 8, 2), dim3(256), 0, st, A, B, c, n, D);
-        hipLaunchKernelGGL(cn_scores_kernel, dim3(c.np / 64, c.np / 64), dim3(256), 0, st, c, labels, inv_num_pos, n, D, loss);
+        static const bool no128 = xmc_debug_off("no_contrastive_128");
+        if (c.np % 128 == 0 && c.np >= 1024 && !no128) {
+            const size_t lds = (size_t)2 * 128 * CN_LD2 * 4;
+            XMC_ALLOW_BIG_LDS(cn_scores128_kernel);
+            hipLaunchKernelGGL(cn_scores128_kernel, dim3(c.np / 128, c.np / 128), dim3(512), lds, st, c, labels, inv_num_pos, n, D);
+        } else {
+            hipLaunchKernelGGL(cn_scores_kernel, dim3(c.np / 64, c.np / 64), dim3(256), 0, st, c, labels, inv_num_pos, n, D, loss);
+        }
         if (labels) hipLaunchKernelGGL(cn_transpose_kernel, dim3(c.np / 64, c.np / 64), dim3(256), 0, st, c.S, c.ST, c.np);
         hipLaunchKernelGGL(cn_finish_kernel, dim3(1), dim3(256), 0, st, c, inv_num_pos, labels ? 1 : 0, n, loss);
         XMC_LAUNCH_CHECK();
@@ -561,17 +703,24 @@ extern "C" int xmc_contrastive_bwd(const float* A, const float* B, const float* 
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (cn_ok(n, D)) {
         Cn c = cn_carve(ws, n, D);
-        int rs_ = c.np / 32 < CN_RS ? c.np / 32 : CN_RS;               // ranges: up to 8, at least one 32-row step each, ~1 k workgroups at most
-        while (rs_ > 1 && (c.np / 32) * 2 * rs_ > 1024) rs_ >>= 1;
-        const dim3 grid(c.np / 32, 2, rs_);
         const int hl = labels ? 1 : 0;
+        static const bool no_cb64 = xmc_debug_off("no_contrastive_cb64");
+        const int cb = (D <= 256 && c.np >= 1024 && !no_cb64) ? 64 : 32;   // 64 output rows per workgroup where the accumulators allow it
+        // ranges: up to 8, at least one 32-row step each, two workgroups per CU at most (n = 2048, measured forward + backward: D = 256,
+        // 32 output blocks per side: 2 / 4 / 8 ranges 137 / 99 / 92 us; D = 512, 64 blocks: 161 / 150 / 163 us -- the K walk of a workgroup
+        // is a chain of memory round trips, so ranges pay until the CUs hold two workgroups each)
+        int rs_ = c.np / 32 < CN_RS ? c.np / 32 : CN_RS;
+        while (rs_ > 1 && (c.np / cb) * 2 * rs_ > 512) rs_ >>= 1;
+        const dim3 grid(c.np / cb, 2, rs_);
+#define CN_GRAD(NB_, CB_) hipLaunchKernelGGL((cn_grad_kernel<NB_, CB_>), grid, dim3(256), 0, st, c, labels, inv_num_pos, hl, dloss_dev, n, D, dA, dB)
         switch (D / 64) {
-            case 1: hipLaunchKernelGGL((cn_grad_kernel<1>), grid, dim3(256), 0, st, c, labels, inv_num_pos, hl, dloss_dev, n, D, dA, dB); break;
-            case 2: hipLaunchKernelGGL((cn_grad_kernel<2>), grid, dim3(256), 0, st, c, labels, inv_num_pos, hl, dloss_dev, n, D, dA, dB); break;
-            case 4: hipLaunchKernelGGL((cn_grad_kernel<4>), grid, dim3(256), 0, st, c, labels, inv_num_pos, hl, dloss_dev, n, D, dA, dB); break;
-            case 8: hipLaunchKernelGGL((cn_grad_kernel<8>), grid, dim3(256), 0, st, c, labels, inv_num_pos, hl, dloss_dev, n, D, dA, dB); break;
+            case 1: if (cb == 64) CN_GRAD(1, 64); else CN_GRAD(1, 32); break;
+            case 2: if (cb == 64) CN_GRAD(2, 64); else CN_GRAD(2, 32); break;
+            case 4: if (cb == 64) CN_GRAD(4, 64); else CN_GRAD(4, 32); break;
+            case 8: CN_GRAD(8, 32); break;
             default: return XMC_ESHAPE;
         }
+#undef CN_GRAD
         hipLaunchKernelGGL(cn_project_kernel, dim3((n + 3) / 4, 2), dim3(256), 0, st, c, rs_, n, D, dA, dB);
         XMC_LAUNCH_CHECK();
         return 0;
