@@ -25,7 +25,7 @@ def timeit(name, fn, gflop, n=10):
 
 
 R = ops._conv_fwd_raw
-for (N, H, C) in [(512, 128, 64), (512, 64, 128), (512, 32, 256), (512, 16, 512)]:
+for (N, H, C) in [(512, 128, 64), (256, 128, 64), (512, 64, 128), (256, 64, 128), (512, 32, 256), (256, 32, 256), (512, 16, 512)]:
     x = torch.randn(N, H, H, C, device=dev).to(dt)
     w = torch.randn(C, C, 3, 3, device=dev) * 0.03
     geom = ops.ConvGeom(C, C, 3, 1, 1)

@@ -222,7 +222,11 @@ int launch_row(const XmcConvDesc& d, const RowCfg& t, float* dwp, float* dbias, 
     XMC_ALLOW_BIG_LDS((wgrad_row_kernel<KW, SA, WR_BCI>));
     const int64_t P = (int64_t)d.N * d.MH * d.MW;
     const int tiles = (d.CDw / WR_BCO) * (d.CS / WR_BCI) * KW;          // KW = KH for the square kernels handled here
-    int64_t nsplit = (256 + tiles - 1) / tiles;                         // one workgroup of 8 waves per CU (accumulators: > 128 VGPRs)
+    // one workgroup of 8 waves per CU (accumulators: > 128 VGPRs), so a grid of more than 256 workgroups runs in two rounds: with the 3 kernel
+    // rows in the grid the tile count is a multiple of 3 and rounding the split UP gave 264 / 288 workgroups (N512 8x8 512->512: 6 x 48),
+    // the last 8 / 32 of them alone on the chip for a second full round.  Round down instead (5 x 48 = 240, one round).
+    static const bool ceil_split = xmc_debug_off("wrow_ceil_split");
+    int64_t nsplit = ceil_split ? (256 + tiles - 1) / tiles : (256 / tiles > 0 ? 256 / tiles : 1);
     const int64_t max_split = P / (4 * WR_KP) > 0 ? P / (4 * WR_KP) : 1;
     if (nsplit > max_split) nsplit = max_split;
     int64_t ppb = (P + nsplit - 1) / nsplit;
