@@ -37,20 +37,11 @@ def rank():
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
 
-@torch.no_grad()
-def allreduce_mean_grads(params, bucket_elems=64 * 1024 * 1024):
-    """Average ``.grad`` over ranks in flat f32 buckets (<= 256 MB each: D's 81 MB and G's 49 MB of gradients at 256 px are ONE
-    collective each -- the 8 GPUs of a node are fully connected over xGMI, and a ring all-reduce of B bytes moves 2*(N-1)/N*B
-    per link pair whatever the bucket count, so fewer, larger collectives only save launch latency).  Parameters whose grad is
-    None are skipped; every rank runs the same graph so the skip pattern is identical.
-    The pack / unpack copies are multi-tensor kernels on the caller's stream (capturable); only the collective itself is an
-    eager seam of a captured iteration (graph.seam)."""
-    W = world()
-    if not active():
-        return
-    from . import graph
+def _pack_buckets(params, bucket_elems):
+    """``.grad`` of ``params`` copied into flat f32 buckets: [(flat, views of flat shaped like the grads, the grads)].  The copies are
+    multi-tensor kernels on the caller's stream (capturable)."""
     grads = [p.grad for p in params if p.grad is not None]
-    bucket, n = [], 0
+    out, bucket, n = [], [], 0
 
     def flush():
         nonlocal bucket, n
@@ -59,9 +50,7 @@ def allreduce_mean_grads(params, bucket_elems=64 * 1024 * 1024):
         flat = torch.empty(n, dtype=bucket[0].dtype, device=bucket[0].device)
         parts = [v.view_as(g) for v, g in zip(flat.split([g.numel() for g in bucket]), bucket)]
         torch._foreach_copy_(parts, bucket)                     # one multi-tensor copy in ...
-        graph.seam(lambda: dist.all_reduce(flat, op=dist.ReduceOp.SUM))
-        flat.mul_(1.0 / W)
-        torch._foreach_copy_(bucket, parts)                     # ... and one back
+        out.append((flat, parts, bucket))
         bucket, n = [], 0
 
     for g in grads:
@@ -70,6 +59,70 @@ def allreduce_mean_grads(params, bucket_elems=64 * 1024 * 1024):
         bucket.append(g)
         n += g.numel()
     flush()
+    return out
+
+
+def _unpack_buckets(packed, W):
+    for flat, parts, bucket in packed:
+        flat.mul_(1.0 / W)
+        torch._foreach_copy_(bucket, parts)                     # ... and one back
+
+
+@torch.no_grad()
+def allreduce_mean_grads(params, bucket_elems=64 * 1024 * 1024):
+    """Average ``.grad`` over ranks in flat f32 buckets (<= 256 MB each: D's 81 MB and G's 49 MB of gradients at 256 px are ONE
+    collective each -- the 8 GPUs of a node are fully connected over xGMI, and a ring all-reduce of B bytes moves 2*(N-1)/N*B
+    per link pair whatever the bucket count, so fewer, larger collectives only save launch latency).  Parameters whose grad is
+    None are skipped; every rank runs the same graph so the skip pattern is identical.
+    The pack / unpack copies are multi-tensor kernels on the caller's stream (capturable); only the collective itself is an
+    eager seam of a captured iteration (graph.seam)."""
+    if not active():
+        return
+    from . import graph
+    packed = _pack_buckets(params, bucket_elems)
+    for flat, _, _ in packed:
+        graph.seam(lambda flat=flat: dist.all_reduce(flat, op=dist.ReduceOp.SUM))
+    _unpack_buckets(packed, world())
+
+
+@torch.no_grad()
+def allreduce_mean_grads_begin(params, bucket_elems=64 * 1024 * 1024):
+    """First half of an all-reduce that runs BESIDE the rest of a backward pass: the gradients of ``params`` (those the backward has
+    finished with: the discriminator's last blocks and head, 93 % of its gradient bytes, done after about a quarter of its backward time)
+    are packed and their collective is started without waiting for it -- on RCCL it runs on the process group's own stream while the
+    caller's stream goes on with the remaining backward.  Returns the handle for ``allreduce_mean_grads_end``; None when the step issues
+    no collectives.  Under graph capture the start is one eager seam (graph.seam), like the collective of ``allreduce_mean_grads``."""
+    if not active():
+        return None
+    from . import graph
+    packed = _pack_buckets(params, bucket_elems)
+    works = [None] * len(packed)
+
+    def start():
+        for k, (flat, _, _) in enumerate(packed):
+            works[k] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+    graph.seam(start)
+    return packed, works
+
+
+@torch.no_grad()
+def allreduce_mean_grads_end(handle, params=(), bucket_elems=64 * 1024 * 1024):
+    """Second half: the gradients of ``params`` (what the rest of the backward produced) are all-reduced, the collectives started by
+    ``allreduce_mean_grads_begin`` are waited for (the caller's stream waits, not the host), and every gradient is scaled to the mean
+    and copied back.  One eager seam under capture."""
+    if handle is None:
+        return allreduce_mean_grads(params, bucket_elems)
+    from . import graph
+    packed, works = handle
+    rest = _pack_buckets(params, bucket_elems)
+
+    def finish():
+        for flat, _, _ in rest:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        for w in works:
+            w.wait()
+    graph.seam(finish)
+    _unpack_buckets(packed + rest, world())
 
 
 class _GatherRows(torch.autograd.Function):

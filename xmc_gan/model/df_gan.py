@@ -151,6 +151,7 @@ class NetD(nn.Module):
             nblk = len(self.downblocks)
             b0 = self.downblocks[0]
             first = 0
+            sink, cut = self.cut_sink, self.cut_block()
             # conv_img + the first block on the composed stem (ops.DStemBlockFn: the image straight to the block's first activation and
             # to its shortcut; conv_img's output never exists).  Under MA-GP (the backward of this forward is differentiated again)
             # the node keeps the branch values and its backward is ops.DStemBwdFn, on the same stem kernels
@@ -167,9 +168,30 @@ class NetD(nn.Module):
                 out = self.conv_img(xin)
             for i, block in enumerate(self.downblocks):
                 if i < first:
+                    if sink is not None and i == cut:         # the cut is the composed stem's output
+                        sink.extend(t for t in (out, pooled) if torch.is_tensor(t) and t.requires_grad)
                     continue
                 out, pooled = block(out, xp_hint=pooled, want_pool=i + 1 < nblk)
+                if sink is not None and i == cut:
+                    sink.extend(t for t in (out, pooled) if torch.is_tensor(t) and t.requires_grad)
         return as_nchw_view(out)
+
+    # Data parallel (xmc_gan/train_gan.py: the discriminator step): the trunk handed out where it enters the last three blocks, so that the
+    # backward can be run in two parts -- head and last blocks first (most of the parameter bytes, a fraction of the time), their
+    # gradient all-reduce started, then the rest beside it.  `cut_sink` is a list while a caller wants those tensors, else None.
+    cut_sink = None
+
+    def cut_block(self):
+        """index of the block whose output is the cut (None: too few blocks, or spectral norm -- the composed blocks are left alone)"""
+        k = len(self.downblocks) - 4
+        return k if k >= 0 and not self.conv_img.spec_norm else None
+
+    def late_parameters(self):
+        """(parameters after the cut, parameters before it), each in registration order"""
+        k = self.cut_block()
+        early = list(self.conv_img.parameters()) + [p for b in self.downblocks[:k + 1] for p in b.parameters()]
+        ids = {id(p) for p in early}
+        return [p for p in self.parameters() if id(p) not in ids], early
 
 
 class D_GET_LOGITS(nn.Module):

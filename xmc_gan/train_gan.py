@@ -176,6 +176,10 @@ def gan_iteration(netG, netD, optimizerG, optimizerD, imgs, sent_embs, words_emb
     # (193, 202) run as ONE pass over 2B images and the three COND_DNET calls (194, 203, 208) as one over 3B-1 rows: same
     # values, half the launches, twice the work per launch on the small maps at the end of D.  Not with spectral norm: there
     # every forward CALL advances the power iteration (modules.py:16-17), so the call pattern is part of the result.
+    # data parallel: the trunk is handed out where it enters D's last blocks, for the two-part backward below (parallel.py)
+    cuts = [] if (parallel.active() and isinstance(netD, DF_DISC) and netD.cut_block() is not None
+                  and not ops.debug_switch('no_dp_overlap')) else None
+    netD.cut_sink = cuts
     if imgs_h is not None and fake_h is not None and not cfg.DISC.SPEC_NORM and ops.fused_blocks() and not ops.debug_switch('no_d2b'):
         B = batch_size
         feats = netD(None, nhwc8=both_h if both_h is not None else torch.cat((imgs_h, fake_h.detach())))
@@ -205,6 +209,7 @@ def gan_iteration(netG, netD, optimizerG, optimizerD, imgs, sent_embs, words_emb
             errD_mismatch = ops.hinge(outputs_mis[0], 1.0)
             mis_loss = mis_loss + errD_mismatch
             out['errD_mismatch'] = errD_mismatch.detach()
+    netD.cut_sink = None
     labels = None
     if E.SENT or E.WORD or E.DISC or E.VGG:
         labels = make_labels(batch_size * (parallel.world() if opts.gather_negatives else 1),
@@ -224,8 +229,23 @@ def gan_iteration(netG, netD, optimizerG, optimizerD, imgs, sent_embs, words_emb
     # gradients normal), HipAdam reads the f32 parameter gradients times 1 / scale and SKIPS the step on the device when one
     # of them is inf / NaN (after the all-reduce, so every rank decides alike).  None in the other modes.
     sc_d = ops.loss_scaler("D", imgs.device)
-    (sc_d.scale(errD) if sc_d is not None else errD).backward()
-    parallel.allreduce_mean_grads(netD.parameters())
+    loss_d = sc_d.scale(errD) if sc_d is not None else errD
+    if cuts:
+        # Backward in two parts.  D's head and last three blocks hold 93 % of its gradient bytes (75 of 81 MB at 256 px) and their backward
+        # is the first quarter of the pass (small maps); the blocks before the cut hold 7 % and take the rest of the time (large maps).  The
+        # first part's all-reduce is started as soon as its gradients exist and runs beside the second part; same gradients as one
+        # `.backward()` (autograd executes the same nodes in the same order, in two calls).
+        late, early = netD.late_parameters()
+        late = [p_ for p_ in late if p_.requires_grad]
+        gs = torch.autograd.grad(loss_d, cuts + late, allow_unused=True)
+        for p_, g_ in zip(late, gs[len(cuts):]):
+            p_.grad = g_
+        pending = parallel.allreduce_mean_grads_begin(late)
+        torch.autograd.backward(cuts, list(gs[:len(cuts)]))
+        parallel.allreduce_mean_grads_end(pending, early)
+    else:
+        loss_d.backward()
+        parallel.allreduce_mean_grads(netD.parameters())
     _step(optimizerD, sc_d)
     out.update(errD=errD.detach(), errD_real=errD_real.detach(), errD_fake=errD_fake.detach())
 
