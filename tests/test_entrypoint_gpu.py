@@ -113,7 +113,7 @@ def test_entry_point_graph_replay_equals_eager_launches(tmp_path, case):
     """`train()` behind `main()` replays the iteration as hipGraphs by default (two eager warm-ups, one capture per N_CRITIC phase, then
     replays with the loader's batches copied into the static inputs).  Six iterations through `main()` with `--graph 1` and with
     `--graph 0` from the same seed, fp32 mode: same final weights (to the f32 atomics order of the weight-gradient kernels: 1e-5 per
-    tensor) and the same last losses -- for the headline loss set, with the gradient penalty, and with two critic steps per generator step
+    tensor, see below) and the same last losses -- for the headline loss set, with the gradient penalty, and with two critic steps per generator step
     (two captured phases)."""
     import xmc_gan.train_gan as tg
     subst = {"MAGP: true": "MAGP: true" if case == "MA-GP" else "MAGP: false"}
@@ -128,13 +128,22 @@ def test_entry_point_graph_replay_equals_eager_launches(tmp_path, case):
         res[graph] = (last, {"G." + k: v.detach().float().cpu().clone() for k, v in netG.state_dict().items()} |
                       {"D." + k: v.detach().float().cpu().clone() for k, v in netD.state_dict().items()})
     assert res[1][0].get("hipgraph") is True and "hipgraph" not in res[0][0]
-    worst = 0.0
+    # Adam with beta1 = 0 moves an element by +-lr whatever the size of its gradient: an element whose gradient is zero to within the
+    # summation-order noise can step the other way in one of the two runs (seen once in ~15 runs: ONE element of an 8 192-element tensor,
+    # 1.4e-4 of the tensor's norm on its own).  So: the tensor without its 1-in-10 000 most different elements (at least one) to 1e-5, and
+    # those elements within what six such steps can differ by (12 x the larger learning rate).
+    worst, flipped = 0.0, 0
     for k, a in res[1][1].items():
         b = res[0][1][k]
-        e = ((a - b).norm() / b.norm().clamp_min(1e-12)).item()
+        d = (a - b).abs().flatten().double()
+        top = d.topk(max(1, d.numel() // 10000)).values
+        e = ((d.square().sum() - top.square().sum()).clamp_min(0).sqrt() / b.norm().double().clamp_min(1e-12)).item()
         worst = max(worst, e)
         assert e <= 1e-5, (k, e)
+        assert top.max().item() <= 12 * 4e-4, (k, top.max().item())
+        flipped += int((top > 1e-4).sum())
     for k in ("errD", "errG", "errD_real", "errD_fake"):
         a, b = float(res[1][0][k]), float(res[0][0][k])
-        assert abs(a - b) <= 1e-5 * abs(b) + 1e-6, (k, a, b)
-    print(f"\n[entry point, {case}] graph replay vs eager launches after 6 iterations: worst parameter tensor {worst:.1e}")
+        assert abs(a - b) <= (2e-4 if flipped else 1e-5) * abs(b) + 1e-6, (k, a, b)      # (one element stepping the other way: 1e-4 of a layer)
+    print(f"\n[entry point, {case}] graph replay vs eager launches after 6 iterations: worst parameter tensor {worst:.1e}"
+          f" ({flipped} elements stepped the other way)")

@@ -1186,8 +1186,12 @@ def test_concept_stage_node_equals_composed_operators(mode, norm, with_sl):
             y = ops.affine_lrelu(x, gamma, beta)
         (y.float() * r.float()).sum().backward()
         res.append([y.detach().float(), x.grad.float(), q.grad, sent.grad, wk.grad] + ([gnw.grad, gnb.grad] if norm else []) + [p.grad for p in P])
+    # (the GroupNorm bias shifts every score of a concept by the same amount and the softmax over the pixels ignores it: its gradient is
+    # zero in exact arithmetic and 1e-8-sized summation-order noise in both forms -- it is held to the scale of its sibling, the GroupNorm
+    # weight's gradient, not to its own)
+    floor = 1e-3 * max(b.abs().max().item() for b in res[1][4:])
     for k, (a, b) in enumerate(zip(*res)):
-        sc = b.abs().max().item() + 1e-12
+        sc = max(b.abs().max().item(), floor if k >= 4 else 0.0) + 1e-12
         # bf16: the composed form rounds each of the three gradients of x to bf16 before adding them, the node adds in f32
         torch.testing.assert_close(a, b, rtol=3e-2 if mode == "bf16" else 2e-4, atol=(3e-2 if mode == "bf16" else 2e-4) * sc, msg=lambda m: f"tensor {k}: {m}")
 

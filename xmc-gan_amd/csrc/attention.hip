@@ -422,6 +422,16 @@ static inline int gn_apply_blocks(int N, int HW, int C8) {
 #define ST(s) reinterpret_cast<hipStream_t>(s)
 
 // GroupNorm forward: y = lrelu?((x - mean)/sqrt(var+eps) * w + b); stats f32 [N][G][2] (mean, rstd) is written for backward;
+// workgroups per image of the statistics pass: 64 pixels per thread lane on the large maps (fewer atomics: see below); on the small maps of
+// a 64-image batch that is ONE workgroup per image, 64 on a 256-CU chip, each walking its pixels in a serial loop (32x32x128: 7.6 us for
+// 17 MB) -- there 32 or 16 pixels per lane until the launch has a workgroup per CU
+static int gn_sums_blocks(int N, int HW, int groups) {
+    static const bool wide = xmc_debug_off("gn_sums_64");
+    int ppl = 64;
+    while (!wide && ppl > 16 && (long long)N * ((HW + groups * ppl - 1) / (groups * ppl)) < 256) ppl >>= 1;
+    const int bx = (HW + groups * ppl - 1) / (groups * ppl);
+    return bx < 1 ? 1 : bx;
+}
 // ws f32 [N][C][2] scratch (zeroed here).  slope < 0: no activation.
 extern "C" int xmc_groupnorm_fwd(const void* x, const float* w, const float* b, void* y, float* stats, float* ws,
                                  int N, int HW, int C, int G, float eps, float slope, int dtype, void* s) {
@@ -429,7 +439,7 @@ extern "C" int xmc_groupnorm_fwd(const void* x, const float* w, const float* b, 
     const int C8 = C / 8, cpg = C / G, groups = NT / C8;
     // 64 pixels per thread lane of the statistics pass: with 16, a 128x128x128 map had 4096 workgroups per launch ending in 1 M
     // atomics on 16 k addresses and read at 2.0 TB/s (sums) / 3.0 (backward sums); 64: whole forward 272 -> 202 us
-    int bx = (HW + groups * 64 - 1) / (groups * 64); if (bx < 1) bx = 1;
+    int bx = gn_sums_blocks(N, HW, groups);
     if (xmc_fixed_order()) bx = 1;                   // one workgroup per image: each (image, channel) sum is formed in one order
     int ppb = (HW + bx - 1) / bx;
     hipError_t e = xmc_zero_acc(ws, (size_t)N * C * 2 * 4, ST(s));
@@ -451,7 +461,7 @@ extern "C" int xmc_groupnorm_bwd(const void* x, const void* dy, const float* w, 
     const int C8 = C / 8, cpg = C / G, groups = NT / C8;
     // 64 pixels per thread lane of the statistics pass: with 16, a 128x128x128 map had 4096 workgroups per launch ending in 1 M
     // atomics on 16 k addresses and read at 2.0 TB/s (sums) / 3.0 (backward sums); 64: whole forward 272 -> 202 us
-    int bx = (HW + groups * 64 - 1) / (groups * 64); if (bx < 1) bx = 1;
+    int bx = gn_sums_blocks(N, HW, groups);
     if (xmc_fixed_order()) bx = 1;                   // one workgroup per image: each (image, channel) sum is formed in one order
     int ppb = (HW + bx - 1) / bx;
     hipError_t e = xmc_zero_acc(ws, (size_t)N * C * 2 * 4, ST(s));

@@ -384,21 +384,36 @@ __global__ __launch_bounds__(256) void concept_head_fwd_kernel(const float* __re
 }
 
 // dgamma, dbeta [B, CARD*PWD], hid -> dctx [B,CARD,PWD] (written), da [B, 2*HID] (written: d of the layer-1 pre-activations,
-// for concept_outer_kernel), small parameter gradients (atomics)
-__global__ __launch_bounds__(64) void concept_head_bwd_kernel(const float* __restrict__ ctx, const float* __restrict__ sent,
-                                                             const float* __restrict__ hid, HeadParams P,
-                                                             const float* __restrict__ dgamma, const float* __restrict__ dbeta,
-                                                             float* __restrict__ dctx, float* __restrict__ da_out,
-                                                             float* __restrict__ ds_out, HeadGrads G, int E) {
-    __shared__ HeadState S;
-    __shared__ __attribute__((aligned(16))) float s_sent[1024];
-    __shared__ float s_do[2][CARD][PWD], s_da[2][CARD][2 * SD], s_dr[CARD][SD], s_dm[CARD][SD], s_de[CARD][CARD], s_dv[CARD][SD];
-    const int b = blockIdx.x, tid = threadIdx.x;
+// for concept_outer_kernel), small parameter gradients (atomics).
+// One WAVE per sample, HB_SPW samples per workgroup.  The parameter gradients are sums over the batch of per-sample products.  Formed by
+// the sample's lanes as they went, each lane issued 56 float atomics (same addresses for every sample; as LDS atomics 16 lanes per bank):
+// 19 of the kernel's 32 us at B = 64, 24 launches per iteration.  Here the waves leave their factors in LDS (they are there anyway), and
+// after the last per-sample phase ALL threads of the workgroup form the HB_SPW-sample partial sum of 16 gradient elements each -- plain LDS
+// reads and FMAs -- and add it to memory once: no LDS atomics, 1 / HB_SPW of the global ones.
+constexpr int HB_SPW = 4;
+struct HeadBwdState {
+    float d_o[2][CARD][PWD], da[2][CARD][2 * SD], dr[CARD][SD], dm[CARD][SD], de[CARD][CARD], dv[CARD][SD];
+};
+__global__ __launch_bounds__(64 * HB_SPW) void concept_head_bwd_kernel(const float* __restrict__ ctx, const float* __restrict__ sent,
+                                                                      const float* __restrict__ hid, HeadParams P,
+                                                                      const float* __restrict__ dgamma, const float* __restrict__ dbeta,
+                                                                      float* __restrict__ dctx, float* __restrict__ da_out,
+                                                                      float* __restrict__ ds_out, HeadGrads G, int E, int B) {
+    __shared__ HeadState Sw[HB_SPW];
+    __shared__ HeadBwdState Tw[HB_SPW];
+    extern __shared__ __attribute__((aligned(16))) float s_sent_all[];        // [HB_SPW][E] (read only when P.Ws)
+    const int wave = threadIdx.x >> 6, tid = threadIdx.x & 63;               // tid: lane = (g, d) of this wave's sample
+    const int bs = blockIdx.x * HB_SPW + wave;
+    const bool on = bs < B;
+    const int b = on ? bs : B - 1;                                            // a spare wave walks the last sample and adds nothing
+    HeadState& S = Sw[wave];
+    HeadBwdState& T = Tw[wave];
+    float* s_sent = s_sent_all + (size_t)wave * E;
     const int g = tid >> 2, d = tid & 3;
     for (int i = tid; i < CARD * PWD; i += 64) {
         (&S.ctx[0][0])[i] = ctx[(size_t)b * CARD * PWD + i];
-        (&s_do[0][0][0])[i] = dgamma[(size_t)b * CARD * PWD + i];
-        (&s_do[1][0][0])[i] = dbeta[(size_t)b * CARD * PWD + i];
+        (&T.d_o[0][0][0])[i] = on ? dgamma[(size_t)b * CARD * PWD + i] : 0.f;
+        (&T.d_o[1][0][0])[i] = on ? dbeta[(size_t)b * CARD * PWD + i] : 0.f;
     }
     for (int i = tid; i < 2 * HID; i += 64) (&S.a[0][0][0])[i] = hid[(size_t)b * 2 * HID + i];
     if (P.Ws) for (int i = tid; i < E; i += 64) s_sent[i] = sent[(size_t)b * E + i];
@@ -414,21 +429,11 @@ __global__ __launch_bounds__(64) void concept_head_bwd_kernel(const float* __res
             const int i = d * 2 + h;
             float dh = 0.f;
 #pragma unroll
-            for (int o = 0; o < PWD; ++o) dh += P.W2[t][(g * PWD + o) * 2 * SD + i] * s_do[t][g][o];
+            for (int o = 0; o < PWD; ++o) dh += P.W2[t][(g * PWD + o) * 2 * SD + i] * T.d_o[t][g][o];
             const float ai = S.a[t][g][i];
             const float da = dh * (ai > 0.f ? 1.f : 0.2f);
-            s_da[t][g][i] = da;
-            da_out[(size_t)b * 2 * HID + t * HID + g * 2 * SD + i] = da;
-            // dW2[o][i] += do[o] * lrelu(a_i)  for all o;  db2 via i running over 0..7 = the PWD outputs as well
-            const float hi = lrelu02(ai);
-#pragma unroll
-            for (int o = 0; o < PWD; ++o) atomicAdd(&G.W2[t][(g * PWD + o) * 2 * SD + i], s_do[t][g][o] * hi);
-            atomicAdd(&G.b2[t][g * PWD + i], s_do[t][g][i]);
-            // layer 1's concept-state columns and bias
-            float* gw = G.W1[t] + (size_t)(g * 2 * SD + i) * ld;
-#pragma unroll
-            for (int dd = 0; dd < SD; ++dd) atomicAdd(&gw[E + dd], da * S.c[g][dd]);
-            atomicAdd(&G.b1[t][g * 2 * SD + i], da);
+            T.da[t][g][i] = da;
+            if (on) da_out[(size_t)b * 2 * HID + t * HID + g * 2 * SD + i] = da;
         }
     }
     __syncthreads();
@@ -437,7 +442,7 @@ __global__ __launch_bounds__(64) void concept_head_bwd_kernel(const float* __res
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int o = 0; o < 2 * SD; ++o) dr += P.W1[t][(size_t)(g * 2 * SD + o) * ld + E + d] * s_da[t][g][o];
+            for (int o = 0; o < 2 * SD; ++o) dr += P.W1[t][(size_t)(g * 2 * SD + o) * ld + E + d] * T.da[t][g][o];
         if (P.Ws) {                       // c[g][d] = att[g] r[g][d], att = softmax_g(l), l[g] = <s, r[g]>, s = Ws sent
             const float dc = dr;
             float da_g = dc * S.r[g][d];                          // d att[g] = <dc[g], r[g]>
@@ -450,54 +455,86 @@ __global__ __launch_bounds__(64) void concept_head_bwd_kernel(const float* __res
             float dsd = dl * S.r[g][d];                           // d s[d] = sum_g dl[g] r[g][d]: lanes with the same d
 #pragma unroll
             for (int o = 32; o >= 4; o >>= 1) dsd += __shfl_xor(dsd, o, 64);
-            if (g == 0) ds_out[(size_t)b * SD + d] = dsd;
+            if (g == 0 && on) ds_out[(size_t)b * SD + d] = dsd;
         }
-        s_dr[g][d] = dr;
+        T.dr[g][d] = dr;
         // ---- reasoner: r = relu(pre), pre = v + adj v, adj = tanh(v We^T)
-        s_dm[g][d] = S.pre[g][d] > 0.f ? dr : 0.f;          // d pre (= d m, and the direct part of d v)
+        T.dm[g][d] = S.pre[g][d] > 0.f ? dr : 0.f;          // d pre (= d m, and the direct part of d v)
     }
     __syncthreads();
     {
-        float dv = s_dm[g][d];    // direct
+        float dv = T.dm[g][d];    // direct
 #pragma unroll
-        for (int gg = 0; gg < CARD; ++gg) dv += S.adj[gg][g] * s_dm[gg][d];      // through m[gg] = sum_k adj[gg][k] v[k]
-        s_dv[g][d] = dv;
+        for (int gg = 0; gg < CARD; ++gg) dv += S.adj[gg][g] * T.dm[gg][d];      // through m[gg] = sum_k adj[gg][k] v[k]
+        T.dv[g][d] = dv;
     }
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {      // d adj[g][k] = sum_d dm[g][d] v[k][d];  de = dadj * (1 - adj^2)
         const int k = d * 4 + kk;
         float da = 0.f;
 #pragma unroll
-        for (int dd = 0; dd < SD; ++dd) da += s_dm[g][dd] * S.v[k][dd];
+        for (int dd = 0; dd < SD; ++dd) da += T.dm[g][dd] * S.v[k][dd];
         const float aj = S.adj[g][k];
-        s_de[g][k] = da * (1.f - aj * aj);
+        T.de[g][k] = da * (1.f - aj * aj);
     }
     __syncthreads();
     {
-        float dv = s_dv[g][d];
+        float dv = T.dv[g][d];
 #pragma unroll
-        for (int k = 0; k < CARD; ++k) dv += s_de[g][k] * P.We[k * SD + d];       // e[g][k] = sum_d v[g][d] We[k][d]
-        s_dv[g][d] = dv;
-        // dWe[k][d] += sum_g de[g][k] v[g][d]: lane (g, d) reused as (k = g, d)
-        float dwe = 0.f;
-#pragma unroll
-        for (int gg = 0; gg < CARD; ++gg) dwe += s_de[gg][g] * S.v[gg][d];
-        atomicAdd(&G.We[g * SD + d], dwe);
+        for (int k = 0; k < CARD; ++k) dv += T.de[g][k] * P.We[k * SD + d];       // e[g][k] = sum_d v[g][d] We[k][d]
+        T.dv[g][d] = dv;
     }
     __syncthreads();
     // ---- value projection: v[g][d] = sum_i Wv[g*SD+d][i] ctx[g][i]
-    {
-        const float dv = s_dv[g][d];
+    if (on) {
 #pragma unroll
-        for (int i = 0; i < PWD; ++i) atomicAdd(&G.Wv[(g * SD + d) * PWD + i], dv * S.ctx[g][i]);
+        for (int h = 0; h < 2; ++h) {
+            const int i = d * 2 + h;
+            float dc = 0.f;
+#pragma unroll
+            for (int dd = 0; dd < SD; ++dd) dc += P.Wv[(g * SD + dd) * PWD + i] * T.dv[g][dd];
+            dctx[(size_t)b * CARD * PWD + g * PWD + i] = dc;
+        }
     }
+    __syncthreads();
+    // ---- parameter gradients: this workgroup's samples summed per element, one atomic per element
+    constexpr int NTH = 64 * HB_SPW;
+    for (int e = threadIdx.x; e < 2 * CARD * PWD * 2 * SD; e += NTH) {        // dW2[t][g*PWD+o][i] = sum do[t][g][o] lrelu(a[t][g][i])
+        const int t = e >> 10, r = e & 1023, go = r >> 3, i = r & 7, gq = go >> 3, o = go & 7;
+        float x = 0.f;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int i = d * 2 + h;
-        float dc = 0.f;
+        for (int w = 0; w < HB_SPW; ++w) x += Tw[w].d_o[t][gq][o] * lrelu02(Sw[w].a[t][gq][i]);
+        atomicAdd(&G.W2[t][r], x);
+    }
+    for (int e = threadIdx.x; e < 2 * HID * SD; e += NTH) {                    // dW1[t][g*8+i][E+dd] = sum da[t][g][i] c[g][dd]
+        const int t = e >> 9, r = e & 511, row = r >> 2, dd = r & 3, gq = row >> 3, i = row & 7;
+        float x = 0.f;
 #pragma unroll
-        for (int dd = 0; dd < SD; ++dd) dc += P.Wv[(g * SD + dd) * PWD + i] * s_dv[g][dd];
-        dctx[(size_t)b * CARD * PWD + g * PWD + i] = dc;
+        for (int w = 0; w < HB_SPW; ++w) x += Tw[w].da[t][gq][i] * Sw[w].c[gq][dd];
+        atomicAdd(&G.W1[t][(size_t)row * ld + E + dd], x);
+    }
+    for (int e = threadIdx.x; e < 2 * 2 * HID; e += NTH) {                     // db2[t][g*PWD+o] = sum do,  db1[t][g*8+i] = sum da
+        const int which = e >> 8, t = (e >> 7) & 1, r = e & 127, gq = r >> 3, i = r & 7;
+        float x = 0.f;
+#pragma unroll
+        for (int w = 0; w < HB_SPW; ++w) x += which ? Tw[w].da[t][gq][i] : Tw[w].d_o[t][gq][i];
+        atomicAdd(which ? &G.b1[t][r] : &G.b2[t][r], x);
+    }
+    for (int e = threadIdx.x; e < CARD * SD * PWD; e += NTH) {                 // dWv[g*SD+d][i] = sum dv[g][d] ctx[g][i]
+        const int gd = e >> 3, i = e & 7, gq = gd >> 2, dq = gd & 3;
+        float x = 0.f;
+#pragma unroll
+        for (int w = 0; w < HB_SPW; ++w) x += Tw[w].dv[gq][dq] * Sw[w].ctx[gq][i];
+        atomicAdd(&G.Wv[e], x);
+    }
+    if (threadIdx.x < CARD * SD) {                                            // dWe[k][d] = sum_g de[g][k] v[g][d]
+        const int k = threadIdx.x >> 2, dq = threadIdx.x & 3;
+        float x = 0.f;
+#pragma unroll
+        for (int w = 0; w < HB_SPW; ++w)
+#pragma unroll
+            for (int gg = 0; gg < CARD; ++gg) x += Tw[w].de[gg][k] * Sw[w].v[gg][dq];
+        atomicAdd(&G.We[threadIdx.x], x);
     }
 }
 
@@ -643,7 +680,8 @@ static int head_bwd_go(const float* ctx, const float* sent, const float* hid, co
     G.W1[0] = grads[2]; G.b1[0] = grads[3]; G.W2[0] = grads[4]; G.b2[0] = grads[5];
     G.W1[1] = grads[6]; G.b1[1] = grads[7]; G.W2[1] = grads[8]; G.b2[1] = grads[9];
     float* ds = scratch + (size_t)B * 2 * HID;       // [B, SD]: d (Ws sent)
-    hipLaunchKernelGGL(concept_head_bwd_kernel, dim3(B), dim3(64), 0, ST(stream), ctx, sent, hid, P, dgamma, dbeta, dctx, scratch, ds, G, E);
+    hipLaunchKernelGGL(concept_head_bwd_kernel, dim3((B + HB_SPW - 1) / HB_SPW), dim3(64 * HB_SPW), sizeof(float) * HB_SPW * (size_t)E, ST(stream),
+                       ctx, sent, hid, P, dgamma, dbeta, dctx, scratch, ds, G, E, B);
     XMC_LAUNCH_CHECK();
     OuterArgs a;
     a.D = scratch; a.X = sent; a.W[0] = P.W1[0]; a.W[1] = P.W1[1]; a.dW[0] = G.W1[0]; a.dW[1] = G.W1[1]; a.dX = dsent;

@@ -1021,6 +1021,10 @@ extern "C" int xmc_nhwc8_to_nchw(const void* src, float* dst, int N, int C, int 
 // (N512 128x128x64: 637 -> 612 us, N256 256x256x32: 689 -> 606)
 static inline int affine_grid(int HW, int C8, int N, dim3& g, int& ppb, int ppl) {
     const int groups = NT / C8;
+    // small maps of a small batch (64 images of 32x32: one workgroup per image, 32 dependent load-compute-store rounds each -- 25 us for
+    // 50 MB): fewer pixels per lane until the launch has a workgroup per CU
+    static const bool wide = xmc_debug_off("affine_wide");
+    while (!wide && ppl > 4 && (long long)N * ((HW + groups * ppl - 1) / (groups * ppl)) < 256) ppl >>= 1;
     int per = groups * ppl;
     int bx = (HW + per - 1) / per;
     if (bx < 1) bx = 1;
