@@ -84,3 +84,21 @@ def test_bench_launches_two_ranks_itself_and_reports_the_job():
     assert 0.1 <= ratio <= 1.3, ratio
     gat = _bench(["--gpus", "2", "--gather_negatives"] + common, {"XMC_DIST_BACKEND": "gloo"})
     assert gat["config"]["parallelism"] == "dp2+gather" and gat["dist"]["collectives_per_iteration"]["g_step"] > 2, gat["dist"]
+
+
+def test_rccl_at_world_size_one_runs_the_two_part_backward_under_graph_replay():
+    """`bench.py --force_dp`: a one-rank `nccl` process group with the data-parallel path forced on -- the discriminator's backward in two
+    calls, its first all-reduce started asynchronously on RCCL's stream between two graph segments and waited for after the second call, the
+    generator's bucket, all as graph seams.  The only RCCL execution a one-GPU box allows: that the calls work under capture / replay, that
+    the losses stay finite, and that it costs a one-rank job next to nothing."""
+    common = ["--steps", "6", "--warmup", "2", "--workload", "config2", "--batch", "32", "--no_parity", "--no_alt_precision", "--no_entrypoint",
+              "--no_cpu_baseline", "--no_roofline"]
+    plain = _bench(common, {})
+    forced = _bench(["--force_dp"] + common, {})
+    d = forced["dist"]
+    assert d["backend"] == "nccl" and d["world_size"] == 1 and d["forced_at_world_1"] and d["collectives_per_iteration"] == {"g_step": 3}, d
+    assert forced["config"]["losses_finite"] and forced["config"]["hipgraph"]
+    ratio = forced["value"] / plain["value"]
+    print(f"\n[bench --force_dp, RCCL, world 1] {forced['value']:.0f} images/s against {plain['value']:.0f} without collectives (x{ratio:.2f}); "
+          f"{d['seam_host_ms']} ms of host time per collective call")
+    assert ratio >= 0.85, ratio

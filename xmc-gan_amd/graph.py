@@ -21,6 +21,22 @@ from . import ops
 _active = None          # the GraphedIteration whose capture is running (collectives consult it through seam())
 
 
+def _quiesce():
+    """Called outside capture, before a capture is opened or re-opened: nothing of a collective may be pending anywhere.  The `nccl` process
+    group's watchdog thread polls the end event of every collective it has not yet seen complete (every 100 ms); on this ROCm such a poll
+    WHILE this thread captures fails now and then with "operation not permitted on an event last recorded in a capturing stream" -- the
+    watchdog throws, the process aborts, or the capture is invalidated (RCCL at world size 1, 64 px, batch 32: about 1 run in 10, with the
+    collectives issued synchronously or not; `capture_error_mode="thread_local"` does not help, the failing call is the other thread's).  So
+    the device is drained and the watchdog is given two polling periods to retire what it holds: it has nothing to poll while the capture
+    runs.  Once per seam of a capture, never at replay."""
+    if not torch.cuda.is_available():
+        return
+    torch.cuda.synchronize()
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl":
+        time.sleep(0.25)
+
+
 def seam(fn):
     """Run the collective ``fn()`` now; under capture: between two graphs, and again at every replay."""
     if _active is None:
@@ -94,6 +110,8 @@ class GraphedIteration:
         acc = self.seam_host_s
 
         def eager():                 # replays run outside the autograd context the collective was first issued in
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("a collective was issued while its stream is capturing")
             t0 = time.perf_counter()
             with torch.no_grad():
                 out = fn()
@@ -102,6 +120,7 @@ class GraphedIteration:
             return out
         self._end()
         out = eager()
+        _quiesce()
         self._seq.append(eager)
         self._begin()
         return out
@@ -120,6 +139,7 @@ class GraphedIteration:
         with torch.cuda.stream(self.stream):
             _active = self
             try:
+                _quiesce()          # (the warm-up iterations' collectives)
                 self._begin()
                 out = self.step_fn(*self.static_in, state)
                 self._end()
