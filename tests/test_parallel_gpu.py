@@ -102,3 +102,37 @@ def test_rccl_at_world_size_one_runs_the_two_part_backward_under_graph_replay():
     print(f"\n[bench --force_dp, RCCL, world 1] {forced['value']:.0f} images/s against {plain['value']:.0f} without collectives (x{ratio:.2f}); "
           f"{d['seam_host_ms']} ms of host time per collective call")
     assert ratio >= 0.85, ratio
+
+
+def test_two_ranks_through_the_entry_point_keep_identical_weights(tmp_path):
+    """`python -m torch.distributed.run --nproc-per-node 2 ... xmc_gan/train_gan.py`-style: `main()` on two gloo ranks sharing the card
+    (tests/entry_dp_rehearsal.py): rank 0's initial weights broadcast, each rank its own synthetic batches (seed + rank), `train()` replaying graph
+    segments with the three gradient collectives of an iteration as seams.  After five iterations the two ranks hold the SAME weights bit for
+    bit (the all-reduced gradients are the same numbers on both, Adam is element-wise) -- and not the weights a single process reaches from
+    that seed (the other rank's batches took part), losses finite, the graph replay in use."""
+    import math
+    from test_entrypoint_gpu import _mini_yml
+    yml = _mini_yml(tmp_path)
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(XMC_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "tests", "entry_dp_rehearsal.py"), "--cfg", yml, "--out", str(tmp_path)]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=480)
+    assert r.returncode == 0, r.stdout[-3000:]
+    a, b = (torch.load(tmp_path / f"rank{k}.pt") for k in (0, 1))
+    assert a["hipgraph"] and b["hipgraph"]
+    for rep in (a, b):
+        assert {"errD", "errG"} <= set(rep["losses"]) and all(math.isfinite(v) for v in rep["losses"].values()), rep["losses"]
+    assert a["weights"].keys() == b["weights"].keys()
+    for k, va in a["weights"].items():
+        assert torch.equal(va, b["weights"][k]), k
+    assert a["losses"]["errD"] != b["losses"]["errD"]          # each rank saw its own batch
+    # a single process from the same seed ends elsewhere
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "entry_dp_rehearsal.py"), "--cfg", yml, "--out", str(tmp_path / "one")],
+                         env={**env, "RANK": "0"}, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=480)
+    assert one.returncode == 0, one.stdout[-3000:]
+    c = torch.load(tmp_path / "one" / "rank0.pt")
+    assert any(not torch.equal(va, c["weights"][k]) for k, va in a["weights"].items())

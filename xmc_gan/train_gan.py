@@ -637,10 +637,15 @@ def main(argv=None):
     local_rank = int(os.environ.get('LOCAL_RANK', str(args.gpu_id)))
     if not torch.cuda.is_available():
         raise RuntimeError('xmc_gan/train_gan.py needs an MI355X (HIP kernels only; the CPU restatement lives in oracle/)')
+    # one process per GPU over RCCL ('nccl'); XMC_DIST_BACKEND=gloo is the one-card rehearsal of the same code (ranks share card 0 when
+    # there are fewer cards than ranks; tests/test_parallel_gpu.py)
+    backend = os.environ.get('XMC_DIST_BACKEND', 'nccl')
+    if backend != 'nccl':
+        local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     if world > 1:
-        torch.distributed.init_process_group('nccl')
+        torch.distributed.init_process_group(backend)
     rank = parallel.rank()
 
     seed = args.seed + rank
