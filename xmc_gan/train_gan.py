@@ -241,7 +241,8 @@ def gan_iteration(netG, netD, optimizerG, optimizerD, imgs, sent_embs, words_emb
         for p_, g_ in zip(late, gs[len(cuts):]):
             p_.grad = g_
         pending = parallel.allreduce_mean_grads_begin(late)
-        torch.autograd.backward(cuts, list(gs[:len(cuts)]))
+        reached = [(c_, g_) for c_, g_ in zip(cuts, gs) if g_ is not None]          # (a handed-out tensor the loss does not use has no gradient)
+        torch.autograd.backward([c_ for c_, _ in reached], [g_ for _, g_ in reached])
         parallel.allreduce_mean_grads_end(pending, early)
     else:
         loss_d.backward()
