@@ -367,6 +367,17 @@ def test_image_grid_and_scalar_log(tmp_path):
     im = np.asarray(Image.open(tmp_path / "g.png"))
     assert im.shape == (g.shape[1], g.shape[2], 3) and im.dtype == np.uint8
     np.testing.assert_allclose(im.transpose(2, 0, 1) / 255.0, g, atol=1 / 255.0 + 1e-6)
+    # the training loop's form: the batch is copied when the call is made (the caller may overwrite its tensor straight away -- a graph's
+    # static output), the file is written by the writer thread and is there after flush_saves(); same bytes as the inline writer's
+    from xmc_gan.utils.visual import flush_saves, save_image_async
+    t = torch.from_numpy(x.copy())
+    save_image_async(t, tmp_path / "g_async.png")
+    t.zero_()
+    save_image_async(np.zeros((1, 5, 4, 4), dtype=np.float32), tmp_path / "bad.png")        # 5 channels: no such image -- reported at the flush
+    with pytest.raises(Exception):
+        flush_saves()
+    assert (tmp_path / "g_async.png").read_bytes() == (tmp_path / "g.png").read_bytes()
+    flush_saves()                                                                             # nothing pending, nothing to report
     assert to_uint8_hwc(np.zeros((3, 4, 4), np.float32)).tolist() == np.full((4, 4, 3), 127, np.uint8).tolist()   # truncation, as upstream
     log = ScalarLog(str(tmp_path), "tb")
     log.add_scalar("Loss_D", 1.5, 3)

@@ -36,7 +36,7 @@ from xmc_gan.model.concept_gan import InNetG as CONCEPT_INATTN_GEN, OutNetG as C
 from xmc_gan.model.encoder import RNN_ENCODER, SBERT_ENCODER
 from xmc_gan.utils.logger import setup_logger
 from xmc_gan.utils.miscc import count_params
-from xmc_gan.utils.visual import ScalarLog, fid_between, save_image, to_uint8_hwc
+from xmc_gan.utils.visual import ScalarLog, fid_between, flush_saves, save_image, save_image_async, to_uint8_hwc
 from xmc_gan_amd import ops, parallel
 from xmc_gan_amd.optim import HipAdam
 
@@ -518,9 +518,11 @@ def train(train_loader, test_loader, state_epoch, text_encoder, netG, netD, opti
                             f'Loss_D: {last["errD"].item():.3f} Loss_G: {last["errG"].item():.3f} '
                             f'errD_real: {last["errD_real"].item():.3f} errD_fake: {last["errD_fake"].item():.3f} ')
             if visual and (step + 1) % cfg.TRAIN.LOG_INTERVAL == 0:
-                save_image(last['fake'], f'{img_dir}/fake_samples_{step + 1:03d}.png', normalize=True, scale_each=True)
+                # (copied to the host now, encoded on the writer thread: utils/visual.py)
+                save_image_async(last['fake'], f'{img_dir}/fake_samples_{step + 1:03d}.png', normalize=True, scale_each=True)
             nsteps += 1
             if max_steps is not None and nsteps >= max_steps:
+                flush_saves()
                 return _detached(last)
         if t_mark[0] is not None and nsteps > t_mark[1]:
             torch.cuda.synchronize(device)               # ... to the end of the epoch (one synchronisation per epoch)
@@ -543,7 +545,7 @@ def train(train_loader, test_loader, state_epoch, text_encoder, netG, netD, opti
             with torch.no_grad():
                 netG.eval()
                 fake = netG(noise=fixed['noise'], sent_embs=fixed['sent'], words_embs=fixed['words'], mask=fixed['mask'])
-                save_image(fake, f'{img_dir}/fake_samples_epoch_{epoch:03d}.png', normalize=True, scale_each=True)
+                save_image_async(fake, f'{img_dir}/fake_samples_epoch_{epoch:03d}.png', normalize=True, scale_each=True)
         if epoch > 50 and parallel.rank() == 0:
             torch.save(netG.state_dict(), f'{model_dir}/netG_{epoch:03d}.pth')
             torch.save(netD.state_dict(), f'{model_dir}/netD_{epoch:03d}.pth')
@@ -555,6 +557,7 @@ def train(train_loader, test_loader, state_epoch, text_encoder, netG, netD, opti
             if test_loader is not None:
                 eval(loader=test_loader, state_epoch=epoch, text_encoder=text_encoder, netG=netG, logger=logger, num_samples=6000,
                      save_dir=f'{img_dir}/test' if img_dir else None, org_dir=f'{img_dir}/org' if img_dir else None, writer=writer)
+    flush_saves()                    # the sample grids queued for the writer thread are on disk when train() returns
     last = _detached(last)
     if thr is not None:
         last['throughput'] = thr

@@ -58,6 +58,59 @@ def save_image(images, path, nrow=8, padding=2, normalize=True, scale_each=True)
     Image.fromarray(arr).save(path)
 
 
+class _Saver:
+    """one background thread that turns queued sample batches into PNG grids (bounded queue: at most four batches wait on the host)"""
+
+    def __init__(self):
+        import queue
+        import threading
+        self.q, self.err = queue.Queue(maxsize=4), None
+        self.t = threading.Thread(target=self._run, name="xmc-gan-image-writer", daemon=True)
+        self.t.start()
+
+    def _run(self):
+        while True:
+            args, kw = self.q.get()
+            try:
+                save_image(*args, **kw)
+            except Exception as e:          # noqa: BLE001 -- reported by flush_saves() on the caller's thread
+                self.err = e
+            finally:
+                self.q.task_done()
+
+
+_saver = None
+
+
+def save_image_async(images, path, **kw):
+    """`save_image` off the training loop's thread.  Grid + PNG encoding of 256 samples at 256 px is ~1.9 s of host time (an 8 258 x 2 066
+    image through zlib), every LOG_INTERVAL steps: written inline it cost a 1 000-iteration run 15 % of its throughput (50.9 against 43 ms
+    per iteration).  The device-to-host copy is made HERE, before returning (under graph replay the tensor is a static output the next
+    iteration overwrites); normalisation, grid and encoding run on a writer thread (numpy and zlib release the interpreter lock).
+    `flush_saves()` waits for the files."""
+    global _saver
+    if hasattr(images, "detach"):
+        host = images.detach().float().cpu()
+        if host.data_ptr() == images.data_ptr():        # already an f32 host tensor: .cpu() handed back the caller's memory
+            host = host.clone()
+        images = host.numpy()
+    else:
+        images = np.array(images, dtype=np.float32, copy=True)
+    if _saver is None:
+        _saver = _Saver()
+    _saver.q.put(((images, path), kw))
+
+
+def flush_saves():
+    """block until every queued image file is on disk; re-raises what the writer thread caught"""
+    if _saver is None:
+        return
+    _saver.q.join()
+    if _saver.err is not None:
+        e, _saver.err = _saver.err, None
+        raise e
+
+
 def to_uint8_hwc(img):
     """one generated / real image in [-1, 1], [3,H,W] -> uint8 [H,W,3] the way eval() writes them ((x + 1) * 127.5, truncated;
     train_gan.py:366-379)"""
