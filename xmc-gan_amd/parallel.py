@@ -38,34 +38,45 @@ def rank():
 
 
 def _pack_buckets(params, bucket_elems):
-    """``.grad`` of ``params`` copied into flat f32 buckets: [(flat, views of flat shaped like the grads, the grads)].  The copies are
-    multi-tensor kernels on the caller's stream (capturable)."""
-    grads = [p.grad for p in params if p.grad is not None]
+    """``.grad`` of ``params`` gathered into flat f32 buckets: [(flat, views of flat shaped like the grads, the parameters)].  One
+    concatenation kernel per 128 tensors on the caller's stream (capturable).  (As `torch._foreach_copy_` the same 130 MB took 14
+    multi-tensor launches and 0.46 ms per iteration, in and out: 0.3 TB/s on lists that mix 4 M-element weights with 64-element biases.)"""
+    owners = [p for p in params if p.grad is not None]
     out, bucket, n = [], [], 0
 
     def flush():
         nonlocal bucket, n
         if not bucket:
             return
-        flat = torch.empty(n, dtype=bucket[0].dtype, device=bucket[0].device)
-        parts = [v.view_as(g) for v, g in zip(flat.split([g.numel() for g in bucket]), bucket)]
-        torch._foreach_copy_(parts, bucket)                     # one multi-tensor copy in ...
+        g0 = bucket[0].grad
+        flat = torch.empty(n, dtype=g0.dtype, device=g0.device)
+        torch.cat([p.grad.reshape(-1) for p in bucket], out=flat)
+        parts = [v.view_as(p.grad) for v, p in zip(flat.split([p.grad.numel() for p in bucket]), bucket)]
         out.append((flat, parts, bucket))
         bucket, n = [], 0
 
-    for g in grads:
-        if n + g.numel() > bucket_elems:
+    for p in owners:
+        if n + p.grad.numel() > bucket_elems:
             flush()
-        bucket.append(g)
-        n += g.numel()
+        bucket.append(p)
+        n += p.grad.numel()
     flush()
     return out
 
 
-def _unpack_buckets(packed, W):
+def _mean_op():
+    """(reduce op, whether the sum still has to be divided): RCCL averages inside the collective, gloo has no such op"""
+    return (dist.ReduceOp.AVG, False) if dist.get_backend() == "nccl" else (dist.ReduceOp.SUM, True)
+
+
+def _adopt_buckets(packed, W, divide):
+    """The reduced buckets BECOME the gradients: every ``p.grad`` is re-pointed at its slice of the flat buffer (nothing is copied back;
+    the optimizer reads the slices)."""
     for flat, parts, bucket in packed:
-        flat.mul_(1.0 / W)
-        torch._foreach_copy_(bucket, parts)                     # ... and one back
+        if divide:
+            flat.mul_(1.0 / W)
+        for p, v in zip(bucket, parts):
+            p.grad = v
 
 
 @torch.no_grad()
@@ -74,15 +85,16 @@ def allreduce_mean_grads(params, bucket_elems=64 * 1024 * 1024):
     collective each -- the 8 GPUs of a node are fully connected over xGMI, and a ring all-reduce of B bytes moves 2*(N-1)/N*B
     per link pair whatever the bucket count, so fewer, larger collectives only save launch latency).  Parameters whose grad is
     None are skipped; every rank runs the same graph so the skip pattern is identical.
-    The pack / unpack copies are multi-tensor kernels on the caller's stream (capturable); only the collective itself is an
-    eager seam of a captured iteration (graph.seam)."""
+    The gather into the bucket is a kernel on the caller's stream (capturable) and the reduced bucket becomes the gradients (each ``.grad``
+    is re-pointed at its slice); only the collective itself is an eager seam of a captured iteration (graph.seam)."""
     if not active():
         return
     from . import graph
     packed = _pack_buckets(params, bucket_elems)
+    op, divide = _mean_op()
     for flat, _, _ in packed:
-        graph.seam(lambda flat=flat: dist.all_reduce(flat, op=dist.ReduceOp.SUM))
-    _unpack_buckets(packed, world())
+        graph.seam(lambda flat=flat: dist.all_reduce(flat, op=op))
+    _adopt_buckets(packed, world(), divide)
 
 
 @torch.no_grad()
@@ -97,10 +109,11 @@ def allreduce_mean_grads_begin(params, bucket_elems=64 * 1024 * 1024):
     from . import graph
     packed = _pack_buckets(params, bucket_elems)
     works = [None] * len(packed)
+    op, _ = _mean_op()
 
     def start():
         for k, (flat, _, _) in enumerate(packed):
-            works[k] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+            works[k] = dist.all_reduce(flat, op=op, async_op=True)
     graph.seam(start)
     return packed, works
 
@@ -109,20 +122,21 @@ def allreduce_mean_grads_begin(params, bucket_elems=64 * 1024 * 1024):
 def allreduce_mean_grads_end(handle, params=(), bucket_elems=64 * 1024 * 1024):
     """Second half: the gradients of ``params`` (what the rest of the backward produced) are all-reduced, the collectives started by
     ``allreduce_mean_grads_begin`` are waited for (the caller's stream waits, not the host), and every gradient is scaled to the mean
-    and copied back.  One eager seam under capture."""
+    (inside the collective on RCCL) and ``.grad`` of every parameter is re-pointed at its slice of the reduced buckets.  One eager seam under capture."""
     if handle is None:
         return allreduce_mean_grads(params, bucket_elems)
     from . import graph
     packed, works = handle
     rest = _pack_buckets(params, bucket_elems)
+    op, divide = _mean_op()
 
     def finish():
         for flat, _, _ in rest:
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            dist.all_reduce(flat, op=op)
         for w in works:
             w.wait()
     graph.seam(finish)
-    _unpack_buckets(packed + rest, world())
+    _adopt_buckets(packed + rest, world(), divide)
 
 
 class _GatherRows(torch.autograd.Function):
