@@ -159,3 +159,18 @@ class _GatherRows(torch.autograd.Function):
 def gather_rows(x):
     """[n, ...] -> [world*n, ...] (rank-major), differentiable; identity when not distributed."""
     return _GatherRows.apply(x) if active() else x
+
+
+def gather_rows_multi(tensors):
+    """``gather_rows`` of several [n, ...] tensors in ONE collective (they are concatenated along their flattened feature axis, gathered,
+    and split again): every collective is a seam of the captured iteration, and the contrastive terms of a step all-gather their image
+    embeddings, text embeddings and pooled features at the same point.  Differentiable; the tensors themselves when not distributed."""
+    tensors = list(tensors)
+    if not active() or len(tensors) < 2:
+        return [gather_rows(t) for t in tensors]
+    n = tensors[0].shape[0]
+    flat = [t.reshape(n, -1).float() for t in tensors]
+    g = _GatherRows.apply(torch.cat(flat, 1))
+    outs = g.split([f.shape[1] for f in flat], 1)
+    return [o.contiguous().to(t.dtype).reshape((g.shape[0],) + tuple(t.shape[1:])) for o, t in zip(outs, tensors)]
+

@@ -154,6 +154,7 @@ def gan_iteration(netG, netD, optimizerG, optimizerD, imgs, sent_embs, words_emb
     batch_size = mask.size(0)
     ops.new_iteration(imgs.device)                 # one memset for all weight-gradient scratch of this iteration
     gather = parallel.gather_rows if opts.gather_negatives else (lambda t: t)
+    gather_all = parallel.gather_rows_multi if opts.gather_negatives else (lambda ts: list(ts))     # several tensors, one collective
     out = {}
 
     # ---- discriminator step (train_gan.py:187-229)
@@ -217,7 +218,8 @@ def gan_iteration(netG, netD, optimizerG, optimizerD, imgs, sent_embs, words_emb
     enc_loss = 0.
     if E.SENT:
         assert cfg.DISC.SENT_MATCH or cfg.DISC.IMG_MATCH
-        ds_loss = sent_loss(imgs=gather(outputs_real[1]), txts=gather(outputs_real[2]), labels=labels, b_global=E.B_GLOBAL)
+        g_img, g_txt = gather_all((outputs_real[1], outputs_real[2]))
+        ds_loss = sent_loss(imgs=g_img, txts=g_txt, labels=labels, b_global=E.B_GLOBAL)
         enc_loss = enc_loss + T.SMOOTH.SENT * ds_loss
         out['ds_loss'] = ds_loss.detach()
     if E.WORD:
@@ -290,19 +292,22 @@ def gan_iteration(netG, netD, optimizerG, optimizerD, imgs, sent_embs, words_emb
             outputs = netD.COND_DNET(features, sent_embs=psent_embs)
             errG_fake = -outputs[0].float().mean()
             enc_loss = 0.0
-            if E.SENT:
-                gs_loss = sent_loss(imgs=gather(outputs[1]), txts=gather(outputs[2]), labels=labels, b_global=E.B_GLOBAL)
-                enc_loss = enc_loss + T.SMOOTH.SENT * gs_loss
-                out['gs_loss'] = gs_loss.detach()
-            if E.WORD:
-                raise NotImplementedError
+            real_pooled = fake_pooled = None
             if E.DISC:
                 with torch.no_grad():
                     real_again = netD(imgs, nhwc8=imgs_h) if imgs_h is not None else netD(imgs)
                     real_pooled = ops.global_avgpool(real_again.permute(0, 2, 3, 1).contiguous())
                 fake_pooled = ops.global_avgpool(features.permute(0, 2, 3, 1).contiguous())
-                disc_loss = img_loss(real_imgs=gather(real_pooled), fake_imgs=gather(fake_pooled), labels=labels,
-                                     b_global=E.B_GLOBAL)
+            # what the contrastive terms of this step compare across ranks, all-gathered in ONE collective (a seam of the captured iteration each)
+            rows = gather_all(([outputs[1], outputs[2]] if E.SENT else []) + ([real_pooled, fake_pooled] if E.DISC else []))
+            if E.SENT:
+                gs_loss = sent_loss(imgs=rows[0], txts=rows[1], labels=labels, b_global=E.B_GLOBAL)
+                enc_loss = enc_loss + T.SMOOTH.SENT * gs_loss
+                out['gs_loss'] = gs_loss.detach()
+            if E.WORD:
+                raise NotImplementedError
+            if E.DISC:
+                disc_loss = img_loss(real_imgs=rows[-2], fake_imgs=rows[-1], labels=labels, b_global=E.B_GLOBAL)
                 enc_loss = enc_loss + T.SMOOTH.DISC * disc_loss
                 out['disc_loss'] = disc_loss.detach()
             if E.VGG:
