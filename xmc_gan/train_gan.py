@@ -212,16 +212,18 @@ def gan_iteration(netG, netD, optimizerG, optimizerD, imgs, sent_embs, words_emb
             out['errD_mismatch'] = errD_mismatch.detach()
     netD.cut_sink = None
     labels = None
-    if E.SENT or E.WORD or E.DISC or E.VGG:
-        labels = make_labels(batch_size * (parallel.world() if opts.gather_negatives else 1),
-                             sent_embs=gather(sent_embs.float()), b_global=E.B_GLOBAL)
+    n_rows = batch_size * (parallel.world() if opts.gather_negatives else 1)
     enc_loss = 0.
     if E.SENT:
         assert cfg.DISC.SENT_MATCH or cfg.DISC.IMG_MATCH
-        g_img, g_txt = gather_all((outputs_real[1], outputs_real[2]))
+        # (the sentence embeddings the labels are made from travel with the two embeddings the loss compares: one collective)
+        g_sent, g_img, g_txt = gather_all((sent_embs.float(), outputs_real[1], outputs_real[2]))
+        labels = make_labels(n_rows, sent_embs=g_sent, b_global=E.B_GLOBAL)
         ds_loss = sent_loss(imgs=g_img, txts=g_txt, labels=labels, b_global=E.B_GLOBAL)
         enc_loss = enc_loss + T.SMOOTH.SENT * ds_loss
         out['ds_loss'] = ds_loss.detach()
+    elif E.WORD or E.DISC or E.VGG:
+        labels = make_labels(n_rows, sent_embs=gather(sent_embs.float()), b_global=E.B_GLOBAL)
     if E.WORD:
         raise NotImplementedError
     errD = errD_real + (mis_loss * T.SMOOTH.MISMATCH) + enc_loss
