@@ -75,7 +75,7 @@ def parse():
     ap.add_argument("--no_parity", action="store_true")
     ap.add_argument("--no_alt_precision", action="store_true")
     ap.add_argument("--gather_negatives", action="store_true", help="BASELINE config 5: all-gather contrastive negatives")
-    ap.add_argument("--graph", type=int, default=-1, help="replay the iteration as a hipGraph (default: on for 1 GPU)")
+    ap.add_argument("--graph", type=int, default=-1, help="replay the iteration as hipGraphs (default: on, for any number of ranks; 0 = eager launches)")
     ap.add_argument("--gen", type=str, default="", help="variant: override GEN.ENCODER_NAME (e.g. CONCEPT_OUTATTN_GEN)")
     ap.add_argument("--spec_norm", action="store_true", help="variant: DISC.SPEC_NORM=True (off in the headline cfg)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
